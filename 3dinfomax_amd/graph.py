@@ -1,0 +1,194 @@
+"""Batched molecular graph container.
+
+Replaces the slice of DGL the hot path uses (`dgl.graph`, `dgl.batch`, `ndata`/`edata`,
+`batch_num_nodes`, `number_of_nodes`, `edges`, `.to`) - see reference
+datasets/custom_collate.py:105-114 (contrastive_collate -> dgl.batch) and
+trainer/self_supervised_trainer.py:24-29 (what the trainer touches).
+
+On top of the DGL-like surface it carries the index the HIP kernels are driven by
+(`GraphIndex`): a CSR **by destination**.  All edge-sized tensors inside the models live
+in *destination-sorted* order ("epos" order, stable w.r.t. edge id, so the per-node
+message order equals DGL's mailbox order), which makes every neighbourhood a contiguous
+row range `[in_ptr[v], in_ptr[v+1])` - the layout the one-pass segmented aggregation
+kernel wants - and needs no atomics anywhere (out-edge sums go through `out_ptr/out_epos`).
+"""
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+
+@dataclass
+class GraphIndex:
+    """int32 index arrays, all on one device.  E edges, N nodes, B graphs."""
+    num_nodes: int
+    num_edges: int
+    num_graphs: int
+    in_ptr: torch.Tensor      # [N+1] CSR row pointer by destination
+    perm: torch.Tensor        # [E]   epos -> edge id (stable sort of dst)
+    src_s: torch.Tensor       # [E]   source node of edge at epos
+    dst_s: torch.Tensor       # [E]   destination node of edge at epos (non-decreasing)
+    out_ptr: torch.Tensor     # [N+1] CSR row pointer by source
+    out_epos: torch.Tensor    # [E]   epos of the out-edges of each node, grouped by source
+    graph_ptr: torch.Tensor   # [B+1] node offsets of the graphs in the batch
+    max_in_degree: int
+
+    def to(self, device):
+        return GraphIndex(self.num_nodes, self.num_edges, self.num_graphs,
+                          *[t.to(device, non_blocking=True) for t in
+                            (self.in_ptr, self.perm, self.src_s, self.dst_s, self.out_ptr,
+                             self.out_epos, self.graph_ptr)], self.max_in_degree)
+
+
+def build_index(src, dst, num_nodes, batch_num_nodes) -> GraphIndex:
+    """Host-side (numpy) construction of the kernel index from an edge list."""
+    src = np.asarray(src, dtype=np.int64)
+    dst = np.asarray(dst, dtype=np.int64)
+    bnn = np.asarray(batch_num_nodes, dtype=np.int64)
+    E = src.shape[0]
+    perm = np.argsort(dst, kind='stable')
+    src_s, dst_s = src[perm], dst[perm]
+    indeg = np.bincount(dst, minlength=num_nodes)
+    in_ptr = np.zeros(num_nodes + 1, dtype=np.int64)
+    np.cumsum(indeg, out=in_ptr[1:])
+    out_epos = np.argsort(src_s, kind='stable')
+    out_ptr = np.zeros(num_nodes + 1, dtype=np.int64)
+    np.cumsum(np.bincount(src, minlength=num_nodes), out=out_ptr[1:])
+    graph_ptr = np.zeros(bnn.shape[0] + 1, dtype=np.int64)
+    np.cumsum(bnn, out=graph_ptr[1:])
+    i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.int32)))
+    return GraphIndex(int(num_nodes), int(E), int(bnn.shape[0]), i32(in_ptr), i32(perm), i32(src_s),
+                      i32(dst_s), i32(out_ptr), i32(out_epos), i32(graph_ptr),
+                      int(indeg.max()) if E else 0)
+
+
+class BatchedMolGraph:
+    """A (batch of) graph(s) with DGL's node/edge-frame surface."""
+
+    def __init__(self, src, dst, num_nodes: int, batch_num_nodes=None,
+                 ndata: Optional[Dict[str, torch.Tensor]] = None,
+                 edata: Optional[Dict[str, torch.Tensor]] = None,
+                 index: Optional[GraphIndex] = None):
+        self._src = torch.as_tensor(src, dtype=torch.long)
+        self._dst = torch.as_tensor(dst, dtype=torch.long)
+        self._n = int(num_nodes)
+        if batch_num_nodes is None:
+            batch_num_nodes = torch.tensor([self._n], dtype=torch.long)
+        self._bnn = torch.as_tensor(batch_num_nodes, dtype=torch.long)
+        self.ndata: Dict[str, torch.Tensor] = dict(ndata or {})
+        self.edata: Dict[str, torch.Tensor] = dict(edata or {})
+        self._index = index
+
+    # ---- DGL-like surface --------------------------------------------------------------
+    def number_of_nodes(self):
+        return self._n
+
+    num_nodes = number_of_nodes
+
+    def number_of_edges(self):
+        return int(self._src.shape[0])
+
+    num_edges = number_of_edges
+
+    def edges(self):
+        return self._src, self._dst
+
+    def batch_num_nodes(self):
+        return self._bnn
+
+    @property
+    def batch_size(self):
+        return int(self._bnn.shape[0])
+
+    @property
+    def device(self):
+        return self._src.device
+
+    def to(self, device):
+        device = torch.device(device)
+        g = BatchedMolGraph(self._src.to(device), self._dst.to(device), self._n, self._bnn.to(device),
+                            {k: v.to(device) for k, v in self.ndata.items()},
+                            {k: v.to(device) for k, v in self.edata.items()},
+                            self.index().to(device))
+        return g
+
+    # ---- kernel index -----------------------------------------------------------------
+    def index(self) -> GraphIndex:
+        if self._index is None:
+            idx = build_index(self._src.cpu().numpy(), self._dst.cpu().numpy(), self._n,
+                              self._bnn.cpu().numpy())
+            self._index = idx.to(self._src.device)
+        return self._index
+
+
+def batch(graphs: List[BatchedMolGraph]) -> BatchedMolGraph:
+    """Block-diagonal batching (DGL `dgl.batch` semantics): nodes and
+    edges concatenated in list order, node ids offset, frames concatenated,
+    batch_num_nodes flattened."""
+    srcs, dsts, bnn = [], [], []
+    off = 0
+    for g in graphs:
+        srcs.append(g._src + off)
+        dsts.append(g._dst + off)
+        bnn.append(g._bnn)
+        off += g._n
+    out = BatchedMolGraph(torch.cat(srcs), torch.cat(dsts), off, torch.cat(bnn))
+    for k in graphs[0].ndata:
+        out.ndata[k] = torch.cat([g.ndata[k] for g in graphs], 0)
+    for k in graphs[0].edata:
+        out.edata[k] = torch.cat([g.edata[k] for g in graphs], 0)
+    return out
+
+
+def bond_graph(mol) -> BatchedMolGraph:
+    """2D bond graph of one `synth.Molecule` (reference datasets/qm9_dataset.py:221-231)."""
+    return BatchedMolGraph(torch.from_numpy(mol.src), torch.from_numpy(mol.dst), mol.n_atoms,
+                           ndata={'feat': torch.from_numpy(mol.atom_feat)},
+                           edata={'feat': torch.from_numpy(mol.bond_feat)})
+
+
+def complete_graph(mol, coords=None) -> BatchedMolGraph:
+    """Complete 3D distance graph of one molecule (reference datasets/qm9_dataset.py:233-244)."""
+    from .synth import complete_graph_edges, pairwise_distances
+    coords = mol.coords if coords is None else coords
+    src, dst = complete_graph_edges(mol.n_atoms)
+    d = pairwise_distances(coords, src, dst)
+    return BatchedMolGraph(torch.from_numpy(src), torch.from_numpy(dst), mol.n_atoms,
+                           ndata={'feat': torch.from_numpy(mol.atom_feat)},
+                           edata={'d': torch.from_numpy(d)})
+
+
+def contrastive_collate(batch_items):
+    """Mirror of reference datasets/custom_collate.py:105-114 on BatchedMolGraph items."""
+    graphs, graphs3d, *targets = map(list, zip(*batch_items))
+    if targets:
+        return [batch(graphs)], [batch(graphs3d)], torch.stack(*targets).float()
+    return [batch(graphs)], [batch(graphs3d)]
+
+
+def conformer_collate(batch_items):
+    """Mirror of reference datasets/custom_collate.py:155-157."""
+    graphs, confs = map(list, zip(*batch_items))
+    return [batch(graphs)], [batch(confs)]
+
+
+def as_batched_graph(g) -> BatchedMolGraph:
+    """Accept a BatchedMolGraph, or any DGL-like object exposing edges(), number_of_nodes(),
+    batch_num_nodes(), ndata, edata (real `dgl.DGLGraph` included).  The frames are shared,
+    so the forward pass's side effects (reference models/pna.py:162-163,213) land on the
+    caller's object."""
+    if isinstance(g, BatchedMolGraph):
+        return g
+    cached = getattr(g, '_amd_batched', None)
+    if cached is not None:
+        return cached
+    src, dst = g.edges()
+    bg = BatchedMolGraph(src, dst, g.number_of_nodes(), g.batch_num_nodes())
+    bg.ndata = g.ndata
+    bg.edata = g.edata
+    try:
+        g._amd_batched = bg
+    except Exception:
+        pass
+    return bg

@@ -1,0 +1,69 @@
+"""Shared test helpers: fixture loading, molecule reconstruction, tolerances."""
+import importlib
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+amd = importlib.import_module('3dinfomax_amd')
+synth = importlib.import_module('3dinfomax_amd.synth')
+
+PNA_YML = dict(target_dim=256, hidden_dim=200, mid_batch_norm=True, last_batch_norm=True, readout_batchnorm=True,
+               batch_norm_momentum=0.93, readout_hidden_dim=200, readout_layers=2, dropout=0.0, propagation_depth=7,
+               aggregators=['mean', 'max', 'min', 'std'], scalers=['identity', 'amplification', 'attenuation'],
+               readout_aggregators=['min', 'max', 'mean'], pretrans_layers=2, posttrans_layers=1, residual=True)
+NET3D_YML = dict(target_dim=256, hidden_dim=20, hidden_edge_dim=20, node_wise_output_layers=0, message_net_layers=1,
+                 update_net_layers=1, reduce_func='mean', fourier_encodings=4, propagation_depth=1, dropout=0.0,
+                 batch_norm=True, readout_batchnorm=True, batch_norm_momentum=0.93, readout_hidden_dim=20,
+                 readout_layers=1, readout_aggregators=['min', 'max', 'mean'])
+PNA_SMALL = dict(PNA_YML, hidden_dim=16, target_dim=8, propagation_depth=2, readout_hidden_dim=16)
+NET3D_SMALL = dict(NET3D_YML, target_dim=8)
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def mols_from_npz(z, prefix='mol'):
+    n_atoms, n_edges = z[f'{prefix}_n_atoms'], z[f'{prefix}_n_edges']
+    mols, a0, e0 = [], 0, 0
+    for n, e in zip(n_atoms, n_edges):
+        mols.append(synth.Molecule(int(n), z[f'{prefix}_src'][e0:e0 + e], z[f'{prefix}_dst'][e0:e0 + e],
+                                   z[f'{prefix}_atom_feat'][a0:a0 + n], z[f'{prefix}_bond_feat'][e0:e0 + e],
+                                   z[f'{prefix}_coords'][a0:a0 + n]))
+        a0 += n
+        e0 += e
+    return mols
+
+
+def sd_from_npz(z, tag):
+    pre = tag + '/'
+    return {k[len(pre):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(pre)}
+
+
+def rel_err(a, b):
+    """max |a-b| / max |b|  (the '1e-4 relative fp32' of BASELINE.json:north_star)."""
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    denom = b.abs().max().clamp(min=1e-30)
+    return ((a - b).abs().max() / denom).item()
+
+
+def grads_close(got, ref, rtol, what=''):
+    """Compare a dict of gradients with the reference's.  Gradients that are analytically zero (e.g. a bias in
+    front of a BatchNorm) are pure rounding noise in both implementations, so the absolute floor is tied to the
+    largest gradient in the whole set."""
+    scale = max(float(np.abs(np.asarray(v)).max()) for v in ref.values())
+    for k, v in ref.items():
+        a = torch.as_tensor(got[k], dtype=torch.float64).cpu()
+        b = torch.as_tensor(v, dtype=torch.float64)
+        err = (a - b).abs().max().item()
+        bound = rtol * b.abs().max().item() + 2e-6 * scale
+        assert err <= bound, f'{what}{k}: err {err:.3e} > {bound:.3e}'
+
+
+def close(a, b, rtol, atol=0.0):
+    a = torch.as_tensor(a, dtype=torch.float64).cpu()
+    b = torch.as_tensor(b, dtype=torch.float64).cpu()
+    return (a - b).abs().max().item() <= rtol * b.abs().max().item() + atol
