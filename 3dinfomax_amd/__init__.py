@@ -1,0 +1,35 @@
+"""3dinfomax_amd - MI355X-native (gfx950, HIP) implementation of the 3DInfomax pre-training hot path:
+PNA(+Net3D)+NT-Xent behind the reference's model_type / model3d_type / loss_func plugin surface.
+
+The package name starts with a digit, so import it with importlib.import_module('3dinfomax_amd') or through
+the alias module `infomax3d_amd` at the repository root.
+"""
+from .graph import (BatchedMolGraph, GraphIndex, as_batched_graph, batch, bond_graph, complete_graph,  # noqa: F401
+                    conformer_collate, contrastive_collate)
+from . import synth  # noqa: F401
+
+
+def __getattr__(name):
+    # model / loss classes need torch + the HIP library: import lazily so that the numpy-only parts
+    # (synth, graph) stay importable everywhere.
+    if name in ('PNA', 'PNAGNN', 'PNALayer', 'PNA_AGGREGATORS', 'PNA_SCALERS'):
+        from . import pna
+        return getattr(pna, name)
+    if name in ('Net3D', 'Net3DLayer'):
+        from . import net3d
+        return getattr(net3d, name)
+    if name in ('NTXent', 'NTXentMultiplePositives'):
+        from . import losses
+        return getattr(losses, name)
+    if name in ('FCLayer', 'MLP'):
+        from . import layers
+        return getattr(layers, name)
+    if name in ('AtomEncoder', 'BondEncoder'):
+        from . import mol_encoder
+        return getattr(mol_encoder, name)
+    raise AttributeError(name)
+
+
+__all__ = ['PNA', 'PNAGNN', 'PNALayer', 'PNA_AGGREGATORS', 'PNA_SCALERS', 'Net3D', 'Net3DLayer', 'NTXent',
+           'NTXentMultiplePositives', 'FCLayer', 'MLP', 'AtomEncoder', 'BondEncoder', 'contrastive_collate',
+           'conformer_collate', 'BatchedMolGraph', 'batch', 'bond_graph', 'complete_graph']

@@ -1,0 +1,99 @@
+"""ctypes binding of lib3dinfomax_hip.so - the C ABI declared in include/infomax3d_hip.h.
+
+The product path has NO fallback: if the HIP library is missing or a call fails, it raises.
+"""
+import ctypes
+import os
+import re
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_long, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'lib3dinfomax_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(HERE), 'include', 'infomax3d_hip.h')
+
+# constants of include/infomax3d_hip.h
+ACT = {'none': 0, None: 0, 'relu': 1, 'silu': 2, 'sigmoid': 3}
+AGG = {'mean': 0, 'sum': 1, 'max': 2, 'min': 3, 'std': 4, 'var': 5}
+SCALER = {'identity': 0, 'amplification': 1, 'attenuation': 2}
+
+_P = c_void_p
+_SIGNATURES = {
+    'i3d_abi_version': (c_int, []),
+    'i3d_last_error': (c_char_p, []),
+    'i3d_embedding_sum_fwd': (c_int, [_P, _P, c_int, c_int, POINTER(c_void_p), c_int, _P, _P]),
+    'i3d_embedding_sum_bwd': (c_int, [_P, _P, c_int, c_int, _P, c_int, POINTER(c_void_p), POINTER(c_int), _P]),
+    'i3d_pna_aggregate_fwd': (c_int, [_P, _P, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_float, _P, _P]),
+    'i3d_pna_aggregate_bwd': (c_int, [_P, _P, _P, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_float,
+                                      _P, _P]),
+    'i3d_segment_readout_fwd': (c_int, [_P, _P, c_int, c_int, POINTER(c_int), c_int, _P, _P]),
+    'i3d_segment_readout_bwd': (c_int, [_P, _P, _P, c_int, c_int, POINTER(c_int), c_int, _P, _P]),
+    'i3d_gemm_f32': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
+    'i3d_colreduce_workspace_bytes': (c_long, [c_int, c_int]),
+    'i3d_act_stats_fwd': (c_int, [_P, c_int, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    'i3d_bn_finalize_stats': (c_int, [_P, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
+    'i3d_bn_apply_fwd': (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P]),
+    'i3d_bn_eval_fwd': (c_int, [_P, c_int, c_int, _P, _P, c_float, _P, _P, c_int, _P, _P, _P]),
+    'i3d_bn_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_long, _P, _P]),
+    'i3d_bn_eval_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    'i3d_colsum': (c_int, [_P, _P, c_int, c_int, _P, _P, _P]),
+    'i3d_act_fwd': (c_int, [_P, c_long, c_int, _P, _P]),
+    'i3d_act_bwd': (c_int, [_P, _P, c_long, c_int, _P, _P]),
+    'i3d_add_inplace': (c_int, [_P, _P, c_long, _P]),
+    'i3d_edge_combine_fwd': (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    'i3d_segment_sum': (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
+    'i3d_segment_bcast': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P]),
+    'i3d_gather_rows': (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    'i3d_fourier_encode': (c_int, [_P, c_int, c_int, _P, _P]),
+    'i3d_soft_edge_fwd': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P]),
+    'i3d_soft_edge_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
+    'i3d_row_norms': (c_int, [_P, c_int, c_int, _P, _P]),
+    'i3d_ntxent_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
+    'i3d_ntxent_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P]),
+    'i3d_row_axpy': (c_int, [_P, _P, c_int, c_int, _P, _P]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Function names declared in include/infomax3d_hip.h."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(i3d_[a-z0-9_]+)\s*\(', text)))
+
+
+def load():
+    """Load the C-ABI library (once) and attach argtypes.  Raises HipLibraryError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, name):
+    if rc != 0:
+        msg = load().i3d_last_error()
+        raise HipLibraryError(f'{name} failed (rc={rc}): {msg.decode() if msg else ""}')
+
+
+def int_array(values):
+    return (c_int * len(values))(*values)
+
+
+def ptr_array(ptrs):
+    return (c_void_p * len(ptrs))(*ptrs)

@@ -1,0 +1,375 @@
+// K4 - the PNA aggregation kernel (the HBM-roofline kernel of this path).
+//
+// Replaces, in ONE pass over a destination-sorted message tensor, what the reference gets
+// from DGL's degree-bucketed update_all + reduce_func + aggregators + scalers
+// (reference models/pna.py:206, 221-235, 17-37, 57-68): per destination node the
+// mean / max / min / std (/sum /var) over its in-edge messages, times the degree scalers
+// {1, log(D+1)/avg, avg/log(D+1)}, written as [N, n_scalers*n_aggregators*F]
+// (column order: scaler-major, aggregator-minor, each block F wide = reference :229-233).
+//
+// Mapping (CDNA4, wave64): messages are stored in CSR (by destination) order, so node v's
+// mailbox is the contiguous row range [in_ptr[v], in_ptr[v+1]).  The reduction axis is the
+// neighbour axis (D <= 4 on QM9) and is walked sequentially by one lane; the feature axis is
+// the parallel one.  One lane owns one (node, 4-feature) item: a wave reads 1 KiB contiguous
+// per neighbour step and writes 1 KiB contiguous per output block with 16-byte accesses, all
+// 64 lanes active (a wave-per-node mapping would idle 14 of 64 lanes at F=200).  The 12 output
+// blocks of a node are produced from registers - the fan-out costs no re-read of the input.
+// Algorithmic bytes per launch: 4*E*F + 4*N*12*F + 4*(N+1).
+#include <math.h>
+
+#include "common.h"
+
+namespace i3d {
+
+struct AggCfg {
+    int n_agg;
+    int agg[8];
+    int n_scaler;       // number of scaler blocks actually written (>= 1)
+    int scaler[4];      // I3D_SCALE_*; reference quirk: a single configured scaler is not applied
+    float amp[32];      // log(D+1)/avg for D < 32 (host-computed in double, like np.log in the reference)
+    float att[32];      // avg/log(D+1)
+    float avg;
+};
+
+__device__ __forceinline__ void scaler_values(const AggCfg& cfg, int D, float& amp, float& att) {
+    if (D < 32) {
+        amp = cfg.amp[D];
+        att = cfg.att[D];
+    } else {
+        double l = log((double)(D + 1));
+        amp = (float)(l / (double)cfg.avg);
+        att = (float)((double)cfg.avg / l);
+    }
+}
+
+struct Stats4 {
+    float4 sum, sq, mx, mn;
+};
+
+template <bool STD>
+__global__ void __launch_bounds__(256)
+pna_aggregate_fwd_kernel(const float4* __restrict__ e, const int* __restrict__ in_ptr, int N, int FV,
+                         AggCfg cfg, float4* __restrict__ out) {
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)N * FV) return;
+    int v = (int)(t / FV), c = (int)(t - (long)v * FV);
+    int beg = in_ptr[v], end = in_ptr[v + 1];
+    int D = end - beg;
+    const int nblk = cfg.n_agg * cfg.n_scaler;
+    float4* o = out + (long)v * nblk * FV + c;
+    if (D <= 0) {  // DGL leaves zero rows for isolated nodes
+        for (int b = 0; b < nblk; ++b) o[(long)b * FV] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float4* p = e + (long)beg * FV + c;
+    float4 x = *p;
+    float4 sum = x, mx = x, mn = x;
+    float4 sq = make_float4(x.x * x.x, x.y * x.y, x.z * x.z, x.w * x.w);
+    for (int j = 1; j < D; ++j) {
+        x = p[(long)j * FV];
+        sum.x += x.x; sum.y += x.y; sum.z += x.z; sum.w += x.w;
+        sq.x += x.x * x.x; sq.y += x.y * x.y; sq.z += x.z * x.z; sq.w += x.w * x.w;
+        mx.x = fmaxf(mx.x, x.x); mx.y = fmaxf(mx.y, x.y); mx.z = fmaxf(mx.z, x.z); mx.w = fmaxf(mx.w, x.w);
+        mn.x = fminf(mn.x, x.x); mn.y = fminf(mn.y, x.y); mn.z = fminf(mn.z, x.z); mn.w = fminf(mn.w, x.w);
+    }
+    const float fD = (float)D;
+    float4 mean = make_float4(sum.x / fD, sum.y / fD, sum.z / fD, sum.w / fD);
+    float4 msq = make_float4(sq.x / fD, sq.y / fD, sq.z / fD, sq.w / fD);
+    float4 var = make_float4(fmaxf(msq.x - mean.x * mean.x, 0.f), fmaxf(msq.y - mean.y * mean.y, 0.f),
+                             fmaxf(msq.z - mean.z * mean.z, 0.f), fmaxf(msq.w - mean.w * mean.w, 0.f));
+    float amp, att;
+    scaler_values(cfg, D, amp, att);
+    if (STD) {  // (mean,max,min,std) x (identity,amplification,attenuation): fully unrolled
+        float4 sd = make_float4(sqrtf(var.x + 1e-5f), sqrtf(var.y + 1e-5f), sqrtf(var.z + 1e-5f), sqrtf(var.w + 1e-5f));
+        float4 a[4] = {mean, mx, mn, sd};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[(long)k * FV] = a[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            o[(long)(4 + k) * FV] = make_float4(a[k].x * amp, a[k].y * amp, a[k].z * amp, a[k].w * amp);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            o[(long)(8 + k) * FV] = make_float4(a[k].x * att, a[k].y * att, a[k].z * att, a[k].w * att);
+    } else {
+        for (int s = 0; s < cfg.n_scaler; ++s) {
+            float sc = cfg.scaler[s] == I3D_SCALE_AMPLIFICATION ? amp
+                       : (cfg.scaler[s] == I3D_SCALE_ATTENUATION ? att : 1.f);
+            for (int k = 0; k < cfg.n_agg; ++k) {
+                float4 a;
+                switch (cfg.agg[k]) {
+                    case I3D_AGG_MEAN: a = mean; break;
+                    case I3D_AGG_SUM: a = sum; break;
+                    case I3D_AGG_MAX: a = mx; break;
+                    case I3D_AGG_MIN: a = mn; break;
+                    case I3D_AGG_VAR: a = var; break;
+                    default:
+                        a = make_float4(sqrtf(var.x + 1e-5f), sqrtf(var.y + 1e-5f), sqrtf(var.z + 1e-5f),
+                                        sqrtf(var.w + 1e-5f));
+                }
+                if (cfg.scaler[s] != I3D_SCALE_IDENTITY) a = make_float4(a.x * sc, a.y * sc, a.z * sc, a.w * sc);
+                o[(long)(s * cfg.n_agg + k) * FV] = a;
+            }
+        }
+    }
+}
+
+// scalar-feature fallback (F % 4 != 0)
+__global__ void __launch_bounds__(256)
+pna_aggregate_fwd_scalar_kernel(const float* __restrict__ e, const int* __restrict__ in_ptr, int N, int F,
+                                AggCfg cfg, float* __restrict__ out) {
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)N * F) return;
+    int v = (int)(t / F), c = (int)(t - (long)v * F);
+    int beg = in_ptr[v], D = in_ptr[v + 1] - beg;
+    const int nblk = cfg.n_agg * cfg.n_scaler;
+    float* o = out + (long)v * nblk * F + c;
+    if (D <= 0) {
+        for (int b = 0; b < nblk; ++b) o[(long)b * F] = 0.f;
+        return;
+    }
+    const float* p = e + (long)beg * F + c;
+    float x = *p, sum = x, sq = x * x, mx = x, mn = x;
+    for (int j = 1; j < D; ++j) {
+        x = p[(long)j * F];
+        sum += x; sq += x * x; mx = fmaxf(mx, x); mn = fminf(mn, x);
+    }
+    float mean = sum / (float)D, msq = sq / (float)D;
+    float var = fmaxf(msq - mean * mean, 0.f);
+    float amp, att;
+    scaler_values(cfg, D, amp, att);
+    for (int s = 0; s < cfg.n_scaler; ++s) {
+        float sc = cfg.scaler[s] == I3D_SCALE_AMPLIFICATION ? amp : (cfg.scaler[s] == I3D_SCALE_ATTENUATION ? att : 1.f);
+        for (int k = 0; k < cfg.n_agg; ++k) {
+            float a;
+            switch (cfg.agg[k]) {
+                case I3D_AGG_MEAN: a = mean; break;
+                case I3D_AGG_SUM: a = sum; break;
+                case I3D_AGG_MAX: a = mx; break;
+                case I3D_AGG_MIN: a = mn; break;
+                case I3D_AGG_VAR: a = var; break;
+                default: a = sqrtf(var + 1e-5f);
+            }
+            if (cfg.scaler[s] != I3D_SCALE_IDENTITY) a *= sc;
+            o[(long)(s * cfg.n_agg + k) * F] = a;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: d e[j] = g_mean/D + g_sum + g_max*[j==first argmax] + g_min*[j==first argmin]
+//                    + g_std*(x_j-mean)/(D*std)*[var_raw>0] + g_var*2(x_j-mean)/D*[var_raw>0]
+// where g_a = sum over scaler blocks of scale_s * dOut[s, a].  Tie routing = first index, as
+// torch.max/min(dim) backward on CPU; relu'(0) = 0 as torch.relu backward.
+// Algorithmic bytes: 4*N*12F (dOut) + 4*E*F (re-read e) + 4*E*F (write de) + 4*(N+1).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int V>
+__device__ __forceinline__ float& comp(T& a, int i) {
+    return reinterpret_cast<float*>(&a)[i];
+}
+
+template <int V>  // V = 4 (float4 items) or 1
+__global__ void __launch_bounds__(256)
+pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ e,
+                         const int* __restrict__ in_ptr, int N, int F, AggCfg cfg, float* __restrict__ ge) {
+    const int FV = F / V;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)N * FV) return;
+    int v = (int)(t / FV), c = (int)(t - (long)v * FV);
+    int beg = in_ptr[v], D = in_ptr[v + 1] - beg;
+    if (D <= 0) return;
+    const int nblk = cfg.n_agg * cfg.n_scaler;
+    const float* go = gout + (long)v * nblk * F + (long)c * V;
+    const float* p = e + (long)beg * F + (long)c * V;
+    float* q = ge + (long)beg * F + (long)c * V;
+    float amp, att;
+    scaler_values(cfg, D, amp, att);
+
+    // combined upstream gradient per aggregator kind
+    float g_mean[V], g_sum[V], g_max[V], g_min[V], g_std[V], g_var[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) g_mean[i] = g_sum[i] = g_max[i] = g_min[i] = g_std[i] = g_var[i] = 0.f;
+    for (int s = 0; s < cfg.n_scaler; ++s) {
+        float sc = cfg.scaler[s] == I3D_SCALE_AMPLIFICATION ? amp : (cfg.scaler[s] == I3D_SCALE_ATTENUATION ? att : 1.f);
+        for (int k = 0; k < cfg.n_agg; ++k) {
+            float g[V];
+            if (V == 4) {
+                float4 gg = *reinterpret_cast<const float4*>(go + (long)(s * cfg.n_agg + k) * F);
+                g[0] = gg.x; g[1 % V] = gg.y; g[2 % V] = gg.z; g[3 % V] = gg.w;
+            } else {
+                g[0] = go[(long)(s * cfg.n_agg + k) * F];
+            }
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                float gi = g[i] * sc;
+                switch (cfg.agg[k]) {
+                    case I3D_AGG_MEAN: g_mean[i] += gi; break;
+                    case I3D_AGG_SUM: g_sum[i] += gi; break;
+                    case I3D_AGG_MAX: g_max[i] += gi; break;
+                    case I3D_AGG_MIN: g_min[i] += gi; break;
+                    case I3D_AGG_VAR: g_var[i] += gi; break;
+                    default: g_std[i] += gi;
+                }
+            }
+        }
+    }
+    // pass 1: statistics + first arg-extrema
+    float sum[V], sq[V], mx[V], mn[V];
+    int amax[V], amin[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { sum[i] = 0.f; sq[i] = 0.f; mx[i] = -INFINITY; mn[i] = INFINITY; amax[i] = 0; amin[i] = 0; }
+    for (int j = 0; j < D; ++j) {
+        float x[V];
+        if (V == 4) {
+            float4 xx = *reinterpret_cast<const float4*>(p + (long)j * F);
+            x[0] = xx.x; x[1 % V] = xx.y; x[2 % V] = xx.z; x[3 % V] = xx.w;
+        } else {
+            x[0] = p[(long)j * F];
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            sum[i] += x[i];
+            sq[i] += x[i] * x[i];
+            if (x[i] > mx[i]) { mx[i] = x[i]; amax[i] = j; }
+            if (x[i] < mn[i]) { mn[i] = x[i]; amin[i] = j; }
+        }
+    }
+    const float fD = (float)D;
+    float mean[V], kstd[V], kvar[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        mean[i] = sum[i] / fD;
+        float raw = sq[i] / fD - mean[i] * mean[i];
+        bool pos = raw > 0.f;
+        float sd = sqrtf(fmaxf(raw, 0.f) + 1e-5f);
+        kstd[i] = pos ? g_std[i] / (fD * sd) : 0.f;          // d std / d x_j = (x_j - mean) / (D std)
+        kvar[i] = pos ? g_var[i] * 2.f / fD : 0.f;           // d var / d x_j = 2 (x_j - mean) / D
+        g_mean[i] = g_mean[i] / fD + g_sum[i];
+    }
+    // pass 2: write gradients (rows come from L1/L2)
+    for (int j = 0; j < D; ++j) {
+        float x[V], r[V];
+        if (V == 4) {
+            float4 xx = *reinterpret_cast<const float4*>(p + (long)j * F);
+            x[0] = xx.x; x[1 % V] = xx.y; x[2 % V] = xx.z; x[3 % V] = xx.w;
+        } else {
+            x[0] = p[(long)j * F];
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            r[i] = g_mean[i] + (kstd[i] + kvar[i]) * (x[i] - mean[i]);
+            if (j == amax[i]) r[i] += g_max[i];
+            if (j == amin[i]) r[i] += g_min[i];
+        }
+        if (V == 4) {
+            *reinterpret_cast<float4*>(q + (long)j * F) = make_float4(r[0], r[1 % V], r[2 % V], r[3 % V]);
+        } else {
+            q[(long)j * F] = r[0];
+        }
+    }
+}
+
+static int make_cfg(const int* aggregators, int n_agg, const int* scalers, int n_scalers, float avg_d_log, AggCfg& cfg) {
+    if (n_agg < 1 || n_agg > 8 || n_scalers < 1 || n_scalers > 4) return -1;
+    cfg.n_agg = n_agg;
+    for (int i = 0; i < n_agg; ++i) {
+        if (aggregators[i] < 0 || aggregators[i] > I3D_AGG_VAR) return -1;
+        cfg.agg[i] = aggregators[i];
+    }
+    // reference models/pna.py:232: scalers are only applied when more than one is configured
+    if (n_scalers == 1) {
+        cfg.n_scaler = 1;
+        cfg.scaler[0] = I3D_SCALE_IDENTITY;
+    } else {
+        cfg.n_scaler = n_scalers;
+        for (int i = 0; i < n_scalers; ++i) {
+            if (scalers[i] < 0 || scalers[i] > I3D_SCALE_ATTENUATION) return -1;
+            cfg.scaler[i] = scalers[i];
+        }
+    }
+    cfg.avg = avg_d_log;
+    cfg.amp[0] = 0.f;
+    cfg.att[0] = 0.f;   // D = 0 rows are never scaled (zero rows)
+    for (int D = 1; D < 32; ++D) {
+        double l = log((double)(D + 1));
+        cfg.amp[D] = (float)(l / (double)avg_d_log);
+        cfg.att[D] = (float)((double)avg_d_log / l);
+    }
+    return 0;
+}
+
+static bool is_std_cfg(const AggCfg& c) {
+    return c.n_agg == 4 && c.n_scaler == 3 && c.agg[0] == I3D_AGG_MEAN && c.agg[1] == I3D_AGG_MAX &&
+           c.agg[2] == I3D_AGG_MIN && c.agg[3] == I3D_AGG_STD && c.scaler[0] == I3D_SCALE_IDENTITY &&
+           c.scaler[1] == I3D_SCALE_AMPLIFICATION && c.scaler[2] == I3D_SCALE_ATTENUATION;
+}
+
+}  // namespace i3d
+
+using namespace i3d;
+
+extern "C" int i3d_pna_aggregate_fwd(const float* e, const int* in_ptr, int num_nodes, int feat,
+                                     const int* aggregators, int n_aggregators, const int* scalers,
+                                     int n_scalers, float avg_d_log, float* out, void* stream) {
+    I3D_CHECK_ARG(num_nodes >= 0 && feat > 0, "num_nodes >= 0 and feat > 0 required");
+    AggCfg cfg;
+    I3D_CHECK_ARG(make_cfg(aggregators, n_aggregators, scalers, n_scalers, avg_d_log, cfg) == 0,
+                  "bad aggregator/scaler list");
+    if (num_nodes == 0) return I3D_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (feat % 4 == 0) {
+        int FV = feat / 4;
+        long items = (long)num_nodes * FV;
+        dim3 grid(cdiv(items, 256));
+        if (is_std_cfg(cfg))
+            hipLaunchKernelGGL(pna_aggregate_fwd_kernel<true>, grid, dim3(256), 0, s, (const float4*)e, in_ptr,
+                               num_nodes, FV, cfg, (float4*)out);
+        else
+            hipLaunchKernelGGL(pna_aggregate_fwd_kernel<false>, grid, dim3(256), 0, s, (const float4*)e, in_ptr,
+                               num_nodes, FV, cfg, (float4*)out);
+    } else {
+        long items = (long)num_nodes * feat;
+        hipLaunchKernelGGL(pna_aggregate_fwd_scalar_kernel, dim3(cdiv(items, 256)), dim3(256), 0, s, e, in_ptr,
+                           num_nodes, feat, cfg, out);
+    }
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_pna_aggregate_bwd(const float* grad_out, const float* e, const int* in_ptr, int num_nodes,
+                                     int feat, const int* aggregators, int n_aggregators, const int* scalers,
+                                     int n_scalers, float avg_d_log, float* grad_e, void* stream) {
+    I3D_CHECK_ARG(num_nodes >= 0 && feat > 0, "num_nodes >= 0 and feat > 0 required");
+    AggCfg cfg;
+    I3D_CHECK_ARG(make_cfg(aggregators, n_aggregators, scalers, n_scalers, avg_d_log, cfg) == 0,
+                  "bad aggregator/scaler list");
+    if (num_nodes == 0) return I3D_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (feat % 4 == 0) {
+        long items = (long)num_nodes * (feat / 4);
+        hipLaunchKernelGGL(pna_aggregate_bwd_kernel<4>, dim3(cdiv(items, 256)), dim3(256), 0, s, grad_out, e, in_ptr,
+                           num_nodes, feat, cfg, grad_e);
+    } else {
+        long items = (long)num_nodes * feat;
+        hipLaunchKernelGGL(pna_aggregate_bwd_kernel<1>, dim3(cdiv(items, 256)), dim3(256), 0, s, grad_out, e, in_ptr,
+                           num_nodes, feat, cfg, grad_e);
+    }
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+// ---- K6: per-graph readout = the same segmented reduction driven by graph_ptr, no scalers ---------------
+// reference models/pna.py:133-134, models/net3d.py:73-74 (dgl.readout_nodes for op in readout_aggregators + cat)
+extern "C" int i3d_segment_readout_fwd(const float* x, const int* graph_ptr, int num_graphs, int feat, const int* ops,
+                                       int n_ops, float* out, void* stream) {
+    for (int i = 0; i < n_ops; ++i)
+        I3D_CHECK_ARG(ops[i] == I3D_AGG_MEAN || ops[i] == I3D_AGG_SUM || ops[i] == I3D_AGG_MAX || ops[i] == I3D_AGG_MIN,
+                      "readout op must be mean/sum/max/min");
+    int ident = I3D_SCALE_IDENTITY;
+    return i3d_pna_aggregate_fwd(x, graph_ptr, num_graphs, feat, ops, n_ops, &ident, 1, 1.0f, out, stream);
+}
+
+extern "C" int i3d_segment_readout_bwd(const float* grad_out, const float* x, const int* graph_ptr, int num_graphs,
+                                       int feat, const int* ops, int n_ops, float* grad_x, void* stream) {
+    int ident = I3D_SCALE_IDENTITY;
+    return i3d_pna_aggregate_bwd(grad_out, x, graph_ptr, num_graphs, feat, ops, n_ops, &ident, 1, 1.0f, grad_x, stream);
+}

@@ -1,0 +1,544 @@
+// Column statistics, BatchNorm1d (train / eval, forward / backward) and the activation fused in front of it.
+//
+// Replaces nn.BatchNorm1d + the activation of FCLayer (reference models/base_layers.py:100-111): the
+// reference's order is Linear -> activation -> BatchNorm, batch statistics over ALL rows of the batch
+// (edges for pretrans, nodes for posttrans, graphs for the head), momentum m, eps 1e-5, unbiased
+// running_var.  All column reductions are two-stage and deterministic: stage 1 reduces a row chunk per
+// workgroup (fp32, shifted by row 0 so E[x^2]-E[x]^2 does not cancel), stage 2 sums the chunk partials in
+// fp64 and finalises.  HBM-bound: one read (+ one write when an activation is fused) per pass.
+#include "common.h"
+
+namespace i3d {
+
+constexpr int MAX_PARTIAL_BLOCKS = 1024;
+
+struct Chunking {
+    int tpr;       // threads per row (column vectors handled in parallel)
+    int rl;        // row lanes per block
+    int rpb;       // rows per block
+    int nblk;      // blocks along rows
+    int ncolblk;   // blocks along columns
+    int cv;        // column vectors per row
+    int V;         // floats per column vector
+};
+
+static Chunking make_chunking(int rows, int feat) {
+    Chunking c;
+    c.V = (feat % 4 == 0) ? 4 : 1;
+    c.cv = feat / c.V;
+    c.tpr = c.cv < 256 ? c.cv : 256;
+    c.rl = 256 / c.tpr;
+    c.ncolblk = cdiv(c.cv, c.tpr);
+    int rpb = cdiv(rows, MAX_PARTIAL_BLOCKS);
+    int min_rpb = c.rl * 4;
+    if (rpb < min_rpb) rpb = min_rpb;
+    c.rpb = rpb;
+    c.nblk = rows > 0 ? cdiv(rows, rpb) : 0;
+    return c;
+}
+
+enum { MODE_STATS = 0, MODE_BN_BWD = 1, MODE_COLSUM = 2 };
+
+struct ReduceArgs {
+    const float* a;        // STATS: pre          BN_BWD: grad_y      COLSUM: x
+    const float* b;        // STATS: -            BN_BWD: x           COLSUM: row weights (or null)
+    float* out;            // STATS: x = act(pre) (or null)
+    const float* mean;     // BN_BWD
+    const float* invstd;   // BN_BWD
+    const float* gamma;    // BN_BWD with post_act
+    const float* beta;     // BN_BWD with post_act
+    int rows, feat, act, post_act;
+    float* partial;        // [nblk][2][feat]
+};
+
+template <int MODE, int V>
+__global__ void __launch_bounds__(256) colreduce_partial_kernel(ReduceArgs g, Chunking ch) {
+    __shared__ float sm[2][256 * 4];
+    const int t = threadIdx.x;
+    const int cl = t % ch.tpr, rlane = t / ch.tpr;
+    const int cvi = blockIdx.y * ch.tpr + cl;
+    const bool active = rlane < ch.rl && cvi < ch.cv;
+    const int F = g.feat;
+    const int c0 = cvi * V;
+    float a1[V], a2[V], shift[V], mu[V], is[V], ga[V], be[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { a1[i] = 0.f; a2[i] = 0.f; shift[i] = 0.f; mu[i] = 0.f; is[i] = 1.f; ga[i] = 1.f; be[i] = 0.f; }
+    if (active) {
+        if (MODE == MODE_STATS) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) shift[i] = apply_act(g.a[c0 + i], g.act);   // row 0
+        }
+        if (MODE == MODE_BN_BWD) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                mu[i] = g.mean[c0 + i];
+                is[i] = g.invstd[c0 + i];
+                if (g.post_act != I3D_ACT_NONE) { ga[i] = g.gamma[c0 + i]; be[i] = g.beta[c0 + i]; }
+            }
+        }
+        const int r_begin = blockIdx.x * ch.rpb;
+        const int r_end = min(g.rows, r_begin + ch.rpb);
+        for (int r = r_begin + rlane; r < r_end; r += ch.rl) {
+            const long off = (long)r * F + c0;
+            float x[V], y[V];
+            if (V == 4) {
+                float4 xx = *reinterpret_cast<const float4*>(g.a + off);
+                x[0] = xx.x; x[1 % V] = xx.y; x[2 % V] = xx.z; x[3 % V] = xx.w;
+            } else {
+                x[0] = g.a[off];
+            }
+            if (MODE == MODE_STATS) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    x[i] = apply_act(x[i], g.act);
+                    float d = x[i] - shift[i];
+                    a1[i] += d;
+                    a2[i] += d * d;
+                }
+                if (g.out != nullptr && g.act != I3D_ACT_NONE) {
+                    if (V == 4) *reinterpret_cast<float4*>(g.out + off) = make_float4(x[0], x[1 % V], x[2 % V], x[3 % V]);
+                    else g.out[off] = x[0];
+                }
+            } else if (MODE == MODE_BN_BWD) {
+                if (V == 4) {
+                    float4 yy = *reinterpret_cast<const float4*>(g.b + off);
+                    y[0] = yy.x; y[1 % V] = yy.y; y[2 % V] = yy.z; y[3 % V] = yy.w;
+                } else {
+                    y[0] = g.b[off];
+                }
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    float xh = (y[i] - mu[i]) * is[i];
+                    float dy = x[i];
+                    if (g.post_act != I3D_ACT_NONE) dy *= act_grad(xh * ga[i] + be[i], g.post_act);
+                    a1[i] += dy;
+                    a2[i] += dy * xh;
+                }
+            } else {
+                float w = g.b != nullptr ? g.b[r] : 1.f;
+#pragma unroll
+                for (int i = 0; i < V; ++i) a1[i] += x[i] * w;
+            }
+        }
+    }
+    // reduce over the row lanes of the block
+#pragma unroll
+    for (int i = 0; i < V; ++i) { sm[0][t * V + i] = a1[i]; sm[1][t * V + i] = a2[i]; }
+    __syncthreads();
+    if (rlane == 0 && cvi < ch.cv) {
+        float s1[V], s2[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+        for (int k = 0; k < ch.rl; ++k) {
+            const int tt = k * ch.tpr + cl;
+#pragma unroll
+            for (int i = 0; i < V; ++i) { s1[i] += sm[0][tt * V + i]; s2[i] += sm[1][tt * V + i]; }
+        }
+        float* p = g.partial + (long)blockIdx.x * 2 * F + c0;
+#pragma unroll
+        for (int i = 0; i < V; ++i) { p[i] = s1[i]; p[F + i] = s2[i]; }
+    }
+}
+
+// ---- stage 2 ----------------------------------------------------------------------------------------
+__global__ void stats_final_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ pre_row0,
+                                   int act, int rows, int feat, float eps, float momentum, float* mean, float* invstd,
+                                   float* running_mean, float* running_var, double* sums_out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= feat) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += (double)partial[(long)b * 2 * feat + c];
+        s2 += (double)partial[(long)b * 2 * feat + feat + c];
+    }
+    double shift = (double)apply_act(pre_row0[c], act);
+    double n = (double)rows;
+    if (sums_out != nullptr) {   // synchronised BN: hand un-shifted fp64 sums to the all-reduce
+        sums_out[c] = s1 + n * shift;
+        sums_out[feat + c] = s2 + 2.0 * shift * s1 + n * shift * shift;
+        if (c == 0) sums_out[2 * feat] = n;
+        return;
+    }
+    double m = s1 / n;
+    double var = s2 / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)(shift + m);
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean != nullptr) {
+        double unbiased = rows > 1 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * (shift + m));
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+}
+
+__global__ void stats_from_sums_kernel(const double* __restrict__ sums, int feat, float eps, float momentum, float* mean,
+                                       float* invstd, float* running_mean, float* running_var) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= feat) return;
+    double n = sums[2 * feat];
+    double m = sums[c] / n;
+    double var = sums[feat + c] / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean != nullptr) {
+        double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+}
+
+// sums of the two partial columns -> out1[feat], out2[feat] (fp32) or fp64 sums_out[2*feat]
+__global__ void pair_final_kernel(const float* __restrict__ partial, int nblk, int feat, float* out1, float* out2,
+                                  double* sums_out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= feat) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += (double)partial[(long)b * 2 * feat + c];
+        s2 += (double)partial[(long)b * 2 * feat + feat + c];
+    }
+    if (sums_out != nullptr) {
+        sums_out[c] = s1;
+        sums_out[feat + c] = s2;
+    }
+    if (out1 != nullptr) out1[c] = (float)s1;
+    if (out2 != nullptr) out2[c] = (float)s2;
+}
+
+__global__ void invstd_from_var_kernel(const float* __restrict__ rv, int feat, float eps, float* __restrict__ o) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < feat) o[c] = 1.f / sqrtf(rv[c] + eps);
+}
+
+// fp64 all-reduced sums {sum dy, sum dy*xhat, count} -> fp32 scratch {.., .., 1/count}
+__global__ void sums_to_float_kernel(const double* __restrict__ sums, int feat, float* out1, float* out2) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= feat) return;
+    out1[c] = (float)sums[c];
+    out2[c] = (float)sums[feat + c];
+    if (c == 0) out2[feat] = (float)(1.0 / sums[2 * feat]);
+}
+
+// ---- elementwise passes ------------------------------------------------------------------------------
+struct ApplyArgs {
+    const float* x;
+    const float* mean;
+    const float* invstd;      // train: invstd      eval: running_var (invstd computed on the fly)
+    const float* gamma;
+    const float* beta;
+    const float* residual;
+    float* y;
+    long items;               // rows * feat / V
+    int feat, post_act, eval_mode;
+    float eps;
+};
+
+template <int V>
+__global__ void __launch_bounds__(256) bn_apply_kernel(ApplyArgs g) {
+    const int FV = g.feat / V;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < g.items; t += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(t % FV) * V;
+        const long off = t * V;
+        float x[V], r[V];
+        if (V == 4) {
+            float4 xx = *reinterpret_cast<const float4*>(g.x + off);
+            x[0] = xx.x; x[1 % V] = xx.y; x[2 % V] = xx.z; x[3 % V] = xx.w;
+            if (g.residual) {
+                float4 rr = *reinterpret_cast<const float4*>(g.residual + off);
+                r[0] = rr.x; r[1 % V] = rr.y; r[2 % V] = rr.z; r[3 % V] = rr.w;
+            }
+        } else {
+            x[0] = g.x[off];
+            if (g.residual) r[0] = g.residual[off];
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float is = g.eval_mode ? 1.f / sqrtf(g.invstd[c0 + i] + g.eps) : g.invstd[c0 + i];
+            float v = (x[i] - g.mean[c0 + i]) * is * g.gamma[c0 + i] + g.beta[c0 + i];
+            v = apply_act(v, g.post_act);
+            if (g.residual) v += r[i];
+            x[i] = v;
+        }
+        if (V == 4) *reinterpret_cast<float4*>(g.y + off) = make_float4(x[0], x[1 % V], x[2 % V], x[3 % V]);
+        else g.y[off] = x[0];
+    }
+}
+
+struct BwdApplyArgs {
+    const float* grad_y;
+    const float* x;
+    const float* pre;
+    const float* mean;
+    const float* invstd;      // eval: running_var
+    const float* gamma;
+    const float* beta;
+    const float* sum_dy;      // [feat]  (train only)
+    const float* sum_dy_xhat; // [feat]
+    float* grad_pre;
+    const float* inv_n_ptr;   // device 1/N (synchronised BN) or null -> inv_n
+    long items;
+    int feat, act, post_act, eval_mode;
+    float inv_n, eps;
+};
+
+template <int V>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BwdApplyArgs g) {
+    const int FV = g.feat / V;
+    const float inv_n = g.inv_n_ptr ? g.inv_n_ptr[0] : g.inv_n;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < g.items; t += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(t % FV) * V;
+        const long off = t * V;
+        float dy[V], x[V], p[V];
+        if (V == 4) {
+            float4 a = *reinterpret_cast<const float4*>(g.grad_y + off);
+            float4 b = *reinterpret_cast<const float4*>(g.x + off);
+            dy[0] = a.x; dy[1 % V] = a.y; dy[2 % V] = a.z; dy[3 % V] = a.w;
+            x[0] = b.x; x[1 % V] = b.y; x[2 % V] = b.z; x[3 % V] = b.w;
+            if (g.pre) {
+                float4 c = *reinterpret_cast<const float4*>(g.pre + off);
+                p[0] = c.x; p[1 % V] = c.y; p[2 % V] = c.z; p[3 % V] = c.w;
+            }
+        } else {
+            dy[0] = g.grad_y[off];
+            x[0] = g.x[off];
+            if (g.pre) p[0] = g.pre[off];
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int c = c0 + i;
+            float is = g.eval_mode ? 1.f / sqrtf(g.invstd[c] + g.eps) : g.invstd[c];
+            float xh = (x[i] - g.mean[c]) * is;
+            float d = dy[i];
+            if (g.post_act != I3D_ACT_NONE) d *= act_grad(xh * g.gamma[c] + g.beta[c], g.post_act);
+            float gx;
+            if (g.eval_mode) gx = d * g.gamma[c] * is;
+            else gx = g.gamma[c] * is * (d - g.sum_dy[c] * inv_n - xh * g.sum_dy_xhat[c] * inv_n);
+            if (g.act != I3D_ACT_NONE) gx *= act_grad(g.pre ? p[i] : x[i], g.act);   // relu'(pre) == relu'(x)
+            dy[i] = gx;
+        }
+        if (V == 4) *reinterpret_cast<float4*>(g.grad_pre + off) = make_float4(dy[0], dy[1 % V], dy[2 % V], dy[3 % V]);
+        else g.grad_pre[off] = dy[0];
+    }
+}
+
+__global__ void __launch_bounds__(256) act_fwd_kernel(const float* __restrict__ x, long n, int act, float* __restrict__ y) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
+        y[t] = apply_act(x[t], act);
+}
+
+__global__ void __launch_bounds__(256)
+act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, long n, int act, float* __restrict__ gx) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
+        gx[t] = gy[t] * act_grad(x[t], act);
+}
+
+__global__ void __launch_bounds__(256) add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, long n) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) dst[t] += src[t];
+}
+
+static int grid_for(long items) {
+    long b = (items + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+template <int MODE>
+static void launch_partial(const ReduceArgs& g, const Chunking& ch, hipStream_t s) {
+    dim3 grid(ch.nblk, ch.ncolblk);
+    if (ch.V == 4) hipLaunchKernelGGL((colreduce_partial_kernel<MODE, 4>), grid, dim3(256), 0, s, g, ch);
+    else hipLaunchKernelGGL((colreduce_partial_kernel<MODE, 1>), grid, dim3(256), 0, s, g, ch);
+}
+
+}  // namespace i3d
+
+using namespace i3d;
+
+extern "C" long i3d_colreduce_workspace_bytes(int rows, int feat) {
+    (void)rows;
+    return (long)MAX_PARTIAL_BLOCKS * 2 * feat * sizeof(float) + 4 * (long)feat * sizeof(double) + 64;
+}
+
+extern "C" int i3d_act_stats_fwd(const float* pre, int rows, int feat, int act, float* x, float eps, float momentum,
+                                 float* mean, float* invstd, float* running_mean, float* running_var,
+                                 double* sums_out, void* workspace, void* stream) {
+    I3D_CHECK_ARG(rows > 0 && feat > 0, "rows > 0 and feat > 0 required");
+    I3D_CHECK_ARG(workspace != nullptr, "workspace required");
+    hipStream_t s = (hipStream_t)stream;
+    Chunking ch = make_chunking(rows, feat);
+    ReduceArgs g = {};
+    g.a = pre; g.out = x; g.rows = rows; g.feat = feat; g.act = act; g.post_act = I3D_ACT_NONE;
+    g.partial = (float*)workspace;
+    launch_partial<MODE_STATS>(g, ch, s);
+    I3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(stats_final_kernel, dim3(cdiv(feat, 128)), dim3(128), 0, s, g.partial, ch.nblk, pre, act, rows,
+                       feat, eps, momentum, mean, invstd, running_mean, running_var, sums_out);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_bn_finalize_stats(const double* sums, int feat, float eps, float momentum, float* mean,
+                                     float* invstd, float* running_mean, float* running_var, void* stream) {
+    I3D_CHECK_ARG(feat > 0, "feat > 0 required");
+    hipLaunchKernelGGL(stats_from_sums_kernel, dim3(cdiv(feat, 128)), dim3(128), 0, (hipStream_t)stream, sums, feat, eps,
+                       momentum, mean, invstd, running_mean, running_var);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+static int bn_apply_common(const float* x, int rows, int feat, const float* mean, const float* invstd_or_var,
+                           const float* gamma, const float* beta, int post_act, const float* residual, float* y,
+                           int eval_mode, float eps, void* stream) {
+    if (rows == 0) return I3D_OK;
+    ApplyArgs g;
+    g.x = x; g.mean = mean; g.invstd = invstd_or_var; g.gamma = gamma; g.beta = beta; g.residual = residual; g.y = y;
+    g.feat = feat; g.post_act = post_act; g.eval_mode = eval_mode; g.eps = eps;
+    hipStream_t s = (hipStream_t)stream;
+    if (feat % 4 == 0) {
+        g.items = (long)rows * feat / 4;
+        hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(grid_for(g.items)), dim3(256), 0, s, g);
+    } else {
+        g.items = (long)rows * feat;
+        hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(grid_for(g.items)), dim3(256), 0, s, g);
+    }
+    return I3D_OK;
+}
+
+extern "C" int i3d_bn_apply_fwd(const float* x, int rows, int feat, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, int post_act, const float* residual, float* y,
+                                void* stream) {
+    I3D_CHECK_ARG(rows >= 0 && feat > 0, "bad shape");
+    bn_apply_common(x, rows, feat, mean, invstd, gamma, beta, post_act, residual, y, 0, 0.f, stream);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_bn_eval_fwd(const float* x, int rows, int feat, const float* running_mean,
+                               const float* running_var, float eps, const float* gamma, const float* beta,
+                               int post_act, const float* residual, float* y, void* stream) {
+    I3D_CHECK_ARG(rows >= 0 && feat > 0, "bad shape");
+    bn_apply_common(x, rows, feat, running_mean, running_var, gamma, beta, post_act, residual, y, 1, eps, stream);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+static void launch_bwd_apply(BwdApplyArgs& g, int rows, int feat, hipStream_t s) {
+    if (feat % 4 == 0) {
+        g.items = (long)rows * feat / 4;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(grid_for(g.items)), dim3(256), 0, s, g);
+    } else {
+        g.items = (long)rows * feat;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(grid_for(g.items)), dim3(256), 0, s, g);
+    }
+}
+
+extern "C" int i3d_bn_bwd(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
+                          int post_act, const float* mean, const float* invstd, const float* gamma,
+                          const float* beta, float* grad_gamma, float* grad_beta, float* grad_pre, double* sums_out,
+                          const double* sums_in, long total_rows, void* workspace, void* stream) {
+    I3D_CHECK_ARG(rows > 0 && feat > 0, "rows > 0 and feat > 0 required");
+    I3D_CHECK_ARG(workspace != nullptr, "workspace required");
+    I3D_CHECK_ARG(act == I3D_ACT_NONE || act == I3D_ACT_RELU || pre != nullptr, "pre required for this activation");
+    hipStream_t s = (hipStream_t)stream;
+    Chunking ch = make_chunking(rows, feat);
+    float* partial = (float*)workspace;
+    if (sums_in == nullptr) {   // phase 1: column sums of dy and dy*xhat
+        ReduceArgs g = {};
+        g.a = grad_y; g.b = x; g.mean = mean; g.invstd = invstd; g.gamma = gamma; g.beta = beta;
+        g.rows = rows; g.feat = feat; g.act = act; g.post_act = post_act; g.partial = partial;
+        launch_partial<MODE_BN_BWD>(g, ch, s);
+        I3D_CHECK_LAUNCH();
+        hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(feat, 128)), dim3(128), 0, s, partial, ch.nblk, feat, grad_beta,
+                           grad_gamma, sums_out);
+        I3D_CHECK_LAUNCH();
+        if (sums_out != nullptr) return I3D_OK;   // caller all-reduces, then calls again with sums_in
+        total_rows = rows;
+    }
+    const float* sum_dy = grad_beta;
+    const float* sum_dy_xhat = grad_gamma;
+    if (sums_in != nullptr) {   // phase 2 of synchronised BN: global sums drive the data gradient
+        float* tmp = partial + (long)MAX_PARTIAL_BLOCKS * 2 * feat;
+        hipLaunchKernelGGL(sums_to_float_kernel, dim3(cdiv(feat, 128)), dim3(128), 0, s, sums_in, feat, tmp, tmp + feat);
+        I3D_CHECK_LAUNCH();
+        sum_dy = tmp;
+        sum_dy_xhat = tmp + feat;
+    }
+    BwdApplyArgs b;
+    b.inv_n_ptr = sums_in != nullptr ? (partial + (long)MAX_PARTIAL_BLOCKS * 2 * feat + 2 * feat) : nullptr;
+    b.grad_y = grad_y; b.x = x; b.pre = (act == I3D_ACT_NONE || act == I3D_ACT_RELU) ? nullptr : pre;
+    b.mean = mean; b.invstd = invstd; b.gamma = gamma; b.beta = beta;
+    b.sum_dy = sum_dy; b.sum_dy_xhat = sum_dy_xhat; b.grad_pre = grad_pre; b.feat = feat; b.act = act;
+    b.post_act = post_act; b.eval_mode = 0; b.inv_n = 1.f / (float)total_rows; b.eps = 0.f;
+    launch_bwd_apply(b, rows, feat, s);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_bn_eval_bwd(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
+                               int post_act, const float* running_mean, const float* running_var, float eps,
+                               const float* gamma, const float* beta, float* grad_gamma, float* grad_beta,
+                               float* grad_pre, void* workspace, void* stream) {
+    I3D_CHECK_ARG(rows > 0 && feat > 0, "rows > 0 and feat > 0 required");
+    I3D_CHECK_ARG(workspace != nullptr, "workspace required");
+    hipStream_t s = (hipStream_t)stream;
+    // grad_gamma / grad_beta need xhat with invstd from running_var: materialise invstd in the workspace tail
+    Chunking ch = make_chunking(rows, feat);
+    float* partial = (float*)workspace;
+    float* invstd = partial + (long)MAX_PARTIAL_BLOCKS * 2 * feat;
+    hipLaunchKernelGGL(invstd_from_var_kernel, dim3(cdiv(feat, 128)), dim3(128), 0, s, running_var, feat, eps, invstd);
+    I3D_CHECK_LAUNCH();
+    ReduceArgs g = {};
+    g.a = grad_y; g.b = x; g.mean = running_mean; g.invstd = invstd; g.gamma = gamma; g.beta = beta;
+    g.rows = rows; g.feat = feat; g.act = act; g.post_act = post_act; g.partial = partial;
+    launch_partial<MODE_BN_BWD>(g, ch, s);
+    I3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(feat, 128)), dim3(128), 0, s, partial, ch.nblk, feat, grad_beta,
+                       grad_gamma, (double*)nullptr);
+    I3D_CHECK_LAUNCH();
+    BwdApplyArgs b;
+    b.grad_y = grad_y; b.x = x; b.pre = (act == I3D_ACT_NONE || act == I3D_ACT_RELU) ? nullptr : pre;
+    b.mean = running_mean; b.invstd = running_var; b.gamma = gamma; b.beta = beta; b.sum_dy = nullptr;
+    b.sum_dy_xhat = nullptr; b.grad_pre = grad_pre; b.feat = feat; b.act = act; b.post_act = post_act;
+    b.inv_n_ptr = nullptr; b.eval_mode = 1; b.inv_n = 0.f; b.eps = eps;
+    launch_bwd_apply(b, rows, feat, s);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_colsum(const float* x, const float* w, int rows, int feat, float* out, void* workspace,
+                          void* stream) {
+    I3D_CHECK_ARG(rows > 0 && feat > 0, "rows > 0 and feat > 0 required");
+    I3D_CHECK_ARG(workspace != nullptr, "workspace required");
+    hipStream_t s = (hipStream_t)stream;
+    Chunking ch = make_chunking(rows, feat);
+    ReduceArgs g = {};
+    g.a = x; g.b = w; g.rows = rows; g.feat = feat; g.partial = (float*)workspace;
+    launch_partial<MODE_COLSUM>(g, ch, s);
+    I3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(feat, 128)), dim3(128), 0, s, g.partial, ch.nblk, feat, out,
+                       (float*)nullptr, (double*)nullptr);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_act_fwd(const float* x, long n, int act, float* y, void* stream) {
+    if (n <= 0) return I3D_OK;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, act, y);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_act_bwd(const float* grad_y, const float* x, long n, int act, float* grad_x, void* stream) {
+    if (n <= 0) return I3D_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, grad_y, x, n, act, grad_x);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_add_inplace(float* dst, const float* src, long n, void* stream) {
+    if (n <= 0) return I3D_OK;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}

@@ -1,0 +1,62 @@
+// Shared helpers for the gfx950 kernels of lib3dinfomax_hip.so (CDNA4 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/infomax3d_hip.h"
+
+namespace i3d {
+
+void set_error(const char* fmt, ...);
+
+// Every C-ABI entry point returns 0 on success.  Launch errors are reported through
+// hipGetLastError() right after the launch (no device synchronisation: the caller's stream
+// stays asynchronous) and turned into a message retrievable with i3d_last_error().
+#define I3D_CHECK_ARG(cond, msg)                                  \
+    do {                                                          \
+        if (!(cond)) {                                            \
+            i3d::set_error("%s: invalid argument: %s", __func__, msg); \
+            return I3D_ERR_INVALID;                               \
+        }                                                         \
+    } while (0)
+
+#define I3D_CHECK_LAUNCH()                                                       \
+    do {                                                                         \
+        hipError_t e_ = hipGetLastError();                                       \
+        if (e_ != hipSuccess) {                                                  \
+            i3d::set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
+            return I3D_ERR_LAUNCH;                                               \
+        }                                                                        \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+    switch (act) {
+        case I3D_ACT_RELU: return x > 0.f ? x : 0.f;
+        case I3D_ACT_SILU: return x / (1.f + __expf(-x));
+        case I3D_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+        default: return x;
+    }
+}
+
+// derivative of act at pre-activation x
+__device__ __forceinline__ float act_grad(float x, int act) {
+    switch (act) {
+        case I3D_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        case I3D_ACT_SILU: {
+            float s = 1.f / (1.f + __expf(-x));
+            return s * (1.f + x * (1.f - s));
+        }
+        case I3D_ACT_SIGMOID: {
+            float s = 1.f / (1.f + __expf(-x));
+            return s * (1.f - s);
+        }
+        default: return 1.f;
+    }
+}
+
+}  // namespace i3d

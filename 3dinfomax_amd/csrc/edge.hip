@@ -1,0 +1,250 @@
+// Edge-side kernels: gather-combine (the fused replacement of "gather src/dst rows, concat, first Linear"),
+// segmented sums for the gather backward and Net3D's mean reduce, Fourier distance features and Net3D's
+// soft edge gate.  All HBM-bound; one lane owns one (row, 4-feature) item with 16-byte accesses, neighbour
+// rows of a molecule sit next to each other so the P[src] / P[dst] gathers hit L2.
+#include "common.h"
+
+namespace i3d {
+
+// pre[j,:] = P[src[j], 0:F] + P[dst[j], F:2F] + Q[j,:] + bias
+// reference models/pna.py:237-252 (cat[src,dst,edge] -> Linear) via  [a|b|c] W^T = a Ws^T + b Wd^T + c Wq^T
+template <int V>
+__global__ void __launch_bounds__(256)
+edge_combine_fwd_kernel(const float* __restrict__ P, int ldp, const float* __restrict__ Q,
+                        const float* __restrict__ bias, const int* __restrict__ src, const int* __restrict__ dst,
+                        int E, int feat, float* __restrict__ pre) {
+    const int FV = feat / V;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)E * FV) return;
+    int j = (int)(t / FV), c = (int)(t - (long)j * FV) * V;
+    const float* ps = P + (long)src[j] * ldp + c;
+    const float* pd = P + (long)dst[j] * ldp + feat + c;
+    float* o = pre + (long)j * feat + c;
+    if (V == 4) {
+        float4 a = *reinterpret_cast<const float4*>(ps);
+        float4 b = *reinterpret_cast<const float4*>(pd);
+        float4 d = Q ? *reinterpret_cast<const float4*>(Q + (long)j * feat + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 r = make_float4(a.x + b.x + d.x, a.y + b.y + d.y, a.z + b.z + d.z, a.w + b.w + d.w);
+        if (bias) {
+            float4 bb = *reinterpret_cast<const float4*>(bias + c);
+            r.x += bb.x; r.y += bb.y; r.z += bb.z; r.w += bb.w;
+        }
+        *reinterpret_cast<float4*>(o) = r;
+    } else {
+        float r = ps[0] + pd[0] + (Q ? Q[(long)j * feat + c] : 0.f);
+        if (bias) r += bias[c];
+        o[0] = r;
+    }
+}
+
+// out[v, :] = scale * sum_{j in [ptr[v], ptr[v+1])} x[idx ? idx[j] : j, :]
+template <int V>
+__global__ void __launch_bounds__(256)
+segment_sum_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ ptr, const int* __restrict__ idx,
+                   int nseg, int feat, int scale_mode, float* __restrict__ out, int ldo) {
+    const int FV = feat / V;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)nseg * FV) return;
+    int v = (int)(t / FV), c = (int)(t - (long)v * FV) * V;
+    int beg = ptr[v], end = ptr[v + 1];
+    float acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = 0.f;
+    for (int j = beg; j < end; ++j) {
+        long row = idx ? idx[j] : j;
+        const float* p = x + row * ldx + c;
+        if (V == 4) {
+            float4 a = *reinterpret_cast<const float4*>(p);
+            acc[0] += a.x; acc[1 % V] += a.y; acc[2 % V] += a.z; acc[3 % V] += a.w;
+        } else {
+            acc[0] += p[0];
+        }
+    }
+    if (scale_mode == 1) {   // DGL fn.mean divides the sum by the in-degree
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] = acc[i] / (float)max(end - beg, 1);
+    }
+    float* o = out + (long)v * ldo + c;
+    if (V == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1 % V], acc[2 % V], acc[3 % V]);
+    else o[0] = acc[0];
+}
+
+// out[j,:] = scale(seg) * g[seg,:]  with seg = seg_of_row[j]
+template <int V>
+__global__ void __launch_bounds__(256)
+segment_bcast_kernel(const float* __restrict__ g, const int* __restrict__ ptr, const int* __restrict__ seg_of_row,
+                     int rows, int feat, int scale_mode, float* __restrict__ out) {
+    const int FV = feat / V;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)rows * FV) return;
+    int j = (int)(t / FV), c = (int)(t - (long)j * FV) * V;
+    int v = seg_of_row[j];
+    float s = 1.f;
+    if (scale_mode == 1) s = (float)max(ptr[v + 1] - ptr[v], 1);
+    const float* p = g + (long)v * feat + c;
+    float* o = out + (long)j * feat + c;
+    if (V == 4) {
+        float4 a = *reinterpret_cast<const float4*>(p);
+        *reinterpret_cast<float4*>(o) = make_float4(a.x / s, a.y / s, a.z / s, a.w / s);
+    } else {
+        o[0] = p[0] / s;
+    }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const float* __restrict__ x, const int* __restrict__ idx, int rows, int feat,
+                   float* __restrict__ out) {
+    const int FV = feat / V;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)rows * FV) return;
+    int j = (int)(t / FV), c = (int)(t - (long)j * FV) * V;
+    const float* p = x + (long)idx[j] * feat + c;
+    float* o = out + (long)j * feat + c;
+    if (V == 4) *reinterpret_cast<float4*>(o) = *reinterpret_cast<const float4*>(p);
+    else o[0] = p[0];
+}
+
+// reference commons/utils.py:103-110: [sin(d/2^k)]_k | [cos(d/2^k)]_k | d
+__global__ void __launch_bounds__(256)
+fourier_encode_kernel(const float* __restrict__ d, int E, int n_enc, float* __restrict__ out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= E) return;
+    float x = d[j];
+    float* o = out + (long)j * (2 * n_enc + 1);
+    float scale = 1.f;
+    for (int k = 0; k < n_enc; ++k) {
+        float v = x / scale;            // torch: x / 2**k
+        o[k] = sinf(v);
+        o[n_enc + k] = cosf(v);
+        scale *= 2.f;
+    }
+    o[2 * n_enc] = x;
+}
+
+// reference models/net3d.py:117-118: w = sigmoid(m . ws + bs), msg = m * w.  One lane per edge (feat is small).
+__global__ void __launch_bounds__(256)
+soft_edge_fwd_kernel(const float* __restrict__ m, const float* __restrict__ ws, const float* __restrict__ bs, int E,
+                     int feat, float* __restrict__ msg, float* __restrict__ w) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= E) return;
+    const float* p = m + (long)j * feat;
+    float dot = bs[0];
+    for (int f = 0; f < feat; ++f) dot += p[f] * ws[f];
+    float g = 1.f / (1.f + expf(-dot));
+    w[j] = g;
+    float* o = msg + (long)j * feat;
+    for (int f = 0; f < feat; ++f) o[f] = p[f] * g;
+}
+
+__global__ void __launch_bounds__(256)
+soft_edge_bwd_kernel(const float* __restrict__ gmsg, const float* __restrict__ m, const float* __restrict__ w,
+                     const float* __restrict__ ws, int E, int feat, float* __restrict__ gm,
+                     float* __restrict__ ggate) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= E) return;
+    const float* p = m + (long)j * feat;
+    const float* gp = gmsg + (long)j * feat;
+    float g = w[j];
+    float dot = 0.f;
+    for (int f = 0; f < feat; ++f) dot += gp[f] * p[f];
+    float gg = dot * g * (1.f - g);
+    ggate[j] = gg;
+    float* o = gm + (long)j * feat;
+    for (int f = 0; f < feat; ++f) o[f] = gp[f] * g + gg * ws[f];
+}
+
+}  // namespace i3d
+
+using namespace i3d;
+
+#define LAUNCH_V(kernel, items_rows, feat, ...)                                                             \
+    do {                                                                                                    \
+        if ((feat) % 4 == 0) {                                                                              \
+            long items_ = (long)(items_rows) * ((feat) / 4);                                                \
+            hipLaunchKernelGGL(kernel<4>, dim3(cdiv(items_, 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+        } else {                                                                                            \
+            long items_ = (long)(items_rows) * (feat);                                                      \
+            hipLaunchKernelGGL(kernel<1>, dim3(cdiv(items_, 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+        }                                                                                                   \
+    } while (0)
+
+extern "C" int i3d_edge_combine_fwd(const float* P, int ldp, const float* Q, const float* bias, const int* src_s,
+                                    const int* dst_s, int num_edges, int feat, float* pre, void* stream) {
+    I3D_CHECK_ARG(num_edges >= 0 && feat > 0 && ldp >= 2 * feat, "bad shape");
+    if (num_edges == 0) return I3D_OK;
+    if (feat % 4 == 0 && ldp % 4 == 0) {
+        long items = (long)num_edges * (feat / 4);
+        hipLaunchKernelGGL(edge_combine_fwd_kernel<4>, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, P, ldp, Q,
+                           bias, src_s, dst_s, num_edges, feat, pre);
+    } else {
+        long items = (long)num_edges * feat;
+        hipLaunchKernelGGL(edge_combine_fwd_kernel<1>, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, P, ldp, Q,
+                           bias, src_s, dst_s, num_edges, feat, pre);
+    }
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_segment_sum(const float* x, int ldx, const int* ptr, const int* idx, int num_segments, int feat,
+                               int scale_mode, float* out, int ldo, void* stream) {
+    I3D_CHECK_ARG(num_segments >= 0 && feat > 0 && ldx >= feat && ldo >= feat, "bad shape");
+    if (num_segments == 0) return I3D_OK;
+    if (feat % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+        long items = (long)num_segments * (feat / 4);
+        hipLaunchKernelGGL(segment_sum_kernel<4>, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, ptr,
+                           idx, num_segments, feat, scale_mode, out, ldo);
+    } else {
+        long items = (long)num_segments * feat;
+        hipLaunchKernelGGL(segment_sum_kernel<1>, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, ptr,
+                           idx, num_segments, feat, scale_mode, out, ldo);
+    }
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_segment_bcast(const float* g, const int* ptr, const int* seg_of_row, int rows, int feat,
+                                 int scale_mode, float* out, void* stream) {
+    I3D_CHECK_ARG(rows >= 0 && feat > 0, "bad shape");
+    if (rows == 0) return I3D_OK;
+    LAUNCH_V(segment_bcast_kernel, rows, feat, g, ptr, seg_of_row, rows, feat, scale_mode, out);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_gather_rows(const float* x, const int* idx, int rows, int feat, float* out, void* stream) {
+    I3D_CHECK_ARG(rows >= 0 && feat > 0, "bad shape");
+    if (rows == 0) return I3D_OK;
+    LAUNCH_V(gather_rows_kernel, rows, feat, x, idx, rows, feat, out);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_fourier_encode(const float* d, int num_edges, int n_enc, float* out, void* stream) {
+    I3D_CHECK_ARG(num_edges >= 0 && n_enc >= 1 && n_enc <= 16, "bad shape");
+    if (num_edges == 0) return I3D_OK;
+    hipLaunchKernelGGL(fourier_encode_kernel, dim3(cdiv(num_edges, 256)), dim3(256), 0, (hipStream_t)stream, d, num_edges,
+                       n_enc, out);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_soft_edge_fwd(const float* m, const float* ws, const float* bs, int num_edges, int feat, float* msg,
+                                 float* w, void* stream) {
+    I3D_CHECK_ARG(num_edges >= 0 && feat > 0, "bad shape");
+    if (num_edges == 0) return I3D_OK;
+    hipLaunchKernelGGL(soft_edge_fwd_kernel, dim3(cdiv(num_edges, 256)), dim3(256), 0, (hipStream_t)stream, m, ws, bs,
+                       num_edges, feat, msg, w);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_soft_edge_bwd(const float* grad_msg, const float* m, const float* w, const float* ws, int num_edges,
+                                 int feat, float* grad_m, float* g_gate, void* stream) {
+    I3D_CHECK_ARG(num_edges >= 0 && feat > 0, "bad shape");
+    if (num_edges == 0) return I3D_OK;
+    hipLaunchKernelGGL(soft_edge_bwd_kernel, dim3(cdiv(num_edges, 256)), dim3(256), 0, (hipStream_t)stream, grad_msg, m, w,
+                       ws, num_edges, feat, grad_m, g_gate);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}

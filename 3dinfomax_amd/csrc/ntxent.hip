@@ -1,0 +1,195 @@
+// NT-Xent contrastive loss (single positive and multiple-positives variants), forward and backward.
+//
+// Replaces NTXent.forward (reference commons/losses.py:143-155) and NTXentMultiplePositives.forward
+// (reference commons/losses.py:225-247):
+//     S = z1 z2^T;  S' = S / (|z1_i||z2_j| + eps);  P = exp(S'/tau);  (multi: P summed over conformers)
+//     loss = - mean_i log( pos_i / (rowsum_i - pos_i) )
+// The similarity GEMM runs on the MFMA GEMM (i3d_gemm_f32); these kernels fuse normalisation, exp, the row
+// reductions and the log, and produce dL/dS plus the rank-1 norm-path terms for the backward GEMMs.
+// Row-sharded for data parallelism: z1 are the LOCAL rows, z2 the all-gathered batch, pos_offset = rank*b1.
+#include "common.h"
+
+namespace i3d {
+
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+    // 256 threads = 4 waves
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ void __launch_bounds__(256)
+row_norms_kernel(const float* __restrict__ z, int rows, int dim, float* __restrict__ norms) {
+    __shared__ float sm[4];
+    int r = blockIdx.x;
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < dim; c += 256) {
+        float v = z[(long)r * dim + c];
+        acc += v * v;
+    }
+    float s = block_sum(acc, sm);
+    if (threadIdx.x == 0) norms[r] = sqrtf(s);
+}
+
+__global__ void __launch_bounds__(256)
+ntxent_fwd_kernel(const float* __restrict__ sim, const float* __restrict__ n1, const float* __restrict__ n2, int b1,
+                  int ncol, int conf, int pos_offset, float inv_tau, float eps, float* __restrict__ row_sum,
+                  float* __restrict__ row_pos) {
+    __shared__ float sm[4];
+    int i = blockIdx.x;
+    float a = n1[i];
+    int p0 = (pos_offset + i) * conf, p1 = p0 + conf;
+    float rs = 0.f, ps = 0.f;
+    for (int j = threadIdx.x; j < ncol; j += 256) {
+        float s = sim[(long)i * ncol + j] / (a * n2[j] + eps);
+        float p = expf(s * inv_tau);
+        rs += p;
+        if (j >= p0 && j < p1) ps += p;
+    }
+    rs = block_sum(rs, sm);
+    ps = block_sum(ps, sm);
+    if (threadIdx.x == 0) {
+        row_sum[i] = rs;
+        row_pos[i] = ps;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+ntxent_loss_kernel(const float* __restrict__ row_sum, const float* __restrict__ row_pos, int b1,
+                   float* __restrict__ loss_sum) {
+    __shared__ float sm[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < b1; i += 256) acc += -logf(row_pos[i] / (row_sum[i] - row_pos[i]));
+    float s = block_sum(acc, sm);
+    if (threadIdx.x == 0) loss_sum[0] = s;
+}
+
+// dL/dP_ij = gs * ( j positive ? -1/pos_i : 1/(rowsum_i - pos_i) ),  G = dL/dP * P / tau,  H = G / (a_i b_j + eps)
+__global__ void __launch_bounds__(256)
+ntxent_bwd_row_kernel(const float* __restrict__ sim, const float* __restrict__ n1, const float* __restrict__ n2,
+                      const float* __restrict__ row_sum, const float* __restrict__ row_pos, int b1, int ncol, int conf,
+                      int pos_offset, float inv_tau, float eps, float gs, float* __restrict__ dsim,
+                      float* __restrict__ ca) {
+    __shared__ float sm[4];
+    int i = blockIdx.x;
+    float a = n1[i];
+    int p0 = (pos_offset + i) * conf, p1 = p0 + conf;
+    float pos = row_pos[i], den = row_sum[i] - pos;
+    float g_neg = gs / den, g_pos = -gs / pos;
+    float da = 0.f;
+    for (int j = threadIdx.x; j < ncol; j += 256) {
+        float b = n2[j];
+        float nrm = a * b + eps;
+        float s = sim[(long)i * ncol + j] / nrm;
+        float p = expf(s * inv_tau);
+        float G = ((j >= p0 && j < p1) ? g_pos : g_neg) * p * inv_tau;
+        float H = G / nrm;
+        dsim[(long)i * ncol + j] = H;
+        da -= H * s * b;
+    }
+    da = block_sum(da, sm);
+    if (threadIdx.x == 0) ca[i] = a > 0.f ? da / a : 0.f;
+}
+
+// cb_j = -(1/b_j) sum_i H_ij * S'_ij * a_i ;  64 columns per block, 4 row lanes
+__global__ void __launch_bounds__(256)
+ntxent_bwd_col_kernel(const float* __restrict__ sim, const float* __restrict__ dsim, const float* __restrict__ n1,
+                      const float* __restrict__ n2, int b1, int ncol, float eps, float* __restrict__ cb) {
+    __shared__ float sm[4][64];
+    int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    int j = blockIdx.x * 64 + cx;
+    float acc = 0.f;
+    if (j < ncol) {
+        float b = n2[j];
+        for (int i = ry; i < b1; i += 4) {
+            float a = n1[i];
+            float s = sim[(long)i * ncol + j] / (a * b + eps);
+            acc -= dsim[(long)i * ncol + j] * s * a;
+        }
+    }
+    sm[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && j < ncol) {
+        float b = n2[j];
+        float t = sm[0][cx] + sm[1][cx] + sm[2][cx] + sm[3][cx];
+        cb[j] = b > 0.f ? t / b : 0.f;
+    }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256)
+row_axpy_kernel(const float* __restrict__ z, const float* __restrict__ coef, int rows, int dim, float* __restrict__ out) {
+    const int DV = dim / V;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)rows * DV) return;
+    int r = (int)(t / DV);
+    float c = coef[r];
+    long off = t * V;
+    if (V == 4) {
+        float4 a = *reinterpret_cast<const float4*>(z + off);
+        float4 o = *reinterpret_cast<const float4*>(out + off);
+        o.x += c * a.x; o.y += c * a.y; o.z += c * a.z; o.w += c * a.w;
+        *reinterpret_cast<float4*>(out + off) = o;
+    } else {
+        out[off] += c * z[off];
+    }
+}
+
+}  // namespace i3d
+
+using namespace i3d;
+
+extern "C" int i3d_row_norms(const float* z, int rows, int dim, float* norms, void* stream) {
+    I3D_CHECK_ARG(rows >= 0 && dim > 0, "bad shape");
+    if (rows == 0) return I3D_OK;
+    hipLaunchKernelGGL(row_norms_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, z, rows, dim, norms);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_ntxent_fwd(const float* sim, const float* n1, const float* n2, int b1, int b2, int conf,
+                              int pos_offset, float tau, float eps, float* row_sum, float* row_pos, float* loss_sum,
+                              void* stream) {
+    I3D_CHECK_ARG(b1 > 0 && b2 > 0 && conf > 0 && tau > 0.f, "bad shape");
+    I3D_CHECK_ARG(pos_offset >= 0 && pos_offset + b1 <= b2, "positive columns out of range");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ntxent_fwd_kernel, dim3(b1), dim3(256), 0, s, sim, n1, n2, b1, b2 * conf, conf, pos_offset,
+                       1.f / tau, eps, row_sum, row_pos);
+    I3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ntxent_loss_kernel, dim3(1), dim3(256), 0, s, row_sum, row_pos, b1, loss_sum);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_ntxent_bwd(const float* sim, const float* n1, const float* n2, const float* row_sum,
+                              const float* row_pos, int b1, int b2, int conf, int pos_offset, float tau, float eps,
+                              float grad_scale, float* dsim, float* ca, float* cb, void* stream) {
+    I3D_CHECK_ARG(b1 > 0 && b2 > 0 && conf > 0 && tau > 0.f, "bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    int ncol = b2 * conf;
+    hipLaunchKernelGGL(ntxent_bwd_row_kernel, dim3(b1), dim3(256), 0, s, sim, n1, n2, row_sum, row_pos, b1, ncol, conf,
+                       pos_offset, 1.f / tau, eps, grad_scale, dsim, ca);
+    I3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ntxent_bwd_col_kernel, dim3(cdiv(ncol, 64)), dim3(256), 0, s, sim, dsim, n1, n2, b1, ncol, eps, cb);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_row_axpy(const float* z, const float* coef, int rows, int dim, float* out, void* stream) {
+    I3D_CHECK_ARG(rows >= 0 && dim > 0, "bad shape");
+    if (rows == 0) return I3D_OK;
+    if (dim % 4 == 0) {
+        long items = (long)rows * dim / 4;
+        hipLaunchKernelGGL(row_axpy_kernel<4>, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, z, coef, rows, dim,
+                           out);
+    } else {
+        long items = (long)rows * dim;
+        hipLaunchKernelGGL(row_axpy_kernel<1>, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, z, coef, rows, dim,
+                           out);
+    }
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}

@@ -32,13 +32,14 @@ class GraphIndex:
     out_ptr: torch.Tensor     # [N+1] CSR row pointer by source
     out_epos: torch.Tensor    # [E]   epos of the out-edges of each node, grouped by source
     graph_ptr: torch.Tensor   # [B+1] node offsets of the graphs in the batch
+    inv_perm: torch.Tensor    # [E]   edge id -> epos
     max_in_degree: int
 
     def to(self, device):
         return GraphIndex(self.num_nodes, self.num_edges, self.num_graphs,
                           *[t.to(device, non_blocking=True) for t in
                             (self.in_ptr, self.perm, self.src_s, self.dst_s, self.out_ptr,
-                             self.out_epos, self.graph_ptr)], self.max_in_degree)
+                             self.out_epos, self.graph_ptr, self.inv_perm)], self.max_in_degree)
 
 
 def build_index(src, dst, num_nodes, batch_num_nodes) -> GraphIndex:
@@ -57,9 +58,11 @@ def build_index(src, dst, num_nodes, batch_num_nodes) -> GraphIndex:
     np.cumsum(np.bincount(src, minlength=num_nodes), out=out_ptr[1:])
     graph_ptr = np.zeros(bnn.shape[0] + 1, dtype=np.int64)
     np.cumsum(bnn, out=graph_ptr[1:])
+    inv_perm = np.empty(E, dtype=np.int64)
+    inv_perm[perm] = np.arange(E)
     i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.int32)))
     return GraphIndex(int(num_nodes), int(E), int(bnn.shape[0]), i32(in_ptr), i32(perm), i32(src_s),
-                      i32(dst_s), i32(out_ptr), i32(out_epos), i32(graph_ptr),
+                      i32(dst_s), i32(out_ptr), i32(out_epos), i32(graph_ptr), i32(inv_perm),
                       int(indeg.max()) if E else 0)
 
 
@@ -112,6 +115,12 @@ class BatchedMolGraph:
                             {k: v.to(device) for k, v in self.edata.items()},
                             self.index().to(device))
         return g
+
+    def local_copy(self):
+        """Same structure and tensors, fresh frames: the forward pass overwrites ndata/edata['feat'] (reference
+        models/pna.py:162-163), so a resident batch that is stepped on repeatedly is forwarded through a copy."""
+        return BatchedMolGraph(self._src, self._dst, self._n, self._bnn, dict(self.ndata), dict(self.edata),
+                               self._index)
 
     # ---- kernel index -----------------------------------------------------------------
     def index(self) -> GraphIndex:

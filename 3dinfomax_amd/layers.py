@@ -1,0 +1,370 @@
+"""FCLayer / MLP towers and the autograd.Functions that chain the HIP kernels.
+
+Mirror of reference models/base_layers.py (FCLayer :23-111, MLP :114-147): same constructor kwargs, same
+sub-module names (`linear`, `batch_norm`, `fully_connected`) hence the same state_dict keys, same init
+(xavier_uniform with gain 1/in_dim, zero bias), same op order Linear -> activation -> dropout -> BatchNorm.
+nn.Linear / nn.BatchNorm1d are used as PARAMETER CONTAINERS only - their forward is never called; all
+arithmetic runs in the gfx950 kernels through ops.py, forward and hand-written backward.
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+SUPPORTED_ACTIVATIONS = {'relu', 'silu', 'sigmoid', 'none'}
+
+
+def act_name(activation):
+    """reference models/base_layers.py:9-20 (get_activation): case-insensitive name or None."""
+    if activation is None:
+        return None
+    if callable(activation) and not isinstance(activation, str):
+        activation = type(activation).__name__
+    a = activation.lower()
+    if a not in SUPPORTED_ACTIVATIONS:
+        raise NotImplementedError(f'activation {activation!r} has no HIP kernel yet (supported: ReLU, SiLU, Sigmoid, None)')
+    return None if a == 'none' else a
+
+
+@dataclass
+class BNSpec:
+    """Everything the fused (activation +) BatchNorm needs besides the affine parameters."""
+    running_mean: Optional[torch.Tensor]
+    running_var: Optional[torch.Tensor]
+    num_batches_tracked: Optional[torch.Tensor]
+    momentum: float
+    eps: float
+    training: bool
+    sync_group: object = None        # torch.distributed process group for synchronised statistics (or None)
+
+
+@dataclass
+class FCSpec:
+    act: Optional[str]               # activation between Linear and BatchNorm
+    bn: Optional[BNSpec]
+    post_act: Optional[str] = None   # activation after the BatchNorm (Net3D edge_input: silu(BN(silu(.))))
+
+
+def _sync_world(group):
+    import torch.distributed as dist
+    return dist.get_world_size(group)
+
+
+class _Tail:
+    """activation + BatchNorm part of an FCLayer, shared by the three FC autograd.Functions.
+
+    forward(pre)  -> y, saved tuple         backward(saved, grad_y) -> grad_pre, grad_gamma, grad_beta"""
+
+    @staticmethod
+    def forward(pre, gamma, beta, spec: FCSpec, residual=None):
+        bn = spec.bn
+        if bn is None:
+            acts = [a for a in (spec.act, spec.post_act) if a is not None]
+            inputs, y = [], pre
+            for a in acts:
+                inputs.append(y)
+                y = ops.act_fwd(y, a)
+            if residual is not None:
+                y = ops.add_inplace(y.clone() if y is pre else y, residual)
+            return y, (inputs, acts)
+        keep_pre = spec.act not in (None, 'relu')       # silu'/sigmoid' need the pre-activation
+        if bn.training:
+            if bn.sync_group is not None:
+                import torch.distributed as dist
+                sums = torch.empty(2 * pre.shape[1] + 1, dtype=torch.float64, device=pre.device)
+                x, _, _ = ops.act_stats_fwd(pre, spec.act, bn.eps, bn.momentum, sums_out=sums,
+                                            out=torch.empty_like(pre) if keep_pre else None)
+                dist.all_reduce(sums, group=bn.sync_group)
+                mean, invstd = ops.bn_finalize_stats(sums, pre.shape[1], bn.eps, bn.momentum, bn.running_mean,
+                                                     bn.running_var)
+            else:
+                x, mean, invstd = ops.act_stats_fwd(pre, spec.act, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                                                    out=torch.empty_like(pre) if keep_pre else None)
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            y = ops.bn_apply_fwd(x, mean, invstd, gamma, beta, spec.post_act, residual)
+            return y, (x, pre if keep_pre else None, mean, invstd)
+        x = ops.act_fwd(pre, spec.act) if spec.act is not None else pre
+        y = ops.bn_eval_fwd(x, bn.running_mean, bn.running_var, bn.eps, gamma, beta, spec.post_act, residual)
+        return y, (x, pre if keep_pre else None, bn.running_mean.clone(), bn.running_var.clone())
+
+    @staticmethod
+    def backward(saved, grad_y, gamma, beta, spec: FCSpec):
+        bn = spec.bn
+        if bn is None:
+            inputs, acts = saved
+            grad_pre = grad_y
+            for x_in, a in zip(reversed(inputs), reversed(acts)):
+                grad_pre = ops.act_bwd(grad_pre, x_in, a)
+            return grad_pre, None, None
+        x, pre, mean, stat2 = saved
+        if bn.training:
+            if bn.sync_group is not None:
+                import torch.distributed as dist
+                feat = x.shape[1]
+                sums = torch.empty(2 * feat + 1, dtype=torch.float64, device=x.device)
+                gg = torch.empty(feat, dtype=torch.float32, device=x.device)
+                gb = torch.empty(feat, dtype=torch.float32, device=x.device)
+                ops.bn_bwd(grad_y, x, pre, spec.act, spec.post_act, mean, stat2, gamma, beta, sums_out=sums,
+                           grad_gamma=gg, grad_beta=gb, out=grad_y)
+                sums[2 * feat:].fill_(x.shape[0])          # local row count rides along in the all-reduce
+                dist.all_reduce(sums, group=bn.sync_group)
+                grad_pre, _, _ = ops.bn_bwd(grad_y, x, pre, spec.act, spec.post_act, mean, stat2, gamma, beta,
+                                            sums_in=sums, grad_gamma=gg, grad_beta=gb)
+                return grad_pre, gg, gb
+            return ops.bn_bwd(grad_y, x, pre, spec.act, spec.post_act, mean, stat2, gamma, beta)
+        return ops.bn_eval_bwd(grad_y, x, pre, spec.act, spec.post_act, mean, stat2, bn.eps, gamma, beta)
+
+
+class FCFn(torch.autograd.Function):
+    """y = post_act(BN(act(x W^T + b))) (+ residual).  reference models/base_layers.py:100-111."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, gamma, beta, residual, spec: FCSpec):
+        x = x.contiguous()
+        pre = ops.gemm(x, W, trans_b=True, bias=b)
+        y, saved = _Tail.forward(pre, gamma, beta, spec, residual)
+        ctx.spec = spec
+        ctx.saved = saved
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, W, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, W, gamma, beta = ctx.saved_tensors
+        grad_y = grad_y.contiguous()
+        grad_res = grad_y if ctx.has_res else None
+        grad_pre, gg, gb = _Tail.backward(ctx.saved, grad_y, gamma, beta, ctx.spec)
+        gW = ops.gemm(grad_pre, x, trans_a=True) if ctx.needs_input_grad[1] else None
+        gbias = ops.colsum(grad_pre) if ctx.needs_input_grad[2] else None
+        gx = ops.gemm(grad_pre, W) if ctx.needs_input_grad[0] else None
+        return gx, gW, gbias, gg, gb, grad_res, None
+
+
+class Concat2FCFn(torch.autograd.Function):
+    """FC layer on the column concatenation [a | c] without materialising it:
+    pre = a W[:, :Fa]^T + c W[:, Fa:]^T + b   (reference models/pna.py:207-209: cat([h, agg]) -> posttrans)."""
+
+    @staticmethod
+    def forward(ctx, a, c, W, b, gamma, beta, residual, spec: FCSpec):
+        Fa = a.shape[1]
+        pre = ops.gemm(a, W[:, :Fa], trans_b=True, bias=b)
+        ops.gemm(c, W[:, Fa:], trans_b=True, out=pre, accumulate=True)
+        y, saved = _Tail.forward(pre, gamma, beta, spec, residual)
+        ctx.spec, ctx.saved, ctx.has_res = spec, saved, residual is not None
+        ctx.save_for_backward(a, c, W, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        a, c, W, gamma, beta = ctx.saved_tensors
+        Fa = a.shape[1]
+        grad_y = grad_y.contiguous()
+        grad_res = grad_y if ctx.has_res else None
+        grad_pre, gg, gb = _Tail.backward(ctx.saved, grad_y, gamma, beta, ctx.spec)
+        gW = torch.empty_like(W)
+        ops.gemm(grad_pre, a, trans_a=True, out=gW[:, :Fa])
+        ops.gemm(grad_pre, c, trans_a=True, out=gW[:, Fa:])
+        gbias = ops.colsum(grad_pre)
+        ga = ops.gemm(grad_pre, W[:, :Fa])
+        gc = ops.gemm(grad_pre, W[:, Fa:])
+        return ga, gc, gW, gbias, gg, gb, grad_res, None
+
+
+class EdgeFCFn(torch.autograd.Function):
+    """First FC layer of an edge MLP on [h_src | h_dst | q] (q optional) without the gather/concat:
+        P = h [W_s | W_d]^T  (node level),  Q = q W_q^T,  pre[j] = P[src_j, :F] + P[dst_j, F:] + Q[j] + b
+    reference models/pna.py:237-252 (pretrans_edges), models/net3d.py:113-115 (message_function).
+    Edge tensors are in destination-sorted order; backward of the gathers = segmented sums (no atomics)."""
+
+    @staticmethod
+    def forward(ctx, h, q, W, b, gamma, beta, index, spec: FCSpec):
+        h = h.contiguous()
+        Fh = h.shape[1]
+        Fo = W.shape[0]
+        N = h.shape[0]
+        P = torch.empty(N, 2 * Fo, dtype=torch.float32, device=h.device)
+        ops.gemm(h, W[:, :Fh], trans_b=True, out=P[:, :Fo])
+        ops.gemm(h, W[:, Fh:2 * Fh], trans_b=True, out=P[:, Fo:])
+        Q = None
+        if q is not None:
+            q = q.contiguous()
+            Q = ops.gemm(q, W[:, 2 * Fh:], trans_b=True)
+        pre = ops.edge_combine_fwd(P, Q, b, index.src_s, index.dst_s)
+        y, saved = _Tail.forward(pre, gamma, beta, spec)
+        ctx.spec, ctx.saved, ctx.index, ctx.has_q = spec, saved, index, q is not None
+        ctx.save_for_backward(h, q if q is not None else h, W, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        h, q, W, gamma, beta = ctx.saved_tensors
+        idx = ctx.index
+        Fh, Fo, N = h.shape[1], W.shape[0], h.shape[0]
+        grad_pre, gg, gb = _Tail.backward(ctx.saved, grad_y.contiguous(), gamma, beta, ctx.spec)
+        gW = torch.empty_like(W)
+        gP = torch.empty(N, 2 * Fo, dtype=torch.float32, device=h.device)
+        ops.segment_sum(grad_pre, idx.out_ptr, idx.out_epos, N, out=gP[:, :Fo])     # d P[src]
+        ops.segment_sum(grad_pre, idx.in_ptr, None, N, out=gP[:, Fo:])              # d P[dst]
+        ops.gemm(gP[:, :Fo], h, trans_a=True, out=gW[:, :Fh])
+        ops.gemm(gP[:, Fo:], h, trans_a=True, out=gW[:, Fh:2 * Fh])
+        gh = ops.gemm(gP[:, :Fo], W[:, :Fh])
+        ops.gemm(gP[:, Fo:], W[:, Fh:2 * Fh], out=gh, accumulate=True)
+        gq = None
+        if ctx.has_q:
+            ops.gemm(grad_pre, q, trans_a=True, out=gW[:, 2 * Fh:])
+            if ctx.needs_input_grad[1]:
+                gq = ops.gemm(grad_pre, W[:, 2 * Fh:])
+        gbias = ops.colsum(grad_pre)
+        return gh, gq, gW, gbias, gg, gb, None, None
+
+
+# ------------------------------------------------------------------------------------------------------------
+class FCLayer(nn.Module):
+    """Drop-in for reference models/base_layers.py:23-111."""
+
+    def __init__(self, in_dim, out_dim, activation='relu', dropout=0., batch_norm=False, batch_norm_momentum=0.1,
+                 bias=True, init_fn=None, device='cpu'):
+        super().__init__()
+        if dropout:
+            raise NotImplementedError('dropout > 0 is not on the accelerated path (all BASELINE configs use 0.0)')
+        if not bias:
+            raise NotImplementedError('bias=False is not on the accelerated path')
+        self.in_dim, self.out_dim, self.bias = in_dim, out_dim, bias
+        self.linear = nn.Linear(in_dim, out_dim, bias=bias).to(device)
+        self.dropout = None
+        self.batch_norm = nn.BatchNorm1d(out_dim, momentum=batch_norm_momentum).to(device) if batch_norm else None
+        self.activation = act_name(activation)
+        self.init_fn = nn.init.xavier_uniform_
+        self.sync_group = None
+        self.reset_parameters()
+
+    def reset_parameters(self, init_fn=None):
+        init_fn = init_fn or self.init_fn
+        if init_fn is not None:
+            init_fn(self.linear.weight, 1 / self.in_dim)      # reference :93-98: gain = 1/in_dim
+        if self.bias:
+            self.linear.bias.data.zero_()
+
+    def spec(self, post_act=None) -> FCSpec:
+        bn = None
+        if self.batch_norm is not None:
+            m = self.batch_norm
+            bn = BNSpec(m.running_mean, m.running_var, m.num_batches_tracked, m.momentum, m.eps, self.training,
+                        self.sync_group if self.training else None)
+        return FCSpec(self.activation, bn, post_act)
+
+    def bn_affine(self):
+        if self.batch_norm is None:
+            return None, None
+        return self.batch_norm.weight, self.batch_norm.bias
+
+    def forward(self, x, residual=None, post_act=None):
+        gamma, beta = self.bn_affine()
+        return FCFn.apply(x, self.linear.weight, self.linear.bias, gamma, beta, residual, self.spec(post_act))
+
+
+class MLP(nn.Module):
+    """Drop-in for reference models/base_layers.py:114-147."""
+
+    def __init__(self, in_dim, out_dim, layers, hidden_size=None, mid_activation='relu', last_activation='none',
+                 dropout=0., mid_batch_norm=False, last_batch_norm=False, batch_norm_momentum=0.1, device='cpu'):
+        super().__init__()
+        self.in_dim, self.hidden_size, self.out_dim = in_dim, hidden_size, out_dim
+        self.fully_connected = nn.ModuleList()
+        if layers <= 1:
+            self.fully_connected.append(FCLayer(in_dim, out_dim, activation=last_activation, batch_norm=last_batch_norm,
+                                                device=device, dropout=dropout,
+                                                batch_norm_momentum=batch_norm_momentum))
+        else:
+            self.fully_connected.append(FCLayer(in_dim, hidden_size, activation=mid_activation,
+                                                batch_norm=mid_batch_norm, device=device, dropout=dropout,
+                                                batch_norm_momentum=batch_norm_momentum))
+            for _ in range(layers - 2):
+                self.fully_connected.append(FCLayer(hidden_size, hidden_size, activation=mid_activation,
+                                                    batch_norm=mid_batch_norm, device=device, dropout=dropout,
+                                                    batch_norm_momentum=batch_norm_momentum))
+            self.fully_connected.append(FCLayer(hidden_size, out_dim, activation=last_activation,
+                                                batch_norm=last_batch_norm, device=device, dropout=dropout,
+                                                batch_norm_momentum=batch_norm_momentum))
+
+    def forward(self, x, residual=None, post_act=None):
+        n = len(self.fully_connected)
+        for i, fc in enumerate(self.fully_connected):
+            last = i == n - 1
+            x = fc(x, residual if last else None, post_act if last else None)
+        return x
+
+    # first layer fed by a fused input operator (edge gather / two-segment concat), rest plain
+    def forward_edge(self, h, q, index, residual=None):
+        fc0 = self.fully_connected[0]
+        gamma, beta = fc0.bn_affine()
+        x = EdgeFCFn.apply(h, q, fc0.linear.weight, fc0.linear.bias, gamma, beta, index, fc0.spec())
+        for fc in list(self.fully_connected)[1:]:
+            x = fc(x)
+        return x
+
+    def forward_concat2(self, a, c, residual=None):
+        fcs = list(self.fully_connected)
+        fc0 = fcs[0]
+        gamma, beta = fc0.bn_affine()
+        x = Concat2FCFn.apply(a, c, fc0.linear.weight, fc0.linear.bias, gamma, beta,
+                              residual if len(fcs) == 1 else None, fc0.spec())
+        for i, fc in enumerate(fcs[1:]):
+            x = fc(x, residual if i == len(fcs) - 2 else None)
+        return x
+
+
+# ------------------------------------------------------------------------------------------------------------
+class EmbeddingSumFn(torch.autograd.Function):
+    """sum_k Emb_k[idx[:,k]]  (reference commons/mol_encoder.py:34-42, 65-73)."""
+
+    @staticmethod
+    def forward(ctx, idx, row_perm, *tables):
+        ctx.idx, ctx.row_perm = idx, row_perm
+        ctx.dims = [t.shape[0] for t in tables]
+        return ops.embedding_sum_fwd(idx, [t.contiguous() for t in tables], row_perm)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grads = ops.embedding_sum_bwd(ctx.idx, grad_out.contiguous(), ctx.dims, ctx.row_perm)
+        return (None, None, *grads)
+
+
+class AggregateFn(torch.autograd.Function):
+    """K4: segmented mean/max/min/std x degree scalers (reference models/pna.py:206, 221-235)."""
+
+    @staticmethod
+    def forward(ctx, e, index, aggregators, scalers, avg_d_log):
+        e = e.contiguous()
+        ctx.cfg = (index, aggregators, scalers, avg_d_log)
+        ctx.save_for_backward(e)
+        return ops.pna_aggregate_fwd(e, index.in_ptr, index.num_nodes, aggregators, scalers, avg_d_log)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (e,) = ctx.saved_tensors
+        index, aggregators, scalers, avg = ctx.cfg
+        return ops.pna_aggregate_bwd(grad_out.contiguous(), e, index.in_ptr, index.num_nodes, aggregators, scalers,
+                                     avg), None, None, None, None
+
+
+class ReadoutFn(torch.autograd.Function):
+    """K6: per-graph min/max/mean/sum (reference models/pna.py:133-134)."""
+
+    @staticmethod
+    def forward(ctx, h, index, op_codes):
+        h = h.contiguous()
+        ctx.cfg = (index, op_codes)
+        ctx.save_for_backward(h)
+        return ops.segment_readout_fwd(h, index.graph_ptr, index.num_graphs, op_codes)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (h,) = ctx.saved_tensors
+        index, op_codes = ctx.cfg
+        return ops.segment_readout_bwd(grad_out.contiguous(), h, index.graph_ptr, index.num_graphs, op_codes), None, None

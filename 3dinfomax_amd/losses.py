@@ -1,0 +1,155 @@
+"""NT-Xent losses on the MI355X kernels - drop-in for `NTXent` / `NTXentMultiplePositives` of reference
+commons/losses.py:126-163, 206-258 (same constructor kwargs, `forward(z1, z2, **kwargs) -> 0-dim tensor`).
+
+Data parallel (absent in the reference, required by BASELINE.json:north_star): when a process group is
+attached (`loss.attach_group(group)` or 3dinfomax_amd.dist.setup), z2 - the 3D-view embeddings - is
+all-gathered over RCCL so each local 2D row sees the FULL negative set; the backward of the gather is a
+reduce-scatter of dz2.  The returned value is this rank's share  sum_local(l_i) / B_global; the shares sum to
+the reference's loss (dist.global_loss all-reduces it for logging).
+"""
+import torch
+from torch import Tensor
+from torch.nn.modules.loss import _Loss
+
+from . import ops
+
+
+class _AllGatherRowsFn(torch.autograd.Function):
+    """all_gather along dim 0 (equal shard sizes); backward = reduce_scatter(sum) of the gathered gradient."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        import torch.distributed as dist
+        ctx.group = group
+        world = dist.get_world_size(group)
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as dist
+        world = dist.get_world_size(ctx.group)
+        out = torch.empty((g.shape[0] // world,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        dist.reduce_scatter_tensor(out, g.contiguous(), op=dist.ReduceOp.SUM, group=ctx.group)
+        return out, None
+
+
+class NTXentFn(torch.autograd.Function):
+    """loss_share = sum_i -log(pos_i / (rowsum_i - pos_i)) / global_batch  over the local rows of z1."""
+
+    @staticmethod
+    def forward(ctx, z1, z2, tau, eps, conf, pos_offset, global_batch):
+        z1, z2 = z1.contiguous(), z2.contiguous()
+        b1, b2 = z1.shape[0], z2.shape[0] // conf
+        n1, n2 = ops.row_norms(z1), ops.row_norms(z2)
+        sim = ops.gemm(z1, z2, trans_b=True)                      # [b1, b2*conf] on the MFMA GEMM
+        row_sum, row_pos, loss_sum = ops.ntxent_fwd(sim, n1, n2, b1, b2, conf, pos_offset, tau, eps)
+        ctx.cfg = (tau, eps, conf, pos_offset, global_batch, b1, b2)
+        ctx.save_for_backward(z1, z2, n1, n2, sim, row_sum, row_pos)
+        return (loss_sum / global_batch).reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        z1, z2, n1, n2, sim, row_sum, row_pos = ctx.saved_tensors
+        tau, eps, conf, pos_offset, global_batch, b1, b2 = ctx.cfg
+        dsim, ca, cb = ops.ntxent_bwd(sim, n1, n2, row_sum, row_pos, b1, b2, conf, pos_offset, tau, eps,
+                                      1.0 / global_batch)
+        dz1 = ops.gemm(dsim, z2)                                  # dS z2
+        ops.row_axpy(z1, ca, dz1)
+        dz2 = ops.gemm(dsim, z1, trans_a=True)                    # dS^T z1
+        ops.row_axpy(z2, cb, dz2)
+        # upstream scalar stays on the device (no host sync)
+        return dz1 * grad_out, dz2 * grad_out, None, None, None, None, None
+
+
+def uniformity_loss(x1: Tensor, x2: Tensor, t=2) -> Tensor:
+    """reference commons/losses.py:946-951 (regulariser, off in every BASELINE config; plain torch)."""
+    u1 = torch.pdist(x1, p=2).pow(2).mul(-t).exp().mean().log()
+    u2 = torch.pdist(x2, p=2).pow(2).mul(-t).exp().mean().log()
+    return (u1 + u2) / 2
+
+
+def cov_loss(x):
+    """reference commons/losses.py:954-959."""
+    batch_size, metric_dim = x.size()
+    x = x - x.mean(dim=0)
+    cov = (x.T @ x) / (batch_size - 1)
+    off_diag_cov = cov.flatten()[:-1].view(metric_dim - 1, metric_dim + 1)[:, 1:].flatten()
+    return off_diag_cov.pow(2).sum() / metric_dim
+
+
+def std_loss(x):
+    """reference commons/losses.py:962-964."""
+    std = torch.sqrt(x.var(dim=0) + 1e-04)
+    return torch.mean(torch.relu(1 - std))
+
+
+class _NTXentBase(_Loss):
+    _eps = 1e-8
+
+    def __init__(self, norm: bool = True, tau: float = 0.5, uniformity_reg=0, variance_reg=0, covariance_reg=0):
+        super().__init__()
+        if not norm:
+            raise NotImplementedError('norm=False is not on the accelerated path (every reference config uses norm=True)')
+        self.norm, self.tau = norm, tau
+        self.uniformity_reg, self.variance_reg, self.covariance_reg = uniformity_reg, variance_reg, covariance_reg
+        self.group = None
+
+    def attach_group(self, group):
+        """Enable the data-parallel form (all-gathered negatives) on a torch.distributed process group."""
+        self.group = group
+        return self
+
+    def _contrastive(self, z1, z2, conf):
+        pos_offset, global_batch = 0, z1.shape[0]
+        if self.group is not None:
+            import torch.distributed as dist
+            world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+            if world > 1:
+                z2 = _AllGatherRowsFn.apply(z2, self.group)
+                pos_offset, global_batch = rank * z1.shape[0], world * z1.shape[0]
+        return NTXentFn.apply(z1, z2, float(self.tau), float(self._eps), conf, pos_offset, global_batch)
+
+    def _regularisers(self, loss, z1, z2):
+        if self.variance_reg > 0:
+            loss = loss + self.variance_reg * (std_loss(z1) + std_loss(z2))
+        if self.covariance_reg > 0:
+            loss = loss + self.covariance_reg * (cov_loss(z1) + cov_loss(z2))
+        if self.uniformity_reg > 0:
+            loss = loss + self.uniformity_reg * uniformity_loss(z1, z2)
+        return loss
+
+
+class NTXent(_NTXentBase):
+    """Normalized Temperature-scaled Cross Entropy Loss (reference commons/losses.py:126-163)."""
+    _eps = 1e-8        # reference :150
+
+    def forward(self, z1, z2, **kwargs) -> Tensor:
+        return self._regularisers(self._contrastive(z1, z2, 1), z1, z2)
+
+
+class NTXentMultiplePositives(_NTXentBase):
+    """reference commons/losses.py:206-258; z2 is [batch*num_conformers, dim], conformer-minor; no epsilon (:239)."""
+    _eps = 0.0
+
+    def __init__(self, norm: bool = True, tau: float = 0.5, uniformity_reg=0, variance_reg=0, covariance_reg=0,
+                 conformer_variance_reg=0) -> None:
+        super().__init__(norm, tau, uniformity_reg, variance_reg, covariance_reg)
+        self.conformer_variance_reg = conformer_variance_reg
+
+    def forward(self, z1, z2, **kwargs) -> Tensor:
+        batch_size, metric_dim = z1.size()
+        conf = z2.shape[0] // batch_size
+        loss = self._contrastive(z1, z2, conf)
+        z2v = z2.view(batch_size, -1, metric_dim)
+        if self.variance_reg > 0:
+            loss = loss + self.variance_reg * (std_loss(z1) + std_loss(z2v))
+        if self.conformer_variance_reg > 0:
+            std = torch.sqrt(z2v.var(dim=1) + 1e-04)
+            loss = loss + self.conformer_variance_reg * torch.mean(torch.relu(1 - std))
+        if self.covariance_reg > 0:
+            loss = loss + self.covariance_reg * (cov_loss(z1) + cov_loss(z2v))
+        if self.uniformity_reg > 0:
+            loss = loss + self.uniformity_reg * uniformity_loss(z1, z2v)
+        return loss

@@ -1,0 +1,352 @@
+"""Tensor-level wrappers over the C ABI (include/infomax3d_hip.h).
+
+torch is plumbing here: it owns device memory (caching allocator) and the current HIP stream; every
+computation below is one of the hand-written gfx950 kernels in csrc/.  No autograd in this file - the
+autograd.Functions in layers.py / pna.py / net3d.py / losses.py chain these calls explicitly.
+"""
+import threading
+from ctypes import c_void_p
+
+import torch
+
+from . import _lib
+from ._lib import ACT, AGG, SCALER, check, int_array, ptr_array
+
+_tls = threading.local()
+KERNEL_TIMERS = None      # set to a dict by bench.py to collect (start, end) HIP events of the roofline kernel
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _chk(t, dtype=torch.float32):
+    assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    return t
+
+
+def _workspace(feat, device):
+    """Thread-local scratch for the two-stage column reductions (stream-ordered reuse)."""
+    need = _lib.load().i3d_colreduce_workspace_bytes(0, feat)
+    key = (device.index,)
+    ws = getattr(_tls, 'ws', None)
+    if ws is None:
+        ws = _tls.ws = {}
+    buf = ws.get(key)
+    if buf is None or buf.numel() < need:
+        buf = ws[key] = torch.empty(max(need, 1 << 22), dtype=torch.uint8, device=device)
+    return buf
+
+
+def agg_codes(names):
+    return [AGG[n] for n in names]
+
+
+def scaler_codes(names):
+    return [SCALER[n] for n in names]
+
+
+# ---- K1 --------------------------------------------------------------------------------------------------
+def embedding_sum_fwd(idx, tables, row_perm=None):
+    _chk(idx, torch.int64)
+    rows, n_cols = idx.shape
+    feat = tables[0].shape[1]
+    out = torch.empty(rows, feat, dtype=torch.float32, device=idx.device)
+    L = _lib.load()
+    check(L.i3d_embedding_sum_fwd(_p(idx), _p(row_perm), rows, n_cols, ptr_array([_chk(t).data_ptr() for t in tables]), feat,
+                                  _p(out), _stream()), 'i3d_embedding_sum_fwd')
+    return out
+
+
+def embedding_sum_bwd(idx, grad_out, dims, row_perm=None):
+    _chk(idx, torch.int64)
+    _chk(grad_out)
+    rows, n_cols = idx.shape
+    feat = grad_out.shape[1]
+    grads = [torch.zeros(d, feat, dtype=torch.float32, device=idx.device) for d in dims]
+    L = _lib.load()
+    check(L.i3d_embedding_sum_bwd(_p(idx), _p(row_perm), rows, n_cols, _p(grad_out), feat, ptr_array([g.data_ptr() for g in grads]),
+                                  int_array(list(dims)), _stream()), 'i3d_embedding_sum_bwd')
+    return grads
+
+
+# ---- K4 / K6 ---------------------------------------------------------------------------------------------
+def pna_aggregate_fwd(e, in_ptr, num_nodes, aggregators, scalers, avg_d_log=1.0):
+    _chk(e)
+    _chk(in_ptr, torch.int32)
+    feat = e.shape[1]
+    n_sc = len(scalers) if len(scalers) > 1 else 1
+    out = torch.empty(num_nodes, n_sc * len(aggregators) * feat, dtype=torch.float32, device=e.device)
+    L = _lib.load()
+    timed = KERNEL_TIMERS is not None
+    if timed:   # bench.py: HIP events on the launch stream around the roofline kernel
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+    check(L.i3d_pna_aggregate_fwd(_p(e), _p(in_ptr), num_nodes, feat, int_array(aggregators), len(aggregators),
+                                  int_array(scalers), len(scalers), float(avg_d_log), _p(out), _stream()),
+          'i3d_pna_aggregate_fwd')
+    if timed:
+        t1.record()
+        KERNEL_TIMERS.setdefault('pna_aggregate_fwd', []).append((t0, t1, num_nodes, e.shape[0], feat, out.shape[1]))
+    return out
+
+
+def pna_aggregate_bwd(grad_out, e, in_ptr, num_nodes, aggregators, scalers, avg_d_log=1.0):
+    _chk(grad_out)
+    _chk(e)
+    grad_e = torch.empty_like(e)
+    L = _lib.load()
+    check(L.i3d_pna_aggregate_bwd(_p(grad_out), _p(e), _p(in_ptr), num_nodes, e.shape[1], int_array(aggregators),
+                                  len(aggregators), int_array(scalers), len(scalers), float(avg_d_log), _p(grad_e),
+                                  _stream()), 'i3d_pna_aggregate_bwd')
+    return grad_e
+
+
+def segment_readout_fwd(x, graph_ptr, num_graphs, ops):
+    _chk(x)
+    _chk(graph_ptr, torch.int32)
+    feat = x.shape[1]
+    out = torch.empty(num_graphs, len(ops) * feat, dtype=torch.float32, device=x.device)
+    L = _lib.load()
+    check(L.i3d_segment_readout_fwd(_p(x), _p(graph_ptr), num_graphs, feat, int_array(ops), len(ops), _p(out), _stream()),
+          'i3d_segment_readout_fwd')
+    return out
+
+
+def segment_readout_bwd(grad_out, x, graph_ptr, num_graphs, ops):
+    _chk(grad_out)
+    _chk(x)
+    grad_x = torch.empty_like(x)
+    L = _lib.load()
+    check(L.i3d_segment_readout_bwd(_p(grad_out), _p(x), _p(graph_ptr), num_graphs, x.shape[1], int_array(ops), len(ops),
+                                    _p(grad_x), _stream()), 'i3d_segment_readout_bwd')
+    return grad_x
+
+
+# ---- GEMM ------------------------------------------------------------------------------------------------
+def _ld(t):
+    assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def gemm(A, B, trans_a=False, trans_b=False, out=None, bias=None, accumulate=False):
+    """out[M,N] = (accumulate ? out : 0) + op(A) op(B) + bias.  A, B, out: 2-D fp32, unit inner stride
+    (row slices / column slices of a contiguous tensor are fine: the row stride is the leading dimension)."""
+    M, K = (A.shape[1], A.shape[0]) if trans_a else A.shape
+    K2, N = (B.shape[1], B.shape[0]) if trans_b else B.shape
+    assert K == K2, (A.shape, B.shape, trans_a, trans_b)
+    if out is None:
+        assert not accumulate
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    L = _lib.load()
+    check(L.i3d_gemm_f32(int(trans_a), int(trans_b), M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), _ld(out),
+                         _p(bias), int(accumulate), _stream()), 'i3d_gemm_f32')
+    return out
+
+
+# ---- BatchNorm / activations -----------------------------------------------------------------------------
+def act_stats_fwd(pre, act, eps, momentum, running_mean=None, running_var=None, sums_out=None, out=None):
+    """x = act(pre) (in place unless `out` is given), returns (x, mean, invstd)."""
+    _chk(pre)
+    rows, feat = pre.shape
+    x = pre if out is None else out
+    mean = torch.empty(feat, dtype=torch.float32, device=pre.device)
+    invstd = torch.empty(feat, dtype=torch.float32, device=pre.device)
+    L = _lib.load()
+    check(L.i3d_act_stats_fwd(_p(pre), rows, feat, ACT[act], _p(x), float(eps), float(momentum), _p(mean), _p(invstd),
+                              _p(running_mean), _p(running_var), _p(sums_out), _p(_workspace(feat, pre.device)),
+                              _stream()), 'i3d_act_stats_fwd')
+    return x, mean, invstd
+
+
+def bn_finalize_stats(sums, feat, eps, momentum, running_mean=None, running_var=None):
+    mean = torch.empty(feat, dtype=torch.float32, device=sums.device)
+    invstd = torch.empty(feat, dtype=torch.float32, device=sums.device)
+    L = _lib.load()
+    check(L.i3d_bn_finalize_stats(_p(sums), feat, float(eps), float(momentum), _p(mean), _p(invstd), _p(running_mean),
+                                  _p(running_var), _stream()), 'i3d_bn_finalize_stats')
+    return mean, invstd
+
+
+def bn_apply_fwd(x, mean, invstd, gamma, beta, post_act=None, residual=None, out=None):
+    _chk(x)
+    rows, feat = x.shape
+    y = torch.empty_like(x) if out is None else out
+    L = _lib.load()
+    check(L.i3d_bn_apply_fwd(_p(x), rows, feat, _p(mean), _p(invstd), _p(gamma), _p(beta), ACT[post_act], _p(residual),
+                             _p(y), _stream()), 'i3d_bn_apply_fwd')
+    return y
+
+
+def bn_eval_fwd(x, running_mean, running_var, eps, gamma, beta, post_act=None, residual=None, out=None):
+    _chk(x)
+    rows, feat = x.shape
+    y = torch.empty_like(x) if out is None else out
+    L = _lib.load()
+    check(L.i3d_bn_eval_fwd(_p(x), rows, feat, _p(running_mean), _p(running_var), float(eps), _p(gamma), _p(beta),
+                            ACT[post_act], _p(residual), _p(y), _stream()), 'i3d_bn_eval_fwd')
+    return y
+
+
+def bn_bwd(grad_y, x, pre, act, post_act, mean, invstd, gamma, beta, sums_out=None, sums_in=None, total_rows=0,
+           grad_gamma=None, grad_beta=None, out=None):
+    """Returns (grad_pre, grad_gamma, grad_beta).  grad_pre may alias grad_y (out=grad_y)."""
+    _chk(grad_y)
+    _chk(x)
+    rows, feat = x.shape
+    if grad_gamma is None:
+        grad_gamma = torch.empty(feat, dtype=torch.float32, device=x.device)
+        grad_beta = torch.empty(feat, dtype=torch.float32, device=x.device)
+    grad_pre = torch.empty_like(x) if out is None else out
+    L = _lib.load()
+    check(L.i3d_bn_bwd(_p(grad_y), _p(x), _p(pre), rows, feat, ACT[act], ACT[post_act], _p(mean), _p(invstd), _p(gamma),
+                       _p(beta), _p(grad_gamma), _p(grad_beta), _p(grad_pre), _p(sums_out), _p(sums_in), int(total_rows),
+                       _p(_workspace(feat, x.device)), _stream()), 'i3d_bn_bwd')
+    return grad_pre, grad_gamma, grad_beta
+
+
+def bn_eval_bwd(grad_y, x, pre, act, post_act, running_mean, running_var, eps, gamma, beta, out=None):
+    _chk(grad_y)
+    _chk(x)
+    rows, feat = x.shape
+    grad_gamma = torch.empty(feat, dtype=torch.float32, device=x.device)
+    grad_beta = torch.empty(feat, dtype=torch.float32, device=x.device)
+    grad_pre = torch.empty_like(x) if out is None else out
+    L = _lib.load()
+    check(L.i3d_bn_eval_bwd(_p(grad_y), _p(x), _p(pre), rows, feat, ACT[act], ACT[post_act], _p(running_mean),
+                            _p(running_var), float(eps), _p(gamma), _p(beta), _p(grad_gamma), _p(grad_beta), _p(grad_pre),
+                            _p(_workspace(feat, x.device)), _stream()), 'i3d_bn_eval_bwd')
+    return grad_pre, grad_gamma, grad_beta
+
+
+def colsum(x, w=None):
+    _chk(x)
+    rows, feat = x.shape
+    out = torch.empty(feat, dtype=torch.float32, device=x.device)
+    L = _lib.load()
+    check(L.i3d_colsum(_p(x), _p(w), rows, feat, _p(out), _p(_workspace(feat, x.device)), _stream()), 'i3d_colsum')
+    return out
+
+
+def act_fwd(x, act, out=None):
+    _chk(x)
+    y = torch.empty_like(x) if out is None else out
+    check(_lib.load().i3d_act_fwd(_p(x), x.numel(), ACT[act], _p(y), _stream()), 'i3d_act_fwd')
+    return y
+
+
+def act_bwd(grad_y, x, act, out=None):
+    _chk(x)
+    g = torch.empty_like(x) if out is None else out
+    check(_lib.load().i3d_act_bwd(_p(grad_y), _p(x), x.numel(), ACT[act], _p(g), _stream()), 'i3d_act_bwd')
+    return g
+
+
+def add_inplace(dst, src):
+    _chk(dst)
+    _chk(src)
+    assert dst.numel() == src.numel()
+    check(_lib.load().i3d_add_inplace(_p(dst), _p(src), dst.numel(), _stream()), 'i3d_add_inplace')
+    return dst
+
+
+# ---- edge kernels ----------------------------------------------------------------------------------------
+def edge_combine_fwd(P, Q, bias, src_s, dst_s):
+    _chk(P)
+    E, feat = src_s.shape[0], P.shape[1] // 2
+    pre = torch.empty(E, feat, dtype=torch.float32, device=P.device)
+    check(_lib.load().i3d_edge_combine_fwd(_p(P), P.shape[1], _p(Q), _p(bias), _p(src_s), _p(dst_s), E, feat, _p(pre),
+                                           _stream()), 'i3d_edge_combine_fwd')
+    return pre
+
+
+def segment_sum(x, ptr, idx, num_segments, mean=False, out=None):
+    """out[v] = sum_{j in [ptr[v],ptr[v+1])} x[idx[j] if idx is not None else j]  (x, out may be column slices)."""
+    feat = x.shape[1]
+    if out is None:
+        out = torch.empty(num_segments, feat, dtype=torch.float32, device=x.device)
+    check(_lib.load().i3d_segment_sum(_p(x), _ld(x), _p(ptr), _p(idx), num_segments, feat, int(mean), _p(out), _ld(out),
+                                      _stream()), 'i3d_segment_sum')
+    return out
+
+
+def segment_bcast(g, ptr, seg_of_row, rows, mean=False):
+    _chk(g)
+    feat = g.shape[1]
+    out = torch.empty(rows, feat, dtype=torch.float32, device=g.device)
+    check(_lib.load().i3d_segment_bcast(_p(g), _p(ptr), _p(seg_of_row), rows, feat, int(mean), _p(out), _stream()),
+          'i3d_segment_bcast')
+    return out
+
+
+def gather_rows(x, idx):
+    _chk(x)
+    _chk(idx, torch.int32)
+    out = torch.empty(idx.shape[0], x.shape[1], dtype=torch.float32, device=x.device)
+    check(_lib.load().i3d_gather_rows(_p(x), _p(idx), idx.shape[0], x.shape[1], _p(out), _stream()), 'i3d_gather_rows')
+    return out
+
+
+def fourier_encode(d, n_enc):
+    _chk(d)
+    E = d.shape[0]
+    out = torch.empty(E, 2 * n_enc + 1, dtype=torch.float32, device=d.device)
+    check(_lib.load().i3d_fourier_encode(_p(d), E, n_enc, _p(out), _stream()), 'i3d_fourier_encode')
+    return out
+
+
+def soft_edge_fwd(m, ws, bs):
+    _chk(m)
+    E, feat = m.shape
+    msg = torch.empty_like(m)
+    w = torch.empty(E, dtype=torch.float32, device=m.device)
+    check(_lib.load().i3d_soft_edge_fwd(_p(m), _p(ws), _p(bs), E, feat, _p(msg), _p(w), _stream()), 'i3d_soft_edge_fwd')
+    return msg, w
+
+
+def soft_edge_bwd(grad_msg, m, w, ws):
+    _chk(grad_msg)
+    E, feat = m.shape
+    gm = torch.empty_like(m)
+    gg = torch.empty(E, dtype=torch.float32, device=m.device)
+    check(_lib.load().i3d_soft_edge_bwd(_p(grad_msg), _p(m), _p(w), _p(ws), E, feat, _p(gm), _p(gg), _stream()),
+          'i3d_soft_edge_bwd')
+    return gm, gg
+
+
+# ---- NT-Xent ---------------------------------------------------------------------------------------------
+def row_norms(z):
+    _chk(z)
+    n = torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
+    check(_lib.load().i3d_row_norms(_p(z), z.shape[0], z.shape[1], _p(n), _stream()), 'i3d_row_norms')
+    return n
+
+
+def ntxent_fwd(sim, n1, n2, b1, b2, conf, pos_offset, tau, eps):
+    row_sum = torch.empty(b1, dtype=torch.float32, device=sim.device)
+    row_pos = torch.empty(b1, dtype=torch.float32, device=sim.device)
+    loss_sum = torch.empty(1, dtype=torch.float32, device=sim.device)
+    check(_lib.load().i3d_ntxent_fwd(_p(sim), _p(n1), _p(n2), b1, b2, conf, pos_offset, float(tau), float(eps),
+                                     _p(row_sum), _p(row_pos), _p(loss_sum), _stream()), 'i3d_ntxent_fwd')
+    return row_sum, row_pos, loss_sum
+
+
+def ntxent_bwd(sim, n1, n2, row_sum, row_pos, b1, b2, conf, pos_offset, tau, eps, grad_scale):
+    dsim = torch.empty_like(sim)
+    ca = torch.empty(b1, dtype=torch.float32, device=sim.device)
+    cb = torch.empty(b2 * conf, dtype=torch.float32, device=sim.device)
+    check(_lib.load().i3d_ntxent_bwd(_p(sim), _p(n1), _p(n2), _p(row_sum), _p(row_pos), b1, b2, conf, pos_offset,
+                                     float(tau), float(eps), float(grad_scale), _p(dsim), _p(ca), _p(cb), _stream()),
+          'i3d_ntxent_bwd')
+    return dsim, ca, cb
+
+
+def row_axpy(z, coef, out):
+    _chk(z)
+    _chk(out)
+    check(_lib.load().i3d_row_axpy(_p(z), _p(coef), z.shape[0], z.shape[1], _p(out), _stream()), 'i3d_row_axpy')
+    return out

@@ -1,0 +1,159 @@
+"""PNA 2D message-passing network on the MI355X kernels - drop-in for reference models/pna.py.
+
+Same class names (`PNA`, `PNAGNN`, `PNALayer`, `PNA_AGGREGATORS`, `PNA_SCALERS`), constructor kwargs
+(unknown kwargs swallowed like reference models/pna.py:115), sub-module names and therefore state_dict keys
+(SURVEY.md 8b), same side effects on the graph (`ndata['feat']` / `edata['feat']` are overwritten with the
+float embeddings, reference models/pna.py:162-163, 213).  The arithmetic is the reference's, re-associated for
+the hardware:
+  * edge tensors live in destination-sorted order, the gather/concat/first-Linear of pretrans is
+    P = h [W_s|W_d]^T at node level + a gather-add per edge (layers.EdgeFCFn);
+  * the four aggregators x three scalers are one segmented pass (csrc/aggregate.hip);
+  * cat([h, agg]) -> posttrans is two accumulating GEMMs (layers.Concat2FCFn), BN + residual fused.
+"""
+from typing import Callable, Dict, List, Union
+
+import torch
+from torch import nn
+
+from . import ops
+from .graph import as_batched_graph
+from .layers import MLP, AggregateFn, ReadoutFn
+from .mol_encoder import AtomEncoder, BondEncoder
+
+EPS = 1e-5
+
+# name tables kept for API compatibility (reference models/pna.py:71-87); values are the kernel codes
+PNA_AGGREGATORS = {k: v for k, v in ops.AGG.items()}
+PNA_SCALERS = {k: v for k, v in ops.SCALER.items()}
+
+
+def _codes(names, table, what):
+    out = []
+    for n in names:
+        if n not in table:
+            raise NotImplementedError(f'{what} {n!r} has no HIP kernel yet (supported: {sorted(table)})')
+        out.append(table[n])
+    return out
+
+
+class PNA(nn.Module):
+    """Message Passing Neural Network that does not use 3D information (reference models/pna.py:90-135)."""
+
+    def __init__(self, hidden_dim, target_dim, aggregators: List[str], scalers: List[str],
+                 readout_aggregators: List[str], readout_batchnorm: bool = True, readout_hidden_dim=None,
+                 readout_layers: int = 2, residual: bool = True, pairwise_distances: bool = False,
+                 activation: Union[Callable, str] = "relu", last_activation: Union[Callable, str] = "none",
+                 mid_batch_norm: bool = False, last_batch_norm: bool = False, propagation_depth: int = 5,
+                 dropout: float = 0.0, posttrans_layers: int = 1, pretrans_layers: int = 1, batch_norm_momentum=0.1,
+                 **kwargs):
+        super().__init__()
+        self.node_gnn = PNAGNN(hidden_dim=hidden_dim, aggregators=aggregators, scalers=scalers, residual=residual,
+                               pairwise_distances=pairwise_distances, activation=activation,
+                               last_activation=last_activation, mid_batch_norm=mid_batch_norm,
+                               last_batch_norm=last_batch_norm, propagation_depth=propagation_depth, dropout=dropout,
+                               posttrans_layers=posttrans_layers, pretrans_layers=pretrans_layers,
+                               batch_norm_momentum=batch_norm_momentum)
+        if readout_hidden_dim is None:
+            readout_hidden_dim = hidden_dim
+        self.readout_aggregators = readout_aggregators
+        self._readout_codes = _codes(readout_aggregators, {k: ops.AGG[k] for k in ('mean', 'sum', 'max', 'min')},
+                                     'readout aggregator')
+        self.output = MLP(in_dim=hidden_dim * len(self.readout_aggregators), hidden_size=readout_hidden_dim,
+                          mid_batch_norm=readout_batchnorm, out_dim=target_dim, layers=readout_layers,
+                          batch_norm_momentum=batch_norm_momentum)
+
+    def forward(self, graph, *unused):
+        g = as_batched_graph(graph)
+        self.node_gnn(g)
+        readout = ReadoutFn.apply(g.ndata['feat'], g.index(), self._readout_codes)
+        return self.output(readout)
+
+
+class PNAGNN(nn.Module):
+    """reference models/pna.py:138-166."""
+
+    def __init__(self, hidden_dim, aggregators: List[str], scalers: List[str], residual: bool = True,
+                 pairwise_distances: bool = False, activation: Union[Callable, str] = "relu",
+                 last_activation: Union[Callable, str] = "none", mid_batch_norm: bool = False,
+                 last_batch_norm: bool = False, batch_norm_momentum=0.1, propagation_depth: int = 5,
+                 dropout: float = 0.0, posttrans_layers: int = 1, pretrans_layers: int = 1, **kwargs):
+        super().__init__()
+        self.mp_layers = nn.ModuleList()
+        for _ in range(propagation_depth):
+            self.mp_layers.append(
+                PNALayer(in_dim=hidden_dim, out_dim=int(hidden_dim), in_dim_edges=hidden_dim, aggregators=aggregators,
+                         scalers=scalers, pairwise_distances=pairwise_distances, residual=residual, dropout=dropout,
+                         activation=activation, last_activation=last_activation, mid_batch_norm=mid_batch_norm,
+                         last_batch_norm=last_batch_norm, avg_d={"log": 1.0}, posttrans_layers=posttrans_layers,
+                         pretrans_layers=pretrans_layers, batch_norm_momentum=batch_norm_momentum))
+        self.atom_encoder = AtomEncoder(emb_dim=hidden_dim)
+        self.bond_encoder = BondEncoder(emb_dim=hidden_dim)
+
+    def forward(self, graph):
+        g = as_batched_graph(graph)
+        idx = g.index()
+        g.ndata['feat'] = self.atom_encoder(g.ndata['feat'])
+        # bond embeddings are produced directly in destination-sorted (kernel) order
+        ef_sorted = self.bond_encoder(g.edata['feat'], perm=idx.perm)
+        for mp_layer in self.mp_layers:
+            mp_layer(g, ef_sorted=ef_sorted)
+        # reference side effect (models/pna.py:163): edata['feat'] becomes the float bond embedding, edge-id order
+        g.edata['feat'] = ops.gather_rows(ef_sorted.detach(), idx.inv_perm)
+
+
+class PNALayer(nn.Module):
+    """reference models/pna.py:169-252."""
+
+    def __init__(self, in_dim: int, out_dim: int, in_dim_edges: int, aggregators: List[str], scalers: List[str],
+                 activation: Union[Callable, str] = "relu", last_activation: Union[Callable, str] = "none",
+                 dropout: float = 0.0, residual: bool = True, pairwise_distances: bool = False,
+                 mid_batch_norm: bool = False, last_batch_norm: bool = False, batch_norm_momentum=0.1,
+                 avg_d: Dict[str, float] = {"log": 1.0}, posttrans_layers: int = 2, pretrans_layers: int = 1):
+        super().__init__()
+        if pairwise_distances:
+            raise NotImplementedError('pairwise_distances=True is not on the accelerated path (no BASELINE config uses it)')
+        self.aggregators = _codes(aggregators, ops.AGG, 'aggregator')
+        self.scalers = _codes(scalers, ops.SCALER, 'scaler')
+        self.edge_features = in_dim_edges > 0
+        self.activation = activation
+        self.avg_d = avg_d
+        self.pairwise_distances = pairwise_distances
+        self.residual = residual
+        if in_dim != out_dim:
+            self.residual = False
+        self.pretrans = MLP(in_dim=2 * in_dim + in_dim_edges, hidden_size=in_dim, out_dim=in_dim,
+                            mid_batch_norm=mid_batch_norm, last_batch_norm=last_batch_norm, layers=pretrans_layers,
+                            mid_activation=activation, dropout=dropout, last_activation=last_activation,
+                            batch_norm_momentum=batch_norm_momentum)
+        self.posttrans = MLP(in_dim=(len(aggregators) * len(scalers) + 1) * in_dim, hidden_size=out_dim,
+                             out_dim=out_dim, layers=posttrans_layers, mid_activation=activation,
+                             last_activation=last_activation, dropout=dropout, mid_batch_norm=mid_batch_norm,
+                             last_batch_norm=last_batch_norm, batch_norm_momentum=batch_norm_momentum)
+
+    def forward(self, g, ef_sorted=None):
+        g = as_batched_graph(g)
+        idx = g.index()
+        h = g.ndata['feat']
+        if ef_sorted is None and self.edge_features:
+            ef_sorted = _GatherRowsFn.apply(g.edata['feat'], idx.perm, idx.inv_perm)
+        # pretransformation (edge MLP on [h_src | h_dst | e_feat]) -> messages, destination-sorted
+        e = self.pretrans.forward_edge(h, ef_sorted if self.edge_features else None, idx)
+        # aggregation: mean/max/min/std x scalers in one segmented pass
+        agg = AggregateFn.apply(e, idx, self.aggregators, self.scalers, float(self.avg_d["log"]))
+        # post-transformation on [h | agg] (+ residual fused into the last BN)
+        h_new = self.posttrans.forward_concat2(h, agg, residual=h if self.residual else None)
+        g.ndata['feat'] = h_new
+        return h_new
+
+
+class _GatherRowsFn(torch.autograd.Function):
+    """edge-id order -> destination-sorted order (standalone PNALayer use with a float edata['feat'])."""
+
+    @staticmethod
+    def forward(ctx, x, perm, inv_perm):
+        ctx.inv_perm = inv_perm
+        return ops.gather_rows(x.contiguous(), perm)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.gather_rows(g.contiguous(), ctx.inv_perm), None, None

@@ -1,0 +1,178 @@
+"""bench.py - molecules/s of the 3DInfomax pre-training step (PNA + Net3D + NT-Xent) on MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = reference trainer/self_supervised_trainer.py:24-29 + trainer/trainer.py:116-124: PNA forward, Net3D
+forward, NT-Xent, backward, Adam step, zero_grad - on a batch of synthetic QM9-shaped molecules already resident
+in HBM.  Workload = BASELINE.json configs[1]: PNA hidden 200, depth 4 (--depth 7 = the yml),
+batch 512 per GPU, fp32.  N>1: molecules sharded by rank (weak scaling, 512 per GPU), all-gathered negatives,
+synchronised BatchNorm, gradient all-reduce (3dinfomax_amd/dist.py).
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     - the PNA aggregation kernel (K4): algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
+  cpu_baseline - the oracle (CPU port of the reference path) timed on this host on a bounded sample (N=1 only)
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+PNA_KW = dict(target_dim=256, hidden_dim=200, mid_batch_norm=True, last_batch_norm=True, readout_batchnorm=True,
+              batch_norm_momentum=0.93, readout_hidden_dim=200, readout_layers=2, dropout=0.0, propagation_depth=4,
+              aggregators=['mean', 'max', 'min', 'std'], scalers=['identity', 'amplification', 'attenuation'],
+              readout_aggregators=['min', 'max', 'mean'], pretrans_layers=2, posttrans_layers=1, residual=True)
+NET3D_KW = dict(target_dim=256, hidden_dim=20, hidden_edge_dim=20, node_wise_output_layers=0, message_net_layers=1,
+                update_net_layers=1, reduce_func='mean', fourier_encodings=4, propagation_depth=1, dropout=0.0,
+                batch_norm=True, readout_batchnorm=True, batch_norm_momentum=0.93, readout_hidden_dim=20,
+                readout_layers=1, readout_aggregators=['min', 'max', 'mean'])
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=512, help='molecules per GPU per step')
+    ap.add_argument('--depth', type=int, default=4, help='PNA propagation depth (BASELINE.json: 4; pre-train_QM9.yml: 7)')
+    ap.add_argument('--pool', type=int, default=4, help='number of distinct resident batches cycled through')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--no-sync-bn', action='store_true', help='throughput mode without synchronised BN (parity loss)')
+    return ap.parse_args()
+
+
+def cpu_baseline(mols, depth, steps):
+    """Oracle (CPU restatement of the reference path) on the same workload, bounded sample."""
+    from oracle import pna3d_oracle as O
+    cfg2 = O.pna_config(**dict(PNA_KW, propagation_depth=depth))
+    cfg3 = O.net3d_config(**NET3D_KW)
+    P2, P3 = O.require_grad(O.init_pna_params(cfg2, 1)), O.require_grad(O.init_net3d_params(cfg3, 2))
+    named = [(k, P2[k]) for k in O.trainable(P2)] + [(k, P3[k]) for k in O.trainable(P3)]
+    optim = torch.optim.Adam([{'params': [p for k, p in named if 'batch_norm' in k], 'weight_decay': 0},
+                              {'params': [p for k, p in named if 'batch_norm' not in k]}], lr=8e-5)
+    g2, g3 = O.graphs_from_molecules(mols)
+    O.train_step(g2, g3, P2, cfg2, P3, cfg3, optim, 0.1)        # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.train_step(g2, g3, P2, cfg2, P3, cfg3, optim, 0.1)
+    dt = (time.perf_counter() - t0) / steps
+    return dict(value=len(mols) / dt, unit='molecules/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{steps} steps of batch {len(mols)} (depth {depth}, fp32, torch CPU eager, '
+                       f'{torch.get_num_threads()} threads), {dt:.3f} s/step')
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    amd = importlib.import_module('3dinfomax_amd')
+    ops = importlib.import_module('3dinfomax_amd.ops')
+    adist = importlib.import_module('3dinfomax_amd.dist')
+
+    # synthetic QM9-shaped data: `pool` global batches, each rank keeps its shard resident in HBM
+    B, pool = args.batch, args.pool
+    batches = []
+    for i in range(pool):
+        mols = amd.synth.make_dataset(B * world, seed=1000 + i)
+        shard = mols[rank * B:(rank + 1) * B]
+        g2 = amd.batch([amd.bond_graph(m) for m in shard]).to(dev)
+        g3 = amd.batch([amd.complete_graph(m) for m in shard]).to(dev)
+        batches.append((g2, g3, shard))
+
+    torch.manual_seed(123)
+    pna = amd.PNA(avg_d=1.0, device=dev, **dict(PNA_KW, propagation_depth=args.depth)).to(dev).train()
+    net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_KW).to(dev).train()
+    loss_fn = amd.NTXent(tau=0.1)
+    named = list(pna.named_parameters()) + list(net.named_parameters())
+    params = [p for _, p in named]
+    # reference trainer/self_supervised_trainer.py:78-86: BN params in their own group
+    optim = torch.optim.Adam([{'params': [p for k, p in named if 'batch_norm' in k], 'weight_decay': 0},
+                              {'params': [p for k, p in named if 'batch_norm' not in k]}], lr=8e-5)
+    if world > 1:
+        adist.setup([pna, net], loss_fn, sync_bn=not args.no_sync_bn)
+
+    def step(i):
+        g2, g3, _ = batches[i % pool]
+        a, b = g2.local_copy(), g3.local_copy()
+        loss = loss_fn(pna(a), net(b), nodes_per_graph=a.batch_num_nodes())
+        loss.backward()
+        if world > 1:
+            adist.allreduce_grads(params)
+        optim.step()
+        optim.zero_grad()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ops.KERNEL_TIMERS = {}
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    timers, ops.KERNEL_TIMERS = ops.KERNEL_TIMERS, None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    # roofline of the dominant HBM kernel: K4 PNA aggregation (forward), algorithmic bytes per SURVEY.md 8d
+    ev = timers.get('pna_aggregate_fwd', [])
+    roof = None
+    if ev:
+        ms = np.array([a.elapsed_time(b) for a, b, *_ in ev])
+        byts = np.array([4.0 * E * F + 4.0 * N * W + 4.0 * (N + 1) for _, _, N, E, F, W in ev])
+        achieved = float(byts.sum() / (ms.sum() * 1e-3) / 1e9)
+        roof = dict(bound='hbm', kernel='pna_aggregate_fwd_kernel', achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+                    unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    launches=len(ev), avg_us=round(float(ms.mean() * 1e3), 2),
+                    algorithmic_bytes_per_launch=int(byts.mean()))
+
+    if rank == 0:
+        mol_per_s = args.steps * B * world / dt
+        out = dict(metric='molecules/sec pretraining step (PNA+Net3D, QM9-50k); PNA-agg HBM GB/s vs peak',
+                   value=round(mol_per_s, 1), unit='molecules/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
+                   vs_baseline=None, dtype='f32', data='synthetic',
+                   config=dict(workload=f'PNA hidden=200 depth={args.depth} + Net3D hidden=20 + NT-Xent tau=0.1, '
+                                        f'QM9-shaped synthetic molecules, batch {B}/GPU, fp32, Adam',
+                               global_batch=B * world, parallelism=f'dp{world}' if world > 1 else 'single',
+                               sync_bn=(world > 1 and not args.no_sync_bn), final_loss=round(float(loss.item()), 5)),
+                   roofline=roof)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(batches[0][2], args.depth, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,203 @@
+/* lib3dinfomax_hip.so - C ABI of the MI355X (gfx950) kernels behind the 3DInfomax pre-training hot path.
+ *
+ * The reference (HannesStark/3DInfomax) is pure Python: its "FFI" for this path is the set of ATen/DGL
+ * calls its nn.Modules make.  Every entry point below replaces one such call site (cited as
+ * reference file:line) and is what a maintainer binds with ctypes (the in-tree
+ * binding is 3dinfomax_amd/_lib.py + ops.py).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless the parameter comment says
+ *    "host"; tensors are dense row-major fp32 unless stated; index arrays are int32.
+ *  - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); all work is enqueued
+ *    asynchronously on it, nothing synchronises the device, no hidden allocations except where a
+ *    `workspace` pointer is taken explicitly.
+ *  - return value: I3D_OK (0) or a negative I3D_ERR_*; i3d_last_error() returns a thread-local message.
+ *  - edge-sized tensors are in DESTINATION-SORTED ("epos") order: the in-edges of node v are the
+ *    contiguous rows [in_ptr[v], in_ptr[v+1]) (stable w.r.t. edge id = DGL's mailbox order).
+ *  - thread safety: no global mutable state besides the thread-local error string.
+ */
+#ifndef INFOMAX3D_HIP_H
+#define INFOMAX3D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define I3D_OK 0
+#define I3D_ERR_INVALID (-1)
+#define I3D_ERR_LAUNCH (-2)
+
+/* activations: reference models/base_layers.py:9-20 (get_activation) */
+#define I3D_ACT_NONE 0
+#define I3D_ACT_RELU 1
+#define I3D_ACT_SILU 2
+#define I3D_ACT_SIGMOID 3
+
+/* aggregators: reference models/pna.py:71-81 (PNA_AGGREGATORS); readout ops: dgl.readout_nodes */
+#define I3D_AGG_MEAN 0
+#define I3D_AGG_SUM 1
+#define I3D_AGG_MAX 2
+#define I3D_AGG_MIN 3
+#define I3D_AGG_STD 4
+#define I3D_AGG_VAR 5
+
+/* scalers: reference models/pna.py:83-87 (PNA_SCALERS) */
+#define I3D_SCALE_IDENTITY 0
+#define I3D_SCALE_AMPLIFICATION 1
+#define I3D_SCALE_ATTENUATION 2
+
+int i3d_abi_version(void);
+const char* i3d_last_error(void);
+
+/* ---- K1: fused multi-table embedding sum -----------------------------------------------------------
+ * replaces AtomEncoder.forward / BondEncoder.forward, reference commons/mol_encoder.py:34-42, 65-73
+ * (n_cols nn.Embedding lookups + adds).  out[r,:] = sum_k tables[k][idx[r,k], :].
+ *   idx     int64 [rows, n_cols]          tables  host array of n_cols device pointers, table k is [dim_k, feat]
+ *   row_perm int32 [rows] or NULL: output row r uses index row row_perm[r] (bond features are stored in edge-id
+ *            order, the kernels want destination-sorted edges: the permutation is folded into the lookup)
+ * bwd: grad_tables[k][idx[r,k], :] += grad_out[r,:]  (caller zero-fills; dims = host array of table sizes,
+ * sum(dims)*feat*4 bytes must fit the 160 KiB LDS of a CU for the LDS-privatised path, else global atomics). */
+int i3d_embedding_sum_fwd(const int64_t* idx, const int* row_perm, int rows, int n_cols, const float* const* tables,
+                          int feat, float* out, void* stream);
+int i3d_embedding_sum_bwd(const int64_t* idx, const int* row_perm, int rows, int n_cols, const float* grad_out,
+                          int feat, float* const* grad_tables, const int* dims, void* stream);
+
+/* ---- K4: PNA aggregation (the HBM-roofline kernel) -------------------------------------------------
+ * replaces DGL update_all(message_func, reduce_func) + aggregators + scalers,
+ * reference models/pna.py:206, 215-235, 17-37, 57-68.
+ *   e [E, feat] messages in epos order;  in_ptr [N+1];  aggregators/scalers: host int arrays (I3D_AGG_*, I3D_SCALE_*)
+ *   out [N, n_scalers_eff * n_aggregators * feat], scaler-major, zero rows for in-degree 0;
+ *   n_scalers_eff = n_scalers if n_scalers > 1 else 1 with NO scaling (reference quirk, models/pna.py:232).
+ *   avg_d_log: the reference hard-codes 1.0 (models/pna.py:153); pna_original.py passes the real value.
+ * bwd: grad_e [E, feat] (fully overwritten).  max/min ties route to the first (lowest edge id) slot. */
+int i3d_pna_aggregate_fwd(const float* e, const int* in_ptr, int num_nodes, int feat, const int* aggregators,
+                          int n_aggregators, const int* scalers, int n_scalers, float avg_d_log, float* out,
+                          void* stream);
+int i3d_pna_aggregate_bwd(const float* grad_out, const float* e, const int* in_ptr, int num_nodes, int feat,
+                          const int* aggregators, int n_aggregators, const int* scalers, int n_scalers,
+                          float avg_d_log, float* grad_e, void* stream);
+
+/* ---- K6: per-graph readout -------------------------------------------------------------------------
+ * replaces dgl.readout_nodes(graph,'feat',op) for op in readout_aggregators + torch.cat,
+ * reference models/pna.py:133-134, models/net3d.py:73-74.
+ *   x [N, feat]; graph_ptr [B+1] node offsets; ops host array of I3D_AGG_{MEAN,SUM,MAX,MIN}
+ *   out [B, n_ops*feat].  bwd: grad_x [N, feat] (fully overwritten), ties -> first node. */
+int i3d_segment_readout_fwd(const float* x, const int* graph_ptr, int num_graphs, int feat, const int* ops,
+                            int n_ops, float* out, void* stream);
+int i3d_segment_readout_bwd(const float* grad_out, const float* x, const int* graph_ptr, int num_graphs, int feat,
+                            const int* ops, int n_ops, float* grad_x, void* stream);
+
+/* ---- dense towers: fp32 MFMA GEMM ------------------------------------------------------------------
+ * replaces nn.Linear forward/backward inside FCLayer, reference models/base_layers.py:101 (aten::addmm/mm).
+ *   C[M,N] (ldc) = (accumulate ? C : 0) + opA(A)[M,K] * opB(B)[K,N] + (bias ? bias[N] : 0)
+ *   trans_a = 0: A stored [M,K] (lda >= K);  1: A stored [K,M] (lda >= M)
+ *   trans_b = 0: B stored [K,N] (ldb >= N);  1: B stored [N,K] (ldb >= K)
+ * exact fp32 (v_mfma_f32_16x16x4_f32), fp32 accumulate.
+ *   Linear fwd  Y = X W^T + b : trans_a=0, trans_b=1, B=W[N,K]
+ *   dX = dY W               : trans_a=0, trans_b=0, B=W
+ *   dW = dY^T X             : trans_a=1, trans_b=0, A=dY[M',N'] (K := rows) */
+int i3d_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                 float* C, int ldc, const float* bias, int accumulate, void* stream);
+
+/* ---- column statistics / BatchNorm1d ---------------------------------------------------------------
+ * replaces nn.BatchNorm1d in FCLayer (train: batch statistics, momentum m, unbiased running_var; eval: running
+ * statistics), reference models/base_layers.py:87, 106-110, plus the activation in front of it (:102-103).
+ *
+ * i3d_act_stats_fwd: x = act(pre) written to `x` (may alias pre; pass act NONE and x == pre for stats only),
+ *   then mean[feat], invstd[feat] = 1/sqrt(biased var + eps); if running_mean != NULL the running statistics are
+ *   updated in place (running = (1-m)*running + m*batch, var unbiased).  `count_extra`/`stats_extra` support
+ *   synchronised BN: when sums_out != NULL the kernel only writes the fp64 sums_out[2*feat+1] = {sum x,
+ *   sum x^2, rows} and does NOT finalise (the caller all-reduces them and calls i3d_bn_finalize_stats).
+ *   workspace: device scratch of i3d_colreduce_workspace_bytes(rows, feat) bytes. */
+long i3d_colreduce_workspace_bytes(int rows, int feat);
+int i3d_act_stats_fwd(const float* pre, int rows, int feat, int act, float* x, float eps, float momentum,
+                      float* mean, float* invstd, float* running_mean, float* running_var, double* sums_out,
+                      void* workspace, void* stream);
+/* fp64 sums [2*feat+1] = {sum x, sum x^2, count} (already all-reduced) -> mean, invstd, running stats update */
+int i3d_bn_finalize_stats(const double* sums, int feat, float eps, float momentum, float* mean, float* invstd,
+                          float* running_mean, float* running_var, void* stream);
+/* y = post_act( (x-mean)*invstd*gamma + beta ) + (residual ? residual : 0).   y may alias x. */
+int i3d_bn_apply_fwd(const float* x, int rows, int feat, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, int post_act, const float* residual, float* y,
+                     void* stream);
+/* eval mode: invstd computed from running_var on the fly */
+int i3d_bn_eval_fwd(const float* x, int rows, int feat, const float* running_mean, const float* running_var,
+                    float eps, const float* gamma, const float* beta, int post_act, const float* residual, float* y,
+                    void* stream);
+/* backward of  y = post_act(BN(x)), x = act(pre)   (train mode):
+ *   grad_y, x [rows,feat]; pre may be NULL when act is NONE or RELU (x itself decides relu');
+ *   outputs: grad_gamma[feat], grad_beta[feat], grad_pre [rows,feat] (may alias grad_y).
+ *   If sums_out != NULL: phase 1 only - writes the LOCAL grad_gamma/grad_beta and the fp64 sums_out[2*feat] =
+ *   {sum dy, sum dy*xhat} for the sync-BN all-reduce (the caller stores its row count in sums[2*feat] before
+ *   reducing); then call again with sums_in != NULL (phase 2: the reduced sums and the count sums_in[2*feat]
+ *   drive grad_pre - total_rows is ignored, nothing is read back to the host; grad_gamma/grad_beta untouched). */
+int i3d_bn_bwd(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act, int post_act,
+               const float* mean, const float* invstd, const float* gamma, const float* beta, float* grad_gamma,
+               float* grad_beta, float* grad_pre, double* sums_out, const double* sums_in, long total_rows,
+               void* workspace, void* stream);
+/* eval-mode backward (statistics are constants): grad_pre = grad_y * post_act' * gamma*invstd * act' */
+int i3d_bn_eval_bwd(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
+                    int post_act, const float* running_mean, const float* running_var, float eps,
+                    const float* gamma, const float* beta, float* grad_gamma, float* grad_beta, float* grad_pre,
+                    void* workspace, void* stream);
+/* out[feat] = sum over rows of x[r,:] * (w ? w[r] : 1)   (bias gradients, weighted column sums) */
+int i3d_colsum(const float* x, const float* w, int rows, int feat, float* out, void* workspace, void* stream);
+/* y = act(x) elementwise (n elements); bwd: grad_x = grad_y * act'(x) */
+int i3d_act_fwd(const float* x, long n, int act, float* y, void* stream);
+int i3d_act_bwd(const float* grad_y, const float* x, long n, int act, float* grad_x, void* stream);
+/* dst += src */
+int i3d_add_inplace(float* dst, const float* src, long n, void* stream);
+
+/* ---- edge kernels ----------------------------------------------------------------------------------
+ * i3d_edge_combine_fwd replaces the gather + concat + first Linear of the edge MLPs,
+ *   reference models/pna.py:237-252 (pretrans_edges: cat[h_src, h_dst, e_feat] -> Linear) and
+ *   models/net3d.py:113-115, using  [h_s|h_d|q] W^T = h_s W_s^T + h_d W_d^T + q W_q^T :
+ *   pre[j,:] = P[src_s[j], 0:feat] + P[dst_s[j], feat:2feat] + Q[j,:] + bias   (P is [N, ldp >= 2*feat]; Q, bias may be NULL)
+ * i3d_segment_sum: out[v,:] = scale(v) * sum_{j in [ptr[v],ptr[v+1])} x[idx ? idx[j] : j, :]
+ *   scale_mode 0: 1;  1: 1/max(count,1)  (DGL fn.mean, reference models/net3d.py:95-96)
+ *   used for the backward of the gathers (by in_ptr, and by out_ptr/out_epos) and for Net3D's mean reduce.
+ * i3d_segment_bcast: grad of segment mean/sum: out[j,:] = scale(seg(j)) * g[seg(j),:], seg given by dst_s. */
+int i3d_edge_combine_fwd(const float* P, int ldp, const float* Q, const float* bias, const int* src_s,
+                         const int* dst_s, int num_edges, int feat, float* pre, void* stream);
+int i3d_segment_sum(const float* x, int ldx, const int* ptr, const int* idx, int num_segments, int feat,
+                    int scale_mode, float* out, int ldo, void* stream);
+int i3d_segment_bcast(const float* g, const int* ptr, const int* seg_of_row, int rows, int feat, int scale_mode,
+                      float* out, void* stream);
+/* rows gather: out[j,:] = x[idx[j],:]  (edge permutation edge-id -> epos order) */
+int i3d_gather_rows(const float* x, const int* idx, int rows, int feat, float* out, void* stream);
+
+/* ---- Net3D specifics -------------------------------------------------------------------------------
+ * fourier: replaces fourier_encode_dist, reference commons/utils.py:103-110, models/net3d.py:63-64:
+ *   out[j,:] = [sin(d/2^k)]_{k<n} | [cos(d/2^k)]_{k<n} | d        out [E, 2n+1]
+ * soft edge gate: reference models/net3d.py:106, 117-118:  w = sigmoid(m . ws + bs);  msg = m * w
+ *   bwd: grad_m [E,feat], g_gate[E] = (sum_f grad_msg*m) * w(1-w)  (so that grad_ws = sum_e g_gate*m, grad_bs = sum g_gate) */
+int i3d_fourier_encode(const float* d, int num_edges, int n_enc, float* out, void* stream);
+int i3d_soft_edge_fwd(const float* m, const float* ws, const float* bs, int num_edges, int feat, float* msg,
+                      float* w, void* stream);
+int i3d_soft_edge_bwd(const float* grad_msg, const float* m, const float* w, const float* ws, int num_edges,
+                      int feat, float* grad_m, float* g_gate, void* stream);
+
+/* ---- NT-Xent ---------------------------------------------------------------------------------------
+ * replaces NTXent.forward / NTXentMultiplePositives.forward, reference commons/losses.py:143-155, 225-247.
+ *   z1 [b1, dim] (local 2D-view rows), z2 [b2*conf, dim] (all 3D-view rows, conformer-minor); the positive columns
+ *   of row i are (pos_offset+i)*conf .. +conf-1 (pos_offset = rank*b1 when z2 is the all-gathered batch).
+ *   eps: 1e-8 for NTXent, 0 for the multiple-positives variant (reference :150 vs :239).
+ *   sim  [b1, b2*conf] = z1 z2^T from i3d_gemm_f32;  dsim [b1, b2*conf] receives dL/dS
+ *   fwd: loss_sum[0] = sum_i -log(pos_i / (rowsum_i - pos_i))   (caller divides by the GLOBAL batch size)
+ *   bwd: writes dsim = dL/dS (scaled by grad_scale = upstream/global_batch) and the norm-path
+ *        coefficients ca[b1], cb[b2*conf] such that dz1 = dS z2 + ca*z1, dz2 = dS^T z1 + cb*z2. */
+int i3d_row_norms(const float* z, int rows, int dim, float* norms, void* stream);
+int i3d_ntxent_fwd(const float* sim, const float* n1, const float* n2, int b1, int b2, int conf, int pos_offset,
+                   float tau, float eps, float* row_sum, float* row_pos, float* loss_sum, void* stream);
+int i3d_ntxent_bwd(const float* sim, const float* n1, const float* n2, const float* row_sum, const float* row_pos,
+                   int b1, int b2, int conf, int pos_offset, float tau, float eps, float grad_scale, float* dsim,
+                   float* ca, float* cb, void* stream);
+/* out[r,:] += coef[r] * z[r,:] */
+int i3d_row_axpy(const float* z, const float* coef, int rows, int dim, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INFOMAX3D_HIP_H */

@@ -1,0 +1,191 @@
+"""-m gpu: the plugin modules (PNA / PNALayer / Net3D / NT-Xent) running on the HIP kernels against the golden
+fixtures produced by the reference itself (tests/golden/gen_golden.py) and against the oracle on bigger batches.
+Bar: BASELINE.json:north_star - node embeddings and loss within 1e-4 relative fp32."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from fill import det_fill
+from helpers import (NET3D_SMALL, NET3D_YML, PNA_SMALL, PNA_YML, close, grads_close, load, mols_from_npz, rel_err,
+                     sd_from_npz, synth)
+from oracle import pna3d_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def amd():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return importlib.import_module('3dinfomax_amd')
+
+
+def make_batch(amd, mols, device='cuda:0'):
+    g2 = amd.batch([amd.bond_graph(m) for m in mols]).to(device)
+    g3 = amd.batch([amd.complete_graph(m) for m in mols]).to(device)
+    return g2, g3
+
+
+def param_grads(module):
+    return {k: p.grad for k, p in module.named_parameters()}
+
+
+@pytest.mark.parametrize('regime', ['init', 'trained'])
+def test_pna_layer_vs_reference_fixture(amd, regime):
+    z = load('pna_layer.npz')
+    F = 8
+    layer = amd.PNALayer(in_dim=F, out_dim=F, in_dim_edges=F, aggregators=['mean', 'max', 'min', 'std'],
+                         scalers=['identity', 'amplification', 'attenuation'], mid_batch_norm=True,
+                         last_batch_norm=True, batch_norm_momentum=0.93, posttrans_layers=1, pretrans_layers=2)
+    layer.load_state_dict(sd_from_npz(z, f'{regime}/sd'), strict=True)
+    layer.cuda().train()
+    g = amd.BatchedMolGraph(torch.from_numpy(z['src']), torch.from_numpy(z['dst']), int(z['n'])).to('cuda:0')
+    h = torch.from_numpy(z['h']).cuda().requires_grad_(True)
+    ef = torch.from_numpy(z['ef']).cuda().requires_grad_(True)
+    g.ndata['feat'], g.edata['feat'] = h, ef
+    out = layer(g)
+    assert rel_err(out.cpu(), z[f'{regime}/h_out']) < TOL
+    (out * torch.from_numpy(z[f'{regime}/cot']).cuda()).sum().backward()
+    assert rel_err(h.grad.cpu(), z[f'{regime}/grad_h']) < 2e-4
+    assert rel_err(ef.grad.cpu(), z[f'{regime}/grad_ef']) < 2e-4
+    grads_close(param_grads(layer), sd_from_npz(z, f'{regime}/grad'), 2e-4)
+    for k, v in sd_from_npz(z, f'{regime}/sd_after').items():
+        if 'running' in k:
+            assert close(layer.state_dict()[k], v, TOL, 1e-6), k
+
+
+@pytest.mark.parametrize('regime', ['init', 'trained'])
+def test_pna_and_net3d_vs_reference_fixture(amd, regime):
+    z = load('models_small.npz')
+    mols = mols_from_npz(z)
+    pna = amd.PNA(avg_d=1.0, device='cuda:0', **PNA_SMALL)
+    net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_SMALL)
+    # the reference's own state_dict loads strictly: identical keys and shapes
+    pna.load_state_dict(sd_from_npz(z, f'{regime}/pna_sd'), strict=True)
+    net.load_state_dict(sd_from_npz(z, f'{regime}/net3d_sd'), strict=True)
+    pna.cuda().train(), net.cuda().train()
+    g2, g3 = make_batch(amd, mols)
+    z2, z3 = pna(g2), net(g3)
+    assert rel_err(g2.ndata['feat'].cpu(), z[f'{regime}/pna_node_emb']) < TOL     # the side effect tensor
+    assert rel_err(z2.cpu(), z[f'{regime}/pna_out']) < TOL
+    assert rel_err(g3.ndata['feat'].cpu(), z[f'{regime}/net3d_node_emb']) < TOL
+    assert rel_err(z3.cpu(), z[f'{regime}/net3d_out']) < TOL
+    c2, c3 = torch.from_numpy(z[f'{regime}/cot2']).cuda(), torch.from_numpy(z[f'{regime}/cot3']).cuda()
+    ((z2 * c2).sum() + (z3 * c3).sum()).backward()
+    grads_close(param_grads(pna), sd_from_npz(z, f'{regime}/pna_grad'), 5e-4, 'pna ')
+    grads_close(param_grads(net), sd_from_npz(z, f'{regime}/net3d_grad'), 5e-4, 'net3d ')
+    for tag, mod in (('pna_sd_after', pna), ('net3d_sd_after', net)):
+        sd = mod.state_dict()
+        for k, v in sd_from_npz(z, f'{regime}/{tag}').items():
+            if 'running' in k or 'num_batches' in k:
+                assert close(sd[k], v, TOL, 1e-6), k
+    pna.eval(), net.eval()
+    g2, g3 = make_batch(amd, mols)
+    with torch.no_grad():
+        assert rel_err(pna(g2).cpu(), z[f'{regime}/pna_out_eval']) < TOL
+        assert rel_err(net(g3).cpu(), z[f'{regime}/net3d_out_eval']) < TOL
+
+
+def test_three_adam_steps_vs_reference_fixture(amd):
+    z = load('train3.npz')
+    mols = mols_from_npz(z)
+    pna = amd.PNA(avg_d=1.0, device='cuda:0', **PNA_SMALL)
+    net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_SMALL)
+    pna.load_state_dict(sd_from_npz(z, 'pna_sd'))
+    net.load_state_dict(sd_from_npz(z, 'net3d_sd'))
+    pna.cuda().train(), net.cuda().train()
+    loss_fn = amd.NTXent(tau=0.1)
+    named = list(pna.named_parameters()) + list(net.named_parameters())
+    optim = torch.optim.Adam([{'params': [p for k, p in named if 'batch_norm' in k], 'weight_decay': 0},
+                              {'params': [p for k, p in named if 'batch_norm' not in k]}], lr=8e-5)
+    g2, g3 = make_batch(amd, mols)
+    losses = []
+    for _ in range(3):
+        a, b = g2.local_copy(), g3.local_copy()
+        loss = loss_fn(pna(a), net(b), nodes_per_graph=a.batch_num_nodes())
+        loss.backward()
+        optim.step()
+        optim.zero_grad()
+        losses.append(loss.item())
+    np.testing.assert_allclose(losses, z['losses'], rtol=1e-4)      # loss within 1e-4 of the reference
+
+
+def _det_load(module, tag):
+    new = {}
+    for k, v in module.state_dict().items():
+        if k.endswith('num_batches_tracked'):
+            new[k] = v
+        elif k.endswith('running_var') or k.endswith('batch_norm.weight'):
+            new[k] = torch.from_numpy(det_fill(tuple(v.shape), f'{tag}/{k}', 0.2, 1.0))
+        elif k.endswith('linear.weight'):
+            new[k] = torch.from_numpy(det_fill(tuple(v.shape), f'{tag}/{k}', 1.2 / np.sqrt(v.shape[1])))
+        elif 'embedding_list' in k or k == 'node_embedding':
+            new[k] = torch.from_numpy(det_fill(tuple(v.shape), f'{tag}/{k}', 1.0))
+        else:
+            new[k] = torch.from_numpy(det_fill(tuple(v.shape), f'{tag}/{k}', 0.2))
+    module.load_state_dict(new)
+
+
+@pytest.mark.parametrize('L', [7, 4])
+def test_full_yml_config_vs_reference_fixture(amd, L):
+    """pre-train_QM9.yml dimensions (F=200, target 256; L=7 as in the yml, L=4 as in BASELINE.json)."""
+    z = load('full_config.npz')
+    mols = mols_from_npz(z)
+    pna = amd.PNA(avg_d=1.0, device='cuda:0', **dict(PNA_YML, propagation_depth=L))
+    net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_YML)
+    _det_load(pna, f'pna{L}')
+    _det_load(net, 'net3d')
+    pna.cuda().train(), net.cuda().train()
+    g2, g3 = make_batch(amd, mols)
+    z2, z3 = pna(g2), net(g3)
+    loss = amd.NTXent(tau=0.1)(z2, z3)
+    loss.backward()
+    assert abs(loss.item() - float(z[f'L{L}/loss'])) < TOL * abs(float(z[f'L{L}/loss']))
+    assert rel_err(z2.cpu(), z[f'L{L}/pna_out']) < TOL
+    assert rel_err(z3.cpu(), z[f'L{L}/net3d_out']) < TOL
+    emb = g2.ndata['feat']
+    assert rel_err(emb[::7].cpu(), z[f'L{L}/node_emb_rows']) < TOL
+    w = pna.node_gnn.mp_layers[0].posttrans.fully_connected[0].linear.weight.grad
+    assert rel_err(w[::16, ::64].cpu(), z[f'L{L}/pna_grad_sample/post0_w']) < 2e-3
+    w = pna.node_gnn.mp_layers[L - 1].pretrans.fully_connected[0].linear.weight.grad
+    assert rel_err(w[::16, ::32].cpu(), z[f'L{L}/pna_grad_sample/preL_w']) < 2e-3
+    ref = {k: z[f'L{L}/net3d_grad/{k}'] for k, _ in net.named_parameters()}
+    grads_close(param_grads(net), ref, 2e-3, 'net3d ')
+
+
+def test_batch64_vs_oracle_fwd_bwd(amd):
+    """A bigger seeded batch (64 QM9-shaped molecules, F=200, L=2): forward, loss, and every parameter gradient
+    against the oracle."""
+    mols = synth.make_dataset(64, seed=5)
+    kw2 = dict(PNA_YML, propagation_depth=2)
+    pna = amd.PNA(avg_d=1.0, device='cuda:0', **kw2)
+    net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_YML)
+    _det_load(pna, 'pnaX')
+    _det_load(net, 'net3dX')
+    P2 = O.require_grad({k: v.clone() for k, v in pna.state_dict().items()})
+    P3 = O.require_grad({k: v.clone() for k, v in net.state_dict().items()})
+    og2, og3 = O.graphs_from_molecules(mols)
+    r2, remb = O.pna_forward(og2, P2, O.pna_config(**kw2), True)
+    r3, _ = O.net3d_forward(og3, P3, O.net3d_config(**NET3D_YML), True)
+    rloss = O.ntxent(r2, r3, 0.1)
+    rloss.backward()
+    pna.cuda().train(), net.cuda().train()
+    g2, g3 = make_batch(amd, mols)
+    z2, z3 = pna(g2), net(g3)
+    loss = amd.NTXent(tau=0.1)(z2, z3)
+    loss.backward()
+    assert abs(loss.item() - rloss.item()) < TOL * abs(rloss.item())
+    assert rel_err(g2.ndata['feat'].cpu(), remb.detach()) < TOL
+    assert rel_err(z2.cpu(), r2.detach()) < TOL and rel_err(z3.cpu(), r3.detach()) < TOL
+    grads_close(param_grads(pna), {k: P2[k].grad for k in O.trainable(P2)}, 1e-3, 'pna ')
+    grads_close(param_grads(net), {k: P3[k].grad for k in O.trainable(P3)}, 1e-3, 'net3d ')
+
+
+def test_missing_library_fails_loudly(amd, monkeypatch):
+    L = importlib.import_module('3dinfomax_amd._lib')
+    monkeypatch.setattr(L, '_lib', None)
+    monkeypatch.setattr(L, 'LIB_PATH', '/nonexistent/lib3dinfomax_hip.so')
+    with pytest.raises(L.HipLibraryError):
+        L.load()

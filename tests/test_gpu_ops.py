@@ -1,0 +1,275 @@
+"""-m gpu: every HIP kernel, called through the C ABI (3dinfomax_amd/ops.py -> ctypes -> lib3dinfomax_hip.so),
+against plain fp32/fp64 torch on the CPU or the oracle.  Tolerances are written next to each check:
+the bar of BASELINE.json:north_star is 1e-4 relative fp32; the kernels are held to ~1e-5."""
+import importlib
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err
+from oracle import pna3d_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ops = None
+DEV = None
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _gpu():
+    global ops, DEV
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    ops = importlib.import_module('3dinfomax_amd.ops')
+    DEV = torch.device('cuda:0')
+    yield
+
+
+def g(t):
+    return t.to(DEV)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+# ---- GEMM ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K', [(64, 200, 200), (1000, 200, 600), (777, 200, 2600), (513, 400, 200), (300, 256, 200),
+                                   (5000, 20, 9), (5000, 20, 60), (33, 8, 7), (1, 1, 1), (129, 208, 17)])
+@pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm_matches_fp64(M, N, K, ta, tb):
+    A = rnd(*((K, M) if ta else (M, K)), seed=1)
+    B = rnd(*((N, K) if tb else (K, N)), seed=2)
+    bias = rnd(N, seed=3)
+    ref = (A.double().T if ta else A.double()) @ (B.double().T if tb else B.double()) + bias.double()
+    out = ops.gemm(g(A), g(B), trans_a=ta, trans_b=tb, bias=g(bias))
+    # fp32 fmaf chain vs fp64: error ~ 1e-7 * sum|a*b|  (MI355X guide, section 3)
+    tol = 3e-6 * (A.abs().max() * B.abs().max() * K).item() / max(ref.abs().max().item(), 1e-30)
+    assert rel_err(out.cpu(), ref) < max(tol, 1e-5)
+
+
+def test_gemm_weight_grad_split_k_and_strided_views():
+    rows, Fo, Fi = 20000, 200, 2600
+    dY, X = rnd(rows, Fo, seed=4, scale=0.1), rnd(rows, Fi, seed=5)
+    ref = dY.double().T @ X.double()
+    out = ops.gemm(g(dY), g(X), trans_a=True)                 # split-K with atomics
+    assert rel_err(out.cpu(), ref) < 2e-5
+    # column-slice views as operands and as output (leading dimension != width), accumulate on top
+    W = rnd(Fo, Fi, seed=6)
+    Wg = g(W)
+    h, agg = rnd(1000, 200, seed=7), rnd(1000, 2400, seed=8)
+    y = ops.gemm(g(h), Wg[:, :200], trans_b=True)
+    ops.gemm(g(agg), Wg[:, 200:], trans_b=True, out=y, accumulate=True)
+    ref = torch.cat([h, agg], 1).double() @ W.double().T
+    assert rel_err(y.cpu(), ref) < 1e-5
+    gW = torch.zeros(Fo, Fi, device=DEV)
+    ops.gemm(g(dY[:1000]), g(h), trans_a=True, out=gW[:, :200])
+    ops.gemm(g(dY[:1000]), g(agg), trans_a=True, out=gW[:, 200:])
+    ref = dY[:1000].double().T @ torch.cat([h, agg], 1).double()
+    assert rel_err(gW.cpu(), ref) < 2e-5
+
+
+# ---- K4 aggregation --------------------------------------------------------------------------------------
+def _random_csr(n, max_deg, seed, zero_frac=0.1):
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(1, max_deg + 1, size=n)
+    deg[rng.random(n) < zero_frac] = 0
+    dst = np.repeat(np.arange(n), deg)
+    ptr = np.zeros(n + 1, dtype=np.int32)
+    ptr[1:] = np.cumsum(deg)
+    return torch.from_numpy(dst), torch.from_numpy(ptr)
+
+
+@pytest.mark.parametrize('feat', [200, 20, 7])
+@pytest.mark.parametrize('aggs,scalers', [(['mean', 'max', 'min', 'std'], ['identity', 'amplification', 'attenuation']),
+                                         (['sum', 'var', 'max'], ['identity']),
+                                         (['mean', 'std'], ['attenuation', 'identity'])])
+def test_pna_aggregate_fwd_bwd_vs_oracle(feat, aggs, scalers):
+    n = 300
+    dst, ptr = _random_csr(n, 6, seed=feat)
+    E = dst.shape[0]
+    e = rnd(E, feat, seed=11)
+    # exact ties: duplicate the first message of every node with degree >= 2 into its second slot
+    for v in range(n):
+        if ptr[v + 1] - ptr[v] >= 2:
+            e[ptr[v] + 1] = e[ptr[v]]
+    e_ref = e.clone().requires_grad_(True)
+    n_out = len(aggs) * (len(scalers) if len(scalers) > 1 else 1) * feat
+    ref = O.degree_bucketed_reduce(e_ref, dst, n, lambda mb, D: O.pna_reduce(mb, D, aggs, scalers), n_out)
+    cot = rnd(n, n_out, seed=12)
+    (ref * cot).sum().backward()
+    ac, sc = ops.agg_codes(aggs), ops.scaler_codes(scalers)
+    out = ops.pna_aggregate_fwd(g(e), g(ptr), n, ac, sc)
+    assert rel_err(out.cpu(), ref.detach()) < 1e-6
+    ge = ops.pna_aggregate_bwd(g(cot), g(e), g(ptr), n, ac, sc)
+    # first-index tie routing as torch CPU; std gradient re-associated: 1e-5
+    assert rel_err(ge.cpu(), e_ref.grad) < 1e-5
+
+
+def test_readout_fwd_bwd():
+    sizes = [5, 1, 18, 29, 3, 9]
+    n, feat = sum(sizes), 200
+    x = rnd(n, feat, seed=20)
+    x[6 + 3] = x[6 + 1]      # tie inside graph 2
+    ptr = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32)
+    names = ['min', 'max', 'mean', 'sum']
+    xr = x.clone().requires_grad_(True)
+    ref = torch.cat([O.segment_readout(xr, sizes, op) for op in names], -1)
+    cot = rnd(len(sizes), 4 * feat, seed=21)
+    (ref * cot).sum().backward()
+    codes = ops.agg_codes(names)
+    out = ops.segment_readout_fwd(g(x), g(ptr), len(sizes), codes)
+    assert rel_err(out.cpu(), ref.detach()) < 1e-6
+    gx = ops.segment_readout_bwd(g(cot), g(x), g(ptr), len(sizes), codes)
+    assert rel_err(gx.cpu(), xr.grad) < 1e-6
+
+
+# ---- K1 embedding ----------------------------------------------------------------------------------------
+def test_embedding_sum_fwd_bwd_with_row_perm():
+    dims, feat, rows = [119, 5, 12, 12, 10, 6, 6, 2, 2], 200, 1000
+    gen = torch.Generator().manual_seed(3)
+    idx = torch.stack([torch.randint(0, d, (rows,), generator=gen) for d in dims], 1)
+    tabs = [rnd(d, feat, seed=30 + i).requires_grad_(True) for i, d in enumerate(dims)]
+    perm = torch.randperm(rows, generator=gen)
+    ref = sum(F.embedding(idx[perm][:, k], tabs[k]) for k in range(len(dims)))
+    cot = rnd(rows, feat, seed=40)
+    (ref * cot).sum().backward()
+    out = ops.embedding_sum_fwd(g(idx), [g(t.detach()) for t in tabs], g(perm.int()))
+    assert rel_err(out.cpu(), ref.detach()) < 1e-6
+    grads = ops.embedding_sum_bwd(g(idx), g(cot), dims, g(perm.int()))
+    for gt, t in zip(grads, tabs):
+        assert rel_err(gt.cpu(), t.grad) < 1e-5     # atomics: summation order differs
+
+
+# ---- BatchNorm -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('rows,feat', [(5000, 200), (300, 20), (17, 7), (70000, 20)])
+@pytest.mark.parametrize('act,post', [('relu', None), (None, None), ('silu', 'silu')])
+def test_act_bn_fwd_bwd_vs_torch(rows, feat, act, post):
+    pre = rnd(rows, feat, seed=50) + 3.0            # large mean: exercises the shifted statistics
+    gamma, beta = rnd(feat, seed=51) * 0.2 + 1, rnd(feat, seed=52) * 0.2
+    res = rnd(rows, feat, seed=53)
+    rm, rv = torch.zeros(feat), torch.ones(feat)
+    acts = {'relu': F.relu, 'silu': F.silu, None: lambda t: t}
+    pr = pre.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    x = acts[act](pr)
+    y = acts[post](F.batch_norm(x, rm, rv, gr, br, True, 0.93, 1e-5)) + res
+    cot = rnd(rows, feat, seed=54)
+    (y * cot).sum().backward()
+    rm_g, rv_g = torch.zeros(feat, device=DEV), torch.ones(feat, device=DEV)
+    pre_g = g(pre)
+    keep = act not in (None, 'relu')
+    xg, mean, invstd = ops.act_stats_fwd(pre_g.clone(), act, 1e-5, 0.93, rm_g, rv_g,
+                                         out=torch.empty_like(pre_g) if keep else None)
+    yg = ops.bn_apply_fwd(xg, mean, invstd, g(gamma), g(beta), post, g(res))
+    assert rel_err(yg.cpu(), y.detach()) < 2e-5
+    assert rel_err(rm_g.cpu(), rm) < 1e-5 and rel_err(rv_g.cpu(), rv) < 1e-5
+    gp, gg, gb = ops.bn_bwd(g(cot), xg, pre_g if keep else None, act, post, mean, invstd, g(gamma), g(beta))
+    assert rel_err(gp.cpu(), pr.grad) < 5e-5
+    assert rel_err(gg.cpu(), gr.grad) < 5e-5 and rel_err(gb.cpu(), br.grad) < 5e-5
+    # eval mode
+    with torch.no_grad():
+        y_eval = acts[post](F.batch_norm(acts[act](pre), rm, rv, gamma, beta, False, 0.93, 1e-5)) + res
+    x_eval = ops.act_fwd(pre_g, act) if act else pre_g
+    ye = ops.bn_eval_fwd(x_eval, g(rm), g(rv), 1e-5, g(gamma), g(beta), post, g(res))
+    assert rel_err(ye.cpu(), y_eval) < 2e-5
+
+
+def test_colsum_and_elementwise():
+    x, w = rnd(3000, 200, seed=60), rnd(3000, seed=61)
+    assert rel_err(ops.colsum(g(x)).cpu(), x.double().sum(0)) < 1e-5
+    assert rel_err(ops.colsum(g(x), g(w)).cpu(), (x.double() * w.double()[:, None]).sum(0)) < 1e-5
+    for act, fn in (('relu', F.relu), ('silu', F.silu), ('sigmoid', torch.sigmoid)):
+        xr = x.clone().requires_grad_(True)
+        fn(xr).backward(torch.ones_like(x))
+        assert rel_err(ops.act_fwd(g(x), act).cpu(), fn(x)) < 1e-6
+        assert rel_err(ops.act_bwd(g(torch.ones_like(x)), g(x), act).cpu(), xr.grad) < 1e-5
+    a = g(x.clone())
+    assert rel_err(ops.add_inplace(a, g(x)).cpu(), 2 * x) < 1e-7
+
+
+# ---- edge kernels ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize('feat', [200, 20])
+def test_edge_combine_and_segment_ops(feat):
+    n = 200
+    dst, ptr = _random_csr(n, 5, seed=70, zero_frac=0.05)
+    E = dst.shape[0]
+    gen = torch.Generator().manual_seed(7)
+    src = torch.randint(0, n, (E,), generator=gen)
+    P, Q, b = rnd(n, 2 * feat, seed=71), rnd(E, feat, seed=72), rnd(feat, seed=73)
+    ref = P[src, :feat] + P[dst, feat:] + Q + b
+    out = ops.edge_combine_fwd(g(P), g(Q), g(b), g(src.int()), g(dst.int()))
+    assert rel_err(out.cpu(), ref) < 1e-6
+    out = ops.edge_combine_fwd(g(P), None, None, g(src.int()), g(dst.int()))
+    assert rel_err(out.cpu(), P[src, :feat] + P[dst, feat:]) < 1e-6
+    # segment sums: by destination (contiguous) and by source (through an index list)
+    x = rnd(E, feat, seed=74)
+    ref_in = torch.zeros(n, feat).index_add(0, dst, x)
+    assert rel_err(ops.segment_sum(g(x), g(ptr), None, n).cpu(), ref_in) < 1e-6
+    deg = torch.bincount(dst, minlength=n).clamp(min=1).float()
+    assert rel_err(ops.segment_sum(g(x), g(ptr), None, n, mean=True).cpu(), ref_in / deg[:, None]) < 1e-6
+    order = torch.sort(src, stable=True)[1]
+    optr = torch.zeros(n + 1, dtype=torch.int32)
+    optr[1:] = torch.cumsum(torch.bincount(src, minlength=n), 0)
+    ref_out = torch.zeros(n, feat).index_add(0, src, x)
+    buf = torch.zeros(n, 2 * feat, device=DEV)
+    ops.segment_sum(g(x), g(optr), g(order.int()), n, out=buf[:, feat:])          # strided output view
+    assert rel_err(buf[:, feat:].cpu(), ref_out) < 1e-6
+    gn = rnd(n, feat, seed=75)
+    assert rel_err(ops.segment_bcast(g(gn), g(ptr), g(dst.int()), E, mean=True).cpu(), (gn / deg[:, None])[dst]) < 1e-6
+    perm = torch.randperm(E, generator=gen).int()
+    assert torch.equal(ops.gather_rows(g(x), g(perm)).cpu(), x[perm.long()])
+
+
+def test_fourier_and_soft_edge():
+    d = torch.rand(5000, generator=torch.Generator().manual_seed(1)) * 8 + 0.5
+    ref = O.fourier_encode_dist(d[:, None], 4)
+    assert rel_err(ops.fourier_encode(g(d), 4).cpu(), ref) < 1e-6
+    E, H = 4000, 20
+    m = rnd(E, H, seed=80).requires_grad_(True)
+    ws, bs = rnd(1, H, seed=81).requires_grad_(True), rnd(1, seed=82).requires_grad_(True)
+    w = torch.sigmoid(F.linear(m, ws, bs))
+    msg = m * w
+    cot = rnd(E, H, seed=83)
+    (msg * cot).sum().backward()
+    mg, wg = ops.soft_edge_fwd(g(m.detach()), g(ws.detach()), g(bs.detach()))
+    assert rel_err(mg.cpu(), msg.detach()) < 1e-6
+    gm, gg = ops.soft_edge_bwd(g(cot), g(m.detach()), wg, g(ws.detach()))
+    assert rel_err(gm.cpu(), m.grad) < 1e-5
+    assert rel_err(ops.colsum(g(m.detach()), gg).cpu(), ws.grad.view(-1)) < 1e-5
+    assert rel_err(ops.colsum(gg.view(-1, 1)).cpu(), bs.grad) < 1e-5
+
+
+# ---- NT-Xent ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B,dim,conf', [(8, 256, 1), (64, 64, 1), (512, 256, 1), (8, 256, 3), (500, 256, 3)])
+def test_ntxent_fwd_bwd_vs_oracle(B, dim, conf):
+    losses = importlib.import_module('3dinfomax_amd.losses')
+    z1 = rnd(B, dim, seed=90).requires_grad_(True)
+    z2 = rnd(B * conf, dim, seed=91).requires_grad_(True)
+    ref = O.ntxent(z1, z2, 0.1) if conf == 1 else O.ntxent_multiple_positives(z1, z2, 0.1)
+    ref.backward()
+    a, b = g(z1.detach()).requires_grad_(True), g(z2.detach()).requires_grad_(True)
+    loss_mod = losses.NTXent(tau=0.1) if conf == 1 else losses.NTXentMultiplePositives(tau=0.1)
+    loss = loss_mod(a, b)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+    assert rel_err(a.grad.cpu(), z1.grad) < 2e-5
+    assert rel_err(b.grad.cpu(), z2.grad) < 2e-5
+
+
+def test_ntxent_row_sharded_equals_full():
+    """Data-parallel form on one device: shares over row shards with pos_offset sum to the full loss/grads."""
+    losses = importlib.import_module('3dinfomax_amd.losses')
+    B, dim, world = 64, 128, 4
+    z1, z2 = g(rnd(B, dim, seed=92)), g(rnd(B, dim, seed=93))
+    full1, full2 = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+    full = losses.NTXentFn.apply(full1, full2, 0.1, 1e-8, 1, 0, B)
+    full.backward()
+    s1, s2 = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+    per = B // world
+    total = sum(losses.NTXentFn.apply(s1[r * per:(r + 1) * per], s2, 0.1, 1e-8, 1, r * per, B) for r in range(world))
+    total.backward()
+    assert abs(total.item() - full.item()) < 1e-6 * abs(full.item())
+    assert rel_err(s1.grad.cpu(), full1.grad.cpu()) < 1e-5 and rel_err(s2.grad.cpu(), full2.grad.cpu()) < 1e-5
