@@ -10,7 +10,7 @@
 
 namespace i3d {
 
-constexpr int MAX_PARTIAL_BLOCKS = 1024;
+constexpr int MAX_PARTIAL_BLOCKS = 256;   // ~ one partial block per CU; stage 2 reduces them with 8 lanes per column
 
 struct Chunking {
     int tpr;       // threads per row (column vectors handled in parallel)
@@ -141,16 +141,38 @@ __global__ void __launch_bounds__(256) colreduce_partial_kernel(ReduceArgs g, Ch
 }
 
 // ---- stage 2 ----------------------------------------------------------------------------------------
+// 256 threads = 32 columns x 8 partial-lanes: coalesced reads of the chunk partials, fp64 accumulation, one LDS
+// hop.  (A one-thread-per-column loop over the partials was latency-bound: 130-150 us per call, 40 % of the step.)
+constexpr int FIN_COLS = 32, FIN_LANES = 8;
+
+__device__ __forceinline__ bool reduce_partials(const float* __restrict__ partial, int nblk, int feat, int& c,
+                                                double& s1, double& s2) {
+    __shared__ double sm[2][FIN_LANES][FIN_COLS];
+    const int cx = threadIdx.x & (FIN_COLS - 1), ly = threadIdx.x / FIN_COLS;
+    c = blockIdx.x * FIN_COLS + cx;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < feat) {
+        for (int b = ly; b < nblk; b += FIN_LANES) {
+            a1 += (double)partial[(long)b * 2 * feat + c];
+            a2 += (double)partial[(long)b * 2 * feat + feat + c];
+        }
+    }
+    sm[0][ly][cx] = a1;
+    sm[1][ly][cx] = a2;
+    __syncthreads();
+    if (ly != 0 || c >= feat) return false;
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < FIN_LANES; ++k) { s1 += sm[0][k][cx]; s2 += sm[1][k][cx]; }
+    return true;
+}
+
 __global__ void stats_final_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ pre_row0,
                                    int act, int rows, int feat, float eps, float momentum, float* mean, float* invstd,
                                    float* running_mean, float* running_var, double* sums_out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= feat) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += (double)partial[(long)b * 2 * feat + c];
-        s2 += (double)partial[(long)b * 2 * feat + feat + c];
-    }
+    int c;
+    double s1, s2;
+    if (!reduce_partials(partial, nblk, feat, c, s1, s2)) return;
     double shift = (double)apply_act(pre_row0[c], act);
     double n = (double)rows;
     if (sums_out != nullptr) {   // synchronised BN: hand un-shifted fp64 sums to the all-reduce
@@ -191,13 +213,9 @@ __global__ void stats_from_sums_kernel(const double* __restrict__ sums, int feat
 // sums of the two partial columns -> out1[feat], out2[feat] (fp32) or fp64 sums_out[2*feat]
 __global__ void pair_final_kernel(const float* __restrict__ partial, int nblk, int feat, float* out1, float* out2,
                                   double* sums_out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= feat) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += (double)partial[(long)b * 2 * feat + c];
-        s2 += (double)partial[(long)b * 2 * feat + feat + c];
-    }
+    int c;
+    double s1, s2;
+    if (!reduce_partials(partial, nblk, feat, c, s1, s2)) return;
     if (sums_out != nullptr) {
         sums_out[c] = s1;
         sums_out[feat + c] = s2;
@@ -372,7 +390,7 @@ extern "C" int i3d_act_stats_fwd(const float* pre, int rows, int feat, int act, 
     g.partial = (float*)workspace;
     launch_partial<MODE_STATS>(g, ch, s);
     I3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(stats_final_kernel, dim3(cdiv(feat, 128)), dim3(128), 0, s, g.partial, ch.nblk, pre, act, rows,
+    hipLaunchKernelGGL(stats_final_kernel, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, s, g.partial, ch.nblk, pre, act, rows,
                        feat, eps, momentum, mean, invstd, running_mean, running_var, sums_out);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
@@ -449,7 +467,7 @@ extern "C" int i3d_bn_bwd(const float* grad_y, const float* x, const float* pre,
         g.rows = rows; g.feat = feat; g.act = act; g.post_act = post_act; g.partial = partial;
         launch_partial<MODE_BN_BWD>(g, ch, s);
         I3D_CHECK_LAUNCH();
-        hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(feat, 128)), dim3(128), 0, s, partial, ch.nblk, feat, grad_beta,
+        hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, s, partial, ch.nblk, feat, grad_beta,
                            grad_gamma, sums_out);
         I3D_CHECK_LAUNCH();
         if (sums_out != nullptr) return I3D_OK;   // caller all-reduces, then calls again with sums_in
@@ -493,7 +511,7 @@ extern "C" int i3d_bn_eval_bwd(const float* grad_y, const float* x, const float*
     g.rows = rows; g.feat = feat; g.act = act; g.post_act = post_act; g.partial = partial;
     launch_partial<MODE_BN_BWD>(g, ch, s);
     I3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(feat, 128)), dim3(128), 0, s, partial, ch.nblk, feat, grad_beta,
+    hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, s, partial, ch.nblk, feat, grad_beta,
                        grad_gamma, (double*)nullptr);
     I3D_CHECK_LAUNCH();
     BwdApplyArgs b;
@@ -516,7 +534,7 @@ extern "C" int i3d_colsum(const float* x, const float* w, int rows, int feat, fl
     g.a = x; g.b = w; g.rows = rows; g.feat = feat; g.partial = (float*)workspace;
     launch_partial<MODE_COLSUM>(g, ch, s);
     I3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(feat, 128)), dim3(128), 0, s, g.partial, ch.nblk, feat, out,
+    hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, s, g.partial, ch.nblk, feat, out,
                        (float*)nullptr, (double*)nullptr);
     I3D_CHECK_LAUNCH();
     return I3D_OK;

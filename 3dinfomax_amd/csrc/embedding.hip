@@ -70,6 +70,51 @@ embedding_sum_bwd_kernel(const int64_t* __restrict__ idx, const int* __restrict_
     }
 }
 
+// LDS-privatised variant (tables with <= 192 rows in total: the ogb atom tables are 173 rows, bond tables 13):
+// a workgroup owns a chunk of rows and a 64-feature slice, accumulates into a [192][64] LDS copy of the tables with
+// ds_add_f32 (a wave hits 64 consecutive floats of one table row: conflict-free) and flushes only the touched
+// entries with global atomics - ~10x fewer L2 atomics and no hot-row serialisation (240 us -> see profiles/).
+constexpr int LDS_TAB_ROWS = 192, LDS_FW = 64;
+
+__global__ void __launch_bounds__(256)
+embedding_sum_bwd_lds_kernel(const int64_t* __restrict__ idx, const int* __restrict__ row_perm, int rows, int n_cols,
+                             const float* __restrict__ gout, int feat, GradTables tabs, int rows_per_block) {
+    __shared__ float acc[LDS_TAB_ROWS * LDS_FW];
+    __shared__ int off[MAX_TABLES + 1];
+    const int t = threadIdx.x;
+    if (t == 0) {
+        int o = 0;
+        for (int k = 0; k < n_cols; ++k) { off[k] = o; o += tabs.dim[k]; }
+        off[n_cols] = o;
+    }
+    for (int i = t; i < LDS_TAB_ROWS * LDS_FW; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    const int f = t & (LDS_FW - 1), rl = t / LDS_FW;
+    const int fg = blockIdx.y * LDS_FW + f;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    if (fg < feat) {
+        for (int r = r0 + rl; r < r1; r += 256 / LDS_FW) {
+            const float g = gout[(long)r * feat + fg];
+            const long ir = row_perm ? row_perm[r] : r;
+            for (int k = 0; k < n_cols; ++k) {
+                const int row = off[k] + (int)idx[ir * n_cols + k];
+                atomicAdd(&acc[row * LDS_FW + f], g);
+            }
+        }
+    }
+    __syncthreads();
+    const int total = off[n_cols];
+    for (int i = t; i < total * LDS_FW; i += 256) {
+        const int row = i / LDS_FW, ff = blockIdx.y * LDS_FW + (i & (LDS_FW - 1));
+        const float v = acc[i];
+        if (v != 0.f && ff < feat) {
+            int k = 0;
+            while (row >= off[k + 1]) ++k;
+            unsafeAtomicAdd(tabs.t[k] + (long)(row - off[k]) * feat + ff, v);
+        }
+    }
+}
+
 }  // namespace i3d
 
 using namespace i3d;
@@ -112,9 +157,19 @@ extern "C" int i3d_embedding_sum_bwd(const int64_t* idx, const int* row_perm, in
         tabs.t[k] = k < n_cols ? grad_tables[k] : nullptr;
         tabs.dim[k] = (k < n_cols && dims) ? dims[k] : 0;
     }
-    long items = (long)rows * feat;
-    hipLaunchKernelGGL(embedding_sum_bwd_kernel, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, idx, row_perm,
-                       rows, n_cols, grad_out, feat, tabs);
+    int total_rows = 0;
+    for (int k = 0; k < n_cols; ++k) total_rows += tabs.dim[k];
+    if (dims != nullptr && total_rows > 0 && total_rows <= LDS_TAB_ROWS) {
+        int rpb = cdiv(rows, 128);
+        if (rpb < 32) rpb = 32;
+        dim3 grid(cdiv(rows, rpb), cdiv(feat, LDS_FW));
+        hipLaunchKernelGGL(embedding_sum_bwd_lds_kernel, grid, dim3(256), 0, (hipStream_t)stream, idx, row_perm, rows,
+                           n_cols, grad_out, feat, tabs, rpb);
+    } else {
+        long items = (long)rows * feat;
+        hipLaunchKernelGGL(embedding_sum_bwd_kernel, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, idx,
+                           row_perm, rows, n_cols, grad_out, feat, tabs);
+    }
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }

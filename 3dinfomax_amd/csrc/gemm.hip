@@ -36,6 +36,7 @@ struct GemmArgs {
     int k_per_split; // multiple of BK
     int atomic_out;  // split-K: atomicAdd into C
     int a_vec, b_vec, c_vec;  // 16-byte access allowed (pointer + leading dimension aligned)
+    unsigned a_bytes, b_bytes;  // extent of the operand views in bytes (buffer descriptor num_records)
 };
 
 constexpr int BK = 16;
@@ -50,42 +51,38 @@ struct TileStage {
 
     // kcontig: slot -> (idx = s / 4, kq = s % 4), 4 consecutive k of one row
     // else   : slot -> (k = s / (R/4), iq = s % (R/4)), 4 consecutive idx of one k
-    __device__ __forceinline__ void load(const float* __restrict__ p, int ld, int kcontig, int vec, int idx0,
+    // BRANCH-FREE through the buffer descriptor: every lane issues the load, lanes outside the matrix pass an
+    // offset beyond num_records and the hardware returns 0 - no per-lane branch, no select, so hipcc keeps the
+    // loads in flight across the MFMA block and waits (counted vmcnt) only in front of the LDS store.  Per-lane
+    // branches around the loads made it serialise them behind vmcnt(0) (MI355X guide 5, trap (c)): 3.5x slower.
+    // VEC: one 16-byte load per slot (pointer/ld 16-byte aligned and the contiguous extent a multiple of 4).
+    template <bool VEC>
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, unsigned oob, int ld, int kcontig, int idx0,
                                          int idx_max, int k0, int k_end) {
 #pragma unroll
         for (int it = 0; it < PER_THREAD; ++it) {
             int s = threadIdx.x + it * 256;
-            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s < SLOTS) {
-                if (kcontig) {
-                    int idx = idx0 + (s >> 2), k = k0 + (s & 3) * 4;
-                    if (idx < idx_max && k < k_end) {
-                        const float* q = p + (long)idx * ld + k;
-                        if (vec && k + 3 < k_end) {
-                            r = *reinterpret_cast<const float4*>(q);
-                        } else {
-                            r.x = q[0];
-                            if (k + 1 < k_end) r.y = q[1];
-                            if (k + 2 < k_end) r.z = q[2];
-                            if (k + 3 < k_end) r.w = q[3];
-                        }
-                    }
-                } else {
-                    int k = k0 + s / (R / 4), idx = idx0 + (s % (R / 4)) * 4;
-                    if (k < k_end && idx < idx_max) {
-                        const float* q = p + (long)k * ld + idx;
-                        if (vec && idx + 3 < idx_max) {
-                            r = *reinterpret_cast<const float4*>(q);
-                        } else {
-                            r.x = q[0];
-                            if (idx + 1 < idx_max) r.y = q[1];
-                            if (idx + 2 < idx_max) r.z = q[2];
-                            if (idx + 3 < idx_max) r.w = q[3];
-                        }
-                    }
+            int idx, k;
+            if (kcontig) { idx = idx0 + (s >> 2); k = k0 + (s & 3) * 4; }
+            else { k = k0 + s / (R / 4); idx = idx0 + (s % (R / 4)) * 4; }
+            if (VEC) {
+                // contiguous extent is a multiple of 4: a valid first element implies a valid float4
+                const bool ok = idx < idx_max && k < k_end && s < SLOTS;
+                const unsigned off = kcontig ? (unsigned)(idx * ld + k) * 4u : (unsigned)(k * ld + idx) * 4u;
+                auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off : oob, 0, 0);
+                static_assert(sizeof(r) == 16, "b128 load");
+                v[it] = __builtin_bit_cast(float4, r);
+            } else {
+                float e[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = kcontig ? k + u : k, ii = kcontig ? idx : idx + u;
+                    const bool ok = ii < idx_max && kk < k_end && s < SLOTS;
+                    const unsigned off = kcontig ? (unsigned)(ii * ld + kk) * 4u : (unsigned)(kk * ld + ii) * 4u;
+                    e[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ok ? off : oob, 0, 0));
                 }
+                v[it] = make_float4(e[0], e[1], e[2], e[3]);
             }
-            v[it] = r;
         }
     }
 
@@ -109,7 +106,7 @@ struct TileStage {
     }
 };
 
-template <int WAVES_M, int WAVES_N, int WM_T, int WN_T>
+template <int WAVES_M, int WAVES_N, int WM_T, int WN_T, bool VEC>
 __global__ void __launch_bounds__(256)
 gemm_f32_kernel(GemmArgs g) {
     constexpr int BM = WAVES_M * WM_T * 16, BN = WAVES_N * WN_T * 16;
@@ -132,10 +129,13 @@ gemm_f32_kernel(GemmArgs g) {
 
     TileStage<BM, LDA> sa;
     TileStage<BN, LDB> sb;
+    // descriptors are built from kernel arguments only (provably wave-uniform: no waterfall loops, guide T20)
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, g.b_bytes, 0x00020000);
     const int nk = (k_end - k_begin + BK - 1) / BK;
     if (nk > 0) {
-        sa.load(g.A, g.lda, g.a_kcontig, g.a_vec, m0, g.M, k_begin, k_end);
-        sb.load(g.B, g.ldb, g.b_kcontig, g.b_vec, n0, g.N, k_begin, k_end);
+        sa.template load<VEC>(ra, g.a_bytes, g.lda, g.a_kcontig, m0, g.M, k_begin, k_end);
+        sb.template load<VEC>(rb, g.b_bytes, g.ldb, g.b_kcontig, n0, g.N, k_begin, k_end);
         sa.store(As[0], g.a_kcontig);
         sb.store(Bs[0], g.b_kcontig);
     }
@@ -144,8 +144,8 @@ gemm_f32_kernel(GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            sa.load(g.A, g.lda, g.a_kcontig, g.a_vec, m0, g.M, k_begin + (kt + 1) * BK, k_end);
-            sb.load(g.B, g.ldb, g.b_kcontig, g.b_vec, n0, g.N, k_begin + (kt + 1) * BK, k_end);
+            sa.template load<VEC>(ra, g.a_bytes, g.lda, g.a_kcontig, m0, g.M, k_begin + (kt + 1) * BK, k_end);
+            sb.template load<VEC>(rb, g.b_bytes, g.ldb, g.b_kcontig, n0, g.N, k_begin + (kt + 1) * BK, k_end);
         }
         const float* as = As[cur];
         const float* bs = Bs[cur];
@@ -209,18 +209,35 @@ gemm_f32_kernel(GemmArgs g) {
 }
 
 template <int WAVES_M, int WAVES_N, int WM_T, int WN_T>
-static void launch(const GemmArgs& g, int splits, hipStream_t s) {
+static void launch(const GemmArgs& g, int splits, bool vec, hipStream_t s) {
     constexpr int BM = WAVES_M * WM_T * 16, BN = WAVES_N * WN_T * 16;
     dim3 grid(cdiv(g.M, BM), cdiv(g.N, BN), splits);
-    hipLaunchKernelGGL((gemm_f32_kernel<WAVES_M, WAVES_N, WM_T, WN_T>), grid, dim3(256), 0, s, g);
+    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<WAVES_M, WAVES_N, WM_T, WN_T, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<WAVES_M, WAVES_N, WM_T, WN_T, false>), grid, dim3(256), 0, s, g);
 }
 
 }  // namespace i3d
 
 using namespace i3d;
 
+static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                     float* C, int ldc, const float* bias, int accumulate, int force_cfg, int force_splits,
+                     void* stream);
+
 extern "C" int i3d_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
                             int ldb, float* C, int ldc, const float* bias, int accumulate, void* stream) {
+    return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, -1, 0, stream);
+}
+
+extern "C" int i3d_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
+                               int ldb, float* C, int ldc, const float* bias, int accumulate, int tile_cfg,
+                               int splits, void* stream) {
+    return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, tile_cfg, splits, stream);
+}
+
+static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                     float* C, int ldc, const float* bias, int accumulate, int force_cfg, int force_splits,
+                     void* stream) {
     I3D_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "negative dimension");
     I3D_CHECK_ARG(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, "leading dimension too small");
     if (M == 0 || N == 0) return I3D_OK;
@@ -232,6 +249,13 @@ extern "C" int i3d_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
     g.a_kcontig = trans_a ? 0 : 1;
     g.b_kcontig = trans_b ? 1 : 0;
     g.accumulate = accumulate ? 1 : 0;
+    {
+        const long a_rows = trans_a ? K : M, a_cols = trans_a ? M : K, b_rows = trans_b ? N : K, b_cols = trans_b ? K : N;
+        const long ab = a_rows > 0 ? ((a_rows - 1) * lda + a_cols) * 4 : 0, bb = b_rows > 0 ? ((b_rows - 1) * ldb + b_cols) * 4 : 0;
+        I3D_CHECK_ARG(ab < (1L << 32) - 16 && bb < (1L << 32) - 16, "operand view larger than 4 GiB (32-bit buffer offsets)");
+        g.a_bytes = (unsigned)ab;
+        g.b_bytes = (unsigned)bb;
+    }
     g.a_vec = (((uintptr_t)A & 15) == 0) && (lda % 4 == 0);
     g.b_vec = (((uintptr_t)B & 15) == 0) && (ldb % 4 == 0);
     g.c_vec = (((uintptr_t)C & 15) == 0) && (ldc % 4 == 0);
@@ -239,19 +263,25 @@ extern "C" int i3d_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
     // tile configuration: the towers have N in {20, 200, 256, 400}; weight gradients have small M,N and huge K.
     int cfg;  // 0: 64x208  1: 128x208  2: 128x128  3: 256x32  4: 64x64
     int bm, bn;
+    // measured on MI355X at the step's shapes (tools/gemm_bench.py, profiles/gemm_bench_r1.log): the batch is small
+    // for a 256-CU chip, so many 64x64 tiles beat fewer big ones until there are thousands of tiles.
     if (N <= 32) { cfg = 3; bm = 256; bn = 32; }
-    else if (N > 128 && N <= 208) {
-        if (cdiv(M, 64) >= 1024) { cfg = 1; bm = 128; bn = 208; } else { cfg = 0; bm = 64; bn = 208; }
-    } else if ((long)cdiv(M, 128) * cdiv(N, 128) >= 256) { cfg = 2; bm = 128; bn = 128; }
+    else if ((long)cdiv(M, 64) * cdiv(N, 64) >= 4096) { cfg = 2; bm = 128; bn = 128; }
     else { cfg = 4; bm = 64; bn = 64; }
+    if (force_cfg >= 0) {
+        static const int BMS[5] = {64, 128, 128, 256, 64}, BNS[5] = {208, 208, 128, 32, 64};
+        I3D_CHECK_ARG(force_cfg < 5, "tile_cfg must be 0..4");
+        cfg = force_cfg; bm = BMS[cfg]; bn = BNS[cfg];
+    }
     int tiles = cdiv(M, bm) * cdiv(N, bn);
     int splits = 1;
-    if (tiles < 256 && K >= 1024) {
-        splits = cdiv(512, tiles);
-        int max_splits = K / 256;
+    if (tiles < 768) {      // split-K until ~1024 workgroups, but keep >= 512 (128 for tiny outputs) of K per split
+        splits = (1024 + tiles / 2) / tiles;
+        int max_splits = K / (tiles < 64 ? 128 : 512);
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
     }
+    if (force_splits > 0) splits = force_splits;
     int kps = cdiv(cdiv(K, splits), BK) * BK;
     if (kps < BK) kps = BK;
     splits = K > 0 ? cdiv(K, kps) : 1;
@@ -271,12 +301,15 @@ extern "C" int i3d_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
             }
         }
     }
+    // fast path: 16-byte loads need aligned pointers / leading dimensions and contiguous extents that are
+    // multiples of 4 (K for k-contiguous operands, M or N for the others)
+    const bool vec = g.a_vec && g.b_vec && ((g.a_kcontig ? K : M) % 4 == 0) && ((g.b_kcontig ? K : N) % 4 == 0);
     switch (cfg) {
-        case 0: launch<4, 1, 1, 13>(g, splits, s); break;
-        case 1: launch<4, 1, 2, 13>(g, splits, s); break;
-        case 2: launch<2, 2, 4, 4>(g, splits, s); break;
-        case 3: launch<4, 1, 4, 2>(g, splits, s); break;
-        default: launch<2, 2, 2, 2>(g, splits, s); break;
+        case 0: launch<4, 1, 1, 13>(g, splits, vec, s); break;
+        case 1: launch<4, 1, 2, 13>(g, splits, vec, s); break;
+        case 2: launch<2, 2, 4, 4>(g, splits, vec, s); break;
+        case 3: launch<4, 1, 4, 2>(g, splits, vec, s); break;
+        default: launch<2, 2, 2, 2>(g, splits, vec, s); break;
     }
     I3D_CHECK_LAUNCH();
     return I3D_OK;
