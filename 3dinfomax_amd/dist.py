@@ -1,4 +1,4 @@
-"""Data-parallel wiring over RCCL (torch.distributed backend "nccl" on ROCm; "gloo" in the CPU tests).
+"""Data-parallel wiring over RCCL (torch.distributed backend "nccl" on ROCm; "gloo" in the tests).
 
 The reference has no distributed code at all; BASELINE.json:north_star asks for molecule
 sharding across the 8 GPUs of a node.  The path shards by molecule with three exchange points:
@@ -8,15 +8,57 @@ sharding across the 8 GPUs of a node.  The path shards by molecule with three ex
       ~32 MB so a ring over xGMI moves few, large messages,
   C3  synchronised BatchNorm statistics (fp64 [sum, sumsq, count] all-reduce per BN, forward and backward -
       layers._Tail) because the reference normalises over the WHOLE batch of edges / nodes / graphs.
+
+The three collective helpers below call RCCL directly for the "nccl" backend.  For "gloo" (CPU tests, and the
+2-process-on-one-GPU parity test) device tensors are staged through the host and reduce-scatter is emulated with
+all-reduce + slice, because gloo implements neither on HIP tensors.
 """
 import torch
 import torch.distributed as dist
 
-from .layers import FCLayer
+
+def _is_gloo(group):
+    return dist.get_backend(group) == 'gloo'
+
+
+def all_reduce_sum(t, group=None):
+    if _is_gloo(group) and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def all_gather_rows(x, group=None):
+    world = dist.get_world_size(group)
+    x = x.contiguous()
+    if _is_gloo(group):
+        parts = [torch.empty_like(x, device='cpu') for _ in range(world)]
+        dist.all_gather(parts, x.cpu(), group=group)
+        return torch.cat(parts, 0).to(x.device)
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x, group=group)
+    return out
+
+
+def reduce_scatter_rows(g, group=None):
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    g = g.contiguous()
+    per = g.shape[0] // world
+    if _is_gloo(group):
+        h = g.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        return h[rank * per:(rank + 1) * per].to(g.device)
+    out = torch.empty((per,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+    dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM, group=group)
+    return out
 
 
 def setup(modules, loss=None, group=None, sync_bn=True, broadcast=True):
     """Attach `group` to every FCLayer (sync-BN) of `modules` and to the loss; broadcast rank-0 weights."""
+    from .layers import FCLayer
     group = group if group is not None else dist.group.WORLD
     for m in modules:
         for sub in m.modules():
@@ -24,8 +66,12 @@ def setup(modules, loss=None, group=None, sync_bn=True, broadcast=True):
                 sub.sync_group = group if sync_bn else None
         if broadcast:
             for t in list(m.parameters()) + list(m.buffers()):
-                dist.broadcast(t.data, src=dist.get_global_rank(group, 0) if hasattr(dist, 'get_global_rank') else 0,
-                               group=group)
+                if _is_gloo(group) and t.is_cuda:
+                    h = t.data.cpu()
+                    dist.broadcast(h, src=0, group=group)
+                    t.data.copy_(h)
+                else:
+                    dist.broadcast(t.data, src=0, group=group)
     if loss is not None and hasattr(loss, 'attach_group'):
         loss.attach_group(group)
     return group
@@ -42,7 +88,7 @@ def allreduce_grads(params, group=None, bucket_bytes=32 << 20):
         if not bucket:
             return
         flat = torch.cat([g.reshape(-1) for g in bucket])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        all_reduce_sum(flat, group)
         off = 0
         for g in bucket:
             n = g.numel()
@@ -60,9 +106,7 @@ def allreduce_grads(params, group=None, bucket_bytes=32 << 20):
 
 def global_loss(loss_share, group=None):
     """Sum of the per-rank loss shares = the reference's full-batch loss (for logging)."""
-    out = loss_share.detach().clone()
-    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group if group is not None else dist.group.WORLD)
-    return out
+    return all_reduce_sum(loss_share.detach().clone(), group if group is not None else dist.group.WORLD)
 
 
 def shard_molecules(mols, rank, world):

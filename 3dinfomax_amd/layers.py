@@ -73,11 +73,11 @@ class _Tail:
         keep_pre = spec.act not in (None, 'relu')       # silu'/sigmoid' need the pre-activation
         if bn.training:
             if bn.sync_group is not None:
-                import torch.distributed as dist
+                from . import dist as adist
                 sums = torch.empty(2 * pre.shape[1] + 1, dtype=torch.float64, device=pre.device)
                 x, _, _ = ops.act_stats_fwd(pre, spec.act, bn.eps, bn.momentum, sums_out=sums,
                                             out=torch.empty_like(pre) if keep_pre else None)
-                dist.all_reduce(sums, group=bn.sync_group)
+                adist.all_reduce_sum(sums, bn.sync_group)
                 mean, invstd = ops.bn_finalize_stats(sums, pre.shape[1], bn.eps, bn.momentum, bn.running_mean,
                                                      bn.running_var)
             else:
@@ -103,7 +103,7 @@ class _Tail:
         x, pre, mean, stat2 = saved
         if bn.training:
             if bn.sync_group is not None:
-                import torch.distributed as dist
+                from . import dist as adist
                 feat = x.shape[1]
                 sums = torch.empty(2 * feat + 1, dtype=torch.float64, device=x.device)
                 gg = torch.empty(feat, dtype=torch.float32, device=x.device)
@@ -111,7 +111,7 @@ class _Tail:
                 ops.bn_bwd(grad_y, x, pre, spec.act, spec.post_act, mean, stat2, gamma, beta, sums_out=sums,
                            grad_gamma=gg, grad_beta=gb, out=grad_y)
                 sums[2 * feat:].fill_(x.shape[0])          # local row count rides along in the all-reduce
-                dist.all_reduce(sums, group=bn.sync_group)
+                adist.all_reduce_sum(sums, bn.sync_group)
                 grad_pre, _, _ = ops.bn_bwd(grad_y, x, pre, spec.act, spec.post_act, mean, stat2, gamma, beta,
                                             sums_in=sums, grad_gamma=gg, grad_beta=gb)
                 return grad_pre, gg, gb

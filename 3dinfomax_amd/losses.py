@@ -19,20 +19,14 @@ class _AllGatherRowsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, group):
-        import torch.distributed as dist
+        from . import dist as adist
         ctx.group = group
-        world = dist.get_world_size(group)
-        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
-        return out
+        return adist.all_gather_rows(x, group)
 
     @staticmethod
     def backward(ctx, g):
-        import torch.distributed as dist
-        world = dist.get_world_size(ctx.group)
-        out = torch.empty((g.shape[0] // world,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
-        dist.reduce_scatter_tensor(out, g.contiguous(), op=dist.ReduceOp.SUM, group=ctx.group)
-        return out, None
+        from . import dist as adist
+        return adist.reduce_scatter_rows(g, ctx.group), None
 
 
 class NTXentFn(torch.autograd.Function):

@@ -136,6 +136,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
+    t_enqueue = time.perf_counter() - t0      # host time to enqueue the steps (== dt when host-bound)
     barrier()
     dt = time.perf_counter() - t0
     timers, ops.KERNEL_TIMERS = ops.KERNEL_TIMERS, None
@@ -151,10 +152,41 @@ def main():
         ms = np.array([a.elapsed_time(b) for a, b, *_ in ev])
         byts = np.array([4.0 * E * F + 4.0 * N * W + 4.0 * (N + 1) for _, _, N, E, F, W in ev])
         achieved = float(byts.sum() / (ms.sum() * 1e-3) / 1e9)
+        # the same kernel on the same resident batches, launched back to back between ONE event pair: amortises the
+        # ~3-4 us an event pair adds around a single 16 us launch (this is the figure rocprofv3's per-kernel
+        # average agrees with, profiles/r01_step_kernel_trace_*.txt)
+        aggs, scalers = ops.agg_codes(PNA_KW['aggregators']), ops.scaler_codes(PNA_KW['scalers'])
+        reps, b2b_ms, b2b_bytes = 20, 0.0, 0.0
+        for g2, _, _ in batches:
+            idx = g2.index()
+            e = torch.randn(idx.num_edges, PNA_KW['hidden_dim'], device=dev)
+            ops.pna_aggregate_fwd(e, idx.in_ptr, idx.num_nodes, aggs, scalers)
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            for _ in range(reps):
+                ops.pna_aggregate_fwd(e, idx.in_ptr, idx.num_nodes, aggs, scalers)
+            t1.record()
+            torch.cuda.synchronize()
+            b2b_ms += t0.elapsed_time(t1)
+            b2b_bytes += reps * (4.0 * idx.num_edges * 200 + 4.0 * idx.num_nodes * 2400 + 4.0 * (idx.num_nodes + 1))
+        b2b = b2b_bytes / (b2b_ms * 1e-3) / 1e9
+        # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured with
+        # rocprofv3 on this kernel and batch shape: profiles/r01_k4_pmc.txt -> traffic / algorithmic = 1.020
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_k4_pmc.json')
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                p = json.load(f)['fwd_B512']
+            traffic = int(byts.mean() * p['traffic_MB'] / p['algorithmic_MB'])
         roof = dict(bound='hbm', kernel='pna_aggregate_fwd_kernel', achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
-                    unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     launches=len(ev), avg_us=round(float(ms.mean() * 1e3), 2),
-                    algorithmic_bytes_per_launch=int(byts.mean()))
+                    algorithmic_bytes_per_launch=int(byts.mean()),
+                    achieved_back_to_back=round(b2b, 1), frac_back_to_back=round(b2b / HBM_PEAK_GBS, 4),
+                    avg_us_back_to_back=round(b2b_ms * 1e3 / (reps * len(batches)), 2),
+                    note='achieved/frac: one HIP-event pair around every K4 launch of the timed steps (includes '
+                         'event overhead); *_back_to_back: 20 launches per event pair after the timed region; '
+                         'traffic: rocprofv3 PMC bytes per launch (profiles/r01_k4_pmc.txt)')
 
     if rank == 0:
         mol_per_s = args.steps * B * world / dt
@@ -165,7 +197,8 @@ def main():
                    config=dict(workload=f'PNA hidden=200 depth={args.depth} + Net3D hidden=20 + NT-Xent tau=0.1, '
                                         f'QM9-shaped synthetic molecules, batch {B}/GPU, fp32, Adam',
                                global_batch=B * world, parallelism=f'dp{world}' if world > 1 else 'single',
-                               sync_bn=(world > 1 and not args.no_sync_bn), final_loss=round(float(loss.item()), 5)),
+                               sync_bn=(world > 1 and not args.no_sync_bn), final_loss=round(float(loss.item()), 5),
+                               host_enqueue_ms_per_step=round(t_enqueue / args.steps * 1e3, 3)),
                    roofline=roof)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(batches[0][2], args.depth, args.cpu_steps)

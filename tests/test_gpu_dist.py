@@ -1,0 +1,93 @@
+"""-m gpu: the data-parallel path THROUGH THE HIP KERNELS.  Two processes share cuda:0 (gloo stages the tiny
+collectives through the host - RCCL needs one device per rank, the driver's 8-GPU node exercises that path), each
+owns half of the molecules; with synchronised BatchNorm, all-gathered negatives and summed gradients the sharded
+step must reproduce the single-process full-batch step: loss, parameter gradients and BN running statistics."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+WORLD = 2
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _models(amd, seed=0):
+    from helpers import NET3D_YML, PNA_YML
+    torch.manual_seed(seed)
+    pna = amd.PNA(avg_d=1.0, device='cuda:0', **dict(PNA_YML, propagation_depth=2, hidden_dim=40, readout_hidden_dim=40,
+                                                      target_dim=32))
+    net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **dict(NET3D_YML, target_dim=32))
+    with torch.no_grad():       # O(1) pre-BN scale so that the statistics matter
+        for m in (pna, net):
+            for n, p in m.named_parameters():
+                if n.endswith('linear.weight'):
+                    p.mul_(p.shape[1] * 0.7)
+    return pna.cuda().train(), net.cuda().train()
+
+
+def _batch(amd, mols):
+    return (amd.batch([amd.bond_graph(m) for m in mols]).to('cuda:0'),
+            amd.batch([amd.complete_graph(m) for m in mols]).to('cuda:0'))
+
+
+def _worker(rank, port, path):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    amd = importlib.import_module('3dinfomax_amd')
+    adist = importlib.import_module('3dinfomax_amd.dist')
+    mols = amd.synth.make_dataset(16, seed=21)
+    pna, net = _models(amd)
+    loss_fn = amd.NTXent(tau=0.1)
+    adist.setup([pna, net], loss_fn)
+    g2, g3 = _batch(amd, adist.shard_molecules(mols, rank, WORLD))
+    share = loss_fn(pna(g2), net(g3))
+    share.backward()
+    params = list(pna.parameters()) + list(net.parameters())
+    adist.allreduce_grads(params)
+    total = adist.global_loss(share)
+    if rank == 0:
+        out = {'loss': total.item()}
+        for tag, m in (('pna', pna), ('net', net)):
+            for k, p in m.named_parameters():
+                out[f'g/{tag}/{k}'] = p.grad.cpu().numpy()
+            for k, b in m.named_buffers():
+                out[f'b/{tag}/{k}'] = b.cpu().numpy()
+        np.savez(path, **out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_step_equals_full_batch(tmp_path):
+    assert torch.cuda.is_available()
+    amd = importlib.import_module('3dinfomax_amd')
+    from helpers import close, grads_close
+    path = str(tmp_path / 'dp.npz')
+    mp.spawn(_worker, args=(_free_port(), path), nprocs=WORLD, join=True)
+    z = np.load(path)
+    mols = amd.synth.make_dataset(16, seed=21)
+    pna, net = _models(amd)
+    g2, g3 = _batch(amd, mols)
+    loss = amd.NTXent(tau=0.1)(pna(g2), net(g3))
+    loss.backward()
+    assert abs(float(z['loss']) - loss.item()) < 1e-5 * abs(loss.item())
+    for tag, m in (('pna', pna), ('net', net)):
+        ref = {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}
+        grads_close({k: z[f'g/{tag}/{k}'] for k in ref}, ref, 2e-4, tag + ' ')
+        for k, b in m.named_buffers():
+            assert close(z[f'b/{tag}/{k}'], b.cpu(), 1e-5, 1e-6), k
