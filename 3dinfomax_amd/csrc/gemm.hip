@@ -39,13 +39,13 @@ struct GemmArgs {
     unsigned a_bytes, b_bytes;  // extent of the operand views in bytes (buffer descriptor num_records)
 };
 
-constexpr int BK = 16;
 
 __device__ __forceinline__ int swz(int k, int idx) { return idx ^ ((((k) ^ (k >> 2)) & 1) << 4); }
 
-template <int R, int LD>
+template <int R, int LD, int BK>
 struct TileStage {
     static constexpr int SLOTS = R * BK / 4;                 // float4 slots in a tile
+    static constexpr int KQ = BK / 4;                        // float4 slots along k of one row
     static constexpr int PER_THREAD = (SLOTS + 255) / 256;
     float4 v[PER_THREAD];
 
@@ -63,7 +63,7 @@ struct TileStage {
         for (int it = 0; it < PER_THREAD; ++it) {
             int s = threadIdx.x + it * 256;
             int idx, k;
-            if (kcontig) { idx = idx0 + (s >> 2); k = k0 + (s & 3) * 4; }
+            if (kcontig) { idx = idx0 + s / KQ; k = k0 + (s % KQ) * 4; }
             else { k = k0 + s / (R / 4); idx = idx0 + (s % (R / 4)) * 4; }
             if (VEC) {
                 // contiguous extent is a multiple of 4: a valid first element implies a valid float4
@@ -92,7 +92,7 @@ struct TileStage {
             int s = threadIdx.x + it * 256;
             if (s < SLOTS) {
                 if (kcontig) {
-                    int idx = s >> 2, k = (s & 3) * 4;
+                    int idx = s / KQ, k = (s % KQ) * 4;
                     T[(k + 0) * LD + swz(k + 0, idx)] = v[it].x;
                     T[(k + 1) * LD + swz(k + 1, idx)] = v[it].y;
                     T[(k + 2) * LD + swz(k + 2, idx)] = v[it].z;
@@ -106,7 +106,7 @@ struct TileStage {
     }
 };
 
-template <int WAVES_M, int WAVES_N, int WM_T, int WN_T, bool VEC>
+template <int WAVES_M, int WAVES_N, int WM_T, int WN_T, int BK, bool VEC>
 __global__ void __launch_bounds__(256)
 gemm_f32_kernel(GemmArgs g) {
     constexpr int BM = WAVES_M * WM_T * 16, BN = WAVES_N * WN_T * 16;
@@ -127,8 +127,8 @@ gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < WN_T; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
-    TileStage<BM, LDA> sa;
-    TileStage<BN, LDB> sb;
+    TileStage<BM, LDA, BK> sa;
+    TileStage<BN, LDB, BK> sb;
     // descriptors are built from kernel arguments only (provably wave-uniform: no waterfall loops, guide T20)
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, g.b_bytes, 0x00020000);
@@ -208,13 +208,19 @@ gemm_f32_kernel(GemmArgs g) {
     }
 }
 
-template <int WAVES_M, int WAVES_N, int WM_T, int WN_T>
+template <int WAVES_M, int WAVES_N, int WM_T, int WN_T, int BK>
 static void launch(const GemmArgs& g, int splits, bool vec, hipStream_t s) {
     constexpr int BM = WAVES_M * WM_T * 16, BN = WAVES_N * WN_T * 16;
     dim3 grid(cdiv(g.M, BM), cdiv(g.N, BN), splits);
-    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<WAVES_M, WAVES_N, WM_T, WN_T, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<WAVES_M, WAVES_N, WM_T, WN_T, false>), grid, dim3(256), 0, s, g);
+    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<WAVES_M, WAVES_N, WM_T, WN_T, BK, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<WAVES_M, WAVES_N, WM_T, WN_T, BK, false>), grid, dim3(256), 0, s, g);
 }
+
+// tile configurations: {BM, BN, BK}
+constexpr int N_CFG = 9;
+static const int CFG_BM[N_CFG] = {64, 128, 128, 256, 64, 64, 128, 128, 32};
+static const int CFG_BN[N_CFG] = {208, 208, 128, 32, 64, 64, 128, 64, 64};
+static const int CFG_BK[N_CFG] = {16, 16, 16, 16, 16, 32, 32, 32, 32};
 
 }  // namespace i3d
 
@@ -265,19 +271,24 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     int bm, bn;
     // measured on MI355X at the step's shapes (tools/gemm_bench.py, profiles/gemm_bench_r1.log): the batch is small
     // for a 256-CU chip, so many 64x64 tiles beat fewer big ones until there are thousands of tiles.
+    const long tiles64 = (long)cdiv(M, 64) * cdiv(N, 64);
     if (N <= 32) { cfg = 3; bm = 256; bn = 32; }
-    else if ((long)cdiv(M, 64) * cdiv(N, 64) >= 4096) { cfg = 2; bm = 128; bn = 128; }
+    else if (tiles64 >= 4096) { cfg = 2; bm = 128; bn = 128; }
+    else if (trans_a && tiles64 < 64) { cfg = 8; bm = 32; bn = 64; }    // tiny weight-gradient outputs: 32x64x32
     else { cfg = 4; bm = 64; bn = 64; }
     if (force_cfg >= 0) {
-        static const int BMS[5] = {64, 128, 128, 256, 64}, BNS[5] = {208, 208, 128, 32, 64};
-        I3D_CHECK_ARG(force_cfg < 5, "tile_cfg must be 0..4");
-        cfg = force_cfg; bm = BMS[cfg]; bn = BNS[cfg];
+        I3D_CHECK_ARG(force_cfg < N_CFG, "tile_cfg out of range");
+        cfg = force_cfg; bm = CFG_BM[cfg]; bn = CFG_BN[cfg];
     }
+    const int BK = CFG_BK[cfg];
     int tiles = cdiv(M, bm) * cdiv(N, bn);
     int splits = 1;
-    if (tiles < 768) {      // split-K until ~1024 workgroups, but keep >= 512 (128 for tiny outputs) of K per split
+    // split-K (fp32 atomics, order not deterministic) ONLY for the row-reduction GEMMs of the backward pass
+    // (trans_a: dW = dY^T X, K = number of rows).  Forward GEMMs stay single-pass and bit-deterministic, so that
+    // the arg-max/arg-min routing of the aggregators and readouts cannot flip from run to run on near-ties.
+    if (trans_a && tiles < 768 && K >= 1024) {   // until ~1024 workgroups, >= 512 of K per split
         splits = (1024 + tiles / 2) / tiles;
-        int max_splits = K / (tiles < 64 ? 128 : 512);
+        int max_splits = K / 512;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
     }
@@ -305,11 +316,15 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     // multiples of 4 (K for k-contiguous operands, M or N for the others)
     const bool vec = g.a_vec && g.b_vec && ((g.a_kcontig ? K : M) % 4 == 0) && ((g.b_kcontig ? K : N) % 4 == 0);
     switch (cfg) {
-        case 0: launch<4, 1, 1, 13>(g, splits, vec, s); break;
-        case 1: launch<4, 1, 2, 13>(g, splits, vec, s); break;
-        case 2: launch<2, 2, 4, 4>(g, splits, vec, s); break;
-        case 3: launch<4, 1, 4, 2>(g, splits, vec, s); break;
-        default: launch<2, 2, 2, 2>(g, splits, vec, s); break;
+        case 0: launch<4, 1, 1, 13, 16>(g, splits, vec, s); break;
+        case 1: launch<4, 1, 2, 13, 16>(g, splits, vec, s); break;
+        case 2: launch<2, 2, 4, 4, 16>(g, splits, vec, s); break;
+        case 3: launch<4, 1, 4, 2, 16>(g, splits, vec, s); break;
+        case 4: launch<2, 2, 2, 2, 16>(g, splits, vec, s); break;
+        case 5: launch<2, 2, 2, 2, 32>(g, splits, vec, s); break;
+        case 6: launch<2, 2, 4, 4, 32>(g, splits, vec, s); break;
+        case 7: launch<2, 2, 4, 2, 32>(g, splits, vec, s); break;
+        default: launch<2, 2, 1, 2, 32>(g, splits, vec, s); break;
     }
     I3D_CHECK_LAUNCH();
     return I3D_OK;

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .streams import fork
 
 SUPPORTED_ACTIVATIONS = {'relu', 'silu', 'sigmoid', 'none'}
 
@@ -139,9 +140,15 @@ class FCFn(torch.autograd.Function):
         grad_y = grad_y.contiguous()
         grad_res = grad_y if ctx.has_res else None
         grad_pre, gg, gb = _Tail.backward(ctx.saved, grad_y, gamma, beta, ctx.spec)
-        gW = ops.gemm(grad_pre, x, trans_a=True) if ctx.needs_input_grad[1] else None
-        gbias = ops.colsum(grad_pre) if ctx.needs_input_grad[2] else None
+        gW = torch.empty_like(W) if ctx.needs_input_grad[1] else None
+        gbias = torch.empty(W.shape[0], dtype=W.dtype, device=W.device) if ctx.needs_input_grad[2] else None
+        with fork(grad_pre, x) as f:            # weight/bias gradients next to the data gradient (streams.py)
+            if gW is not None:
+                ops.gemm(grad_pre, x, trans_a=True, out=gW)
+            if gbias is not None:
+                ops.colsum(grad_pre, out=gbias)
         gx = ops.gemm(grad_pre, W) if ctx.needs_input_grad[0] else None
+        f.join()
         return gx, gW, gbias, gg, gb, grad_res, None
 
 
@@ -167,11 +174,14 @@ class Concat2FCFn(torch.autograd.Function):
         grad_res = grad_y if ctx.has_res else None
         grad_pre, gg, gb = _Tail.backward(ctx.saved, grad_y, gamma, beta, ctx.spec)
         gW = torch.empty_like(W)
-        ops.gemm(grad_pre, a, trans_a=True, out=gW[:, :Fa])
-        ops.gemm(grad_pre, c, trans_a=True, out=gW[:, Fa:])
-        gbias = ops.colsum(grad_pre)
-        ga = ops.gemm(grad_pre, W[:, :Fa])
+        gbias = torch.empty(W.shape[0], dtype=W.dtype, device=W.device)
+        with fork(grad_pre, a, c) as f:
+            ops.gemm(grad_pre, c, trans_a=True, out=gW[:, Fa:])
+            ops.gemm(grad_pre, a, trans_a=True, out=gW[:, :Fa])
+            ops.colsum(grad_pre, out=gbias)
         gc = ops.gemm(grad_pre, W[:, Fa:])
+        ga = ops.gemm(grad_pre, W[:, :Fa])
+        f.join()
         return ga, gc, gW, gbias, gg, gb, grad_res, None
 
 
@@ -210,16 +220,19 @@ class EdgeFCFn(torch.autograd.Function):
         gP = torch.empty(N, 2 * Fo, dtype=torch.float32, device=h.device)
         ops.segment_sum(grad_pre, idx.out_ptr, idx.out_epos, N, out=gP[:, :Fo])     # d P[src]
         ops.segment_sum(grad_pre, idx.in_ptr, None, N, out=gP[:, Fo:])              # d P[dst]
-        ops.gemm(gP[:, :Fo], h, trans_a=True, out=gW[:, :Fh])
-        ops.gemm(gP[:, Fo:], h, trans_a=True, out=gW[:, Fh:2 * Fh])
+        gbias = torch.empty(Fo, dtype=W.dtype, device=W.device)
+        with fork(gP, h, grad_pre, q if ctx.has_q else None) as f:
+            if ctx.has_q:
+                ops.gemm(grad_pre, q, trans_a=True, out=gW[:, 2 * Fh:])
+            ops.gemm(gP[:, :Fo], h, trans_a=True, out=gW[:, :Fh])
+            ops.gemm(gP[:, Fo:], h, trans_a=True, out=gW[:, Fh:2 * Fh])
+            ops.colsum(grad_pre, out=gbias)
+        gq = None
+        if ctx.has_q and ctx.needs_input_grad[1]:
+            gq = ops.gemm(grad_pre, W[:, 2 * Fh:])
         gh = ops.gemm(gP[:, :Fo], W[:, :Fh])
         ops.gemm(gP[:, Fo:], W[:, Fh:2 * Fh], out=gh, accumulate=True)
-        gq = None
-        if ctx.has_q:
-            ops.gemm(grad_pre, q, trans_a=True, out=gW[:, 2 * Fh:])
-            if ctx.needs_input_grad[1]:
-                gq = ops.gemm(grad_pre, W[:, 2 * Fh:])
-        gbias = ops.colsum(grad_pre)
+        f.join()
         return gh, gq, gW, gbias, gg, gb, None, None
 
 

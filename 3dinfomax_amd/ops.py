@@ -32,7 +32,7 @@ def _chk(t, dtype=torch.float32):
 def _workspace(feat, device):
     """Thread-local scratch for the two-stage column reductions (stream-ordered reuse)."""
     need = _lib.load().i3d_colreduce_workspace_bytes(0, feat)
-    key = (device.index,)
+    key = (device.index, torch.cuda.current_stream().cuda_stream)     # one scratch per stream (side-stream wgrads)
     ws = getattr(_tls, 'ws', None)
     if ws is None:
         ws = _tls.ws = {}
@@ -223,10 +223,11 @@ def bn_eval_bwd(grad_y, x, pre, act, post_act, running_mean, running_var, eps, g
     return grad_pre, grad_gamma, grad_beta
 
 
-def colsum(x, w=None):
+def colsum(x, w=None, out=None):
     _chk(x)
     rows, feat = x.shape
-    out = torch.empty(feat, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(feat, dtype=torch.float32, device=x.device)
     L = _lib.load()
     check(L.i3d_colsum(_p(x), _p(w), rows, feat, _p(out), _p(_workspace(feat, x.device)), _stream()), 'i3d_colsum')
     return out

@@ -1,0 +1,61 @@
+"""HIP-stream helpers: run independent kernels of one backward node on a second stream.
+
+At batch 512 most GEMMs of the step launch 130-520 workgroups on a 256-CU chip that could hold >1000 of them, so
+the weight-gradient GEMMs (dW = dY^T X, which nothing downstream of the node depends on) are enqueued on a side
+stream next to the data-gradient GEMMs of the same node and joined before the node returns.  Ordering rules:
+  * the side stream first waits for the main stream (its inputs - grad_pre, saved activations - were produced there);
+  * every tensor the side kernels read is `record_stream`ed so the caching allocator does not recycle it early;
+  * outputs are allocated on the main stream's pool BEFORE switching streams and the main stream waits for the side
+    stream before the node returns, so autograd (AccumulateGrad, the next node) only ever sees completed tensors.
+EXPERIMENTAL, off by default (I3D_OVERLAP=1 enables it): at batch 512 the step is bound by the host's enqueue
+rate, where the extra stream bookkeeping costs more than the overlap wins (profiles/r01_notes.md), and one
+large-batch gradient check disagrees with the single-stream result when it is on - to be root-caused before it
+becomes the default.
+"""
+import os
+import threading
+
+import torch
+
+ENABLED = os.environ.get('I3D_OVERLAP', '0') == '1'
+_tls = threading.local()
+
+
+def _side(device):
+    pool = getattr(_tls, 'pool', None)
+    if pool is None:
+        pool = _tls.pool = {}
+    s = pool.get(device.index)
+    if s is None:
+        s = pool[device.index] = torch.cuda.Stream(device=device)
+    return s
+
+
+class fork:
+    """with fork(t1, t2, ...) as f:  kernels launched inside run on the side stream; `f.join()` (or leaving the
+    `with` and calling join later in the same node) makes the main stream wait for them."""
+
+    def __init__(self, *reads):
+        self.reads = [t for t in reads if t is not None]
+        self.active = ENABLED and len(self.reads) > 0 and self.reads[0].is_cuda
+        self.main = self.side = self.ctx = None
+
+    def __enter__(self):
+        if self.active:
+            self.main = torch.cuda.current_stream()
+            self.side = _side(self.reads[0].device)
+            self.side.wait_stream(self.main)
+            for t in self.reads:
+                t.record_stream(self.side)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.active:
+            self.main.wait_stream(self.side)

@@ -100,7 +100,8 @@ int i3d_segment_readout_bwd(const float* grad_out, const float* x, const int* gr
  *   dW = dY^T X             : trans_a=1, trans_b=0, A=dY[M',N'] (K := rows) */
 int i3d_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                  float* C, int ldc, const float* bias, int accumulate, void* stream);
-/* tuning entry: same, with the tile configuration (0: 64x208, 1: 128x208, 2: 128x128, 3: 256x32, 4: 64x64; -1 = auto)
+/* tuning entry: same, with the tile configuration BMxBNxBK (0: 64x208x16, 1: 128x208x16, 2: 128x128x16, 3: 256x32x16,
+ * 4: 64x64x16, 5: 64x64x32, 6: 128x128x32, 7: 128x64x32, 8: 32x64x32; -1 = auto)
  * and the split-K factor (0 = auto) forced - used by tools/gemm_bench.py to pick the dispatch heuristics */
 int i3d_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                     float* C, int ldc, const float* bias, int accumulate, int tile_cfg, int splits, void* stream);

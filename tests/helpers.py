@@ -59,7 +59,7 @@ def grads_close(got, ref, rtol, what=''):
         a = torch.as_tensor(got[k], dtype=torch.float64).cpu()
         b = torch.as_tensor(v, dtype=torch.float64)
         err = (a - b).abs().max().item()
-        bound = rtol * b.abs().max().item() + 2e-6 * scale
+        bound = rtol * b.abs().max().item() + 5e-6 * scale
         assert err <= bound, f'{what}{k}: err {err:.3e} > {bound:.3e}'
 
 
@@ -67,3 +67,17 @@ def close(a, b, rtol, atol=0.0):
     a = torch.as_tensor(a, dtype=torch.float64).cpu()
     b = torch.as_tensor(b, dtype=torch.float64).cpu()
     return (a - b).abs().max().item() <= rtol * b.abs().max().item() + atol
+
+
+def grads_close_l2(got, ref, rtol, what=''):
+    """Per-parameter relative L2 error.  Used where the batch is big enough that fp32 rounding can flip the
+    arg-max/arg-min of a near-tie (two different atoms whose feature value agrees to ~1e-6) in a max/min aggregator
+    or readout: the routing of that one gradient element then differs between two correct fp32 implementations
+    (max-norm error O(1e-2) on a few entries) while the gradient as a whole still agrees (L2 error << 1e-2)."""
+    scale = max(float(np.linalg.norm(np.asarray(v).ravel())) for v in ref.values())
+    for k, v in ref.items():
+        a = torch.as_tensor(got[k], dtype=torch.float64).cpu().flatten()
+        b = torch.as_tensor(v, dtype=torch.float64).flatten()
+        err = (a - b).norm().item()
+        bound = rtol * b.norm().item() + 5e-6 * scale
+        assert err <= bound, f'{what}{k}: L2 err {err:.3e} > {bound:.3e}'

@@ -71,6 +71,32 @@ def test_gemm_weight_grad_split_k_and_strided_views():
     assert rel_err(gW.cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize('rows', [2100, 4200, 530])
+def test_gemm_split_k_into_strided_column_block(rows):
+    """weight gradient of posttrans written into a column block of dW (leading dimension != width) with split-K:
+    the zero-fill + atomics path must only touch - and fully initialise - its own block."""
+    Fo, Fa, Fc = 200, 200, 2400
+    dY, a, c = rnd(rows, Fo, seed=1, scale=0.3), rnd(rows, Fa, seed=2), rnd(rows, Fc, seed=3)
+    gW = torch.full((Fo, Fa + Fc), 7.0, device=DEV)           # poisoned: stale values must not survive
+    ops.gemm(g(dY), g(c), trans_a=True, out=gW[:, Fa:])
+    ops.gemm(g(dY), g(a), trans_a=True, out=gW[:, :Fa])
+    ref = dY.double().T @ torch.cat([a, c], 1).double()
+    assert rel_err(gW.cpu(), ref) < 2e-5
+    # the same through the tuning entry with forced split factors
+    L = importlib.import_module('3dinfomax_amd._lib')
+    from ctypes import c_void_p
+    lib = L.load()
+    for cfg, splits in ((4, 4), (8, 16), (2, 2), (5, 7)):
+        out = torch.full((Fo, Fa + Fc), 7.0, device=DEV)
+        A, B = g(dY), g(c)
+        rc = lib.i3d_gemm_f32_ex(1, 0, Fo, Fc, rows, c_void_p(A.data_ptr()), Fo, c_void_p(B.data_ptr()), Fc,
+                                 c_void_p(out[:, Fa:].data_ptr()), Fa + Fc, None, 0, cfg, splits,
+                                 c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        assert rel_err(out[:, Fa:].cpu(), ref[:, Fa:]) < 2e-5, (cfg, splits)
+        assert torch.all(out[:, :Fa] == 7.0)
+
+
 # ---- K4 aggregation --------------------------------------------------------------------------------------
 def _random_csr(n, max_deg, seed, zero_frac=0.1):
     rng = np.random.default_rng(seed)

@@ -61,9 +61,9 @@ if __name__ == '__main__':
         us, tf, err = run(lib, ta, tb, M, N, K, -1, 0)
         print(f'{name} M={M:6d} N={N:5d} K={K:6d}  auto: {us:8.1f} us {tf:7.1f} TF  err {err:.1e}', flush=True)
         if a.all_cfgs:
-            for cfg in range(5):
-                for splits in ((1,) if K <= 2400 and M > 2000 else (1, 4, 8, 16, 32)):
-                    if cfg == 3 and N > 64:
+            for cfg in (2, 4, 5, 6, 7, 8):
+                for splits in ((1, 2, 4) if K <= 2400 and M > 2000 else (4, 8, 16, 32)):
+                    if splits > 1 and K < 1024:
                         continue
                     us, tf, err = run(lib, ta, tb, M, N, K, cfg, splits)
                     print(f'      cfg {cfg} splits {splits:2d}: {us:8.1f} us {tf:7.1f} TF  err {err:.1e}', flush=True)
