@@ -141,9 +141,9 @@ __global__ void __launch_bounds__(256) colreduce_partial_kernel(ReduceArgs g, Ch
 }
 
 // ---- stage 2 ----------------------------------------------------------------------------------------
-// 256 threads = 32 columns x 8 partial-lanes: coalesced reads of the chunk partials, fp64 accumulation, one LDS
+// 256 threads = 8 columns x 32 partial-lanes: reads of the chunk partials, fp64 accumulation, one LDS
 // hop.  (A one-thread-per-column loop over the partials was latency-bound: 130-150 us per call, 40 % of the step.)
-constexpr int FIN_COLS = 32, FIN_LANES = 8;
+constexpr int FIN_COLS = 8, FIN_LANES = 32;    // 25 workgroups at F=200, 8 partials per thread
 
 __device__ __forceinline__ bool reduce_partials(const float* __restrict__ partial, int nblk, int feat, int& c,
                                                 double& s1, double& s2) {

@@ -216,11 +216,130 @@ static void launch(const GemmArgs& g, int splits, bool vec, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_f32_kernel<WAVES_M, WAVES_N, WM_T, WN_T, BK, false>), grid, dim3(256), 0, s, g);
 }
 
+// ---- variant on v_mfma_f32_32x32x2_f32: one 32x32 accumulator tile per MFMA (64-cycle issue = dependent latency, so
+// a single accumulator chain keeps the pipe busy), half as many MFMA instructions per FLOP.  Same staging, same LDS
+// image (the bit-4 swizzle is a permutation inside a 32-wide read, so the 32-lane fragment reads stay conflict-free).
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+template <int WAVES_M, int WAVES_N, int WM_T, int WN_T, int BK, bool VEC>
+__global__ void __launch_bounds__(256)
+gemm_f32_m32_kernel(GemmArgs g) {
+    constexpr int BM = WAVES_M * WM_T * 32, BN = WAVES_N * WN_T * 32;
+    constexpr int LDA = BM, LDB = BN;
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int k_begin = blockIdx.z * g.k_per_split;
+    const int k_end = min(g.K, k_begin + g.k_per_split);
+    if (k_begin >= k_end && !(blockIdx.z == 0)) return;
+
+    floatx16 acc[WM_T][WN_T];
+#pragma unroll
+    for (int i = 0; i < WM_T; ++i)
+#pragma unroll
+        for (int j = 0; j < WN_T; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    TileStage<BM, LDA, BK> sa;
+    TileStage<BN, LDB, BK> sb;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, g.b_bytes, 0x00020000);
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+    if (nk > 0) {
+        sa.template load<VEC>(ra, g.a_bytes, g.lda, g.a_kcontig, m0, g.M, k_begin, k_end);
+        sb.template load<VEC>(rb, g.b_bytes, g.ldb, g.b_kcontig, n0, g.N, k_begin, k_end);
+        sa.store(As[0], g.a_kcontig);
+        sb.store(Bs[0], g.b_kcontig);
+    }
+    __syncthreads();
+    const int l31 = lane & 31, lk = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            sa.template load<VEC>(ra, g.a_bytes, g.lda, g.a_kcontig, m0, g.M, k_begin + (kt + 1) * BK, k_end);
+            sb.template load<VEC>(rb, g.b_bytes, g.ldb, g.b_kcontig, n0, g.N, k_begin + (kt + 1) * BK, k_end);
+        }
+        const float* as = As[cur];
+        const float* bs = Bs[cur];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int kr = kk * 2 + lk;
+            float af[WM_T], bf[WN_T];
+#pragma unroll
+            for (int i = 0; i < WM_T; ++i) af[i] = as[kr * LDA + swz(kr, (wm * WM_T + i) * 32 + l31)];
+#pragma unroll
+            for (int j = 0; j < WN_T; ++j) bf[j] = bs[kr * LDB + swz(kr, (wn * WN_T + j) * 32 + l31)];
+#pragma unroll
+            for (int i = 0; i < WM_T; ++i)
+#pragma unroll
+                for (int j = 0; j < WN_T; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            sa.store(As[cur ^ 1], g.a_kcontig);
+            sb.store(Bs[cur ^ 1], g.b_kcontig);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: D[row = n][col = m]: lane owns m = tile col (lane&31), n = 8*grp + 4*(lane>>5) + 0..3 per register group
+    const bool add_bias = g.bias != nullptr && blockIdx.z == 0;
+#pragma unroll
+    for (int i = 0; i < WM_T; ++i) {
+        const int m = m0 + (wm * WM_T + i) * 32 + l31;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < WN_T; ++j) {
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                const int n = n0 + (wn * WN_T + j) * 32 + 8 * grp + 4 * lk;
+                if (n >= g.N) continue;
+                float r[4] = {acc[i][j][4 * grp + 0], acc[i][j][4 * grp + 1], acc[i][j][4 * grp + 2], acc[i][j][4 * grp + 3]};
+                float* c = g.C + (long)m * g.ldc + n;
+                const bool full = (n + 3 < g.N);
+                if (add_bias) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < g.N) r[q] += g.bias[n + q];
+                }
+                if (g.atomic_out) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < g.N) unsafeAtomicAdd(c + q, r[q]);
+                } else if (full && g.c_vec) {
+                    float4 o = make_float4(r[0], r[1], r[2], r[3]);
+                    if (g.accumulate) {
+                        float4 old = *reinterpret_cast<const float4*>(c);
+                        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                    }
+                    *reinterpret_cast<float4*>(c) = o;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < g.N) c[q] = g.accumulate ? c[q] + r[q] : r[q];
+                }
+            }
+        }
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int WM_T, int WN_T, int BK>
+static void launch32(const GemmArgs& g, int splits, bool vec, hipStream_t s) {
+    constexpr int BM = WAVES_M * WM_T * 32, BN = WAVES_N * WN_T * 32;
+    dim3 grid(cdiv(g.M, BM), cdiv(g.N, BN), splits);
+    if (vec) hipLaunchKernelGGL((gemm_f32_m32_kernel<WAVES_M, WAVES_N, WM_T, WN_T, BK, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_m32_kernel<WAVES_M, WAVES_N, WM_T, WN_T, BK, false>), grid, dim3(256), 0, s, g);
+}
+
 // tile configurations: {BM, BN, BK}
-constexpr int N_CFG = 9;
-static const int CFG_BM[N_CFG] = {64, 128, 128, 256, 64, 64, 128, 128, 32};
-static const int CFG_BN[N_CFG] = {208, 208, 128, 32, 64, 64, 128, 64, 64};
-static const int CFG_BK[N_CFG] = {16, 16, 16, 16, 16, 32, 32, 32, 32};
+constexpr int N_CFG = 12;   // 9..11: the 32x32x2 MFMA variant
+static const int CFG_BM[N_CFG] = {64, 128, 128, 256, 64, 64, 128, 128, 32, 64, 128, 64};
+static const int CFG_BN[N_CFG] = {208, 208, 128, 32, 64, 64, 128, 64, 64, 64, 128, 64};
+static const int CFG_BK[N_CFG] = {16, 16, 16, 16, 16, 32, 32, 32, 32, 16, 16, 32};
 
 }  // namespace i3d
 
@@ -275,7 +394,7 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     if (N <= 32) { cfg = 3; bm = 256; bn = 32; }
     else if (tiles64 >= 4096) { cfg = 2; bm = 128; bn = 128; }
     else if (trans_a && tiles64 < 64) { cfg = 8; bm = 32; bn = 64; }    // tiny weight-gradient outputs: 32x64x32
-    else { cfg = 4; bm = 64; bn = 64; }
+    else { cfg = 9; bm = 64; bn = 64; }    // 64x64x16 on v_mfma_f32_32x32x2_f32: 3-5 % ahead of the 16x16x4 form
     if (force_cfg >= 0) {
         I3D_CHECK_ARG(force_cfg < N_CFG, "tile_cfg out of range");
         cfg = force_cfg; bm = CFG_BM[cfg]; bn = CFG_BN[cfg];
@@ -324,7 +443,10 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
         case 5: launch<2, 2, 2, 2, 32>(g, splits, vec, s); break;
         case 6: launch<2, 2, 4, 4, 32>(g, splits, vec, s); break;
         case 7: launch<2, 2, 4, 2, 32>(g, splits, vec, s); break;
-        default: launch<2, 2, 1, 2, 32>(g, splits, vec, s); break;
+        case 8: launch<2, 2, 1, 2, 32>(g, splits, vec, s); break;
+        case 9: launch32<2, 2, 1, 1, 16>(g, splits, vec, s); break;
+        case 10: launch32<2, 2, 2, 2, 16>(g, splits, vec, s); break;
+        default: launch32<2, 2, 1, 1, 32>(g, splits, vec, s); break;
     }
     I3D_CHECK_LAUNCH();
     return I3D_OK;

@@ -5,7 +5,6 @@ computation below is one of the hand-written gfx950 kernels in csrc/.  No autogr
 autograd.Functions in layers.py / pna.py / net3d.py / losses.py chain these calls explicitly.
 """
 import threading
-from ctypes import c_void_p
 
 import torch
 
@@ -16,16 +15,23 @@ _tls = threading.local()
 KERNEL_TIMERS = None      # set to a dict by bench.py to collect (start, end) HIP events of the roofline kernel
 
 
+# The wrappers below are on the host's critical path (~210 calls per training step): pointers and the stream are
+# passed to ctypes as plain ints (argtypes are c_void_p), the raw current stream comes from one C call.
+_raw_stream = torch._C._cuda_getCurrentRawStream
+
+
 def _stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _raw_stream(torch.cuda.current_device())
 
 
 def _p(t):
-    return c_void_p(t.data_ptr()) if t is not None else None
+    return t.data_ptr() if t is not None else None
 
 
 def _chk(t, dtype=torch.float32):
-    assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise AssertionError(f'expected a contiguous {dtype} HIP tensor, got {t.device} {t.dtype} '
+                             f'contiguous={t.is_contiguous()} (there is no CPU fallback)')
     return t
 
 
