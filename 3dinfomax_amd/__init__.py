@@ -15,6 +15,10 @@ def __getattr__(name):
     if name in ('PNA', 'PNAGNN', 'PNALayer', 'PNA_AGGREGATORS', 'PNA_SCALERS'):
         from . import pna
         return getattr(pna, name)
+    if name in ('PNAOriginal', 'PNAOriginalSimple', 'PNAGNNOriginal', 'PNAGNNSimple', 'PNATower', 'PNASimpleLayer',
+                'MLPReadout'):
+        from . import pna_original
+        return getattr(pna_original, name)
     if name in ('Net3D', 'Net3DLayer'):
         from . import net3d
         return getattr(net3d, name)
@@ -30,6 +34,7 @@ def __getattr__(name):
     raise AttributeError(name)
 
 
-__all__ = ['PNA', 'PNAGNN', 'PNALayer', 'PNA_AGGREGATORS', 'PNA_SCALERS', 'Net3D', 'Net3DLayer', 'NTXent',
+__all__ = ['PNA', 'PNAGNN', 'PNALayer', 'PNA_AGGREGATORS', 'PNA_SCALERS', 'PNAOriginal', 'PNAOriginalSimple',
+           'PNAGNNOriginal', 'PNAGNNSimple', 'PNATower', 'PNASimpleLayer', 'MLPReadout', 'Net3D', 'Net3DLayer', 'NTXent',
            'NTXentMultiplePositives', 'FCLayer', 'MLP', 'AtomEncoder', 'BondEncoder', 'contrastive_collate',
            'conformer_collate', 'BatchedMolGraph', 'batch', 'bond_graph', 'complete_graph']

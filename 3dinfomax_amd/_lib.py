@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, 'lib', 'lib3dinfomax_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(HERE), 'include', 'infomax3d_hip.h')
 
 # constants of include/infomax3d_hip.h
-ACT = {'none': 0, None: 0, 'relu': 1, 'silu': 2, 'sigmoid': 3}
+ACT = {'none': 0, None: 0, 'relu': 1, 'silu': 2, 'sigmoid': 3, 'leakyrelu': 4}
 AGG = {'mean': 0, 'sum': 1, 'max': 2, 'min': 3, 'std': 4, 'var': 5}
 SCALER = {'identity': 0, 'amplification': 1, 'attenuation': 2}
 
@@ -22,8 +22,9 @@ _SIGNATURES = {
     'i3d_last_error': (c_char_p, []),
     'i3d_embedding_sum_fwd': (c_int, [_P, _P, c_int, c_int, POINTER(c_void_p), c_int, _P, _P]),
     'i3d_embedding_sum_bwd': (c_int, [_P, _P, c_int, c_int, _P, c_int, POINTER(c_void_p), POINTER(c_int), _P]),
-    'i3d_pna_aggregate_fwd': (c_int, [_P, _P, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_float, _P, _P]),
-    'i3d_pna_aggregate_bwd': (c_int, [_P, _P, _P, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_float,
+    'i3d_pna_aggregate_fwd': (c_int, [_P, _P, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_int, c_float, _P,
+                                      _P]),
+    'i3d_pna_aggregate_bwd': (c_int, [_P, _P, _P, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_int, c_float,
                                       _P, _P]),
     'i3d_segment_readout_fwd': (c_int, [_P, _P, c_int, c_int, POINTER(c_int), c_int, _P, _P]),
     'i3d_segment_readout_bwd': (c_int, [_P, _P, _P, c_int, c_int, POINTER(c_int), c_int, _P, _P]),
@@ -52,6 +53,7 @@ _SIGNATURES = {
     'i3d_ntxent_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
     'i3d_ntxent_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P]),
     'i3d_row_axpy': (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    'i3d_row_scale': (c_int, [_P, _P, c_int, c_int, _P, _P]),
 }
 
 _lib = None

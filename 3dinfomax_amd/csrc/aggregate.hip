@@ -268,7 +268,8 @@ pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict
     }
 }
 
-static int make_cfg(const int* aggregators, int n_agg, const int* scalers, int n_scalers, float avg_d_log, AggCfg& cfg) {
+static int make_cfg(const int* aggregators, int n_agg, const int* scalers, int n_scalers, int force_scalers,
+                    float avg_d_log, AggCfg& cfg) {
     if (n_agg < 1 || n_agg > 8 || n_scalers < 1 || n_scalers > 4) return -1;
     cfg.n_agg = n_agg;
     for (int i = 0; i < n_agg; ++i) {
@@ -276,7 +277,7 @@ static int make_cfg(const int* aggregators, int n_agg, const int* scalers, int n
         cfg.agg[i] = aggregators[i];
     }
     // reference models/pna.py:232: scalers are only applied when more than one is configured
-    if (n_scalers == 1) {
+    if (n_scalers == 1 && !force_scalers) {
         cfg.n_scaler = 1;
         cfg.scaler[0] = I3D_SCALE_IDENTITY;
     } else {
@@ -309,10 +310,10 @@ using namespace i3d;
 
 extern "C" int i3d_pna_aggregate_fwd(const float* e, const int* in_ptr, int num_nodes, int feat,
                                      const int* aggregators, int n_aggregators, const int* scalers,
-                                     int n_scalers, float avg_d_log, float* out, void* stream) {
+                                     int n_scalers, int force_scalers, float avg_d_log, float* out, void* stream) {
     I3D_CHECK_ARG(num_nodes >= 0 && feat > 0, "num_nodes >= 0 and feat > 0 required");
     AggCfg cfg;
-    I3D_CHECK_ARG(make_cfg(aggregators, n_aggregators, scalers, n_scalers, avg_d_log, cfg) == 0,
+    I3D_CHECK_ARG(make_cfg(aggregators, n_aggregators, scalers, n_scalers, force_scalers, avg_d_log, cfg) == 0,
                   "bad aggregator/scaler list");
     if (num_nodes == 0) return I3D_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -337,10 +338,10 @@ extern "C" int i3d_pna_aggregate_fwd(const float* e, const int* in_ptr, int num_
 
 extern "C" int i3d_pna_aggregate_bwd(const float* grad_out, const float* e, const int* in_ptr, int num_nodes,
                                      int feat, const int* aggregators, int n_aggregators, const int* scalers,
-                                     int n_scalers, float avg_d_log, float* grad_e, void* stream) {
+                                     int n_scalers, int force_scalers, float avg_d_log, float* grad_e, void* stream) {
     I3D_CHECK_ARG(num_nodes >= 0 && feat > 0, "num_nodes >= 0 and feat > 0 required");
     AggCfg cfg;
-    I3D_CHECK_ARG(make_cfg(aggregators, n_aggregators, scalers, n_scalers, avg_d_log, cfg) == 0,
+    I3D_CHECK_ARG(make_cfg(aggregators, n_aggregators, scalers, n_scalers, force_scalers, avg_d_log, cfg) == 0,
                   "bad aggregator/scaler list");
     if (num_nodes == 0) return I3D_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -365,11 +366,11 @@ extern "C" int i3d_segment_readout_fwd(const float* x, const int* graph_ptr, int
         I3D_CHECK_ARG(ops[i] == I3D_AGG_MEAN || ops[i] == I3D_AGG_SUM || ops[i] == I3D_AGG_MAX || ops[i] == I3D_AGG_MIN,
                       "readout op must be mean/sum/max/min");
     int ident = I3D_SCALE_IDENTITY;
-    return i3d_pna_aggregate_fwd(x, graph_ptr, num_graphs, feat, ops, n_ops, &ident, 1, 1.0f, out, stream);
+    return i3d_pna_aggregate_fwd(x, graph_ptr, num_graphs, feat, ops, n_ops, &ident, 1, 0, 1.0f, out, stream);
 }
 
 extern "C" int i3d_segment_readout_bwd(const float* grad_out, const float* x, const int* graph_ptr, int num_graphs,
                                        int feat, const int* ops, int n_ops, float* grad_x, void* stream) {
     int ident = I3D_SCALE_IDENTITY;
-    return i3d_pna_aggregate_bwd(grad_out, x, graph_ptr, num_graphs, feat, ops, n_ops, &ident, 1, 1.0f, grad_x, stream);
+    return i3d_pna_aggregate_bwd(grad_out, x, graph_ptr, num_graphs, feat, ops, n_ops, &ident, 1, 0, 1.0f, grad_x, stream);
 }

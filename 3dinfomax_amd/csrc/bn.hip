@@ -457,7 +457,7 @@ extern "C" int i3d_bn_bwd(const float* grad_y, const float* x, const float* pre,
                           const double* sums_in, long total_rows, void* workspace, void* stream) {
     I3D_CHECK_ARG(rows > 0 && feat > 0, "rows > 0 and feat > 0 required");
     I3D_CHECK_ARG(workspace != nullptr, "workspace required");
-    I3D_CHECK_ARG(act == I3D_ACT_NONE || act == I3D_ACT_RELU || pre != nullptr, "pre required for this activation");
+    I3D_CHECK_ARG(act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU || pre != nullptr, "pre required for this activation");
     hipStream_t s = (hipStream_t)stream;
     Chunking ch = make_chunking(rows, feat);
     float* partial = (float*)workspace;
@@ -484,7 +484,7 @@ extern "C" int i3d_bn_bwd(const float* grad_y, const float* x, const float* pre,
     }
     BwdApplyArgs b;
     b.inv_n_ptr = sums_in != nullptr ? (partial + (long)MAX_PARTIAL_BLOCKS * 2 * feat + 2 * feat) : nullptr;
-    b.grad_y = grad_y; b.x = x; b.pre = (act == I3D_ACT_NONE || act == I3D_ACT_RELU) ? nullptr : pre;
+    b.grad_y = grad_y; b.x = x; b.pre = (act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU) ? nullptr : pre;
     b.mean = mean; b.invstd = invstd; b.gamma = gamma; b.beta = beta;
     b.sum_dy = sum_dy; b.sum_dy_xhat = sum_dy_xhat; b.grad_pre = grad_pre; b.feat = feat; b.act = act;
     b.post_act = post_act; b.eval_mode = 0; b.inv_n = 1.f / (float)total_rows; b.eps = 0.f;
@@ -515,7 +515,7 @@ extern "C" int i3d_bn_eval_bwd(const float* grad_y, const float* x, const float*
                        grad_gamma, (double*)nullptr);
     I3D_CHECK_LAUNCH();
     BwdApplyArgs b;
-    b.grad_y = grad_y; b.x = x; b.pre = (act == I3D_ACT_NONE || act == I3D_ACT_RELU) ? nullptr : pre;
+    b.grad_y = grad_y; b.x = x; b.pre = (act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU) ? nullptr : pre;
     b.mean = running_mean; b.invstd = running_var; b.gamma = gamma; b.beta = beta; b.sum_dy = nullptr;
     b.sum_dy_xhat = nullptr; b.grad_pre = grad_pre; b.feat = feat; b.act = act; b.post_act = post_act;
     b.inv_n_ptr = nullptr; b.eval_mode = 1; b.inv_n = 0.f; b.eps = eps;

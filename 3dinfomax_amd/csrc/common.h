@@ -39,6 +39,7 @@ __device__ __forceinline__ float apply_act(float x, int act) {
         case I3D_ACT_RELU: return x > 0.f ? x : 0.f;
         case I3D_ACT_SILU: return x / (1.f + __expf(-x));
         case I3D_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+        case I3D_ACT_LEAKY_RELU: return x > 0.f ? x : 0.01f * x;
         default: return x;
     }
 }
@@ -55,6 +56,7 @@ __device__ __forceinline__ float act_grad(float x, int act) {
             float s = 1.f / (1.f + __expf(-x));
             return s * (1.f - s);
         }
+        case I3D_ACT_LEAKY_RELU: return x > 0.f ? 1.f : 0.01f;
         default: return 1.f;
     }
 }

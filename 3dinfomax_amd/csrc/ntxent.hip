@@ -138,6 +138,22 @@ row_axpy_kernel(const float* __restrict__ z, const float* __restrict__ coef, int
     }
 }
 
+template <int V>
+__global__ void __launch_bounds__(256)
+row_scale_kernel(const float* __restrict__ z, const float* __restrict__ coef, int rows, int dim, float* __restrict__ out) {
+    const int DV = dim / V;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)rows * DV) return;
+    float c = coef[(int)(t / DV)];
+    long off = t * V;
+    if (V == 4) {
+        float4 a = *reinterpret_cast<const float4*>(z + off);
+        *reinterpret_cast<float4*>(out + off) = make_float4(c * a.x, c * a.y, c * a.z, c * a.w);
+    } else {
+        out[off] = c * z[off];
+    }
+}
+
 }  // namespace i3d
 
 using namespace i3d;
@@ -188,6 +204,22 @@ extern "C" int i3d_row_axpy(const float* z, const float* coef, int rows, int dim
     } else {
         long items = (long)rows * dim;
         hipLaunchKernelGGL(row_axpy_kernel<1>, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, z, coef, rows, dim,
+                           out);
+    }
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_row_scale(const float* z, const float* coef, int rows, int dim, float* out, void* stream) {
+    I3D_CHECK_ARG(rows >= 0 && dim > 0, "bad shape");
+    if (rows == 0) return I3D_OK;
+    if (dim % 4 == 0) {
+        long items = (long)rows * dim / 4;
+        hipLaunchKernelGGL(row_scale_kernel<4>, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, z, coef, rows, dim,
+                           out);
+    } else {
+        long items = (long)rows * dim;
+        hipLaunchKernelGGL(row_scale_kernel<1>, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, z, coef, rows, dim,
                            out);
     }
     I3D_CHECK_LAUNCH();

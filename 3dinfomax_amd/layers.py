@@ -15,7 +15,7 @@ import torch.nn as nn
 from . import ops
 from .streams import fork
 
-SUPPORTED_ACTIVATIONS = {'relu', 'silu', 'sigmoid', 'none'}
+SUPPORTED_ACTIVATIONS = {'relu', 'silu', 'sigmoid', 'leakyrelu', 'none'}
 
 
 def act_name(activation):
@@ -71,7 +71,7 @@ class _Tail:
             if residual is not None:
                 y = ops.add_inplace(y.clone() if y is pre else y, residual)
             return y, (inputs, acts)
-        keep_pre = spec.act not in (None, 'relu')       # silu'/sigmoid' need the pre-activation
+        keep_pre = spec.act not in (None, 'relu', 'leakyrelu')   # silu'/sigmoid' need the pre-activation
         if bn.training:
             if bn.sync_group is not None:
                 from . import dist as adist
@@ -352,18 +352,18 @@ class AggregateFn(torch.autograd.Function):
     """K4: segmented mean/max/min/std x degree scalers (reference models/pna.py:206, 221-235)."""
 
     @staticmethod
-    def forward(ctx, e, index, aggregators, scalers, avg_d_log):
+    def forward(ctx, e, index, aggregators, scalers, avg_d_log, force_scalers=False):
         e = e.contiguous()
-        ctx.cfg = (index, aggregators, scalers, avg_d_log)
+        ctx.cfg = (index, aggregators, scalers, avg_d_log, force_scalers)
         ctx.save_for_backward(e)
-        return ops.pna_aggregate_fwd(e, index.in_ptr, index.num_nodes, aggregators, scalers, avg_d_log)
+        return ops.pna_aggregate_fwd(e, index.in_ptr, index.num_nodes, aggregators, scalers, avg_d_log, force_scalers)
 
     @staticmethod
     def backward(ctx, grad_out):
         (e,) = ctx.saved_tensors
-        index, aggregators, scalers, avg = ctx.cfg
+        index, aggregators, scalers, avg, force = ctx.cfg
         return ops.pna_aggregate_bwd(grad_out.contiguous(), e, index.in_ptr, index.num_nodes, aggregators, scalers,
-                                     avg), None, None, None, None
+                                     avg, force), None, None, None, None, None
 
 
 class ReadoutFn(torch.autograd.Function):

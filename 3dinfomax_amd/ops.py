@@ -81,11 +81,11 @@ def embedding_sum_bwd(idx, grad_out, dims, row_perm=None):
 
 
 # ---- K4 / K6 ---------------------------------------------------------------------------------------------
-def pna_aggregate_fwd(e, in_ptr, num_nodes, aggregators, scalers, avg_d_log=1.0):
+def pna_aggregate_fwd(e, in_ptr, num_nodes, aggregators, scalers, avg_d_log=1.0, force_scalers=False):
     _chk(e)
     _chk(in_ptr, torch.int32)
     feat = e.shape[1]
-    n_sc = len(scalers) if len(scalers) > 1 else 1
+    n_sc = len(scalers) if (len(scalers) > 1 or force_scalers) else 1
     out = torch.empty(num_nodes, n_sc * len(aggregators) * feat, dtype=torch.float32, device=e.device)
     L = _lib.load()
     timed = KERNEL_TIMERS is not None
@@ -93,7 +93,7 @@ def pna_aggregate_fwd(e, in_ptr, num_nodes, aggregators, scalers, avg_d_log=1.0)
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0.record()
     check(L.i3d_pna_aggregate_fwd(_p(e), _p(in_ptr), num_nodes, feat, int_array(aggregators), len(aggregators),
-                                  int_array(scalers), len(scalers), float(avg_d_log), _p(out), _stream()),
+                                  int_array(scalers), len(scalers), int(force_scalers), float(avg_d_log), _p(out), _stream()),
           'i3d_pna_aggregate_fwd')
     if timed:
         t1.record()
@@ -101,14 +101,14 @@ def pna_aggregate_fwd(e, in_ptr, num_nodes, aggregators, scalers, avg_d_log=1.0)
     return out
 
 
-def pna_aggregate_bwd(grad_out, e, in_ptr, num_nodes, aggregators, scalers, avg_d_log=1.0):
+def pna_aggregate_bwd(grad_out, e, in_ptr, num_nodes, aggregators, scalers, avg_d_log=1.0, force_scalers=False):
     _chk(grad_out)
     _chk(e)
     grad_e = torch.empty_like(e)
     L = _lib.load()
     check(L.i3d_pna_aggregate_bwd(_p(grad_out), _p(e), _p(in_ptr), num_nodes, e.shape[1], int_array(aggregators),
-                                  len(aggregators), int_array(scalers), len(scalers), float(avg_d_log), _p(grad_e),
-                                  _stream()), 'i3d_pna_aggregate_bwd')
+                                  len(aggregators), int_array(scalers), len(scalers), int(force_scalers), float(avg_d_log),
+                                  _p(grad_e), _stream()), 'i3d_pna_aggregate_bwd')
     return grad_e
 
 
@@ -356,4 +356,11 @@ def row_axpy(z, coef, out):
     _chk(z)
     _chk(out)
     check(_lib.load().i3d_row_axpy(_p(z), _p(coef), z.shape[0], z.shape[1], _p(out), _stream()), 'i3d_row_axpy')
+    return out
+
+
+def row_scale(z, coef):
+    _chk(z)
+    out = torch.empty_like(z)
+    check(_lib.load().i3d_row_scale(_p(z), _p(coef), z.shape[0], z.shape[1], _p(out), _stream()), 'i3d_row_scale')
     return out

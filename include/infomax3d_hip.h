@@ -34,6 +34,7 @@ extern "C" {
 #define I3D_ACT_RELU 1
 #define I3D_ACT_SILU 2
 #define I3D_ACT_SIGMOID 3
+#define I3D_ACT_LEAKY_RELU 4 /* negative slope 0.01 = nn.LeakyReLU() default, reference models/pna_original.py:291 */
 
 /* aggregators: reference models/pna.py:71-81 (PNA_AGGREGATORS); readout ops: dgl.readout_nodes */
 #define I3D_AGG_MEAN 0
@@ -70,14 +71,16 @@ int i3d_embedding_sum_bwd(const int64_t* idx, const int* row_perm, int rows, int
  *   e [E, feat] messages in epos order;  in_ptr [N+1];  aggregators/scalers: host int arrays (I3D_AGG_*, I3D_SCALE_*)
  *   out [N, n_scalers_eff * n_aggregators * feat], scaler-major, zero rows for in-degree 0;
  *   n_scalers_eff = n_scalers if n_scalers > 1 else 1 with NO scaling (reference quirk, models/pna.py:232).
+ *   force_scalers != 0: apply the scalers also when only one is configured (reference models/pna_original.py:235,
+ *   422 - the original PNA layers have no such quirk).
  *   avg_d_log: the reference hard-codes 1.0 (models/pna.py:153); pna_original.py passes the real value.
  * bwd: grad_e [E, feat] (fully overwritten).  max/min ties route to the first (lowest edge id) slot. */
 int i3d_pna_aggregate_fwd(const float* e, const int* in_ptr, int num_nodes, int feat, const int* aggregators,
-                          int n_aggregators, const int* scalers, int n_scalers, float avg_d_log, float* out,
-                          void* stream);
+                          int n_aggregators, const int* scalers, int n_scalers, int force_scalers, float avg_d_log,
+                          float* out, void* stream);
 int i3d_pna_aggregate_bwd(const float* grad_out, const float* e, const int* in_ptr, int num_nodes, int feat,
                           const int* aggregators, int n_aggregators, const int* scalers, int n_scalers,
-                          float avg_d_log, float* grad_e, void* stream);
+                          int force_scalers, float avg_d_log, float* grad_e, void* stream);
 
 /* ---- K6: per-graph readout -------------------------------------------------------------------------
  * replaces dgl.readout_nodes(graph,'feat',op) for op in readout_aggregators + torch.cat,
@@ -201,6 +204,8 @@ int i3d_ntxent_bwd(const float* sim, const float* n1, const float* n2, const flo
                    float* ca, float* cb, void* stream);
 /* out[r,:] += coef[r] * z[r,:] */
 int i3d_row_axpy(const float* z, const float* coef, int rows, int dim, float* out, void* stream);
+/* out[r,:] = coef[r] * z[r,:]   (graph-size normalisation h * snorm_n, reference models/pna_original.py:258-259) */
+int i3d_row_scale(const float* z, const float* coef, int rows, int dim, float* out, void* stream);
 
 #ifdef __cplusplus
 }

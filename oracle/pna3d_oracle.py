@@ -413,3 +413,91 @@ def train_step(g2, g3, P2, cfg2, P3, cfg3, optim, tau=0.1):
     optim.step()
     optim.zero_grad()
     return loss.detach()
+
+
+# ------------------------------------------------------------------------------------------
+# Original-PNA variants: reference models/pna_original.py
+# ------------------------------------------------------------------------------------------
+def mlp_readout(x, P, prefix, L=2):
+    """reference models/base_layers.py:149-164 (MLPReadout: L halving Linear+ReLU layers, then Linear)."""
+    for l in range(L):
+        x = F.relu(F.linear(x, P[f'{prefix}.FC_layers.{l}.weight'], P[f'{prefix}.FC_layers.{l}.bias']))
+    return F.linear(x, P[f'{prefix}.FC_layers.{L}.weight'], P[f'{prefix}.FC_layers.{L}.bias'])
+
+
+def pna_original_reduce(mailbox, D, aggregators, scalers, avg_d):
+    """reference models/pna_original.py:231-236 / 418-423: scalers are ALWAYS applied, with the real avg_d."""
+    h = torch.cat([aggregate(mailbox, a) for a in aggregators], dim=1)
+    return torch.cat([scale(h, s, D, avg_d) for s in scalers], dim=1)
+
+
+def pna_original_forward(graph, snorm_n, P, cfg, training=True):
+    """reference models/pna_original.py:138-146 (PNAOriginal.forward), :181-194 (PNAGNNOriginal.forward),
+    :241-261 (PNATower.forward), :296-312 (PNALayer.forward).  gru_enable / use_3d / dropout are off."""
+    src, dst = graph['src'], graph['dst']
+    n = graph['num_nodes']
+    mom = 0.1   # MLP default batch_norm_momentum: pna_original never passes one
+    h = embedding_sum(graph['atom_feat'], P, 'node_gnn.embedding_h.atom_embedding_list', graph['atom_feat'].shape[1])
+    e = None
+    if cfg.get('edge_feat', True):
+        e = embedding_sum(graph['bond_feat'], P, 'node_gnn.embedding_e.bond_embedding_list', graph['bond_feat'].shape[1])
+    L, towers = cfg['propagation_depth'], cfg.get('towers', 1)
+    n_blocks = len(cfg['aggregators']) * len(cfg['scalers'])
+    for l in range(L):
+        last = l == L - 1
+        in_dim = cfg['hidden_dim']
+        out_dim = cfg['last_layer_dim'] if last else cfg['hidden_dim']
+        divide = cfg.get('divide_input_last', True) if last else cfg.get('divide_input_first', True)
+        it = in_dim // towers if divide else in_dim
+        outs = []
+        for t in range(towers):
+            pre = f'node_gnn.layers.{l}.towers.{t}'
+            ht = h[:, t * it:(t + 1) * it] if divide else h
+            z = torch.cat([ht[src], ht[dst]] + ([e] if e is not None else []), dim=1)              # :221-225
+            msg = mlp(z, P, f'{pre}.pretrans', cfg['pretrans_layers'], 'relu', 'none', False, False, mom, training)
+            agg = degree_bucketed_reduce(msg, dst, n, lambda mb, D: pna_original_reduce(
+                mb, D, cfg['aggregators'], cfg['scalers'], cfg['avg_d']), n_blocks * it)            # :250
+            ho = mlp(torch.cat([ht, agg], dim=1), P, f'{pre}.posttrans', cfg['posttrans_layers'], 'relu', 'none',
+                     cfg['mid_batch_norm'], cfg['last_batch_norm'], mom, training)                 # :251-254
+            if cfg.get('graph_norm', False):
+                ho = ho * snorm_n                                                                   # :257-258
+            outs.append(ho)
+        h_cat = torch.cat(outs, dim=1)
+        h_out = F.leaky_relu(F.linear(h_cat, P[f'node_gnn.layers.{l}.mixing_network.weight'],
+                                      P[f'node_gnn.layers.{l}.mixing_network.bias']))               # :308
+        if cfg.get('residual', False) and in_dim == out_dim:
+            h_out = h + h_out
+        h = h_out
+    r = torch.cat([segment_readout(h, graph['batch_num_nodes'], op) for op in cfg['readout_aggregators']], dim=-1)
+    return mlp_readout(r, P, 'output'), h
+
+
+def pna_original_simple_forward(graph, P, cfg, training=True):
+    """reference models/pna_original.py:341-348, :374-382, :425-444 (PNASimpleLayer: copy_u messages, no edge MLP,
+    ReLU after posttrans)."""
+    src, dst = graph['src'], graph['dst']
+    n = graph['num_nodes']
+    mom = 0.1
+    h = embedding_sum(graph['atom_feat'], P, 'node_gnn.embedding_h.atom_embedding_list', graph['atom_feat'].shape[1])
+    L = cfg['propagation_depth']
+    n_blocks = len(cfg['aggregators']) * len(cfg['scalers'])
+    for l in range(L):
+        in_dim = cfg['hidden_dim']
+        out_dim = cfg['last_layer_dim'] if l == L - 1 else cfg['hidden_dim']
+        agg = degree_bucketed_reduce(h[src], dst, n, lambda mb, D: pna_original_reduce(
+            mb, D, cfg['aggregators'], cfg['scalers'], cfg['avg_d']), n_blocks * in_dim)
+        ho = mlp(agg, P, f'node_gnn.layers.{l}.posttrans', cfg['posttrans_layers'], 'relu', 'none',
+                 cfg['mid_batch_norm'], cfg['last_batch_norm'], mom, training)
+        ho = F.relu(ho)
+        if cfg.get('residual', False) and in_dim == out_dim:
+            ho = h + ho
+        h = ho
+    r = torch.cat([segment_readout(h, graph['batch_num_nodes'], op) for op in cfg['readout_aggregators']], dim=-1)
+    out = mlp(r, P, 'output', cfg['readout_layers'], 'relu', 'none', cfg['readout_batchnorm'], False,
+              cfg['batch_norm_momentum'], training)
+    return out, h
+
+
+def snorm_n(batch_num_nodes):
+    """reference datasets/custom_collate.py:46-47: per-node 1/sqrt(graph size), [N,1]."""
+    return torch.cat([torch.full((n, 1), 1.0 / float(n)) for n in batch_num_nodes]).sqrt()

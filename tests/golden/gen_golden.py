@@ -311,6 +311,50 @@ def gen_full_config(dgl, PNA, Net3D, NTXent):
     print('full_config.npz', len(out), 'arrays')
 
 
+PNA_ORIG_KW = dict(target_dim=4, hidden_dim=20, last_layer_dim=20, mid_batch_norm=True, last_batch_norm=True,
+                   graph_norm=True, readout_batchnorm=True, edge_hidden_dim=12, readout_hidden_dim=12, readout_layers=2,
+                   dropout=0.0, in_feat_dropout=0.0, propagation_depth=3, towers=5, divide_input_first=False,
+                   divide_input_last=True, aggregators=['mean', 'max', 'min', 'std'],
+                   scalers=['identity', 'amplification', 'attenuation'], readout_aggregators=['mean', 'max', 'min', 'sum'],
+                   pretrans_layers=1, posttrans_layers=1, residual=True, avg_d=1.4, device='cpu')
+PNA_SIMPLE_KW = dict(target_dim=4, hidden_dim=24, last_layer_dim=24, mid_batch_norm=True, last_batch_norm=True,
+                     readout_batchnorm=True, readout_hidden_dim=12, readout_layers=2, dropout=0.0, in_feat_dropout=0.0,
+                     propagation_depth=2, aggregators=['mean', 'max', 'min', 'std'],
+                     scalers=['identity', 'amplification', 'attenuation'], readout_aggregators=['min', 'max', 'mean'],
+                     posttrans_layers=1, residual=True, avg_d=1.4, batch_norm_momentum=0.1)
+
+
+def gen_pna_original(dgl):
+    """G8: the original-PNA variants of reference models/pna_original.py (config shape of
+    configs/pna_original.yml: towers 5, graph_norm, divide_input_first False / last True)."""
+    from models.pna_original import PNAOriginal, PNAOriginalSimple
+    mols = synth.make_dataset(6, seed=42)
+    out = mols_to_npz(mols)
+    for tag, cls, kw in (('orig', PNAOriginal, PNA_ORIG_KW), ('simple', PNAOriginalSimple, PNA_SIMPLE_KW)):
+        torch.manual_seed(321)
+        model = cls(**kw)
+        make_trained_like(model, 23)
+        with torch.no_grad():       # nn.Linear mixing / MLPReadout layers are not FCLayers: scale them as well
+            for n_, p in model.named_parameters():
+                if n_.endswith('mixing_network.weight') or ('FC_layers' in n_ and n_.endswith('weight')):
+                    p.mul_(2.0)
+        model.train()
+        out.update(sd_np(model, f'{tag}/sd'))
+        g2, _ = dgl_graphs(dgl, mols)
+        snorm = torch.cat([torch.full((m.n_atoms, 1), 1.0 / float(m.n_atoms)) for m in mols]).sqrt()
+        z = model(g2, snorm) if tag == 'orig' else model(g2)
+        out[f'{tag}/out'] = z.detach().numpy()
+        out[f'{tag}/node_emb'] = g2.ndata['feat'].detach().numpy()
+        c = torch.from_numpy(det_fill(tuple(z.shape), f'cot_{tag}'))
+        out[f'{tag}/cot'] = c.numpy()
+        (z * c).sum().backward()
+        out.update({f'{tag}/grad/{k}': p.grad.detach().numpy().copy() for k, p in model.named_parameters()
+                    if p.grad is not None})
+        out.update(sd_np(model, f'{tag}/sd_after'))
+    np.savez_compressed(os.path.join(HERE, 'pna_original.npz'), **out)
+    print('pna_original.npz', len(out), 'arrays')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
     dgl, PNA, PNALayer, Net3D, NTXent, NTXentMP = import_reference()
@@ -318,6 +362,7 @@ if __name__ == '__main__':
     gen_models_small(dgl, PNA, Net3D, NTXent)
     gen_ntxent(NTXent, NTXentMP)
     gen_full_config(dgl, PNA, Net3D, NTXent)
+    gen_pna_original(dgl)
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')

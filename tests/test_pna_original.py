@@ -1,0 +1,84 @@
+"""Original-PNA variants (reference models/pna_original.py): the oracle restatement is pinned to
+the fixture produced by the reference (CPU test), the HIP modules are compared with the same fixture (-m gpu)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import close, grads_close, load, mols_from_npz, rel_err, sd_from_npz
+from oracle import pna3d_oracle as O
+
+PNA_ORIG_KW = dict(target_dim=4, hidden_dim=20, last_layer_dim=20, mid_batch_norm=True, last_batch_norm=True,
+                   graph_norm=True, readout_batchnorm=True, edge_hidden_dim=12, readout_hidden_dim=12, readout_layers=2,
+                   dropout=0.0, in_feat_dropout=0.0, propagation_depth=3, towers=5, divide_input_first=False,
+                   divide_input_last=True, aggregators=['mean', 'max', 'min', 'std'],
+                   scalers=['identity', 'amplification', 'attenuation'], readout_aggregators=['mean', 'max', 'min', 'sum'],
+                   pretrans_layers=1, posttrans_layers=1, residual=True, avg_d=1.4, device='cpu')
+PNA_SIMPLE_KW = dict(target_dim=4, hidden_dim=24, last_layer_dim=24, mid_batch_norm=True, last_batch_norm=True,
+                     readout_batchnorm=True, readout_hidden_dim=12, readout_layers=2, dropout=0.0, in_feat_dropout=0.0,
+                     propagation_depth=2, aggregators=['mean', 'max', 'min', 'std'],
+                     scalers=['identity', 'amplification', 'attenuation'], readout_aggregators=['min', 'max', 'mean'],
+                     posttrans_layers=1, residual=True, avg_d=1.4, batch_norm_momentum=0.1)
+
+
+def _used(ref_grads):
+    """MLP_layer / node_gnn.output are constructed but never used by the reference's forward: no gradient."""
+    return {k: v for k, v in ref_grads.items()}
+
+
+@pytest.mark.parametrize('tag', ['orig', 'simple'])
+def test_oracle_matches_reference_fixture(tag):
+    z = load('pna_original.npz')
+    mols = mols_from_npz(z)
+    g2, _ = O.graphs_from_molecules(mols)
+    P = O.require_grad(sd_from_npz(z, f'{tag}/sd'))
+    if tag == 'orig':
+        out, emb = O.pna_original_forward(g2, O.snorm_n(g2['batch_num_nodes']), P, PNA_ORIG_KW, True)
+    else:
+        out, emb = O.pna_original_simple_forward(g2, P, PNA_SIMPLE_KW, True)
+    assert rel_err(emb, z[f'{tag}/node_emb']) < 2e-5
+    assert rel_err(out, z[f'{tag}/out']) < 2e-5
+    (out * torch.from_numpy(z[f'{tag}/cot'])).sum().backward()
+    ref = _used(sd_from_npz(z, f'{tag}/grad'))
+    grads_close({k: P[k].grad for k in ref}, ref, 2e-4)
+    for k, v in sd_from_npz(z, f'{tag}/sd_after').items():
+        if 'running' in k:
+            assert close(P[k], v, 2e-5, 1e-6), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['orig', 'simple'])
+def test_hip_modules_match_reference_fixture(tag):
+    assert torch.cuda.is_available()
+    amd = importlib.import_module('3dinfomax_amd')
+    z = load('pna_original.npz')
+    mols = mols_from_npz(z)
+    model = amd.PNAOriginal(**PNA_ORIG_KW) if tag == 'orig' else amd.PNAOriginalSimple(**PNA_SIMPLE_KW)
+    model.load_state_dict(sd_from_npz(z, f'{tag}/sd'), strict=True)       # identical keys and shapes
+    model.cuda().train()
+    g2 = amd.batch([amd.bond_graph(m) for m in mols]).to('cuda:0')
+    if tag == 'orig':
+        snorm = O.snorm_n([m.n_atoms for m in mols]).cuda()
+        out = model(g2, snorm)
+    else:
+        out = model(g2)
+    assert rel_err(g2.ndata['feat'].cpu(), z[f'{tag}/node_emb']) < 1e-4
+    assert rel_err(out.cpu(), z[f'{tag}/out']) < 1e-4
+    (out * torch.from_numpy(z[f'{tag}/cot']).cuda()).sum().backward()
+    ref = sd_from_npz(z, f'{tag}/grad')
+    grads_close({k: p.grad for k, p in model.named_parameters() if k in ref}, ref, 5e-4)
+    sd = model.state_dict()
+    for k, v in sd_from_npz(z, f'{tag}/sd_after').items():
+        if 'running' in k:
+            assert close(sd[k], v, 1e-4, 1e-6), k
+
+
+def test_state_dict_surface_of_original_variants():
+    amd = importlib.import_module('3dinfomax_amd')
+    z = load('pna_original.npz')
+    for tag, model in (('orig', amd.PNAOriginal(**PNA_ORIG_KW)), ('simple', amd.PNAOriginalSimple(**PNA_SIMPLE_KW))):
+        ref = sd_from_npz(z, f'{tag}/sd')
+        assert list(model.state_dict().keys()) == list(ref.keys()), tag
+        for k, v in model.state_dict().items():
+            assert tuple(v.shape) == tuple(ref[k].shape), k
