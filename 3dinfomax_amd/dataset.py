@@ -1,0 +1,145 @@
+"""Flat-tensor molecule store + vectorised batch assembly.
+
+The reference keeps a dataset as flat tensors with per-molecule slices (`features_tensor`, `e_features_tensor`,
+`edge_indices`, `coordinates`, `atom_slices`, `edge_slices`: reference datasets/qm9_dataset.py:153, 189-208) but then
+builds 2 x B Python graph objects per step and `dgl.batch`es them in the training thread
+(datasets/qm9_dataset.py:221-244, datasets/custom_collate.py:105-114) - on a GPU that is what bounds the step.
+
+Here a batch is assembled WITHOUT a per-molecule Python loop:
+  * 2D bond graph: numpy gathers over the flat arrays; because batching is block-diagonal, the destination-sorted
+    kernel index of the batch is the concatenation of per-molecule indices that are precomputed ONCE
+    (`perm`, in/out degrees, `out_epos`), shifted by the node/edge offsets;
+  * 3D complete graph: only coordinates and node offsets go to the device, the edges, distances and the index are
+    built there by one kernel (csrc/batch.hip).
+The result is identical to `graph.batch([bond_graph(m) ...])` / `graph.batch([complete_graph(m) ...])`
+(tests/test_dataset.py).
+"""
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from .graph import BatchedMolGraph, GraphIndex
+
+
+def _ranges(starts, lengths):
+    """Concatenation of arange(s, s+l) for every (s, l) - vectorised."""
+    total = int(lengths.sum())
+    if total == 0:
+        return np.zeros(0, dtype=np.int64)
+    offs = np.cumsum(lengths) - lengths
+    return np.repeat(starts - offs, lengths) + np.arange(total, dtype=np.int64)
+
+
+class FlatMolDataset:
+    def __init__(self, mols: Sequence):
+        n = np.array([m.n_atoms for m in mols], dtype=np.int64)
+        e = np.array([m.src.shape[0] for m in mols], dtype=np.int64)
+        self.n_atoms, self.n_edges = n, e
+        self.atom_start = np.cumsum(n) - n
+        self.edge_start = np.cumsum(e) - e
+        self.atom_feat = np.concatenate([m.atom_feat for m in mols]).astype(np.int64)
+        self.bond_feat = np.concatenate([m.bond_feat for m in mols]).astype(np.int64)
+        self.coords = np.concatenate([m.coords for m in mols]).astype(np.float32)
+        self.src = np.concatenate([m.src for m in mols]).astype(np.int64)          # local node ids, edge-id order
+        self.dst = np.concatenate([m.dst for m in mols]).astype(np.int64)
+        # per-molecule kernel index, computed once (block-diagonal batching concatenates them)
+        perm, inv, out_epos, indeg, outdeg = [], [], [], [], []
+        for m in mols:
+            p = np.argsort(m.dst, kind='stable')
+            ip = np.empty_like(p)
+            ip[p] = np.arange(p.shape[0])
+            perm.append(p)
+            inv.append(ip)
+            out_epos.append(np.argsort(m.src[p], kind='stable'))
+            indeg.append(np.bincount(m.dst, minlength=m.n_atoms))
+            outdeg.append(np.bincount(m.src, minlength=m.n_atoms))
+        self.perm = np.concatenate(perm).astype(np.int64)            # local epos -> local edge id
+        self.inv_perm = np.concatenate(inv).astype(np.int64)
+        self.out_epos = np.concatenate(out_epos).astype(np.int64)
+        self.indeg = np.concatenate(indeg).astype(np.int64)
+        self.outdeg = np.concatenate(outdeg).astype(np.int64)
+
+    def __len__(self):
+        return self.n_atoms.shape[0]
+
+    # ------------------------------------------------------------------------------------------------------
+    def assemble(self, ids, device, pin=False):
+        """-> ([g2d], [g3d]) on `device`, the layout `contrastive_collate` returns (reference
+        datasets/custom_collate.py:105-114)."""
+        g2, xyz, graph_ptr_dev, n, bnn = self.assemble_2d(ids, device, pin)
+        return [g2], [complete_graphs_on_device(xyz, graph_ptr_dev, n, bnn)]
+
+    def assemble_2d(self, ids, device, pin=False):
+        """The bond-graph half (pure numpy + three H2D copies; also usable on the CPU for tests)."""
+        ids = np.asarray(ids, dtype=np.int64)
+        n, e = self.n_atoms[ids], self.n_edges[ids]
+        B, N, E = ids.shape[0], int(n.sum()), int(e.sum())
+        node_off = np.cumsum(n) - n
+        edge_off = np.cumsum(e) - e
+        ngi = _ranges(self.atom_start[ids], n)            # rows of the flat node arrays
+        egi = _ranges(self.edge_start[ids], e)            # rows of the flat edge arrays
+        e_node_off = np.repeat(node_off, e)
+        e_edge_off = np.repeat(edge_off, e)
+        src = self.src[egi] + e_node_off                  # edge-id order
+        dst = self.dst[egi] + e_node_off
+        perm = self.perm[egi] + e_edge_off
+        i32 = np.empty(2 * (N + 1) + 5 * E + (B + 1), dtype=np.int32)
+        o = 0
+
+        def put(a):
+            nonlocal o
+            i32[o:o + a.shape[0]] = a
+            sl = slice(o, o + a.shape[0])
+            o += a.shape[0]
+            return sl
+        in_ptr = np.zeros(N + 1, dtype=np.int64)
+        np.cumsum(self.indeg[ngi], out=in_ptr[1:])
+        out_ptr = np.zeros(N + 1, dtype=np.int64)
+        np.cumsum(self.outdeg[ngi], out=out_ptr[1:])
+        graph_ptr = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(n, out=graph_ptr[1:])
+        s_in, s_perm, s_src, s_dst = put(in_ptr), put(perm), put(src[perm]), put(dst[perm])
+        s_out, s_oe, s_gp = put(out_ptr), put(self.out_epos[egi] + e_edge_off), put(graph_ptr)
+        s_inv = put(self.inv_perm[egi] + e_edge_off)
+        i64 = np.concatenate([src, dst, self.atom_feat[ngi].ravel(), self.bond_feat[egi].ravel()])
+        f32 = self.coords[ngi]
+        ti32, ti64, tf32 = torch.from_numpy(i32), torch.from_numpy(i64), torch.from_numpy(f32)
+        if pin:
+            ti32, ti64, tf32 = ti32.pin_memory(), ti64.pin_memory(), tf32.pin_memory()
+        d32 = ti32.to(device, non_blocking=True)
+        d64 = ti64.to(device, non_blocking=True)
+        xyz = tf32.to(device, non_blocking=True)
+        bnn = torch.from_numpy(n)
+        idx2 = GraphIndex(N, E, B, d32[s_in], d32[s_perm], d32[s_src], d32[s_dst], d32[s_out], d32[s_oe], d32[s_gp],
+                          d32[s_inv], int(self.indeg[ngi].max()) if E else 0)
+        g2 = BatchedMolGraph(d64[:E], d64[E:2 * E], N, bnn,
+                             ndata={'feat': d64[2 * E:2 * E + 9 * N].view(N, 9)},
+                             edata={'feat': d64[2 * E + 9 * N:].view(E, 3)}, index=idx2)
+        return g2, xyz, d32[s_gp], n, bnn
+
+
+def complete_graphs_on_device(xyz, graph_ptr_dev, n_atoms_host, bnn) -> BatchedMolGraph:
+    """Complete distance graphs of a batch, built by csrc/batch.hip from coordinates [N,3] on the device."""
+    from . import _lib
+    dev = xyz.device
+    B, N = int(n_atoms_host.shape[0]), int(xyz.shape[0])
+    e3 = n_atoms_host * (n_atoms_host - 1)
+    edge_ptr = np.zeros(B + 1, dtype=np.int32)
+    np.cumsum(e3, out=edge_ptr[1:])
+    E3 = int(edge_ptr[-1])
+    edge_ptr_d = torch.from_numpy(edge_ptr).to(dev, non_blocking=True)
+    ints = torch.empty((N + 1) + 5 * E3, dtype=torch.int32, device=dev)
+    in_ptr = ints[:N + 1]
+    src_s, dst_s, perm, inv_perm, out_epos = [ints[N + 1 + k * E3:N + 1 + (k + 1) * E3] for k in range(5)]
+    ids = torch.empty(2 * E3, dtype=torch.int64, device=dev)
+    d = torch.empty(E3, 1, dtype=torch.float32, device=dev)
+    L = _lib.load()
+    stream = torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+    _lib.check(L.i3d_complete_graph_build(xyz.data_ptr(), graph_ptr_dev.data_ptr(), edge_ptr_d.data_ptr(), B, N, E3,
+                                          in_ptr.data_ptr(), src_s.data_ptr(), dst_s.data_ptr(), perm.data_ptr(),
+                                          inv_perm.data_ptr(), out_epos.data_ptr(), ids[:E3].data_ptr(),
+                                          ids[E3:].data_ptr(), d.data_ptr(), stream), 'i3d_complete_graph_build')
+    idx3 = GraphIndex(N, E3, B, in_ptr, perm, src_s, dst_s, in_ptr, out_epos, graph_ptr_dev, inv_perm,
+                      int(n_atoms_host.max()) - 1)
+    return BatchedMolGraph(ids[:E3], ids[E3:], N, bnn, ndata={}, edata={'d': d}, index=idx3)

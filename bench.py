@@ -151,6 +151,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
+    # secondary figure (SURVEY.md 8d "also report with H2D/collate included", row f1): every step first assembles a
+    # fresh batch from the flat dataset on the host (vectorised numpy), copies it and builds the 3D graphs on device
+    with_assembly = None
+    if not use_dist or world == 1:
+        dataset = importlib.import_module('3dinfomax_amd.dataset')
+        all_mols = [m for _, _, shard in batches for m in shard]
+        flat = dataset.FlatMolDataset(all_mols)
+        rng = np.random.default_rng(0)
+        n_asm = min(args.steps, 20)
+
+        def step_asm():
+            ids = rng.permutation(len(all_mols))[:B]
+            (a,), (b,) = flat.assemble(ids, dev)
+            loss = loss_fn(pna(a), net(b), nodes_per_graph=a.batch_num_nodes())
+            loss.backward()
+            if use_dist:
+                adist.allreduce_grads(params)
+            optim.step()
+            optim.zero_grad()
+        for _ in range(3):
+            step_asm()
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(n_asm):
+            step_asm()
+        torch.cuda.synchronize()
+        with_assembly = round(n_asm * B / (time.perf_counter() - ta), 1)
+
     # roofline of the dominant HBM kernel: K4 PNA aggregation (forward), algorithmic bytes per SURVEY.md 8d
     ev = timers.get('pna_aggregate_fwd', [])
     roof = None
@@ -204,7 +232,8 @@ def main():
                                         f'QM9-shaped synthetic molecules, batch {B}/GPU, fp32, Adam',
                                global_batch=B * world, parallelism=f'dp{world}' if world > 1 else 'single',
                                sync_bn=(use_dist and not args.no_sync_bn), final_loss=round(float(loss.item()), 5),
-                               host_enqueue_ms_per_step=round(t_enqueue / args.steps * 1e3, 3)),
+                               host_enqueue_ms_per_step=round(t_enqueue / args.steps * 1e3, 3),
+                               molecules_per_s_incl_batch_assembly_and_h2d=with_assembly),
                    roofline=roof)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(batches[0][2], args.depth, args.cpu_steps)

@@ -207,6 +207,17 @@ int i3d_row_axpy(const float* z, const float* coef, int rows, int dim, float* ou
 /* out[r,:] = coef[r] * z[r,:]   (graph-size normalisation h * snorm_n, reference models/pna_original.py:258-259) */
 int i3d_row_scale(const float* z, const float* coef, int rows, int dim, float* out, void* stream);
 
+/* ---- batch assembly -----------------------------------------------------------------
+ * replaces B x QM9Dataset.get_complete_graph (reference datasets/qm9_dataset.py:233-244, :215-217) + dgl.batch
+ * (datasets/custom_collate.py:108-109) for the 3D view: from coords [N,3] and the node offsets graph_ptr[B+1] (plus
+ * edge_ptr[B+1], the prefix sum of n(n-1)) builds, on the device, the complete graphs in the reference's edge-id
+ * order (src_id/dst_id int64 [E3], d_id fp32 [E3] = ||x_src-x_dst||) AND the destination-sorted kernel index
+ * (in_ptr[N+1] (== out_ptr), src_s, dst_s, perm, inv_perm, out_epos: int32 [E3]). */
+int i3d_complete_graph_build(const float* coords, const int* graph_ptr, const int* edge_ptr, int num_graphs,
+                             int num_nodes, int num_edges, int* in_ptr, int* src_s, int* dst_s, int* perm,
+                             int* inv_perm, int* out_epos, int64_t* src_id, int64_t* dst_id, float* d_id,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif
