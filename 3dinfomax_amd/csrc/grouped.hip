@@ -1,0 +1,94 @@
+// Degree-combined posttrans weights of the PNA layer.
+//
+// The reference concatenates [h | a | amp(D) a | att(D) a] (a = the n_agg aggregators, models/pna.py:229-233, 207) and
+// multiplies by W3 [F_out, F_in + S*A] (A = n_agg*F_in).  The scalers are per-node scalars that only depend on the
+// in-degree D, so for all nodes of one degree
+//     [a | amp a | att a] W_agg^T  =  a ( sum_s c_s(D) W_s )^T  =:  a W_D^T            (re-association only)
+// which cuts the K of the dominant GEMM of the layer from S*A to A (12F -> 4F) and lets the aggregation kernel write
+// [N, 4F] instead of [N, 12F].  W_D is built here per degree group (a handful of [F_out, A] matrices, ~1 MB), its
+// gradient is folded back into the S blocks of dW3:  dW_s = sum_D c_s(D) dW_D.
+#include "common.h"
+
+namespace i3d {
+
+constexpr int MAX_GROUPS = 32, MAX_SCALERS = 4;
+struct Coef {
+    float c[MAX_GROUPS][MAX_SCALERS];
+};
+
+// WD[g][n][k] = sum_s coef[g][s] * W[n][f_in + s*A + k]
+__global__ void __launch_bounds__(256)
+combine_weights_fwd_kernel(const float4* __restrict__ W, int ldw4, int f_in4, int f_out, int A4, int n_groups,
+                           int n_scalers, Coef coef, float4* __restrict__ WD) {
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long per = (long)f_out * A4;
+    if (t >= per) return;
+    int n = (int)(t / A4), k = (int)(t - (long)n * A4);
+    float4 w[MAX_SCALERS];
+    for (int s = 0; s < n_scalers; ++s) w[s] = W[(long)n * ldw4 + f_in4 + (long)s * A4 + k];
+    for (int g = 0; g < n_groups; ++g) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < n_scalers; ++s) {
+            float c = coef.c[g][s];
+            o.x += c * w[s].x; o.y += c * w[s].y; o.z += c * w[s].z; o.w += c * w[s].w;
+        }
+        WD[(long)g * per + t] = o;
+    }
+}
+
+// dW[n][f_in + s*A + k] = sum_g coef[g][s] * dWD[g][n][k]
+__global__ void __launch_bounds__(256)
+combine_weights_bwd_kernel(const float4* __restrict__ dWD, int ldw4, int f_in4, int f_out, int A4, int n_groups,
+                           int n_scalers, Coef coef, float4* __restrict__ dW) {
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long per = (long)f_out * A4;
+    if (t >= per) return;
+    int n = (int)(t / A4), k = (int)(t - (long)n * A4);
+    float4 acc[MAX_SCALERS];
+    for (int s = 0; s < n_scalers; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < n_groups; ++g) {
+        float4 d = dWD[(long)g * per + t];
+        for (int s = 0; s < n_scalers; ++s) {
+            float c = coef.c[g][s];
+            acc[s].x += c * d.x; acc[s].y += c * d.y; acc[s].z += c * d.z; acc[s].w += c * d.w;
+        }
+    }
+    for (int s = 0; s < n_scalers; ++s) dW[(long)n * ldw4 + f_in4 + (long)s * A4 + k] = acc[s];
+}
+
+static int fill_coef(const float* coef_host, int n_groups, int n_scalers, Coef& c) {
+    if (n_groups < 1 || n_groups > MAX_GROUPS || n_scalers < 1 || n_scalers > MAX_SCALERS) return -1;
+    for (int g = 0; g < n_groups; ++g)
+        for (int s = 0; s < n_scalers; ++s) c.c[g][s] = coef_host[g * n_scalers + s];
+    return 0;
+}
+
+}  // namespace i3d
+
+using namespace i3d;
+
+extern "C" int i3d_pna_combine_weights_fwd(const float* W, int ldw, int f_in, int f_out, int agg_width, int n_groups,
+                                           int n_scalers, const float* coef, float* WD, void* stream) {
+    I3D_CHECK_ARG(f_in % 4 == 0 && agg_width % 4 == 0 && ldw % 4 == 0, "dimensions must be multiples of 4");
+    I3D_CHECK_ARG((((uintptr_t)W | (uintptr_t)WD) & 15) == 0, "16-byte aligned pointers required");
+    Coef c;
+    I3D_CHECK_ARG(fill_coef(coef, n_groups, n_scalers, c) == 0, "1..32 groups and 1..4 scalers supported");
+    long items = (long)f_out * (agg_width / 4);
+    hipLaunchKernelGGL(combine_weights_fwd_kernel, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)W, ldw / 4, f_in / 4, f_out, agg_width / 4, n_groups, n_scalers, c, (float4*)WD);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_pna_combine_weights_bwd(const float* dWD, int ldw, int f_in, int f_out, int agg_width, int n_groups,
+                                           int n_scalers, const float* coef, float* dW, void* stream) {
+    I3D_CHECK_ARG(f_in % 4 == 0 && agg_width % 4 == 0 && ldw % 4 == 0, "dimensions must be multiples of 4");
+    I3D_CHECK_ARG((((uintptr_t)dW | (uintptr_t)dWD) & 15) == 0, "16-byte aligned pointers required");
+    Coef c;
+    I3D_CHECK_ARG(fill_coef(coef, n_groups, n_scalers, c) == 0, "1..32 groups and 1..4 scalers supported");
+    long items = (long)f_out * (agg_width / 4);
+    hipLaunchKernelGGL(combine_weights_bwd_kernel, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)dWD, ldw / 4, f_in / 4, f_out, agg_width / 4, n_groups, n_scalers, c, (float4*)dW);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}

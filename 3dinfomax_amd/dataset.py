@@ -19,7 +19,7 @@ from typing import List, Sequence
 import numpy as np
 import torch
 
-from .graph import BatchedMolGraph, GraphIndex
+from .graph import BatchedMolGraph, GraphIndex, group_nodes_by_degree
 
 
 def _ranges(starts, lengths):
@@ -111,8 +111,11 @@ class FlatMolDataset:
         d64 = ti64.to(device, non_blocking=True)
         xyz = tf32.to(device, non_blocking=True)
         bnn = torch.from_numpy(n)
+        rows, tiles, groups = group_nodes_by_degree(self.indeg[ngi])
         idx2 = GraphIndex(N, E, B, d32[s_in], d32[s_perm], d32[s_src], d32[s_dst], d32[s_out], d32[s_oe], d32[s_gp],
-                          d32[s_inv], int(self.indeg[ngi].max()) if E else 0)
+                          d32[s_inv], int(self.indeg[ngi].max()) if E else 0,
+                          torch.from_numpy(rows).to(device, non_blocking=True),
+                          torch.from_numpy(tiles).to(device, non_blocking=True), groups)
         g2 = BatchedMolGraph(d64[:E], d64[E:2 * E], N, bnn,
                              ndata={'feat': d64[2 * E:2 * E + 9 * N].view(N, 9)},
                              edata={'feat': d64[2 * E + 9 * N:].view(E, 3)}, index=idx2)

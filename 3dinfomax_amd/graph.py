@@ -34,12 +34,51 @@ class GraphIndex:
     graph_ptr: torch.Tensor   # [B+1] node offsets of the graphs in the batch
     inv_perm: torch.Tensor    # [E]   edge id -> epos
     max_in_degree: int
+    # nodes grouped by in-degree (degree-combined posttrans weights, csrc/grouped.hip); built lazily by degree_groups()
+    deg_rows: Optional[torch.Tensor] = None        # [M_pad] node ids grouped by in-degree, each group padded to 64 with -1
+    deg_tile_group: Optional[torch.Tensor] = None  # [M_pad/64] group of every 64-row tile
+    deg_groups: Optional[tuple] = None             # host: ((D, start, count), ...) for the in-degrees D > 0 present
 
     def to(self, device):
-        return GraphIndex(self.num_nodes, self.num_edges, self.num_graphs,
-                          *[t.to(device, non_blocking=True) for t in
-                            (self.in_ptr, self.perm, self.src_s, self.dst_s, self.out_ptr,
-                             self.out_epos, self.graph_ptr, self.inv_perm)], self.max_in_degree)
+        out = GraphIndex(self.num_nodes, self.num_edges, self.num_graphs,
+                         *[t.to(device, non_blocking=True) for t in
+                           (self.in_ptr, self.perm, self.src_s, self.dst_s, self.out_ptr,
+                            self.out_epos, self.graph_ptr, self.inv_perm)], self.max_in_degree)
+        if self.deg_rows is not None:
+            out.deg_rows = self.deg_rows.to(device, non_blocking=True)
+            out.deg_tile_group = self.deg_tile_group.to(device, non_blocking=True)
+            out.deg_groups = self.deg_groups
+        return out
+
+    def degree_groups(self):
+        """(deg_rows, deg_tile_group, deg_groups), computed once per batch from in_ptr (host round trip only if the
+        batch was not assembled through build_index / dataset.assemble, which fill them in on the host)."""
+        if self.deg_rows is None:
+            indeg = np.diff(self.in_ptr.cpu().numpy().astype(np.int64))
+            rows, tiles, groups = group_nodes_by_degree(indeg)
+            dev = self.in_ptr.device
+            self.deg_rows = torch.from_numpy(rows).to(dev)
+            self.deg_tile_group = torch.from_numpy(tiles).to(dev)
+            self.deg_groups = groups
+        return self.deg_rows, self.deg_tile_group, self.deg_groups
+
+
+def group_nodes_by_degree(indeg, pad=64):
+    """Node ids grouped by in-degree D > 0 (ascending D, ascending node id), every group padded with -1 to a multiple of
+    `pad` rows; tile -> group map; ((D, start, count), ...)."""
+    indeg = np.asarray(indeg, dtype=np.int64)
+    order = np.argsort(indeg, kind='stable')
+    order = order[indeg[order] > 0]
+    degs, counts = np.unique(indeg[order], return_counts=True)
+    padded = (counts + pad - 1) // pad * pad
+    starts = np.cumsum(padded) - padded
+    rows = np.full(int(padded.sum()), -1, dtype=np.int32)
+    src_off = np.cumsum(counts) - counts
+    dst_idx = np.repeat(starts - src_off, counts) + np.arange(order.shape[0])
+    rows[dst_idx] = order.astype(np.int32)
+    tiles = np.repeat(np.arange(degs.shape[0], dtype=np.int32), padded // pad)
+    groups = tuple((int(d), int(s), int(c)) for d, s, c in zip(degs, starts, counts))
+    return rows, tiles, groups
 
 
 def build_index(src, dst, num_nodes, batch_num_nodes) -> GraphIndex:
@@ -61,9 +100,10 @@ def build_index(src, dst, num_nodes, batch_num_nodes) -> GraphIndex:
     inv_perm = np.empty(E, dtype=np.int64)
     inv_perm[perm] = np.arange(E)
     i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.int32)))
+    rows, tiles, groups = group_nodes_by_degree(indeg)
     return GraphIndex(int(num_nodes), int(E), int(bnn.shape[0]), i32(in_ptr), i32(perm), i32(src_s),
                       i32(dst_s), i32(out_ptr), i32(out_epos), i32(graph_ptr), i32(inv_perm),
-                      int(indeg.max()) if E else 0)
+                      int(indeg.max()) if E else 0, torch.from_numpy(rows), torch.from_numpy(tiles), groups)
 
 
 class BatchedMolGraph:

@@ -185,6 +185,49 @@ class Concat2FCFn(torch.autograd.Function):
         return ga, gc, gW, gbias, gg, gb, grad_res, None
 
 
+class GroupedConcat2FCFn(torch.autograd.Function):
+    """FC layer on [h | a | s_2(D) a | s_3(D) a ...] where only the aggregator block `a` [N, A] exists: the scaler
+    blocks are per-node multiples that depend on the in-degree D alone, so nodes of one degree share the combined weight
+    W_D = sum_s c_s(D) W_s  (csrc/grouped.hip).  pre = h W_h^T + b + a[deg group] W_D^T  - K of the dominant GEMM drops from
+    S*A to A.  reference models/pna.py:207-209 + 229-233, re-associated.  `coef` = [[c_s(D) for s] for D in groups]."""
+
+    @staticmethod
+    def forward(ctx, h, a, W, b, gamma, beta, residual, index, coef, spec: FCSpec):
+        h, a = h.contiguous(), a.contiguous()
+        Fh, A = h.shape[1], a.shape[1]
+        rows, tiles, groups = index.degree_groups()
+        nG, nS = len(groups), len(coef[0])
+        flat = [c for g in coef for c in g]
+        pre = ops.gemm(h, W[:, :Fh], trans_b=True, bias=b)
+        WD = ops.combine_weights_fwd(W, Fh, A, flat, nG, nS)
+        ops.gemm_grouped(a, rows, tiles, WD, pre, trans_b=True, accumulate=True)
+        y, saved = _Tail.forward(pre, gamma, beta, spec, residual)
+        ctx.spec, ctx.saved, ctx.has_res, ctx.index, ctx.coef = spec, saved, residual is not None, index, (flat, nG, nS)
+        ctx.save_for_backward(h, a, W, WD, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        h, a, W, WD, gamma, beta = ctx.saved_tensors
+        Fh, A = h.shape[1], a.shape[1]
+        flat, nG, nS = ctx.coef
+        rows, tiles, groups = ctx.index.degree_groups()
+        grad_y = grad_y.contiguous()
+        grad_res = grad_y if ctx.has_res else None
+        grad_pre, gg, gb = _Tail.backward(ctx.saved, grad_y, gamma, beta, ctx.spec)
+        gW = torch.empty_like(W)
+        ops.gemm(grad_pre, h, trans_a=True, out=gW[:, :Fh])
+        gWD = torch.empty_like(WD)
+        for gi, (_, start, count) in enumerate(groups):       # dW_D = dY_D^T a_D over the rows of the group
+            ops.gemm_rowsubset(grad_pre, a, rows[start:start + count], gWD[gi])
+        ops.combine_weights_bwd(gWD, gW, Fh, A, flat, nG, nS)
+        gbias = ops.colsum(grad_pre)
+        gh = ops.gemm(grad_pre, W[:, :Fh])
+        ga = torch.empty_like(a)        # rows of in-degree 0 stay unwritten: the aggregation backward never reads them
+        ops.gemm_grouped(grad_pre, rows, tiles, WD, ga, trans_b=False, accumulate=False)
+        return gh, ga, gW, gbias, gg, gb, grad_res, None, None, None
+
+
 class EdgeFCFn(torch.autograd.Function):
     """First FC layer of an edge MLP on [h_src | h_dst | q] (q optional) without the gather/concat:
         P = h [W_s | W_d]^T  (node level),  Q = q W_q^T,  pre[j] = P[src_j, :F] + P[dst_j, F:] + Q[j] + b
@@ -319,6 +362,17 @@ class MLP(nn.Module):
         x = EdgeFCFn.apply(h, q, fc0.linear.weight, fc0.linear.bias, gamma, beta, index, fc0.spec())
         for fc in list(self.fully_connected)[1:]:
             x = fc(x)
+        return x
+
+    def forward_concat2_grouped(self, h, a, index, coef, residual=None):
+        """[h | scaler blocks of a] -> MLP with the degree-combined weights (GroupedConcat2FCFn) for the first layer."""
+        fcs = list(self.fully_connected)
+        fc0 = fcs[0]
+        gamma, beta = fc0.bn_affine()
+        x = GroupedConcat2FCFn.apply(h, a, fc0.linear.weight, fc0.linear.bias, gamma, beta,
+                                     residual if len(fcs) == 1 else None, index, coef, fc0.spec())
+        for i, fc in enumerate(fcs[1:]):
+            x = fc(x, residual if i == len(fcs) - 2 else None)
         return x
 
     def forward_concat2(self, a, c, residual=None):

@@ -364,3 +364,52 @@ def row_scale(z, coef):
     out = torch.empty_like(z)
     check(_lib.load().i3d_row_scale(_p(z), _p(coef), z.shape[0], z.shape[1], _p(out), _stream()), 'i3d_row_scale')
     return out
+
+
+# ---- degree-grouped posttrans ------------------------------------------------------------------------------
+def _float_array(values):
+    from ctypes import c_float
+    return (c_float * len(values))(*values)
+
+
+def combine_weights_fwd(W, f_in, agg_width, coef, n_groups, n_scalers):
+    """WD[g] = sum_s coef[g][s] * W[:, f_in + s*agg_width : f_in + (s+1)*agg_width]  -> [n_groups, f_out, agg_width]."""
+    _chk(W)
+    f_out = W.shape[0]
+    WD = torch.empty(n_groups, f_out, agg_width, dtype=torch.float32, device=W.device)
+    check(_lib.load().i3d_pna_combine_weights_fwd(_p(W), W.shape[1], f_in, f_out, agg_width, n_groups, n_scalers,
+                                                  _float_array(coef), _p(WD), _stream()), 'i3d_pna_combine_weights_fwd')
+    return WD
+
+
+def combine_weights_bwd(dWD, dW, f_in, agg_width, coef, n_groups, n_scalers):
+    """dW[:, f_in + s*agg_width ...] = sum_g coef[g][s] * dWD[g]   (writes the aggregate blocks of dW in place)."""
+    _chk(dWD)
+    _chk(dW)
+    check(_lib.load().i3d_pna_combine_weights_bwd(_p(dWD), dW.shape[1], f_in, dW.shape[0], agg_width, n_groups,
+                                                  n_scalers, _float_array(coef), _p(dW), _stream()),
+          'i3d_pna_combine_weights_bwd')
+    return dW
+
+
+def gemm_grouped(A, m_rows, tile_group, Bg, out, trans_b, accumulate):
+    """out[r] (+)= A[r] @ op(Bg[group of r])  for the rows listed in m_rows (64-padded per group, -1 = padding)."""
+    _chk(A)
+    _chk(Bg)
+    K = A.shape[1]
+    N = Bg.shape[1] if trans_b else Bg.shape[2]
+    assert (Bg.shape[2] if trans_b else Bg.shape[1]) == K and out.shape[1] == N
+    check(_lib.load().i3d_gemm_f32_grouped(int(trans_b), m_rows.shape[0], N, K, _p(A), A.shape[1], A.shape[0], _p(m_rows),
+                                           _p(tile_group), _p(Bg), Bg.shape[2], Bg.shape[1] * Bg.shape[2], _p(out),
+                                           _ld(out), int(accumulate), _stream()), 'i3d_gemm_f32_grouped')
+    return out
+
+
+def gemm_rowsubset(A, B, k_rows, out):
+    """out[M,N] = sum over rows r in k_rows of A[r,:M]^T B[r,:N]."""
+    _chk(A)
+    _chk(B)
+    check(_lib.load().i3d_gemm_f32_rowsubset(A.shape[1], B.shape[1], k_rows.shape[0], _p(A), A.shape[1], _p(B), B.shape[1],
+                                             _p(k_rows), A.shape[0], _p(out), _ld(out), 0, _stream()),
+          'i3d_gemm_f32_rowsubset')
+    return out

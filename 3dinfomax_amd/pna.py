@@ -10,7 +10,11 @@ the hardware:
   * the four aggregators x three scalers are one segmented pass (csrc/aggregate.hip);
   * cat([h, agg]) -> posttrans is two accumulating GEMMs (layers.Concat2FCFn), BN + residual fused.
 """
+import math
+import os
 from typing import Callable, Dict, List, Union
+
+import numpy as np
 
 import torch
 from torch import nn
@@ -25,6 +29,19 @@ EPS = 1e-5
 # name tables kept for API compatibility (reference models/pna.py:71-87); values are the kernel codes
 PNA_AGGREGATORS = {k: v for k, v in ops.AGG.items()}
 PNA_SCALERS = {k: v for k, v in ops.SCALER.items()}
+
+
+# I3D_GROUPED_POSTTRANS=0 selects the reference-shaped path ([N,12F] aggregate + K=13F posttrans GEMM)
+GROUPED_POSTTRANS = os.environ.get('I3D_GROUPED_POSTTRANS', '1') != '0'
+
+
+def _scaler_coef(scaler_code, D, avg):
+    """reference models/pna.py:57-68: np.log in float64, then cast to the fp32 tensor's dtype."""
+    if scaler_code == ops.SCALER['amplification']:
+        return float(np.float32(math.log(D + 1) / avg))
+    if scaler_code == ops.SCALER['attenuation']:
+        return float(np.float32(avg / math.log(D + 1)))
+    return 1.0
 
 
 def _codes(names, table, what):
@@ -138,10 +155,18 @@ class PNALayer(nn.Module):
             ef_sorted = _GatherRowsFn.apply(g.edata['feat'], idx.perm, idx.inv_perm)
         # pretransformation (edge MLP on [h_src | h_dst | e_feat]) -> messages, destination-sorted
         e = self.pretrans.forward_edge(h, ef_sorted if self.edge_features else None, idx)
-        # aggregation: mean/max/min/std x scalers in one segmented pass
-        agg = AggregateFn.apply(e, idx, self.aggregators, self.scalers, float(self.avg_d["log"]))
-        # post-transformation on [h | agg] (+ residual fused into the last BN)
-        h_new = self.posttrans.forward_concat2(h, agg, residual=h if self.residual else None)
+        avg = float(self.avg_d["log"])
+        if GROUPED_POSTTRANS and len(self.scalers) > 1 and h.shape[1] % 4 == 0:
+            # the scaler blocks are per-node multiples of the aggregator block that depend on the in-degree only:
+            # aggregate once ([N, n_agg*F], identity block) and fold the scalers into per-degree posttrans weights
+            a = AggregateFn.apply(e, idx, self.aggregators, [ops.SCALER['identity']], avg)
+            coef = [[_scaler_coef(s, D, avg) for s in self.scalers] for D, _, _ in idx.degree_groups()[2]]
+            h_new = self.posttrans.forward_concat2_grouped(h, a, idx, coef, residual=h if self.residual else None)
+        else:
+            # reference-shaped path: mean/max/min/std x scalers written as [N, 12F] in one segmented pass, then
+            # post-transformation on [h | agg] (+ residual fused into the last BN)
+            agg = AggregateFn.apply(e, idx, self.aggregators, self.scalers, avg)
+            h_new = self.posttrans.forward_concat2(h, agg, residual=h if self.residual else None)
         g.ndata['feat'] = h_new
         return h_new
 

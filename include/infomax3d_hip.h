@@ -103,11 +103,32 @@ int i3d_segment_readout_bwd(const float* grad_out, const float* x, const int* gr
  *   dW = dY^T X             : trans_a=1, trans_b=0, A=dY[M',N'] (K := rows) */
 int i3d_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                  float* C, int ldc, const float* bias, int accumulate, void* stream);
-/* tuning entry: same, with the tile configuration BMxBNxBK (0: 64x208x16, 1: 128x208x16, 2: 128x128x16, 3: 256x32x16,
- * 4: 64x64x16, 5: 64x64x32, 6: 128x128x32, 7: 128x64x32, 8: 32x64x32; -1 = auto)
- * and the split-K factor (0 = auto) forced - used by tools/gemm_bench.py to pick the dispatch heuristics */
+/* tuning entry: same, with the tile configuration BMxBNxBK forced (0: 128x128x16, 1: 256x32x16, 2: 64x64x16, 3: 32x64x32 on
+ * v_mfma_f32_16x16x4_f32; 4: 64x64x16, 5: 128x128x16 on v_mfma_f32_32x32x2_f32; -1 = auto) and the split-K factor
+ * (0 = auto) - used by tools/gemm_bench.py to pick the dispatch heuristics */
 int i3d_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                     float* C, int ldc, const float* bias, int accumulate, int tile_cfg, int splits, void* stream);
+
+/* ---- degree-grouped posttrans of the PNA layer ------------------------------------------------------
+ * replaces cat([h, agg]) -> posttrans Linear of reference models/pna.py:207-209 for the aggregated part:  the three
+ * scaler blocks of agg are per-node multiples (functions of the in-degree D only) of the same aggregator block a,
+ * so  [a | amp(D) a | att(D) a] W_agg^T = a W_D^T  with  W_D = sum_s c_s(D) W_s  (re-association only): K drops
+ * from n_scalers*A to A, and the aggregation kernel only has to write the identity block.
+ *  combine_weights_fwd: WD[g, n, k] = sum_s coef[g*n_scalers+s] * W[n, f_in + s*agg_width + k]   (coef: host array)
+ *  combine_weights_bwd: dW[n, f_in + s*agg_width + k] = sum_g coef[g*n_scalers+s] * dWD[g, n, k]
+ *  gemm_f32_grouped:    C[r, :] (+)= A[r, :] * op(B_g) for r = m_rows[m] >= 0, g = tile_group[m / 64]; m_rows lists
+ *                       the nodes grouped by in-degree, every group padded with -1 to a multiple of 64 rows;
+ *                       trans_b = 1: B_g stored [N, K] (forward, B_g = WD[g]);  0: B_g stored [K, N] (data gradient)
+ *  gemm_f32_rowsubset:  C[M, N] = sum_j A[k_rows[j], 0:M]^T B[k_rows[j], 0:N]   (weight gradient of one group) */
+int i3d_pna_combine_weights_fwd(const float* W, int ldw, int f_in, int f_out, int agg_width, int n_groups,
+                                int n_scalers, const float* coef, float* WD, void* stream);
+int i3d_pna_combine_weights_bwd(const float* dWD, int ldw, int f_in, int f_out, int agg_width, int n_groups,
+                                int n_scalers, const float* coef, float* dW, void* stream);
+int i3d_gemm_f32_grouped(int trans_b, int m_padded, int N, int K, const float* A, int lda, long a_rows_total,
+                         const int* m_rows, const int* tile_group, const float* B, int ldb, long b_group_stride,
+                         float* C, int ldc, int accumulate, void* stream);
+int i3d_gemm_f32_rowsubset(int M, int N, int n_rows, const float* A, int lda, const float* B, int ldb,
+                           const int* k_rows, long rows_total, float* C, int ldc, int accumulate, void* stream);
 
 /* ---- column statistics / BatchNorm1d ---------------------------------------------------------------
  * replaces nn.BatchNorm1d in FCLayer (train: batch statistics, momentum m, unbiased running_var; eval: running

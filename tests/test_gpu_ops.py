@@ -86,7 +86,7 @@ def test_gemm_split_k_into_strided_column_block(rows):
     L = importlib.import_module('3dinfomax_amd._lib')
     from ctypes import c_void_p
     lib = L.load()
-    for cfg, splits in ((4, 4), (8, 16), (2, 2), (5, 7)):
+    for cfg, splits in ((4, 4), (3, 16), (2, 2), (0, 7)):
         out = torch.full((Fo, Fa + Fc), 7.0, device=DEV)
         A, B = g(dY), g(c)
         rc = lib.i3d_gemm_f32_ex(1, 0, Fo, Fc, rows, c_void_p(A.data_ptr()), Fo, c_void_p(B.data_ptr()), Fc,
@@ -95,6 +95,47 @@ def test_gemm_split_k_into_strided_column_block(rows):
         assert rc == 0
         assert rel_err(out[:, Fa:].cpu(), ref[:, Fa:]) < 2e-5, (cfg, splits)
         assert torch.all(out[:, :Fa] == 7.0)
+
+
+def test_degree_grouped_posttrans_gemms():
+    """gemm_grouped / gemm_rowsubset / combine_weights against the reference-shaped computation
+    [a | amp(D) a | att(D) a] W_agg^T with per-node scalers."""
+    graph = importlib.import_module('3dinfomax_amd.graph')
+    n, F_out, A, S = 1500, 200, 800, 3
+    rng = np.random.default_rng(0)
+    indeg = rng.choice([0, 1, 2, 3, 4, 6], size=n, p=[0.03, 0.45, 0.1, 0.1, 0.3, 0.02])
+    rows, tiles, groups = graph.group_nodes_by_degree(indeg)
+    assert rows.shape[0] % 64 == 0 and sorted(rows[rows >= 0].tolist()) == np.nonzero(indeg > 0)[0].tolist()
+    coef = [[1.0, float(np.float32(math.log(D + 1))), float(np.float32(1 / math.log(D + 1)))] for D, _, _ in groups]
+    flat = [c for gco in coef for c in gco]
+    a, W = rnd(n, A, seed=1), rnd(F_out, 200 + S * A, seed=2, scale=0.05)
+    a[indeg == 0] = 0
+    amp = torch.tensor([math.log(d + 1) if d > 0 else 0.0 for d in indeg], dtype=torch.float32)[:, None]
+    att = torch.tensor([1 / math.log(d + 1) if d > 0 else 0.0 for d in indeg], dtype=torch.float32)[:, None]
+    agg12 = torch.cat([a, a * amp, a * att], 1)
+    ref = agg12.double() @ W[:, 200:].double().T
+    WD = ops.combine_weights_fwd(g(W), 200, A, flat, len(groups), S)
+    out = torch.zeros(n, F_out, device=DEV)
+    ops.gemm_grouped(g(a), g(torch.from_numpy(rows)), g(torch.from_numpy(tiles)), WD, out, trans_b=True, accumulate=True)
+    assert rel_err(out.cpu(), ref) < 1e-5
+    # data gradient: d a = dY W_D  (only rows with D > 0 are written)
+    dY = rnd(n, F_out, seed=3)
+    ga = torch.zeros(n, A, device=DEV)
+    ops.gemm_grouped(g(dY), g(torch.from_numpy(rows)), g(torch.from_numpy(tiles)), WD, ga, trans_b=False, accumulate=False)
+    Wagg = W[:, 200:].double()
+    ref_ga = dY.double() @ Wagg[:, :A] + amp.double() * (dY.double() @ Wagg[:, A:2 * A]) + att.double() * (dY.double() @ Wagg[:, 2 * A:])
+    ref_ga[indeg == 0] = 0
+    assert rel_err(ga.cpu(), ref_ga) < 1e-5
+    # weight gradient: per-group dW_D folded back into the three scaler blocks
+    gWD = torch.empty_like(WD)
+    rows_d = g(torch.from_numpy(rows))
+    for gi, (_, start, count) in enumerate(groups):
+        ops.gemm_rowsubset(g(dY), g(a), rows_d[start:start + count], gWD[gi])
+    gW = torch.full((F_out, 200 + S * A), 7.0, device=DEV)
+    ops.combine_weights_bwd(gWD, gW, 200, A, flat, len(groups), S)
+    ref_gW = dY.double().T @ agg12.double()
+    assert rel_err(gW[:, 200:].cpu(), ref_gW) < 2e-5
+    assert torch.all(gW[:, :200] == 7.0)
 
 
 # ---- K4 aggregation --------------------------------------------------------------------------------------

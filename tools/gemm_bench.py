@@ -61,7 +61,7 @@ if __name__ == '__main__':
         us, tf, err = run(lib, ta, tb, M, N, K, -1, 0)
         print(f'{name} M={M:6d} N={N:5d} K={K:6d}  auto: {us:8.1f} us {tf:7.1f} TF  err {err:.1e}', flush=True)
         if a.all_cfgs:
-            for cfg in (2, 4, 8, 9, 10, 11):
+            for cfg in (0, 2, 3, 4, 5):
                 for splits in ((1, 2, 4) if K <= 2400 and M > 2000 else (4, 8, 16, 32)):
                     if splits > 1 and K < 1024:
                         continue
