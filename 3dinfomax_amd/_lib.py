@@ -17,7 +17,47 @@ AGG = {'mean': 0, 'sum': 1, 'max': 2, 'min': 3, 'std': 4, 'var': 5}
 SCALER = {'identity': 0, 'amplification': 1, 'attenuation': 2}
 
 _P = c_void_p
+
+
+# mirrors of the argument structs of include/infomax3d_hip.h (composites)
+class BnTail(ctypes.Structure):
+    _fields_ = [('act', c_int), ('post_act', c_int), ('eps', c_float), ('momentum', c_float), ('gamma', _P),
+                ('beta', _P), ('running_mean', _P), ('running_var', _P), ('mean', _P), ('invstd', _P),
+                ('workspace', _P)]
+
+
+class FcArgs(ctypes.Structure):
+    _fields_ = [('tail', BnTail), ('rows', c_int), ('f_in', c_int), ('f_out', c_int), ('ldw', c_int), ('x', _P),
+                ('W', _P), ('bias', _P), ('residual', _P), ('xact', _P), ('pre_keep', _P), ('y', _P), ('grad_y', _P),
+                ('grad_pre', _P), ('grad_gamma', _P), ('grad_beta', _P), ('grad_W', _P), ('grad_bias', _P),
+                ('grad_x', _P)]
+
+
+class EdgeFcArgs(ctypes.Structure):
+    _fields_ = [('tail', BnTail), ('num_nodes', c_int), ('num_edges', c_int), ('f_h', c_int), ('f_q', c_int),
+                ('f_out', c_int), ('ldw', c_int), ('h', _P), ('q', _P), ('W', _P), ('bias', _P), ('src_s', _P),
+                ('dst_s', _P), ('in_ptr', _P), ('out_ptr', _P), ('out_epos', _P), ('P', _P), ('Q', _P), ('xact', _P),
+                ('pre_keep', _P), ('y', _P), ('grad_y', _P), ('grad_pre', _P), ('grad_P', _P), ('grad_gamma', _P),
+                ('grad_beta', _P), ('grad_W', _P), ('grad_bias', _P), ('grad_h', _P), ('grad_q', _P)]
+
+
+class GroupedFcArgs(ctypes.Structure):
+    _fields_ = [('tail', BnTail), ('num_nodes', c_int), ('f_h', c_int), ('f_out', c_int), ('agg_width', c_int),
+                ('ldw', c_int), ('n_groups', c_int), ('n_scalers', c_int), ('m_padded', c_int),
+                ('group_start', c_int * 32), ('group_count', c_int * 32), ('coef', c_float * 128), ('h', _P),
+                ('agg', _P), ('W', _P), ('bias', _P), ('residual', _P), ('deg_rows', _P), ('deg_tile_group', _P),
+                ('WD', _P), ('xact', _P), ('pre_keep', _P), ('y', _P), ('grad_y', _P), ('grad_pre', _P),
+                ('grad_WD', _P), ('grad_gamma', _P), ('grad_beta', _P), ('grad_W', _P), ('grad_bias', _P),
+                ('grad_h', _P), ('grad_agg', _P)]
+
+
 _SIGNATURES = {
+    'i3d_fc_bn_fwd': (c_int, [POINTER(FcArgs), _P]),
+    'i3d_fc_bn_bwd': (c_int, [POINTER(FcArgs), _P]),
+    'i3d_edge_fc_bn_fwd': (c_int, [POINTER(EdgeFcArgs), _P]),
+    'i3d_edge_fc_bn_bwd': (c_int, [POINTER(EdgeFcArgs), _P]),
+    'i3d_grouped_fc_bn_fwd': (c_int, [POINTER(GroupedFcArgs), _P]),
+    'i3d_grouped_fc_bn_bwd': (c_int, [POINTER(GroupedFcArgs), _P]),
     'i3d_abi_version': (c_int, []),
     'i3d_last_error': (c_char_p, []),
     'i3d_embedding_sum_fwd': (c_int, [_P, _P, c_int, c_int, POINTER(c_void_p), c_int, _P, _P]),

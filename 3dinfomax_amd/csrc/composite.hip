@@ -1,0 +1,125 @@
+// Host-side composites: one C call enqueues the whole kernel sequence of an FCLayer-shaped block.
+//
+// The step is ~400 small launches; with one Python->C transition per kernel the host needed ~5 ms to enqueue a
+// 4.6 ms step.  These entry points keep the kernels unchanged and move the *sequencing* of an
+// "input operator -> Linear -> activation -> BatchNorm(train) -> post-activation (+ residual)" block and of its
+// backward into C++ (reference models/base_layers.py:100-111 with the three input operators of layers.py: plain,
+// edge gather-combine, degree-grouped concat).  Training mode with local batch statistics only; eval mode,
+// synchronised BN and BN-less layers keep using the per-kernel entry points.
+#include "common.h"
+
+using namespace i3d;
+
+#define TRY(call)                 \
+    do {                          \
+        int rc_ = (call);         \
+        if (rc_ != I3D_OK) return rc_; \
+    } while (0)
+
+// one zero-fill for a whole weight-gradient buffer; the GEMMs then accumulate (their own per-call zero-fills for the
+// split-K atomics would be 3-6 extra launches per block)
+static int zero(float* p, size_t n, void* stream) {
+    if (hipMemsetAsync(p, 0, n * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+        i3d::set_error("composite: memset failed");
+        return I3D_ERR_LAUNCH;
+    }
+    return I3D_OK;
+}
+
+static int tail_fwd(const I3dBnTail* t, int rows, int f_out, float* pre, float* xact, const float* residual, float* y,
+                    void* stream) {
+    // pre holds the Linear output.  xact == pre: activation in place (ReLU/none); else pre is kept for act'
+    TRY(i3d_act_stats_fwd(pre, rows, f_out, t->act, xact, t->eps, t->momentum, t->mean, t->invstd, t->running_mean,
+                          t->running_var, nullptr, t->workspace, stream));
+    return i3d_bn_apply_fwd(xact, rows, f_out, t->mean, t->invstd, t->gamma, t->beta, t->post_act, residual, y, stream);
+}
+
+static int tail_bwd(const I3dBnTail* t, int rows, int f_out, const float* grad_y, const float* xact, const float* pre,
+                    float* grad_gamma, float* grad_beta, float* grad_pre, void* stream) {
+    return i3d_bn_bwd(grad_y, xact, pre, rows, f_out, t->act, t->post_act, t->mean, t->invstd, t->gamma, t->beta,
+                      grad_gamma, grad_beta, grad_pre, nullptr, nullptr, rows, t->workspace, stream);
+}
+
+// ---- plain FC ------------------------------------------------------------------------------------------
+extern "C" int i3d_fc_bn_fwd(const I3dFcArgs* a, void* stream) {
+    I3D_CHECK_ARG(a != nullptr && a->rows > 0, "bad arguments");
+    float* lin = a->pre_keep ? a->pre_keep : a->xact;
+    TRY(i3d_gemm_f32(0, 1, a->rows, a->f_out, a->f_in, a->x, a->f_in, a->W, a->ldw, lin, a->f_out, a->bias, 0, stream));
+    return tail_fwd(&a->tail, a->rows, a->f_out, lin, a->xact, a->residual, a->y, stream);
+}
+
+extern "C" int i3d_fc_bn_bwd(const I3dFcArgs* a, void* stream) {
+    I3D_CHECK_ARG(a != nullptr && a->rows > 0, "bad arguments");
+    TRY(tail_bwd(&a->tail, a->rows, a->f_out, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre,
+                 stream));
+    TRY(i3d_gemm_f32(1, 0, a->f_out, a->f_in, a->rows, a->grad_pre, a->f_out, a->x, a->f_in, a->grad_W, a->ldw, nullptr, 0,
+                     stream));
+    TRY(i3d_colsum(a->grad_pre, nullptr, a->rows, a->f_out, a->grad_bias, a->tail.workspace, stream));
+    if (a->grad_x != nullptr)
+        TRY(i3d_gemm_f32(0, 0, a->rows, a->f_in, a->f_out, a->grad_pre, a->f_out, a->W, a->ldw, a->grad_x, a->f_in, nullptr,
+                         0, stream));
+    return I3D_OK;
+}
+
+// ---- edge FC: [h_src | h_dst | q] -> Linear as node-level P + gather-combine -------------------------
+extern "C" int i3d_edge_fc_bn_fwd(const I3dEdgeFcArgs* a, void* stream) {
+    I3D_CHECK_ARG(a != nullptr && a->num_edges > 0 && a->num_nodes > 0, "bad arguments");
+    const int Fh = a->f_h, Fo = a->f_out;
+    TRY(i3d_gemm_f32(0, 1, a->num_nodes, Fo, Fh, a->h, Fh, a->W, a->ldw, a->P, 2 * Fo, nullptr, 0, stream));
+    TRY(i3d_gemm_f32(0, 1, a->num_nodes, Fo, Fh, a->h, Fh, a->W + Fh, a->ldw, a->P + Fo, 2 * Fo, nullptr, 0, stream));
+    if (a->q != nullptr)
+        TRY(i3d_gemm_f32(0, 1, a->num_edges, Fo, a->f_q, a->q, a->f_q, a->W + 2 * Fh, a->ldw, a->Q, Fo, nullptr, 0, stream));
+    float* lin = a->pre_keep ? a->pre_keep : a->xact;
+    TRY(i3d_edge_combine_fwd(a->P, 2 * Fo, a->q ? a->Q : nullptr, a->bias, a->src_s, a->dst_s, a->num_edges, Fo, lin,
+                             stream));
+    return tail_fwd(&a->tail, a->num_edges, Fo, lin, a->xact, nullptr, a->y, stream);
+}
+
+extern "C" int i3d_edge_fc_bn_bwd(const I3dEdgeFcArgs* a, void* stream) {
+    I3D_CHECK_ARG(a != nullptr && a->num_edges > 0 && a->num_nodes > 0, "bad arguments");
+    const int Fh = a->f_h, Fo = a->f_out, N = a->num_nodes, E = a->num_edges;
+    TRY(tail_bwd(&a->tail, E, Fo, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre, stream));
+    // d P[src] (out-edges through the source index), d P[dst] (in-edges are contiguous): segmented sums, no atomics
+    TRY(i3d_segment_sum(a->grad_pre, Fo, a->out_ptr, a->out_epos, N, Fo, 0, a->grad_P, 2 * Fo, stream));
+    TRY(i3d_segment_sum(a->grad_pre, Fo, a->in_ptr, nullptr, N, Fo, 0, a->grad_P + Fo, 2 * Fo, stream));
+    TRY(zero(a->grad_W, (size_t)Fo * a->ldw, stream));
+    TRY(i3d_gemm_f32(1, 0, Fo, Fh, N, a->grad_P, 2 * Fo, a->h, Fh, a->grad_W, a->ldw, nullptr, 1, stream));
+    TRY(i3d_gemm_f32(1, 0, Fo, Fh, N, a->grad_P + Fo, 2 * Fo, a->h, Fh, a->grad_W + Fh, a->ldw, nullptr, 1, stream));
+    TRY(i3d_gemm_f32(0, 0, N, Fh, Fo, a->grad_P, 2 * Fo, a->W, a->ldw, a->grad_h, Fh, nullptr, 0, stream));
+    TRY(i3d_gemm_f32(0, 0, N, Fh, Fo, a->grad_P + Fo, 2 * Fo, a->W + Fh, a->ldw, a->grad_h, Fh, nullptr, 1, stream));
+    if (a->q != nullptr) {
+        TRY(i3d_gemm_f32(1, 0, Fo, a->f_q, E, a->grad_pre, Fo, a->q, a->f_q, a->grad_W + 2 * Fh, a->ldw, nullptr, 1, stream));
+        if (a->grad_q != nullptr)
+            TRY(i3d_gemm_f32(0, 0, E, a->f_q, Fo, a->grad_pre, Fo, a->W + 2 * Fh, a->ldw, a->grad_q, a->f_q, nullptr, 0, stream));
+    }
+    return i3d_colsum(a->grad_pre, nullptr, E, Fo, a->grad_bias, a->tail.workspace, stream);
+}
+
+// ---- degree-grouped concat FC: [h | scaler blocks of a] -> Linear with per-degree combined weights -----------
+extern "C" int i3d_grouped_fc_bn_fwd(const I3dGroupedFcArgs* a, void* stream) {
+    I3D_CHECK_ARG(a != nullptr && a->num_nodes > 0 && a->n_groups > 0, "bad arguments");
+    const int Fh = a->f_h, Fo = a->f_out, A = a->agg_width, N = a->num_nodes;
+    float* lin = a->pre_keep ? a->pre_keep : a->xact;
+    TRY(i3d_gemm_f32(0, 1, N, Fo, Fh, a->h, Fh, a->W, a->ldw, lin, Fo, a->bias, 0, stream));
+    TRY(i3d_pna_combine_weights_fwd(a->W, a->ldw, Fh, Fo, A, a->n_groups, a->n_scalers, a->coef, a->WD, stream));
+    TRY(i3d_gemm_f32_grouped(1, a->m_padded, Fo, A, a->agg, A, N, a->deg_rows, a->deg_tile_group, a->WD, A, (long)Fo * A, lin,
+                             Fo, 1, stream));
+    return tail_fwd(&a->tail, N, Fo, lin, a->xact, a->residual, a->y, stream);
+}
+
+extern "C" int i3d_grouped_fc_bn_bwd(const I3dGroupedFcArgs* a, void* stream) {
+    I3D_CHECK_ARG(a != nullptr && a->num_nodes > 0 && a->n_groups > 0, "bad arguments");
+    const int Fh = a->f_h, Fo = a->f_out, A = a->agg_width, N = a->num_nodes;
+    TRY(tail_bwd(&a->tail, N, Fo, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre, stream));
+    TRY(zero(a->grad_W, (size_t)Fo * a->ldw, stream));
+    TRY(zero(a->grad_WD, (size_t)a->n_groups * Fo * A, stream));
+    TRY(i3d_gemm_f32(1, 0, Fo, Fh, N, a->grad_pre, Fo, a->h, Fh, a->grad_W, a->ldw, nullptr, 1, stream));
+    for (int g = 0; g < a->n_groups; ++g)    // dW_D = dY_D^T a_D over the rows of each in-degree group
+        TRY(i3d_gemm_f32_rowsubset(Fo, A, a->group_count[g], a->grad_pre, Fo, a->agg, A, a->deg_rows + a->group_start[g], N,
+                                   a->grad_WD + (long)g * Fo * A, A, 1, stream));
+    TRY(i3d_pna_combine_weights_bwd(a->grad_WD, a->ldw, Fh, Fo, A, a->n_groups, a->n_scalers, a->coef, a->grad_W, stream));
+    TRY(i3d_colsum(a->grad_pre, nullptr, N, Fo, a->grad_bias, a->tail.workspace, stream));
+    TRY(i3d_gemm_f32(0, 0, N, Fh, Fo, a->grad_pre, Fo, a->W, a->ldw, a->grad_h, Fh, nullptr, 0, stream));
+    return i3d_gemm_f32_grouped(0, a->m_padded, A, Fo, a->grad_pre, Fo, N, a->deg_rows, a->deg_tile_group, a->WD, A,
+                                (long)Fo * A, a->grad_agg, A, 0, stream);
+}

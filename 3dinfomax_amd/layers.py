@@ -6,13 +6,16 @@ sub-module names (`linear`, `batch_norm`, `fully_connected`) hence the same stat
 nn.Linear / nn.BatchNorm1d are used as PARAMETER CONTAINERS only - their forward is never called; all
 arithmetic runs in the gfx950 kernels through ops.py, forward and hand-written backward.
 """
+import ctypes
+import os
+import threading
 from dataclasses import dataclass
 from typing import Optional
 
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from .streams import fork
 
 SUPPORTED_ACTIVATIONS = {'relu', 'silu', 'sigmoid', 'leakyrelu', 'none'}
@@ -49,9 +52,41 @@ class FCSpec:
     post_act: Optional[str] = None   # activation after the BatchNorm (Net3D edge_input: silu(BN(silu(.))))
 
 
-def _sync_world(group):
-    import torch.distributed as dist
-    return dist.get_world_size(group)
+# num_batches_tracked of every BatchNorm touched in a model forward is bumped by ONE multi-tensor op at the end of that
+# forward (a torch op costs ~35 us of host time on this stack; 16-25 separate add_ calls were 0.6 ms per step).
+_counters = threading.local()
+
+
+class bn_counter_scope:
+    """with bn_counter_scope(): ... model forward ...   -> one torch._foreach_add_ over the pending counters at exit."""
+
+    def __enter__(self):
+        _counters.depth = getattr(_counters, 'depth', 0) + 1
+        return self
+
+    def __exit__(self, *exc):
+        _counters.depth -= 1
+        if _counters.depth == 0:
+            flush_bn_counters()
+        return False
+
+
+def flush_bn_counters():
+    pending = getattr(_counters, 'pending', None)
+    if pending:
+        torch._foreach_add_(pending, 1)
+        _counters.pending = []
+
+
+def _bump(counter):
+    if counter is None:
+        return
+    if getattr(_counters, 'depth', 0) > 0:
+        if getattr(_counters, 'pending', None) is None:
+            _counters.pending = []
+        _counters.pending.append(counter)
+    else:
+        counter.add_(1)
 
 
 class _Tail:
@@ -84,8 +119,7 @@ class _Tail:
             else:
                 x, mean, invstd = ops.act_stats_fwd(pre, spec.act, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
                                                     out=torch.empty_like(pre) if keep_pre else None)
-            if bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+            _bump(bn.num_batches_tracked)
             y = ops.bn_apply_fwd(x, mean, invstd, gamma, beta, spec.post_act, residual)
             return y, (x, pre if keep_pre else None, mean, invstd)
         x = ops.act_fwd(pre, spec.act) if spec.act is not None else pre
@@ -120,17 +154,70 @@ class _Tail:
         return ops.bn_eval_bwd(grad_y, x, pre, spec.act, spec.post_act, mean, stat2, bn.eps, gamma, beta)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Composite fast path (csrc/composite.hip): one C call enqueues the whole block.  Eligible: BatchNorm in training mode
+# with local statistics.  I3D_COMPOSITE=0 forces the per-kernel path (identical arithmetic, used by the tests to
+# cross-check).
+COMPOSITE = os.environ.get('I3D_COMPOSITE', '1') != '0'
+
+
+def _composite_ok(spec: FCSpec, *tensors):
+    return (COMPOSITE and spec.bn is not None and spec.bn.training and spec.bn.sync_group is None
+            and all(t is None or t.is_cuda for t in tensors))
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _f32(shape, device):
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def _fill_tail(tail, spec: FCSpec, gamma, beta, mean, invstd, feat, device):
+    bn = spec.bn
+    tail.act, tail.post_act = ops.ACT[spec.act], ops.ACT[spec.post_act]
+    tail.eps, tail.momentum = bn.eps, bn.momentum
+    tail.gamma, tail.beta = gamma.data_ptr(), beta.data_ptr()
+    tail.running_mean, tail.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+    tail.mean, tail.invstd = mean.data_ptr(), invstd.data_ptr()
+    tail.workspace = ops._workspace(feat, device).data_ptr()
+
+
+def _keeps_pre(spec):
+    return spec.act not in (None, 'relu', 'leakyrelu')
+
+
+def _call(fn_name, args):
+    L = _lib.load()
+    _lib.check(getattr(L, fn_name)(ctypes.byref(args), ops._stream()), fn_name)
+
+
 class FCFn(torch.autograd.Function):
     """y = post_act(BN(act(x W^T + b))) (+ residual).  reference models/base_layers.py:100-111."""
 
     @staticmethod
     def forward(ctx, x, W, b, gamma, beta, residual, spec: FCSpec):
         x = x.contiguous()
+        ctx.spec, ctx.has_res, ctx.cargs = spec, residual is not None, None
+        if _composite_ok(spec, x, W) and W.is_contiguous():
+            rows, f_out, dev = x.shape[0], W.shape[0], x.device
+            xact, y = _f32((rows, f_out), dev), _f32((rows, f_out), dev)
+            pre_keep = _f32((rows, f_out), dev) if _keeps_pre(spec) else None
+            mean, invstd = _f32((f_out,), dev), _f32((f_out,), dev)
+            a = _lib.FcArgs()
+            _fill_tail(a.tail, spec, gamma, beta, mean, invstd, f_out, dev)
+            a.rows, a.f_in, a.f_out, a.ldw = rows, x.shape[1], f_out, W.stride(0)
+            a.x, a.W, a.bias, a.residual = x.data_ptr(), W.data_ptr(), _ptr(b), _ptr(residual)
+            a.xact, a.pre_keep, a.y = xact.data_ptr(), _ptr(pre_keep), y.data_ptr()
+            _call('i3d_fc_bn_fwd', a)
+            _bump(spec.bn.num_batches_tracked)
+            ctx.cargs, ctx.saved = a, (xact, pre_keep, mean, invstd)
+            ctx.save_for_backward(x, W, gamma, beta)
+            return y
         pre = ops.gemm(x, W, trans_b=True, bias=b)
         y, saved = _Tail.forward(pre, gamma, beta, spec, residual)
-        ctx.spec = spec
         ctx.saved = saved
-        ctx.has_res = residual is not None
         ctx.save_for_backward(x, W, gamma, beta)
         return y
 
@@ -139,6 +226,17 @@ class FCFn(torch.autograd.Function):
         x, W, gamma, beta = ctx.saved_tensors
         grad_y = grad_y.contiguous()
         grad_res = grad_y if ctx.has_res else None
+        if ctx.cargs is not None:
+            a, dev, f_out = ctx.cargs, x.device, W.shape[0]
+            grad_pre = _f32((x.shape[0], f_out), dev)
+            gg, gb, gbias = _f32((f_out,), dev), _f32((f_out,), dev), _f32((f_out,), dev)
+            gW = torch.empty_like(W)
+            gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+            a.tail.workspace = ops._workspace(f_out, dev).data_ptr()
+            a.grad_y, a.grad_pre, a.grad_gamma, a.grad_beta = grad_y.data_ptr(), grad_pre.data_ptr(), gg.data_ptr(), gb.data_ptr()
+            a.grad_W, a.grad_bias, a.grad_x = gW.data_ptr(), gbias.data_ptr(), _ptr(gx)
+            _call('i3d_fc_bn_bwd', a)
+            return gx, gW, gbias, gg, gb, grad_res, None
         grad_pre, gg, gb = _Tail.backward(ctx.saved, grad_y, gamma, beta, ctx.spec)
         gW = torch.empty_like(W) if ctx.needs_input_grad[1] else None
         gbias = torch.empty(W.shape[0], dtype=W.dtype, device=W.device) if ctx.needs_input_grad[2] else None
@@ -198,6 +296,30 @@ class GroupedConcat2FCFn(torch.autograd.Function):
         rows, tiles, groups = index.degree_groups()
         nG, nS = len(groups), len(coef[0])
         flat = [c for g in coef for c in g]
+        ctx.cargs = None
+        if _composite_ok(spec, h, a, W) and W.is_contiguous() and nG <= 32 and nG * nS <= 128:
+            N, f_out, dev = h.shape[0], W.shape[0], h.device
+            xact, y = _f32((N, f_out), dev), _f32((N, f_out), dev)
+            pre_keep = _f32((N, f_out), dev) if _keeps_pre(spec) else None
+            mean, invstd = _f32((f_out,), dev), _f32((f_out,), dev)
+            WD = _f32((nG, f_out, A), dev)
+            c = _lib.GroupedFcArgs()
+            _fill_tail(c.tail, spec, gamma, beta, mean, invstd, f_out, dev)
+            c.num_nodes, c.f_h, c.f_out, c.agg_width, c.ldw = N, Fh, f_out, A, W.stride(0)
+            c.n_groups, c.n_scalers, c.m_padded = nG, nS, rows.shape[0]
+            for gi, (_, start, count) in enumerate(groups):
+                c.group_start[gi], c.group_count[gi] = start, count
+            for i, v in enumerate(flat):
+                c.coef[i] = v
+            c.h, c.agg, c.W, c.bias, c.residual = h.data_ptr(), a.data_ptr(), W.data_ptr(), _ptr(b), _ptr(residual)
+            c.deg_rows, c.deg_tile_group = rows.data_ptr(), tiles.data_ptr()
+            c.WD, c.xact, c.pre_keep, c.y = WD.data_ptr(), xact.data_ptr(), _ptr(pre_keep), y.data_ptr()
+            _call('i3d_grouped_fc_bn_fwd', c)
+            _bump(spec.bn.num_batches_tracked)
+            ctx.cargs, ctx.saved = c, (xact, pre_keep, mean, invstd)
+            ctx.spec, ctx.has_res, ctx.index, ctx.coef = spec, residual is not None, index, (flat, nG, nS)
+            ctx.save_for_backward(h, a, W, WD, gamma, beta)
+            return y
         pre = ops.gemm(h, W[:, :Fh], trans_b=True, bias=b)
         WD = ops.combine_weights_fwd(W, Fh, A, flat, nG, nS)
         ops.gemm_grouped(a, rows, tiles, WD, pre, trans_b=True, accumulate=True)
@@ -214,6 +336,17 @@ class GroupedConcat2FCFn(torch.autograd.Function):
         rows, tiles, groups = ctx.index.degree_groups()
         grad_y = grad_y.contiguous()
         grad_res = grad_y if ctx.has_res else None
+        if ctx.cargs is not None:
+            c, dev, f_out, N = ctx.cargs, h.device, W.shape[0], h.shape[0]
+            grad_pre, gWD = _f32((N, f_out), dev), torch.empty_like(WD)
+            gg, gb, gbias = _f32((f_out,), dev), _f32((f_out,), dev), _f32((f_out,), dev)
+            gW, gh, ga = torch.empty_like(W), torch.empty_like(h), torch.empty_like(a)
+            c.tail.workspace = ops._workspace(f_out, dev).data_ptr()
+            c.grad_y, c.grad_pre, c.grad_WD = grad_y.data_ptr(), grad_pre.data_ptr(), gWD.data_ptr()
+            c.grad_gamma, c.grad_beta, c.grad_W, c.grad_bias = gg.data_ptr(), gb.data_ptr(), gW.data_ptr(), gbias.data_ptr()
+            c.grad_h, c.grad_agg = gh.data_ptr(), ga.data_ptr()
+            _call('i3d_grouped_fc_bn_bwd', c)
+            return gh, ga, gW, gbias, gg, gb, grad_res, None, None, None
         grad_pre, gg, gb = _Tail.backward(ctx.saved, grad_y, gamma, beta, ctx.spec)
         gW = torch.empty_like(W)
         ops.gemm(grad_pre, h, trans_a=True, out=gW[:, :Fh])
@@ -240,12 +373,34 @@ class EdgeFCFn(torch.autograd.Function):
         Fh = h.shape[1]
         Fo = W.shape[0]
         N = h.shape[0]
+        ctx.cargs = None
+        if q is not None:
+            q = q.contiguous()
+        if _composite_ok(spec, h, q, W) and W.is_contiguous() and index.num_edges > 0:
+            E, dev = index.num_edges, h.device
+            P = _f32((N, 2 * Fo), dev)
+            Q = _f32((E, Fo), dev) if q is not None else None
+            xact, y = _f32((E, Fo), dev), _f32((E, Fo), dev)
+            pre_keep = _f32((E, Fo), dev) if _keeps_pre(spec) else None
+            mean, invstd = _f32((Fo,), dev), _f32((Fo,), dev)
+            a = _lib.EdgeFcArgs()
+            _fill_tail(a.tail, spec, gamma, beta, mean, invstd, Fo, dev)
+            a.num_nodes, a.num_edges, a.f_h, a.f_q, a.f_out, a.ldw = N, E, Fh, (q.shape[1] if q is not None else 0), Fo, W.stride(0)
+            a.h, a.q, a.W, a.bias = h.data_ptr(), _ptr(q), W.data_ptr(), _ptr(b)
+            a.src_s, a.dst_s, a.in_ptr = index.src_s.data_ptr(), index.dst_s.data_ptr(), index.in_ptr.data_ptr()
+            a.out_ptr, a.out_epos = index.out_ptr.data_ptr(), index.out_epos.data_ptr()
+            a.P, a.Q, a.xact, a.pre_keep, a.y = P.data_ptr(), _ptr(Q), xact.data_ptr(), _ptr(pre_keep), y.data_ptr()
+            _call('i3d_edge_fc_bn_fwd', a)
+            _bump(spec.bn.num_batches_tracked)
+            ctx.cargs, ctx.saved = a, (xact, pre_keep, mean, invstd)
+            ctx.spec, ctx.index, ctx.has_q = spec, index, q is not None
+            ctx.save_for_backward(h, q if q is not None else h, W, gamma, beta)
+            return y
         P = torch.empty(N, 2 * Fo, dtype=torch.float32, device=h.device)
         ops.gemm(h, W[:, :Fh], trans_b=True, out=P[:, :Fo])
         ops.gemm(h, W[:, Fh:2 * Fh], trans_b=True, out=P[:, Fo:])
         Q = None
         if q is not None:
-            q = q.contiguous()
             Q = ops.gemm(q, W[:, 2 * Fh:], trans_b=True)
         pre = ops.edge_combine_fwd(P, Q, b, index.src_s, index.dst_s)
         y, saved = _Tail.forward(pre, gamma, beta, spec)
@@ -258,6 +413,19 @@ class EdgeFCFn(torch.autograd.Function):
         h, q, W, gamma, beta = ctx.saved_tensors
         idx = ctx.index
         Fh, Fo, N = h.shape[1], W.shape[0], h.shape[0]
+        if ctx.cargs is not None:
+            a, dev, E = ctx.cargs, h.device, idx.num_edges
+            grad_y = grad_y.contiguous()
+            grad_pre, gP = _f32((E, Fo), dev), _f32((N, 2 * Fo), dev)
+            gg, gb, gbias = _f32((Fo,), dev), _f32((Fo,), dev), _f32((Fo,), dev)
+            gW, gh = torch.empty_like(W), torch.empty_like(h)
+            gq = torch.empty_like(q) if (ctx.has_q and ctx.needs_input_grad[1]) else None
+            a.tail.workspace = ops._workspace(Fo, dev).data_ptr()
+            a.grad_y, a.grad_pre, a.grad_P = grad_y.data_ptr(), grad_pre.data_ptr(), gP.data_ptr()
+            a.grad_gamma, a.grad_beta, a.grad_W, a.grad_bias = gg.data_ptr(), gb.data_ptr(), gW.data_ptr(), gbias.data_ptr()
+            a.grad_h, a.grad_q = gh.data_ptr(), _ptr(gq)
+            _call('i3d_edge_fc_bn_bwd', a)
+            return gh, gq, gW, gbias, gg, gb, None, None
         grad_pre, gg, gb = _Tail.backward(ctx.saved, grad_y.contiguous(), gamma, beta, ctx.spec)
         gW = torch.empty_like(W)
         gP = torch.empty(N, 2 * Fo, dtype=torch.float32, device=h.device)

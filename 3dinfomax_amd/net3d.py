@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from . import ops
 from .graph import as_batched_graph
-from .layers import MLP, ReadoutFn, act_name
+from .layers import MLP, ReadoutFn, act_name, bn_counter_scope
 from .mol_encoder import AtomEncoder
 
 
@@ -115,6 +115,10 @@ class Net3D(nn.Module):
                           layers=readout_layers)
 
     def forward(self, graph, *unused):
+        with bn_counter_scope():
+            return self._forward(graph)
+
+    def _forward(self, graph):
         g = as_batched_graph(graph)
         idx = g.index()
         if self.use_node_features:

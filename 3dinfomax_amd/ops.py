@@ -73,7 +73,11 @@ def embedding_sum_bwd(idx, grad_out, dims, row_perm=None):
     _chk(grad_out)
     rows, n_cols = idx.shape
     feat = grad_out.shape[1]
-    grads = [torch.zeros(d, feat, dtype=torch.float32, device=idx.device) for d in dims]
+    flat = torch.zeros(sum(dims), feat, dtype=torch.float32, device=idx.device)     # one fill for all tables
+    grads, o = [], 0
+    for d in dims:
+        grads.append(flat[o:o + d])
+        o += d
     L = _lib.load()
     check(L.i3d_embedding_sum_bwd(_p(idx), _p(row_perm), rows, n_cols, _p(grad_out), feat, ptr_array([g.data_ptr() for g in grads]),
                                   int_array(list(dims)), _stream()), 'i3d_embedding_sum_bwd')

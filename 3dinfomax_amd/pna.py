@@ -21,7 +21,7 @@ from torch import nn
 
 from . import ops
 from .graph import as_batched_graph
-from .layers import MLP, AggregateFn, ReadoutFn
+from .layers import MLP, AggregateFn, ReadoutFn, bn_counter_scope
 from .mol_encoder import AtomEncoder, BondEncoder
 
 EPS = 1e-5
@@ -81,9 +81,10 @@ class PNA(nn.Module):
 
     def forward(self, graph, *unused):
         g = as_batched_graph(graph)
-        self.node_gnn(g)
-        readout = ReadoutFn.apply(g.ndata['feat'], g.index(), self._readout_codes)
-        return self.output(readout)
+        with bn_counter_scope():
+            self.node_gnn(g)
+            readout = ReadoutFn.apply(g.ndata['feat'], g.index(), self._readout_codes)
+            return self.output(readout)
 
 
 class PNAGNN(nn.Module):

@@ -228,6 +228,107 @@ int i3d_row_axpy(const float* z, const float* coef, int rows, int dim, float* ou
 /* out[r,:] = coef[r] * z[r,:]   (graph-size normalisation h * snorm_n, reference models/pna_original.py:258-259) */
 int i3d_row_scale(const float* z, const float* coef, int rows, int dim, float* out, void* stream);
 
+/* ---- composites: one call enqueues a whole FCLayer-shaped block (forward or backward) ------------------------
+ * "input operator -> Linear -> activation -> BatchNorm1d (training, local statistics) -> post-activation (+ residual)",
+ * reference models/base_layers.py:100-111, with the three input operators of the PNA / Net3D layers.  Same kernels
+ * as the per-kernel entry points above, sequenced in C++ so the host pays one transition per block instead of ~7-13.
+ * All pointers are device pointers except the struct itself (host).  Forward fills xact (activation output, saved),
+ * pre_keep (Linear output, only when the activation needs it: SiLU/Sigmoid; NULL otherwise: activation in place),
+ * tail.mean / tail.invstd, y.  Backward reads them and fills the grad_* members (grad_x / grad_q may be NULL). */
+typedef struct {
+    int act, post_act;
+    float eps, momentum;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    float* mean;
+    float* invstd;
+    void* workspace; /* i3d_colreduce_workspace_bytes(rows, f_out) */
+} I3dBnTail;
+
+typedef struct { /* y = tail(x W^T + b) */
+    I3dBnTail tail;
+    int rows, f_in, f_out, ldw;
+    const float* x;
+    const float* W;
+    const float* bias;
+    const float* residual;
+    float* xact;
+    float* pre_keep;
+    float* y;
+    const float* grad_y;
+    float* grad_pre; /* scratch [rows, f_out] */
+    float* grad_gamma;
+    float* grad_beta;
+    float* grad_W;
+    float* grad_bias;
+    float* grad_x;
+} I3dFcArgs;
+
+typedef struct { /* y = tail(P[src,:F] + P[dst,F:] + q W_q^T + b),  P = h [W_s|W_d]^T  (reference models/pna.py:237-252) */
+    I3dBnTail tail;
+    int num_nodes, num_edges, f_h, f_q, f_out, ldw;
+    const float* h;
+    const float* q;
+    const float* W;
+    const float* bias;
+    const int* src_s;
+    const int* dst_s;
+    const int* in_ptr;
+    const int* out_ptr;
+    const int* out_epos;
+    float* P; /* [N, 2*f_out] scratch */
+    float* Q; /* [E, f_out] scratch (NULL when q is NULL) */
+    float* xact;
+    float* pre_keep;
+    float* y;
+    const float* grad_y;
+    float* grad_pre; /* scratch [E, f_out] */
+    float* grad_P;   /* scratch [N, 2*f_out] */
+    float* grad_gamma;
+    float* grad_beta;
+    float* grad_W;
+    float* grad_bias;
+    float* grad_h;
+    float* grad_q;
+} I3dEdgeFcArgs;
+
+typedef struct { /* y = tail(h W_h^T + b + agg[deg group] W_D^T),  W_D = sum_s coef[g][s] W_s  (models/pna.py:207-209, 229-233) */
+    I3dBnTail tail;
+    int num_nodes, f_h, f_out, agg_width, ldw, n_groups, n_scalers, m_padded;
+    int group_start[32];
+    int group_count[32];
+    float coef[128]; /* [n_groups][n_scalers] */
+    const float* h;
+    const float* agg;
+    const float* W;
+    const float* bias;
+    const float* residual;
+    const int* deg_rows;
+    const int* deg_tile_group;
+    float* WD; /* [n_groups, f_out, agg_width] */
+    float* xact;
+    float* pre_keep;
+    float* y;
+    const float* grad_y;
+    float* grad_pre; /* scratch [N, f_out] */
+    float* grad_WD;  /* scratch like WD */
+    float* grad_gamma;
+    float* grad_beta;
+    float* grad_W;
+    float* grad_bias;
+    float* grad_h;
+    float* grad_agg;
+} I3dGroupedFcArgs;
+
+int i3d_fc_bn_fwd(const I3dFcArgs* args, void* stream);
+int i3d_fc_bn_bwd(const I3dFcArgs* args, void* stream);
+int i3d_edge_fc_bn_fwd(const I3dEdgeFcArgs* args, void* stream);
+int i3d_edge_fc_bn_bwd(const I3dEdgeFcArgs* args, void* stream);
+int i3d_grouped_fc_bn_fwd(const I3dGroupedFcArgs* args, void* stream);
+int i3d_grouped_fc_bn_bwd(const I3dGroupedFcArgs* args, void* stream);
+
 /* ---- batch assembly -----------------------------------------------------------------
  * replaces B x QM9Dataset.get_complete_graph (reference datasets/qm9_dataset.py:233-244, :215-217) + dgl.batch
  * (datasets/custom_collate.py:108-109) for the 3D view: from coords [N,3] and the node offsets graph_ptr[B+1] (plus
