@@ -76,6 +76,8 @@ _SIGNATURES = {
     'i3d_gemm_f32_grouped': (c_int, [c_int, c_int, c_int, c_int, _P, c_int, c_long, _P, _P, _P, c_int, c_long, _P, c_int,
                                      c_int, _P]),
     'i3d_gemm_f32_rowsubset': (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_long, _P, c_int, c_int, _P]),
+    'i3d_gemm_f32_rowsubset_multi': (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), _P, c_int, _P, c_int, _P,
+                                             c_long, _P, c_long, c_int, c_int, c_int, c_int, _P]),
     'i3d_colreduce_workspace_bytes': (c_long, [c_int, c_int]),
     'i3d_act_stats_fwd': (c_int, [_P, c_int, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     'i3d_bn_finalize_stats': (c_int, [_P, c_int, c_float, c_float, _P, _P, _P, _P, _P]),

@@ -114,9 +114,9 @@ extern "C" int i3d_grouped_fc_bn_bwd(const I3dGroupedFcArgs* a, void* stream) {
     TRY(zero(a->grad_W, (size_t)Fo * a->ldw, stream));
     TRY(zero(a->grad_WD, (size_t)a->n_groups * Fo * A, stream));
     TRY(i3d_gemm_f32(1, 0, Fo, Fh, N, a->grad_pre, Fo, a->h, Fh, a->grad_W, a->ldw, nullptr, 1, stream));
-    for (int g = 0; g < a->n_groups; ++g)    // dW_D = dY_D^T a_D over the rows of each in-degree group
-        TRY(i3d_gemm_f32_rowsubset(Fo, A, a->group_count[g], a->grad_pre, Fo, a->agg, A, a->deg_rows + a->group_start[g], N,
-                                   a->grad_WD + (long)g * Fo * A, A, 1, stream));
+    // dW_D = dY_D^T a_D over the rows of each in-degree group, all groups in one launch
+    TRY(i3d_gemm_f32_rowsubset_multi(Fo, A, a->n_groups, a->group_start, a->group_count, a->grad_pre, Fo, a->agg, A,
+                                     a->deg_rows, N, a->grad_WD, (long)Fo * A, A, 1, -1, 0, stream));
     TRY(i3d_pna_combine_weights_bwd(a->grad_WD, a->ldw, Fh, Fo, A, a->n_groups, a->n_scalers, a->coef, a->grad_W, stream));
     TRY(i3d_colsum(a->grad_pre, nullptr, N, Fo, a->grad_bias, a->tail.workspace, stream));
     TRY(i3d_gemm_f32(0, 0, N, Fh, Fo, a->grad_pre, Fo, a->W, a->ldw, a->grad_h, Fh, nullptr, 0, stream));

@@ -10,11 +10,13 @@
 //    is one conflict-free ds_read_b32: for the 16-wide MFMA the two 16-lane halves of a 32-lane group are
 //    steered to different bank halves by XOR-ing bit 4 of idx with ((k ^ (k>>2)) & 1); a 32-wide fragment read is
 //    a permutation of 32 consecutive banks either way.
-//  * register-staged double buffering: global loads of K-tile t+1 are issued before the MFMAs of tile t
-//    and written to the other LDS buffer afterwards: one barrier per K-tile.
+//  * register-staged pipeline with a ring of PF K-tiles in flight: the loads of tile t+PF are issued before the
+//    MFMAs of tile t, tile t+1 is written to the other LDS buffer afterwards: one barrier per K-tile.  Every load
+//    of the loop is issued unconditionally (tiles past the end read out of bounds and return 0): a load inside a
+//    branch makes the compiler's vmcnt bookkeeping fall back to vmcnt(0) at the join, which drains the ring.
 //  * loads go through buffer descriptors: lanes outside the matrix pass an offset beyond num_records and the
-//    hardware returns 0 - no per-lane branch around a load (those made hipcc serialise the loads behind vmcnt(0):
-//    3.5x slower, MI355X guide 5 trap (c)), per-slot address parts are hoisted out of the K loop.
+//    hardware returns 0 - no per-lane branch around a load (MI355X guide 5 trap (c)); the operand layouts are
+//    template parameters, per-slot address parts are hoisted out of the K loop.
 //  * the MFMA is issued with (W-fragment, X-fragment) so the accumulator holds C^T tiles: a lane owns 4
 //    consecutive output columns of one row -> the epilogue (bias, accumulate, split-K atomics) is 16-byte accesses.
 //  * k-contiguous operands (X[m][k], W[n][k]) are loaded with 16-byte loads along k and transposed on the
@@ -24,6 +26,7 @@
 //    posttrans GEMMs of the PNA layer (i3d_gemm_f32_grouped): rows of one in-degree share the combined weight
 //    W_D = W_id + amp(D) W_amp + att(D) W_att, which cuts K from 12F to 4F.
 #include "common.h"
+#include <algorithm>
 
 namespace i3d {
 
@@ -37,8 +40,6 @@ struct GemmArgs {
     const float* bias;
     int M, N, K;
     int lda, ldb, ldc;
-    int a_kcontig;   // 1: A[m*lda + k]   0: A[k*lda + m]
-    int b_kcontig;   // 1: B[n*ldb + k]   0: B[k*ldb + n]
     int accumulate;  // C += ...
     int k_per_split; // multiple of BK
     int atomic_out;  // split-K: atomicAdd into C
@@ -46,31 +47,32 @@ struct GemmArgs {
     unsigned a_bytes, b_bytes;  // extent of the operand views in bytes (buffer descriptor num_records)
     const int* m_rows;      // [M] or null: logical row m lives at row m_rows[m] of A (k-contiguous A only) and of C;
                             //          -1 = padding row (loads return 0, nothing is stored)
-    const int* k_rows;      // [K] or null: reduction index k lives at row k_rows[k] of the idx-contiguous operands
+    const int* k_rows;      // row-segment kernel: reduction index k lives at row k_rows[k] of both operands
     const int* tile_group;  // [ceil(M/BM)] or null: B of m-tile t is g.B + tile_group[t] * b_group_stride
     long b_group_stride;    // floats
 };
 
 __device__ __forceinline__ int swz(int k, int idx) { return idx ^ ((((k) ^ (k >> 2)) & 1) << 4); }
 
-template <int R, int LD, int BK>
+// KC: the operand is k-contiguous (T[idx*ld + k]); otherwise idx-contiguous (T[k*ld + idx])
+template <int R, int LD, int BK, bool KC>
 struct TileStage {
     static constexpr int SLOTS = R * BK / 4;                 // float4 slots in a tile
     static constexpr int KQ = BK / 4;                        // float4 slots along k of one row
     static constexpr int PER_THREAD = (SLOTS + 255) / 256;
-    float4 v[PER_THREAD];
+    struct Regs { float4 v[PER_THREAD]; };                   // one K-tile in flight (the kernel keeps a ring of PF of them)
     unsigned base[PER_THREAD];   // loop-invariant byte offset of the slot (row part or idx part)
     int kloc[PER_THREAD];        // k of the slot inside a K-tile
     int iloc[PER_THREAD];        // idx of the slot (idx-contiguous: first of 4)
     bool ok[PER_THREAD];
 
-    // kcontig: slot -> (idx = s / KQ, kq = s % KQ), 4 consecutive k of one row
-    // else   : slot -> (k = s / (R/4), iq = s % (R/4)), 4 consecutive idx of one k
-    __device__ __forceinline__ void prepare(int ld, int kcontig, int idx0, int idx_max, const int* __restrict__ rows) {
+    // KC : slot -> (idx = s / KQ, kq = s % KQ), 4 consecutive k of one row
+    // else: slot -> (k = s / (R/4), iq = s % (R/4)), 4 consecutive idx of one k
+    __device__ __forceinline__ void prepare(int ld, int idx0, int idx_max, const int* __restrict__ rows) {
 #pragma unroll
         for (int it = 0; it < PER_THREAD; ++it) {
             const int s = threadIdx.x + it * 256;
-            if (kcontig) {
+            if (KC) {
                 const int idx = idx0 + s / KQ;
                 kloc[it] = (s % KQ) * 4;
                 int row = -1;
@@ -87,51 +89,53 @@ struct TileStage {
         }
     }
 
-    template <bool VEC>
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, unsigned oob, int ld, int kcontig, int idx_max,
-                                         int k0, int k_end, const int* __restrict__ k_rows) {
+    // ROWS: kidx is an LDS copy of k_rows[k_begin .. k_end) (LDS reads count on lgkmcnt, so they do not drain the
+    // in-order vmcnt queue of the tiles already in flight)
+    template <bool VEC, bool ROWS>
+    __device__ __forceinline__ void load(Regs& r, __amdgpu_buffer_rsrc_t rsrc, unsigned oob, int ld, int idx_max, int k0,
+                                         int k_begin, int k_end, const int* kidx) const {
 #pragma unroll
         for (int it = 0; it < PER_THREAD; ++it) {
             const int k = k0 + kloc[it];
             unsigned off;
             const bool valid = ok[it] && k < k_end;
-            if (kcontig) {
+            if (KC) {
                 off = base[it] + (unsigned)k0 * 4u;
             } else {
                 int krow = k;
-                if (k_rows != nullptr) krow = k_rows[min(k, k_end - 1)];   // unconditional (clamped) index load
+                if (ROWS) krow = kidx[max(min(k, k_end - 1) - k_begin, 0)];
                 off = (unsigned)(krow * ld) * 4u + base[it];
             }
             if (VEC) {   // contiguous extent is a multiple of 4: a valid first element implies a valid float4
-                auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, valid ? off : oob, 0, 0);
-                static_assert(sizeof(r) == 16, "b128 load");
-                v[it] = __builtin_bit_cast(float4, r);
+                auto q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, valid ? off : oob, 0, 0);
+                static_assert(sizeof(q) == 16, "b128 load");
+                r.v[it] = __builtin_bit_cast(float4, q);
             } else {
                 float e[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const bool oku = valid && (kcontig ? (k + u < k_end) : (iloc[it] + u < idx_max));
+                    const bool oku = valid && (KC ? (k + u < k_end) : (iloc[it] + u < idx_max));
                     e[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oku ? off + 4u * u : oob, 0, 0));
                 }
-                v[it] = make_float4(e[0], e[1], e[2], e[3]);
+                r.v[it] = make_float4(e[0], e[1], e[2], e[3]);
             }
         }
     }
 
-    __device__ __forceinline__ void store(float* __restrict__ T, int kcontig) const {
+    __device__ __forceinline__ void store(const Regs& r, float* __restrict__ T) const {
 #pragma unroll
         for (int it = 0; it < PER_THREAD; ++it) {
             int s = threadIdx.x + it * 256;
             if (s < SLOTS) {
-                if (kcontig) {
+                if (KC) {
                     int idx = s / KQ, k = (s % KQ) * 4;
-                    T[(k + 0) * LD + swz(k + 0, idx)] = v[it].x;
-                    T[(k + 1) * LD + swz(k + 1, idx)] = v[it].y;
-                    T[(k + 2) * LD + swz(k + 2, idx)] = v[it].z;
-                    T[(k + 3) * LD + swz(k + 3, idx)] = v[it].w;
+                    T[(k + 0) * LD + swz(k + 0, idx)] = r.v[it].x;
+                    T[(k + 1) * LD + swz(k + 1, idx)] = r.v[it].y;
+                    T[(k + 2) * LD + swz(k + 2, idx)] = r.v[it].z;
+                    T[(k + 3) * LD + swz(k + 3, idx)] = r.v[it].w;
                 } else {
                     int k = s / (R / 4), idx = (s % (R / 4)) * 4;
-                    *reinterpret_cast<float4*>(&T[k * LD + swz(k, idx)]) = v[it];
+                    *reinterpret_cast<float4*>(&T[k * LD + swz(k, idx)]) = r.v[it];
                 }
             }
         }
@@ -142,11 +146,26 @@ template <int MT> struct Acc;
 template <> struct Acc<16> { typedef floatx4 type; static constexpr int REGS = 4; };
 template <> struct Acc<32> { typedef floatx16 type; static constexpr int REGS = 16; };
 
-// MT = MFMA tile (16: v_mfma_f32_16x16x4_f32, 32: v_mfma_f32_32x32x2_f32); a wave computes WM_T x WN_T such tiles
-template <int MT, int WAVES_M, int WAVES_N, int WM_T, int WN_T, int BK, bool VEC>
-__global__ void __launch_bounds__(256)
-gemm_f32_kernel(GemmArgs g) {
-    constexpr int BM = WAVES_M * WM_T * MT, BN = WAVES_N * WN_T * MT;
+// Row-subset / segmented reductions (weight gradients of the degree groups): blockIdx.z walks a table of
+// (k range, output offset) segments, every segment accumulates with atomics into its group's output.
+constexpr int MAX_SEGS = 96;
+constexpr int SEG_MAX_K = 2048;          // k_rows of one segment are staged in LDS
+struct Seg { int k_begin, k_end; long c_off; };
+struct SegTable { Seg s[MAX_SEGS]; };
+
+// Tile shape: MT = MFMA tile (16: v_mfma_f32_16x16x4_f32, 32: v_mfma_f32_32x32x2_f32), a wave computes WM_T x WN_T
+// such tiles; PF = K-tiles in flight per workgroup.
+template <int MT_, int WAVES_M_, int WAVES_N_, int WM_T_, int WN_T_, int BK_, int PF_>
+struct Shape {
+    static constexpr int MT = MT_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, WM_T = WM_T_, WN_T = WN_T_, BK = BK_, PF = PF_;
+    static constexpr int BM = WAVES_M * WM_T * MT, BN = WAVES_N * WN_T * MT;
+};
+
+template <class S, bool VEC, bool A_KC, bool B_KC, bool ROWS>
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int k_begin, const int k_end, float* __restrict__ Cout,
+                                          const int* kidx, const bool first_split) {
+    constexpr int MT = S::MT, WAVES_N = S::WAVES_N, WM_T = S::WM_T, WN_T = S::WN_T, BK = S::BK, PF = S::PF;
+    constexpr int BM = S::BM, BN = S::BN;
     constexpr int LDA = (BM + 31) / 32 * 32, LDB = (BN + 31) / 32 * 32;
     constexpr int KSTEP = (MT == 16) ? 4 : 2;         // k per MFMA
     __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
@@ -155,9 +174,6 @@ gemm_f32_kernel(GemmArgs g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int k_begin = blockIdx.z * g.k_per_split;
-    const int k_end = min(g.K, k_begin + g.k_per_split);
-    if (k_begin >= k_end && !(blockIdx.z == 0)) return;
 
     typename Acc<MT>::type acc[WM_T][WN_T];
 #pragma unroll
@@ -167,58 +183,66 @@ gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < Acc<MT>::REGS; ++r) acc[i][j][r] = 0.f;
 
-    TileStage<BM, LDA, BK> sa;
-    TileStage<BN, LDB, BK> sb;
+    typedef TileStage<BM, LDA, BK, A_KC> StageA;
+    typedef TileStage<BN, LDB, BK, B_KC> StageB;
+    StageA sa;
+    StageB sb;
+    typename StageA::Regs ra_[PF];
+    typename StageB::Regs rb_[PF];
     // descriptors are built from kernel arguments / blockIdx only (wave-uniform: no waterfall loops, guide T20)
     const float* Bp = g.B;
     if (g.tile_group != nullptr) Bp += (long)g.tile_group[blockIdx.x] * g.b_group_stride;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bp), 0, g.b_bytes, 0x00020000);
-    sa.prepare(g.lda, g.a_kcontig, m0, g.M, g.m_rows);
-    sb.prepare(g.ldb, g.b_kcontig, n0, g.N, nullptr);
+    sa.prepare(g.lda, m0, g.M, g.m_rows);
+    sb.prepare(g.ldb, n0, g.N, nullptr);
     const int nk = (k_end - k_begin + BK - 1) / BK;
-    if (nk > 0) {
-        sa.template load<VEC>(ra, g.a_bytes, g.lda, g.a_kcontig, g.M, k_begin, k_end, g.k_rows);
-        sb.template load<VEC>(rb, g.b_bytes, g.ldb, g.b_kcontig, g.N, k_begin, k_end, g.k_rows);
-        sa.store(As[0], g.a_kcontig);
-        sb.store(Bs[0], g.b_kcontig);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        sa.template load<VEC, ROWS>(ra_[u], ra, g.a_bytes, g.lda, g.M, k_begin + u * BK, k_begin, k_end, kidx);
+        sb.template load<VEC, ROWS>(rb_[u], rb, g.b_bytes, g.ldb, g.N, k_begin + u * BK, k_begin, k_end, kidx);
     }
+    sa.store(ra_[0], As[0]);
+    sb.store(rb_[0], Bs[0]);
     __syncthreads();
     const int lt = lane % MT, lk = lane / MT;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            sa.template load<VEC>(ra, g.a_bytes, g.lda, g.a_kcontig, g.M, k_begin + (kt + 1) * BK, k_end, g.k_rows);
-            sb.template load<VEC>(rb, g.b_bytes, g.ldb, g.b_kcontig, g.N, k_begin + (kt + 1) * BK, k_end, g.k_rows);
-        }
-        const float* as = As[cur];
-        const float* bs = Bs[cur];
+    for (int kt = 0; kt < nk; kt += PF) {
 #pragma unroll
-        for (int kk = 0; kk < BK / KSTEP; ++kk) {
-            const int kr = kk * KSTEP + lk;
-            float af[WM_T], bf[WN_T];
+        for (int u = 0; u < PF; ++u) {
+            // tile t is in LDS buffer t & 1; ring slot u (tile t) was written to LDS one iteration ago and is free
+            const int t = kt + u;
+            const int cur = (PF % 2 == 0) ? (u & 1) : (t & 1);
+            sa.template load<VEC, ROWS>(ra_[u], ra, g.a_bytes, g.lda, g.M, k_begin + (t + PF) * BK, k_begin, k_end, kidx);
+            sb.template load<VEC, ROWS>(rb_[u], rb, g.b_bytes, g.ldb, g.N, k_begin + (t + PF) * BK, k_begin, k_end, kidx);
+            if (t < nk) {
+                const float* as = As[cur];
+                const float* bs = Bs[cur];
 #pragma unroll
-            for (int i = 0; i < WM_T; ++i) af[i] = as[kr * LDA + swz(kr, (wm * WM_T + i) * MT + lt)];
+                for (int kk = 0; kk < BK / KSTEP; ++kk) {
+                    const int kr = kk * KSTEP + lk;
+                    float af[WM_T], bf[WN_T];
 #pragma unroll
-            for (int j = 0; j < WN_T; ++j) bf[j] = bs[kr * LDB + swz(kr, (wn * WN_T + j) * MT + lt)];
+                    for (int i = 0; i < WM_T; ++i) af[i] = as[kr * LDA + swz(kr, (wm * WM_T + i) * MT + lt)];
 #pragma unroll
-            for (int i = 0; i < WM_T; ++i)
+                    for (int j = 0; j < WN_T; ++j) bf[j] = bs[kr * LDB + swz(kr, (wn * WN_T + j) * MT + lt)];
 #pragma unroll
-                for (int j = 0; j < WN_T; ++j) {
-                    if constexpr (MT == 16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j], af[i], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < WM_T; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN_T; ++j) {
+                            if constexpr (MT == 16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j], af[i], acc[i][j], 0, 0, 0);
+                        }
                 }
+            }
+            sa.store(ra_[(u + 1) % PF], As[cur ^ 1]);     // tile t+1 (zeros past the end)
+            sb.store(rb_[(u + 1) % PF], Bs[cur ^ 1]);
+            __syncthreads();
         }
-        if (kt + 1 < nk) {
-            sa.store(As[cur ^ 1], g.a_kcontig);
-            sb.store(Bs[cur ^ 1], g.b_kcontig);
-        }
-        __syncthreads();
     }
 
     // epilogue.  D[row = n][col = m]; a lane owns one m (lane % MT) and groups of 4 consecutive n:
     //   MT = 16: n = 4*(lane>>4) + 0..3 (one group);  MT = 32: n = 8*grp + 4*(lane>>5) + 0..3, grp = 0..3
-    const bool add_bias = g.bias != nullptr && blockIdx.z == 0;
+    const bool add_bias = g.bias != nullptr && first_split;
     constexpr int GROUPS = (MT == 16) ? 1 : 4;
 #pragma unroll
     for (int i = 0; i < WM_T; ++i) {
@@ -233,7 +257,7 @@ gemm_f32_kernel(GemmArgs g) {
                 const int n = n0 + (wn * WN_T + j) * MT + ((MT == 16) ? lk * 4 : 8 * grp + 4 * lk);
                 if (n >= g.N) continue;
                 float r[4] = {acc[i][j][4 * grp + 0], acc[i][j][4 * grp + 1], acc[i][j][4 * grp + 2], acc[i][j][4 * grp + 3]};
-                float* c = g.C + (long)row * g.ldc + n;
+                float* c = Cout + (long)row * g.ldc + n;
                 const bool full = (n + 3 < g.N);
                 if (add_bias) {
 #pragma unroll
@@ -261,19 +285,72 @@ gemm_f32_kernel(GemmArgs g) {
     }
 }
 
-template <int MT, int WAVES_M, int WAVES_N, int WM_T, int WN_T, int BK>
-static void launch(const GemmArgs& g, int splits, bool vec, hipStream_t s) {
-    constexpr int BM = WAVES_M * WM_T * MT, BN = WAVES_N * WN_T * MT;
-    dim3 grid(cdiv(g.M, BM), cdiv(g.N, BN), splits);
-    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<MT, WAVES_M, WAVES_N, WM_T, WN_T, BK, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<MT, WAVES_M, WAVES_N, WM_T, WN_T, BK, false>), grid, dim3(256), 0, s, g);
+template <class S, bool VEC, bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(256)
+gemm_f32_kernel(GemmArgs g) {
+    const int k_begin = blockIdx.z * g.k_per_split;
+    const int k_end = min(g.K, k_begin + g.k_per_split);
+    if (k_begin >= k_end && !(blockIdx.z == 0)) return;
+    gemm_body<S, VEC, A_KC, B_KC, false>(g, k_begin, k_end, g.C, nullptr, blockIdx.z == 0);
 }
 
-// tile configurations {BM, BN, BK, MFMA}; the numbering is part of the tuning entry i3d_gemm_f32_ex
-constexpr int N_CFG = 6;
-static const int CFG_BM[N_CFG] = {128, 256, 64, 32, 64, 128};
-static const int CFG_BN[N_CFG] = {128, 32, 64, 64, 64, 128};
-static const int CFG_BK[N_CFG] = {16, 16, 16, 32, 16, 16};
+template <class S, bool VEC>
+__global__ void __launch_bounds__(256)
+gemm_f32_rowseg_kernel(GemmArgs g, SegTable segs) {
+    __shared__ int kidx[SEG_MAX_K];
+    const Seg sg = segs.s[blockIdx.z];
+    for (int i = threadIdx.x; i < sg.k_end - sg.k_begin; i += 256) kidx[i] = g.k_rows[sg.k_begin + i];
+    __syncthreads();
+    gemm_body<S, VEC, false, false, true>(g, sg.k_begin, sg.k_end, g.C + sg.c_off, kidx, false);
+}
+
+// layout: 0 forward (A and B k-contiguous), 1 data gradient (A k-contiguous, B idx-contiguous),
+//         2 weight gradient (both idx-contiguous), 3 (A idx-contiguous, B k-contiguous; not on the training path)
+template <class S>
+static void launch(const GemmArgs& g, int layout, int splits, bool vec, hipStream_t s) {
+    dim3 grid(cdiv(g.M, S::BM), cdiv(g.N, S::BN), splits), block(256);
+#define I3D_GEMM_LAUNCH(V, AK, BKC) hipLaunchKernelGGL((gemm_f32_kernel<S, V, AK, BKC>), grid, block, 0, s, g)
+    switch (layout * 2 + (vec ? 1 : 0)) {
+        case 0: I3D_GEMM_LAUNCH(false, true, true); break;
+        case 1: I3D_GEMM_LAUNCH(true, true, true); break;
+        case 2: I3D_GEMM_LAUNCH(false, true, false); break;
+        case 3: I3D_GEMM_LAUNCH(true, true, false); break;
+        case 4: I3D_GEMM_LAUNCH(false, false, false); break;
+        default: I3D_GEMM_LAUNCH(true, false, false); break;
+    }
+#undef I3D_GEMM_LAUNCH
+}
+
+template <class S>
+static void launch_rowseg(const GemmArgs& g, const SegTable& t, int n_segs, bool vec, hipStream_t s) {
+    dim3 grid(cdiv(g.M, S::BM), cdiv(g.N, S::BN), n_segs);
+    if (vec) hipLaunchKernelGGL((gemm_f32_rowseg_kernel<S, true>), grid, dim3(256), 0, s, g, t);
+    else hipLaunchKernelGGL((gemm_f32_rowseg_kernel<S, false>), grid, dim3(256), 0, s, g, t);
+}
+
+// tile configurations; the numbering is part of the tuning entry i3d_gemm_f32_ex
+//   0: 128x128x16 (32x32x2)  1: 256x32x16 (16x16x4)  2: 64x64x16 (32x32x2)  3: 32x64x32 (16x16x4)
+//   4: 64x64x32 (32x32x2)    5: 128x64x16 (32x32x2)  6 / 7: as 2 with 1 / 4 K-tiles in flight instead of 2
+typedef Shape<32, 2, 2, 2, 2, 16, 2> Cfg0;
+typedef Shape<16, 4, 1, 4, 2, 16, 2> Cfg1;
+typedef Shape<32, 2, 2, 1, 1, 16, 2> Cfg2;
+typedef Shape<16, 2, 2, 1, 2, 32, 2> Cfg3;
+typedef Shape<32, 2, 2, 1, 1, 32, 2> Cfg4;
+typedef Shape<32, 2, 2, 2, 1, 16, 4> Cfg5;
+typedef Shape<32, 2, 2, 1, 1, 16, 1> Cfg6;
+typedef Shape<32, 2, 2, 1, 1, 16, 4> Cfg7;
+constexpr int N_CFG = 8;
+static const int CFG_BM[N_CFG] = {Cfg0::BM, Cfg1::BM, Cfg2::BM, Cfg3::BM, Cfg4::BM, Cfg5::BM, Cfg6::BM, Cfg7::BM};
+static const int CFG_BN[N_CFG] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN};
+static const int CFG_BK[N_CFG] = {Cfg0::BK, Cfg1::BK, Cfg2::BK, Cfg3::BK, Cfg4::BK, Cfg5::BK, Cfg6::BK, Cfg7::BK};
+
+// the (A idx-contiguous, B k-contiguous) layout is computed as layout 2 would need B transposed: it only exists for
+// API completeness, through one configuration
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+gemm_f32_tt_kernel(GemmArgs g) {
+    gemm_body<Cfg6, VEC, false, true, false>(g, 0, g.K, g.C, nullptr, true);
+}
 
 struct Extra {
     const int* m_rows = nullptr;
@@ -281,8 +358,25 @@ struct Extra {
     const int* tile_group = nullptr;
     long b_group_stride = 0;
     long a_rows_total = -1;   // number of physical rows of A / C when m_rows is used (for the descriptor extent)
-    long k_rows_total = -1;   // number of physical rows of the idx-contiguous operands when k_rows is used
+    long k_rows_total = -1;   // number of physical rows of the operands when k_rows is used
+    // row-subset reductions: n_groups disjoint ranges [start, start + count) of k_rows, one output per group
+    int n_groups = 0;
+    const int* group_start = nullptr;
+    const int* group_count = nullptr;
+    long c_group_stride = 0;
 };
+
+static int fill_views(GemmArgs& g, int trans_a, int trans_b, int M, int N, int K, int lda, int ldb, const Extra& ex) {
+    long a_rows = trans_a ? K : M, a_cols = trans_a ? M : K, b_rows = trans_b ? N : K, b_cols = trans_b ? K : N;
+    if (!trans_a && ex.m_rows) a_rows = ex.a_rows_total;
+    if (trans_a && ex.k_rows) a_rows = ex.k_rows_total;
+    if (!trans_b && ex.k_rows) b_rows = ex.k_rows_total;
+    const long ab = a_rows > 0 ? ((a_rows - 1) * lda + a_cols) * 4 : 0, bb = b_rows > 0 ? ((b_rows - 1) * ldb + b_cols) * 4 : 0;
+    I3D_CHECK_ARG(ab < (1L << 32) - 16 && bb < (1L << 32) - 16, "operand view larger than 4 GiB (32-bit buffer offsets)");
+    g.a_bytes = (unsigned)ab;
+    g.b_bytes = (unsigned)bb;
+    return I3D_OK;
+}
 
 static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                      float* C, int ldc, const float* bias, int accumulate, int force_cfg, int force_splits,
@@ -295,32 +389,37 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     g.A = A; g.B = B; g.C = C; g.bias = bias;
     g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-    g.a_kcontig = trans_a ? 0 : 1;
-    g.b_kcontig = trans_b ? 1 : 0;
     g.accumulate = accumulate ? 1 : 0;
-    g.m_rows = ex.m_rows; g.k_rows = ex.k_rows; g.tile_group = ex.tile_group; g.b_group_stride = ex.b_group_stride;
-    {
-        long a_rows = trans_a ? K : M, a_cols = trans_a ? M : K, b_rows = trans_b ? N : K, b_cols = trans_b ? K : N;
-        if (!trans_a && ex.m_rows) a_rows = ex.a_rows_total;
-        if (trans_a && ex.k_rows) a_rows = ex.k_rows_total;
-        if (!trans_b && ex.k_rows) b_rows = ex.k_rows_total;
-        const long ab = a_rows > 0 ? ((a_rows - 1) * lda + a_cols) * 4 : 0, bb = b_rows > 0 ? ((b_rows - 1) * ldb + b_cols) * 4 : 0;
-        I3D_CHECK_ARG(ab < (1L << 32) - 16 && bb < (1L << 32) - 16, "operand view larger than 4 GiB (32-bit buffer offsets)");
-        g.a_bytes = (unsigned)ab;
-        g.b_bytes = (unsigned)bb;
-    }
+    g.m_rows = ex.m_rows; g.k_rows = nullptr; g.tile_group = ex.tile_group; g.b_group_stride = ex.b_group_stride;
+    int rc = fill_views(g, trans_a, trans_b, M, N, K, lda, ldb, ex);
+    if (rc != I3D_OK) return rc;
     const bool a_al = (((uintptr_t)A & 15) == 0) && (lda % 4 == 0), b_al = (((uintptr_t)B & 15) == 0) && (ldb % 4 == 0);
     g.c_vec = (((uintptr_t)C & 15) == 0) && (ldc % 4 == 0);
+    // fast path: 16-byte loads need aligned pointers / leading dimensions and contiguous extents that are
+    // multiples of 4 (K for k-contiguous operands, M or N for the others)
+    const bool vec = a_al && b_al && ((trans_a ? M : K) % 4 == 0) && ((trans_b ? K : N) % 4 == 0) &&
+                     (ex.b_group_stride % 4 == 0);
+    const int layout = trans_a ? (trans_b ? 3 : 2) : (trans_b ? 0 : 1);
+
+    if (layout == 3) {
+        I3D_CHECK_ARG(ex.m_rows == nullptr && ex.tile_group == nullptr, "row indirection needs a k-contiguous A");
+        g.k_per_split = K; g.atomic_out = 0;
+        dim3 grid(cdiv(M, Cfg6::BM), cdiv(N, Cfg6::BN), 1);
+        if (vec) hipLaunchKernelGGL((gemm_f32_tt_kernel<true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_f32_tt_kernel<false>), grid, dim3(256), 0, s, g);
+        I3D_CHECK_LAUNCH();
+        return I3D_OK;
+    }
 
     // tile configuration, measured on MI355X at the step's shapes (tools/gemm_bench.py, profiles/r01_gemm_bench_*.log):
     // the batch is small for a 256-CU chip, so many 64x64 tiles beat fewer big ones until there are thousands of tiles.
-    int cfg;  // 0: 128x128x16 (16x16x4)  1: 256x32x16  2: 64x64x16 (16x16x4)  3: 32x64x32  4: 64x64x16 (32x32x2)  5: 128x128x16 (32x32x2)
+    int cfg;
     const long tiles64 = (long)cdiv(M, 64) * cdiv(N, 64);
     if (N <= 32) cfg = 1;
-    else if (tiles64 >= 4096) cfg = 5;
-    else if (trans_a && tiles64 < 64) cfg = 3;    // tiny weight-gradient outputs
-    else cfg = 4;
-    if (ex.tile_group != nullptr) cfg = 4;        // the group padding of m_rows is 64 rows
+    else if (tiles64 >= 4096) cfg = 0;
+    else if (trans_a && tiles64 < 512) cfg = 3;   // weight gradients: few output tiles, long K
+    else cfg = 2;
+    if (ex.tile_group != nullptr) cfg = 2;        // the group padding of m_rows is 64 rows
     if (force_cfg >= 0) {
         I3D_CHECK_ARG(force_cfg < N_CFG, "tile_cfg out of range");
         I3D_CHECK_ARG(ex.tile_group == nullptr || CFG_BM[force_cfg] == 64, "grouped GEMM needs 64-row tiles");
@@ -332,8 +431,8 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     // split-K (fp32 atomics, order not deterministic) ONLY for the row-reduction GEMMs of the backward pass
     // (trans_a: dW = dY^T X, K = number of rows).  Forward GEMMs stay single-pass and bit-deterministic, so that
     // the arg-max/arg-min routing of the aggregators and readouts cannot flip from run to run on near-ties.
-    if (trans_a && tiles < 768 && K >= 1024) {   // until ~1024 workgroups, >= 512 of K per split
-        splits = (1024 + tiles / 2) / tiles;
+    if (trans_a && tiles < 512 && K >= 1024) {   // until ~512 workgroups (the atomics of the epilogue are not free), >= 512 of K per split
+        splits = (512 + tiles - 1) / tiles;
         int max_splits = K / 512;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
@@ -353,17 +452,89 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
             return I3D_ERR_LAUNCH;
         }
     }
-    // fast path: 16-byte loads need aligned pointers / leading dimensions and contiguous extents that are
-    // multiples of 4 (K for k-contiguous operands, M or N for the others)
-    const bool vec = a_al && b_al && ((g.a_kcontig ? K : M) % 4 == 0) && ((g.b_kcontig ? K : N) % 4 == 0) &&
-                     (ex.b_group_stride % 4 == 0);
     switch (cfg) {
-        case 0: launch<16, 2, 2, 4, 4, 16>(g, splits, vec, s); break;
-        case 1: launch<16, 4, 1, 4, 2, 16>(g, splits, vec, s); break;
-        case 2: launch<16, 2, 2, 2, 2, 16>(g, splits, vec, s); break;
-        case 3: launch<16, 2, 2, 1, 2, 32>(g, splits, vec, s); break;
-        case 4: launch<32, 2, 2, 1, 1, 16>(g, splits, vec, s); break;
-        default: launch<32, 2, 2, 2, 2, 16>(g, splits, vec, s); break;
+        case 0: launch<Cfg0>(g, layout, splits, vec, s); break;
+        case 1: launch<Cfg1>(g, layout, splits, vec, s); break;
+        case 2: launch<Cfg2>(g, layout, splits, vec, s); break;
+        case 3: launch<Cfg3>(g, layout, splits, vec, s); break;
+        case 4: launch<Cfg4>(g, layout, splits, vec, s); break;
+        case 5: launch<Cfg5>(g, layout, splits, vec, s); break;
+        case 6: launch<Cfg6>(g, layout, splits, vec, s); break;
+        default: launch<Cfg7>(g, layout, splits, vec, s); break;
+    }
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+// C_g[M,N] (+)= sum_{j in group g} A[k_rows[j], 0:M]^T B[k_rows[j], 0:N] for all groups in ONE launch: the reduction
+// ranges are cut into <= MAX_SEGS segments of <= SEG_MAX_K rows, each a blockIdx.z slice that accumulates with atomics.
+static int rowseg_impl(int M, int N, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int accumulate,
+                       int force_cfg, int force_seg_rows, const Extra& ex, void* stream) {
+    I3D_CHECK_ARG(M > 0 && N > 0 && ex.n_groups > 0 && ex.k_rows != nullptr, "bad arguments");
+    I3D_CHECK_ARG(lda >= M && ldb >= N && ldc >= N, "leading dimension too small");
+    hipStream_t s = (hipStream_t)stream;
+    long total = 0;
+    int k_hi = 0;
+    for (int gi = 0; gi < ex.n_groups; ++gi) {
+        I3D_CHECK_ARG(ex.group_start[gi] >= 0 && ex.group_count[gi] >= 0, "bad group range");
+        total += ex.group_count[gi];
+        k_hi = std::max(k_hi, ex.group_start[gi] + ex.group_count[gi]);
+    }
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = nullptr;
+    g.M = M; g.N = N; g.K = k_hi;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.accumulate = 1; g.atomic_out = 1; g.k_per_split = 0;
+    g.m_rows = nullptr; g.k_rows = ex.k_rows; g.tile_group = nullptr; g.b_group_stride = 0;
+    int rc = fill_views(g, 1, 0, M, N, k_hi, lda, ldb, ex);
+    if (rc != I3D_OK) return rc;
+    g.c_vec = (((uintptr_t)C & 15) == 0) && (ldc % 4 == 0);
+    if (!accumulate) {
+        for (int gi = 0; gi < ex.n_groups; ++gi) {
+            float* Cg = C + gi * ex.c_group_stride;
+            hipError_t e = (ldc == N) ? hipMemsetAsync(Cg, 0, (size_t)M * N * sizeof(float), s)
+                                      : hipMemset2DAsync(Cg, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s);
+            if (e != hipSuccess) {
+                set_error("i3d_gemm_f32_rowsubset: memset failed");
+                return I3D_ERR_LAUNCH;
+            }
+        }
+    }
+    if (total == 0) return I3D_OK;
+    int cfg = 3;
+    if (force_cfg >= 0) {
+        I3D_CHECK_ARG(force_cfg >= 2 && force_cfg <= 4, "row-subset GEMM: tile_cfg must be 2, 3 or 4");
+        cfg = force_cfg;
+    }
+    const int BK = CFG_BK[cfg];
+    const int tiles = cdiv(M, CFG_BM[cfg]) * cdiv(N, CFG_BN[cfg]);
+    // the atomics of the epilogue are the expensive part of a segment: ~1000 workgroups, >= 1024 rows per segment
+    long want = std::max<long>(ex.n_groups, (1024 + tiles / 2) / tiles);
+    long seg_rows = std::max<long>(1024, (long)cdiv((int)cdiv((int)total, (int)want), BK) * BK);
+    if (force_seg_rows > 0) seg_rows = (long)cdiv(force_seg_rows, BK) * BK;
+    SegTable t;
+    int n_segs;
+    for (;;) {
+        if (seg_rows > SEG_MAX_K) seg_rows = SEG_MAX_K;
+        n_segs = 0;
+        bool fits = true;
+        for (int gi = 0; gi < ex.n_groups && fits; ++gi) {
+            const int b = ex.group_start[gi], e = b + ex.group_count[gi];
+            for (int k = b; k < e; k += (int)seg_rows) {
+                if (n_segs == MAX_SEGS) { fits = false; break; }
+                t.s[n_segs++] = Seg{k, std::min<int>(e, k + (int)seg_rows), gi * ex.c_group_stride};
+            }
+        }
+        if (fits) break;
+        I3D_CHECK_ARG(seg_rows < SEG_MAX_K, "row-subset GEMM: more than MAX_SEGS * SEG_MAX_K rows");
+        seg_rows *= 2;
+    }
+    const bool vec = (((uintptr_t)A & 15) == 0) && (lda % 4 == 0) && (((uintptr_t)B & 15) == 0) && (ldb % 4 == 0) &&
+                     (M % 4 == 0) && (N % 4 == 0);
+    switch (cfg) {
+        case 2: launch_rowseg<Cfg2>(g, t, n_segs, vec, s); break;
+        case 3: launch_rowseg<Cfg3>(g, t, n_segs, vec, s); break;
+        default: launch_rowseg<Cfg4>(g, t, n_segs, vec, s); break;
     }
     I3D_CHECK_LAUNCH();
     return I3D_OK;
@@ -399,8 +570,23 @@ extern "C" int i3d_gemm_f32_grouped(int trans_b, int m_padded, int N, int K, con
 extern "C" int i3d_gemm_f32_rowsubset(int M, int N, int n_rows, const float* A, int lda, const float* B, int ldb,
                                       const int* k_rows, long rows_total, float* C, int ldc, int accumulate,
                                       void* stream) {
-    I3D_CHECK_ARG(k_rows != nullptr, "k_rows required");
+    I3D_CHECK_ARG(k_rows != nullptr && n_rows >= 0, "k_rows required");
+    const int start = 0;
     Extra ex;
     ex.k_rows = k_rows; ex.k_rows_total = rows_total;
-    return gemm_impl(1, 0, M, N, n_rows, A, lda, B, ldb, C, ldc, nullptr, accumulate, -1, 0, ex, stream);
+    ex.n_groups = 1; ex.group_start = &start; ex.group_count = &n_rows; ex.c_group_stride = 0;
+    return rowseg_impl(M, N, A, lda, B, ldb, C, ldc, accumulate, -1, 0, ex, stream);
+}
+
+// C_g[M,N] = sum_{group_start[g] <= j < group_start[g] + group_count[g]} A[k_rows[j], 0:M]^T B[k_rows[j], 0:N],
+// C_g = C + g * c_group_stride: the weight gradients of all in-degree groups in one launch.
+extern "C" int i3d_gemm_f32_rowsubset_multi(int M, int N, int n_groups, const int* group_start, const int* group_count,
+                                            const float* A, int lda, const float* B, int ldb, const int* k_rows,
+                                            long rows_total, float* C, long c_group_stride, int ldc, int accumulate,
+                                            int tile_cfg, int seg_rows, void* stream) {
+    I3D_CHECK_ARG(k_rows != nullptr && group_start != nullptr && group_count != nullptr && n_groups > 0, "bad arguments");
+    Extra ex;
+    ex.k_rows = k_rows; ex.k_rows_total = rows_total;
+    ex.n_groups = n_groups; ex.group_start = group_start; ex.group_count = group_count; ex.c_group_stride = c_group_stride;
+    return rowseg_impl(M, N, A, lda, B, ldb, C, ldc, accumulate, tile_cfg, seg_rows, ex, stream);
 }

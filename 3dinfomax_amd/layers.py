@@ -351,8 +351,8 @@ class GroupedConcat2FCFn(torch.autograd.Function):
         gW = torch.empty_like(W)
         ops.gemm(grad_pre, h, trans_a=True, out=gW[:, :Fh])
         gWD = torch.empty_like(WD)
-        for gi, (_, start, count) in enumerate(groups):       # dW_D = dY_D^T a_D over the rows of the group
-            ops.gemm_rowsubset(grad_pre, a, rows[start:start + count], gWD[gi])
+        # dW_D = dY_D^T a_D over the rows of each in-degree group, one launch for all groups
+        ops.gemm_rowsubset_multi(grad_pre, a, rows, [st for _, st, _ in groups], [ct for _, _, ct in groups], gWD)
         ops.combine_weights_bwd(gWD, gW, Fh, A, flat, nG, nS)
         gbias = ops.colsum(grad_pre)
         gh = ops.gemm(grad_pre, W[:, :Fh])

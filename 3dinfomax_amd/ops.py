@@ -409,6 +409,21 @@ def gemm_grouped(A, m_rows, tile_group, Bg, out, trans_b, accumulate):
     return out
 
 
+def gemm_rowsubset_multi(A, B, k_rows, group_start, group_count, out, accumulate=False, tile_cfg=-1, seg_rows=0):
+    """out[g] = sum over j in [group_start[g], +group_count[g]) of A[k_rows[j],:]^T B[k_rows[j],:]; out: [G, M, N]."""
+    _chk(A)
+    _chk(B)
+    _chk(out)
+    G = len(group_start)
+    assert out.shape == (G, A.shape[1], B.shape[1])
+    check(_lib.load().i3d_gemm_f32_rowsubset_multi(A.shape[1], B.shape[1], G, int_array(list(group_start)),
+                                                   int_array(list(group_count)), _p(A), A.shape[1], _p(B), B.shape[1],
+                                                   _p(k_rows), A.shape[0], _p(out), out.shape[1] * out.shape[2],
+                                                   out.shape[2], int(accumulate), tile_cfg, seg_rows, _stream()),
+          'i3d_gemm_f32_rowsubset_multi')
+    return out
+
+
 def gemm_rowsubset(A, B, k_rows, out):
     """out[M,N] = sum over rows r in k_rows of A[r,:M]^T B[r,:N]."""
     _chk(A)

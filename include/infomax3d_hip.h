@@ -119,7 +119,10 @@ int i3d_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, const float* 
  *  gemm_f32_grouped:    C[r, :] (+)= A[r, :] * op(B_g) for r = m_rows[m] >= 0, g = tile_group[m / 64]; m_rows lists
  *                       the nodes grouped by in-degree, every group padded with -1 to a multiple of 64 rows;
  *                       trans_b = 1: B_g stored [N, K] (forward, B_g = WD[g]);  0: B_g stored [K, N] (data gradient)
- *  gemm_f32_rowsubset:  C[M, N] = sum_j A[k_rows[j], 0:M]^T B[k_rows[j], 0:N]   (weight gradient of one group) */
+ *  gemm_f32_rowsubset:  C[M, N] = sum_j A[k_rows[j], 0:M]^T B[k_rows[j], 0:N]   (weight gradient of one group)
+ *  gemm_f32_rowsubset_multi: the same for n_groups disjoint ranges [group_start[g], +group_count[g]) of k_rows in ONE
+ *                       launch, C_g = C + g * c_group_stride (host arrays for the ranges; tile_cfg -1 / seg_rows 0 =
+ *                       automatic; fp32 atomics over the row segments, like the split-K weight gradients) */
 int i3d_pna_combine_weights_fwd(const float* W, int ldw, int f_in, int f_out, int agg_width, int n_groups,
                                 int n_scalers, const float* coef, float* WD, void* stream);
 int i3d_pna_combine_weights_bwd(const float* dWD, int ldw, int f_in, int f_out, int agg_width, int n_groups,
@@ -129,6 +132,10 @@ int i3d_gemm_f32_grouped(int trans_b, int m_padded, int N, int K, const float* A
                          float* C, int ldc, int accumulate, void* stream);
 int i3d_gemm_f32_rowsubset(int M, int N, int n_rows, const float* A, int lda, const float* B, int ldb,
                            const int* k_rows, long rows_total, float* C, int ldc, int accumulate, void* stream);
+int i3d_gemm_f32_rowsubset_multi(int M, int N, int n_groups, const int* group_start, const int* group_count,
+                                 const float* A, int lda, const float* B, int ldb, const int* k_rows, long rows_total,
+                                 float* C, long c_group_stride, int ldc, int accumulate, int tile_cfg, int seg_rows,
+                                 void* stream);
 
 /* ---- column statistics / BatchNorm1d ---------------------------------------------------------------
  * replaces nn.BatchNorm1d in FCLayer (train: batch statistics, momentum m, unbiased running_var; eval: running

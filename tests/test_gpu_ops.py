@@ -131,6 +131,12 @@ def test_degree_grouped_posttrans_gemms():
     rows_d = g(torch.from_numpy(rows))
     for gi, (_, start, count) in enumerate(groups):
         ops.gemm_rowsubset(g(dY), g(a), rows_d[start:start + count], gWD[gi])
+    # ... and all groups in one launch (several tile configurations / segment lengths)
+    for cfg, seg in ((-1, 0), (3, 128), (4, 64), (2, 2048)):
+        gWD2 = torch.full_like(WD, 3.0)
+        ops.gemm_rowsubset_multi(g(dY), g(a), rows_d, [st for _, st, _ in groups], [ct for _, _, ct in groups], gWD2,
+                                 tile_cfg=cfg, seg_rows=seg)
+        assert rel_err(gWD2.cpu(), gWD.cpu()) < 2e-6, (cfg, seg)
     gW = torch.full((F_out, 200 + S * A), 7.0, device=DEV)
     ops.combine_weights_bwd(gWD, gW, 200, A, flat, len(groups), S)
     ref_gW = dY.double().T @ agg12.double()

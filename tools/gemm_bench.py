@@ -3,6 +3,7 @@ prints time and TFLOP/s per (shape, tile config, split-K).  Run on the MI355X bo
     python tools/gemm_bench.py [--all-cfgs]
 """
 import argparse
+import ctypes
 import importlib
 import os
 import sys
@@ -23,6 +24,8 @@ SHAPES = [  # name, ta, tb, M, N, K
     ('wgrad  dY^T[F,N] X[N,F]  ', 1, 0, F, F, N_NODES),
     ('wgrad  dY^T[F,E] X[E,F]  ', 1, 0, F, F, N_EDGES),
     ('wgrad  dY^T[F,N] agg     ', 1, 0, F, 12 * F, N_NODES),
+    ('post4  agg[N,4F] W^T     ', 0, 1, N_NODES, F, 4 * F),
+    ('dgrad4 dY[N,F] W[F,4F]   ', 0, 0, N_NODES, 4 * F, F),
     ('net3d  d[E3,20] W^T      ', 0, 1, 140000, 20, 20),
     ('head   r[512,600] W^T    ', 0, 1, 512, 200, 600),
     ('sim    z1 z2^T           ', 0, 1, 512, 512, 256),
@@ -52,6 +55,42 @@ def run(lib, ta, tb, M, N, K, cfg, splits, reps=20):
     return us, 2.0 * M * N * K / us * 1e-6, err
 
 
+def run_rowseg(lib, cfg, seg_rows, reps=20):
+    """weight gradients of the in-degree groups (QM9-like degree histogram) in one launch"""
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    deg = torch.multinomial(torch.tensor([0.0, 0.42, 0.13, 0.17, 0.28]), N_NODES, replacement=True)
+    order = torch.argsort(deg, stable=True).int()
+    counts = torch.bincount(deg, minlength=5).tolist()
+    starts, cnts, o = [], [], 0
+    for c in counts:
+        if c:
+            starts.append(o)
+            cnts.append(c)
+        o += c
+    G = len(starts)
+    dY, a = torch.randn(N_NODES, F, device=dev), torch.randn(N_NODES, 4 * F, device=dev)
+    rows = order.to(dev)
+    out = torch.zeros(G, F, 4 * F, device=dev)
+    ia = lambda v: (ctypes.c_int * len(v))(*v)
+    st = c_void_p(torch.cuda.current_stream().cuda_stream)
+    args = (F, 4 * F, G, ia(starts), ia(cnts), c_void_p(dY.data_ptr()), F, c_void_p(a.data_ptr()), 4 * F,
+            c_void_p(rows.data_ptr()), N_NODES, c_void_p(out.data_ptr()), F * 4 * F, 4 * F, 0, cfg, seg_rows, st)
+    for _ in range(3):
+        assert lib.i3d_gemm_f32_rowsubset_multi(*args) == 0, lib.i3d_last_error()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        lib.i3d_gemm_f32_rowsubset_multi(*args)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    ref = torch.stack([dY[rows[s:s + c].long()].double().T @ a[rows[s:s + c].long()].double() for s, c in zip(starts, cnts)])
+    err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
+    return us, 2.0 * N_NODES * F * 4 * F / us * 1e-6, err
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--all-cfgs', action='store_true')
@@ -61,9 +100,11 @@ if __name__ == '__main__':
         us, tf, err = run(lib, ta, tb, M, N, K, -1, 0)
         print(f'{name} M={M:6d} N={N:5d} K={K:6d}  auto: {us:8.1f} us {tf:7.1f} TF  err {err:.1e}', flush=True)
         if a.all_cfgs:
-            for cfg in (0, 2, 3, 4, 5):
-                for splits in ((1, 2, 4) if K <= 2400 and M > 2000 else (4, 8, 16, 32)):
-                    if splits > 1 and K < 1024:
-                        continue
+            wgrad = bool(ta)
+            for cfg in ((3, 2, 4, 6) if wgrad else (0, 2, 4, 5, 6, 7)):
+                for splits in ((4, 8, 16, 32, 64) if wgrad else (1,)):
                     us, tf, err = run(lib, ta, tb, M, N, K, cfg, splits)
-                    print(f'      cfg {cfg} splits {splits:2d}: {us:8.1f} us {tf:7.1f} TF  err {err:.1e}', flush=True)
+                    print(f'      cfg {cfg:2d} splits {splits:2d}: {us:8.1f} us {tf:7.1f} TF  err {err:.1e}', flush=True)
+    for cfg, seg in ((-1, 0), (3, 256), (3, 512), (3, 1024), (3, 2048), (2, 512), (2, 1024), (4, 512), (4, 1024), (4, 2048)):
+        us, tf, err = run_rowseg(lib, cfg, seg)
+        print(f'rowseg wgrad 5 groups [F x 4F] cfg {cfg:2d} seg_rows {seg:4d}: {us:8.1f} us {tf:7.1f} TF  err {err:.1e}', flush=True)
