@@ -161,9 +161,24 @@ struct Shape {
     static constexpr int BM = WAVES_M * WM_T * MT, BN = WAVES_N * WN_T * MT;
 };
 
+// blockIdx -> (m tile, n tile, z) such that the workgroups that run on one XCD (observed: linear block id % 8; a speed
+// assumption only) are CONSECUTIVE work items in (z, m tile, n tile) order: the n-tiles of one m-tile - which read
+// the same rows of A - and the tiles of one K split - which read the same rows of both operands - then share that
+// XCD's L2 instead of each pulling their own copy through the fabric (the L2s of the 8 XCDs are separate).
+__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz) {
+    const int nx = gridDim.x, ny = gridDim.y;
+    const int total = nx * ny * gridDim.z;
+    const int id = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const int q = total / 8, r = total % 8, xcd = id % 8;
+    const int w = xcd * q + min(xcd, r) + id / 8;      // XCD x owns q (+1 if x < r) consecutive items
+    by = w % ny;
+    bx = (w / ny) % nx;
+    bz = w / (ny * nx);
+}
+
 template <class S, bool VEC, bool A_KC, bool B_KC, bool ROWS>
-__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int k_begin, const int k_end, float* __restrict__ Cout,
-                                          const int* kidx, const bool first_split) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int k_begin, const int k_end,
+                                          float* __restrict__ Cout, const int* kidx, const bool first_split) {
     constexpr int MT = S::MT, WAVES_N = S::WAVES_N, WM_T = S::WM_T, WN_T = S::WN_T, BK = S::BK, PF = S::PF;
     constexpr int BM = S::BM, BN = S::BN;
     constexpr int LDA = (BM + 31) / 32 * 32, LDB = (BN + 31) / 32 * 32;
@@ -173,7 +188,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int k_begin, 
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * BM, n0 = by * BN;
 
     typename Acc<MT>::type acc[WM_T][WN_T];
 #pragma unroll
@@ -191,7 +206,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int k_begin, 
     typename StageB::Regs rb_[PF];
     // descriptors are built from kernel arguments / blockIdx only (wave-uniform: no waterfall loops, guide T20)
     const float* Bp = g.B;
-    if (g.tile_group != nullptr) Bp += (long)g.tile_group[blockIdx.x] * g.b_group_stride;
+    if (g.tile_group != nullptr) Bp += (long)g.tile_group[bx] * g.b_group_stride;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bp), 0, g.b_bytes, 0x00020000);
     sa.prepare(g.lda, m0, g.M, g.m_rows);
@@ -288,20 +303,24 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int k_begin, 
 template <class S, bool VEC, bool A_KC, bool B_KC>
 __global__ void __launch_bounds__(256)
 gemm_f32_kernel(GemmArgs g) {
-    const int k_begin = blockIdx.z * g.k_per_split;
+    int bx, by, bz;
+    xcd_tile(bx, by, bz);
+    const int k_begin = bz * g.k_per_split;
     const int k_end = min(g.K, k_begin + g.k_per_split);
-    if (k_begin >= k_end && !(blockIdx.z == 0)) return;
-    gemm_body<S, VEC, A_KC, B_KC, false>(g, k_begin, k_end, g.C, nullptr, blockIdx.z == 0);
+    if (k_begin >= k_end && !(bz == 0)) return;
+    gemm_body<S, VEC, A_KC, B_KC, false>(g, bx, by, k_begin, k_end, g.C, nullptr, bz == 0);
 }
 
 template <class S, bool VEC>
 __global__ void __launch_bounds__(256)
 gemm_f32_rowseg_kernel(GemmArgs g, SegTable segs) {
     __shared__ int kidx[SEG_MAX_K];
-    const Seg sg = segs.s[blockIdx.z];
+    int bx, by, bz;
+    xcd_tile(bx, by, bz);
+    const Seg sg = segs.s[bz];
     for (int i = threadIdx.x; i < sg.k_end - sg.k_begin; i += 256) kidx[i] = g.k_rows[sg.k_begin + i];
     __syncthreads();
-    gemm_body<S, VEC, false, false, true>(g, sg.k_begin, sg.k_end, g.C + sg.c_off, kidx, false);
+    gemm_body<S, VEC, false, false, true>(g, bx, by, sg.k_begin, sg.k_end, g.C + sg.c_off, kidx, false);
 }
 
 // layout: 0 forward (A and B k-contiguous), 1 data gradient (A k-contiguous, B idx-contiguous),
@@ -331,6 +350,7 @@ static void launch_rowseg(const GemmArgs& g, const SegTable& t, int n_segs, bool
 // tile configurations; the numbering is part of the tuning entry i3d_gemm_f32_ex
 //   0: 128x128x16 (32x32x2)  1: 256x32x16 (16x16x4)  2: 64x64x16 (32x32x2)  3: 32x64x32 (16x16x4)
 //   4: 64x64x32 (32x32x2)    5: 128x64x16 (32x32x2)  6 / 7: as 2 with 1 / 4 K-tiles in flight instead of 2
+//   8: 32x32x32 (16x16x4): weight gradients of the narrow (hidden_dim 20) 3D network, K = number of edges
 typedef Shape<32, 2, 2, 2, 2, 16, 2> Cfg0;
 typedef Shape<16, 4, 1, 4, 2, 16, 2> Cfg1;
 typedef Shape<32, 2, 2, 1, 1, 16, 2> Cfg2;
@@ -339,17 +359,18 @@ typedef Shape<32, 2, 2, 1, 1, 32, 2> Cfg4;
 typedef Shape<32, 2, 2, 2, 1, 16, 4> Cfg5;
 typedef Shape<32, 2, 2, 1, 1, 16, 1> Cfg6;
 typedef Shape<32, 2, 2, 1, 1, 16, 4> Cfg7;
-constexpr int N_CFG = 8;
-static const int CFG_BM[N_CFG] = {Cfg0::BM, Cfg1::BM, Cfg2::BM, Cfg3::BM, Cfg4::BM, Cfg5::BM, Cfg6::BM, Cfg7::BM};
-static const int CFG_BN[N_CFG] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN};
-static const int CFG_BK[N_CFG] = {Cfg0::BK, Cfg1::BK, Cfg2::BK, Cfg3::BK, Cfg4::BK, Cfg5::BK, Cfg6::BK, Cfg7::BK};
+typedef Shape<16, 2, 2, 1, 1, 32, 2> Cfg8;
+constexpr int N_CFG = 9;
+static const int CFG_BM[N_CFG] = {Cfg0::BM, Cfg1::BM, Cfg2::BM, Cfg3::BM, Cfg4::BM, Cfg5::BM, Cfg6::BM, Cfg7::BM, Cfg8::BM};
+static const int CFG_BN[N_CFG] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN};
+static const int CFG_BK[N_CFG] = {Cfg0::BK, Cfg1::BK, Cfg2::BK, Cfg3::BK, Cfg4::BK, Cfg5::BK, Cfg6::BK, Cfg7::BK, Cfg8::BK};
 
 // the (A idx-contiguous, B k-contiguous) layout is computed as layout 2 would need B transposed: it only exists for
 // API completeness, through one configuration
 template <bool VEC>
 __global__ void __launch_bounds__(256)
 gemm_f32_tt_kernel(GemmArgs g) {
-    gemm_body<Cfg6, VEC, false, true, false>(g, 0, g.K, g.C, nullptr, true);
+    gemm_body<Cfg6, VEC, false, true, false>(g, blockIdx.x, blockIdx.y, 0, g.K, g.C, nullptr, true);
 }
 
 struct Extra {
@@ -415,7 +436,8 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     // the batch is small for a 256-CU chip, so many 64x64 tiles beat fewer big ones until there are thousands of tiles.
     int cfg;
     const long tiles64 = (long)cdiv(M, 64) * cdiv(N, 64);
-    if (N <= 32) cfg = 1;
+    if (trans_a && M <= 32 && N <= 32) cfg = 8;
+    else if (N <= 32) cfg = 1;
     else if (tiles64 >= 4096) cfg = 0;
     else if (trans_a && tiles64 < 512) cfg = 3;   // weight gradients: few output tiles, long K
     else cfg = 2;
@@ -460,7 +482,8 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
         case 4: launch<Cfg4>(g, layout, splits, vec, s); break;
         case 5: launch<Cfg5>(g, layout, splits, vec, s); break;
         case 6: launch<Cfg6>(g, layout, splits, vec, s); break;
-        default: launch<Cfg7>(g, layout, splits, vec, s); break;
+        case 7: launch<Cfg7>(g, layout, splits, vec, s); break;
+        default: launch<Cfg8>(g, layout, splits, vec, s); break;
     }
     I3D_CHECK_LAUNCH();
     return I3D_OK;

@@ -27,6 +27,8 @@ SHAPES = [  # name, ta, tb, M, N, K
     ('post4  agg[N,4F] W^T     ', 0, 1, N_NODES, F, 4 * F),
     ('dgrad4 dY[N,F] W[F,4F]   ', 0, 0, N_NODES, 4 * F, F),
     ('net3d  d[E3,20] W^T      ', 0, 1, 140000, 20, 20),
+    ('net3d  wgrad [20,20]     ', 1, 0, 20, 20, 140000),
+    ('net3d  wgrad [20,13]     ', 1, 0, 20, 13, 140000),
     ('head   r[512,600] W^T    ', 0, 1, 512, 200, 600),
     ('sim    z1 z2^T           ', 0, 1, 512, 512, 256),
 ]
@@ -101,8 +103,8 @@ if __name__ == '__main__':
         print(f'{name} M={M:6d} N={N:5d} K={K:6d}  auto: {us:8.1f} us {tf:7.1f} TF  err {err:.1e}', flush=True)
         if a.all_cfgs:
             wgrad = bool(ta)
-            for cfg in ((3, 2, 4, 6) if wgrad else (0, 2, 4, 5, 6, 7)):
-                for splits in ((4, 8, 16, 32, 64) if wgrad else (1,)):
+            for cfg in ((3, 2, 8, 1) if wgrad else (0, 2, 4, 5, 6, 7)):
+                for splits in ((8, 16, 32, 64, 128, 256) if wgrad else (1,)):
                     us, tf, err = run(lib, ta, tb, M, N, K, cfg, splits)
                     print(f'      cfg {cfg:2d} splits {splits:2d}: {us:8.1f} us {tf:7.1f} TF  err {err:.1e}', flush=True)
     for cfg, seg in ((-1, 0), (3, 256), (3, 512), (3, 1024), (3, 2048), (2, 512), (2, 1024), (4, 512), (4, 1024), (4, 2048)):
