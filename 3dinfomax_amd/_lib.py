@@ -35,7 +35,8 @@ class FcArgs(ctypes.Structure):
 
 class EdgeFcArgs(ctypes.Structure):
     _fields_ = [('tail', BnTail), ('num_nodes', c_int), ('num_edges', c_int), ('f_h', c_int), ('f_q', c_int),
-                ('f_out', c_int), ('ldw', c_int), ('h', _P), ('q', _P), ('W', _P), ('bias', _P), ('src_s', _P),
+                ('f_out', c_int), ('ldw', c_int), ('q_rows', c_int), ('v_pad', c_int), ('q_code', _P), ('onehot', _P),
+                ('grad_Q', _P), ('h', _P), ('q', _P), ('W', _P), ('bias', _P), ('src_s', _P),
                 ('dst_s', _P), ('in_ptr', _P), ('out_ptr', _P), ('out_epos', _P), ('P', _P), ('Q', _P), ('xact', _P),
                 ('pre_keep', _P), ('y', _P), ('grad_y', _P), ('grad_pre', _P), ('grad_P', _P), ('grad_gamma', _P),
                 ('grad_beta', _P), ('grad_W', _P), ('grad_bias', _P), ('grad_h', _P), ('grad_q', _P)]
@@ -89,7 +90,8 @@ _SIGNATURES = {
     'i3d_act_fwd': (c_int, [_P, c_long, c_int, _P, _P]),
     'i3d_act_bwd': (c_int, [_P, _P, c_long, c_int, _P, _P]),
     'i3d_add_inplace': (c_int, [_P, _P, c_long, _P]),
-    'i3d_edge_combine_fwd': (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    'i3d_edge_combine_fwd': (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    'i3d_edge_codes': (c_int, [_P, _P, c_int, c_int, POINTER(c_int), c_int, _P, _P, _P]),
     'i3d_segment_sum': (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     'i3d_segment_bcast': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P]),
     'i3d_gather_rows': (c_int, [_P, _P, c_int, c_int, _P, _P]),

@@ -67,11 +67,12 @@ extern "C" int i3d_edge_fc_bn_fwd(const I3dEdgeFcArgs* a, void* stream) {
     const int Fh = a->f_h, Fo = a->f_out;
     TRY(i3d_gemm_f32(0, 1, a->num_nodes, Fo, Fh, a->h, Fh, a->W, a->ldw, a->P, 2 * Fo, nullptr, 0, stream));
     TRY(i3d_gemm_f32(0, 1, a->num_nodes, Fo, Fh, a->h, Fh, a->W + Fh, a->ldw, a->P + Fo, 2 * Fo, nullptr, 0, stream));
-    if (a->q != nullptr)
-        TRY(i3d_gemm_f32(0, 1, a->num_edges, Fo, a->f_q, a->q, a->f_q, a->W + 2 * Fh, a->ldw, a->Q, Fo, nullptr, 0, stream));
+    if (a->q != nullptr)     // table mode: Q = table W_q^T has q_rows rows, the combine gathers row q_code[j]
+        TRY(i3d_gemm_f32(0, 1, a->q_rows > 0 ? a->q_rows : a->num_edges, Fo, a->f_q, a->q, a->f_q, a->W + 2 * Fh, a->ldw, a->Q,
+                         Fo, nullptr, 0, stream));
     float* lin = a->pre_keep ? a->pre_keep : a->xact;
-    TRY(i3d_edge_combine_fwd(a->P, 2 * Fo, a->q ? a->Q : nullptr, a->bias, a->src_s, a->dst_s, a->num_edges, Fo, lin,
-                             stream));
+    TRY(i3d_edge_combine_fwd(a->P, 2 * Fo, a->q ? a->Q : nullptr, a->q_rows > 0 ? a->q_code : nullptr, a->bias, a->src_s,
+                             a->dst_s, a->num_edges, Fo, lin, stream));
     return tail_fwd(&a->tail, a->num_edges, Fo, lin, a->xact, nullptr, a->y, stream);
 }
 
@@ -87,7 +88,14 @@ extern "C" int i3d_edge_fc_bn_bwd(const I3dEdgeFcArgs* a, void* stream) {
     TRY(i3d_gemm_f32(1, 0, Fo, Fh, N, a->grad_P + Fo, 2 * Fo, a->h, Fh, a->grad_W + Fh, a->ldw, nullptr, 1, stream));
     TRY(i3d_gemm_f32(0, 0, N, Fh, Fo, a->grad_P, 2 * Fo, a->W, a->ldw, a->grad_h, Fh, nullptr, 0, stream));
     TRY(i3d_gemm_f32(0, 0, N, Fh, Fo, a->grad_P + Fo, 2 * Fo, a->W + Fh, a->ldw, a->grad_h, Fh, nullptr, 1, stream));
-    if (a->q != nullptr) {
+    if (a->q != nullptr && a->q_rows > 0) {
+        // table mode: dQ[v] = sum of dpre over the edges of category v (one-hot^T dpre), then two [V, .] products
+        const int V = a->q_rows;
+        TRY(i3d_gemm_f32(1, 0, a->v_pad, Fo, E, a->onehot, a->v_pad, a->grad_pre, Fo, a->grad_Q, Fo, nullptr, 0, stream));
+        TRY(i3d_gemm_f32(1, 0, Fo, a->f_q, V, a->grad_Q, Fo, a->q, a->f_q, a->grad_W + 2 * Fh, a->ldw, nullptr, 1, stream));
+        if (a->grad_q != nullptr)
+            TRY(i3d_gemm_f32(0, 0, V, a->f_q, Fo, a->grad_Q, Fo, a->W + 2 * Fh, a->ldw, a->grad_q, a->f_q, nullptr, 0, stream));
+    } else if (a->q != nullptr) {
         TRY(i3d_gemm_f32(1, 0, Fo, a->f_q, E, a->grad_pre, Fo, a->q, a->f_q, a->grad_W + 2 * Fh, a->ldw, nullptr, 1, stream));
         if (a->grad_q != nullptr)
             TRY(i3d_gemm_f32(0, 0, E, a->f_q, Fo, a->grad_pre, Fo, a->W + 2 * Fh, a->ldw, a->grad_q, a->f_q, nullptr, 0, stream));

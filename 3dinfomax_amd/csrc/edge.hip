@@ -6,11 +6,11 @@
 
 namespace i3d {
 
-// pre[j,:] = P[src[j], 0:F] + P[dst[j], F:2F] + Q[j,:] + bias
+// pre[j,:] = P[src[j], 0:F] + P[dst[j], F:2F] + Q[q_code ? q_code[j] : j, :] + bias
 // reference models/pna.py:237-252 (cat[src,dst,edge] -> Linear) via  [a|b|c] W^T = a Ws^T + b Wd^T + c Wq^T
 template <int V>
 __global__ void __launch_bounds__(256)
-edge_combine_fwd_kernel(const float* __restrict__ P, int ldp, const float* __restrict__ Q,
+edge_combine_fwd_kernel(const float* __restrict__ P, int ldp, const float* __restrict__ Q, const int* __restrict__ q_code,
                         const float* __restrict__ bias, const int* __restrict__ src, const int* __restrict__ dst,
                         int E, int feat, float* __restrict__ pre) {
     const int FV = feat / V;
@@ -20,10 +20,11 @@ edge_combine_fwd_kernel(const float* __restrict__ P, int ldp, const float* __res
     const float* ps = P + (long)src[j] * ldp + c;
     const float* pd = P + (long)dst[j] * ldp + feat + c;
     float* o = pre + (long)j * feat + c;
+    const long qrow = q_code ? q_code[j] : j;
     if (V == 4) {
         float4 a = *reinterpret_cast<const float4*>(ps);
         float4 b = *reinterpret_cast<const float4*>(pd);
-        float4 d = Q ? *reinterpret_cast<const float4*>(Q + (long)j * feat + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 d = Q ? *reinterpret_cast<const float4*>(Q + qrow * feat + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 r = make_float4(a.x + b.x + d.x, a.y + b.y + d.y, a.z + b.z + d.z, a.w + b.w + d.w);
         if (bias) {
             float4 bb = *reinterpret_cast<const float4*>(bias + c);
@@ -31,10 +32,30 @@ edge_combine_fwd_kernel(const float* __restrict__ P, int ldp, const float* __res
         }
         *reinterpret_cast<float4*>(o) = r;
     } else {
-        float r = ps[0] + pd[0] + (Q ? Q[(long)j * feat + c] : 0.f);
+        float r = ps[0] + pd[0] + (Q ? Q[qrow * feat + c] : 0.f);
         if (bias) r += bias[c];
         o[0] = r;
     }
+}
+
+// Categorical edge features with a small joint vocabulary (bonds: 5 x 6 x 2 = 60 combinations): the embedding sum of an
+// edge is a row of the [V, F] table of all combinations, so  ef W_q^T  is a gather from (table W_q^T) and the
+// gradients reduce over the one-hot matrix.  codes[j] = sum_c idx[row(j), c] * stride[c];  onehot[j, codes[j]] = 1.
+struct CodeStrides { int s[8]; };
+__global__ void __launch_bounds__(256)
+edge_codes_kernel(const long* __restrict__ idx, const int* __restrict__ row_perm, int rows, int n_cols, CodeStrides st,
+                  int v_pad, int* __restrict__ codes, float* __restrict__ onehot) {
+    const int VQ = v_pad / 4;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)rows * VQ) return;
+    const int j = (int)(t / VQ), q = (int)(t - (long)j * VQ);
+    const long row = row_perm ? row_perm[j] : j;
+    int code = 0;
+    for (int c = 0; c < n_cols; ++c) code += (int)idx[row * n_cols + c] * st.s[c];
+    if (q == 0) codes[j] = code;
+    const int c0 = q * 4;
+    *reinterpret_cast<float4*>(onehot + (long)j * v_pad + c0) =
+        make_float4(code == c0 ? 1.f : 0.f, code == c0 + 1 ? 1.f : 0.f, code == c0 + 2 ? 1.f : 0.f, code == c0 + 3 ? 1.f : 0.f);
 }
 
 // out[v, :] = scale * sum_{j in [ptr[v], ptr[v+1])} x[idx ? idx[j] : j, :]
@@ -169,18 +190,19 @@ using namespace i3d;
         }                                                                                                   \
     } while (0)
 
-extern "C" int i3d_edge_combine_fwd(const float* P, int ldp, const float* Q, const float* bias, const int* src_s,
-                                    const int* dst_s, int num_edges, int feat, float* pre, void* stream) {
+extern "C" int i3d_edge_combine_fwd(const float* P, int ldp, const float* Q, const int* q_code, const float* bias,
+                                    const int* src_s, const int* dst_s, int num_edges, int feat, float* pre,
+                                    void* stream) {
     I3D_CHECK_ARG(num_edges >= 0 && feat > 0 && ldp >= 2 * feat, "bad shape");
     if (num_edges == 0) return I3D_OK;
     if (feat % 4 == 0 && ldp % 4 == 0) {
         long items = (long)num_edges * (feat / 4);
         hipLaunchKernelGGL(edge_combine_fwd_kernel<4>, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, P, ldp, Q,
-                           bias, src_s, dst_s, num_edges, feat, pre);
+                           q_code, bias, src_s, dst_s, num_edges, feat, pre);
     } else {
         long items = (long)num_edges * feat;
         hipLaunchKernelGGL(edge_combine_fwd_kernel<1>, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, P, ldp, Q,
-                           bias, src_s, dst_s, num_edges, feat, pre);
+                           q_code, bias, src_s, dst_s, num_edges, feat, pre);
     }
     I3D_CHECK_LAUNCH();
     return I3D_OK;
@@ -199,6 +221,19 @@ extern "C" int i3d_segment_sum(const float* x, int ldx, const int* ptr, const in
         hipLaunchKernelGGL(segment_sum_kernel<1>, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, ptr,
                            idx, num_segments, feat, scale_mode, out, ldo);
     }
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_edge_codes(const int64_t* idx, const int* row_perm, int rows, int n_cols, const int* strides, int v_pad,
+                              int* codes, float* onehot, void* stream) {
+    I3D_CHECK_ARG(rows >= 0 && n_cols >= 1 && n_cols <= 8 && v_pad > 0 && v_pad % 4 == 0, "bad shape");
+    if (rows == 0) return I3D_OK;
+    CodeStrides st;
+    for (int c = 0; c < 8; ++c) st.s[c] = c < n_cols ? strides[c] : 0;
+    long items = (long)rows * (v_pad / 4);
+    hipLaunchKernelGGL(edge_codes_kernel, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, (const long*)idx, row_perm,
+                       rows, n_cols, st, v_pad, codes, onehot);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }

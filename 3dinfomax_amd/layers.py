@@ -361,6 +361,16 @@ class GroupedConcat2FCFn(torch.autograd.Function):
         return gh, ga, gW, gbias, gg, gb, grad_res, None, None, None
 
 
+class EdgeTable:
+    """Categorical edge features with a small joint vocabulary (ops.edge_codes): the edge operand q of EdgeFCFn is then
+    the [V, F] table of all combinations, `codes` [E] (destination-sorted order) names the row of every edge and
+    `onehot` [E, v_pad] drives the gradient reductions."""
+    __slots__ = ('codes', 'onehot', 'rows', 'v_pad')
+
+    def __init__(self, codes, onehot, rows, v_pad):
+        self.codes, self.onehot, self.rows, self.v_pad = codes, onehot, rows, v_pad
+
+
 class EdgeFCFn(torch.autograd.Function):
     """First FC layer of an edge MLP on [h_src | h_dst | q] (q optional) without the gather/concat:
         P = h [W_s | W_d]^T  (node level),  Q = q W_q^T,  pre[j] = P[src_j, :F] + P[dst_j, F:] + Q[j] + b
@@ -368,18 +378,20 @@ class EdgeFCFn(torch.autograd.Function):
     Edge tensors are in destination-sorted order; backward of the gathers = segmented sums (no atomics)."""
 
     @staticmethod
-    def forward(ctx, h, q, W, b, gamma, beta, index, spec: FCSpec):
+    def forward(ctx, h, q, W, b, gamma, beta, index, spec: FCSpec, qmap: EdgeTable = None):
         h = h.contiguous()
         Fh = h.shape[1]
         Fo = W.shape[0]
         N = h.shape[0]
         ctx.cargs = None
+        ctx.qmap = qmap
         if q is not None:
             q = q.contiguous()
+            assert qmap is None or q.shape[0] == qmap.rows
         if _composite_ok(spec, h, q, W) and W.is_contiguous() and index.num_edges > 0:
             E, dev = index.num_edges, h.device
             P = _f32((N, 2 * Fo), dev)
-            Q = _f32((E, Fo), dev) if q is not None else None
+            Q = _f32((qmap.rows if qmap is not None else E, Fo), dev) if q is not None else None
             xact, y = _f32((E, Fo), dev), _f32((E, Fo), dev)
             pre_keep = _f32((E, Fo), dev) if _keeps_pre(spec) else None
             mean, invstd = _f32((Fo,), dev), _f32((Fo,), dev)
@@ -387,6 +399,8 @@ class EdgeFCFn(torch.autograd.Function):
             _fill_tail(a.tail, spec, gamma, beta, mean, invstd, Fo, dev)
             a.num_nodes, a.num_edges, a.f_h, a.f_q, a.f_out, a.ldw = N, E, Fh, (q.shape[1] if q is not None else 0), Fo, W.stride(0)
             a.h, a.q, a.W, a.bias = h.data_ptr(), _ptr(q), W.data_ptr(), _ptr(b)
+            if qmap is not None and q is not None:
+                a.q_rows, a.v_pad, a.q_code, a.onehot = qmap.rows, qmap.v_pad, qmap.codes.data_ptr(), qmap.onehot.data_ptr()
             a.src_s, a.dst_s, a.in_ptr = index.src_s.data_ptr(), index.dst_s.data_ptr(), index.in_ptr.data_ptr()
             a.out_ptr, a.out_epos = index.out_ptr.data_ptr(), index.out_epos.data_ptr()
             a.P, a.Q, a.xact, a.pre_keep, a.y = P.data_ptr(), _ptr(Q), xact.data_ptr(), _ptr(pre_keep), y.data_ptr()
@@ -402,7 +416,8 @@ class EdgeFCFn(torch.autograd.Function):
         Q = None
         if q is not None:
             Q = ops.gemm(q, W[:, 2 * Fh:], trans_b=True)
-        pre = ops.edge_combine_fwd(P, Q, b, index.src_s, index.dst_s)
+        pre = ops.edge_combine_fwd(P, Q, b, index.src_s, index.dst_s,
+                                   q_code=qmap.codes if (qmap is not None and q is not None) else None)
         y, saved = _Tail.forward(pre, gamma, beta, spec)
         ctx.spec, ctx.saved, ctx.index, ctx.has_q = spec, saved, index, q is not None
         ctx.save_for_backward(h, q if q is not None else h, W, gamma, beta)
@@ -420,31 +435,38 @@ class EdgeFCFn(torch.autograd.Function):
             gg, gb, gbias = _f32((Fo,), dev), _f32((Fo,), dev), _f32((Fo,), dev)
             gW, gh = torch.empty_like(W), torch.empty_like(h)
             gq = torch.empty_like(q) if (ctx.has_q and ctx.needs_input_grad[1]) else None
+            if ctx.has_q and ctx.qmap is not None:
+                gQ = _f32((ctx.qmap.v_pad, Fo), dev)
+                a.grad_Q = gQ.data_ptr()
             a.tail.workspace = ops._workspace(Fo, dev).data_ptr()
             a.grad_y, a.grad_pre, a.grad_P = grad_y.data_ptr(), grad_pre.data_ptr(), gP.data_ptr()
             a.grad_gamma, a.grad_beta, a.grad_W, a.grad_bias = gg.data_ptr(), gb.data_ptr(), gW.data_ptr(), gbias.data_ptr()
             a.grad_h, a.grad_q = gh.data_ptr(), _ptr(gq)
             _call('i3d_edge_fc_bn_bwd', a)
-            return gh, gq, gW, gbias, gg, gb, None, None
+            return gh, gq, gW, gbias, gg, gb, None, None, None
         grad_pre, gg, gb = _Tail.backward(ctx.saved, grad_y.contiguous(), gamma, beta, ctx.spec)
         gW = torch.empty_like(W)
         gP = torch.empty(N, 2 * Fo, dtype=torch.float32, device=h.device)
         ops.segment_sum(grad_pre, idx.out_ptr, idx.out_epos, N, out=gP[:, :Fo])     # d P[src]
         ops.segment_sum(grad_pre, idx.in_ptr, None, N, out=gP[:, Fo:])              # d P[dst]
         gbias = torch.empty(Fo, dtype=W.dtype, device=W.device)
+        qmap = ctx.qmap if ctx.has_q else None
+        gQ = None
+        if qmap is not None:      # dQ[v] = sum of dpre over the edges of category v
+            gQ = ops.gemm(qmap.onehot, grad_pre, trans_a=True)[:qmap.rows]
         with fork(gP, h, grad_pre, q if ctx.has_q else None) as f:
             if ctx.has_q:
-                ops.gemm(grad_pre, q, trans_a=True, out=gW[:, 2 * Fh:])
+                ops.gemm(gQ if qmap is not None else grad_pre, q, trans_a=True, out=gW[:, 2 * Fh:])
             ops.gemm(gP[:, :Fo], h, trans_a=True, out=gW[:, :Fh])
             ops.gemm(gP[:, Fo:], h, trans_a=True, out=gW[:, Fh:2 * Fh])
             ops.colsum(grad_pre, out=gbias)
         gq = None
         if ctx.has_q and ctx.needs_input_grad[1]:
-            gq = ops.gemm(grad_pre, W[:, 2 * Fh:])
+            gq = ops.gemm(gQ if qmap is not None else grad_pre, W[:, 2 * Fh:])
         gh = ops.gemm(gP[:, :Fo], W[:, :Fh])
         ops.gemm(gP[:, Fo:], W[:, Fh:2 * Fh], out=gh, accumulate=True)
         f.join()
-        return gh, gq, gW, gbias, gg, gb, None, None
+        return gh, gq, gW, gbias, gg, gb, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -524,10 +546,10 @@ class MLP(nn.Module):
         return x
 
     # first layer fed by a fused input operator (edge gather / two-segment concat), rest plain
-    def forward_edge(self, h, q, index, residual=None):
+    def forward_edge(self, h, q, index, residual=None, qmap=None):
         fc0 = self.fully_connected[0]
         gamma, beta = fc0.bn_affine()
-        x = EdgeFCFn.apply(h, q, fc0.linear.weight, fc0.linear.bias, gamma, beta, index, fc0.spec())
+        x = EdgeFCFn.apply(h, q, fc0.linear.weight, fc0.linear.bias, gamma, beta, index, fc0.spec(), qmap)
         for fc in list(self.fully_connected)[1:]:
             x = fc(x)
         return x

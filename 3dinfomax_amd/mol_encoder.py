@@ -32,6 +32,10 @@ class _Encoder(torch.nn.Module):
             lst.append(emb)
         return lst
 
+    @property
+    def dims(self):
+        return [emb.num_embeddings for emb in getattr(self, self._list_name)]
+
     def _tables(self):
         return [emb.weight for emb in getattr(self, self._list_name)]
 

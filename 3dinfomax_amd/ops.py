@@ -266,13 +266,29 @@ def add_inplace(dst, src):
 
 
 # ---- edge kernels ----------------------------------------------------------------------------------------
-def edge_combine_fwd(P, Q, bias, src_s, dst_s):
+def edge_combine_fwd(P, Q, bias, src_s, dst_s, q_code=None):
     _chk(P)
     E, feat = src_s.shape[0], P.shape[1] // 2
     pre = torch.empty(E, feat, dtype=torch.float32, device=P.device)
-    check(_lib.load().i3d_edge_combine_fwd(_p(P), P.shape[1], _p(Q), _p(bias), _p(src_s), _p(dst_s), E, feat, _p(pre),
-                                           _stream()), 'i3d_edge_combine_fwd')
+    check(_lib.load().i3d_edge_combine_fwd(_p(P), P.shape[1], _p(Q), _p(q_code), _p(bias), _p(src_s), _p(dst_s), E, feat,
+                                           _p(pre), _stream()), 'i3d_edge_combine_fwd')
     return pre
+
+
+def edge_codes(idx, row_perm, dims, v_pad):
+    """codes[j] = joint category of row (row_perm[j] if given else j) of idx [rows, C]; onehot [rows, v_pad]."""
+    _chk(idx, torch.int64)
+    rows, n_cols = idx.shape
+    strides, s = [], 1
+    for d in dims:
+        strides.append(s)
+        s *= d
+    assert s <= v_pad and v_pad % 4 == 0 and len(dims) == n_cols
+    codes = torch.empty(rows, dtype=torch.int32, device=idx.device)
+    onehot = torch.empty(rows, v_pad, dtype=torch.float32, device=idx.device)
+    check(_lib.load().i3d_edge_codes(_p(idx), _p(row_perm), rows, n_cols, int_array(strides), v_pad, _p(codes), _p(onehot),
+                                     _stream()), 'i3d_edge_codes')
+    return codes, onehot
 
 
 def segment_sum(x, ptr, idx, num_segments, mean=False, out=None):

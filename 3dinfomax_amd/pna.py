@@ -21,7 +21,7 @@ from torch import nn
 
 from . import ops
 from .graph import as_batched_graph
-from .layers import MLP, AggregateFn, ReadoutFn, bn_counter_scope
+from .layers import MLP, AggregateFn, EdgeTable, ReadoutFn, bn_counter_scope
 from .mol_encoder import AtomEncoder, BondEncoder
 
 EPS = 1e-5
@@ -33,6 +33,8 @@ PNA_SCALERS = {k: v for k, v in ops.SCALER.items()}
 
 # I3D_GROUPED_POSTTRANS=0 selects the reference-shaped path ([N,12F] aggregate + K=13F posttrans GEMM)
 GROUPED_POSTTRANS = os.environ.get('I3D_GROUPED_POSTTRANS', '1') != '0'
+# I3D_EDGE_TABLE=0 materialises the [E, F] bond embeddings and multiplies them by W_q in every layer (reference shape)
+EDGE_TABLE = os.environ.get('I3D_EDGE_TABLE', '1') != '0'
 
 
 def _scaler_coef(scaler_code, D, avg):
@@ -111,12 +113,42 @@ class PNAGNN(nn.Module):
         g = as_batched_graph(graph)
         idx = g.index()
         g.ndata['feat'] = self.atom_encoder(g.ndata['feat'])
+        bond_idx = g.edata['feat']
+        dims = self.bond_encoder.dims
+        n_comb = 1
+        for d in dims:
+            n_comb *= d
+        if EDGE_TABLE and n_comb <= 256 and idx.num_edges > 0 and bond_idx.dtype == torch.int64:
+            # the bond embedding takes n_comb (60) distinct values: every layer's  e_feat W_q^T  is a gather from the
+            # [n_comb, F] table of all combinations times W_q^T (layers.EdgeTable) instead of an [E, F] x [F, F] product
+            v_pad = (n_comb + 31) // 32 * 32
+            table = self.bond_encoder(self._combinations(dims, bond_idx.device))
+            codes, onehot = ops.edge_codes(bond_idx.contiguous(), idx.perm, dims, v_pad)
+            qmap = EdgeTable(codes, onehot, n_comb, v_pad)
+            for mp_layer in self.mp_layers:
+                mp_layer(g, ef_sorted=table, qmap=qmap)
+            with torch.no_grad():   # reference side effect (models/pna.py:163): float bond embedding, edge-id order
+                g.edata['feat'] = self.bond_encoder(bond_idx)
+            return
         # bond embeddings are produced directly in destination-sorted (kernel) order
-        ef_sorted = self.bond_encoder(g.edata['feat'], perm=idx.perm)
+        ef_sorted = self.bond_encoder(bond_idx, perm=idx.perm)
         for mp_layer in self.mp_layers:
             mp_layer(g, ef_sorted=ef_sorted)
         # reference side effect (models/pna.py:163): edata['feat'] becomes the float bond embedding, edge-id order
         g.edata['feat'] = ops.gather_rows(ef_sorted.detach(), idx.inv_perm)
+
+    def _combinations(self, dims, device):
+        """[prod(dims), C] int64: row v holds the categories with joint code v (first column fastest, ops.edge_codes)."""
+        key = (tuple(dims), str(device))
+        cache = self.__dict__.setdefault('_comb_cache', {})
+        if key not in cache:
+            v = torch.arange(int(torch.tensor(dims).prod()), dtype=torch.int64)
+            cols, stride = [], 1
+            for d in dims:
+                cols.append((v // stride) % d)
+                stride *= d
+            cache[key] = torch.stack(cols, 1).contiguous().to(device)
+        return cache[key]
 
 
 class PNALayer(nn.Module):
@@ -148,14 +180,15 @@ class PNALayer(nn.Module):
                              last_activation=last_activation, dropout=dropout, mid_batch_norm=mid_batch_norm,
                              last_batch_norm=last_batch_norm, batch_norm_momentum=batch_norm_momentum)
 
-    def forward(self, g, ef_sorted=None):
+    def forward(self, g, ef_sorted=None, qmap=None):
         g = as_batched_graph(g)
         idx = g.index()
         h = g.ndata['feat']
         if ef_sorted is None and self.edge_features:
             ef_sorted = _GatherRowsFn.apply(g.edata['feat'], idx.perm, idx.inv_perm)
         # pretransformation (edge MLP on [h_src | h_dst | e_feat]) -> messages, destination-sorted
-        e = self.pretrans.forward_edge(h, ef_sorted if self.edge_features else None, idx)
+        e = self.pretrans.forward_edge(h, ef_sorted if self.edge_features else None, idx,
+                                       qmap=qmap if self.edge_features else None)
         avg = float(self.avg_d["log"])
         if GROUPED_POSTTRANS and len(self.scalers) > 1 and h.shape[1] % 4 == 0:
             # the scaler blocks are per-node multiples of the aggregator block that depend on the in-degree only:

@@ -190,13 +190,21 @@ int i3d_add_inplace(float* dst, const float* src, long n, void* stream);
  * i3d_edge_combine_fwd replaces the gather + concat + first Linear of the edge MLPs,
  *   reference models/pna.py:237-252 (pretrans_edges: cat[h_src, h_dst, e_feat] -> Linear) and
  *   models/net3d.py:113-115, using  [h_s|h_d|q] W^T = h_s W_s^T + h_d W_d^T + q W_q^T :
- *   pre[j,:] = P[src_s[j], 0:feat] + P[dst_s[j], feat:2feat] + Q[j,:] + bias   (P is [N, ldp >= 2*feat]; Q, bias may be NULL)
+ *   pre[j,:] = P[src_s[j], 0:feat] + P[dst_s[j], feat:2feat] + Q[q_code ? q_code[j] : j,:] + bias
+ *   (P is [N, ldp >= 2*feat]; Q, q_code, bias may be NULL)
+ * i3d_edge_codes: categorical edge features with a small joint vocabulary V (bonds, commons/mol_encoder.py:45-73:
+ *   5 x 6 x 2 = 60): codes[j] = sum_c idx[row_perm ? row_perm[j] : j, c] * strides[c] (host array), and the one-hot
+ *   matrix onehot[rows, v_pad] (v_pad >= V, multiple of 4).  The bond embedding of an edge is then row codes[j] of the
+ *   [V, F] table of all combinations, so the per-layer  e_feat W_q^T  is a gather from (table W_q^T) (q_code above)
+ *   and its gradients are  onehot^T dpre  ([V, F] instead of two [E, F] x [F, F] products).
  * i3d_segment_sum: out[v,:] = scale(v) * sum_{j in [ptr[v],ptr[v+1])} x[idx ? idx[j] : j, :]
  *   scale_mode 0: 1;  1: 1/max(count,1)  (DGL fn.mean, reference models/net3d.py:95-96)
  *   used for the backward of the gathers (by in_ptr, and by out_ptr/out_epos) and for Net3D's mean reduce.
  * i3d_segment_bcast: grad of segment mean/sum: out[j,:] = scale(seg(j)) * g[seg(j),:], seg given by dst_s. */
-int i3d_edge_combine_fwd(const float* P, int ldp, const float* Q, const float* bias, const int* src_s,
-                         const int* dst_s, int num_edges, int feat, float* pre, void* stream);
+int i3d_edge_combine_fwd(const float* P, int ldp, const float* Q, const int* q_code, const float* bias,
+                         const int* src_s, const int* dst_s, int num_edges, int feat, float* pre, void* stream);
+int i3d_edge_codes(const int64_t* idx, const int* row_perm, int rows, int n_cols, const int* strides, int v_pad,
+                   int* codes, float* onehot, void* stream);
 int i3d_segment_sum(const float* x, int ldx, const int* ptr, const int* idx, int num_segments, int feat,
                     int scale_mode, float* out, int ldo, void* stream);
 int i3d_segment_bcast(const float* g, const int* ptr, const int* seg_of_row, int rows, int feat, int scale_mode,
@@ -276,6 +284,11 @@ typedef struct { /* y = tail(x W^T + b) */
 typedef struct { /* y = tail(P[src,:F] + P[dst,F:] + q W_q^T + b),  P = h [W_s|W_d]^T  (reference models/pna.py:237-252) */
     I3dBnTail tail;
     int num_nodes, num_edges, f_h, f_q, f_out, ldw;
+    int q_rows;  /* 0: q is [E, f_q];  V > 0: q is the [V, f_q] table of all categorical combinations (i3d_edge_codes) */
+    int v_pad;   /* leading dimension of onehot */
+    const int* q_code;   /* [E] row of q for every edge (table mode) */
+    const float* onehot; /* [E, v_pad] */
+    float* grad_Q;       /* scratch [v_pad, f_out] (table mode) */
     const float* h;
     const float* q;
     const float* W;
@@ -286,7 +299,7 @@ typedef struct { /* y = tail(P[src,:F] + P[dst,F:] + q W_q^T + b),  P = h [W_s|W
     const int* out_ptr;
     const int* out_epos;
     float* P; /* [N, 2*f_out] scratch */
-    float* Q; /* [E, f_out] scratch (NULL when q is NULL) */
+    float* Q; /* [E, f_out] ([V, f_out] in table mode) scratch (NULL when q is NULL) */
     float* xact;
     float* pre_keep;
     float* y;

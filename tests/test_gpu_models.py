@@ -183,6 +183,33 @@ def test_batch64_vs_oracle_fwd_bwd(amd):
     grads_close(param_grads(net), {k: P3[k].grad for k in O.trainable(P3)}, 1e-3, 'net3d ')
 
 
+@pytest.mark.parametrize('composite', [True, False])
+def test_bond_table_path_matches_dense_bond_embeddings(amd, composite, monkeypatch):
+    """The [60, F] table of all bond-category combinations + per-edge codes (default) against materialised [E, F] bond
+    embeddings multiplied by W_q in every layer (I3D_EDGE_TABLE=0): same outputs, side effects and gradients."""
+    pna_mod = importlib.import_module('3dinfomax_amd.pna')
+    layers_mod = importlib.import_module('3dinfomax_amd.layers')
+    if not composite:
+        monkeypatch.setattr(layers_mod, '_composite_ok', lambda *a, **k: False)
+    mols = synth.make_dataset(48, seed=11)
+    kw2 = dict(PNA_YML, propagation_depth=2)
+    pna = amd.PNA(avg_d=1.0, device='cuda:0', **kw2)
+    _det_load(pna, 'pnaT')
+    pna.cuda().train()
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(pna_mod, 'EDGE_TABLE', mode)
+        pna.zero_grad()
+        g2, _ = make_batch(amd, mols)
+        z = pna(g2)
+        (z * z).sum().backward()
+        res[mode] = (z.detach().cpu(), g2.ndata['feat'].detach().cpu(), g2.edata['feat'].detach().cpu(),
+                     {k: v.cpu() for k, v in param_grads(pna).items()})
+    for i in range(3):
+        assert rel_err(res[True][i], res[False][i]) < 1e-5, i
+    grads_close(res[True][3], res[False][3], 1e-4, 'pna ')
+
+
 SMOOTH = dict(aggregators=['mean', 'sum', 'std', 'var'], readout_aggregators=['mean', 'sum'])
 
 
