@@ -46,7 +46,9 @@ struct Stats4 {
     float4 sum, sq, mx, mn;
 };
 
-template <bool STD>
+// MODE 0: any aggregator/scaler list   1: (mean,max,min,std) x (identity,amplification,attenuation), 12 blocks
+//      2: (mean,max,min,std) x identity, 4 blocks (degree-grouped posttrans: the scalers live in the combined weights)
+template <int MODE>
 __global__ void __launch_bounds__(256)
 pna_aggregate_fwd_kernel(const float4* __restrict__ e, const int* __restrict__ in_ptr, int N, int FV,
                          AggCfg cfg, float4* __restrict__ out) {
@@ -62,16 +64,28 @@ pna_aggregate_fwd_kernel(const float4* __restrict__ e, const int* __restrict__ i
         return;
     }
     const float4* p = e + (long)beg * FV + c;
-    float4 x = *p;
+    // molecules: D <= 4 almost always.  The first four message rows are loaded unconditionally (clamped index, the
+    // duplicates hit L1) so four loads are in flight instead of a dependent load-accumulate chain; the accumulation
+    // order stays j = 0 .. D-1.
+    float4 x = p[0];
+    const float4 x1 = p[(long)min(1, D - 1) * FV], x2 = p[(long)min(2, D - 1) * FV], x3 = p[(long)min(3, D - 1) * FV];
     float4 sum = x, mx = x, mn = x;
     float4 sq = make_float4(x.x * x.x, x.y * x.y, x.z * x.z, x.w * x.w);
-    for (int j = 1; j < D; ++j) {
+#define I3D_AGG_ACC(X)                                                                                              \
+    do {                                                                                                            \
+        sum.x += (X).x; sum.y += (X).y; sum.z += (X).z; sum.w += (X).w;                                             \
+        sq.x += (X).x * (X).x; sq.y += (X).y * (X).y; sq.z += (X).z * (X).z; sq.w += (X).w * (X).w;                 \
+        mx.x = fmaxf(mx.x, (X).x); mx.y = fmaxf(mx.y, (X).y); mx.z = fmaxf(mx.z, (X).z); mx.w = fmaxf(mx.w, (X).w); \
+        mn.x = fminf(mn.x, (X).x); mn.y = fminf(mn.y, (X).y); mn.z = fminf(mn.z, (X).z); mn.w = fminf(mn.w, (X).w); \
+    } while (0)
+    if (D > 1) I3D_AGG_ACC(x1);
+    if (D > 2) I3D_AGG_ACC(x2);
+    if (D > 3) I3D_AGG_ACC(x3);
+    for (int j = 4; j < D; ++j) {
         x = p[(long)j * FV];
-        sum.x += x.x; sum.y += x.y; sum.z += x.z; sum.w += x.w;
-        sq.x += x.x * x.x; sq.y += x.y * x.y; sq.z += x.z * x.z; sq.w += x.w * x.w;
-        mx.x = fmaxf(mx.x, x.x); mx.y = fmaxf(mx.y, x.y); mx.z = fmaxf(mx.z, x.z); mx.w = fmaxf(mx.w, x.w);
-        mn.x = fminf(mn.x, x.x); mn.y = fminf(mn.y, x.y); mn.z = fminf(mn.z, x.z); mn.w = fminf(mn.w, x.w);
+        I3D_AGG_ACC(x);
     }
+#undef I3D_AGG_ACC
     const float fD = (float)D;
     float4 mean = make_float4(sum.x / fD, sum.y / fD, sum.z / fD, sum.w / fD);
     float4 msq = make_float4(sq.x / fD, sq.y / fD, sq.z / fD, sq.w / fD);
@@ -79,7 +93,12 @@ pna_aggregate_fwd_kernel(const float4* __restrict__ e, const int* __restrict__ i
                              fmaxf(msq.z - mean.z * mean.z, 0.f), fmaxf(msq.w - mean.w * mean.w, 0.f));
     float amp, att;
     scaler_values(cfg, D, amp, att);
-    if (STD) {  // (mean,max,min,std) x (identity,amplification,attenuation): fully unrolled
+    if (MODE == 2) {
+        o[0] = mean;
+        o[(long)FV] = mx;
+        o[(long)2 * FV] = mn;
+        o[(long)3 * FV] = make_float4(sqrtf(var.x + 1e-5f), sqrtf(var.y + 1e-5f), sqrtf(var.z + 1e-5f), sqrtf(var.w + 1e-5f));
+    } else if (MODE == 1) {  // fully unrolled
         float4 sd = make_float4(sqrtf(var.x + 1e-5f), sqrtf(var.y + 1e-5f), sqrtf(var.z + 1e-5f), sqrtf(var.w + 1e-5f));
         float4 a[4] = {mean, mx, mn, sd};
 #pragma unroll
@@ -217,7 +236,33 @@ pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict
     int amax[V], amin[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) { sum[i] = 0.f; sq[i] = 0.f; mx[i] = -INFINITY; mn[i] = INFINITY; amax[i] = 0; amin[i] = 0; }
-    for (int j = 0; j < D; ++j) {
+    // the first four message rows (D <= 4 for almost every atom) are loaded up front - four loads in flight - and
+    // stay in registers for pass 2; accumulation order j = 0 .. D-1 as in the forward kernel
+    float xr[4][V];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const long row = min(jj, D - 1);
+        if (V == 4) {
+            float4 xx = *reinterpret_cast<const float4*>(p + row * F);
+            xr[jj][0] = xx.x; xr[jj][1 % V] = xx.y; xr[jj][2 % V] = xx.z; xr[jj][3 % V] = xx.w;
+        } else {
+            xr[jj][0] = p[row * F];
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        if (jj < D) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float xv = xr[jj][i];
+                sum[i] += xv;
+                sq[i] += xv * xv;
+                if (xv > mx[i]) { mx[i] = xv; amax[i] = jj; }
+                if (xv < mn[i]) { mn[i] = xv; amin[i] = jj; }
+            }
+        }
+    }
+    for (int j = 4; j < D; ++j) {
         float x[V];
         if (V == 4) {
             float4 xx = *reinterpret_cast<const float4*>(p + (long)j * F);
@@ -245,8 +290,22 @@ pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict
         kvar[i] = pos ? g_var[i] * 2.f / fD : 0.f;           // d var / d x_j = 2 (x_j - mean) / D
         g_mean[i] = g_mean[i] / fD + g_sum[i];
     }
-    // pass 2: write gradients (rows come from L1/L2)
-    for (int j = 0; j < D; ++j) {
+    // pass 2: write gradients (rows 0..3 from registers, the rest from L1/L2)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        if (jj < D) {
+            float r[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                r[i] = g_mean[i] + (kstd[i] + kvar[i]) * (xr[jj][i] - mean[i]);
+                if (jj == amax[i]) r[i] += g_max[i];
+                if (jj == amin[i]) r[i] += g_min[i];
+            }
+            if (V == 4) *reinterpret_cast<float4*>(q + (long)jj * F) = make_float4(r[0], r[1 % V], r[2 % V], r[3 % V]);
+            else q[(long)jj * F] = r[0];
+        }
+    }
+    for (int j = 4; j < D; ++j) {
         float x[V], r[V];
         if (V == 4) {
             float4 xx = *reinterpret_cast<const float4*>(p + (long)j * F);
@@ -298,10 +357,18 @@ static int make_cfg(const int* aggregators, int n_agg, const int* scalers, int n
     return 0;
 }
 
+static bool is_std_aggs(const AggCfg& c) {
+    return c.n_agg == 4 && c.agg[0] == I3D_AGG_MEAN && c.agg[1] == I3D_AGG_MAX && c.agg[2] == I3D_AGG_MIN &&
+           c.agg[3] == I3D_AGG_STD;
+}
+
 static bool is_std_cfg(const AggCfg& c) {
-    return c.n_agg == 4 && c.n_scaler == 3 && c.agg[0] == I3D_AGG_MEAN && c.agg[1] == I3D_AGG_MAX &&
-           c.agg[2] == I3D_AGG_MIN && c.agg[3] == I3D_AGG_STD && c.scaler[0] == I3D_SCALE_IDENTITY &&
+    return is_std_aggs(c) && c.n_scaler == 3 && c.scaler[0] == I3D_SCALE_IDENTITY &&
            c.scaler[1] == I3D_SCALE_AMPLIFICATION && c.scaler[2] == I3D_SCALE_ATTENUATION;
+}
+
+static bool is_ident_cfg(const AggCfg& c) {
+    return is_std_aggs(c) && c.n_scaler == 1 && c.scaler[0] == I3D_SCALE_IDENTITY;
 }
 
 }  // namespace i3d
@@ -322,10 +389,13 @@ extern "C" int i3d_pna_aggregate_fwd(const float* e, const int* in_ptr, int num_
         long items = (long)num_nodes * FV;
         dim3 grid(cdiv(items, 256));
         if (is_std_cfg(cfg))
-            hipLaunchKernelGGL(pna_aggregate_fwd_kernel<true>, grid, dim3(256), 0, s, (const float4*)e, in_ptr,
+            hipLaunchKernelGGL(pna_aggregate_fwd_kernel<1>, grid, dim3(256), 0, s, (const float4*)e, in_ptr,
+                               num_nodes, FV, cfg, (float4*)out);
+        else if (is_ident_cfg(cfg))
+            hipLaunchKernelGGL(pna_aggregate_fwd_kernel<2>, grid, dim3(256), 0, s, (const float4*)e, in_ptr,
                                num_nodes, FV, cfg, (float4*)out);
         else
-            hipLaunchKernelGGL(pna_aggregate_fwd_kernel<false>, grid, dim3(256), 0, s, (const float4*)e, in_ptr,
+            hipLaunchKernelGGL(pna_aggregate_fwd_kernel<0>, grid, dim3(256), 0, s, (const float4*)e, in_ptr,
                                num_nodes, FV, cfg, (float4*)out);
     } else {
         long items = (long)num_nodes * feat;

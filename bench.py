@@ -190,37 +190,51 @@ def main():
         # ~3-4 us an event pair adds around a single 16 us launch (this is the figure rocprofv3's per-kernel
         # average agrees with, profiles/r01_step_kernel_trace_*.txt)
         aggs, scalers = ops.agg_codes(PNA_KW['aggregators']), ops.scaler_codes(PNA_KW['scalers'])
-        reps, b2b_ms, b2b_bytes = 20, 0.0, 0.0
-        for g2, _, _ in batches:
-            idx = g2.index()
-            e = torch.randn(idx.num_edges, PNA_KW['hidden_dim'], device=dev)
-            ops.pna_aggregate_fwd(e, idx.in_ptr, idx.num_nodes, aggs, scalers)
-            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t0.record()
-            for _ in range(reps):
-                ops.pna_aggregate_fwd(e, idx.in_ptr, idx.num_nodes, aggs, scalers)
-            t1.record()
-            torch.cuda.synchronize()
-            b2b_ms += t0.elapsed_time(t1)
-            b2b_bytes += reps * (4.0 * idx.num_edges * 200 + 4.0 * idx.num_nodes * 2400 + 4.0 * (idx.num_nodes + 1))
-        b2b = b2b_bytes / (b2b_ms * 1e-3) / 1e9
+        blocks = int(round(ev[0][5] / ev[0][4]))      # output blocks of the kernel the step launches: 4 (identity block,
+        #                                               degree-grouped posttrans) or 12 (reference-shaped [N, 12F])
+        F = PNA_KW['hidden_dim']
+
+        def back_to_back(n_blocks, reps=20):
+            sc = scalers if n_blocks == 12 else scalers[:1]
+            tot_ms, tot_bytes = 0.0, 0.0
+            for g2, _, _ in batches:
+                idx = g2.index()
+                e = torch.randn(idx.num_edges, F, device=dev)
+                ops.pna_aggregate_fwd(e, idx.in_ptr, idx.num_nodes, aggs, sc)
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record()
+                for _ in range(reps):
+                    ops.pna_aggregate_fwd(e, idx.in_ptr, idx.num_nodes, aggs, sc)
+                t1.record()
+                torch.cuda.synchronize()
+                tot_ms += t0.elapsed_time(t1)
+                tot_bytes += reps * (4.0 * idx.num_edges * F + 4.0 * idx.num_nodes * n_blocks * F + 4.0 * (idx.num_nodes + 1))
+            return tot_bytes / (tot_ms * 1e-3) / 1e9, tot_ms * 1e3 / (reps * len(batches))
+
+        b2b, b2b_us = back_to_back(blocks)
+        b2b12, b2b12_us = back_to_back(12)
         # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured with
-        # rocprofv3 on this kernel and batch shape: profiles/r01_k4_pmc.txt -> traffic / algorithmic = 1.020
+        # rocprofv3 on this kernel variant and batch shape (tools/k4_pmc_summary.py -> profiles/r01_k4_pmc_v2.txt)
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_k4_pmc.json')
+        pmc = os.path.join(ROOT, 'profiles', 'r01_k4_pmc_v2.json')
         if os.path.exists(pmc):
             with open(pmc) as f:
-                p = json.load(f)['fwd_B512']
-            traffic = int(byts.mean() * p['traffic_MB'] / p['algorithmic_MB'])
-        roof = dict(bound='hbm', kernel='pna_aggregate_fwd_kernel', achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+                p = json.load(f).get(f'fwd{blocks}_B512')
+            if p:
+                traffic = int(byts.mean() * p['traffic_MB'] / p['algorithmic_MB'])
+        roof = dict(bound='hbm', kernel=f'pna_aggregate_fwd_kernel ({blocks} output blocks [N,{blocks}F], as launched by the step)',
+                    achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                     unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     launches=len(ev), avg_us=round(float(ms.mean() * 1e3), 2),
                     algorithmic_bytes_per_launch=int(byts.mean()),
                     achieved_back_to_back=round(b2b, 1), frac_back_to_back=round(b2b / HBM_PEAK_GBS, 4),
-                    avg_us_back_to_back=round(b2b_ms * 1e3 / (reps * len(batches)), 2),
-                    note='achieved/frac: one HIP-event pair around every K4 launch of the timed steps (includes '
-                         'event overhead); *_back_to_back: 20 launches per event pair after the timed region; '
-                         'traffic: rocprofv3 PMC bytes per launch (profiles/r01_k4_pmc.txt)')
+                    avg_us_back_to_back=round(b2b_us, 2),
+                    reference_shaped_12F=dict(achieved_back_to_back=round(b2b12, 1), frac_back_to_back=round(b2b12 / HBM_PEAK_GBS, 4),
+                                              avg_us_back_to_back=round(b2b12_us, 2)),
+                    note='achieved/frac: one HIP-event pair around every K4 launch of the timed steps (an event pair adds '
+                         '~3 us of dispatch latency to a ~9 us kernel; rocprofv3 kernel time in profiles/); *_back_to_back: '
+                         '20 launches per event pair after the timed region; reference_shaped_12F: the [N,12F] kernel of '
+                         'SURVEY.md 8(d) (I3D_GROUPED_POSTTRANS=0 path); traffic: rocprofv3 PMC bytes per launch')
 
     if rank == 0:
         mol_per_s = args.steps * B * world / dt

@@ -32,11 +32,18 @@ def main():
         N, E, F = idx.num_nodes, idx.num_edges, a.feat
         e = torch.randn(E, F, device=dev)
         gout = torch.randn(N, 12 * F, device=dev)
+        gout4 = torch.randn(N, 4 * F, device=dev)
         fwd_bytes = 4.0 * E * F + 4.0 * N * 12 * F + 4.0 * (N + 1)
         bwd_bytes = 4.0 * N * 12 * F + 2 * 4.0 * E * F + 4.0 * (N + 1)
-        for name, fn, byts in (('fwd', lambda: ops.pna_aggregate_fwd(e, idx.in_ptr, N, aggs, scalers), fwd_bytes),
-                               ('bwd', lambda: ops.pna_aggregate_bwd(gout, e, idx.in_ptr, N, aggs, scalers), bwd_bytes)):
-            if name == 'bwd' and not a.bwd:
+        fwd4_bytes = 4.0 * E * F + 4.0 * N * 4 * F + 4.0 * (N + 1)
+        bwd4_bytes = 4.0 * N * 4 * F + 2 * 4.0 * E * F + 4.0 * (N + 1)
+        ident = scalers[:1]
+        # "12F": the reference-shaped output [N, 12F]; "4F": identity block only (degree-grouped posttrans, the step's kernel)
+        for name, fn, byts in (('fwd 12F', lambda: ops.pna_aggregate_fwd(e, idx.in_ptr, N, aggs, scalers), fwd_bytes),
+                               ('fwd  4F', lambda: ops.pna_aggregate_fwd(e, idx.in_ptr, N, aggs, ident), fwd4_bytes),
+                               ('bwd 12F', lambda: ops.pna_aggregate_bwd(gout, e, idx.in_ptr, N, aggs, scalers), bwd_bytes),
+                               ('bwd  4F', lambda: ops.pna_aggregate_bwd(gout4, e, idx.in_ptr, N, aggs, ident), bwd4_bytes)):
+            if name.startswith('bwd') and not a.bwd:
                 continue
             for _ in range(3):
                 fn()
