@@ -10,7 +10,8 @@
 
 namespace i3d {
 
-constexpr int MAX_PARTIAL_BLOCKS = 256;   // ~ one partial block per CU; stage 2 reduces them with 8 lanes per column
+constexpr int MAX_PARTIAL_BLOCKS = 256;
+constexpr int RU = 4;                     // rows per thread in flight in the streaming kernels   // ~ one partial block per CU; stage 2 reduces them with 8 lanes per column
 
 struct Chunking {
     int tpr;       // threads per row (column vectors handled in parallel)
@@ -78,46 +79,61 @@ __global__ void __launch_bounds__(256) colreduce_partial_kernel(ReduceArgs g, Ch
         }
         const int r_begin = blockIdx.x * ch.rpb;
         const int r_end = min(g.rows, r_begin + ch.rpb);
-        for (int r = r_begin + rlane; r < r_end; r += ch.rl) {
-            const long off = (long)r * F + c0;
-            float x[V], y[V];
-            if (V == 4) {
-                float4 xx = *reinterpret_cast<const float4*>(g.a + off);
-                x[0] = xx.x; x[1 % V] = xx.y; x[2 % V] = xx.z; x[3 % V] = xx.w;
-            } else {
-                x[0] = g.a[off];
-            }
-            if (MODE == MODE_STATS) {
+        // RU rows per thread in flight (clamped row index: the loads are unconditional, the accumulation is masked and
+        // keeps the row order r, r + rl, r + 2 rl, ...): a one-row loop left one 16-byte load in flight per lane
+        for (int r0 = r_begin + rlane; r0 < r_end; r0 += ch.rl * RU) {
+            float xs[RU][V], ys[RU][V], ws[RU];
 #pragma unroll
-                for (int i = 0; i < V; ++i) {
-                    x[i] = apply_act(x[i], g.act);
-                    float d = x[i] - shift[i];
-                    a1[i] += d;
-                    a2[i] += d * d;
-                }
-                if (g.out != nullptr && g.act != I3D_ACT_NONE) {
-                    if (V == 4) *reinterpret_cast<float4*>(g.out + off) = make_float4(x[0], x[1 % V], x[2 % V], x[3 % V]);
-                    else g.out[off] = x[0];
-                }
-            } else if (MODE == MODE_BN_BWD) {
+            for (int u = 0; u < RU; ++u) {
+                const int r = min(r0 + u * ch.rl, r_end - 1);
+                const long off = (long)r * F + c0;
                 if (V == 4) {
-                    float4 yy = *reinterpret_cast<const float4*>(g.b + off);
-                    y[0] = yy.x; y[1 % V] = yy.y; y[2 % V] = yy.z; y[3 % V] = yy.w;
+                    float4 xx = *reinterpret_cast<const float4*>(g.a + off);
+                    xs[u][0] = xx.x; xs[u][1 % V] = xx.y; xs[u][2 % V] = xx.z; xs[u][3 % V] = xx.w;
                 } else {
-                    y[0] = g.b[off];
+                    xs[u][0] = g.a[off];
                 }
-#pragma unroll
-                for (int i = 0; i < V; ++i) {
-                    float xh = (y[i] - mu[i]) * is[i];
-                    float dy = x[i];
-                    if (g.post_act != I3D_ACT_NONE) dy *= act_grad(xh * ga[i] + be[i], g.post_act);
-                    a1[i] += dy;
-                    a2[i] += dy * xh;
+                if (MODE == MODE_BN_BWD) {
+                    if (V == 4) {
+                        float4 yy = *reinterpret_cast<const float4*>(g.b + off);
+                        ys[u][0] = yy.x; ys[u][1 % V] = yy.y; ys[u][2 % V] = yy.z; ys[u][3 % V] = yy.w;
+                    } else {
+                        ys[u][0] = g.b[off];
+                    }
                 }
-            } else {
-                float w = g.b != nullptr ? g.b[r] : 1.f;
+                if (MODE == MODE_COLSUM) ws[u] = g.b != nullptr ? g.b[r] : 1.f;
+            }
 #pragma unroll
-                for (int i = 0; i < V; ++i) a1[i] += x[i] * w;
+            for (int u = 0; u < RU; ++u) {
+                const int r = r0 + u * ch.rl;
+                if (r >= r_end) continue;
+                const long off = (long)r * F + c0;
+                float* x = xs[u];
+                if (MODE == MODE_STATS) {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) {
+                        x[i] = apply_act(x[i], g.act);
+                        float d = x[i] - shift[i];
+                        a1[i] += d;
+                        a2[i] += d * d;
+                    }
+                    if (g.out != nullptr && g.act != I3D_ACT_NONE) {
+                        if (V == 4) *reinterpret_cast<float4*>(g.out + off) = make_float4(x[0], x[1 % V], x[2 % V], x[3 % V]);
+                        else g.out[off] = x[0];
+                    }
+                } else if (MODE == MODE_BN_BWD) {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) {
+                        float xh = (ys[u][i] - mu[i]) * is[i];
+                        float dy = x[i];
+                        if (g.post_act != I3D_ACT_NONE) dy *= act_grad(xh * ga[i] + be[i], g.post_act);
+                        a1[i] += dy;
+                        a2[i] += dy * xh;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) a1[i] += x[i] * ws[u];
+                }
             }
         }
     }
@@ -252,34 +268,70 @@ struct ApplyArgs {
     float eps;
 };
 
+// Elementwise passes: a thread owns one column vector (its per-column parameters live in registers) and RU rows per
+// trip, rows of a block are consecutive: no index division and no parameter gathers in the loop, RU 16-byte loads per
+// operand in flight.  (The first version walked a flat grid-stride index and re-read 4 parameters per element: ~1.7 TB/s.)
+struct RowTiling {
+    int tpr, rl, cv, ncolblk;   // threads per row, row lanes per block, column vectors per row, blocks along columns
+};
+
+static RowTiling make_row_tiling(int feat, int V) {
+    RowTiling t;
+    t.cv = feat / V;
+    t.tpr = t.cv < 256 ? t.cv : 256;
+    t.rl = 256 / t.tpr;
+    t.ncolblk = cdiv(t.cv, t.tpr);
+    return t;
+}
+
 template <int V>
-__global__ void __launch_bounds__(256) bn_apply_kernel(ApplyArgs g) {
-    const int FV = g.feat / V;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < g.items; t += (long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(t % FV) * V;
-        const long off = t * V;
-        float x[V], r[V];
+__global__ void __launch_bounds__(256) bn_apply_kernel(ApplyArgs g, RowTiling rt, int rows) {
+    const int cl = threadIdx.x % rt.tpr, rlane = threadIdx.x / rt.tpr;
+    const int cvi = blockIdx.y * rt.tpr + cl;
+    if (rlane >= rt.rl || cvi >= rt.cv) return;
+    const int c0 = cvi * V, F = g.feat;
+    float sc[V], sh[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const float is = g.eval_mode ? 1.f / sqrtf(g.invstd[c0 + i] + g.eps) : g.invstd[c0 + i];
+        sc[i] = is;
+        sh[i] = g.mean[c0 + i];
+    }
+    float ga[V], be[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { ga[i] = g.gamma[c0 + i]; be[i] = g.beta[c0 + i]; }
+    const int r0 = blockIdx.x * rt.rl * RU + rlane;
+    float x[RU][V], r[RU][V];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+        const int row = min(r0 + u * rt.rl, rows - 1);
+        const long off = (long)row * F + c0;
         if (V == 4) {
             float4 xx = *reinterpret_cast<const float4*>(g.x + off);
-            x[0] = xx.x; x[1 % V] = xx.y; x[2 % V] = xx.z; x[3 % V] = xx.w;
+            x[u][0] = xx.x; x[u][1 % V] = xx.y; x[u][2 % V] = xx.z; x[u][3 % V] = xx.w;
             if (g.residual) {
                 float4 rr = *reinterpret_cast<const float4*>(g.residual + off);
-                r[0] = rr.x; r[1 % V] = rr.y; r[2 % V] = rr.z; r[3 % V] = rr.w;
+                r[u][0] = rr.x; r[u][1 % V] = rr.y; r[u][2 % V] = rr.z; r[u][3 % V] = rr.w;
             }
         } else {
-            x[0] = g.x[off];
-            if (g.residual) r[0] = g.residual[off];
+            x[u][0] = g.x[off];
+            if (g.residual) r[u][0] = g.residual[off];
         }
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+        const int row = r0 + u * rt.rl;
+        if (row >= rows) continue;
+        const long off = (long)row * F + c0;
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            float is = g.eval_mode ? 1.f / sqrtf(g.invstd[c0 + i] + g.eps) : g.invstd[c0 + i];
-            float v = (x[i] - g.mean[c0 + i]) * is * g.gamma[c0 + i] + g.beta[c0 + i];
+            float v = (x[u][i] - sh[i]) * sc[i] * ga[i] + be[i];
             v = apply_act(v, g.post_act);
-            if (g.residual) v += r[i];
-            x[i] = v;
+            if (g.residual) v += r[u][i];
+            x[u][i] = v;
         }
-        if (V == 4) *reinterpret_cast<float4*>(g.y + off) = make_float4(x[0], x[1 % V], x[2 % V], x[3 % V]);
-        else g.y[off] = x[0];
+        if (V == 4) *reinterpret_cast<float4*>(g.y + off) = make_float4(x[u][0], x[u][1 % V], x[u][2 % V], x[u][3 % V]);
+        else g.y[off] = x[u][0];
     }
 }
 
@@ -301,42 +353,62 @@ struct BwdApplyArgs {
 };
 
 template <int V>
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BwdApplyArgs g) {
-    const int FV = g.feat / V;
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BwdApplyArgs g, RowTiling rt, int rows) {
+    const int cl = threadIdx.x % rt.tpr, rlane = threadIdx.x / rt.tpr;
+    const int cvi = blockIdx.y * rt.tpr + cl;
+    if (rlane >= rt.rl || cvi >= rt.cv) return;
+    const int c0 = cvi * V, F = g.feat;
     const float inv_n = g.inv_n_ptr ? g.inv_n_ptr[0] : g.inv_n;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < g.items; t += (long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(t % FV) * V;
-        const long off = t * V;
-        float dy[V], x[V], p[V];
+    float mu[V], is[V], ga[V], be[V], k1[V], k2[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = c0 + i;
+        is[i] = g.eval_mode ? 1.f / sqrtf(g.invstd[c] + g.eps) : g.invstd[c];
+        mu[i] = g.mean[c];
+        ga[i] = g.gamma[c];
+        be[i] = g.beta[c];
+        k1[i] = g.eval_mode ? 0.f : g.sum_dy[c] * inv_n;
+        k2[i] = g.eval_mode ? 0.f : g.sum_dy_xhat[c] * inv_n;
+    }
+    const int r0 = blockIdx.x * rt.rl * RU + rlane;
+    float dy[RU][V], x[RU][V], p[RU][V];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+        const int row = min(r0 + u * rt.rl, rows - 1);
+        const long off = (long)row * F + c0;
         if (V == 4) {
             float4 a = *reinterpret_cast<const float4*>(g.grad_y + off);
             float4 b = *reinterpret_cast<const float4*>(g.x + off);
-            dy[0] = a.x; dy[1 % V] = a.y; dy[2 % V] = a.z; dy[3 % V] = a.w;
-            x[0] = b.x; x[1 % V] = b.y; x[2 % V] = b.z; x[3 % V] = b.w;
+            dy[u][0] = a.x; dy[u][1 % V] = a.y; dy[u][2 % V] = a.z; dy[u][3 % V] = a.w;
+            x[u][0] = b.x; x[u][1 % V] = b.y; x[u][2 % V] = b.z; x[u][3 % V] = b.w;
             if (g.pre) {
                 float4 c = *reinterpret_cast<const float4*>(g.pre + off);
-                p[0] = c.x; p[1 % V] = c.y; p[2 % V] = c.z; p[3 % V] = c.w;
+                p[u][0] = c.x; p[u][1 % V] = c.y; p[u][2 % V] = c.z; p[u][3 % V] = c.w;
             }
         } else {
-            dy[0] = g.grad_y[off];
-            x[0] = g.x[off];
-            if (g.pre) p[0] = g.pre[off];
+            dy[u][0] = g.grad_y[off];
+            x[u][0] = g.x[off];
+            if (g.pre) p[u][0] = g.pre[off];
         }
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+        const int row = r0 + u * rt.rl;
+        if (row >= rows) continue;
+        const long off = (long)row * F + c0;
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            const int c = c0 + i;
-            float is = g.eval_mode ? 1.f / sqrtf(g.invstd[c] + g.eps) : g.invstd[c];
-            float xh = (x[i] - g.mean[c]) * is;
-            float d = dy[i];
-            if (g.post_act != I3D_ACT_NONE) d *= act_grad(xh * g.gamma[c] + g.beta[c], g.post_act);
+            float xh = (x[u][i] - mu[i]) * is[i];
+            float d = dy[u][i];
+            if (g.post_act != I3D_ACT_NONE) d *= act_grad(xh * ga[i] + be[i], g.post_act);
             float gx;
-            if (g.eval_mode) gx = d * g.gamma[c] * is;
-            else gx = g.gamma[c] * is * (d - g.sum_dy[c] * inv_n - xh * g.sum_dy_xhat[c] * inv_n);
-            if (g.act != I3D_ACT_NONE) gx *= act_grad(g.pre ? p[i] : x[i], g.act);   // relu'(pre) == relu'(x)
-            dy[i] = gx;
+            if (g.eval_mode) gx = d * ga[i] * is[i];
+            else gx = ga[i] * is[i] * (d - k1[i] - xh * k2[i]);
+            if (g.act != I3D_ACT_NONE) gx *= act_grad(g.pre ? p[u][i] : x[u][i], g.act);   // relu'(pre) == relu'(x)
+            dy[u][i] = gx;
         }
-        if (V == 4) *reinterpret_cast<float4*>(g.grad_pre + off) = make_float4(dy[0], dy[1 % V], dy[2 % V], dy[3 % V]);
-        else g.grad_pre[off] = dy[0];
+        if (V == 4) *reinterpret_cast<float4*>(g.grad_pre + off) = make_float4(dy[u][0], dy[u][1 % V], dy[u][2 % V], dy[u][3 % V]);
+        else g.grad_pre[off] = dy[u][0];
     }
 }
 
@@ -413,13 +485,12 @@ static int bn_apply_common(const float* x, int rows, int feat, const float* mean
     g.x = x; g.mean = mean; g.invstd = invstd_or_var; g.gamma = gamma; g.beta = beta; g.residual = residual; g.y = y;
     g.feat = feat; g.post_act = post_act; g.eval_mode = eval_mode; g.eps = eps;
     hipStream_t s = (hipStream_t)stream;
-    if (feat % 4 == 0) {
-        g.items = (long)rows * feat / 4;
-        hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(grid_for(g.items)), dim3(256), 0, s, g);
-    } else {
-        g.items = (long)rows * feat;
-        hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(grid_for(g.items)), dim3(256), 0, s, g);
-    }
+    g.items = 0;
+    const int V = feat % 4 == 0 ? 4 : 1;
+    const RowTiling rt = make_row_tiling(feat, V);
+    dim3 grid(cdiv(rows, rt.rl * RU), rt.ncolblk);
+    if (V == 4) hipLaunchKernelGGL(bn_apply_kernel<4>, grid, dim3(256), 0, s, g, rt, rows);
+    else hipLaunchKernelGGL(bn_apply_kernel<1>, grid, dim3(256), 0, s, g, rt, rows);
     return I3D_OK;
 }
 
@@ -442,13 +513,12 @@ extern "C" int i3d_bn_eval_fwd(const float* x, int rows, int feat, const float* 
 }
 
 static void launch_bwd_apply(BwdApplyArgs& g, int rows, int feat, hipStream_t s) {
-    if (feat % 4 == 0) {
-        g.items = (long)rows * feat / 4;
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(grid_for(g.items)), dim3(256), 0, s, g);
-    } else {
-        g.items = (long)rows * feat;
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(grid_for(g.items)), dim3(256), 0, s, g);
-    }
+    g.items = 0;
+    const int V = feat % 4 == 0 ? 4 : 1;
+    const RowTiling rt = make_row_tiling(feat, V);
+    dim3 grid(cdiv(rows, rt.rl * RU), rt.ncolblk);
+    if (V == 4) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, grid, dim3(256), 0, s, g, rt, rows);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, s, g, rt, rows);
 }
 
 extern "C" int i3d_bn_bwd(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
