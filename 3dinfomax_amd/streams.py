@@ -7,10 +7,11 @@ stream next to the data-gradient GEMMs of the same node and joined before the no
   * every tensor the side kernels read is `record_stream`ed so the caching allocator does not recycle it early;
   * outputs are allocated on the main stream's pool BEFORE switching streams and the main stream waits for the side
     stream before the node returns, so autograd (AccumulateGrad, the next node) only ever sees completed tensors.
-EXPERIMENTAL, off by default (I3D_OVERLAP=1 enables it): at batch 512 the step is bound by the host's enqueue
-rate, where the extra stream bookkeeping costs more than the overlap wins (profiles/r01_notes.md), and one
-large-batch gradient check disagrees with the single-stream result when it is on - to be root-caused before it
-becomes the default.
+EXPERIMENTAL, off by default (I3D_OVERLAP=1 enables it) and only wired into the per-kernel (I3D_COMPOSITE=0) backward
+paths: at batch 512 the host's enqueue rate is as much on the critical path as the GPU, where the extra stream
+bookkeeping costs more than the overlap wins.  (A large-batch gradient check that disagreed with it switched on
+turned out to be arg-max routing flipping on near-ties between two summation orders - DESIGN.md section 6 - not a
+race.)
 """
 import os
 import threading
