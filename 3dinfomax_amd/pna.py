@@ -21,7 +21,8 @@ from torch import nn
 
 from . import ops
 from .graph import as_batched_graph
-from .layers import MLP, AggregateFn, EdgeTable, ReadoutFn, bn_counter_scope
+from .layers import (MLP, AggregateFn, Concat2FCFn, EdgeFCFn, EdgeTable, FCFn, GroupedConcat2FCFn, ReadoutFn,
+                     bn_counter_scope)
 from .mol_encoder import AtomEncoder, BondEncoder
 
 EPS = 1e-5
@@ -33,6 +34,8 @@ PNA_SCALERS = {k: v for k, v in ops.SCALER.items()}
 
 # I3D_GROUPED_POSTTRANS=0 selects the reference-shaped path ([N,12F] aggregate + K=13F posttrans GEMM)
 GROUPED_POSTTRANS = os.environ.get('I3D_GROUPED_POSTTRANS', '1') != '0'
+# I3D_FUSED_LAYER=0 runs a PNA layer as four autograd nodes (edge FC, FC, aggregate, posttrans) instead of one
+FUSED_LAYER = os.environ.get('I3D_FUSED_LAYER', '1') != '0'
 # I3D_EDGE_TABLE=0 materialises the [E, F] bond embeddings and multiplies them by W_q in every layer (reference shape)
 EDGE_TABLE = os.environ.get('I3D_EDGE_TABLE', '1') != '0'
 
@@ -151,6 +154,98 @@ class PNAGNN(nn.Module):
         return cache[key]
 
 
+class _SubCtx:
+    """Stand-in for the autograd context when the forward/backward of one of the block Functions of layers.py runs as
+    a step inside PNALayerFn."""
+
+    def __init__(self, needs_input_grad=(True,) * 12):
+        self.needs_input_grad = needs_input_grad
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class _LayerPlan:
+    """Non-tensor configuration of one PNALayerFn call (built by PNALayer.forward)."""
+    __slots__ = ('pre_specs', 'post_specs', 'aggregators', 'agg_scalers', 'avg', 'coef', 'grouped', 'residual')
+
+
+class PNALayerFn(torch.autograd.Function):
+    """One PNA layer (reference models/pna.py:199-216) as ONE autograd node: pretrans edge MLP -> aggregation ->
+    posttrans MLP (+ residual).  The steps are the forward/backward bodies of the block Functions of layers.py run back
+    to back; the three contributions to dL/dh (edge MLP, posttrans, residual) are summed by i3d_add_inplace here
+    instead of by autograd's accumulation (a torch add costs ~35 us of host time on this stack, an autograd node ~30 us;
+    the host is on the critical path of the step).  params = (W, b, gamma, beta) of every pretrans FC layer, then of
+    every posttrans FC layer."""
+
+    @staticmethod
+    def forward(ctx, h, q, index, qmap, plan, *params):
+        k = 0
+        subs = []
+        W, b, ga, be = params[k:k + 4]
+        k += 4
+        c = _SubCtx((True, ctx.needs_input_grad[1]) + (True,) * 10)
+        e = EdgeFCFn.forward(c, h, q, W, b, ga, be, index, plan.pre_specs[0], qmap)
+        subs.append(c)
+        for spec in plan.pre_specs[1:]:
+            W, b, ga, be = params[k:k + 4]
+            k += 4
+            c = _SubCtx()
+            e = FCFn.forward(c, e, W, b, ga, be, None, spec)
+            subs.append(c)
+        c = _SubCtx()
+        a = AggregateFn.forward(c, e, index, plan.aggregators, plan.agg_scalers, plan.avg)
+        subs.append(c)
+        n_post = len(plan.post_specs)
+        W, b, ga, be = params[k:k + 4]
+        k += 4
+        res0 = h if (plan.residual and n_post == 1) else None
+        c = _SubCtx()
+        if plan.grouped:
+            x = GroupedConcat2FCFn.forward(c, h, a, W, b, ga, be, res0, index, plan.coef, plan.post_specs[0])
+        else:
+            x = Concat2FCFn.forward(c, h, a, W, b, ga, be, res0, plan.post_specs[0])
+        subs.append(c)
+        for i, spec in enumerate(plan.post_specs[1:]):
+            W, b, ga, be = params[k:k + 4]
+            k += 4
+            c = _SubCtx()
+            x = FCFn.forward(c, x, W, b, ga, be, h if (plan.residual and i == n_post - 2) else None, spec)
+            subs.append(c)
+        ctx.subs, ctx.plan = subs, plan
+        return x
+
+    @staticmethod
+    def backward(ctx, grad):
+        plan, subs = ctx.plan, list(ctx.subs)
+        n_pre, n_post = len(plan.pre_specs), len(plan.post_specs)
+        grad = grad.contiguous()
+        post_grads, pre_grads = [], []
+        g = grad
+        for _ in range(n_post - 1):                       # plain posttrans layers, last first
+            gx, gW, gb, gg, gbe, _, _ = FCFn.backward(subs.pop(), g)
+            post_grads.insert(0, (gW, gb, gg, gbe))
+            g = gx
+        if plan.grouped:
+            gh, gagg, gW, gb, gg, gbe = GroupedConcat2FCFn.backward(subs.pop(), g)[:6]
+        else:
+            gh, gagg, gW, gb, gg, gbe = Concat2FCFn.backward(subs.pop(), g)[:6]
+        post_grads.insert(0, (gW, gb, gg, gbe))
+        ge = AggregateFn.backward(subs.pop(), gagg)[0]
+        for _ in range(n_pre - 1):
+            gx, gW, gb, gg, gbe, _, _ = FCFn.backward(subs.pop(), ge)
+            pre_grads.insert(0, (gW, gb, gg, gbe))
+            ge = gx
+        gh_edge, gq, gW, gb, gg, gbe = EdgeFCFn.backward(subs.pop(), ge)[:6]
+        pre_grads.insert(0, (gW, gb, gg, gbe))
+        ops.add_inplace(gh, gh_edge)                      # gh is a fresh buffer of the posttrans backward
+        if plan.residual:
+            ops.add_inplace(gh, grad)
+        flat = [t for quad in pre_grads + post_grads for t in quad]
+        return (gh, gq, None, None, None) + tuple(flat)
+
+
 class PNALayer(nn.Module):
     """reference models/pna.py:169-252."""
 
@@ -186,11 +281,27 @@ class PNALayer(nn.Module):
         h = g.ndata['feat']
         if ef_sorted is None and self.edge_features:
             ef_sorted = _GatherRowsFn.apply(g.edata['feat'], idx.perm, idx.inv_perm)
+        avg = float(self.avg_d["log"])
+        grouped = GROUPED_POSTTRANS and len(self.scalers) > 1 and h.shape[1] % 4 == 0
+        if FUSED_LAYER and h.is_cuda:
+            plan = _LayerPlan()
+            pre, post = list(self.pretrans.fully_connected), list(self.posttrans.fully_connected)
+            plan.pre_specs, plan.post_specs = [fc.spec() for fc in pre], [fc.spec() for fc in post]
+            plan.aggregators, plan.avg, plan.grouped, plan.residual = self.aggregators, avg, grouped, self.residual
+            plan.agg_scalers = [ops.SCALER['identity']] if grouped else self.scalers
+            plan.coef = ([[_scaler_coef(s, D, avg) for s in self.scalers] for D, _, _ in idx.degree_groups()[2]]
+                         if grouped else None)
+            params = []
+            for fc in pre + post:
+                params += [fc.linear.weight, fc.linear.bias, *fc.bn_affine()]
+            h_new = PNALayerFn.apply(h, ef_sorted if self.edge_features else None, idx,
+                                     qmap if self.edge_features else None, plan, *params)
+            g.ndata['feat'] = h_new
+            return h_new
         # pretransformation (edge MLP on [h_src | h_dst | e_feat]) -> messages, destination-sorted
         e = self.pretrans.forward_edge(h, ef_sorted if self.edge_features else None, idx,
                                        qmap=qmap if self.edge_features else None)
-        avg = float(self.avg_d["log"])
-        if GROUPED_POSTTRANS and len(self.scalers) > 1 and h.shape[1] % 4 == 0:
+        if grouped:
             # the scaler blocks are per-node multiples of the aggregator block that depend on the in-degree only:
             # aggregate once ([N, n_agg*F], identity block) and fold the scalers into per-degree posttrans weights
             a = AggregateFn.apply(e, idx, self.aggregators, [ops.SCALER['identity']], avg)
