@@ -23,7 +23,7 @@ _P = c_void_p
 class BnTail(ctypes.Structure):
     _fields_ = [('act', c_int), ('post_act', c_int), ('eps', c_float), ('momentum', c_float), ('gamma', _P),
                 ('beta', _P), ('running_mean', _P), ('running_var', _P), ('mean', _P), ('invstd', _P),
-                ('workspace', _P)]
+                ('workspace', _P), ('gemm_workspace', _P), ('gemm_workspace_bytes', c_long)]
 
 
 class FcArgs(ctypes.Structure):
@@ -71,14 +71,15 @@ _SIGNATURES = {
     'i3d_segment_readout_bwd': (c_int, [_P, _P, _P, c_int, c_int, POINTER(c_int), c_int, _P, _P]),
     'i3d_gemm_f32': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
     'i3d_gemm_f32_ex': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int,
-                                _P]),
+                                _P, c_long, _P]),
+    'i3d_gemm_f32_ws': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_long, _P]),
     'i3d_pna_combine_weights_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), _P, _P]),
     'i3d_pna_combine_weights_bwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), _P, _P]),
     'i3d_gemm_f32_grouped': (c_int, [c_int, c_int, c_int, c_int, _P, c_int, c_long, _P, _P, _P, c_int, c_long, _P, c_int,
                                      c_int, _P]),
     'i3d_gemm_f32_rowsubset': (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_long, _P, c_int, c_int, _P]),
     'i3d_gemm_f32_rowsubset_multi': (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), _P, c_int, _P, c_int, _P,
-                                             c_long, _P, c_long, c_int, c_int, c_int, c_int, _P]),
+                                             c_long, _P, c_long, c_int, c_int, c_int, c_int, _P, c_long, _P]),
     'i3d_colreduce_workspace_bytes': (c_long, [c_int, c_int]),
     'i3d_act_stats_fwd': (c_int, [_P, c_int, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     'i3d_bn_finalize_stats': (c_int, [_P, c_int, c_float, c_float, _P, _P, _P, _P, _P]),

@@ -16,16 +16,6 @@ using namespace i3d;
         if (rc_ != I3D_OK) return rc_; \
     } while (0)
 
-// one zero-fill for a whole weight-gradient buffer; the GEMMs then accumulate (their own per-call zero-fills for the
-// split-K atomics would be 3-6 extra launches per block)
-static int zero(float* p, size_t n, void* stream) {
-    if (hipMemsetAsync(p, 0, n * sizeof(float), (hipStream_t)stream) != hipSuccess) {
-        i3d::set_error("composite: memset failed");
-        return I3D_ERR_LAUNCH;
-    }
-    return I3D_OK;
-}
-
 static int tail_fwd(const I3dBnTail* t, int rows, int f_out, float* pre, float* xact, const float* residual, float* y,
                     void* stream) {
     // pre holds the Linear output.  xact == pre: activation in place (ReLU/none); else pre is kept for act'
@@ -52,8 +42,7 @@ extern "C" int i3d_fc_bn_bwd(const I3dFcArgs* a, void* stream) {
     I3D_CHECK_ARG(a != nullptr && a->rows > 0, "bad arguments");
     TRY(tail_bwd(&a->tail, a->rows, a->f_out, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre,
                  stream));
-    TRY(i3d_gemm_f32(1, 0, a->f_out, a->f_in, a->rows, a->grad_pre, a->f_out, a->x, a->f_in, a->grad_W, a->ldw, nullptr, 0,
-                     stream));
+    TRY(i3d_gemm_f32_ws(1, 0, a->f_out, a->f_in, a->rows, a->grad_pre, a->f_out, a->x, a->f_in, a->grad_W, a->ldw, nullptr, 0, a->tail.gemm_workspace, a->tail.gemm_workspace_bytes, stream));
     TRY(i3d_colsum(a->grad_pre, nullptr, a->rows, a->f_out, a->grad_bias, a->tail.workspace, stream));
     if (a->grad_x != nullptr)
         TRY(i3d_gemm_f32(0, 0, a->rows, a->f_in, a->f_out, a->grad_pre, a->f_out, a->W, a->ldw, a->grad_x, a->f_in, nullptr,
@@ -83,20 +72,22 @@ extern "C" int i3d_edge_fc_bn_bwd(const I3dEdgeFcArgs* a, void* stream) {
     // d P[src] (out-edges through the source index), d P[dst] (in-edges are contiguous): segmented sums, no atomics
     TRY(i3d_segment_sum(a->grad_pre, Fo, a->out_ptr, a->out_epos, N, Fo, 0, a->grad_P, 2 * Fo, stream));
     TRY(i3d_segment_sum(a->grad_pre, Fo, a->in_ptr, nullptr, N, Fo, 0, a->grad_P + Fo, 2 * Fo, stream));
-    TRY(zero(a->grad_W, (size_t)Fo * a->ldw, stream));
-    TRY(i3d_gemm_f32(1, 0, Fo, Fh, N, a->grad_P, 2 * Fo, a->h, Fh, a->grad_W, a->ldw, nullptr, 1, stream));
-    TRY(i3d_gemm_f32(1, 0, Fo, Fh, N, a->grad_P + Fo, 2 * Fo, a->h, Fh, a->grad_W + Fh, a->ldw, nullptr, 1, stream));
+    // every column block of dW is written exactly once: no zero-fill (the split-K slices go through the scratch)
+    void* ws = a->tail.gemm_workspace;
+    const long wsb = a->tail.gemm_workspace_bytes;
+    TRY(i3d_gemm_f32_ws(1, 0, Fo, Fh, N, a->grad_P, 2 * Fo, a->h, Fh, a->grad_W, a->ldw, nullptr, 0, ws, wsb, stream));
+    TRY(i3d_gemm_f32_ws(1, 0, Fo, Fh, N, a->grad_P + Fo, 2 * Fo, a->h, Fh, a->grad_W + Fh, a->ldw, nullptr, 0, ws, wsb, stream));
     TRY(i3d_gemm_f32(0, 0, N, Fh, Fo, a->grad_P, 2 * Fo, a->W, a->ldw, a->grad_h, Fh, nullptr, 0, stream));
     TRY(i3d_gemm_f32(0, 0, N, Fh, Fo, a->grad_P + Fo, 2 * Fo, a->W + Fh, a->ldw, a->grad_h, Fh, nullptr, 1, stream));
     if (a->q != nullptr && a->q_rows > 0) {
         // table mode: dQ[v] = sum of dpre over the edges of category v (one-hot^T dpre), then two [V, .] products
         const int V = a->q_rows;
-        TRY(i3d_gemm_f32(1, 0, a->v_pad, Fo, E, a->onehot, a->v_pad, a->grad_pre, Fo, a->grad_Q, Fo, nullptr, 0, stream));
-        TRY(i3d_gemm_f32(1, 0, Fo, a->f_q, V, a->grad_Q, Fo, a->q, a->f_q, a->grad_W + 2 * Fh, a->ldw, nullptr, 1, stream));
+        TRY(i3d_gemm_f32_ws(1, 0, a->v_pad, Fo, E, a->onehot, a->v_pad, a->grad_pre, Fo, a->grad_Q, Fo, nullptr, 0, ws, wsb, stream));
+        TRY(i3d_gemm_f32_ws(1, 0, Fo, a->f_q, V, a->grad_Q, Fo, a->q, a->f_q, a->grad_W + 2 * Fh, a->ldw, nullptr, 0, ws, wsb, stream));
         if (a->grad_q != nullptr)
             TRY(i3d_gemm_f32(0, 0, V, a->f_q, Fo, a->grad_Q, Fo, a->W + 2 * Fh, a->ldw, a->grad_q, a->f_q, nullptr, 0, stream));
     } else if (a->q != nullptr) {
-        TRY(i3d_gemm_f32(1, 0, Fo, a->f_q, E, a->grad_pre, Fo, a->q, a->f_q, a->grad_W + 2 * Fh, a->ldw, nullptr, 1, stream));
+        TRY(i3d_gemm_f32_ws(1, 0, Fo, a->f_q, E, a->grad_pre, Fo, a->q, a->f_q, a->grad_W + 2 * Fh, a->ldw, nullptr, 0, ws, wsb, stream));
         if (a->grad_q != nullptr)
             TRY(i3d_gemm_f32(0, 0, E, a->f_q, Fo, a->grad_pre, Fo, a->W + 2 * Fh, a->ldw, a->grad_q, a->f_q, nullptr, 0, stream));
     }
@@ -119,12 +110,11 @@ extern "C" int i3d_grouped_fc_bn_bwd(const I3dGroupedFcArgs* a, void* stream) {
     I3D_CHECK_ARG(a != nullptr && a->num_nodes > 0 && a->n_groups > 0, "bad arguments");
     const int Fh = a->f_h, Fo = a->f_out, A = a->agg_width, N = a->num_nodes;
     TRY(tail_bwd(&a->tail, N, Fo, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre, stream));
-    TRY(zero(a->grad_W, (size_t)Fo * a->ldw, stream));
-    TRY(zero(a->grad_WD, (size_t)a->n_groups * Fo * A, stream));
-    TRY(i3d_gemm_f32(1, 0, Fo, Fh, N, a->grad_pre, Fo, a->h, Fh, a->grad_W, a->ldw, nullptr, 1, stream));
+    TRY(i3d_gemm_f32_ws(1, 0, Fo, Fh, N, a->grad_pre, Fo, a->h, Fh, a->grad_W, a->ldw, nullptr, 0, a->tail.gemm_workspace, a->tail.gemm_workspace_bytes, stream));
     // dW_D = dY_D^T a_D over the rows of each in-degree group, all groups in one launch
     TRY(i3d_gemm_f32_rowsubset_multi(Fo, A, a->n_groups, a->group_start, a->group_count, a->grad_pre, Fo, a->agg, A,
-                                     a->deg_rows, N, a->grad_WD, (long)Fo * A, A, 1, -1, 0, stream));
+                                     a->deg_rows, N, a->grad_WD, (long)Fo * A, A, 0, -1, 0, a->tail.gemm_workspace,
+                                     a->tail.gemm_workspace_bytes, stream));
     TRY(i3d_pna_combine_weights_bwd(a->grad_WD, a->ldw, Fh, Fo, A, a->n_groups, a->n_scalers, a->coef, a->grad_W, stream));
     TRY(i3d_colsum(a->grad_pre, nullptr, N, Fo, a->grad_bias, a->tail.workspace, stream));
     TRY(i3d_gemm_f32(0, 0, N, Fh, Fo, a->grad_pre, Fo, a->W, a->ldw, a->grad_h, Fh, nullptr, 0, stream));

@@ -50,6 +50,9 @@ struct GemmArgs {
     const int* k_rows;      // row-segment kernel: reduction index k lives at row k_rows[k] of both operands
     const int* tile_group;  // [ceil(M/BM)] or null: B of m-tile t is g.B + tile_group[t] * b_group_stride
     long b_group_stride;    // floats
+    float* slab;            // split-K / row segments: blockIdx.z slice z stores its partial tile to slab[z][M][N]
+                            // (plain 16-byte stores), slab_reduce_kernel sums the slices in a fixed order: deterministic
+                            // and cheaper than fp32 atomics on top of a zero-fill.  null: atomics.
 };
 
 __device__ __forceinline__ int swz(int k, int idx) { return idx ^ ((((k) ^ (k >> 2)) & 1) << 4); }
@@ -307,6 +310,12 @@ gemm_f32_kernel(GemmArgs g) {
     xcd_tile(bx, by, bz);
     const int k_begin = bz * g.k_per_split;
     const int k_end = min(g.K, k_begin + g.k_per_split);
+    if (g.slab != nullptr) {           // every slice writes (zeros for an empty one): the reduction reads them all
+        GemmArgs gl = g;
+        gl.ldc = g.N; gl.accumulate = 0; gl.atomic_out = 0; gl.c_vec = (g.N % 4 == 0); gl.bias = nullptr;
+        gemm_body<S, VEC, A_KC, B_KC, false>(gl, bx, by, min(k_begin, g.K), k_end, g.slab + (long)bz * g.M * g.N, nullptr, false);
+        return;
+    }
     if (k_begin >= k_end && !(bz == 0)) return;
     gemm_body<S, VEC, A_KC, B_KC, false>(g, bx, by, k_begin, k_end, g.C, nullptr, bz == 0);
 }
@@ -320,7 +329,118 @@ gemm_f32_rowseg_kernel(GemmArgs g, SegTable segs) {
     const Seg sg = segs.s[bz];
     for (int i = threadIdx.x; i < sg.k_end - sg.k_begin; i += 256) kidx[i] = g.k_rows[sg.k_begin + i];
     __syncthreads();
+    if (g.slab != nullptr) {
+        GemmArgs gl = g;
+        gl.ldc = g.N; gl.accumulate = 0; gl.atomic_out = 0; gl.c_vec = (g.N % 4 == 0);
+        gemm_body<S, VEC, false, false, true>(gl, bx, by, sg.k_begin, sg.k_end, g.slab + (long)bz * g.M * g.N, kidx, false);
+        return;
+    }
     gemm_body<S, VEC, false, false, true>(g, bx, by, sg.k_begin, sg.k_end, g.C + sg.c_off, kidx, false);
+}
+
+// C_g[m, n] (+)= sum_{z in [seg_ptr[g], seg_ptr[g+1])} slab[z][m][n]   (fixed order: deterministic)
+struct SlabReduce {
+    const float* slab;
+    float* C;
+    const float* bias;
+    int M, N, ldc, accumulate, n_groups;
+    long c_group_stride;
+    int seg_ptr[34];
+};
+
+template <int V>
+__global__ void __launch_bounds__(256) slab_reduce_kernel(SlabReduce a) {
+    const int NV = a.N / V;
+    const long per_group = (long)a.M * NV;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per_group * a.n_groups) return;
+    const int gi = (int)(t / per_group);
+    const long r = t - gi * per_group;
+    const int m = (int)(r / NV), n = (int)(r - (long)m * NV) * V;
+    float* c = a.C + gi * a.c_group_stride + (long)m * a.ldc + n;
+    float acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = a.accumulate ? c[i] : 0.f;
+    const long slice = (long)a.M * a.N;
+    const float* p = a.slab + (long)m * a.N + n;
+    for (int z = a.seg_ptr[gi]; z < a.seg_ptr[gi + 1]; ++z) {
+        if (V == 4) {
+            float4 x = *reinterpret_cast<const float4*>(p + z * slice);
+            acc[0] += x.x; acc[1 % V] += x.y; acc[2 % V] += x.z; acc[3 % V] += x.w;
+        } else {
+            acc[0] += p[z * slice];
+        }
+    }
+    if (a.bias != nullptr) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] += a.bias[n + i];
+    }
+    if (V == 4) *reinterpret_cast<float4*>(c) = make_float4(acc[0], acc[1 % V], acc[2 % V], acc[3 % V]);
+    else c[0] = acc[0];
+}
+
+// few outputs, many slices (the 20-wide 3D network: 400 outputs, ~270 slices): 16 lanes share the slices of one output
+// item and are combined through LDS in lane order (still a fixed summation order)
+constexpr int ZL = 16;
+template <int V>
+__global__ void __launch_bounds__(256) slab_reduce_small_kernel(SlabReduce a) {
+    __shared__ float sm[256 / ZL][ZL][V];
+    const int NV = a.N / V;
+    const long per_group = (long)a.M * NV;
+    const int il = threadIdx.x / ZL, zl = threadIdx.x % ZL;
+    const long t = (long)blockIdx.x * (256 / ZL) + il;
+    const bool live = t < per_group * a.n_groups;
+    int gi = 0, m = 0, n = 0;
+    float acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = 0.f;
+    if (live) {
+        gi = (int)(t / per_group);
+        const long r = t - gi * per_group;
+        m = (int)(r / NV);
+        n = (int)(r - (long)m * NV) * V;
+        const long slice = (long)a.M * a.N;
+        const float* p = a.slab + (long)m * a.N + n;
+        for (int z = a.seg_ptr[gi] + zl; z < a.seg_ptr[gi + 1]; z += ZL) {
+            if (V == 4) {
+                float4 x = *reinterpret_cast<const float4*>(p + z * slice);
+                acc[0] += x.x; acc[1 % V] += x.y; acc[2 % V] += x.z; acc[3 % V] += x.w;
+            } else {
+                acc[0] += p[z * slice];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) sm[il][zl][i] = acc[i];
+    __syncthreads();
+    if (!live || zl != 0) return;
+    float* c = a.C + gi * a.c_group_stride + (long)m * a.ldc + n;
+    float tot[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) tot[i] = a.accumulate ? c[i] : 0.f;
+    for (int k = 0; k < ZL; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) tot[i] += sm[il][k][i];
+    if (a.bias != nullptr) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) tot[i] += a.bias[n + i];
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) c[i] = tot[i];
+}
+
+static void launch_slab_reduce(const SlabReduce& a, hipStream_t s) {
+    const bool v4 = a.N % 4 == 0 && a.ldc % 4 == 0 && a.c_group_stride % 4 == 0 && (((uintptr_t)a.C | (uintptr_t)a.slab) & 15) == 0;
+    const long items = (long)a.n_groups * a.M * (v4 ? a.N / 4 : a.N);
+    const int slices = a.seg_ptr[a.n_groups] - a.seg_ptr[0];
+    if (items <= 8192 && slices >= 4 * ZL) {
+        dim3 grid(cdiv(items, 256 / ZL));
+        if (v4) hipLaunchKernelGGL(slab_reduce_small_kernel<4>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(slab_reduce_small_kernel<1>, grid, dim3(256), 0, s, a);
+        return;
+    }
+    if (v4) hipLaunchKernelGGL(slab_reduce_kernel<4>, dim3(cdiv(items, 256)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(slab_reduce_kernel<1>, dim3(cdiv(items, 256)), dim3(256), 0, s, a);
 }
 
 // layout: 0 forward (A and B k-contiguous), 1 data gradient (A k-contiguous, B idx-contiguous),
@@ -385,6 +505,9 @@ struct Extra {
     const int* group_start = nullptr;
     const int* group_count = nullptr;
     long c_group_stride = 0;
+    // scratch for the two-stage split-K / row-segment reduction (slices x M x N floats); null or too small: atomics
+    void* workspace = nullptr;
+    long workspace_bytes = 0;
 };
 
 static int fill_views(GemmArgs& g, int trans_a, int trans_b, int M, int N, int K, int lda, int ldb, const Extra& ex) {
@@ -412,6 +535,7 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.accumulate = accumulate ? 1 : 0;
     g.m_rows = ex.m_rows; g.k_rows = nullptr; g.tile_group = ex.tile_group; g.b_group_stride = ex.b_group_stride;
+    g.slab = nullptr;
     int rc = fill_views(g, trans_a, trans_b, M, N, K, lda, ldb, ex);
     if (rc != I3D_OK) return rc;
     const bool a_al = (((uintptr_t)A & 15) == 0) && (lda % 4 == 0), b_al = (((uintptr_t)B & 15) == 0) && (ldb % 4 == 0);
@@ -436,7 +560,9 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     // the batch is small for a 256-CU chip, so many 64x64 tiles beat fewer big ones until there are thousands of tiles.
     int cfg;
     const long tiles64 = (long)cdiv(M, 64) * cdiv(N, 64);
+    const bool have_ws = ex.workspace != nullptr && (((uintptr_t)ex.workspace & 15) == 0) && ex.m_rows == nullptr;
     if (trans_a && M <= 32 && N <= 32) cfg = 8;
+    else if (trans_a && have_ws && tiles64 <= 16) cfg = 8;   // small weight gradients: 32x32 tiles, slices through the scratch
     else if (N <= 32) cfg = 1;
     else if (tiles64 >= 4096) cfg = 0;
     else if (trans_a && tiles64 < 512) cfg = 3;   // weight gradients: few output tiles, long K
@@ -450,10 +576,17 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     const int bm = CFG_BM[cfg], bn = CFG_BN[cfg], BK = CFG_BK[cfg];
     int tiles = cdiv(M, bm) * cdiv(N, bn);
     int splits = 1;
-    // split-K (fp32 atomics, order not deterministic) ONLY for the row-reduction GEMMs of the backward pass
-    // (trans_a: dW = dY^T X, K = number of rows).  Forward GEMMs stay single-pass and bit-deterministic, so that
-    // the arg-max/arg-min routing of the aggregators and readouts cannot flip from run to run on near-ties.
-    if (trans_a && tiles < 512 && K >= 1024) {   // until ~512 workgroups (the atomics of the epilogue are not free), >= 512 of K per split
+    // split-K ONLY for the row-reduction GEMMs of the backward pass (trans_a: dW = dY^T X, K = number of rows).
+    // Forward GEMMs stay single-pass and bit-deterministic, so that the arg-max/arg-min routing of the aggregators and
+    // readouts cannot flip from run to run on near-ties.  With scratch the slices are summed in a fixed order by
+    // slab_reduce_kernel (>= 1024 of K per slice, up to ~800 workgroups); without it they are fp32 atomics on top of a
+    // zero-fill (not free: up to ~512 workgroups, >= 512 of K per slice).
+    if (trans_a && have_ws && tiles < 800 && K >= 2048) {
+        splits = (800 + tiles / 2) / tiles;
+        int max_splits = K / 1024;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    } else if (trans_a && tiles < 512 && K >= 1024) {
         splits = (512 + tiles - 1) / tiles;
         int max_splits = K / 512;
         if (splits > max_splits) splits = max_splits;
@@ -465,7 +598,13 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     splits = K > 0 ? cdiv(K, kps) : 1;
     g.k_per_split = kps;
     g.atomic_out = splits > 1;
-    if (splits > 1 && !accumulate) {
+    const bool use_slab = splits > 1 && ex.workspace != nullptr && (long)splits * M * N * 4 <= ex.workspace_bytes &&
+                          (((uintptr_t)ex.workspace & 15) == 0) && ex.m_rows == nullptr;
+    if (use_slab) {
+        g.slab = (float*)ex.workspace;
+        g.atomic_out = 0;
+    }
+    if (splits > 1 && !accumulate && !use_slab) {
         // atomics accumulate on top of zeros
         hipError_t e = (ldc == N) ? hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), s)
                                   : hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s);
@@ -486,6 +625,13 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
         default: launch<Cfg8>(g, layout, splits, vec, s); break;
     }
     I3D_CHECK_LAUNCH();
+    if (use_slab) {
+        SlabReduce r;
+        r.slab = g.slab; r.C = C; r.bias = bias; r.M = M; r.N = N; r.ldc = ldc; r.accumulate = accumulate ? 1 : 0;
+        r.n_groups = 1; r.c_group_stride = 0; r.seg_ptr[0] = 0; r.seg_ptr[1] = splits;
+        launch_slab_reduce(r, s);
+        I3D_CHECK_LAUNCH();
+    }
     return I3D_OK;
 }
 
@@ -509,10 +655,13 @@ static int rowseg_impl(int M, int N, const float* A, int lda, const float* B, in
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.accumulate = 1; g.atomic_out = 1; g.k_per_split = 0;
     g.m_rows = nullptr; g.k_rows = ex.k_rows; g.tile_group = nullptr; g.b_group_stride = 0;
+    g.slab = nullptr;
     int rc = fill_views(g, 1, 0, M, N, k_hi, lda, ldb, ex);
     if (rc != I3D_OK) return rc;
     g.c_vec = (((uintptr_t)C & 15) == 0) && (ldc % 4 == 0);
-    if (!accumulate) {
+    // upper bound of the number of segments (>= 512 rows each unless forced): enough scratch -> two-stage reduction
+    const bool want_slab = ex.workspace != nullptr && (((uintptr_t)ex.workspace & 15) == 0) && ex.n_groups <= 32;
+    if (!accumulate && !want_slab) {
         for (int gi = 0; gi < ex.n_groups; ++gi) {
             float* Cg = C + gi * ex.c_group_stride;
             hipError_t e = (ldc == N) ? hipMemsetAsync(Cg, 0, (size_t)M * N * sizeof(float), s)
@@ -523,8 +672,14 @@ static int rowseg_impl(int M, int N, const float* A, int lda, const float* B, in
             }
         }
     }
-    if (total == 0) return I3D_OK;
-    int cfg = 3;
+    if (total == 0) {
+        if (!accumulate && want_slab)
+            for (int gi = 0; gi < ex.n_groups; ++gi)
+                if (hipMemset2DAsync(C + gi * ex.c_group_stride, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess)
+                    return I3D_ERR_LAUNCH;
+        return I3D_OK;
+    }
+    int cfg = want_slab ? 2 : 3;      // measured (tools/gemm_bench.py): 64x64 tiles once the epilogue is a plain store
     if (force_cfg >= 0) {
         I3D_CHECK_ARG(force_cfg >= 2 && force_cfg <= 4, "row-subset GEMM: tile_cfg must be 2, 3 or 4");
         cfg = force_cfg;
@@ -533,9 +688,10 @@ static int rowseg_impl(int M, int N, const float* A, int lda, const float* B, in
     const int tiles = cdiv(M, CFG_BM[cfg]) * cdiv(N, CFG_BN[cfg]);
     // the atomics of the epilogue are the expensive part of a segment: ~1000 workgroups, >= 1024 rows per segment
     long want = std::max<long>(ex.n_groups, (1024 + tiles / 2) / tiles);
-    long seg_rows = std::max<long>(1024, (long)cdiv((int)cdiv((int)total, (int)want), BK) * BK);
+    long seg_rows = std::max<long>(want_slab ? 512 : 1024, (long)cdiv((int)cdiv((int)total, (int)want), BK) * BK);
     if (force_seg_rows > 0) seg_rows = (long)cdiv(force_seg_rows, BK) * BK;
     SegTable t;
+    int seg_first[33];          // first segment of every group (segments of a group are consecutive table entries)
     int n_segs;
     for (;;) {
         if (seg_rows > SEG_MAX_K) seg_rows = SEG_MAX_K;
@@ -543,6 +699,7 @@ static int rowseg_impl(int M, int N, const float* A, int lda, const float* B, in
         bool fits = true;
         for (int gi = 0; gi < ex.n_groups && fits; ++gi) {
             const int b = ex.group_start[gi], e = b + ex.group_count[gi];
+            if (gi < 33) seg_first[gi] = n_segs;
             for (int k = b; k < e; k += (int)seg_rows) {
                 if (n_segs == MAX_SEGS) { fits = false; break; }
                 t.s[n_segs++] = Seg{k, std::min<int>(e, k + (int)seg_rows), gi * ex.c_group_stride};
@@ -554,12 +711,36 @@ static int rowseg_impl(int M, int N, const float* A, int lda, const float* B, in
     }
     const bool vec = (((uintptr_t)A & 15) == 0) && (lda % 4 == 0) && (((uintptr_t)B & 15) == 0) && (ldb % 4 == 0) &&
                      (M % 4 == 0) && (N % 4 == 0);
+    const bool use_slab = want_slab && (long)n_segs * M * N * 4 <= ex.workspace_bytes;
+    if (use_slab) {
+        g.slab = (float*)ex.workspace;
+        g.atomic_out = 0;
+    } else if (want_slab && !accumulate) {       // scratch too small after all: atomics on top of zeros
+        for (int gi = 0; gi < ex.n_groups; ++gi) {
+            float* Cg = C + gi * ex.c_group_stride;
+            hipError_t e = (ldc == N) ? hipMemsetAsync(Cg, 0, (size_t)M * N * sizeof(float), s)
+                                      : hipMemset2DAsync(Cg, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s);
+            if (e != hipSuccess) {
+                set_error("i3d_gemm_f32_rowsubset: memset failed");
+                return I3D_ERR_LAUNCH;
+            }
+        }
+    }
     switch (cfg) {
         case 2: launch_rowseg<Cfg2>(g, t, n_segs, vec, s); break;
         case 3: launch_rowseg<Cfg3>(g, t, n_segs, vec, s); break;
         default: launch_rowseg<Cfg4>(g, t, n_segs, vec, s); break;
     }
     I3D_CHECK_LAUNCH();
+    if (use_slab) {
+        SlabReduce r;
+        r.slab = g.slab; r.C = C; r.bias = nullptr; r.M = M; r.N = N; r.ldc = ldc; r.accumulate = accumulate ? 1 : 0;
+        r.n_groups = ex.n_groups; r.c_group_stride = ex.c_group_stride;
+        for (int gi = 0; gi < ex.n_groups; ++gi) r.seg_ptr[gi] = seg_first[gi];
+        r.seg_ptr[ex.n_groups] = n_segs;
+        launch_slab_reduce(r, s);
+        I3D_CHECK_LAUNCH();
+    }
     return I3D_OK;
 }
 
@@ -574,9 +755,18 @@ extern "C" int i3d_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
 
 extern "C" int i3d_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
                                int ldb, float* C, int ldc, const float* bias, int accumulate, int tile_cfg,
-                               int splits, void* stream) {
-    return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, tile_cfg, splits, Extra(),
-                     stream);
+                               int splits, void* workspace, long workspace_bytes, void* stream) {
+    Extra ex;
+    ex.workspace = workspace; ex.workspace_bytes = workspace_bytes;
+    return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, tile_cfg, splits, ex, stream);
+}
+
+extern "C" int i3d_gemm_f32_ws(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
+                               int ldb, float* C, int ldc, const float* bias, int accumulate, void* workspace,
+                               long workspace_bytes, void* stream) {
+    Extra ex;
+    ex.workspace = workspace; ex.workspace_bytes = workspace_bytes;
+    return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, -1, 0, ex, stream);
 }
 
 // C[m_rows[m], :] (+)= A[m_rows[m], :] * op(B_g),  g = tile_group[m / 64];  m_rows is padded with -1 to 64 per group
@@ -606,9 +796,11 @@ extern "C" int i3d_gemm_f32_rowsubset(int M, int N, int n_rows, const float* A, 
 extern "C" int i3d_gemm_f32_rowsubset_multi(int M, int N, int n_groups, const int* group_start, const int* group_count,
                                             const float* A, int lda, const float* B, int ldb, const int* k_rows,
                                             long rows_total, float* C, long c_group_stride, int ldc, int accumulate,
-                                            int tile_cfg, int seg_rows, void* stream) {
+                                            int tile_cfg, int seg_rows, void* workspace, long workspace_bytes,
+                                            void* stream) {
     I3D_CHECK_ARG(k_rows != nullptr && group_start != nullptr && group_count != nullptr && n_groups > 0, "bad arguments");
     Extra ex;
+    ex.workspace = workspace; ex.workspace_bytes = workspace_bytes;
     ex.k_rows = k_rows; ex.k_rows_total = rows_total;
     ex.n_groups = n_groups; ex.group_start = group_start; ex.group_count = group_count; ex.c_group_stride = c_group_stride;
     return rowseg_impl(M, N, A, lda, B, ldb, C, ldc, accumulate, tile_cfg, seg_rows, ex, stream);

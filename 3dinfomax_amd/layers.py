@@ -181,7 +181,13 @@ def _fill_tail(tail, spec: FCSpec, gamma, beta, mean, invstd, feat, device):
     tail.gamma, tail.beta = gamma.data_ptr(), beta.data_ptr()
     tail.running_mean, tail.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
     tail.mean, tail.invstd = mean.data_ptr(), invstd.data_ptr()
+    _set_workspaces(tail, feat, device)
+
+
+def _set_workspaces(tail, feat, device):
+    # per thread and stream (the backward runs on autograd's thread)
     tail.workspace = ops._workspace(feat, device).data_ptr()
+    tail.gemm_workspace, tail.gemm_workspace_bytes = ops._gemm_workspace(device).data_ptr(), ops.GEMM_WORKSPACE_BYTES
 
 
 def _keeps_pre(spec):
@@ -232,7 +238,7 @@ class FCFn(torch.autograd.Function):
             gg, gb, gbias = _f32((f_out,), dev), _f32((f_out,), dev), _f32((f_out,), dev)
             gW = torch.empty_like(W)
             gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-            a.tail.workspace = ops._workspace(f_out, dev).data_ptr()
+            _set_workspaces(a.tail, f_out, dev)
             a.grad_y, a.grad_pre, a.grad_gamma, a.grad_beta = grad_y.data_ptr(), grad_pre.data_ptr(), gg.data_ptr(), gb.data_ptr()
             a.grad_W, a.grad_bias, a.grad_x = gW.data_ptr(), gbias.data_ptr(), _ptr(gx)
             _call('i3d_fc_bn_bwd', a)
@@ -341,7 +347,7 @@ class GroupedConcat2FCFn(torch.autograd.Function):
             grad_pre, gWD = _f32((N, f_out), dev), torch.empty_like(WD)
             gg, gb, gbias = _f32((f_out,), dev), _f32((f_out,), dev), _f32((f_out,), dev)
             gW, gh, ga = torch.empty_like(W), torch.empty_like(h), torch.empty_like(a)
-            c.tail.workspace = ops._workspace(f_out, dev).data_ptr()
+            _set_workspaces(c.tail, f_out, dev)
             c.grad_y, c.grad_pre, c.grad_WD = grad_y.data_ptr(), grad_pre.data_ptr(), gWD.data_ptr()
             c.grad_gamma, c.grad_beta, c.grad_W, c.grad_bias = gg.data_ptr(), gb.data_ptr(), gW.data_ptr(), gbias.data_ptr()
             c.grad_h, c.grad_agg = gh.data_ptr(), ga.data_ptr()
@@ -438,7 +444,7 @@ class EdgeFCFn(torch.autograd.Function):
             if ctx.has_q and ctx.qmap is not None:
                 gQ = _f32((ctx.qmap.v_pad, Fo), dev)
                 a.grad_Q = gQ.data_ptr()
-            a.tail.workspace = ops._workspace(Fo, dev).data_ptr()
+            _set_workspaces(a.tail, Fo, dev)
             a.grad_y, a.grad_pre, a.grad_P = grad_y.data_ptr(), grad_pre.data_ptr(), gP.data_ptr()
             a.grad_gamma, a.grad_beta, a.grad_W, a.grad_bias = gg.data_ptr(), gb.data_ptr(), gW.data_ptr(), gbias.data_ptr()
             a.grad_h, a.grad_q = gh.data_ptr(), _ptr(gq)

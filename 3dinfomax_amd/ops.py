@@ -4,6 +4,7 @@ torch is plumbing here: it owns device memory (caching allocator) and the curren
 computation below is one of the hand-written gfx950 kernels in csrc/.  No autograd in this file - the
 autograd.Functions in layers.py / pna.py / net3d.py / losses.py chain these calls explicitly.
 """
+import os
 import threading
 
 import torch
@@ -46,6 +47,23 @@ def _workspace(feat, device):
     if buf is None or buf.numel() < need:
         buf = ws[key] = torch.empty(max(need, 1 << 22), dtype=torch.uint8, device=device)
     return buf
+
+
+def _gemm_workspace(device):
+    """Thread-local scratch of the weight-gradient GEMMs (split-K / row-segment slices, include/infomax3d_hip.h
+    i3d_gemm_f32_ws), one per stream."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = getattr(_tls, 'gws', None)
+    if ws is None:
+        ws = _tls.gws = {}
+    buf = ws.get(key)
+    if buf is None:
+        buf = ws[key] = torch.empty(max(GEMM_WORKSPACE_BYTES, 16), dtype=torch.uint8, device=device)
+    return buf
+
+
+# I3D_GEMM_SCRATCH=0: fp32 atomics on top of a zero-fill instead of the two-stage reduction (A/B switch)
+GEMM_WORKSPACE_BYTES = (48 << 20) if os.environ.get('I3D_GEMM_SCRATCH', '1') != '0' else 0
 
 
 def agg_codes(names):
@@ -153,6 +171,11 @@ def gemm(A, B, trans_a=False, trans_b=False, out=None, bias=None, accumulate=Fal
         assert not accumulate
         out = torch.empty(M, N, dtype=torch.float32, device=A.device)
     L = _lib.load()
+    if trans_a and K >= 1024:     # weight gradient: the split-K slices are combined through the scratch (deterministic)
+        check(L.i3d_gemm_f32_ws(int(trans_a), int(trans_b), M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), _ld(out),
+                                _p(bias), int(accumulate), _p(_gemm_workspace(A.device)), GEMM_WORKSPACE_BYTES, _stream()),
+              'i3d_gemm_f32_ws')
+        return out
     check(L.i3d_gemm_f32(int(trans_a), int(trans_b), M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), _ld(out),
                          _p(bias), int(accumulate), _stream()), 'i3d_gemm_f32')
     return out
@@ -425,7 +448,8 @@ def gemm_grouped(A, m_rows, tile_group, Bg, out, trans_b, accumulate):
     return out
 
 
-def gemm_rowsubset_multi(A, B, k_rows, group_start, group_count, out, accumulate=False, tile_cfg=-1, seg_rows=0):
+def gemm_rowsubset_multi(A, B, k_rows, group_start, group_count, out, accumulate=False, tile_cfg=-1, seg_rows=0,
+                         use_workspace=True):
     """out[g] = sum over j in [group_start[g], +group_count[g]) of A[k_rows[j],:]^T B[k_rows[j],:]; out: [G, M, N]."""
     _chk(A)
     _chk(B)
@@ -435,7 +459,9 @@ def gemm_rowsubset_multi(A, B, k_rows, group_start, group_count, out, accumulate
     check(_lib.load().i3d_gemm_f32_rowsubset_multi(A.shape[1], B.shape[1], G, int_array(list(group_start)),
                                                    int_array(list(group_count)), _p(A), A.shape[1], _p(B), B.shape[1],
                                                    _p(k_rows), A.shape[0], _p(out), out.shape[1] * out.shape[2],
-                                                   out.shape[2], int(accumulate), tile_cfg, seg_rows, _stream()),
+                                                   out.shape[2], int(accumulate), tile_cfg, seg_rows,
+                                                   _p(_gemm_workspace(A.device)) if use_workspace else None,
+                                                   GEMM_WORKSPACE_BYTES if use_workspace else 0, _stream()),
           'i3d_gemm_f32_rowsubset_multi')
     return out
 

@@ -107,7 +107,14 @@ int i3d_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float* A, 
  * v_mfma_f32_16x16x4_f32; 4: 64x64x16, 5: 128x128x16 on v_mfma_f32_32x32x2_f32; -1 = auto) and the split-K factor
  * (0 = auto) - used by tools/gemm_bench.py to pick the dispatch heuristics */
 int i3d_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                    float* C, int ldc, const float* bias, int accumulate, int tile_cfg, int splits, void* stream);
+                    float* C, int ldc, const float* bias, int accumulate, int tile_cfg, int splits, void* workspace,
+                    long workspace_bytes, void* stream);
+/* i3d_gemm_f32 with scratch: when the reduction dimension is split over workgroups (weight gradients), the slices are
+ * written to workspace[slices][M][N] and summed in a fixed order by a second kernel (deterministic, no zero-fill, no
+ * atomics).  workspace NULL or too small: fp32 atomics as i3d_gemm_f32. */
+int i3d_gemm_f32_ws(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                    float* C, int ldc, const float* bias, int accumulate, void* workspace, long workspace_bytes,
+                    void* stream);
 
 /* ---- degree-grouped posttrans of the PNA layer ------------------------------------------------------
  * replaces cat([h, agg]) -> posttrans Linear of reference models/pna.py:207-209 for the aggregated part:  the three
@@ -122,7 +129,8 @@ int i3d_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, const float* 
  *  gemm_f32_rowsubset:  C[M, N] = sum_j A[k_rows[j], 0:M]^T B[k_rows[j], 0:N]   (weight gradient of one group)
  *  gemm_f32_rowsubset_multi: the same for n_groups disjoint ranges [group_start[g], +group_count[g]) of k_rows in ONE
  *                       launch, C_g = C + g * c_group_stride (host arrays for the ranges; tile_cfg -1 / seg_rows 0 =
- *                       automatic; fp32 atomics over the row segments, like the split-K weight gradients) */
+ *                       automatic; the row segments are combined through `workspace` like i3d_gemm_f32_ws, or with
+ *                       fp32 atomics when it is NULL / too small) */
 int i3d_pna_combine_weights_fwd(const float* W, int ldw, int f_in, int f_out, int agg_width, int n_groups,
                                 int n_scalers, const float* coef, float* WD, void* stream);
 int i3d_pna_combine_weights_bwd(const float* dWD, int ldw, int f_in, int f_out, int agg_width, int n_groups,
@@ -135,7 +143,7 @@ int i3d_gemm_f32_rowsubset(int M, int N, int n_rows, const float* A, int lda, co
 int i3d_gemm_f32_rowsubset_multi(int M, int N, int n_groups, const int* group_start, const int* group_count,
                                  const float* A, int lda, const float* B, int ldb, const int* k_rows, long rows_total,
                                  float* C, long c_group_stride, int ldc, int accumulate, int tile_cfg, int seg_rows,
-                                 void* stream);
+                                 void* workspace, long workspace_bytes, void* stream);
 
 /* ---- column statistics / BatchNorm1d ---------------------------------------------------------------
  * replaces nn.BatchNorm1d in FCLayer (train: batch statistics, momentum m, unbiased running_var; eval: running
@@ -260,6 +268,8 @@ typedef struct {
     float* mean;
     float* invstd;
     void* workspace; /* i3d_colreduce_workspace_bytes(rows, f_out) */
+    void* gemm_workspace; /* scratch of the weight-gradient GEMMs of the backward (i3d_gemm_f32_ws), may be NULL */
+    long gemm_workspace_bytes;
 } I3dBnTail;
 
 typedef struct { /* y = tail(x W^T + b) */

@@ -86,15 +86,28 @@ def test_gemm_split_k_into_strided_column_block(rows):
     L = importlib.import_module('3dinfomax_amd._lib')
     from ctypes import c_void_p
     lib = L.load()
-    for cfg, splits in ((4, 4), (3, 16), (2, 2), (0, 7)):
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    for cfg, splits, scratch in ((4, 4, 0), (3, 16, 0), (2, 2, 0), (0, 7, 0), (3, 16, 64 << 20), (2, 5, 64 << 20), (8, 3, 64 << 20),
+                                 (3, 16, 1 << 20)):    # the last one: scratch too small -> atomics
         out = torch.full((Fo, Fa + Fc), 7.0, device=DEV)
         A, B = g(dY), g(c)
         rc = lib.i3d_gemm_f32_ex(1, 0, Fo, Fc, rows, c_void_p(A.data_ptr()), Fo, c_void_p(B.data_ptr()), Fc,
                                  c_void_p(out[:, Fa:].data_ptr()), Fa + Fc, None, 0, cfg, splits,
+                                 c_void_p(ws.data_ptr()) if scratch else None, scratch,
                                  c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0
-        assert rel_err(out[:, Fa:].cpu(), ref[:, Fa:]) < 2e-5, (cfg, splits)
+        assert rel_err(out[:, Fa:].cpu(), ref[:, Fa:]) < 2e-5, (cfg, splits, scratch)
         assert torch.all(out[:, :Fa] == 7.0)
+        if scratch >= (64 << 20):        # two-stage reduction: bit-identical from run to run, accumulate adds on top
+            out2 = torch.full((Fo, Fa + Fc), 7.0, device=DEV)
+            lib.i3d_gemm_f32_ex(1, 0, Fo, Fc, rows, c_void_p(A.data_ptr()), Fo, c_void_p(B.data_ptr()), Fc,
+                                c_void_p(out2[:, Fa:].data_ptr()), Fa + Fc, None, 0, cfg, splits, c_void_p(ws.data_ptr()), scratch,
+                                c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert torch.equal(out, out2)
+            lib.i3d_gemm_f32_ex(1, 0, Fo, Fc, rows, c_void_p(A.data_ptr()), Fo, c_void_p(B.data_ptr()), Fc,
+                                c_void_p(out2[:, Fa:].data_ptr()), Fa + Fc, None, 1, cfg, splits, c_void_p(ws.data_ptr()), scratch,
+                                c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rel_err(out2[:, Fa:].cpu(), 2 * ref[:, Fa:]) < 2e-5
 
 
 def test_degree_grouped_posttrans_gemms():
@@ -134,9 +147,11 @@ def test_degree_grouped_posttrans_gemms():
     # ... and all groups in one launch (several tile configurations / segment lengths)
     for cfg, seg in ((-1, 0), (3, 128), (4, 64), (2, 2048)):
         gWD2 = torch.full_like(WD, 3.0)
-        ops.gemm_rowsubset_multi(g(dY), g(a), rows_d, [st for _, st, _ in groups], [ct for _, _, ct in groups], gWD2,
-                                 tile_cfg=cfg, seg_rows=seg)
-        assert rel_err(gWD2.cpu(), gWD.cpu()) < 2e-6, (cfg, seg)
+        for use_ws in (True, False):     # scratch + fixed-order reduction / fp32 atomics
+            gWD2 = torch.full_like(WD, 3.0)
+            ops.gemm_rowsubset_multi(g(dY), g(a), rows_d, [st for _, st, _ in groups], [ct for _, _, ct in groups], gWD2,
+                                     tile_cfg=cfg, seg_rows=seg, use_workspace=use_ws)
+            assert rel_err(gWD2.cpu(), gWD.cpu()) < 2e-6, (cfg, seg, use_ws)
     gW = torch.full((F_out, 200 + S * A), 7.0, device=DEV)
     ops.combine_weights_bwd(gWD, gW, 200, A, flat, len(groups), S)
     ref_gW = dY.double().T @ agg12.double()

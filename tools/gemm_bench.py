@@ -34,14 +34,22 @@ SHAPES = [  # name, ta, tb, M, N, K
 ]
 
 
-def run(lib, ta, tb, M, N, K, cfg, splits, reps=20):
+WS_BYTES = 64 << 20
+_ws = None
+
+
+def run(lib, ta, tb, M, N, K, cfg, splits, reps=20, scratch=True):
     dev = torch.device('cuda:0')
     A = torch.randn((K, M) if ta else (M, K), device=dev)
     B = torch.randn((N, K) if tb else (K, N), device=dev)
     C = torch.empty(M, N, device=dev)
     st = c_void_p(torch.cuda.current_stream().cuda_stream)
+    global _ws
+    if _ws is None:
+        _ws = torch.empty(WS_BYTES, dtype=torch.uint8, device=dev)
     args = (ta, tb, M, N, K, c_void_p(A.data_ptr()), A.shape[1], c_void_p(B.data_ptr()), B.shape[1],
-            c_void_p(C.data_ptr()), N, None, 0, cfg, splits, st)
+            c_void_p(C.data_ptr()), N, None, 0, cfg, splits, c_void_p(_ws.data_ptr()) if scratch else None,
+            WS_BYTES if scratch else 0, st)
     for _ in range(3):
         assert lib.i3d_gemm_f32_ex(*args) == 0, lib.i3d_last_error()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -57,7 +65,7 @@ def run(lib, ta, tb, M, N, K, cfg, splits, reps=20):
     return us, 2.0 * M * N * K / us * 1e-6, err
 
 
-def run_rowseg(lib, cfg, seg_rows, reps=20):
+def run_rowseg(lib, cfg, seg_rows, reps=20, scratch=True):
     """weight gradients of the in-degree groups (QM9-like degree histogram) in one launch"""
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
@@ -77,7 +85,8 @@ def run_rowseg(lib, cfg, seg_rows, reps=20):
     ia = lambda v: (ctypes.c_int * len(v))(*v)
     st = c_void_p(torch.cuda.current_stream().cuda_stream)
     args = (F, 4 * F, G, ia(starts), ia(cnts), c_void_p(dY.data_ptr()), F, c_void_p(a.data_ptr()), 4 * F,
-            c_void_p(rows.data_ptr()), N_NODES, c_void_p(out.data_ptr()), F * 4 * F, 4 * F, 0, cfg, seg_rows, st)
+            c_void_p(rows.data_ptr()), N_NODES, c_void_p(out.data_ptr()), F * 4 * F, 4 * F, 0, cfg, seg_rows,
+            c_void_p(_ws.data_ptr()) if scratch else None, WS_BYTES if scratch else 0, st)
     for _ in range(3):
         assert lib.i3d_gemm_f32_rowsubset_multi(*args) == 0, lib.i3d_last_error()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -101,6 +110,9 @@ if __name__ == '__main__':
     for name, ta, tb, M, N, K in SHAPES:
         us, tf, err = run(lib, ta, tb, M, N, K, -1, 0)
         print(f'{name} M={M:6d} N={N:5d} K={K:6d}  auto: {us:8.1f} us {tf:7.1f} TF  err {err:.1e}', flush=True)
+        if ta:
+            us, tf, err = run(lib, ta, tb, M, N, K, -1, 0, scratch=False)
+            print(f'{name} M={M:6d} N={N:5d} K={K:6d}  auto, fp32 atomics instead of scratch: {us:8.1f} us {tf:7.1f} TF', flush=True)
         if a.all_cfgs:
             wgrad = bool(ta)
             for cfg in ((3, 2, 8, 1) if wgrad else (0, 2, 4, 5, 6, 7)):
@@ -109,4 +121,6 @@ if __name__ == '__main__':
                     print(f'      cfg {cfg:2d} splits {splits:2d}: {us:8.1f} us {tf:7.1f} TF  err {err:.1e}', flush=True)
     for cfg, seg in ((-1, 0), (3, 256), (3, 512), (3, 1024), (3, 2048), (2, 512), (2, 1024), (4, 512), (4, 1024), (4, 2048)):
         us, tf, err = run_rowseg(lib, cfg, seg)
-        print(f'rowseg wgrad 5 groups [F x 4F] cfg {cfg:2d} seg_rows {seg:4d}: {us:8.1f} us {tf:7.1f} TF  err {err:.1e}', flush=True)
+        us2, _, _ = run_rowseg(lib, cfg, seg, scratch=False)
+        print(f'rowseg wgrad 5 groups [F x 4F] cfg {cfg:2d} seg_rows {seg:4d}: {us:8.1f} us {tf:7.1f} TF  err {err:.1e}   '
+              f'(atomics: {us2:.1f} us)', flush=True)
