@@ -31,10 +31,13 @@ def __getattr__(name):
     if name in ('AtomEncoder', 'BondEncoder'):
         from . import mol_encoder
         return getattr(mol_encoder, name)
+    if name == 'Adam':
+        from . import optim
+        return optim.Adam
     raise AttributeError(name)
 
 
 __all__ = ['PNA', 'PNAGNN', 'PNALayer', 'PNA_AGGREGATORS', 'PNA_SCALERS', 'PNAOriginal', 'PNAOriginalSimple',
            'PNAGNNOriginal', 'PNAGNNSimple', 'PNATower', 'PNASimpleLayer', 'MLPReadout', 'Net3D', 'Net3DLayer', 'NTXent',
            'NTXentMultiplePositives', 'FCLayer', 'MLP', 'AtomEncoder', 'BondEncoder', 'contrastive_collate',
-           'conformer_collate', 'BatchedMolGraph', 'batch', 'bond_graph', 'complete_graph']
+           'conformer_collate', 'BatchedMolGraph', 'batch', 'bond_graph', 'complete_graph', 'Adam']

@@ -1,0 +1,89 @@
+"""Host-side fast path of torch.optim.Adam for the pre-training step.
+
+The reference builds `Adam(param_groups, **optimizer_params)` by name (train.py:189, trainer/trainer.py:216-238) and
+calls `optim.step()` once per batch (trainer/trainer.py:120).  SURVEY.md K12 keeps torch's optimizer - and this IS
+torch's optimizer: the same state layout (`step`, `exp_avg`, `exp_avg_sq`, so `state_dict()` round-trips with
+torch.optim.Adam), the same fused multi-tensor kernel (`torch._fused_adam_`).  The only difference is the Python in
+front of the kernel: torch re-derives the tensor lists of every group on every call (~0.6 ms for the 110 parameter
+tensors of PNA + Net3D, as much as a sixth of the whole step on this host); here they are cached and only the gradient
+list is rebuilt.  Anything outside the plain case (closure, amsgrad, maximize, capturable, tensor lr, CPU or mixed
+devices, a parameter without gradient) goes through torch's own `step()`.
+"""
+import torch
+
+
+class Adam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kwargs):
+        if 'fused' not in kwargs and 'foreach' not in kwargs:
+            kwargs['fused'] = self._all_cuda(params)
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kwargs)
+        self._lists = None
+
+    @staticmethod
+    def _all_cuda(params):
+        params = list(params)
+        flat = []
+        for p in params:
+            flat += list(p['params']) if isinstance(p, dict) else [p]
+        return len(flat) > 0 and all(t.is_cuda and t.dtype == torch.float32 for t in flat)
+
+    def _plain(self, group):
+        return (group.get('fused') and not group['amsgrad'] and not group['maximize'] and not group['capturable']
+                and not group['differentiable'] and not isinstance(group['lr'], torch.Tensor)
+                and not group.get('decoupled_weight_decay', False))
+
+    def _build_lists(self):
+        lists = []
+        for group in self.param_groups:
+            ps = group['params']
+            if not ps:
+                lists.append(None)
+                continue
+            if not self._plain(group) or any((not p.is_cuda) or p.dtype != torch.float32 or p.device != ps[0].device
+                                             or p not in self.state or len(self.state[p]) == 0 for p in ps):
+                return None
+            st = [self.state[p] for p in ps]
+            if any((not torch.is_tensor(s['step'])) or (not s['step'].is_cuda) for s in st):
+                return None
+            lists.append((list(ps), [s['exp_avg'] for s in st], [s['exp_avg_sq'] for s in st], [s['step'] for s in st]))
+        return lists
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            return super().step(closure)
+        if self._lists is None or len(self._lists) != len(self.param_groups):
+            out = super().step()              # torch initialises the state on its first call
+            self._lists = self._build_lists()
+            return out
+        work = []
+        for group, lst in zip(self.param_groups, self._lists):
+            if lst is None:
+                if group['params']:
+                    self._lists = None
+                    return super().step()
+                continue
+            ps = lst[0]
+            if len(ps) != len(group['params']) or not self._plain(group):
+                self._lists = None
+                return super().step()
+            grads = [p.grad for p in ps]
+            if any(g is None for g in grads):
+                self._lists = None
+                return super().step()
+            work.append((group, lst, grads))
+        for group, (ps, exp_avgs, exp_avg_sqs, steps), grads in work:
+            beta1, beta2 = group['betas']
+            torch._foreach_add_(steps, 1)
+            torch._fused_adam_(ps, grads, exp_avgs, exp_avg_sqs, [], steps, amsgrad=False, lr=group['lr'], beta1=beta1,
+                               beta2=beta2, weight_decay=group['weight_decay'], eps=group['eps'], maximize=False,
+                               grad_scale=None, found_inf=None)
+        return None
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._lists = None
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._lists = None

@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=512, help='molecules per GPU per step')
     ap.add_argument('--depth', type=int, default=4, help='PNA propagation depth (BASELINE.json: 4; pre-train_QM9.yml: 7)')
     ap.add_argument('--pool', type=int, default=4, help='number of distinct resident batches cycled through')
+    ap.add_argument('--torch-adam', action='store_true', help='stock torch.optim.Adam(fused=True) instead of amd.Adam')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--no-sync-bn', action='store_true', help='throughput mode without synchronised BN (parity loss)')
@@ -112,10 +113,13 @@ def main():
     named = list(pna.named_parameters()) + list(net.named_parameters())
     params = [p for _, p in named]
     # reference trainer/self_supervised_trainer.py:78-86: BN params in their own group
-    optim = torch.optim.Adam([{'params': [p for k, p in named if 'batch_norm' in k], 'weight_decay': 0},
-                              {'params': [p for k, p in named if 'batch_norm' not in k]}], lr=8e-5, fused=True)
     # fused=True: same Adam arithmetic, one multi-tensor HIP kernel per group instead of ~10 foreach launches; the
-    # reference forwards `optimizer_params` verbatim (train.py:189), so `fused: True` in the yml selects it there too
+    # reference forwards `optimizer_params` verbatim (train.py:189), so `fused: True` in the yml selects it there too.
+    # amd.Adam is torch.optim.Adam (same state, same torch._fused_adam_ kernel) with the per-step Python of torch's
+    # step() cached (3dinfomax_amd/optim.py); --torch-adam runs the stock class.
+    adam_cls = torch.optim.Adam if args.torch_adam else amd.Adam
+    optim = adam_cls([{'params': [p for k, p in named if 'batch_norm' in k], 'weight_decay': 0},
+                      {'params': [p for k, p in named if 'batch_norm' not in k]}], lr=8e-5, fused=True)
     if use_dist:
         adist.setup([pna, net], loss_fn, sync_bn=not args.no_sync_bn)
 
@@ -244,6 +248,7 @@ def main():
                    vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload=f'PNA hidden=200 depth={args.depth} + Net3D hidden=20 + NT-Xent tau=0.1, '
                                         f'QM9-shaped synthetic molecules, batch {B}/GPU, fp32, Adam',
+                               optimizer='torch.optim.Adam(fused=True)' if args.torch_adam else 'infomax3d_amd.Adam (torch.optim.Adam subclass, torch._fused_adam_ kernel, cached tensor lists)',
                                global_batch=B * world, parallelism=f'dp{world}' if world > 1 else 'single',
                                sync_bn=(use_dist and not args.no_sync_bn), final_loss=round(float(loss.item()), 5),
                                host_enqueue_ms_per_step=round(t_enqueue / args.steps * 1e3, 3),

@@ -1,6 +1,7 @@
 """-m gpu: the plugin modules (PNA / PNALayer / Net3D / NT-Xent) running on the HIP kernels against the golden
 fixtures produced by the reference itself (tests/golden/gen_golden.py) and against the oracle on bigger batches.
 Bar: BASELINE.json:north_star - node embeddings and loss within 1e-4 relative fp32."""
+import copy
 import importlib
 
 import numpy as np
@@ -292,6 +293,43 @@ def test_finetune_config_pna_only_l1_vs_oracle(amd, variant):
         grads_close(param_grads(pna), {k: P[k].grad for k in O.trainable(P)}, 2e-3, 'pna ')
     else:
         grads_close_l2(param_grads(pna), {k: P[k].grad for k in O.trainable(P)}, 5e-2, 'pna ')
+
+
+def test_adam_fast_path_is_torch_adam(amd):
+    """infomax3d_amd.Adam (cached tensor lists in front of torch._fused_adam_) against torch.optim.Adam(fused=True):
+    bit-identical parameters and state over several steps, a changing lr, and a state_dict round trip."""
+    torch.manual_seed(0)
+    shapes = [(200, 600), (200,), (7, 3), (1,), (64, 64)]
+    pa = [torch.randn(s, device='cuda:0').requires_grad_() for s in shapes]
+    pb = [p.detach().clone().requires_grad_() for p in pa]
+
+    def groups(ps):
+        return [{'params': ps[:2], 'weight_decay': 0}, {'params': ps[2:], 'weight_decay': 1e-3}]
+    oa, ob = amd.Adam(groups(pa), lr=8e-5, fused=True), torch.optim.Adam(groups(pb), lr=8e-5, fused=True)
+    for it in range(6):
+        if it == 3:
+            for o in (oa, ob):
+                for gr in o.param_groups:
+                    gr['lr'] = 3e-4
+            ob2 = torch.optim.Adam(groups(pb), lr=1.0, fused=True)      # state_dict written by amd.Adam loads into torch's
+            ob2.load_state_dict(copy.deepcopy(oa.state_dict()))
+            oa.load_state_dict(copy.deepcopy(ob.state_dict()))   # (torch shares the tensors of a state_dict it loads)
+        gs = [torch.randn(s, device='cuda:0') for s in shapes]
+        for p, q, g_ in zip(pa, pb, gs):
+            p.grad, q.grad = g_.clone(), g_.clone()
+        oa.step()
+        ob.step()
+        oa.zero_grad()
+        ob.zero_grad()
+        for p, q in zip(pa, pb):
+            assert torch.equal(p, q), it
+    for p, q in zip(pa, pb):
+        assert torch.equal(oa.state[p]['exp_avg_sq'], ob.state[q]['exp_avg_sq'])
+        assert float(oa.state[p]['step']) == float(ob.state[q]['step']) == 6
+    pa[0].grad = None                       # a parameter without gradient: falls back to torch's step
+    for p in pa[1:]:
+        p.grad = torch.ones_like(p)
+    oa.step()
 
 
 def test_missing_library_fails_loudly(amd, monkeypatch):
