@@ -85,7 +85,7 @@ _SIGNATURES = {
     'i3d_bn_finalize_stats': (c_int, [_P, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
     'i3d_bn_apply_fwd': (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P]),
     'i3d_bn_eval_fwd': (c_int, [_P, c_int, c_int, _P, _P, c_float, _P, _P, c_int, _P, _P, _P]),
-    'i3d_bn_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_long, _P, _P]),
+    'i3d_bn_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_long, _P, _P]),
     'i3d_bn_eval_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P]),
     'i3d_colsum': (c_int, [_P, _P, c_int, c_int, _P, _P, _P]),
     'i3d_act_fwd': (c_int, [_P, c_long, c_int, _P, _P]),

@@ -412,6 +412,93 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BwdApplyArgs g, RowTi
     }
 }
 
+// bn_bwd_apply + column sums of the result (the bias gradient of the Linear in front: dL/db = sum_rows grad_pre): the
+// row-chunk layout of the reduction kernels, one partial row per block, finalised by pair_final_kernel.
+template <int V>
+__global__ void __launch_bounds__(256) bn_bwd_apply_colsum_kernel(BwdApplyArgs g, Chunking ch, int rows, float* partial) {
+    __shared__ float sm[256 * 4];
+    const int t = threadIdx.x;
+    const int cl = t % ch.tpr, rlane = t / ch.tpr;
+    const int cvi = blockIdx.y * ch.tpr + cl;
+    const bool active = rlane < ch.rl && cvi < ch.cv;
+    const int c0 = cvi * V, F = g.feat;
+    float a1[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) a1[i] = 0.f;
+    if (active) {
+        const float inv_n = g.inv_n_ptr ? g.inv_n_ptr[0] : g.inv_n;
+        float mu[V], is[V], ga[V], be[V], k1[V], k2[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int c = c0 + i;
+            is[i] = g.invstd[c];
+            mu[i] = g.mean[c];
+            ga[i] = g.gamma[c];
+            be[i] = g.beta[c];
+            k1[i] = g.sum_dy[c] * inv_n;
+            k2[i] = g.sum_dy_xhat[c] * inv_n;
+        }
+        const int r_begin = blockIdx.x * ch.rpb;
+        const int r_end = min(rows, r_begin + ch.rpb);
+        for (int r0 = r_begin + rlane; r0 < r_end; r0 += ch.rl * RU) {
+            float dy[RU][V], x[RU][V], p[RU][V];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int row = min(r0 + u * ch.rl, r_end - 1);
+                const long off = (long)row * F + c0;
+                if (V == 4) {
+                    float4 a = *reinterpret_cast<const float4*>(g.grad_y + off);
+                    float4 b = *reinterpret_cast<const float4*>(g.x + off);
+                    dy[u][0] = a.x; dy[u][1 % V] = a.y; dy[u][2 % V] = a.z; dy[u][3 % V] = a.w;
+                    x[u][0] = b.x; x[u][1 % V] = b.y; x[u][2 % V] = b.z; x[u][3 % V] = b.w;
+                    if (g.pre) {
+                        float4 c = *reinterpret_cast<const float4*>(g.pre + off);
+                        p[u][0] = c.x; p[u][1 % V] = c.y; p[u][2 % V] = c.z; p[u][3 % V] = c.w;
+                    }
+                } else {
+                    dy[u][0] = g.grad_y[off];
+                    x[u][0] = g.x[off];
+                    if (g.pre) p[u][0] = g.pre[off];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int row = r0 + u * ch.rl;
+                if (row >= r_end) continue;
+                const long off = (long)row * F + c0;
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    float xh = (x[u][i] - mu[i]) * is[i];
+                    float d = dy[u][i];
+                    if (g.post_act != I3D_ACT_NONE) d *= act_grad(xh * ga[i] + be[i], g.post_act);
+                    float gx = ga[i] * is[i] * (d - k1[i] - xh * k2[i]);
+                    if (g.act != I3D_ACT_NONE) gx *= act_grad(g.pre ? p[u][i] : x[u][i], g.act);
+                    dy[u][i] = gx;
+                    a1[i] += gx;
+                }
+                if (V == 4) *reinterpret_cast<float4*>(g.grad_pre + off) = make_float4(dy[u][0], dy[u][1 % V], dy[u][2 % V], dy[u][3 % V]);
+                else g.grad_pre[off] = dy[u][0];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) sm[t * V + i] = a1[i];
+    __syncthreads();
+    if (rlane == 0 && cvi < ch.cv) {
+        float s1[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) s1[i] = 0.f;
+        for (int k = 0; k < ch.rl; ++k) {
+            const int tt = k * ch.tpr + cl;
+#pragma unroll
+            for (int i = 0; i < V; ++i) s1[i] += sm[tt * V + i];
+        }
+        float* q = partial + (long)blockIdx.x * 2 * F + c0;
+#pragma unroll
+        for (int i = 0; i < V; ++i) { q[i] = s1[i]; q[F + i] = 0.f; }
+    }
+}
+
 __global__ void __launch_bounds__(256) act_fwd_kernel(const float* __restrict__ x, long n, int act, float* __restrict__ y) {
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
         y[t] = apply_act(x[t], act);
@@ -523,8 +610,8 @@ static void launch_bwd_apply(BwdApplyArgs& g, int rows, int feat, hipStream_t s)
 
 extern "C" int i3d_bn_bwd(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
                           int post_act, const float* mean, const float* invstd, const float* gamma,
-                          const float* beta, float* grad_gamma, float* grad_beta, float* grad_pre, double* sums_out,
-                          const double* sums_in, long total_rows, void* workspace, void* stream) {
+                          const float* beta, float* grad_gamma, float* grad_beta, float* grad_pre, float* grad_bias,
+                          double* sums_out, const double* sums_in, long total_rows, void* workspace, void* stream) {
     I3D_CHECK_ARG(rows > 0 && feat > 0, "rows > 0 and feat > 0 required");
     I3D_CHECK_ARG(workspace != nullptr, "workspace required");
     I3D_CHECK_ARG(act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU || pre != nullptr, "pre required for this activation");
@@ -558,6 +645,17 @@ extern "C" int i3d_bn_bwd(const float* grad_y, const float* x, const float* pre,
     b.mean = mean; b.invstd = invstd; b.gamma = gamma; b.beta = beta;
     b.sum_dy = sum_dy; b.sum_dy_xhat = sum_dy_xhat; b.grad_pre = grad_pre; b.feat = feat; b.act = act;
     b.post_act = post_act; b.eval_mode = 0; b.inv_n = 1.f / (float)total_rows; b.eps = 0.f;
+    if (grad_bias != nullptr) {     // data gradient and its column sums (bias gradient of the Linear in front) in one pass
+        b.items = 0;
+        dim3 grid(ch.nblk, ch.ncolblk);
+        if (ch.V == 4) hipLaunchKernelGGL(bn_bwd_apply_colsum_kernel<4>, grid, dim3(256), 0, s, b, ch, rows, partial);
+        else hipLaunchKernelGGL(bn_bwd_apply_colsum_kernel<1>, grid, dim3(256), 0, s, b, ch, rows, partial);
+        I3D_CHECK_LAUNCH();
+        hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, s, partial, ch.nblk, feat, grad_bias,
+                           (float*)nullptr, (double*)nullptr);
+        I3D_CHECK_LAUNCH();
+        return I3D_OK;
+    }
     launch_bwd_apply(b, rows, feat, s);
     I3D_CHECK_LAUNCH();
     return I3D_OK;

@@ -24,10 +24,11 @@ static int tail_fwd(const I3dBnTail* t, int rows, int f_out, float* pre, float* 
     return i3d_bn_apply_fwd(xact, rows, f_out, t->mean, t->invstd, t->gamma, t->beta, t->post_act, residual, y, stream);
 }
 
+// BN/activation backward; grad_bias = column sums of grad_pre from the same pass
 static int tail_bwd(const I3dBnTail* t, int rows, int f_out, const float* grad_y, const float* xact, const float* pre,
-                    float* grad_gamma, float* grad_beta, float* grad_pre, void* stream) {
+                    float* grad_gamma, float* grad_beta, float* grad_pre, float* grad_bias, void* stream) {
     return i3d_bn_bwd(grad_y, xact, pre, rows, f_out, t->act, t->post_act, t->mean, t->invstd, t->gamma, t->beta,
-                      grad_gamma, grad_beta, grad_pre, nullptr, nullptr, rows, t->workspace, stream);
+                      grad_gamma, grad_beta, grad_pre, grad_bias, nullptr, nullptr, rows, t->workspace, stream);
 }
 
 // ---- plain FC ------------------------------------------------------------------------------------------
@@ -41,9 +42,8 @@ extern "C" int i3d_fc_bn_fwd(const I3dFcArgs* a, void* stream) {
 extern "C" int i3d_fc_bn_bwd(const I3dFcArgs* a, void* stream) {
     I3D_CHECK_ARG(a != nullptr && a->rows > 0, "bad arguments");
     TRY(tail_bwd(&a->tail, a->rows, a->f_out, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre,
-                 stream));
+                 a->grad_bias, stream));
     TRY(i3d_gemm_f32_ws(1, 0, a->f_out, a->f_in, a->rows, a->grad_pre, a->f_out, a->x, a->f_in, a->grad_W, a->ldw, nullptr, 0, a->tail.gemm_workspace, a->tail.gemm_workspace_bytes, stream));
-    TRY(i3d_colsum(a->grad_pre, nullptr, a->rows, a->f_out, a->grad_bias, a->tail.workspace, stream));
     if (a->grad_x != nullptr)
         TRY(i3d_gemm_f32(0, 0, a->rows, a->f_in, a->f_out, a->grad_pre, a->f_out, a->W, a->ldw, a->grad_x, a->f_in, nullptr,
                          0, stream));
@@ -68,7 +68,8 @@ extern "C" int i3d_edge_fc_bn_fwd(const I3dEdgeFcArgs* a, void* stream) {
 extern "C" int i3d_edge_fc_bn_bwd(const I3dEdgeFcArgs* a, void* stream) {
     I3D_CHECK_ARG(a != nullptr && a->num_edges > 0 && a->num_nodes > 0, "bad arguments");
     const int Fh = a->f_h, Fo = a->f_out, N = a->num_nodes, E = a->num_edges;
-    TRY(tail_bwd(&a->tail, E, Fo, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre, stream));
+    TRY(tail_bwd(&a->tail, E, Fo, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre, a->grad_bias,
+                 stream));
     // d P[src] (out-edges through the source index), d P[dst] (in-edges are contiguous): segmented sums, no atomics
     TRY(i3d_segment_sum(a->grad_pre, Fo, a->out_ptr, a->out_epos, N, Fo, 0, a->grad_P, 2 * Fo, stream));
     TRY(i3d_segment_sum(a->grad_pre, Fo, a->in_ptr, nullptr, N, Fo, 0, a->grad_P + Fo, 2 * Fo, stream));
@@ -91,7 +92,7 @@ extern "C" int i3d_edge_fc_bn_bwd(const I3dEdgeFcArgs* a, void* stream) {
         if (a->grad_q != nullptr)
             TRY(i3d_gemm_f32(0, 0, E, a->f_q, Fo, a->grad_pre, Fo, a->W + 2 * Fh, a->ldw, a->grad_q, a->f_q, nullptr, 0, stream));
     }
-    return i3d_colsum(a->grad_pre, nullptr, E, Fo, a->grad_bias, a->tail.workspace, stream);
+    return I3D_OK;
 }
 
 // ---- degree-grouped concat FC: [h | scaler blocks of a] -> Linear with per-degree combined weights -----------
@@ -109,14 +110,14 @@ extern "C" int i3d_grouped_fc_bn_fwd(const I3dGroupedFcArgs* a, void* stream) {
 extern "C" int i3d_grouped_fc_bn_bwd(const I3dGroupedFcArgs* a, void* stream) {
     I3D_CHECK_ARG(a != nullptr && a->num_nodes > 0 && a->n_groups > 0, "bad arguments");
     const int Fh = a->f_h, Fo = a->f_out, A = a->agg_width, N = a->num_nodes;
-    TRY(tail_bwd(&a->tail, N, Fo, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre, stream));
+    TRY(tail_bwd(&a->tail, N, Fo, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre, a->grad_bias,
+                 stream));
     TRY(i3d_gemm_f32_ws(1, 0, Fo, Fh, N, a->grad_pre, Fo, a->h, Fh, a->grad_W, a->ldw, nullptr, 0, a->tail.gemm_workspace, a->tail.gemm_workspace_bytes, stream));
     // dW_D = dY_D^T a_D over the rows of each in-degree group, all groups in one launch
     TRY(i3d_gemm_f32_rowsubset_multi(Fo, A, a->n_groups, a->group_start, a->group_count, a->grad_pre, Fo, a->agg, A,
                                      a->deg_rows, N, a->grad_WD, (long)Fo * A, A, 0, -1, 0, a->tail.gemm_workspace,
                                      a->tail.gemm_workspace_bytes, stream));
     TRY(i3d_pna_combine_weights_bwd(a->grad_WD, a->ldw, Fh, Fo, A, a->n_groups, a->n_scalers, a->coef, a->grad_W, stream));
-    TRY(i3d_colsum(a->grad_pre, nullptr, N, Fo, a->grad_bias, a->tail.workspace, stream));
     TRY(i3d_gemm_f32(0, 0, N, Fh, Fo, a->grad_pre, Fo, a->W, a->ldw, a->grad_h, Fh, nullptr, 0, stream));
     return i3d_gemm_f32_grouped(0, a->m_padded, A, Fo, a->grad_pre, Fo, N, a->deg_rows, a->deg_tile_group, a->WD, A,
                                 (long)Fo * A, a->grad_agg, A, 0, stream);

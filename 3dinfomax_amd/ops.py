@@ -226,8 +226,9 @@ def bn_eval_fwd(x, running_mean, running_var, eps, gamma, beta, post_act=None, r
 
 
 def bn_bwd(grad_y, x, pre, act, post_act, mean, invstd, gamma, beta, sums_out=None, sums_in=None, total_rows=0,
-           grad_gamma=None, grad_beta=None, out=None):
-    """Returns (grad_pre, grad_gamma, grad_beta).  grad_pre may alias grad_y (out=grad_y)."""
+           grad_gamma=None, grad_beta=None, out=None, grad_bias=None):
+    """Returns (grad_pre, grad_gamma, grad_beta).  grad_pre may alias grad_y (out=grad_y); grad_bias (optional, [feat])
+    receives the column sums of grad_pre from the same pass."""
     _chk(grad_y)
     _chk(x)
     rows, feat = x.shape
@@ -237,8 +238,8 @@ def bn_bwd(grad_y, x, pre, act, post_act, mean, invstd, gamma, beta, sums_out=No
     grad_pre = torch.empty_like(x) if out is None else out
     L = _lib.load()
     check(L.i3d_bn_bwd(_p(grad_y), _p(x), _p(pre), rows, feat, ACT[act], ACT[post_act], _p(mean), _p(invstd), _p(gamma),
-                       _p(beta), _p(grad_gamma), _p(grad_beta), _p(grad_pre), _p(sums_out), _p(sums_in), int(total_rows),
-                       _p(_workspace(feat, x.device)), _stream()), 'i3d_bn_bwd')
+                       _p(beta), _p(grad_gamma), _p(grad_beta), _p(grad_pre), _p(grad_bias), _p(sums_out), _p(sums_in),
+                       int(total_rows), _p(_workspace(feat, x.device)), _stream()), 'i3d_bn_bwd')
     return grad_pre, grad_gamma, grad_beta
 
 

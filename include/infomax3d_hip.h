@@ -176,11 +176,12 @@ int i3d_bn_eval_fwd(const float* x, int rows, int feat, const float* running_mea
  *   If sums_out != NULL: phase 1 only - writes the LOCAL grad_gamma/grad_beta and the fp64 sums_out[2*feat] =
  *   {sum dy, sum dy*xhat} for the sync-BN all-reduce (the caller stores its row count in sums[2*feat] before
  *   reducing); then call again with sums_in != NULL (phase 2: the reduced sums and the count sums_in[2*feat]
- *   drive grad_pre - total_rows is ignored, nothing is read back to the host; grad_gamma/grad_beta untouched). */
+ *   drive grad_pre - total_rows is ignored, nothing is read back to the host; grad_gamma/grad_beta untouched).   grad_bias (may be NULL): column sums of grad_pre - the bias gradient of the Linear in
+ * front of the block - from the same pass that writes grad_pre. */
 int i3d_bn_bwd(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act, int post_act,
                const float* mean, const float* invstd, const float* gamma, const float* beta, float* grad_gamma,
-               float* grad_beta, float* grad_pre, double* sums_out, const double* sums_in, long total_rows,
-               void* workspace, void* stream);
+               float* grad_beta, float* grad_pre, float* grad_bias, double* sums_out, const double* sums_in,
+               long total_rows, void* workspace, void* stream);
 /* eval-mode backward (statistics are constants): grad_pre = grad_y * post_act' * gamma*invstd * act' */
 int i3d_bn_eval_bwd(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
                     int post_act, const float* running_mean, const float* running_var, float eps,

@@ -257,6 +257,12 @@ def test_act_bn_fwd_bwd_vs_torch(rows, feat, act, post):
     gp, gg, gb = ops.bn_bwd(g(cot), xg, pre_g if keep else None, act, post, mean, invstd, g(gamma), g(beta))
     assert rel_err(gp.cpu(), pr.grad) < 5e-5
     assert rel_err(gg.cpu(), gr.grad) < 5e-5 and rel_err(gb.cpu(), br.grad) < 5e-5
+    # the fused variant: same grad_pre (bit for bit) plus its column sums (the bias gradient of the Linear in front)
+    gbias = torch.full((feat,), 7.0, device=DEV)
+    gp2, _, _ = ops.bn_bwd(g(cot), xg, pre_g if keep else None, act, post, mean, invstd, g(gamma), g(beta), grad_bias=gbias)
+    assert torch.equal(gp2, gp)
+    ref_bias = gp.double().sum(0).cpu()
+    assert float((gbias.cpu().double() - ref_bias).abs().max()) < 1e-5 * max(1.0, float(gp.abs().double().sum(0).max()))
     # eval mode
     with torch.no_grad():
         y_eval = acts[post](F.batch_norm(acts[act](pre), rm, rv, gamma, beta, False, 0.93, 1e-5)) + res
