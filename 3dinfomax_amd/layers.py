@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from . import _lib, ops
+from . import _lib, ops, tape
 from .streams import fork
 
 SUPPORTED_ACTIVATIONS = {'relu', 'silu', 'sigmoid', 'leakyrelu', 'none'}
@@ -517,7 +517,7 @@ class FCLayer(nn.Module):
 
     def forward(self, x, residual=None, post_act=None):
         gamma, beta = self.bn_affine()
-        return FCFn.apply(x, self.linear.weight, self.linear.bias, gamma, beta, residual, self.spec(post_act))
+        return tape.apply(FCFn, x, self.linear.weight, self.linear.bias, gamma, beta, residual, self.spec(post_act))
 
 
 class MLP(nn.Module):
@@ -555,7 +555,7 @@ class MLP(nn.Module):
     def forward_edge(self, h, q, index, residual=None, qmap=None):
         fc0 = self.fully_connected[0]
         gamma, beta = fc0.bn_affine()
-        x = EdgeFCFn.apply(h, q, fc0.linear.weight, fc0.linear.bias, gamma, beta, index, fc0.spec(), qmap)
+        x = tape.apply(EdgeFCFn, h, q, fc0.linear.weight, fc0.linear.bias, gamma, beta, index, fc0.spec(), qmap)
         for fc in list(self.fully_connected)[1:]:
             x = fc(x)
         return x
@@ -565,7 +565,7 @@ class MLP(nn.Module):
         fcs = list(self.fully_connected)
         fc0 = fcs[0]
         gamma, beta = fc0.bn_affine()
-        x = GroupedConcat2FCFn.apply(h, a, fc0.linear.weight, fc0.linear.bias, gamma, beta,
+        x = tape.apply(GroupedConcat2FCFn, h, a, fc0.linear.weight, fc0.linear.bias, gamma, beta,
                                      residual if len(fcs) == 1 else None, index, coef, fc0.spec())
         for i, fc in enumerate(fcs[1:]):
             x = fc(x, residual if i == len(fcs) - 2 else None)
@@ -575,7 +575,7 @@ class MLP(nn.Module):
         fcs = list(self.fully_connected)
         fc0 = fcs[0]
         gamma, beta = fc0.bn_affine()
-        x = Concat2FCFn.apply(a, c, fc0.linear.weight, fc0.linear.bias, gamma, beta,
+        x = tape.apply(Concat2FCFn, a, c, fc0.linear.weight, fc0.linear.bias, gamma, beta,
                               residual if len(fcs) == 1 else None, fc0.spec())
         for i, fc in enumerate(fcs[1:]):
             x = fc(x, residual if i == len(fcs) - 2 else None)

@@ -5,6 +5,7 @@ from math import sqrt
 
 import torch
 
+from . import tape
 from .layers import EmbeddingSumFn
 from .synth import ATOM_FEATURE_DIMS, BOND_FEATURE_DIMS
 
@@ -40,7 +41,7 @@ class _Encoder(torch.nn.Module):
         return [emb.weight for emb in getattr(self, self._list_name)]
 
     def forward(self, x, perm=None):
-        return EmbeddingSumFn.apply(x.contiguous(), perm, *self._tables())
+        return tape.apply(EmbeddingSumFn, x.contiguous(), perm, *self._tables())
 
 
 class AtomEncoder(_Encoder):

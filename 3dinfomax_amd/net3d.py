@@ -11,7 +11,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, tape
 from .graph import as_batched_graph
 from .layers import MLP, ReadoutFn, act_name, bn_counter_scope
 from .mol_encoder import AtomEncoder
@@ -116,7 +116,7 @@ class Net3D(nn.Module):
 
     def forward(self, graph, *unused):
         with bn_counter_scope():
-            return self._forward(graph)
+            return tape.run_model(self, lambda: self._forward(graph))
 
     def _forward(self, graph):
         g = as_batched_graph(graph)
@@ -124,7 +124,7 @@ class Net3D(nn.Module):
         if self.use_node_features:
             h = self.atom_encoder(g.ndata['feat'])
         else:
-            h = _BroadcastRowFn.apply(self.node_embedding, g.number_of_nodes())
+            h = tape.apply(_BroadcastRowFn, self.node_embedding, g.number_of_nodes())
         # distances: edge-id order -> destination-sorted order, then Fourier features (inputs: no gradient)
         d = g.edata['d']
         with torch.no_grad():
@@ -139,7 +139,7 @@ class Net3D(nn.Module):
             h = self.node_wise_output_network(h)
         g.ndata['feat'] = h
         g.edata['d'] = ops.gather_rows(d.detach().contiguous(), idx.inv_perm)   # side effect, edge-id order
-        readout = ReadoutFn.apply(h, idx, self._readout_codes)
+        readout = tape.apply(ReadoutFn, h, idx, self._readout_codes)
         return self.output(readout)
 
 
@@ -165,10 +165,10 @@ class Net3DLayer(nn.Module):
 
     def step(self, h, d, idx, need_edge_update=True):
         m = self.message_network.forward_edge(h, d, idx)                        # :113-115
-        d_new = _AddFn.apply(d, m) if need_edge_update else d                   # :116 (dead for the last layer)
-        msg = SoftEdgeFn.apply(m, self.soft_edge_network.weight, self.soft_edge_network.bias)   # :117-118
-        m_sum = SegmentReduceFn.apply(msg, idx, self.reduce_mean)               # :109 fn.mean / fn.sum
-        h_new = self.update_network(_AddFn.apply(m_sum, h), residual=h)         # :120-125
+        d_new = tape.apply(_AddFn, d, m) if need_edge_update else d                   # :116 (dead for the last layer)
+        msg = tape.apply(SoftEdgeFn, m, self.soft_edge_network.weight, self.soft_edge_network.bias)   # :117-118
+        m_sum = tape.apply(SegmentReduceFn, msg, idx, self.reduce_mean)               # :109 fn.mean / fn.sum
+        h_new = self.update_network(tape.apply(_AddFn, m_sum, h), residual=h)         # :120-125
         return h_new, d_new
 
     def forward(self, graph):

@@ -36,10 +36,16 @@ def _chk(t, dtype=torch.float32):
     return t
 
 
+_ws_need = {}
+
+
 def _workspace(feat, device):
-    """Thread-local scratch for the two-stage column reductions (stream-ordered reuse)."""
-    need = _lib.load().i3d_colreduce_workspace_bytes(0, feat)
-    key = (device.index, torch.cuda.current_stream().cuda_stream)     # one scratch per stream (side-stream wgrads)
+    """Thread-local scratch for the two-stage column reductions (stream-ordered reuse), one per stream (the raw stream
+    handle is the key: torch.cuda.current_stream() builds a Python object, ~10 us, and this runs ~60 times per step)."""
+    need = _ws_need.get(feat)
+    if need is None:
+        need = _ws_need[feat] = _lib.load().i3d_colreduce_workspace_bytes(0, feat)
+    key = (device.index, _raw_stream(device.index))
     ws = getattr(_tls, 'ws', None)
     if ws is None:
         ws = _tls.ws = {}
@@ -52,7 +58,7 @@ def _workspace(feat, device):
 def _gemm_workspace(device):
     """Thread-local scratch of the weight-gradient GEMMs (split-K / row-segment slices, include/infomax3d_hip.h
     i3d_gemm_f32_ws), one per stream."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    key = (device.index, _raw_stream(device.index))
     ws = getattr(_tls, 'gws', None)
     if ws is None:
         ws = _tls.gws = {}

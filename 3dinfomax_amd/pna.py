@@ -19,7 +19,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import ops
+from . import ops, tape
 from .graph import as_batched_graph
 from .layers import (MLP, AggregateFn, Concat2FCFn, EdgeFCFn, EdgeTable, FCFn, GroupedConcat2FCFn, ReadoutFn,
                      bn_counter_scope)
@@ -87,9 +87,12 @@ class PNA(nn.Module):
     def forward(self, graph, *unused):
         g = as_batched_graph(graph)
         with bn_counter_scope():
-            self.node_gnn(g)
-            readout = ReadoutFn.apply(g.ndata['feat'], g.index(), self._readout_codes)
-            return self.output(readout)
+            return tape.run_model(self, lambda: self._forward(g))     # one autograd node for the whole model
+
+    def _forward(self, g):
+        self.node_gnn(g)
+        readout = tape.apply(ReadoutFn, g.ndata['feat'], g.index(), self._readout_codes)
+        return self.output(readout)
 
 
 class PNAGNN(nn.Module):
@@ -130,7 +133,7 @@ class PNAGNN(nn.Module):
             qmap = EdgeTable(codes, onehot, n_comb, v_pad)
             for mp_layer in self.mp_layers:
                 mp_layer(g, ef_sorted=table, qmap=qmap)
-            with torch.no_grad():   # reference side effect (models/pna.py:163): float bond embedding, edge-id order
+            with torch.no_grad(), tape.paused():   # reference side effect (models/pna.py:163): float bond embedding, edge-id order
                 g.edata['feat'] = self.bond_encoder(bond_idx)
             return
         # bond embeddings are produced directly in destination-sorted (kernel) order
@@ -154,18 +157,6 @@ class PNAGNN(nn.Module):
         return cache[key]
 
 
-class _SubCtx:
-    """Stand-in for the autograd context when the forward/backward of one of the block Functions of layers.py runs as
-    a step inside PNALayerFn."""
-
-    def __init__(self, needs_input_grad=(True,) * 12):
-        self.needs_input_grad = needs_input_grad
-        self.saved_tensors = ()
-
-    def save_for_backward(self, *tensors):
-        self.saved_tensors = tensors
-
-
 class _LayerPlan:
     """Non-tensor configuration of one PNALayerFn call (built by PNALayer.forward)."""
     __slots__ = ('pre_specs', 'post_specs', 'aggregators', 'agg_scalers', 'avg', 'coef', 'grouped', 'residual')
@@ -185,23 +176,23 @@ class PNALayerFn(torch.autograd.Function):
         subs = []
         W, b, ga, be = params[k:k + 4]
         k += 4
-        c = _SubCtx((True, ctx.needs_input_grad[1]) + (True,) * 10)
+        c = tape.SubCtx((True, ctx.needs_input_grad[1]) + (True,) * 10)
         e = EdgeFCFn.forward(c, h, q, W, b, ga, be, index, plan.pre_specs[0], qmap)
         subs.append(c)
         for spec in plan.pre_specs[1:]:
             W, b, ga, be = params[k:k + 4]
             k += 4
-            c = _SubCtx()
+            c = tape.SubCtx()
             e = FCFn.forward(c, e, W, b, ga, be, None, spec)
             subs.append(c)
-        c = _SubCtx()
+        c = tape.SubCtx()
         a = AggregateFn.forward(c, e, index, plan.aggregators, plan.agg_scalers, plan.avg)
         subs.append(c)
         n_post = len(plan.post_specs)
         W, b, ga, be = params[k:k + 4]
         k += 4
         res0 = h if (plan.residual and n_post == 1) else None
-        c = _SubCtx()
+        c = tape.SubCtx()
         if plan.grouped:
             x = GroupedConcat2FCFn.forward(c, h, a, W, b, ga, be, res0, index, plan.coef, plan.post_specs[0])
         else:
@@ -210,7 +201,7 @@ class PNALayerFn(torch.autograd.Function):
         for i, spec in enumerate(plan.post_specs[1:]):
             W, b, ga, be = params[k:k + 4]
             k += 4
-            c = _SubCtx()
+            c = tape.SubCtx()
             x = FCFn.forward(c, x, W, b, ga, be, h if (plan.residual and i == n_post - 2) else None, spec)
             subs.append(c)
         ctx.subs, ctx.plan = subs, plan
@@ -280,7 +271,7 @@ class PNALayer(nn.Module):
         idx = g.index()
         h = g.ndata['feat']
         if ef_sorted is None and self.edge_features:
-            ef_sorted = _GatherRowsFn.apply(g.edata['feat'], idx.perm, idx.inv_perm)
+            ef_sorted = tape.apply(_GatherRowsFn, g.edata['feat'], idx.perm, idx.inv_perm)
         avg = float(self.avg_d["log"])
         grouped = GROUPED_POSTTRANS and len(self.scalers) > 1 and h.shape[1] % 4 == 0
         if FUSED_LAYER and h.is_cuda:
@@ -294,7 +285,7 @@ class PNALayer(nn.Module):
             params = []
             for fc in pre + post:
                 params += [fc.linear.weight, fc.linear.bias, *fc.bn_affine()]
-            h_new = PNALayerFn.apply(h, ef_sorted if self.edge_features else None, idx,
+            h_new = tape.apply(PNALayerFn, h, ef_sorted if self.edge_features else None, idx,
                                      qmap if self.edge_features else None, plan, *params)
             g.ndata['feat'] = h_new
             return h_new
@@ -304,13 +295,13 @@ class PNALayer(nn.Module):
         if grouped:
             # the scaler blocks are per-node multiples of the aggregator block that depend on the in-degree only:
             # aggregate once ([N, n_agg*F], identity block) and fold the scalers into per-degree posttrans weights
-            a = AggregateFn.apply(e, idx, self.aggregators, [ops.SCALER['identity']], avg)
+            a = tape.apply(AggregateFn, e, idx, self.aggregators, [ops.SCALER['identity']], avg)
             coef = [[_scaler_coef(s, D, avg) for s in self.scalers] for D, _, _ in idx.degree_groups()[2]]
             h_new = self.posttrans.forward_concat2_grouped(h, a, idx, coef, residual=h if self.residual else None)
         else:
             # reference-shaped path: mean/max/min/std x scalers written as [N, 12F] in one segmented pass, then
             # post-transformation on [h | agg] (+ residual fused into the last BN)
-            agg = AggregateFn.apply(e, idx, self.aggregators, self.scalers, avg)
+            agg = tape.apply(AggregateFn, e, idx, self.aggregators, self.scalers, avg)
             h_new = self.posttrans.forward_concat2(h, agg, residual=h if self.residual else None)
         g.ndata['feat'] = h_new
         return h_new

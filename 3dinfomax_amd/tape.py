@@ -1,0 +1,154 @@
+"""A define-by-run tape over the block Functions of this package: a whole model forward/backward as ONE autograd node.
+
+Why: the pre-training step is ~330 small kernel launches and the host is as much on the critical path as the GPU
+(DESIGN.md section 7).  torch's autograd costs ~25-30 us of host time per node in each direction and ~35 us per
+gradient accumulation (`at::add`) on this stack; PNA + Net3D are ~35 nodes.  Under a tape the same `forward` /
+`backward` static methods of the block Functions (layers.py, net3d.py, pna.py - unchanged) run back to back from plain
+Python: the tape records (Function, context, inputs, output), walks the records in reverse for the backward pass and
+sums multiple gradient contributions with the in-place add kernel.  torch.autograd only sees the model's parameters
+going in and the model output coming out (`ModelFn`).
+
+Gradient-buffer ownership: a backward may return the incoming gradient itself (residual branches, `_AddFn`) or the
+same tensor for two inputs; such aliases are never written in place - the accumulator is either a buffer a kernel just
+produced ("fresh") or a new one.
+"""
+import contextlib
+import os
+import threading
+
+import torch
+
+from . import ops
+
+_tls = threading.local()
+
+
+class SubCtx:
+    """Stand-in for the autograd context of a block Function whose forward/backward runs as a step of a tape (or of a
+    fused layer Function)."""
+
+    def __init__(self, needs_input_grad=(True,) * 16):
+        self.needs_input_grad = needs_input_grad
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+def active():
+    return getattr(_tls, 'tape', None)
+
+
+def apply(fn, *args):
+    """fn.apply(*args) - through the active tape if there is one."""
+    tape = getattr(_tls, 'tape', None)
+    if tape is None:
+        return fn.apply(*args)
+    return tape.run(fn, args)
+
+
+@contextlib.contextmanager
+def paused():
+    """Code whose results are not differentiated (side-effect tensors): nothing is recorded."""
+    tape = getattr(_tls, 'tape', None)
+    _tls.tape = None
+    try:
+        yield
+    finally:
+        _tls.tape = tape
+
+
+class Tape:
+    def __init__(self, leaves):
+        self.req = {id(t) for t in leaves}        # tensors a gradient has to reach
+        self.nodes = []
+
+    def run(self, fn, args):
+        req = self.req
+        needs = tuple(torch.is_tensor(a) and id(a) in req for a in args)
+        ctx = SubCtx(needs)
+        out = fn.forward(ctx, *args)
+        if True in needs:
+            req.add(id(out))
+            self.nodes.append([fn, ctx, args, needs, id(out), out])     # holding `out` keeps the ids unique
+        return out
+
+    def release(self, out):
+        """The model output gets a grad_fn that owns this tape: drop the tape's own references to it (no cycle)."""
+        for node in self.nodes:
+            if node[5] is out:
+                node[5] = None
+
+    def backward(self, out_id, grad):
+        grads = {out_id: (grad, False)}
+        for fn, ctx, args, needs, oid, _ in reversed(self.nodes):
+            ent = grads.pop(oid, None)
+            if ent is None:                       # output never used downstream
+                continue
+            g = ent[0]
+            res = fn.backward(ctx, g)
+            if not isinstance(res, tuple):
+                res = (res,)
+            for i, need in enumerate(needs):
+                if not need:
+                    continue
+                ga = res[i]
+                if ga is None:
+                    continue
+                fresh = ga is not g
+                if fresh:
+                    for j, other in enumerate(res):
+                        if other is ga and j != i:
+                            fresh = False
+                            break
+                key = id(args[i])
+                cur = grads.get(key)
+                if cur is None:
+                    grads[key] = (ga, fresh)
+                elif cur[1]:
+                    ops.add_inplace(cur[0], ga.contiguous())
+                elif fresh:
+                    grads[key] = (ops.add_inplace(ga, cur[0].contiguous()), True)
+                else:
+                    grads[key] = (ops.add_inplace(cur[0].clone(), ga.contiguous()), True)
+        return grads
+
+
+class ModelFn(torch.autograd.Function):
+    """run(*) under a tape as one autograd node; `params` are the leaves."""
+
+    @staticmethod
+    def forward(ctx, run, *params):
+        tape = Tape(params)
+        prev = getattr(_tls, 'tape', None)
+        _tls.tape = tape
+        try:
+            out = run()
+        finally:
+            _tls.tape = prev
+        tape.release(out)
+        ctx.tape, ctx.out_id, ctx.params = tape, id(out), params
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        grads = ctx.tape.backward(ctx.out_id, grad.contiguous())
+        return (None,) + tuple(grads[id(p)][0] if id(p) in grads else None for p in ctx.params)
+
+
+# I3D_FUSED_MODEL=0: one autograd node per block (or per PNA layer) instead of one per model
+FUSED_MODEL = os.environ.get('I3D_FUSED_MODEL', '1') != '0'
+
+
+def run_model(module, run):
+    """module-level entry: `run()` is the plain forward of `module`.  Falls back to per-block autograd nodes when
+    gradients are off, a tape is already recording, or nothing is trainable."""
+    if not FUSED_MODEL or not torch.is_grad_enabled() or getattr(_tls, 'tape', None) is not None:
+        return run()
+    cached = module.__dict__.get('_i3d_param_list')
+    if cached is None:
+        cached = module.__dict__['_i3d_param_list'] = list(module.parameters())
+    params = [p for p in cached if p.requires_grad]
+    if not params or not params[0].is_cuda:
+        return run()
+    return ModelFn.apply(run, *params)

@@ -28,12 +28,29 @@ def main():
     net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **bench.NET3D_KW).to(dev).train()
     loss_fn = amd.NTXent(tau=0.1)
     named = list(pna.named_parameters()) + list(net.named_parameters())
-    optim = torch.optim.Adam([{'params': [p for k, p in named if 'batch_norm' in k], 'weight_decay': 0},
+    optim = amd.Adam([{'params': [p for k, p in named if 'batch_norm' in k], 'weight_decay': 0},
                               {'params': [p for k, p in named if 'batch_norm' not in k]}], lr=8e-5, fused=True)
+
+    bw_prof = cProfile.Profile()
+
+    class _ProfileBackwardThread(torch.autograd.Function):
+        """first node of the backward pass: switches cProfile on in autograd's worker thread (cProfile is per thread)"""
+        @staticmethod
+        def forward(ctx, x):
+            return x.view_as(x)
+
+        @staticmethod
+        def backward(ctx, g):
+            if state['profile_backward']:
+                bw_prof.enable()
+            return g
+
+    state = {'profile_backward': False}
 
     def step():
         a_, b_ = g2.local_copy(), g3.local_copy()
         loss = loss_fn(pna(a_), net(b_), nodes_per_graph=a_.batch_num_nodes())
+        loss = _ProfileBackwardThread.apply(loss)
         loss.backward()
         optim.step()
         optim.zero_grad()
@@ -42,15 +59,17 @@ def main():
         step()
     torch.cuda.synchronize()
     pr = cProfile.Profile()
+    state['profile_backward'] = True
     pr.enable()
     for _ in range(a.steps):
         step()
     pr.disable()
     torch.cuda.synchronize()
-    st = pstats.Stats(pr)
-    st.sort_stats('tottime')
     print(f'per-step figures: divide by {a.steps}')
-    st.print_stats(a.top)
+    print('==== main thread (forward, loss, optimizer) ====')
+    pstats.Stats(pr).sort_stats('tottime').print_stats(a.top)
+    print('==== autograd worker thread (backward) ====')
+    pstats.Stats(bw_prof).sort_stats('tottime').print_stats(a.top)
 
 
 if __name__ == '__main__':
