@@ -40,6 +40,128 @@ static Chunking make_chunking(int rows, int feat) {
 
 enum { MODE_STATS = 0, MODE_BN_BWD = 1, MODE_COLSUM = 2 };
 
+constexpr int FIN_COLS = 8, FIN_LANES = 32;    // stage 2: 8 columns x 32 partial-lanes per workgroup (25 of them at F=200)
+constexpr int WS_HEADER = 128;                 // bytes in front of the partial rows: the arrival / done counters
+
+// Stage 2 inside the stage-1 launch.  Every workgroup publishes its partial row (agent-scope stores), waits for its
+// own stores (vmcnt(0)), then takes an arrival ticket.  The LAST R arrivers (R = number of 8-column groups, <= grid
+// size) wait until all partial rows are published - they are the last to arrive, the wait is short, and the grid
+// (<= 256 x ncolblk workgroups) is always fully resident, so it cannot deadlock - and each reduces its column groups in
+// a fixed order (deterministic, as the separate finalise kernels are).  Saves one launch per reduction, 53 per
+// training step (see fused_final() for the measured trade-off).  The counters live at the head of the workspace, start at zero and are reset by
+// the last reducer, so the workspace must be zero-initialised once and must not be shared by concurrent streams.
+struct Final {
+    int kind;              // 0: batch statistics (mean / invstd / running stats / fp64 sums)   1: pair of column sums
+    int feat, rows, act;
+    float eps, momentum;
+    const float* pre_row0; // statistics: row 0 of the pre-activation (the shift of the shifted sums)
+    float* mean;
+    float* invstd;
+    float* running_mean;
+    float* running_var;
+    float* out1;           // pair: fp32 results (may be null)
+    float* out2;
+    double* sums_out;      // fp64 results for the synchronised-BN all-reduce (may be null)
+    unsigned* counters;    // null: stage 2 is a separate launch (I3D_FUSED_FINAL=0)
+};
+
+__device__ __forceinline__ float ld_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void finalize_column(const Final& f, int c, double s1, double s2) {
+    if (f.kind == 0) {
+        const double shift = (double)apply_act(f.pre_row0[c], f.act);
+        const double n = (double)f.rows;
+        if (f.sums_out != nullptr) {   // synchronised BN: hand un-shifted fp64 sums to the all-reduce
+            f.sums_out[c] = s1 + n * shift;
+            f.sums_out[f.feat + c] = s2 + 2.0 * shift * s1 + n * shift * shift;
+            if (c == 0) f.sums_out[2 * f.feat] = n;
+            return;
+        }
+        const double m = s1 / n;
+        double var = s2 / n - m * m;
+        if (var < 0.0) var = 0.0;
+        f.mean[c] = (float)(shift + m);
+        f.invstd[c] = (float)(1.0 / sqrt(var + (double)f.eps));
+        if (f.running_mean != nullptr) {
+            const double unbiased = f.rows > 1 ? var * n / (n - 1.0) : var;
+            f.running_mean[c] = (float)((1.0 - f.momentum) * (double)f.running_mean[c] + f.momentum * (shift + m));
+            f.running_var[c] = (float)((1.0 - f.momentum) * (double)f.running_var[c] + f.momentum * unbiased);
+        }
+    } else {
+        if (f.sums_out != nullptr) {
+            f.sums_out[c] = s1;
+            f.sums_out[f.feat + c] = s2;
+        }
+        if (f.out1 != nullptr) f.out1[c] = (float)s1;
+        if (f.out2 != nullptr) f.out2[c] = (float)s2;
+    }
+}
+
+// called by ALL threads of every workgroup after the partial row of the workgroup has been stored with st_agent
+__device__ __forceinline__ void arrive_and_finalize(const Final& f, const float* partial, int nblk) {
+    __shared__ unsigned s_ticket;
+    __shared__ double s_red[2][FIN_LANES][FIN_COLS];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's partial stores have left (agent-scope, write-through)
+    __syncthreads();
+    const unsigned total = gridDim.x * gridDim.y;
+    if (threadIdx.x == 0)
+        s_ticket = __hip_atomic_fetch_add(&f.counters[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = s_ticket;
+    const unsigned ncb = (unsigned)((f.feat + FIN_COLS - 1) / FIN_COLS);
+    const unsigned R = ncb < total ? ncb : total;
+    if (ticket < total - R) return;
+    if (threadIdx.x == 0) {        // bounded: a poisoned counter must not hang the device (results are then wrong, not stuck)
+        int spins = 0;
+        while (__hip_atomic_load(&f.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total && ++spins < (1 << 24))
+            __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    const int cx = threadIdx.x & (FIN_COLS - 1), ly = threadIdx.x / FIN_COLS;
+    for (unsigned cb = ticket - (total - R); cb < ncb; cb += R) {
+        const int c = (int)cb * FIN_COLS + cx;
+        double a1 = 0.0, a2 = 0.0;
+        if (c < f.feat) {
+            // all loads of the lane first (<= MAX_PARTIAL_BLOCKS / FIN_LANES = 8 partial rows, 16 uncached loads in
+            // flight), then the sums: a load-add loop pays the ~1.5 us agent-scope latency once per iteration
+            constexpr int NB = MAX_PARTIAL_BLOCKS / FIN_LANES;
+            float v1[NB], v2[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int b = min(ly + k * FIN_LANES, nblk - 1);
+                v1[k] = ld_agent(partial + (long)b * 2 * f.feat + c);
+                v2[k] = ld_agent(partial + (long)b * 2 * f.feat + f.feat + c);
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                if (ly + k * FIN_LANES < nblk) { a1 += (double)v1[k]; a2 += (double)v2[k]; }
+            }
+        }
+        s_red[0][ly][cx] = a1;
+        s_red[1][ly][cx] = a2;
+        __syncthreads();
+        if (ly == 0 && c < f.feat) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < FIN_LANES; ++k) { s1 += s_red[0][k][cx]; s2 += s_red[1][k][cx]; }
+            finalize_column(f, c, s1, s2);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const unsigned d = __hip_atomic_fetch_add(&f.counters[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d == R - 1) {          // every reducer is done reading: re-arm for the next launch
+            __hip_atomic_store(&f.counters[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&f.counters[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 struct ReduceArgs {
     const float* a;        // STATS: pre          BN_BWD: grad_y      COLSUM: x
     const float* b;        // STATS: -            BN_BWD: x           COLSUM: row weights (or null)
@@ -53,7 +175,7 @@ struct ReduceArgs {
 };
 
 template <int MODE, int V>
-__global__ void __launch_bounds__(256) colreduce_partial_kernel(ReduceArgs g, Chunking ch) {
+__global__ void __launch_bounds__(256) colreduce_partial_kernel(ReduceArgs g, Chunking ch, Final fin) {
     __shared__ float sm[2][256 * 4];
     const int t = threadIdx.x;
     const int cl = t % ch.tpr, rlane = t / ch.tpr;
@@ -152,14 +274,14 @@ __global__ void __launch_bounds__(256) colreduce_partial_kernel(ReduceArgs g, Ch
         }
         float* p = g.partial + (long)blockIdx.x * 2 * F + c0;
 #pragma unroll
-        for (int i = 0; i < V; ++i) { p[i] = s1[i]; p[F + i] = s2[i]; }
+        for (int i = 0; i < V; ++i) { st_agent(p + i, s1[i]); st_agent(p + F + i, s2[i]); }
     }
+    if (fin.counters != nullptr) arrive_and_finalize(fin, g.partial, gridDim.x);
 }
 
 // ---- stage 2 ----------------------------------------------------------------------------------------
 // 256 threads = 8 columns x 32 partial-lanes: reads of the chunk partials, fp64 accumulation, one LDS
 // hop.  (A one-thread-per-column loop over the partials was latency-bound: 130-150 us per call, 40 % of the step.)
-constexpr int FIN_COLS = 8, FIN_LANES = 32;    // 25 workgroups at F=200, 8 partials per thread
 
 __device__ __forceinline__ bool reduce_partials(const float* __restrict__ partial, int nblk, int feat, int& c,
                                                 double& s1, double& s2) {
@@ -415,7 +537,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BwdApplyArgs g, RowTi
 // bn_bwd_apply + column sums of the result (the bias gradient of the Linear in front: dL/db = sum_rows grad_pre): the
 // row-chunk layout of the reduction kernels, one partial row per block, finalised by pair_final_kernel.
 template <int V>
-__global__ void __launch_bounds__(256) bn_bwd_apply_colsum_kernel(BwdApplyArgs g, Chunking ch, int rows, float* partial) {
+__global__ void __launch_bounds__(256) bn_bwd_apply_colsum_kernel(BwdApplyArgs g, Chunking ch, int rows, float* partial,
+                                                                  Final fin) {
     __shared__ float sm[256 * 4];
     const int t = threadIdx.x;
     const int cl = t % ch.tpr, rlane = t / ch.tpr;
@@ -495,8 +618,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_colsum_kernel(BwdApplyArgs g
         }
         float* q = partial + (long)blockIdx.x * 2 * F + c0;
 #pragma unroll
-        for (int i = 0; i < V; ++i) { q[i] = s1[i]; q[F + i] = 0.f; }
+        for (int i = 0; i < V; ++i) { st_agent(q + i, s1[i]); st_agent(q + F + i, 0.f); }
     }
+    if (fin.counters != nullptr) arrive_and_finalize(fin, partial, gridDim.x);
 }
 
 __global__ void __launch_bounds__(256) act_fwd_kernel(const float* __restrict__ x, long n, int act, float* __restrict__ y) {
@@ -521,11 +645,45 @@ static int grid_for(long items) {
     return (int)b;
 }
 
+// Off by default: measured on MI355X the in-launch stage 2 costs what it saves on the GPU (ticket + poll + uncached
+// partial reads ~ 5 us vs a 4.5 us kernel + boundary) and only saves host launches (53 per step, ~0.18 ms);
+// I3D_FUSED_FINAL=1 enables it.
+static bool fused_final() {
+    static const bool on = [] { const char* e = getenv("I3D_FUSED_FINAL"); return e != nullptr && e[0] == '1'; }();
+    return on;
+}
+
+static float* partial_of(void* workspace) { return (float*)((char*)workspace + WS_HEADER); }
+
+static Final stats_final_desc(void* workspace, const float* pre, int act, int rows, int feat, float eps, float momentum,
+                              float* mean, float* invstd, float* running_mean, float* running_var, double* sums_out) {
+    Final f = {};
+    f.kind = 0; f.feat = feat; f.rows = rows; f.act = act; f.eps = eps; f.momentum = momentum; f.pre_row0 = pre;
+    f.mean = mean; f.invstd = invstd; f.running_mean = running_mean; f.running_var = running_var; f.sums_out = sums_out;
+    f.counters = fused_final() ? (unsigned*)workspace : nullptr;
+    return f;
+}
+
+static Final pair_final_desc(void* workspace, int feat, float* out1, float* out2, double* sums_out) {
+    Final f = {};
+    f.kind = 1; f.feat = feat; f.out1 = out1; f.out2 = out2; f.sums_out = sums_out;
+    f.counters = fused_final() ? (unsigned*)workspace : nullptr;
+    return f;
+}
+
+// stage 1 (+ stage 2 in the same launch, or as a second launch when I3D_FUSED_FINAL=0)
 template <int MODE>
-static void launch_partial(const ReduceArgs& g, const Chunking& ch, hipStream_t s) {
+static void launch_reduction(const ReduceArgs& g, const Chunking& ch, const Final& f, hipStream_t s) {
     dim3 grid(ch.nblk, ch.ncolblk);
-    if (ch.V == 4) hipLaunchKernelGGL((colreduce_partial_kernel<MODE, 4>), grid, dim3(256), 0, s, g, ch);
-    else hipLaunchKernelGGL((colreduce_partial_kernel<MODE, 1>), grid, dim3(256), 0, s, g, ch);
+    if (ch.V == 4) hipLaunchKernelGGL((colreduce_partial_kernel<MODE, 4>), grid, dim3(256), 0, s, g, ch, f);
+    else hipLaunchKernelGGL((colreduce_partial_kernel<MODE, 1>), grid, dim3(256), 0, s, g, ch, f);
+    if (f.counters != nullptr) return;
+    if (f.kind == 0)
+        hipLaunchKernelGGL(stats_final_kernel, dim3(cdiv(f.feat, FIN_COLS)), dim3(256), 0, s, g.partial, ch.nblk, f.pre_row0,
+                           f.act, f.rows, f.feat, f.eps, f.momentum, f.mean, f.invstd, f.running_mean, f.running_var, f.sums_out);
+    else
+        hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(f.feat, FIN_COLS)), dim3(256), 0, s, g.partial, ch.nblk, f.feat, f.out1,
+                           f.out2, f.sums_out);
 }
 
 }  // namespace i3d
@@ -534,7 +692,7 @@ using namespace i3d;
 
 extern "C" long i3d_colreduce_workspace_bytes(int rows, int feat) {
     (void)rows;
-    return (long)MAX_PARTIAL_BLOCKS * 2 * feat * sizeof(float) + 4 * (long)feat * sizeof(double) + 64;
+    return WS_HEADER + (long)MAX_PARTIAL_BLOCKS * 2 * feat * sizeof(float) + 4 * (long)feat * sizeof(double) + 64;
 }
 
 extern "C" int i3d_act_stats_fwd(const float* pre, int rows, int feat, int act, float* x, float eps, float momentum,
@@ -546,11 +704,9 @@ extern "C" int i3d_act_stats_fwd(const float* pre, int rows, int feat, int act, 
     Chunking ch = make_chunking(rows, feat);
     ReduceArgs g = {};
     g.a = pre; g.out = x; g.rows = rows; g.feat = feat; g.act = act; g.post_act = I3D_ACT_NONE;
-    g.partial = (float*)workspace;
-    launch_partial<MODE_STATS>(g, ch, s);
-    I3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(stats_final_kernel, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, s, g.partial, ch.nblk, pre, act, rows,
-                       feat, eps, momentum, mean, invstd, running_mean, running_var, sums_out);
+    g.partial = partial_of(workspace);
+    launch_reduction<MODE_STATS>(g, ch, stats_final_desc(workspace, pre, act, rows, feat, eps, momentum, mean, invstd,
+                                                         running_mean, running_var, sums_out), s);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }
@@ -617,15 +773,12 @@ extern "C" int i3d_bn_bwd(const float* grad_y, const float* x, const float* pre,
     I3D_CHECK_ARG(act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU || pre != nullptr, "pre required for this activation");
     hipStream_t s = (hipStream_t)stream;
     Chunking ch = make_chunking(rows, feat);
-    float* partial = (float*)workspace;
+    float* partial = partial_of(workspace);
     if (sums_in == nullptr) {   // phase 1: column sums of dy and dy*xhat
         ReduceArgs g = {};
         g.a = grad_y; g.b = x; g.mean = mean; g.invstd = invstd; g.gamma = gamma; g.beta = beta;
         g.rows = rows; g.feat = feat; g.act = act; g.post_act = post_act; g.partial = partial;
-        launch_partial<MODE_BN_BWD>(g, ch, s);
-        I3D_CHECK_LAUNCH();
-        hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, s, partial, ch.nblk, feat, grad_beta,
-                           grad_gamma, sums_out);
+        launch_reduction<MODE_BN_BWD>(g, ch, pair_final_desc(workspace, feat, grad_beta, grad_gamma, sums_out), s);
         I3D_CHECK_LAUNCH();
         if (sums_out != nullptr) return I3D_OK;   // caller all-reduces, then calls again with sums_in
         total_rows = rows;
@@ -648,12 +801,15 @@ extern "C" int i3d_bn_bwd(const float* grad_y, const float* x, const float* pre,
     if (grad_bias != nullptr) {     // data gradient and its column sums (bias gradient of the Linear in front) in one pass
         b.items = 0;
         dim3 grid(ch.nblk, ch.ncolblk);
-        if (ch.V == 4) hipLaunchKernelGGL(bn_bwd_apply_colsum_kernel<4>, grid, dim3(256), 0, s, b, ch, rows, partial);
-        else hipLaunchKernelGGL(bn_bwd_apply_colsum_kernel<1>, grid, dim3(256), 0, s, b, ch, rows, partial);
+        const Final f = pair_final_desc(workspace, feat, grad_bias, nullptr, nullptr);
+        if (ch.V == 4) hipLaunchKernelGGL(bn_bwd_apply_colsum_kernel<4>, grid, dim3(256), 0, s, b, ch, rows, partial, f);
+        else hipLaunchKernelGGL(bn_bwd_apply_colsum_kernel<1>, grid, dim3(256), 0, s, b, ch, rows, partial, f);
         I3D_CHECK_LAUNCH();
-        hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, s, partial, ch.nblk, feat, grad_bias,
-                           (float*)nullptr, (double*)nullptr);
-        I3D_CHECK_LAUNCH();
+        if (f.counters == nullptr) {
+            hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, s, partial, ch.nblk, feat, grad_bias,
+                               (float*)nullptr, (double*)nullptr);
+            I3D_CHECK_LAUNCH();
+        }
         return I3D_OK;
     }
     launch_bwd_apply(b, rows, feat, s);
@@ -670,17 +826,14 @@ extern "C" int i3d_bn_eval_bwd(const float* grad_y, const float* x, const float*
     hipStream_t s = (hipStream_t)stream;
     // grad_gamma / grad_beta need xhat with invstd from running_var: materialise invstd in the workspace tail
     Chunking ch = make_chunking(rows, feat);
-    float* partial = (float*)workspace;
+    float* partial = partial_of(workspace);
     float* invstd = partial + (long)MAX_PARTIAL_BLOCKS * 2 * feat;
     hipLaunchKernelGGL(invstd_from_var_kernel, dim3(cdiv(feat, 128)), dim3(128), 0, s, running_var, feat, eps, invstd);
     I3D_CHECK_LAUNCH();
     ReduceArgs g = {};
     g.a = grad_y; g.b = x; g.mean = running_mean; g.invstd = invstd; g.gamma = gamma; g.beta = beta;
     g.rows = rows; g.feat = feat; g.act = act; g.post_act = post_act; g.partial = partial;
-    launch_partial<MODE_BN_BWD>(g, ch, s);
-    I3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, s, partial, ch.nblk, feat, grad_beta,
-                       grad_gamma, (double*)nullptr);
+    launch_reduction<MODE_BN_BWD>(g, ch, pair_final_desc(workspace, feat, grad_beta, grad_gamma, nullptr), s);
     I3D_CHECK_LAUNCH();
     BwdApplyArgs b;
     b.grad_y = grad_y; b.x = x; b.pre = (act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU) ? nullptr : pre;
@@ -699,11 +852,8 @@ extern "C" int i3d_colsum(const float* x, const float* w, int rows, int feat, fl
     hipStream_t s = (hipStream_t)stream;
     Chunking ch = make_chunking(rows, feat);
     ReduceArgs g = {};
-    g.a = x; g.b = w; g.rows = rows; g.feat = feat; g.partial = (float*)workspace;
-    launch_partial<MODE_COLSUM>(g, ch, s);
-    I3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, s, g.partial, ch.nblk, feat, out,
-                       (float*)nullptr, (double*)nullptr);
+    g.a = x; g.b = w; g.rows = rows; g.feat = feat; g.partial = partial_of(workspace);
+    launch_reduction<MODE_COLSUM>(g, ch, pair_final_desc(workspace, feat, out, nullptr, nullptr), s);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }

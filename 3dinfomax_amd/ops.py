@@ -51,7 +51,8 @@ def _workspace(feat, device):
         ws = _tls.ws = {}
     buf = ws.get(key)
     if buf is None or buf.numel() < need:
-        buf = ws[key] = torch.empty(max(need, 1 << 22), dtype=torch.uint8, device=device)
+        # zero-initialised: the arrival counters of the in-kernel finalisation live at its head (include/infomax3d_hip.h)
+        buf = ws[key] = torch.zeros(max(need, 1 << 22), dtype=torch.uint8, device=device)
     return buf
 
 

@@ -154,7 +154,11 @@ int i3d_gemm_f32_rowsubset_multi(int M, int N, int n_groups, const int* group_st
  *   updated in place (running = (1-m)*running + m*batch, var unbiased).  `count_extra`/`stats_extra` support
  *   synchronised BN: when sums_out != NULL the kernel only writes the fp64 sums_out[2*feat+1] = {sum x,
  *   sum x^2, rows} and does NOT finalise (the caller all-reduces them and calls i3d_bn_finalize_stats).
- *   workspace: device scratch of i3d_colreduce_workspace_bytes(rows, feat) bytes. */
+ *   workspace: device scratch of i3d_colreduce_workspace_bytes(rows, feat) bytes, ZERO-INITIALISED once by the caller
+ *   and used by one stream at a time: the column reductions (this function, i3d_bn_bwd, i3d_bn_eval_bwd, i3d_colsum)
+ *   are two-stage and deterministic.  With I3D_FUSED_FINAL=1 in the environment the second stage runs inside the first
+ *   stage's launch (the last workgroups to arrive reduce the partial rows), synchronised through two counters at the
+ *   head of the workspace that every launch leaves at zero; by default it is a separate small launch. */
 long i3d_colreduce_workspace_bytes(int rows, int feat);
 int i3d_act_stats_fwd(const float* pre, int rows, int feat, int act, float* x, float eps, float momentum,
                       float* mean, float* invstd, float* running_mean, float* running_var, double* sums_out,

@@ -271,6 +271,38 @@ def test_act_bn_fwd_bwd_vs_torch(rows, feat, act, post):
     assert rel_err(ye.cpu(), y_eval) < 2e-5
 
 
+def test_in_launch_finalisation_matches_separate_launch():
+    """I3D_FUSED_FINAL=1 (stage 2 of the column reductions inside the stage-1 launch, last arrivers reduce) gives the same
+    bits as the default separate finalise launch; the switch is read once per process -> subprocess."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import importlib, torch, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "ops = importlib.import_module('3dinfomax_amd.ops')\n"
+        "torch.manual_seed(0)\n"
+        "out = []\n"
+        "for rows, feat in ((70000, 20), (16000, 200), (300, 7), (5000, 2400)):\n"
+        "    pre = torch.randn(rows, feat, device='cuda:0') + 2\n"
+        "    rm, rv = torch.zeros(feat, device='cuda:0'), torch.ones(feat, device='cuda:0')\n"
+        "    for rep in range(3):\n"
+        "        x, mean, invstd = ops.act_stats_fwd(pre.clone(), 'relu', 1e-5, 0.9, rm, rv)\n"
+        "        gb = torch.empty(feat, device='cuda:0')\n"
+        "        gp, gg, gbeta = ops.bn_bwd(pre, x, None, 'relu', None, mean, invstd, torch.ones(feat, device='cuda:0'), torch.zeros(feat, device='cuda:0'), grad_bias=gb)\n"
+        "        cs = ops.colsum(pre)\n"
+        "    out += [mean, invstd, rm, rv, gg, gbeta, gb, cs, gp.sum(0)]\n"
+        "torch.save([t.cpu() for t in out], sys.argv[1])\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ('0', '1'):
+        path = f'/tmp/i3d_fused_final_{mode}.pt'
+        env = dict(os.environ, I3D_FUSED_FINAL=mode)
+        subprocess.run([sys.executable, '-c', code, path], check=True, env=env, timeout=300)
+        res[mode] = torch.load(path)
+    for a, b in zip(res['0'], res['1']):
+        assert torch.equal(a, b)
+
+
 def test_colsum_and_elementwise():
     x, w = rnd(3000, 200, seed=60), rnd(3000, seed=61)
     assert rel_err(ops.colsum(g(x)).cpu(), x.double().sum(0)) < 1e-5
