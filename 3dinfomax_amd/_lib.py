@@ -72,6 +72,8 @@ _SIGNATURES = {
     'i3d_gemm_f32': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
     'i3d_gemm_f32_ex': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int,
                                 _P, c_long, _P]),
+    'i3d_gemm_f32_blocks': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_long, c_long, _P, c_int,
+                                    c_int, c_long, c_int, _P, c_long, _P]),
     'i3d_gemm_f32_ws': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_long, _P]),
     'i3d_pna_combine_weights_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), _P, _P]),
     'i3d_pna_combine_weights_bwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), _P, _P]),

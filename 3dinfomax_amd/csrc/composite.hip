@@ -54,8 +54,11 @@ extern "C" int i3d_fc_bn_bwd(const I3dFcArgs* a, void* stream) {
 extern "C" int i3d_edge_fc_bn_fwd(const I3dEdgeFcArgs* a, void* stream) {
     I3D_CHECK_ARG(a != nullptr && a->num_edges > 0 && a->num_nodes > 0, "bad arguments");
     const int Fh = a->f_h, Fo = a->f_out;
-    TRY(i3d_gemm_f32(0, 1, a->num_nodes, Fo, Fh, a->h, Fh, a->W, a->ldw, a->P, 2 * Fo, nullptr, 0, stream));
-    TRY(i3d_gemm_f32(0, 1, a->num_nodes, Fo, Fh, a->h, Fh, a->W + Fh, a->ldw, a->P + Fo, 2 * Fo, nullptr, 0, stream));
+    // P = h [W_s | W_d]^T: one GEMM over both column blocks of W (rows n >= Fo of the virtual [2Fo, Fh] operand are
+    // rows n - Fo of W shifted by Fh columns)
+    const long wdelta = (long)Fh - (long)Fo * a->ldw, wview = (long)(Fo - 1) * a->ldw + 2 * Fh;
+    TRY(i3d_gemm_f32_blocks(0, 1, a->num_nodes, 2 * Fo, Fh, a->h, Fh, a->W, a->ldw, Fo, wdelta, wview, a->P, 2 * Fo, 0, 0, 0,
+                            nullptr, 0, stream));
     if (a->q != nullptr)     // table mode: Q = table W_q^T has q_rows rows, the combine gathers row q_code[j]
         TRY(i3d_gemm_f32(0, 1, a->q_rows > 0 ? a->q_rows : a->num_edges, Fo, a->f_q, a->q, a->f_q, a->W + 2 * Fh, a->ldw, a->Q,
                          Fo, nullptr, 0, stream));
@@ -76,10 +79,12 @@ extern "C" int i3d_edge_fc_bn_bwd(const I3dEdgeFcArgs* a, void* stream) {
     // every column block of dW is written exactly once: no zero-fill (the split-K slices go through the scratch)
     void* ws = a->tail.gemm_workspace;
     const long wsb = a->tail.gemm_workspace_bytes;
-    TRY(i3d_gemm_f32_ws(1, 0, Fo, Fh, N, a->grad_P, 2 * Fo, a->h, Fh, a->grad_W, a->ldw, nullptr, 0, ws, wsb, stream));
-    TRY(i3d_gemm_f32_ws(1, 0, Fo, Fh, N, a->grad_P + Fo, 2 * Fo, a->h, Fh, a->grad_W + Fh, a->ldw, nullptr, 0, ws, wsb, stream));
-    TRY(i3d_gemm_f32(0, 0, N, Fh, Fo, a->grad_P, 2 * Fo, a->W, a->ldw, a->grad_h, Fh, nullptr, 0, stream));
-    TRY(i3d_gemm_f32(0, 0, N, Fh, Fo, a->grad_P + Fo, 2 * Fo, a->W + Fh, a->ldw, a->grad_h, Fh, nullptr, 1, stream));
+    const long wdelta = (long)Fh - (long)Fo * a->ldw, wview = (long)(Fo - 1) * a->ldw + 2 * Fh;
+    // d[W_s | W_d] = dP^T h (rows >= Fo of the [2Fo, Fh] result land in the second column block), dh = dP [W_s; W_d]
+    TRY(i3d_gemm_f32_blocks(1, 0, 2 * Fo, Fh, N, a->grad_P, 2 * Fo, a->h, Fh, 0, 0, 0, a->grad_W, a->ldw, Fo, wdelta, 0, ws, wsb,
+                            stream));
+    TRY(i3d_gemm_f32_blocks(0, 0, N, Fh, 2 * Fo, a->grad_P, 2 * Fo, a->W, a->ldw, Fo, wdelta, wview, a->grad_h, Fh, 0, 0, 0,
+                            nullptr, 0, stream));
     if (a->q != nullptr && a->q_rows > 0) {
         // table mode: dQ[v] = sum of dpre over the edges of category v (one-hot^T dpre), then two [V, .] products
         const int V = a->q_rows;

@@ -50,6 +50,11 @@ struct GemmArgs {
     const int* k_rows;      // row-segment kernel: reduction index k lives at row k_rows[k] of both operands
     const int* tile_group;  // [ceil(M/BM)] or null: B of m-tile t is g.B + tile_group[t] * b_group_stride
     long b_group_stride;    // floats
+    // two-block operands (the [W_s | W_d] halves of an edge-MLP weight addressed as ONE matrix, P trick of edge.hip):
+    // B index (n when B is k-contiguous, k otherwise) >= b_split adds b_delta floats to the address; C rows >= c_split
+    // add c_delta.  split = INT_MAX: plain operand.
+    int b_split, c_split;
+    long b_delta, c_delta;
     float* slab;            // split-K / row segments: blockIdx.z slice z stores its partial tile to slab[z][M][N]
                             // (plain 16-byte stores), slab_reduce_kernel sums the slices in a fixed order: deterministic
                             // and cheaper than fp32 atomics on top of a zero-fill.  null: atomics.
@@ -71,7 +76,8 @@ struct TileStage {
 
     // KC : slot -> (idx = s / KQ, kq = s % KQ), 4 consecutive k of one row
     // else: slot -> (k = s / (R/4), iq = s % (R/4)), 4 consecutive idx of one k
-    __device__ __forceinline__ void prepare(int ld, int idx0, int idx_max, const int* __restrict__ rows) {
+    __device__ __forceinline__ void prepare(int ld, int idx0, int idx_max, const int* __restrict__ rows, int split = 0x7fffffff,
+                                            long delta = 0) {
 #pragma unroll
         for (int it = 0; it < PER_THREAD; ++it) {
             const int s = threadIdx.x + it * 256;
@@ -82,7 +88,7 @@ struct TileStage {
                 if (idx < idx_max && s < SLOTS) row = rows ? rows[idx] : idx;
                 ok[it] = row >= 0;
                 iloc[it] = idx;
-                base[it] = (unsigned)(max(row, 0) * ld + kloc[it]) * 4u;
+                base[it] = (unsigned)((long)max(row, 0) * ld + kloc[it] + (idx >= split ? delta : 0)) * 4u;
             } else {
                 kloc[it] = s / (R / 4);
                 iloc[it] = idx0 + (s % (R / 4)) * 4;
@@ -96,7 +102,8 @@ struct TileStage {
     // in-order vmcnt queue of the tiles already in flight)
     template <bool VEC, bool ROWS>
     __device__ __forceinline__ void load(Regs& r, __amdgpu_buffer_rsrc_t rsrc, unsigned oob, int ld, int idx_max, int k0,
-                                         int k_begin, int k_end, const int* kidx) const {
+                                         int k_begin, int k_end, const int* kidx, int split = 0x7fffffff,
+                                         long delta = 0) const {
 #pragma unroll
         for (int it = 0; it < PER_THREAD; ++it) {
             const int k = k0 + kloc[it];
@@ -107,7 +114,7 @@ struct TileStage {
             } else {
                 int krow = k;
                 if (ROWS) krow = kidx[max(min(k, k_end - 1) - k_begin, 0)];
-                off = (unsigned)(krow * ld) * 4u + base[it];
+                off = (unsigned)((long)krow * ld + (k >= split ? delta : 0)) * 4u + base[it];
             }
             if (VEC) {   // contiguous extent is a multiple of 4: a valid first element implies a valid float4
                 auto q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, valid ? off : oob, 0, 0);
@@ -213,12 +220,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bp), 0, g.b_bytes, 0x00020000);
     sa.prepare(g.lda, m0, g.M, g.m_rows);
-    sb.prepare(g.ldb, n0, g.N, nullptr);
+    sb.prepare(g.ldb, n0, g.N, nullptr, g.b_split, g.b_delta);
     const int nk = (k_end - k_begin + BK - 1) / BK;
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         sa.template load<VEC, ROWS>(ra_[u], ra, g.a_bytes, g.lda, g.M, k_begin + u * BK, k_begin, k_end, kidx);
-        sb.template load<VEC, ROWS>(rb_[u], rb, g.b_bytes, g.ldb, g.N, k_begin + u * BK, k_begin, k_end, kidx);
+        sb.template load<VEC, ROWS>(rb_[u], rb, g.b_bytes, g.ldb, g.N, k_begin + u * BK, k_begin, k_end, kidx, g.b_split, g.b_delta);
     }
     sa.store(ra_[0], As[0]);
     sb.store(rb_[0], Bs[0]);
@@ -231,7 +238,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
             const int t = kt + u;
             const int cur = (PF % 2 == 0) ? (u & 1) : (t & 1);
             sa.template load<VEC, ROWS>(ra_[u], ra, g.a_bytes, g.lda, g.M, k_begin + (t + PF) * BK, k_begin, k_end, kidx);
-            sb.template load<VEC, ROWS>(rb_[u], rb, g.b_bytes, g.ldb, g.N, k_begin + (t + PF) * BK, k_begin, k_end, kidx);
+            sb.template load<VEC, ROWS>(rb_[u], rb, g.b_bytes, g.ldb, g.N, k_begin + (t + PF) * BK, k_begin, k_end, kidx, g.b_split,
+                                        g.b_delta);
             if (t < nk) {
                 const float* as = As[cur];
                 const float* bs = Bs[cur];
@@ -275,7 +283,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
                 const int n = n0 + (wn * WN_T + j) * MT + ((MT == 16) ? lk * 4 : 8 * grp + 4 * lk);
                 if (n >= g.N) continue;
                 float r[4] = {acc[i][j][4 * grp + 0], acc[i][j][4 * grp + 1], acc[i][j][4 * grp + 2], acc[i][j][4 * grp + 3]};
-                float* c = Cout + (long)row * g.ldc + n;
+                float* c = Cout + (long)row * g.ldc + n + (row >= g.c_split ? g.c_delta : 0);
                 const bool full = (n + 3 < g.N);
                 if (add_bias) {
 #pragma unroll
@@ -313,6 +321,7 @@ gemm_f32_kernel(GemmArgs g) {
     if (g.slab != nullptr) {           // every slice writes (zeros for an empty one): the reduction reads them all
         GemmArgs gl = g;
         gl.ldc = g.N; gl.accumulate = 0; gl.atomic_out = 0; gl.c_vec = (g.N % 4 == 0); gl.bias = nullptr;
+        gl.c_split = 0x7fffffff; gl.c_delta = 0;
         gemm_body<S, VEC, A_KC, B_KC, false>(gl, bx, by, min(k_begin, g.K), k_end, g.slab + (long)bz * g.M * g.N, nullptr, false);
         return;
     }
@@ -332,6 +341,7 @@ gemm_f32_rowseg_kernel(GemmArgs g, SegTable segs) {
     if (g.slab != nullptr) {
         GemmArgs gl = g;
         gl.ldc = g.N; gl.accumulate = 0; gl.atomic_out = 0; gl.c_vec = (g.N % 4 == 0);
+        gl.c_split = 0x7fffffff; gl.c_delta = 0;
         gemm_body<S, VEC, false, false, true>(gl, bx, by, sg.k_begin, sg.k_end, g.slab + (long)bz * g.M * g.N, kidx, false);
         return;
     }
@@ -345,6 +355,8 @@ struct SlabReduce {
     const float* bias;
     int M, N, ldc, accumulate, n_groups;
     long c_group_stride;
+    int c_split;       // rows >= c_split of C are displaced by c_delta floats (two-block outputs)
+    long c_delta;
     int seg_ptr[34];
 };
 
@@ -357,7 +369,7 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(SlabReduce a) {
     const int gi = (int)(t / per_group);
     const long r = t - gi * per_group;
     const int m = (int)(r / NV), n = (int)(r - (long)m * NV) * V;
-    float* c = a.C + gi * a.c_group_stride + (long)m * a.ldc + n;
+    float* c = a.C + gi * a.c_group_stride + (long)m * a.ldc + n + (m >= a.c_split ? a.c_delta : 0);
     float acc[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) acc[i] = a.accumulate ? c[i] : 0.f;
@@ -414,7 +426,7 @@ __global__ void __launch_bounds__(256) slab_reduce_small_kernel(SlabReduce a) {
     for (int i = 0; i < V; ++i) sm[il][zl][i] = acc[i];
     __syncthreads();
     if (!live || zl != 0) return;
-    float* c = a.C + gi * a.c_group_stride + (long)m * a.ldc + n;
+    float* c = a.C + gi * a.c_group_stride + (long)m * a.ldc + n + (m >= a.c_split ? a.c_delta : 0);
     float tot[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) tot[i] = a.accumulate ? c[i] : 0.f;
@@ -430,7 +442,8 @@ __global__ void __launch_bounds__(256) slab_reduce_small_kernel(SlabReduce a) {
 }
 
 static void launch_slab_reduce(const SlabReduce& a, hipStream_t s) {
-    const bool v4 = a.N % 4 == 0 && a.ldc % 4 == 0 && a.c_group_stride % 4 == 0 && (((uintptr_t)a.C | (uintptr_t)a.slab) & 15) == 0;
+    const bool v4 = a.N % 4 == 0 && a.ldc % 4 == 0 && a.c_group_stride % 4 == 0 && a.c_delta % 4 == 0 &&
+                    (((uintptr_t)a.C | (uintptr_t)a.slab) & 15) == 0;
     const long items = (long)a.n_groups * a.M * (v4 ? a.N / 4 : a.N);
     const int slices = a.seg_ptr[a.n_groups] - a.seg_ptr[0];
     if (items <= 8192 && slices >= 4 * ZL) {
@@ -508,6 +521,9 @@ struct Extra {
     // scratch for the two-stage split-K / row-segment reduction (slices x M x N floats); null or too small: atomics
     void* workspace = nullptr;
     long workspace_bytes = 0;
+    // two-block operands (GemmArgs::b_split ...); b_view_floats = addressable floats behind B when b_split is used
+    int b_split = 0x7fffffff, c_split = 0x7fffffff;
+    long b_delta = 0, c_delta = 0, b_view_floats = 0;
 };
 
 static int fill_views(GemmArgs& g, int trans_a, int trans_b, int M, int N, int K, int lda, int ldb, const Extra& ex) {
@@ -536,14 +552,20 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     g.accumulate = accumulate ? 1 : 0;
     g.m_rows = ex.m_rows; g.k_rows = nullptr; g.tile_group = ex.tile_group; g.b_group_stride = ex.b_group_stride;
     g.slab = nullptr;
+    g.b_split = ex.b_split; g.b_delta = ex.b_delta; g.c_split = ex.c_split; g.c_delta = ex.c_delta;
     int rc = fill_views(g, trans_a, trans_b, M, N, K, lda, ldb, ex);
     if (rc != I3D_OK) return rc;
+    if (ex.b_view_floats > 0) {
+        I3D_CHECK_ARG(ex.b_view_floats * 4 < (1L << 32) - 16, "operand view larger than 4 GiB (32-bit buffer offsets)");
+        g.b_bytes = (unsigned)(ex.b_view_floats * 4);
+    }
     const bool a_al = (((uintptr_t)A & 15) == 0) && (lda % 4 == 0), b_al = (((uintptr_t)B & 15) == 0) && (ldb % 4 == 0);
     g.c_vec = (((uintptr_t)C & 15) == 0) && (ldc % 4 == 0);
     // fast path: 16-byte loads need aligned pointers / leading dimensions and contiguous extents that are
     // multiples of 4 (K for k-contiguous operands, M or N for the others)
     const bool vec = a_al && b_al && ((trans_a ? M : K) % 4 == 0) && ((trans_b ? K : N) % 4 == 0) &&
-                     (ex.b_group_stride % 4 == 0);
+                     (ex.b_group_stride % 4 == 0) && (ex.b_delta % 4 == 0);
+    if (ex.c_delta % 4 != 0) g.c_vec = 0;
     const int layout = trans_a ? (trans_b ? 3 : 2) : (trans_b ? 0 : 1);
 
     if (layout == 3) {
@@ -605,9 +627,11 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
         g.atomic_out = 0;
     }
     if (splits > 1 && !accumulate && !use_slab) {
-        // atomics accumulate on top of zeros
-        hipError_t e = (ldc == N) ? hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), s)
-                                  : hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s);
+        // atomics accumulate on top of zeros (a two-block C: both blocks)
+        const int m1 = std::min(M, ex.c_split);
+        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), m1, s);
+        if (e == hipSuccess && M > m1)
+            e = hipMemset2DAsync(C + (long)m1 * ldc + ex.c_delta, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M - m1, s);
         if (e != hipSuccess) {
             set_error("i3d_gemm_f32: memset failed");
             return I3D_ERR_LAUNCH;
@@ -629,6 +653,7 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
         SlabReduce r;
         r.slab = g.slab; r.C = C; r.bias = bias; r.M = M; r.N = N; r.ldc = ldc; r.accumulate = accumulate ? 1 : 0;
         r.n_groups = 1; r.c_group_stride = 0; r.seg_ptr[0] = 0; r.seg_ptr[1] = splits;
+        r.c_split = ex.c_split; r.c_delta = ex.c_delta;
         launch_slab_reduce(r, s);
         I3D_CHECK_LAUNCH();
     }
@@ -656,6 +681,7 @@ static int rowseg_impl(int M, int N, const float* A, int lda, const float* B, in
     g.accumulate = 1; g.atomic_out = 1; g.k_per_split = 0;
     g.m_rows = nullptr; g.k_rows = ex.k_rows; g.tile_group = nullptr; g.b_group_stride = 0;
     g.slab = nullptr;
+    g.b_split = g.c_split = 0x7fffffff; g.b_delta = g.c_delta = 0;
     int rc = fill_views(g, 1, 0, M, N, k_hi, lda, ldb, ex);
     if (rc != I3D_OK) return rc;
     g.c_vec = (((uintptr_t)C & 15) == 0) && (ldc % 4 == 0);
@@ -736,6 +762,7 @@ static int rowseg_impl(int M, int N, const float* A, int lda, const float* B, in
         SlabReduce r;
         r.slab = g.slab; r.C = C; r.bias = nullptr; r.M = M; r.N = N; r.ldc = ldc; r.accumulate = accumulate ? 1 : 0;
         r.n_groups = ex.n_groups; r.c_group_stride = ex.c_group_stride;
+        r.c_split = 0x7fffffff; r.c_delta = 0;
         for (int gi = 0; gi < ex.n_groups; ++gi) r.seg_ptr[gi] = seg_first[gi];
         r.seg_ptr[ex.n_groups] = n_segs;
         launch_slab_reduce(r, s);
@@ -767,6 +794,18 @@ extern "C" int i3d_gemm_f32_ws(int trans_a, int trans_b, int M, int N, int K, co
     Extra ex;
     ex.workspace = workspace; ex.workspace_bytes = workspace_bytes;
     return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, -1, 0, ex, stream);
+}
+
+// i3d_gemm_f32_ws with a two-block B and/or C (include/infomax3d_hip.h)
+extern "C" int i3d_gemm_f32_blocks(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
+                                   int ldb, int b_split, long b_delta, long b_view_floats, float* C, int ldc, int c_split,
+                                   long c_delta, int accumulate, void* workspace, long workspace_bytes, void* stream) {
+    Extra ex;
+    ex.workspace = workspace; ex.workspace_bytes = workspace_bytes;
+    if (b_split > 0) { ex.b_split = b_split; ex.b_delta = b_delta; ex.b_view_floats = b_view_floats; }
+    if (c_split > 0) { ex.c_split = c_split; ex.c_delta = c_delta; }
+    I3D_CHECK_ARG(!(trans_a && trans_b), "layout not supported");
+    return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, nullptr, accumulate, -1, 0, ex, stream);
 }
 
 // C[m_rows[m], :] (+)= A[m_rows[m], :] * op(B_g),  g = tile_group[m / 64];  m_rows is padded with -1 to 64 per group

@@ -116,6 +116,15 @@ int i3d_gemm_f32_ws(int trans_a, int trans_b, int M, int N, int K, const float* 
                     float* C, int ldc, const float* bias, int accumulate, void* workspace, long workspace_bytes,
                     void* stream);
 
+/* i3d_gemm_f32_ws where B and/or C consist of two blocks of one parent matrix (the [W_s | W_d] column blocks of an
+ * edge-MLP weight, P trick of i3d_edge_combine_fwd: P = h [W_s | W_d]^T, dh = dP [W_s; W_d], d[W_s | W_d] = dP^T h as ONE
+ * GEMM each instead of two):  B index (n if trans_b, k otherwise) >= b_split adds b_delta floats to the address and
+ * b_view_floats is the number of floats addressable behind B; C rows >= c_split add c_delta floats.  b_split / c_split
+ * <= 0: plain operand. */
+int i3d_gemm_f32_blocks(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                        int b_split, long b_delta, long b_view_floats, float* C, int ldc, int c_split, long c_delta,
+                        int accumulate, void* workspace, long workspace_bytes, void* stream);
+
 /* ---- degree-grouped posttrans of the PNA layer ------------------------------------------------------
  * replaces cat([h, agg]) -> posttrans Linear of reference models/pna.py:207-209 for the aggregated part:  the three
  * scaler blocks of agg are per-node multiples (functions of the in-degree D only) of the same aggregator block a,

@@ -110,6 +110,38 @@ def test_gemm_split_k_into_strided_column_block(rows):
             assert rel_err(out2[:, Fa:].cpu(), 2 * ref[:, Fa:]) < 2e-5
 
 
+@pytest.mark.parametrize('scratch', [True, False])
+def test_two_block_gemms_of_the_edge_mlp(scratch):
+    """P = h [W_s | W_d]^T, dh = dP [W_s; W_d] and d[W_s | W_d] = dP^T h, each as ONE GEMM over the two column blocks of the
+    pretrans weight (i3d_gemm_f32_blocks) against the two-GEMM formulation."""
+    from ctypes import c_void_p
+    L = importlib.import_module('3dinfomax_amd._lib')
+    lib = L.load()
+    st = c_void_p(torch.cuda.current_stream().cuda_stream)
+    N, Fh, Fo, ldw = 3000, 200, 200, 600
+    h, W, dP = rnd(N, Fh, seed=1), rnd(Fo, ldw, seed=2), rnd(N, 2 * Fo, seed=3)
+    hg, Wg, dPg = g(h), g(W), g(dP)
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device=DEV)
+    wsp, wsb = (c_void_p(ws.data_ptr()), 32 << 20) if scratch else (None, 0)
+    delta, view = Fh - Fo * ldw, (Fo - 1) * ldw + 2 * Fh
+    P = torch.empty(N, 2 * Fo, device=DEV)
+    assert lib.i3d_gemm_f32_blocks(0, 1, N, 2 * Fo, Fh, c_void_p(hg.data_ptr()), Fh, c_void_p(Wg.data_ptr()), ldw, Fo, delta, view,
+                                   c_void_p(P.data_ptr()), 2 * Fo, 0, 0, 0, None, 0, st) == 0
+    ref = torch.cat([h.double() @ W[:, :Fh].double().T, h.double() @ W[:, Fh:2 * Fh].double().T], 1)
+    assert rel_err(P.cpu(), ref) < 1e-5
+    gW = torch.full((Fo, ldw), 7.0, device=DEV)
+    assert lib.i3d_gemm_f32_blocks(1, 0, 2 * Fo, Fh, N, c_void_p(dPg.data_ptr()), 2 * Fo, c_void_p(hg.data_ptr()), Fh, 0, 0, 0,
+                                   c_void_p(gW.data_ptr()), ldw, Fo, delta, 0, wsp, wsb, st) == 0
+    ref = torch.cat([dP[:, :Fo].double().T @ h.double(), dP[:, Fo:].double().T @ h.double()], 1)
+    assert rel_err(gW[:, :2 * Fh].cpu(), ref) < 2e-5
+    assert torch.all(gW[:, 2 * Fh:] == 7.0)
+    gh = torch.empty(N, Fh, device=DEV)
+    assert lib.i3d_gemm_f32_blocks(0, 0, N, Fh, 2 * Fo, c_void_p(dPg.data_ptr()), 2 * Fo, c_void_p(Wg.data_ptr()), ldw, Fo, delta, view,
+                                   c_void_p(gh.data_ptr()), Fh, 0, 0, 0, None, 0, st) == 0
+    ref = dP[:, :Fo].double() @ W[:, :Fh].double() + dP[:, Fo:].double() @ W[:, Fh:2 * Fh].double()
+    assert rel_err(gh.cpu(), ref) < 1e-5
+
+
 def test_degree_grouped_posttrans_gemms():
     """gemm_grouped / gemm_rowsubset / combine_weights against the reference-shaped computation
     [a | amp(D) a | att(D) a] W_agg^T with per-node scalers."""
