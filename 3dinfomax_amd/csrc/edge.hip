@@ -58,6 +58,27 @@ edge_codes_kernel(const long* __restrict__ idx, const int* __restrict__ row_perm
         make_float4(code == c0 ? 1.f : 0.f, code == c0 + 1 ? 1.f : 0.f, code == c0 + 2 ? 1.f : 0.f, code == c0 + 3 ? 1.f : 0.f);
 }
 
+// Multi-hot encoding of the categorical feature columns: out[j, offset[c] + idx[row(j), c]] = 1 for every column c, else 0
+// (offset = prefix sum of the table sizes).  The gradient of ALL embedding tables of an encoder is then one product
+// out^T dY ([sum of table sizes, F], split-K through the scratch: deterministic) instead of atomics.
+struct ColOffsets { int o[16]; };
+__global__ void __launch_bounds__(256)
+multihot_kernel(const long* __restrict__ idx, const int* __restrict__ row_perm, int rows, int n_cols, ColOffsets off, int v_pad,
+                float* __restrict__ out) {
+    const int VQ = v_pad / 4;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)rows * VQ) return;
+    const int j = (int)(t / VQ), q = (int)(t - (long)j * VQ);
+    const long row = row_perm ? row_perm[j] : j;
+    const int c0 = q * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < n_cols; ++c) {
+        const int pos = off.o[c] + (int)idx[row * n_cols + c] - c0;
+        if (pos >= 0 && pos < 4) v[pos] = 1.f;
+    }
+    *reinterpret_cast<float4*>(out + (long)j * v_pad + c0) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // out[v, :] = scale * sum_{j in [ptr[v], ptr[v+1])} x[idx ? idx[j] : j, :]
 template <int V>
 __global__ void __launch_bounds__(256)
@@ -234,6 +255,19 @@ extern "C" int i3d_edge_codes(const int64_t* idx, const int* row_perm, int rows,
     long items = (long)rows * (v_pad / 4);
     hipLaunchKernelGGL(edge_codes_kernel, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, (const long*)idx, row_perm,
                        rows, n_cols, st, v_pad, codes, onehot);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_multihot(const int64_t* idx, const int* row_perm, int rows, int n_cols, const int* offsets, int v_pad,
+                            float* out, void* stream) {
+    I3D_CHECK_ARG(rows >= 0 && n_cols >= 1 && n_cols <= 16 && v_pad > 0 && v_pad % 4 == 0, "bad shape");
+    if (rows == 0) return I3D_OK;
+    ColOffsets off;
+    for (int c = 0; c < 16; ++c) off.o[c] = c < n_cols ? offsets[c] : 0;
+    long items = (long)rows * (v_pad / 4);
+    hipLaunchKernelGGL(multihot_kernel, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, (const long*)idx, row_perm, rows,
+                       n_cols, off, v_pad, out);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }

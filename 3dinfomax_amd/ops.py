@@ -98,15 +98,36 @@ def embedding_sum_bwd(idx, grad_out, dims, row_perm=None):
     _chk(grad_out)
     rows, n_cols = idx.shape
     feat = grad_out.shape[1]
-    flat = torch.zeros(sum(dims), feat, dtype=torch.float32, device=idx.device)     # one fill for all tables
+    total = sum(dims)
+    L = _lib.load()
+    if MULTIHOT_EMB_BWD and rows > 0 and total <= 1024 and n_cols <= 16 and feat % 4 == 0:
+        # all tables at once: multi-hot^T dY, split-K through the scratch (deterministic; the LDS-atomics kernel below
+        # needs ~115 us for the 9 atom tables of a 512-molecule batch)
+        v_pad = (total + 31) // 32 * 32
+        offsets, o = [], 0
+        for d in dims:
+            offsets.append(o)
+            o += d
+        hot = torch.empty(rows, v_pad, dtype=torch.float32, device=idx.device)
+        check(L.i3d_multihot(_p(idx), _p(row_perm), rows, n_cols, int_array(offsets), v_pad, _p(hot), _stream()), 'i3d_multihot')
+        flat = gemm(hot, grad_out, trans_a=True)
+    else:
+        flat = torch.zeros(total, feat, dtype=torch.float32, device=idx.device)     # one fill for all tables
+        ptrs, o = [], 0
+        for d in dims:
+            ptrs.append(flat.data_ptr() + 4 * o * feat)
+            o += d
+        check(L.i3d_embedding_sum_bwd(_p(idx), _p(row_perm), rows, n_cols, _p(grad_out), feat, ptr_array(ptrs),
+                                      int_array(list(dims)), _stream()), 'i3d_embedding_sum_bwd')
     grads, o = [], 0
     for d in dims:
         grads.append(flat[o:o + d])
         o += d
-    L = _lib.load()
-    check(L.i3d_embedding_sum_bwd(_p(idx), _p(row_perm), rows, n_cols, _p(grad_out), feat, ptr_array([g.data_ptr() for g in grads]),
-                                  int_array(list(dims)), _stream()), 'i3d_embedding_sum_bwd')
     return grads
+
+
+# I3D_MULTIHOT_EMB_BWD=0: embedding-table gradients by LDS-privatised atomics instead of the multi-hot GEMM
+MULTIHOT_EMB_BWD = os.environ.get('I3D_MULTIHOT_EMB_BWD', '1') != '0'
 
 
 # ---- K4 / K6 ---------------------------------------------------------------------------------------------

@@ -225,6 +225,12 @@ int i3d_add_inplace(float* dst, const float* src, long n, void* stream);
  * i3d_segment_bcast: grad of segment mean/sum: out[j,:] = scale(seg(j)) * g[seg(j),:], seg given by dst_s. */
 int i3d_edge_combine_fwd(const float* P, int ldp, const float* Q, const int* q_code, const float* bias,
                          const int* src_s, const int* dst_s, int num_edges, int feat, float* pre, void* stream);
+/* multi-hot encoding of categorical columns: out[j, offsets[c] + idx[row_perm ? row_perm[j] : j, c]] = 1, else 0
+ * (out [rows, v_pad], offsets: host prefix sums of the table sizes).  out^T dY is the gradient of all embedding tables of
+ * an encoder (commons/mol_encoder.py:34-42) as one weight-gradient GEMM - deterministic, unlike the atomics of
+ * i3d_embedding_sum_bwd. */
+int i3d_multihot(const int64_t* idx, const int* row_perm, int rows, int n_cols, const int* offsets, int v_pad, float* out,
+                 void* stream);
 int i3d_edge_codes(const int64_t* idx, const int* row_perm, int rows, int n_cols, const int* strides, int v_pad,
                    int* codes, float* onehot, void* stream);
 int i3d_segment_sum(const float* x, int ldx, const int* ptr, const int* idx, int num_segments, int feat,

@@ -297,6 +297,34 @@ def test_finetune_config_pna_only_l1_vs_oracle(amd, variant):
         grads_close_l2(param_grads(pna), {k: P[k].grad for k in O.trainable(P)}, 5e-2, 'pna ')
 
 
+def test_training_step_is_bit_deterministic(amd):
+    """Two runs of three optimisation steps from the same initial state end in bit-identical parameters: every
+    reduction on the path has a fixed summation order (segmented sums, two-stage column reductions, split-K slices
+    through the scratch, embedding-table gradients as a multi-hot GEMM) - no atomics."""
+    mols = synth.make_dataset(96, seed=21)
+
+    def run():
+        torch.manual_seed(7)
+        pna = amd.PNA(avg_d=1.0, device='cuda:0', **dict(PNA_YML, propagation_depth=2)).cuda().train()
+        net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_YML).cuda().train()
+        loss_fn = amd.NTXent(tau=0.1)
+        params = list(pna.parameters()) + list(net.parameters())
+        optim = amd.Adam(params, lr=1e-3)
+        for _ in range(3):
+            g2, g3 = make_batch(amd, mols)
+            loss = loss_fn(pna(g2), net(g3))
+            loss.backward()
+            optim.step()
+            optim.zero_grad()
+        return float(loss), [p.detach().clone() for p in params]
+
+    l1, p1 = run()
+    l2, p2 = run()
+    assert l1 == l2
+    for a, b in zip(p1, p2):
+        assert torch.equal(a, b)
+
+
 def test_adam_fast_path_is_torch_adam(amd):
     """infomax3d_amd.Adam (cached tensor lists in front of torch._fused_adam_) against torch.optim.Adam(fused=True):
     bit-identical parameters and state over several steps, a changing lr, and a state_dict round trip."""

@@ -247,8 +247,10 @@ def test_readout_fwd_bwd():
 
 
 # ---- K1 embedding ----------------------------------------------------------------------------------------
-def test_embedding_sum_fwd_bwd_with_row_perm():
-    dims, feat, rows = [119, 5, 12, 12, 10, 6, 6, 2, 2], 200, 1000
+@pytest.mark.parametrize('rows,multihot', [(1000, True), (9000, True), (60, True), (1000, False)])
+def test_embedding_sum_fwd_bwd_with_row_perm(rows, multihot, monkeypatch):
+    monkeypatch.setattr(ops, 'MULTIHOT_EMB_BWD', multihot)     # multi-hot GEMM (deterministic) / LDS-atomics kernel
+    dims, feat = [119, 5, 12, 12, 10, 6, 6, 2, 2], 200
     gen = torch.Generator().manual_seed(3)
     idx = torch.stack([torch.randint(0, d, (rows,), generator=gen) for d in dims], 1)
     tabs = [rnd(d, feat, seed=30 + i).requires_grad_(True) for i, d in enumerate(dims)]
@@ -260,7 +262,10 @@ def test_embedding_sum_fwd_bwd_with_row_perm():
     assert rel_err(out.cpu(), ref.detach()) < 1e-6
     grads = ops.embedding_sum_bwd(g(idx), g(cot), dims, g(perm.int()))
     for gt, t in zip(grads, tabs):
-        assert rel_err(gt.cpu(), t.grad) < 1e-5     # atomics: summation order differs
+        assert rel_err(gt.cpu(), t.grad) < 1e-5     # summation order differs
+    if multihot:                                    # the GEMM path is deterministic
+        again = ops.embedding_sum_bwd(g(idx), g(cot), dims, g(perm.int()))
+        assert all(torch.equal(a, b) for a, b in zip(grads, again))
 
 
 # ---- BatchNorm -------------------------------------------------------------------------------------------
