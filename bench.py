@@ -50,7 +50,10 @@ def parse():
     ap.add_argument('--torch-adam', action='store_true', help='stock torch.optim.Adam(fused=True) instead of amd.Adam')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3)
-    ap.add_argument('--no-sync-bn', action='store_true', help='throughput mode without synchronised BN (parity loss)')
+    ap.add_argument('--sync-bn', action='store_true',
+                    help='N > 1: BatchNorm statistics over the global batch (exact single-process equivalence) instead of '
+                         'per-rank statistics (DistributedDataParallel semantics, the default)')
+    ap.add_argument('--no-sync-bn', action='store_true', help=argparse.SUPPRESS)   # former name of the default
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise RCCL and run the data-parallel code path even with one rank (self-test)')
     return ap.parse_args()
@@ -121,7 +124,7 @@ def main():
     optim = adam_cls([{'params': [p for k, p in named if 'batch_norm' in k], 'weight_decay': 0},
                       {'params': [p for k, p in named if 'batch_norm' not in k]}], lr=8e-5, fused=True)
     if use_dist:
-        adist.setup([pna, net], loss_fn, sync_bn=not args.no_sync_bn)
+        adist.setup([pna, net], loss_fn, sync_bn=args.sync_bn)
 
     def step(i):
         g2, g3, _ = batches[i % pool]
@@ -250,7 +253,7 @@ def main():
                                         f'QM9-shaped synthetic molecules, batch {B}/GPU, fp32, Adam',
                                optimizer='torch.optim.Adam(fused=True)' if args.torch_adam else 'infomax3d_amd.Adam (torch.optim.Adam subclass, torch._fused_adam_ kernel, cached tensor lists)',
                                global_batch=B * world, parallelism=f'dp{world}' if world > 1 else 'single',
-                               sync_bn=(use_dist and not args.no_sync_bn), final_loss=round(float(loss.item()), 5),
+                               sync_bn=(use_dist and args.sync_bn), final_loss=round(float(loss.item()), 5),
                                host_enqueue_ms_per_step=round(t_enqueue / args.steps * 1e3, 3),
                                molecules_per_s_incl_batch_assembly_and_h2d=with_assembly),
                    roofline=roof)

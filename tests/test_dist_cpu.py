@@ -58,7 +58,7 @@ def _worker(rank, port, out):
     b_full = losses._AllGatherRowsFn.apply(b_local, dist.group.WORLD)         # C1
     share = _share(a, b_full, rank * per, B)
     share.backward()
-    adist.allreduce_grads([Ws], bucket_bytes=64)                              # C2 (tiny bucket: exercises flushing)
+    adist.allreduce_grads([Ws])                                               # C2 (persistent flat buffer)
     total = adist.global_loss(share)
     ok = (abs(total.item() - full.item()) < 1e-5 * abs(full.item())
           and torch.allclose(Ws.grad, Wr.grad, rtol=1e-4, atol=1e-6))

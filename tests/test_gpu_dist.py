@@ -55,7 +55,7 @@ def _worker(rank, port, path):
     mols = amd.synth.make_dataset(16, seed=21)
     pna, net = _models(amd)
     loss_fn = amd.NTXent(tau=0.1)
-    adist.setup([pna, net], loss_fn)
+    adist.setup([pna, net], loss_fn, sync_bn=True)      # global-batch BN statistics: equals the single-process step
     g2, g3 = _batch(amd, adist.shard_molecules(mols, rank, WORLD))
     share = loss_fn(pna(g2), net(g3))
     share.backward()
