@@ -482,16 +482,16 @@ static void launch_rowseg(const GemmArgs& g, const SegTable& t, int n_segs, bool
 
 // tile configurations; the numbering is part of the tuning entry i3d_gemm_f32_ex
 //   0: 128x128x16 (32x32x2)  1: 256x32x16 (16x16x4)  2: 64x64x16 (32x32x2)  3: 32x64x32 (16x16x4)
-//   4: 64x64x32 (32x32x2)    5: 128x64x16 (32x32x2)  6 / 7: as 2 with 1 / 4 K-tiles in flight instead of 2
+//   4: 64x64x32 (32x32x2)    5: 128x64x16 (32x32x2)  6 / 7: as 2 with 1 / 2 K-tiles in flight instead of 4
 //   8: 32x32x32 (16x16x4): weight gradients of the narrow (hidden_dim 20) 3D network, K = number of edges
 typedef Shape<32, 2, 2, 2, 2, 16, 2> Cfg0;
 typedef Shape<16, 4, 1, 4, 2, 16, 2> Cfg1;
-typedef Shape<32, 2, 2, 1, 1, 16, 2> Cfg2;
+typedef Shape<32, 2, 2, 1, 1, 16, 4> Cfg2;
 typedef Shape<16, 2, 2, 1, 2, 32, 2> Cfg3;
 typedef Shape<32, 2, 2, 1, 1, 32, 2> Cfg4;
 typedef Shape<32, 2, 2, 2, 1, 16, 4> Cfg5;
 typedef Shape<32, 2, 2, 1, 1, 16, 1> Cfg6;
-typedef Shape<32, 2, 2, 1, 1, 16, 4> Cfg7;
+typedef Shape<32, 2, 2, 1, 1, 16, 2> Cfg7;
 typedef Shape<16, 2, 2, 1, 1, 32, 2> Cfg8;
 constexpr int N_CFG = 9;
 static const int CFG_BM[N_CFG] = {Cfg0::BM, Cfg1::BM, Cfg2::BM, Cfg3::BM, Cfg4::BM, Cfg5::BM, Cfg6::BM, Cfg7::BM, Cfg8::BM};
