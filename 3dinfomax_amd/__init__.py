@@ -31,6 +31,10 @@ def __getattr__(name):
     if name in ('AtomEncoder', 'BondEncoder'):
         from . import mol_encoder
         return getattr(mol_encoder, name)
+    if name in ('PositiveSimilarity', 'NegativeSimilarity', 'ContrastiveAccuracy', 'TrueNegativeRate', 'TruePositiveRate',
+                'Uniformity', 'Alignment', 'BatchVariance', 'DimensionCovariance', 'contrastive_metrics'):
+        from . import metrics
+        return getattr(metrics, name)
     if name == 'Adam':
         from . import optim
         return optim.Adam
@@ -40,4 +44,6 @@ def __getattr__(name):
 __all__ = ['PNA', 'PNAGNN', 'PNALayer', 'PNA_AGGREGATORS', 'PNA_SCALERS', 'PNAOriginal', 'PNAOriginalSimple',
            'PNAGNNOriginal', 'PNAGNNSimple', 'PNATower', 'PNASimpleLayer', 'MLPReadout', 'Net3D', 'Net3DLayer', 'NTXent',
            'NTXentMultiplePositives', 'FCLayer', 'MLP', 'AtomEncoder', 'BondEncoder', 'contrastive_collate',
-           'conformer_collate', 'BatchedMolGraph', 'batch', 'bond_graph', 'complete_graph', 'Adam']
+           'conformer_collate', 'BatchedMolGraph', 'batch', 'bond_graph', 'complete_graph', 'Adam', 'PositiveSimilarity',
+           'NegativeSimilarity', 'ContrastiveAccuracy', 'TrueNegativeRate', 'TruePositiveRate', 'Uniformity', 'Alignment',
+           'BatchVariance', 'DimensionCovariance']

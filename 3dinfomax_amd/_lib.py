@@ -107,6 +107,8 @@ _SIGNATURES = {
     'i3d_ntxent_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P]),
     'i3d_row_axpy': (c_int, [_P, _P, c_int, c_int, _P, _P]),
     'i3d_row_scale': (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    'i3d_contrastive_rowstats': (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, c_float, _P, _P]),
+    'i3d_cov_rowstats': (c_int, [_P, _P, c_int, c_int, _P, _P]),
     'i3d_complete_graph_build': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 

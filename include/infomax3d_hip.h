@@ -379,6 +379,19 @@ int i3d_edge_fc_bn_bwd(const I3dEdgeFcArgs* args, void* stream);
 int i3d_grouped_fc_bn_fwd(const I3dGroupedFcArgs* args, void* stream);
 int i3d_grouped_fc_bn_bwd(const I3dGroupedFcArgs* args, void* stream);
 
+/* ---- contrastive monitoring metrics -------------------------------------------------
+ * replaces the nine metric modules of configs_clean/pre-train_QM9.yml:15-24 (reference trainer/metrics.py:161-174,
+ * 212-333, 443-463; commons/losses.py:946-959), evaluated every log_iterations steps by
+ * trainer/self_supervised_trainer.py:31-50.  Inputs are products computed with i3d_gemm_f32:
+ *   S = x1 x2[:B1]^T [B1,B1], G1 = x1 x1^T [B1,B1], G2 = x2 x2^T [B2,B2] (B2 >= B1: "noisy" extra rows), C = X^T X [D,D].
+ * i3d_contrastive_rowstats: out[B2, 8] per row i: {sum_j cos_ij, cos_ii, [(cos_ii+1)/2 > threshold],
+ *   #{j != i: (cos_ij+1)/2 <= threshold}, |x1_i - x2_i|^alpha, sum_{j>i} exp(-t|x1_i-x1_j|^2), the same for x2, 0}
+ *   (cos = S / (|x1_i| |x2_j|); rows >= B1 only carry the x2 term).
+ * i3d_cov_rowstats: out[D, 2] per row a of C: {sum_{b != a} ((C_ab - s_a s_b / n)/(n-1))^2, C_aa}, s = column sums. */
+int i3d_contrastive_rowstats(const float* S, const float* G1, const float* G2, int B1, int B2, float threshold, float t,
+                             float alpha, float* out, void* stream);
+int i3d_cov_rowstats(const float* C, const float* colsum, int n, int D, float* out, void* stream);
+
 /* ---- batch assembly -----------------------------------------------------------------
  * replaces B x QM9Dataset.get_complete_graph (reference datasets/qm9_dataset.py:233-244, :215-217) + dgl.batch
  * (datasets/custom_collate.py:108-109) for the 3D view: from coords [N,3] and the node offsets graph_ptr[B+1] (plus

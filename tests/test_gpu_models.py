@@ -316,7 +316,7 @@ def test_training_step_is_bit_deterministic(amd):
             loss.backward()
             optim.step()
             optim.zero_grad()
-        return float(loss), [p.detach().clone() for p in params]
+        return loss.item(), [p.detach().clone() for p in params]
 
     l1, p1 = run()
     l2, p2 = run()
