@@ -94,17 +94,19 @@ ntxent_bwd_row_kernel(const float* __restrict__ sim, const float* __restrict__ n
     if (threadIdx.x == 0) ca[i] = a > 0.f ? da / a : 0.f;
 }
 
-// cb_j = -(1/b_j) sum_i H_ij * S'_ij * a_i ;  64 columns per block, 4 row lanes
+// cb_j = -(1/b_j) sum_i H_ij * S'_ij * a_i ;  16 columns per block, 16 row lanes (B = 512: 32 workgroups, 32 rows per
+// lane; with 64 columns x 4 lanes it was 8 workgroups walking 128 rows each: 39 us)
+constexpr int COL_W = 16, COL_L = 16;
 __global__ void __launch_bounds__(256)
 ntxent_bwd_col_kernel(const float* __restrict__ sim, const float* __restrict__ dsim, const float* __restrict__ n1,
                       const float* __restrict__ n2, int b1, int ncol, float eps, float* __restrict__ cb) {
-    __shared__ float sm[4][64];
-    int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    int j = blockIdx.x * 64 + cx;
+    __shared__ float sm[COL_L][COL_W];
+    int cx = threadIdx.x % COL_W, ry = threadIdx.x / COL_W;
+    int j = blockIdx.x * COL_W + cx;
     float acc = 0.f;
     if (j < ncol) {
         float b = n2[j];
-        for (int i = ry; i < b1; i += 4) {
+        for (int i = ry; i < b1; i += COL_L) {
             float a = n1[i];
             float s = sim[(long)i * ncol + j] / (a * b + eps);
             acc -= dsim[(long)i * ncol + j] * s * a;
@@ -114,7 +116,9 @@ ntxent_bwd_col_kernel(const float* __restrict__ sim, const float* __restrict__ d
     __syncthreads();
     if (ry == 0 && j < ncol) {
         float b = n2[j];
-        float t = sm[0][cx] + sm[1][cx] + sm[2][cx] + sm[3][cx];
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < COL_L; ++k) t += sm[k][cx];
         cb[j] = b > 0.f ? t / b : 0.f;
     }
 }
@@ -189,7 +193,7 @@ extern "C" int i3d_ntxent_bwd(const float* sim, const float* n1, const float* n2
     hipLaunchKernelGGL(ntxent_bwd_row_kernel, dim3(b1), dim3(256), 0, s, sim, n1, n2, row_sum, row_pos, b1, ncol, conf,
                        pos_offset, 1.f / tau, eps, grad_scale, dsim, ca);
     I3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ntxent_bwd_col_kernel, dim3(cdiv(ncol, 64)), dim3(256), 0, s, sim, dsim, n1, n2, b1, ncol, eps, cb);
+    hipLaunchKernelGGL(ntxent_bwd_col_kernel, dim3(cdiv(ncol, COL_W)), dim3(256), 0, s, sim, dsim, n1, n2, b1, ncol, eps, cb);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }

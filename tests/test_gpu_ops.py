@@ -386,11 +386,11 @@ def test_edge_combine_and_segment_ops(feat):
     assert torch.equal(ops.gather_rows(g(x), g(perm)).cpu(), x[perm.long()])
 
 
-def test_fourier_and_soft_edge():
+@pytest.mark.parametrize('E,H', [(4000, 20), (4001, 32), (333, 8), (500, 13), (700, 40)])   # 8-lanes-per-edge / scalar kernels
+def test_fourier_and_soft_edge(E, H):
     d = torch.rand(5000, generator=torch.Generator().manual_seed(1)) * 8 + 0.5
     ref = O.fourier_encode_dist(d[:, None], 4)
     assert rel_err(ops.fourier_encode(g(d), 4).cpu(), ref) < 1e-6
-    E, H = 4000, 20
     m = rnd(E, H, seed=80).requires_grad_(True)
     ws, bs = rnd(1, H, seed=81).requires_grad_(True), rnd(1, seed=82).requires_grad_(True)
     w = torch.sigmoid(F.linear(m, ws, bs))
