@@ -82,43 +82,71 @@ def setup(modules, loss=None, group=None, sync_bn=False, broadcast=True):
 class GradReducer:
     """C2: SUM all-reduce of all parameter gradients through ONE persistent flat buffer.
 
-    Per step: one multi-tensor copy into the buffer, one all-reduce (20 MB for PNA + Net3D: ring all-reduce over xGMI is
-    per-link bound, so one large message beats many small ones), and every `p.grad` is re-pointed at its slice of the
-    buffer (no copy back).  The per-tensor version of this (110 x copy_) cost ~4 ms of host time per step."""
+    The models' backward passes (tape.ModelFn) deliver their parameter gradients straight into slices of the buffer
+    (one multi-tensor copy per model) and autograd stores those slices as `p.grad`, so a step costs one all-reduce
+    (20 MB for PNA + Net3D: ring all-reduce over xGMI is per-link bound, one large message beats many small ones)
+    and no copy back.  Gradients that arrive another way (per-block autograd nodes, I3D_FUSED_MODEL=0) are copied in
+    here and `p.grad` is re-pointed.  (The per-tensor version - 110 x copy_ - cost ~4 ms of host time per step.)"""
 
     def __init__(self, params, group=None):
+        from . import tape
         self.params = [p for p in params if p.requires_grad]
         self.group = group if group is not None else dist.group.WORLD
         p0 = self.params[0]
         sizes = [p.numel() for p in self.params]
         self.flat = torch.zeros(sum(sizes), dtype=p0.dtype, device=p0.device)
         self.views = [v.view_as(p) for v, p in zip(self.flat.split(sizes), self.params)]
+        self.view_of = {id(p): v for p, v in zip(self.params, self.views)}
+        self._tape = tape
+
+    def attach(self, modules):
+        """route the gradients of these modules (whole-model tape nodes) into the buffer"""
+        for m in modules:
+            ps = [p for p in m.parameters() if p.requires_grad]
+            if ps:
+                self._tape.register_grad_sink(ps, self._sink)
+
+    def _sink(self, params, grads):
+        dst = [self.view_of.get(id(p)) for p in params]
+        pairs = [(d, g) for d, g in zip(dst, grads) if d is not None and g is not None and g is not d]
+        if pairs:
+            torch._foreach_copy_([d for d, _ in pairs], [g for _, g in pairs])
+        return [d if (d is not None and g is not None) else g for d, g in zip(dst, grads)]
 
     def reduce(self):
         grads = [p.grad for p in self.params]
-        if any(g is None for g in grads):            # a parameter without gradient this step counts as zero
-            self.flat.zero_()
-            have = [(v, g) for v, g in zip(self.views, grads) if g is not None]
+        todo = [(v, g) for v, g in zip(self.views, grads) if g is not v]
+        if todo:
+            missing = [v for v, g in todo if g is None]
+            if missing:                                 # a parameter without gradient this step counts as zero
+                torch._foreach_zero_(missing)
+            have = [(v, g) for v, g in todo if g is not None]
             if have:
                 torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        else:
-            torch._foreach_copy_(self.views, grads)
         all_reduce_sum(self.flat, self.group)
-        for p, v in zip(self.params, self.views):
-            p.grad = v
+        if todo:
+            for p, v in zip(self.params, self.views):
+                p.grad = v
 
 
 _reducers = {}
 
 
-def allreduce_grads(params, group=None):
-    """Sum the gradients over ranks (C2); see GradReducer."""
+def grad_reducer(params, group=None, modules=None):
+    """The GradReducer of this parameter list (created on first use); `modules`: attach their backward passes to it."""
     group = group if group is not None else dist.group.WORLD
     key = (id(group), tuple(id(p) for p in params))
     red = _reducers.get(key)
     if red is None:
         red = _reducers[key] = GradReducer(params, group)
-    red.reduce()
+        if modules:
+            red.attach(modules)
+    return red
+
+
+def allreduce_grads(params, group=None):
+    """Sum the gradients over ranks (C2); see GradReducer."""
+    grad_reducer(params, group).reduce()
 
 
 def global_loss(loss_share, group=None):

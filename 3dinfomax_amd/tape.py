@@ -133,7 +133,20 @@ class ModelFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         grads = ctx.tape.backward(ctx.out_id, grad.contiguous())
-        return (None,) + tuple(grads[id(p)][0] if id(p) in grads else None for p in ctx.params)
+        out = [grads[id(p)][0] if id(p) in grads else None for p in ctx.params]
+        sink = _grad_sinks.get(id(ctx.params[0]))
+        if sink is not None:         # data parallel: the gradients go straight into the all-reduce buffer (dist.GradReducer)
+            out = sink(ctx.params, out)
+        return (None,) + tuple(out)
+
+
+_grad_sinks = {}       # id(first parameter of a model) -> callable(params, grads) -> grads
+
+
+def register_grad_sink(params, fn):
+    """`fn(params, grads)` receives the parameter gradients of the model whose first parameter is params[0] at the end of
+    its backward pass and returns the tensors autograd should store in `.grad`."""
+    _grad_sinks[id(params[0])] = fn
 
 
 # I3D_FUSED_MODEL=0: one autograd node per block (or per PNA layer) instead of one per model

@@ -125,6 +125,7 @@ def main():
                       {'params': [p for k, p in named if 'batch_norm' not in k]}], lr=8e-5, fused=True)
     if use_dist:
         adist.setup([pna, net], loss_fn, sync_bn=args.sync_bn)
+        adist.grad_reducer(params, modules=[pna, net])        # backward passes write into the all-reduce buffer
 
     def step(i):
         g2, g3, _ = batches[i % pool]

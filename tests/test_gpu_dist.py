@@ -57,9 +57,11 @@ def _worker(rank, port, path):
     loss_fn = amd.NTXent(tau=0.1)
     adist.setup([pna, net], loss_fn, sync_bn=True)      # global-batch BN statistics: equals the single-process step
     g2, g3 = _batch(amd, adist.shard_molecules(mols, rank, WORLD))
+    params = list(pna.parameters()) + list(net.parameters())
+    if rank == 0:    # one rank delivers its gradients straight into the all-reduce buffer, the other through the copy path
+        adist.grad_reducer(params, modules=[pna, net])
     share = loss_fn(pna(g2), net(g3))
     share.backward()
-    params = list(pna.parameters()) + list(net.parameters())
     adist.allreduce_grads(params)
     total = adist.global_loss(share)
     if rank == 0:

@@ -48,7 +48,7 @@ def main():
     net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **bench.NET3D_KW).to(dev).train()
     loss_fn = amd.NTXent(tau=0.1)
     named = list(pna.named_parameters()) + list(net.named_parameters())
-    optim = torch.optim.Adam([{'params': [p for k, p in named if 'batch_norm' in k], 'weight_decay': 0},
+    optim = amd.Adam([{'params': [p for k, p in named if 'batch_norm' in k], 'weight_decay': 0},
                               {'params': [p for k, p in named if 'batch_norm' not in k]}], lr=8e-5)
     phases = {'fwd_pna': 0.0, 'fwd_net3d': 0.0, 'loss': 0.0, 'backward': 0.0, 'optim': 0.0, 'zero_grad': 0.0}
 
