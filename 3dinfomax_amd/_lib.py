@@ -52,7 +52,16 @@ class GroupedFcArgs(ctypes.Structure):
                 ('grad_h', _P), ('grad_agg', _P)]
 
 
+class PnaLayerArgs(ctypes.Structure):
+    _fields_ = [('edge', EdgeFcArgs), ('n_pre_extra', c_int), ('pre', FcArgs * 3), ('n_aggregators', c_int),
+                ('n_scalers', c_int), ('force_scalers', c_int), ('aggregators', c_int * 8), ('scalers', c_int * 4),
+                ('avg_d_log', c_float), ('msg', _P), ('grad_msg', _P), ('post', GroupedFcArgs), ('n_post_extra', c_int),
+                ('postx', FcArgs * 3), ('residual', c_int), ('grad_out', _P)]
+
+
 _SIGNATURES = {
+    'i3d_pna_layer_fwd': (c_int, [POINTER(PnaLayerArgs), _P]),
+    'i3d_pna_layer_bwd': (c_int, [POINTER(PnaLayerArgs), _P]),
     'i3d_fc_bn_fwd': (c_int, [POINTER(FcArgs), _P]),
     'i3d_fc_bn_bwd': (c_int, [POINTER(FcArgs), _P]),
     'i3d_edge_fc_bn_fwd': (c_int, [POINTER(EdgeFcArgs), _P]),

@@ -127,3 +127,31 @@ extern "C" int i3d_grouped_fc_bn_bwd(const I3dGroupedFcArgs* a, void* stream) {
     return i3d_gemm_f32_grouped(0, a->m_padded, A, Fo, a->grad_pre, Fo, N, a->deg_rows, a->deg_tile_group, a->WD, A,
                                 (long)Fo * A, a->grad_agg, A, 0, stream);
 }
+
+// ---- one PNA layer ---------------------------------------------------------------------------------------
+extern "C" int i3d_pna_layer_fwd(const I3dPnaLayerArgs* a, void* stream) {
+    I3D_CHECK_ARG(a != nullptr && a->n_pre_extra >= 0 && a->n_pre_extra <= I3D_MAX_EXTRA_FC && a->n_post_extra >= 0 &&
+                      a->n_post_extra <= I3D_MAX_EXTRA_FC, "bad arguments");
+    TRY(i3d_edge_fc_bn_fwd(&a->edge, stream));
+    for (int i = 0; i < a->n_pre_extra; ++i) TRY(i3d_fc_bn_fwd(&a->pre[i], stream));
+    TRY(i3d_pna_aggregate_fwd(a->msg, a->edge.in_ptr, a->edge.num_nodes, a->edge.f_out, a->aggregators, a->n_aggregators,
+                              a->scalers, a->n_scalers, a->force_scalers, a->avg_d_log, const_cast<float*>(a->post.agg), stream));
+    TRY(i3d_grouped_fc_bn_fwd(&a->post, stream));
+    for (int i = 0; i < a->n_post_extra; ++i) TRY(i3d_fc_bn_fwd(&a->postx[i], stream));
+    return I3D_OK;
+}
+
+extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
+    I3D_CHECK_ARG(a != nullptr && a->n_pre_extra >= 0 && a->n_pre_extra <= I3D_MAX_EXTRA_FC && a->n_post_extra >= 0 &&
+                      a->n_post_extra <= I3D_MAX_EXTRA_FC, "bad arguments");
+    for (int i = a->n_post_extra - 1; i >= 0; --i) TRY(i3d_fc_bn_bwd(&a->postx[i], stream));
+    TRY(i3d_grouped_fc_bn_bwd(&a->post, stream));
+    TRY(i3d_pna_aggregate_bwd(a->post.grad_agg, a->msg, a->edge.in_ptr, a->edge.num_nodes, a->edge.f_out, a->aggregators,
+                              a->n_aggregators, a->scalers, a->n_scalers, a->force_scalers, a->avg_d_log, a->grad_msg, stream));
+    for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(i3d_fc_bn_bwd(&a->pre[i], stream));
+    TRY(i3d_edge_fc_bn_bwd(&a->edge, stream));
+    const long n = (long)a->edge.num_nodes * a->edge.f_h;
+    TRY(i3d_add_inplace(a->post.grad_h, a->edge.grad_h, n, stream));
+    if (a->residual) TRY(i3d_add_inplace(a->post.grad_h, a->grad_out, n, stream));
+    return I3D_OK;
+}

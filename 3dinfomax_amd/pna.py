@@ -19,7 +19,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import ops, tape
+from . import layer_native, ops, tape
 from .graph import as_batched_graph
 from .layers import (MLP, AggregateFn, Concat2FCFn, EdgeFCFn, EdgeTable, FCFn, GroupedConcat2FCFn, ReadoutFn,
                      bn_counter_scope)
@@ -172,6 +172,9 @@ class PNALayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, q, index, qmap, plan, *params):
+        ctx.native = None
+        if layer_native.eligible(h, q, index, qmap, plan, params):      # the whole layer from one C call per direction
+            return layer_native.forward(ctx, h, q, index, qmap, plan, params)
         k = 0
         subs = []
         W, b, ga, be = params[k:k + 4]
@@ -209,6 +212,8 @@ class PNALayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
+        if ctx.native is not None:
+            return layer_native.backward(ctx, grad)
         plan, subs = ctx.plan, list(ctx.subs)
         n_pre, n_post = len(plan.pre_specs), len(plan.post_specs)
         grad = grad.contiguous()

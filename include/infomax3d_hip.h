@@ -372,6 +372,30 @@ typedef struct { /* y = tail(h W_h^T + b + agg[deg group] W_D^T),  W_D = sum_s c
     float* grad_agg;
 } I3dGroupedFcArgs;
 
+#define I3D_MAX_EXTRA_FC 3
+typedef struct { /* one PNA layer, reference models/pna.py:199-216: pretrans edge MLP (edge block + n_pre_extra plain FC
+                  * blocks) -> aggregation (i3d_pna_aggregate_*) -> posttrans (degree-grouped block + n_post_extra plain FC
+                  * blocks) + residual.  The member blocks are chained by the caller (pre[0].x = edge.y, ...); forward
+                  * and backward are the member composites back to back, the three contributions to dL/dh (posttrans,
+                  * edge MLP, residual) are summed into post.grad_h. */
+    I3dEdgeFcArgs edge;
+    int n_pre_extra;
+    I3dFcArgs pre[I3D_MAX_EXTRA_FC];
+    int n_aggregators, n_scalers, force_scalers;
+    int aggregators[8];
+    int scalers[4];
+    float avg_d_log;
+    const float* msg;      /* [E, F] output of the pretrans MLP (= y of its last block) */
+    float* grad_msg;       /* [E, F] scratch: gradient of the messages */
+    I3dGroupedFcArgs post;
+    int n_post_extra;
+    I3dFcArgs postx[I3D_MAX_EXTRA_FC];
+    int residual;          /* h_new += h (fused into the last block's BN apply by the caller via its residual pointer) */
+    const float* grad_out; /* [N, F] incoming gradient of the layer output (added to post.grad_h when residual) */
+} I3dPnaLayerArgs;
+
+int i3d_pna_layer_fwd(const I3dPnaLayerArgs* args, void* stream);
+int i3d_pna_layer_bwd(const I3dPnaLayerArgs* args, void* stream);
 int i3d_fc_bn_fwd(const I3dFcArgs* args, void* stream);
 int i3d_fc_bn_bwd(const I3dFcArgs* args, void* stream);
 int i3d_edge_fc_bn_fwd(const I3dEdgeFcArgs* args, void* stream);

@@ -184,15 +184,17 @@ def test_batch64_vs_oracle_fwd_bwd(amd):
     grads_close(param_grads(net), {k: P3[k].grad for k in O.trainable(P3)}, 1e-3, 'net3d ')
 
 
-@pytest.mark.parametrize('composite,fused,fused_model', [(True, True, True), (False, True, True), (True, False, True),
-                                                         (False, False, False), (True, True, False)])
-def test_bond_table_path_matches_dense_bond_embeddings(amd, composite, fused, fused_model, monkeypatch):
+@pytest.mark.parametrize('composite,fused,fused_model,native', [(True, True, True, True), (True, True, True, False),
+                                                                (False, True, True, True), (True, False, True, True),
+                                                                (False, False, False, False), (True, True, False, True)])
+def test_bond_table_path_matches_dense_bond_embeddings(amd, composite, fused, fused_model, native, monkeypatch):
     """The [60, F] table of all bond-category combinations + per-edge codes (default) against materialised [E, F] bond
     embeddings multiplied by W_q in every layer (I3D_EDGE_TABLE=0): same outputs, side effects and gradients."""
     pna_mod = importlib.import_module('3dinfomax_amd.pna')
     layers_mod = importlib.import_module('3dinfomax_amd.layers')
     if not composite:
         monkeypatch.setattr(layers_mod, '_composite_ok', lambda *a, **k: False)
+    monkeypatch.setattr(importlib.import_module('3dinfomax_amd.layer_native'), 'NATIVE_LAYER', native)   # one C call per layer
     monkeypatch.setattr(pna_mod, 'FUSED_LAYER', fused)      # one autograd node per layer vs one per block
     monkeypatch.setattr(importlib.import_module('3dinfomax_amd.tape'), 'FUSED_MODEL', fused_model)   # ... vs one per model
     mols = synth.make_dataset(48, seed=11)
