@@ -145,4 +145,6 @@ def complete_graphs_on_device(xyz, graph_ptr_dev, n_atoms_host, bnn) -> BatchedM
                                           ids[E3:].data_ptr(), d.data_ptr(), stream), 'i3d_complete_graph_build')
     idx3 = GraphIndex(N, E3, B, in_ptr, perm, src_s, dst_s, in_ptr, out_epos, graph_ptr_dev, inv_perm,
                       int(n_atoms_host.max()) - 1)
-    return BatchedMolGraph(ids[:E3], ids[E3:], N, bnn, ndata={}, edata={'d': d}, index=idx3)
+    g3 = BatchedMolGraph(ids[:E3], ids[E3:], N, bnn, ndata={}, edata={'d': d}, index=idx3)
+    g3.mark_ready()          # everything the 3D batch consists of is enqueued: an independent stream may wait for just this
+    return g3

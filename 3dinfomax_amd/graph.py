@@ -119,6 +119,7 @@ class BatchedMolGraph:
         if batch_num_nodes is None:
             batch_num_nodes = torch.tensor([self._n], dtype=torch.long)
         self._bnn = torch.as_tensor(batch_num_nodes, dtype=torch.long)
+        self.ready_event = None
         self.ndata: Dict[str, torch.Tensor] = dict(ndata or {})
         self.edata: Dict[str, torch.Tensor] = dict(edata or {})
         self._index = index
@@ -154,13 +155,24 @@ class BatchedMolGraph:
                             {k: v.to(device) for k, v in self.ndata.items()},
                             {k: v.to(device) for k, v in self.edata.items()},
                             self.index().to(device))
+        if device.type == 'cuda':
+            g.mark_ready()
         return g
+
+    def mark_ready(self):
+        """Record that everything this batch consists of has been enqueued on the current stream (streams.py: lets an
+        independent consumer on another stream wait for the batch only)."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self._src.device))
+        self.ready_event = ev
 
     def local_copy(self):
         """Same structure and tensors, fresh frames: the forward pass overwrites ndata/edata['feat'] (reference
         models/pna.py:162-163), so a resident batch that is stepped on repeatedly is forwarded through a copy."""
-        return BatchedMolGraph(self._src, self._dst, self._n, self._bnn, dict(self.ndata), dict(self.edata),
-                               self._index)
+        g = BatchedMolGraph(self._src, self._dst, self._n, self._bnn, dict(self.ndata), dict(self.edata),
+                            self._index)
+        g.ready_event = self.ready_event
+        return g
 
     # ---- kernel index -----------------------------------------------------------------
     def index(self) -> GraphIndex:

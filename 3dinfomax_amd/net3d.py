@@ -11,7 +11,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from . import ops, tape
+from . import ops, streams, tape
 from .graph import as_batched_graph
 from .layers import MLP, ReadoutFn, act_name, bn_counter_scope
 from .mol_encoder import AtomEncoder
@@ -115,8 +115,23 @@ class Net3D(nn.Module):
                           layers=readout_layers)
 
     def forward(self, graph, *unused):
-        with bn_counter_scope():
-            return tape.run_model(self, lambda: self._forward(graph))
+        g = as_batched_graph(graph)
+        side = None
+        if self.training and torch.is_grad_enabled() and g.device.type == 'cuda':
+            side = streams.side_stream_for(getattr(g, 'ready_event', None), g.device)
+        if side is None:
+            with bn_counter_scope():
+                return tape.run_model(self, lambda: self._forward(g))
+        # next to the 2D network on a side stream (streams.py); the caller's stream waits before anything is handed back
+        main = torch.cuda.current_stream(g.device)
+        with torch.cuda.stream(side):
+            with bn_counter_scope():
+                z = tape.run_model(self, lambda: self._forward(g))
+        for t in (z, g.ndata.get('feat'), g.edata.get('d')):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(main)
+        main.wait_stream(side)
+        return z
 
     def _forward(self, graph):
         g = as_batched_graph(graph)

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import layer_native, ops, tape
+from . import layer_native, ops, streams, tape
 from .graph import as_batched_graph
 from .layers import (MLP, AggregateFn, Concat2FCFn, EdgeFCFn, EdgeTable, FCFn, GroupedConcat2FCFn, ReadoutFn,
                      bn_counter_scope)
@@ -86,6 +86,8 @@ class PNA(nn.Module):
 
     def forward(self, graph, *unused):
         g = as_batched_graph(graph)
+        if self.training and g.device.type == 'cuda' and torch.is_grad_enabled():
+            streams.note_step_start(g.device)       # lets an independent Net3D forward run next to this one
         with bn_counter_scope():
             return tape.run_model(self, lambda: self._forward(g))     # one autograd node for the whole model
 

@@ -60,3 +60,50 @@ class fork:
     def join(self):
         if self.active:
             self.main.wait_stream(self.side)
+
+
+# ---- the 3D network next to the 2D network ---------------------------------------------------------------------------
+# Net3D is ~85 small launches per step (140k edges x 20 features: 5-15 us kernels that occupy a fraction of the chip)
+# and is independent of PNA until the loss.  When the caller runs `model(g2d)` and then `model3d(g3d)` - the reference's
+# forward_pass, trainer/self_supervised_trainer.py:24-29 - Net3D's kernels go to a side stream that only waits for (a)
+# everything the main stream held when PNA.forward was ENTERED (so the previous optimizer step is in, PNA's own kernels
+# are not) and (b) the event the batch carries from its own assembly (graph.py: BatchedMolGraph.ready_event).  The main
+# stream waits for the side stream before Net3D.forward returns, so every consumer of its output is ordered as before;
+# autograd runs the backward of Net3D on the same side stream and joins it.  Any other call pattern (no step-start
+# mark, a backward pass in between, a foreign graph object without the event) keeps Net3D on the caller's stream.
+# I3D_NET3D_STREAM=0 switches it off.
+NET3D_STREAM = os.environ.get('I3D_NET3D_STREAM', '1') != '0'
+
+
+def note_step_start(device):
+    """PNA.forward entry: remember the main stream's position."""
+    if not NET3D_STREAM:
+        return
+    ev = getattr(_tls, 'step_event', None)
+    if ev is None:
+        ev = _tls.step_event = torch.cuda.Event()
+    stream = torch.cuda.current_stream(device)
+    ev.record(stream)
+    _tls.step_valid = (device.index, stream.cuda_stream, _generation[0])
+
+
+_generation = [0]      # bumped by every model backward pass (any thread): a mark taken before it is stale
+
+
+def invalidate_step():
+    """a backward pass ran: parameters may change before the next forward"""
+    _generation[0] += 1
+
+
+def side_stream_for(graph_event, device):
+    """The side stream, already ordered after the step-start mark and the batch's own event - or None."""
+    if not NET3D_STREAM or graph_event is None:
+        return None
+    main = torch.cuda.current_stream(device)
+    if getattr(_tls, 'step_valid', None) != (device.index, main.cuda_stream, _generation[0]):
+        return None
+    _tls.step_valid = None                      # one consumer per mark
+    side = _side(device)
+    side.wait_event(_tls.step_event)
+    side.wait_event(graph_event)
+    return side

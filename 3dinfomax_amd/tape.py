@@ -18,7 +18,7 @@ import threading
 
 import torch
 
-from . import ops
+from . import ops, streams
 
 _tls = threading.local()
 
@@ -132,6 +132,7 @@ class ModelFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
+        streams.invalidate_step()
         grads = ctx.tape.backward(ctx.out_id, grad.contiguous())
         out = [grads[id(p)][0] if id(p) in grads else None for p in ctx.params]
         sink = _grad_sinks.get(id(ctx.params[0]))

@@ -299,7 +299,42 @@ def test_finetune_config_pna_only_l1_vs_oracle(amd, variant):
         grads_close_l2(param_grads(pna), {k: P[k].grad for k in O.trainable(P)}, 5e-2, 'pna ')
 
 
-def test_training_step_is_bit_deterministic(amd):
+@pytest.mark.parametrize('side_stream', [True, False])
+def test_training_step_is_bit_deterministic(amd, side_stream, monkeypatch):
+    monkeypatch.setattr(importlib.import_module('3dinfomax_amd.streams'), 'NET3D_STREAM', side_stream)
+    _training_step_is_bit_deterministic(amd)
+
+
+def test_net3d_side_stream_equals_single_stream(amd, monkeypatch):
+    """Net3D next to PNA on a side stream (streams.py) gives the same bits as the single-stream schedule, over several
+    optimisation steps (parameter updates, BN buffers and the side effects on the graph included)."""
+    streams = importlib.import_module('3dinfomax_amd.streams')
+    mols = synth.make_dataset(128, seed=33)
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(streams, 'NET3D_STREAM', mode)
+        torch.manual_seed(3)
+        pna = amd.PNA(avg_d=1.0, device='cuda:0', **dict(PNA_YML, propagation_depth=3)).cuda().train()
+        net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_YML).cuda().train()
+        loss_fn = amd.NTXent(tau=0.1)
+        params = list(pna.parameters()) + list(net.parameters())
+        optim = amd.Adam(params, lr=1e-3)
+        g2, g3 = make_batch(amd, mols)
+        for _ in range(6):
+            a, b = g2.local_copy(), g3.local_copy()
+            loss = loss_fn(pna(a), net(b))
+            loss.backward()
+            optim.step()
+            optim.zero_grad()
+        torch.cuda.synchronize()
+        res[mode] = ([p.detach().clone() for p in params] + [bf.detach().clone().float() for bf in net.buffers()]
+                     + [b.ndata['feat'].detach().clone(), b.edata['d'].detach().clone()], loss.item())
+    assert res[True][1] == res[False][1]
+    for x, y in zip(res[True][0], res[False][0]):
+        assert torch.equal(x, y)
+
+
+def _training_step_is_bit_deterministic(amd):
     """Two runs of three optimisation steps from the same initial state end in bit-identical parameters: every
     reduction on the path has a fixed summation order (segmented sums, two-stage column reductions, split-K slices
     through the scratch, embedding-table gradients as a multi-hot GEMM) - no atomics."""
