@@ -56,10 +56,13 @@ class PnaLayerArgs(ctypes.Structure):
     _fields_ = [('edge', EdgeFcArgs), ('n_pre_extra', c_int), ('pre', FcArgs * 3), ('n_aggregators', c_int),
                 ('n_scalers', c_int), ('force_scalers', c_int), ('aggregators', c_int * 8), ('scalers', c_int * 4),
                 ('avg_d_log', c_float), ('msg', _P), ('grad_msg', _P), ('post', GroupedFcArgs), ('n_post_extra', c_int),
-                ('postx', FcArgs * 3), ('residual', c_int), ('grad_out', _P)]
+                ('postx', FcArgs * 3), ('residual', c_int), ('grad_out', _P), ('agg_event_start', _P), ('agg_event_stop', _P)]
 
 
 _SIGNATURES = {
+    'i3d_event_create': (c_int, [POINTER(c_void_p)]),
+    'i3d_event_destroy': (c_int, [_P]),
+    'i3d_event_elapsed_ms': (c_int, [_P, _P, POINTER(c_float)]),
     'i3d_pna_layer_fwd': (c_int, [POINTER(PnaLayerArgs), _P]),
     'i3d_pna_layer_bwd': (c_int, [POINTER(PnaLayerArgs), _P]),
     'i3d_fc_bn_fwd': (c_int, [POINTER(FcArgs), _P]),

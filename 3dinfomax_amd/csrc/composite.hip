@@ -134,8 +134,10 @@ extern "C" int i3d_pna_layer_fwd(const I3dPnaLayerArgs* a, void* stream) {
                       a->n_post_extra <= I3D_MAX_EXTRA_FC, "bad arguments");
     TRY(i3d_edge_fc_bn_fwd(&a->edge, stream));
     for (int i = 0; i < a->n_pre_extra; ++i) TRY(i3d_fc_bn_fwd(&a->pre[i], stream));
+    if (a->agg_event_start != nullptr) hipEventRecord((hipEvent_t)a->agg_event_start, (hipStream_t)stream);
     TRY(i3d_pna_aggregate_fwd(a->msg, a->edge.in_ptr, a->edge.num_nodes, a->edge.f_out, a->aggregators, a->n_aggregators,
                               a->scalers, a->n_scalers, a->force_scalers, a->avg_d_log, const_cast<float*>(a->post.agg), stream));
+    if (a->agg_event_stop != nullptr) hipEventRecord((hipEvent_t)a->agg_event_stop, (hipStream_t)stream);
     TRY(i3d_grouped_fc_bn_fwd(&a->post, stream));
     for (int i = 0; i < a->n_post_extra; ++i) TRY(i3d_fc_bn_fwd(&a->postx[i], stream));
     return I3D_OK;
@@ -153,5 +155,31 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     const long n = (long)a->edge.num_nodes * a->edge.f_h;
     TRY(i3d_add_inplace(a->post.grad_h, a->edge.grad_h, n, stream));
     if (a->residual) TRY(i3d_add_inplace(a->post.grad_h, a->grad_out, n, stream));
+    return I3D_OK;
+}
+
+// ---- timing events -------------------------------------------------------------------------------------
+extern "C" int i3d_event_create(void** event) {
+    I3D_CHECK_ARG(event != nullptr, "null");
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) {
+        i3d::set_error("hipEventCreate failed");
+        return I3D_ERR_LAUNCH;
+    }
+    *event = (void*)e;
+    return I3D_OK;
+}
+
+extern "C" int i3d_event_destroy(void* event) {
+    if (event != nullptr) hipEventDestroy((hipEvent_t)event);
+    return I3D_OK;
+}
+
+extern "C" int i3d_event_elapsed_ms(void* start, void* stop, float* ms) {
+    I3D_CHECK_ARG(start != nullptr && stop != nullptr && ms != nullptr, "null");
+    if (hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) {
+        i3d::set_error("hipEventElapsedTime failed (events not completed?)");
+        return I3D_ERR_LAUNCH;
+    }
     return I3D_OK;
 }

@@ -191,8 +191,14 @@ def forward(ctx, h, q, index, qmap, plan, params):
         if last and plan.residual:
             c.residual = h.data_ptr()
         x_ptr, f_in = c.y, Fo
+    if ops.KERNEL_TIMERS is not None:   # bench.py: HIP events on the launch stream around the roofline kernel
+        t0, t1 = ops.RawEvent(), ops.RawEvent()
+        a.agg_event_start, a.agg_event_stop = t0.handle, t1.handle
+        ops.KERNEL_TIMERS.setdefault('pna_aggregate_fwd', []).append(
+            (t0, t1, N, E, Fmsg, len(plan.aggregators) * len(plan.agg_scalers) * Fmsg))
     L = _lib.load()
     _lib.check(L.i3d_pna_layer_fwd(ctypes.byref(a), ops._stream()), 'i3d_pna_layer_fwd')
+    a.agg_event_start = a.agg_event_stop = None
     for spec in plan.pre_specs + plan.post_specs:
         _bump(spec.bn.num_batches_tracked)
     ctx.native = (a, ar, h, q, qmap, index, plan, params, (N, E, Fh, Fq, A, nG))

@@ -4,6 +4,7 @@ torch is plumbing here: it owns device memory (caching allocator) and the curren
 computation below is one of the hand-written gfx950 kernels in csrc/.  No autograd in this file - the
 autograd.Functions in layers.py / pna.py / net3d.py / losses.py chain these calls explicitly.
 """
+import ctypes
 import os
 import threading
 
@@ -71,6 +72,26 @@ def _gemm_workspace(device):
 
 # I3D_GEMM_SCRATCH=0: fp32 atomics on top of a zero-fill instead of the two-stage reduction (A/B switch)
 GEMM_WORKSPACE_BYTES = (48 << 20) if os.environ.get('I3D_GEMM_SCRATCH', '1') != '0' else 0
+
+
+class RawEvent:
+    """hipEvent_t created through the C ABI (for measurements around a kernel that a composite launches)"""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        check(_lib.load().i3d_event_create(ctypes.byref(h)), 'i3d_event_create')
+        self.handle = h.value
+
+    def elapsed_time(self, stop):
+        ms = ctypes.c_float()
+        check(_lib.load().i3d_event_elapsed_ms(self.handle, stop.handle, ctypes.byref(ms)), 'i3d_event_elapsed_ms')
+        return ms.value
+
+    def __del__(self):
+        try:
+            _lib.load().i3d_event_destroy(self.handle)
+        except Exception:
+            pass
 
 
 def agg_codes(names):

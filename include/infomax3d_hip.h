@@ -392,7 +392,14 @@ typedef struct { /* one PNA layer, reference models/pna.py:199-216: pretrans edg
     I3dFcArgs postx[I3D_MAX_EXTRA_FC];
     int residual;          /* h_new += h (fused into the last block's BN apply by the caller via its residual pointer) */
     const float* grad_out; /* [N, F] incoming gradient of the layer output (added to post.grad_h when residual) */
+    void* agg_event_start; /* optional (i3d_event_create): recorded on the stream right before / after the forward */
+    void* agg_event_stop;  /* aggregation kernel - the roofline measurement of bench.py */
 } I3dPnaLayerArgs;
+
+/* timing events for measurements around a kernel inside a composite (thin wrappers of hipEvent_t) */
+int i3d_event_create(void** event);
+int i3d_event_destroy(void* event);
+int i3d_event_elapsed_ms(void* start, void* stop, float* ms);   /* both events must have completed */
 
 int i3d_pna_layer_fwd(const I3dPnaLayerArgs* args, void* stream);
 int i3d_pna_layer_bwd(const I3dPnaLayerArgs* args, void* stream);
