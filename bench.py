@@ -219,6 +219,22 @@ def main():
                 tot_bytes += reps * (4.0 * idx.num_edges * F + 4.0 * idx.num_nodes * n_blocks * F + 4.0 * (idx.num_nodes + 1))
             return tot_bytes / (tot_ms * 1e-3) / 1e9, tot_ms * 1e3 / (reps * len(batches))
 
+        # what an event pair costs by itself: the same measurement around a one-workgroup kernel (dispatch after the start
+        # event's barrier packet + completion signalling; the kernel body is ~1 us)
+        tiny = torch.zeros(64, device=dev)
+        null_ms = []
+        idx0 = batches[0][0].index()
+        e0 = torch.randn(idx0.num_edges, PNA_KW['hidden_dim'], device=dev)
+        for _ in range(150):      # ~2.5 ms of queued work: the pairs below are then measured on the device's time line,
+            ops.pna_aggregate_fwd(e0, idx0.in_ptr, idx0.num_nodes, aggs, scalers)      # not the host's enqueue pace
+        for _ in range(60):
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            ops.add_inplace(tiny, tiny)
+            t1.record()
+            null_ms.append((t0, t1))
+        torch.cuda.synchronize()
+        null_us = float(np.median([a.elapsed_time(b) for a, b in null_ms[10:]]) * 1e3)
         b2b, b2b_us = back_to_back(blocks)
         b2b12, b2b12_us = back_to_back(12)
         # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured with
@@ -235,12 +251,16 @@ def main():
                     unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     launches=len(ev), avg_us=round(float(ms.mean() * 1e3), 2),
                     algorithmic_bytes_per_launch=int(byts.mean()),
+                    event_pair_null_kernel_us=round(null_us, 2),
                     achieved_back_to_back=round(b2b, 1), frac_back_to_back=round(b2b / HBM_PEAK_GBS, 4),
                     avg_us_back_to_back=round(b2b_us, 2),
                     reference_shaped_12F=dict(achieved_back_to_back=round(b2b12, 1), frac_back_to_back=round(b2b12 / HBM_PEAK_GBS, 4),
                                               avg_us_back_to_back=round(b2b12_us, 2)),
-                    note='achieved/frac: one HIP-event pair around every K4 launch of the timed steps (an event pair adds '
-                         '~3 us of dispatch latency to a ~9 us kernel; rocprofv3 kernel time in profiles/); *_back_to_back: '
+                    note='achieved/frac: one HIP-event pair around every K4 launch of the timed steps, recorded by the layer '
+                         'composite right before/after the launch; Net3D kernels run concurrently on a side stream. The '
+                         'same event pair around a one-workgroup kernel on a busy device measures '
+                         'event_pair_null_kernel_us (dispatch + completion signalling: the part of avg_us that is not the '
+                         'kernel; rocprofv3 kernel time in profiles/); *_back_to_back: '
                          '20 launches per event pair after the timed region; reference_shaped_12F: the [N,12F] kernel of '
                          'SURVEY.md 8(d) (I3D_GROUPED_POSTTRANS=0 path); traffic: rocprofv3 PMC bytes per launch')
 
