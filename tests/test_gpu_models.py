@@ -216,6 +216,69 @@ def test_bond_table_path_matches_dense_bond_embeddings(amd, composite, fused, fu
     grads_close(res[True][3], res[False][3], 1e-4, 'pna ')
 
 
+def _star(n_leaves, seed):
+    """a centre atom bonded to n_leaves atoms (in-degree n_leaves at the centre, 1 at the leaves)"""
+    rng = np.random.default_rng(seed)
+    n = n_leaves + 1
+    src = np.concatenate([np.zeros(n_leaves, np.int64), np.arange(1, n, dtype=np.int64)])
+    dst = np.concatenate([np.arange(1, n, dtype=np.int64), np.zeros(n_leaves, np.int64)])
+    order = rng.permutation(len(src))                       # edge ids in arbitrary order
+    return synth.Molecule(n, src[order], dst[order],
+                          np.stack([rng.integers(0, d, n) for d in synth.ATOM_FEATURE_DIMS], 1).astype(np.int64),
+                          np.stack([rng.integers(0, d, len(src)) for d in synth.BOND_FEATURE_DIMS], 1).astype(np.int64),
+                          rng.normal(0, 1.5, (n, 3)).astype(np.float32))
+
+
+def _lonely(seed):
+    """a single atom: no bonds (in-degree 0: DGL leaves zero rows), a one-node complete graph without edges"""
+    rng = np.random.default_rng(seed)
+    return synth.Molecule(1, np.zeros(0, np.int64), np.zeros(0, np.int64),
+                          np.stack([rng.integers(0, d, 1) for d in synth.ATOM_FEATURE_DIMS], 1).astype(np.int64),
+                          np.zeros((0, 3), np.int64), rng.normal(0, 1.5, (1, 3)).astype(np.float32))
+
+
+@pytest.mark.parametrize('case', ['ragged', 'tiny_batch', 'wide_degrees'])
+def test_edge_case_batches_vs_oracle(amd, case):
+    """Ragged and degenerate batches through the whole fast path (native layer, tape, side stream) against the oracle:
+    isolated atoms (in-degree 0, a graph without edges), two-atom molecules, a hub of in-degree 33 (beyond the 32-entry
+    scaler table), many distinct degrees (> 5 degree groups), a batch of six large graphs (one graph in training mode is an
+    error in the reference too: BatchNorm over a single row)."""
+    if case == 'ragged':
+        mols = [_lonely(1), _star(1, 2), synth.make_dataset(3, seed=9)[0], _star(6, 3), _lonely(4), _star(33, 5),
+                synth.make_dataset(3, seed=9)[1]]
+    elif case == 'tiny_batch':
+        mols = synth.make_dataset(6, seed=12, kind='qmugs')      # (two graphs: the head's BatchNorm over 2 rows is x_hat = +-1,
+        #                                                          its gradient is rounding noise times 1/sqrt(var): not comparable)
+    else:
+        mols = [_star(k, 20 + k) for k in (1, 2, 3, 5, 7, 8, 9, 12, 17)] + synth.make_dataset(4, seed=13)
+    kw2 = dict(PNA_SMALL, aggregators=['mean', 'sum', 'std', 'var'], readout_aggregators=['mean', 'sum'])   # smooth: no arg-max routing
+    kw3 = dict(NET3D_SMALL, readout_aggregators=['mean', 'sum'])
+    pna = amd.PNA(avg_d=1.0, device='cuda:0', **kw2)
+    net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **kw3)
+    _det_load(pna, 'pnaE')
+    _det_load(net, 'net3dE')
+    P2 = O.require_grad({k: v.clone() for k, v in pna.state_dict().items()})
+    P3 = O.require_grad({k: v.clone() for k, v in net.state_dict().items()})
+    og2, og3 = O.graphs_from_molecules(mols)
+    r2, remb = O.pna_forward(og2, P2, O.pna_config(**kw2), True)
+    r3, _ = O.net3d_forward(og3, P3, O.net3d_config(**kw3), True)
+    pna.cuda().train(), net.cuda().train()
+    g2, g3 = make_batch(amd, mols)
+    z2, z3 = pna(g2), net(g3)
+    assert rel_err(g2.ndata['feat'].cpu(), remb.detach()) < TOL
+    assert rel_err(z2.cpu(), r2.detach()) < TOL and rel_err(z3.cpu(), r3.detach()) < TOL
+    if len(mols) > 1:
+        rloss = O.ntxent(r2, r3, 0.1)
+        loss = amd.NTXent(tau=0.1)(z2, z3)
+        assert abs(loss.item() - rloss.item()) < TOL * abs(rloss.item())
+    else:                       # NT-Xent of a single pair has no negatives: compare through a plain quadratic loss
+        rloss, loss = (r2 * r2).sum() + (r3 * r3).sum(), (z2 * z2).sum() + (z3 * z3).sum()
+    rloss.backward()
+    loss.backward()
+    grads_close(param_grads(pna), {k: P2[k].grad for k in O.trainable(P2)}, 1e-3, 'pna ')
+    grads_close(param_grads(net), {k: P3[k].grad for k in O.trainable(P3)}, 1e-3, 'net3d ')
+
+
 SMOOTH = dict(aggregators=['mean', 'sum', 'std', 'var'], readout_aggregators=['mean', 'sum'])
 
 
