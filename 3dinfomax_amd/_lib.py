@@ -105,6 +105,8 @@ _SIGNATURES = {
     'i3d_act_fwd': (c_int, [_P, c_long, c_int, _P, _P]),
     'i3d_act_bwd': (c_int, [_P, _P, c_long, c_int, _P, _P]),
     'i3d_add_inplace': (c_int, [_P, _P, c_long, _P]),
+    'i3d_add': (c_int, [_P, _P, c_long, _P, _P]),
+    'i3d_broadcast_row': (c_int, [_P, c_long, c_int, _P, _P]),
     'i3d_edge_combine_fwd': (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     'i3d_multihot': (c_int, [_P, _P, c_int, c_int, POINTER(c_int), c_int, _P, _P]),
     'i3d_edge_codes': (c_int, [_P, _P, c_int, c_int, POINTER(c_int), c_int, _P, _P, _P]),
@@ -115,8 +117,8 @@ _SIGNATURES = {
     'i3d_soft_edge_fwd': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P]),
     'i3d_soft_edge_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
     'i3d_row_norms': (c_int, [_P, c_int, c_int, _P, _P]),
-    'i3d_ntxent_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
-    'i3d_ntxent_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P]),
+    'i3d_ntxent_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P]),
+    'i3d_ntxent_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P]),
     'i3d_row_axpy': (c_int, [_P, _P, c_int, c_int, _P, _P]),
     'i3d_row_scale': (c_int, [_P, _P, c_int, c_int, _P, _P]),
     'i3d_contrastive_rowstats': (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, c_float, _P, _P]),

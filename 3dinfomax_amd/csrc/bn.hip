@@ -638,6 +638,17 @@ __global__ void __launch_bounds__(256) add_inplace_kernel(float* __restrict__ ds
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) dst[t] += src[t];
 }
 
+__global__ void __launch_bounds__(256) add_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                  float* __restrict__ out) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) out[t] = a[t] + b[t];
+}
+
+__global__ void __launch_bounds__(256) broadcast_row_kernel(const float* __restrict__ row, long rows, int feat,
+                                                            float* __restrict__ out) {
+    const long n = rows * feat;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) out[t] = row[t % feat];
+}
+
 static int grid_for(long items) {
     long b = (items + 255) / 256;
     if (b > 256 * 16) b = 256 * 16;
@@ -875,6 +886,21 @@ extern "C" int i3d_act_bwd(const float* grad_y, const float* x, long n, int act,
 extern "C" int i3d_add_inplace(float* dst, const float* src, long n, void* stream) {
     if (n <= 0) return I3D_OK;
     hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_add(const float* a, const float* b, long n, float* out, void* stream) {
+    if (n <= 0) return I3D_OK;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, out);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_broadcast_row(const float* row, long rows, int feat, float* out, void* stream) {
+    I3D_CHECK_ARG(rows >= 0 && feat > 0, "bad shape");
+    if (rows == 0) return I3D_OK;
+    hipLaunchKernelGGL(broadcast_row_kernel, dim3(grid_for(rows * feat)), dim3(256), 0, (hipStream_t)stream, row, rows, feat, out);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }

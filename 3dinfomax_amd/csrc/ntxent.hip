@@ -58,23 +58,24 @@ ntxent_fwd_kernel(const float* __restrict__ sim, const float* __restrict__ n1, c
 }
 
 __global__ void __launch_bounds__(256)
-ntxent_loss_kernel(const float* __restrict__ row_sum, const float* __restrict__ row_pos, int b1,
+ntxent_loss_kernel(const float* __restrict__ row_sum, const float* __restrict__ row_pos, int b1, float scale,
                    float* __restrict__ loss_sum) {
     __shared__ float sm[4];
     float acc = 0.f;
     for (int i = threadIdx.x; i < b1; i += 256) acc += -logf(row_pos[i] / (row_sum[i] - row_pos[i]));
     float s = block_sum(acc, sm);
-    if (threadIdx.x == 0) loss_sum[0] = s;
+    if (threadIdx.x == 0) loss_sum[0] = s * scale;
 }
 
 // dL/dP_ij = gs * ( j positive ? -1/pos_i : 1/(rowsum_i - pos_i) ),  G = dL/dP * P / tau,  H = G / (a_i b_j + eps)
 __global__ void __launch_bounds__(256)
 ntxent_bwd_row_kernel(const float* __restrict__ sim, const float* __restrict__ n1, const float* __restrict__ n2,
                       const float* __restrict__ row_sum, const float* __restrict__ row_pos, int b1, int ncol, int conf,
-                      int pos_offset, float inv_tau, float eps, float gs, float* __restrict__ dsim,
-                      float* __restrict__ ca) {
+                      int pos_offset, float inv_tau, float eps, float gs, const float* __restrict__ gs_dev,
+                      float* __restrict__ dsim, float* __restrict__ ca) {
     __shared__ float sm[4];
     int i = blockIdx.x;
+    if (gs_dev != nullptr) gs *= gs_dev[0];      // the upstream scalar gradient stays on the device
     float a = n1[i];
     int p0 = (pos_offset + i) * conf, p1 = p0 + conf;
     float pos = row_pos[i], den = row_sum[i] - pos;
@@ -171,27 +172,28 @@ extern "C" int i3d_row_norms(const float* z, int rows, int dim, float* norms, vo
 }
 
 extern "C" int i3d_ntxent_fwd(const float* sim, const float* n1, const float* n2, int b1, int b2, int conf,
-                              int pos_offset, float tau, float eps, float* row_sum, float* row_pos, float* loss_sum,
-                              void* stream) {
+                              int pos_offset, float tau, float eps, float loss_scale, float* row_sum, float* row_pos,
+                              float* loss_sum, void* stream) {
     I3D_CHECK_ARG(b1 > 0 && b2 > 0 && conf > 0 && tau > 0.f, "bad shape");
     I3D_CHECK_ARG(pos_offset >= 0 && pos_offset + b1 <= b2, "positive columns out of range");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(ntxent_fwd_kernel, dim3(b1), dim3(256), 0, s, sim, n1, n2, b1, b2 * conf, conf, pos_offset,
                        1.f / tau, eps, row_sum, row_pos);
     I3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ntxent_loss_kernel, dim3(1), dim3(256), 0, s, row_sum, row_pos, b1, loss_sum);
+    hipLaunchKernelGGL(ntxent_loss_kernel, dim3(1), dim3(256), 0, s, row_sum, row_pos, b1, loss_scale, loss_sum);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }
 
 extern "C" int i3d_ntxent_bwd(const float* sim, const float* n1, const float* n2, const float* row_sum,
                               const float* row_pos, int b1, int b2, int conf, int pos_offset, float tau, float eps,
-                              float grad_scale, float* dsim, float* ca, float* cb, void* stream) {
+                              float grad_scale, const float* grad_scale_dev, float* dsim, float* ca, float* cb,
+                              void* stream) {
     I3D_CHECK_ARG(b1 > 0 && b2 > 0 && conf > 0 && tau > 0.f, "bad shape");
     hipStream_t s = (hipStream_t)stream;
     int ncol = b2 * conf;
     hipLaunchKernelGGL(ntxent_bwd_row_kernel, dim3(b1), dim3(256), 0, s, sim, n1, n2, row_sum, row_pos, b1, ncol, conf,
-                       pos_offset, 1.f / tau, eps, grad_scale, dsim, ca);
+                       pos_offset, 1.f / tau, eps, grad_scale, grad_scale_dev, dsim, ca);
     I3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(ntxent_bwd_col_kernel, dim3(cdiv(ncol, COL_W)), dim3(256), 0, s, sim, dsim, n1, n2, b1, ncol, eps, cb);
     I3D_CHECK_LAUNCH();

@@ -38,23 +38,23 @@ class NTXentFn(torch.autograd.Function):
         b1, b2 = z1.shape[0], z2.shape[0] // conf
         n1, n2 = ops.row_norms(z1), ops.row_norms(z2)
         sim = ops.gemm(z1, z2, trans_b=True)                      # [b1, b2*conf] on the MFMA GEMM
-        row_sum, row_pos, loss_sum = ops.ntxent_fwd(sim, n1, n2, b1, b2, conf, pos_offset, tau, eps)
+        row_sum, row_pos, loss = ops.ntxent_fwd(sim, n1, n2, b1, b2, conf, pos_offset, tau, eps, 1.0 / global_batch)
         ctx.cfg = (tau, eps, conf, pos_offset, global_batch, b1, b2)
         ctx.save_for_backward(z1, z2, n1, n2, sim, row_sum, row_pos)
-        return (loss_sum / global_batch).reshape(())
+        return loss.reshape(())
 
     @staticmethod
     def backward(ctx, grad_out):
         z1, z2, n1, n2, sim, row_sum, row_pos = ctx.saved_tensors
         tau, eps, conf, pos_offset, global_batch, b1, b2 = ctx.cfg
+        # the upstream scalar gradient is multiplied in on the device (no host read-back, no extra elementwise op)
         dsim, ca, cb = ops.ntxent_bwd(sim, n1, n2, row_sum, row_pos, b1, b2, conf, pos_offset, tau, eps,
-                                      1.0 / global_batch)
+                                      1.0 / global_batch, grad_out.contiguous().float())
         dz1 = ops.gemm(dsim, z2)                                  # dS z2
         ops.row_axpy(z1, ca, dz1)
         dz2 = ops.gemm(dsim, z1, trans_a=True)                    # dS^T z1
         ops.row_axpy(z2, cb, dz2)
-        # upstream scalar stays on the device (no host sync)
-        return dz1 * grad_out, dz2 * grad_out, None, None, None, None, None
+        return dz1, dz2, None, None, None, None, None
 
 
 def uniformity_loss(x1: Tensor, x2: Tensor, t=2) -> Tensor:

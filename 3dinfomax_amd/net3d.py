@@ -22,7 +22,7 @@ class _BroadcastRowFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, emb, n):
-        return emb[None, :].expand(n, -1).contiguous()
+        return ops.broadcast_row(emb.contiguous(), n)
 
     @staticmethod
     def backward(ctx, g):
@@ -32,7 +32,7 @@ class _BroadcastRowFn(torch.autograd.Function):
 class _AddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
-        return ops.add_inplace(a.clone(), b.contiguous())
+        return ops.add(a.contiguous(), b.contiguous())
 
     @staticmethod
     def backward(ctx, g):

@@ -426,23 +426,38 @@ def row_norms(z):
     return n
 
 
-def ntxent_fwd(sim, n1, n2, b1, b2, conf, pos_offset, tau, eps):
+def ntxent_fwd(sim, n1, n2, b1, b2, conf, pos_offset, tau, eps, loss_scale=1.0):
     row_sum = torch.empty(b1, dtype=torch.float32, device=sim.device)
     row_pos = torch.empty(b1, dtype=torch.float32, device=sim.device)
     loss_sum = torch.empty(1, dtype=torch.float32, device=sim.device)
     check(_lib.load().i3d_ntxent_fwd(_p(sim), _p(n1), _p(n2), b1, b2, conf, pos_offset, float(tau), float(eps),
-                                     _p(row_sum), _p(row_pos), _p(loss_sum), _stream()), 'i3d_ntxent_fwd')
+                                     float(loss_scale), _p(row_sum), _p(row_pos), _p(loss_sum), _stream()), 'i3d_ntxent_fwd')
     return row_sum, row_pos, loss_sum
 
 
-def ntxent_bwd(sim, n1, n2, row_sum, row_pos, b1, b2, conf, pos_offset, tau, eps, grad_scale):
+def ntxent_bwd(sim, n1, n2, row_sum, row_pos, b1, b2, conf, pos_offset, tau, eps, grad_scale, grad_scale_dev=None):
     dsim = torch.empty_like(sim)
     ca = torch.empty(b1, dtype=torch.float32, device=sim.device)
     cb = torch.empty(b2 * conf, dtype=torch.float32, device=sim.device)
     check(_lib.load().i3d_ntxent_bwd(_p(sim), _p(n1), _p(n2), _p(row_sum), _p(row_pos), b1, b2, conf, pos_offset,
-                                     float(tau), float(eps), float(grad_scale), _p(dsim), _p(ca), _p(cb), _stream()),
+                                     float(tau), float(eps), float(grad_scale), _p(grad_scale_dev), _p(dsim), _p(ca), _p(cb),
+                                     _stream()),
           'i3d_ntxent_bwd')
     return dsim, ca, cb
+
+
+def add(a, b):
+    """a + b (new tensor) without a torch op: clone-free"""
+    out = torch.empty_like(a)
+    check(_lib.load().i3d_add(_p(a), _p(b), a.numel(), _p(out), _stream()), 'i3d_add')
+    return out
+
+
+def broadcast_row(row, rows):
+    """[rows, F] with every row = `row` [F]"""
+    out = torch.empty(rows, row.shape[0], dtype=torch.float32, device=row.device)
+    check(_lib.load().i3d_broadcast_row(_p(row), rows, row.shape[0], _p(out), _stream()), 'i3d_broadcast_row')
+    return out
 
 
 def row_axpy(z, coef, out):

@@ -110,7 +110,7 @@ class Tape:
                 elif fresh:
                     grads[key] = (ops.add_inplace(ga, cur[0].contiguous()), True)
                 else:
-                    grads[key] = (ops.add_inplace(cur[0].clone(), ga.contiguous()), True)
+                    grads[key] = (ops.add(cur[0].contiguous(), ga.contiguous()), True)
         return grads
 
 

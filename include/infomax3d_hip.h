@@ -205,8 +205,10 @@ int i3d_colsum(const float* x, const float* w, int rows, int feat, float* out, v
 /* y = act(x) elementwise (n elements); bwd: grad_x = grad_y * act'(x) */
 int i3d_act_fwd(const float* x, long n, int act, float* y, void* stream);
 int i3d_act_bwd(const float* grad_y, const float* x, long n, int act, float* grad_x, void* stream);
-/* dst += src */
+/* dst += src;  out = a + b;  out[r, :] = row for r < rows (Net3D's broadcast node embedding, models/net3d.py:61) */
 int i3d_add_inplace(float* dst, const float* src, long n, void* stream);
+int i3d_add(const float* a, const float* b, long n, float* out, void* stream);
+int i3d_broadcast_row(const float* row, long rows, int feat, float* out, void* stream);
 
 /* ---- edge kernels ----------------------------------------------------------------------------------
  * i3d_edge_combine_fwd replaces the gather + concat + first Linear of the edge MLPs,
@@ -261,11 +263,13 @@ int i3d_soft_edge_bwd(const float* grad_msg, const float* m, const float* w, con
  *   bwd: writes dsim = dL/dS (scaled by grad_scale = upstream/global_batch) and the norm-path
  *        coefficients ca[b1], cb[b2*conf] such that dz1 = dS z2 + ca*z1, dz2 = dS^T z1 + cb*z2. */
 int i3d_row_norms(const float* z, int rows, int dim, float* norms, void* stream);
+/* loss_sum[0] = loss_scale * sum_i l_i (loss_scale = 1/global batch);  the backward multiplies by grad_scale and, when
+ * grad_scale_dev != NULL, by the device scalar grad_scale_dev[0] (the upstream gradient of the loss: no host read-back) */
 int i3d_ntxent_fwd(const float* sim, const float* n1, const float* n2, int b1, int b2, int conf, int pos_offset,
-                   float tau, float eps, float* row_sum, float* row_pos, float* loss_sum, void* stream);
+                   float tau, float eps, float loss_scale, float* row_sum, float* row_pos, float* loss_sum, void* stream);
 int i3d_ntxent_bwd(const float* sim, const float* n1, const float* n2, const float* row_sum, const float* row_pos,
-                   int b1, int b2, int conf, int pos_offset, float tau, float eps, float grad_scale, float* dsim,
-                   float* ca, float* cb, void* stream);
+                   int b1, int b2, int conf, int pos_offset, float tau, float eps, float grad_scale,
+                   const float* grad_scale_dev, float* dsim, float* ca, float* cb, void* stream);
 /* out[r,:] += coef[r] * z[r,:] */
 int i3d_row_axpy(const float* z, const float* coef, int rows, int dim, float* out, void* stream);
 /* out[r,:] = coef[r] * z[r,:]   (graph-size normalisation h * snorm_n, reference models/pna_original.py:258-259) */
