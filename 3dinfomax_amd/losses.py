@@ -57,26 +57,34 @@ class NTXentFn(torch.autograd.Function):
         return dz1, dz2, None, None, None, None, None
 
 
+# Optional regularisers (weights 0 in every BASELINE config, so they are plain differentiable torch expressions here,
+# not kernels).  Semantics of reference commons/losses.py:946-964.
+def _log_mean_gaussian_potential(x, t):
+    """log of the mean of exp(-t |x_i - x_j|^2) over all unordered pairs i < j"""
+    n = x.shape[0]
+    sq = (x * x).sum(dim=1)
+    d2 = (sq[:, None] + sq[None, :] - 2.0 * (x @ x.T)).clamp_min(0.0)
+    iu = torch.triu_indices(n, n, offset=1, device=x.device)
+    return torch.exp(-t * d2[iu[0], iu[1]]).mean().log()
+
+
 def uniformity_loss(x1: Tensor, x2: Tensor, t=2) -> Tensor:
-    """reference commons/losses.py:946-951 (regulariser, off in every BASELINE config; plain torch)."""
-    u1 = torch.pdist(x1, p=2).pow(2).mul(-t).exp().mean().log()
-    u2 = torch.pdist(x2, p=2).pow(2).mul(-t).exp().mean().log()
-    return (u1 + u2) / 2
+    """mean of the two views' uniformity terms (Wang & Isola), reference :946-951"""
+    return 0.5 * (_log_mean_gaussian_potential(x1, t) + _log_mean_gaussian_potential(x2, t))
 
 
 def cov_loss(x):
-    """reference commons/losses.py:954-959."""
-    batch_size, metric_dim = x.size()
-    x = x - x.mean(dim=0)
-    cov = (x.T @ x) / (batch_size - 1)
-    off_diag_cov = cov.flatten()[:-1].view(metric_dim - 1, metric_dim + 1)[:, 1:].flatten()
-    return off_diag_cov.pow(2).sum() / metric_dim
+    """sum of squared off-diagonal entries of the feature covariance, divided by the feature count (reference :954-959)"""
+    n, dim = x.shape
+    centred = x - x.mean(dim=0, keepdim=True)
+    cov = centred.T @ centred / (n - 1)
+    off = cov - torch.diag_embed(torch.diagonal(cov))
+    return (off * off).sum() / dim
 
 
 def std_loss(x):
-    """reference commons/losses.py:962-964."""
-    std = torch.sqrt(x.var(dim=0) + 1e-04)
-    return torch.mean(torch.relu(1 - std))
+    """hinge on the per-feature standard deviation: mean(relu(1 - sqrt(var + 1e-4))) (reference :962-964)"""
+    return torch.relu(1.0 - (x.var(dim=0) + 1e-4).sqrt()).mean()
 
 
 class _NTXentBase(_Loss):
@@ -139,9 +147,8 @@ class NTXentMultiplePositives(_NTXentBase):
         z2v = z2.view(batch_size, -1, metric_dim)
         if self.variance_reg > 0:
             loss = loss + self.variance_reg * (std_loss(z1) + std_loss(z2v))
-        if self.conformer_variance_reg > 0:
-            std = torch.sqrt(z2v.var(dim=1) + 1e-04)
-            loss = loss + self.conformer_variance_reg * torch.mean(torch.relu(1 - std))
+        if self.conformer_variance_reg > 0:       # the same hinge over the conformer axis
+            loss = loss + self.conformer_variance_reg * torch.relu(1.0 - (z2v.var(dim=1) + 1e-4).sqrt()).mean()
         if self.covariance_reg > 0:
             loss = loss + self.covariance_reg * (cov_loss(z1) + cov_loss(z2v))
         if self.uniformity_reg > 0:
