@@ -47,6 +47,9 @@ def parse():
     ap.add_argument('--batch', type=int, default=512, help='molecules per GPU per step')
     ap.add_argument('--depth', type=int, default=4, help='PNA propagation depth (BASELINE.json: 4; pre-train_QM9.yml: 7)')
     ap.add_argument('--pool', type=int, default=4, help='number of distinct resident batches cycled through')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='nccl = RCCL (the measured path); gloo: host-staged collectives, several ranks may share a GPU '
+                         '(functional check of the N > 1 code path only)')
     ap.add_argument('--torch-adam', action='store_true', help='stock torch.optim.Adam(fused=True) instead of amd.Adam')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3)
@@ -86,6 +89,8 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    if args.backend == 'gloo':      # functional check of the N > 1 code path on a box with fewer GPUs than ranks
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
@@ -93,7 +98,10 @@ def main():
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.backend == 'gloo':
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     amd = importlib.import_module('3dinfomax_amd')
     ops = importlib.import_module('3dinfomax_amd.ops')
