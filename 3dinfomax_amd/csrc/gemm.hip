@@ -63,8 +63,13 @@ struct GemmArgs {
 __device__ __forceinline__ int swz(int k, int idx) { return idx ^ ((((k) ^ (k >> 2)) & 1) << 4); }
 
 // KC: the operand is k-contiguous (T[idx*ld + k]); otherwise idx-contiguous (T[k*ld + idx])
-template <int R, int LD, int BK, bool KC>
+// IM (k-contiguous operands only): the LDS image is idx-major, T[idx][BK + 2]: the 16-byte global load of 4 consecutive
+// k is stored with two 8-byte writes (instead of four transposing 4-byte writes) and a lane's MFMA operands for two
+// consecutive k-steps come from one 8-byte read; the row pitch BK + 2 keeps both conflict-free.
+template <int R, int LD, int BK, bool KC, bool IM = false>
 struct TileStage {
+    static constexpr int LDK = BK + 2;
+    static constexpr int LDS_FLOATS = IM ? R * LDK : BK * LD;
     static constexpr int SLOTS = R * BK / 4;                 // float4 slots in a tile
     static constexpr int KQ = BK / 4;                        // float4 slots along k of one row
     static constexpr int PER_THREAD = (SLOTS + 255) / 256;
@@ -137,7 +142,11 @@ struct TileStage {
         for (int it = 0; it < PER_THREAD; ++it) {
             int s = threadIdx.x + it * 256;
             if (s < SLOTS) {
-                if (KC) {
+                if (IM) {
+                    int idx = s / KQ, k = (s % KQ) * 4;
+                    *reinterpret_cast<float2*>(&T[idx * LDK + k]) = make_float2(r.v[it].x, r.v[it].y);
+                    *reinterpret_cast<float2*>(&T[idx * LDK + k + 2]) = make_float2(r.v[it].z, r.v[it].w);
+                } else if (KC) {
                     int idx = s / KQ, k = (s % KQ) * 4;
                     T[(k + 0) * LD + swz(k + 0, idx)] = r.v[it].x;
                     T[(k + 1) * LD + swz(k + 1, idx)] = r.v[it].y;
@@ -165,9 +174,10 @@ struct SegTable { Seg s[MAX_SEGS]; };
 
 // Tile shape: MT = MFMA tile (16: v_mfma_f32_16x16x4_f32, 32: v_mfma_f32_32x32x2_f32), a wave computes WM_T x WN_T
 // such tiles; PF = K-tiles in flight per workgroup.
-template <int MT_, int WAVES_M_, int WAVES_N_, int WM_T_, int WN_T_, int BK_, int PF_>
+template <int MT_, int WAVES_M_, int WAVES_N_, int WM_T_, int WN_T_, int BK_, int PF_, bool KP_ = false>
 struct Shape {
     static constexpr int MT = MT_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, WM_T = WM_T_, WN_T = WN_T_, BK = BK_, PF = PF_;
+    static constexpr bool KP = KP_;     // idx-major LDS image for k-contiguous operands (TileStage IM), 32x32x2 MFMA only
     static constexpr int BM = WAVES_M * WM_T * MT, BN = WAVES_N * WN_T * MT;
 };
 
@@ -193,8 +203,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     constexpr int BM = S::BM, BN = S::BN;
     constexpr int LDA = (BM + 31) / 32 * 32, LDB = (BN + 31) / 32 * 32;
     constexpr int KSTEP = (MT == 16) ? 4 : 2;         // k per MFMA
-    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+    constexpr bool A_IM = S::KP && A_KC && MT == 32, B_IM = S::KP && B_KC && MT == 32;
+    typedef TileStage<BM, LDA, BK, A_KC, A_IM> StageA;
+    typedef TileStage<BN, LDB, BK, B_KC, B_IM> StageB;
+    __shared__ __attribute__((aligned(16))) float As[2][StageA::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][StageB::LDS_FLOATS];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -208,8 +221,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 #pragma unroll
             for (int r = 0; r < Acc<MT>::REGS; ++r) acc[i][j][r] = 0.f;
 
-    typedef TileStage<BM, LDA, BK, A_KC> StageA;
-    typedef TileStage<BN, LDB, BK, B_KC> StageB;
     StageA sa;
     StageB sb;
     typename StageA::Regs ra_[PF];
@@ -243,6 +254,43 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
             if (t < nk) {
                 const float* as = As[cur];
                 const float* bs = Bs[cur];
+                if constexpr (S::KP && MT == 32) {
+                    // two k-steps per trip: lane half lk supplies k = 4 j + 2 lk (step 2j) and 4 j + 2 lk + 1 (step 2j+1)
+#pragma unroll
+                    for (int j4 = 0; j4 < BK / 4; ++j4) {
+                        const int k0 = 4 * j4 + 2 * lk;
+                        float a0[WM_T], a1[WM_T], b0[WN_T], b1[WN_T];
+#pragma unroll
+                        for (int i = 0; i < WM_T; ++i) {
+                            const int idx = (wm * WM_T + i) * MT + lt;
+                            if constexpr (A_IM) {
+                                const float2 v = *reinterpret_cast<const float2*>(&as[idx * StageA::LDK + k0]);
+                                a0[i] = v.x; a1[i] = v.y;
+                            } else {
+                                a0[i] = as[k0 * LDA + swz(k0, idx)];
+                                a1[i] = as[(k0 + 1) * LDA + swz(k0 + 1, idx)];
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < WN_T; ++j) {
+                            const int idx = (wn * WN_T + j) * MT + lt;
+                            if constexpr (B_IM) {
+                                const float2 v = *reinterpret_cast<const float2*>(&bs[idx * StageB::LDK + k0]);
+                                b0[j] = v.x; b1[j] = v.y;
+                            } else {
+                                b0[j] = bs[k0 * LDB + swz(k0, idx)];
+                                b1[j] = bs[(k0 + 1) * LDB + swz(k0 + 1, idx)];
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < WM_T; ++i)
+#pragma unroll
+                            for (int j = 0; j < WN_T; ++j) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[j], a0[i], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[j], a1[i], acc[i][j], 0, 0, 0);
+                            }
+                    }
+                } else
 #pragma unroll
                 for (int kk = 0; kk < BK / KSTEP; ++kk) {
                     const int kr = kk * KSTEP + lk;
@@ -484,6 +532,7 @@ static void launch_rowseg(const GemmArgs& g, const SegTable& t, int n_segs, bool
 //   0: 128x128x16 (32x32x2)  1: 256x32x16 (16x16x4)  2: 64x64x16 (32x32x2)  3: 32x64x32 (16x16x4)
 //   4: 64x64x32 (32x32x2)    5: 128x64x16 (32x32x2)  6 / 7: as 2 with 1 / 2 K-tiles in flight instead of 4
 //   8: 32x32x32 (16x16x4): weight gradients of the narrow (hidden_dim 20) 3D network, K = number of edges
+//   9 / 10: as 2 / 0 with the idx-major LDS image (TileStage IM) for k-contiguous operands
 typedef Shape<32, 2, 2, 2, 2, 16, 2> Cfg0;
 typedef Shape<16, 4, 1, 4, 2, 16, 2> Cfg1;
 typedef Shape<32, 2, 2, 1, 1, 16, 4> Cfg2;
@@ -493,10 +542,12 @@ typedef Shape<32, 2, 2, 2, 1, 16, 4> Cfg5;
 typedef Shape<32, 2, 2, 1, 1, 16, 1> Cfg6;
 typedef Shape<32, 2, 2, 1, 1, 16, 2> Cfg7;
 typedef Shape<16, 2, 2, 1, 1, 32, 2> Cfg8;
-constexpr int N_CFG = 9;
-static const int CFG_BM[N_CFG] = {Cfg0::BM, Cfg1::BM, Cfg2::BM, Cfg3::BM, Cfg4::BM, Cfg5::BM, Cfg6::BM, Cfg7::BM, Cfg8::BM};
-static const int CFG_BN[N_CFG] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN};
-static const int CFG_BK[N_CFG] = {Cfg0::BK, Cfg1::BK, Cfg2::BK, Cfg3::BK, Cfg4::BK, Cfg5::BK, Cfg6::BK, Cfg7::BK, Cfg8::BK};
+typedef Shape<32, 2, 2, 1, 1, 16, 4, true> Cfg9;       // as 2 with the idx-major LDS image for k-contiguous operands
+typedef Shape<32, 2, 2, 2, 2, 16, 2, true> Cfg10;      // as 0 with it
+constexpr int N_CFG = 11;
+static const int CFG_BM[N_CFG] = {Cfg0::BM, Cfg1::BM, Cfg2::BM, Cfg3::BM, Cfg4::BM, Cfg5::BM, Cfg6::BM, Cfg7::BM, Cfg8::BM, Cfg9::BM, Cfg10::BM};
+static const int CFG_BN[N_CFG] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN, Cfg9::BN, Cfg10::BN};
+static const int CFG_BK[N_CFG] = {Cfg0::BK, Cfg1::BK, Cfg2::BK, Cfg3::BK, Cfg4::BK, Cfg5::BK, Cfg6::BK, Cfg7::BK, Cfg8::BK, Cfg9::BK, Cfg10::BK};
 
 // the (A idx-contiguous, B k-contiguous) layout is computed as layout 2 would need B transposed: it only exists for
 // API completeness, through one configuration
@@ -590,6 +641,7 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     else if (trans_a && tiles64 < 512) cfg = 3;   // weight gradients: few output tiles, long K
     else cfg = 2;
     if (ex.tile_group != nullptr) cfg = 2;        // the group padding of m_rows is 64 rows
+    if (cfg == 2 && (!trans_a || trans_b)) cfg = 9;   // a k-contiguous operand: idx-major LDS image (2-4 % faster, r01_gemm_bench_v5)
     if (force_cfg >= 0) {
         I3D_CHECK_ARG(force_cfg < N_CFG, "tile_cfg out of range");
         I3D_CHECK_ARG(ex.tile_group == nullptr || CFG_BM[force_cfg] == 64, "grouped GEMM needs 64-row tiles");
@@ -646,7 +698,9 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
         case 5: launch<Cfg5>(g, layout, splits, vec, s); break;
         case 6: launch<Cfg6>(g, layout, splits, vec, s); break;
         case 7: launch<Cfg7>(g, layout, splits, vec, s); break;
-        default: launch<Cfg8>(g, layout, splits, vec, s); break;
+        case 8: launch<Cfg8>(g, layout, splits, vec, s); break;
+        case 9: launch<Cfg9>(g, layout, splits, vec, s); break;
+        default: launch<Cfg10>(g, layout, splits, vec, s); break;
     }
     I3D_CHECK_LAUNCH();
     if (use_slab) {

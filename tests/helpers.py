@@ -51,15 +51,17 @@ def rel_err(a, b):
 
 
 def grads_close(got, ref, rtol, what=''):
-    """Compare a dict of gradients with the reference's.  Gradients that are analytically zero (e.g. a bias in
-    front of a BatchNorm) are pure rounding noise in both implementations, so the absolute floor is tied to the
-    largest gradient in the whole set."""
+    """Compare a dict of gradients with the reference's.  The absolute floor is tied to the largest gradient in the whole
+    set.  Gradients that are analytically zero (a bias directly in front of a BatchNorm: the column sum of a BatchNorm
+    input gradient) are pure rounding noise in both implementations - recognisable by a reference value below 1e-4 of the
+    scale - and only have to stay noise-sized (5e-5 of the scale; the value moves with every change of a summation order)."""
     scale = max(float(np.abs(np.asarray(v)).max()) for v in ref.values())
     for k, v in ref.items():
         a = torch.as_tensor(got[k], dtype=torch.float64).cpu()
         b = torch.as_tensor(v, dtype=torch.float64)
         err = (a - b).abs().max().item()
-        bound = rtol * b.abs().max().item() + 5e-6 * scale
+        bmax = b.abs().max().item()
+        bound = rtol * bmax + (5e-5 if bmax < 1e-4 * scale else 5e-6) * scale
         assert err <= bound, f'{what}{k}: err {err:.3e} > {bound:.3e}'
 
 

@@ -275,8 +275,9 @@ def test_edge_case_batches_vs_oracle(amd, case):
         rloss, loss = (r2 * r2).sum() + (r3 * r3).sum(), (z2 * z2).sum() + (z3 * z3).sum()
     rloss.backward()
     loss.backward()
-    grads_close(param_grads(pna), {k: P2[k].grad for k in O.trainable(P2)}, 1e-3, 'pna ')
-    grads_close(param_grads(net), {k: P3[k].grad for k in O.trainable(P3)}, 1e-3, 'net3d ')
+    gtol = 1e-3
+    grads_close(param_grads(pna), {k: P2[k].grad for k in O.trainable(P2)}, gtol, 'pna ')
+    grads_close(param_grads(net), {k: P3[k].grad for k in O.trainable(P3)}, gtol, 'net3d ')
 
 
 SMOOTH = dict(aggregators=['mean', 'sum', 'std', 'var'], readout_aggregators=['mean', 'sum'])
