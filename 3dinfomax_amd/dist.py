@@ -58,6 +58,35 @@ def reduce_scatter_rows(g, group=None):
     return out
 
 
+def warm_up(device, steps=2):
+    """Run a tiny pre-training step on `device` BEFORE `init_process_group`.
+
+    Measured on MI355X / ROCm 7 (tools/step_segments.py --pg-first [--prepare-step]): a process that creates its RCCL
+    communicator before it has launched its own kernels and started autograd's worker thread runs EVERY later step ~7 %
+    slower (3.39-3.45 ms against 3.13-3.21 ms; the slowdown is per launch, on all segments of the step, and is there
+    even when no collective is ever called).  Two throw-away steps of a small model first - HIP library loaded, compute
+    and side streams created, autograd thread running, allocator pools populated - and the effect is gone."""
+    from . import synth
+    from .graph import batch, bond_graph, complete_graph
+    from .losses import NTXent
+    from .net3d import Net3D
+    from .pna import PNA
+    device = torch.device(device)
+    mols = synth.make_dataset(16, seed=0)
+    g2 = batch([bond_graph(m) for m in mols]).to(device)
+    g3 = batch([complete_graph(m) for m in mols]).to(device)
+    pna = PNA(hidden_dim=32, target_dim=16, propagation_depth=2, aggregators=['mean', 'max', 'min', 'std'],
+              scalers=['identity', 'amplification', 'attenuation'], readout_aggregators=['min', 'max', 'mean'],
+              avg_d=1.0, device=device).to(device).train()
+    net = Net3D(node_dim=0, edge_dim=1, hidden_dim=16, target_dim=16, propagation_depth=1, avg_d=1.0,
+                readout_aggregators=['min', 'max', 'mean']).to(device).train()
+    loss_fn = NTXent(tau=0.1)
+    for _ in range(steps):
+        a, b = g2.local_copy(), g3.local_copy()
+        loss_fn(pna(a), net(b)).backward()
+    torch.cuda.synchronize(device)
+
+
 def setup(modules, loss=None, group=None, sync_bn=False, broadcast=True):
     """Attach `group` to every FCLayer (sync-BN) of `modules` and to the loss; broadcast rank-0 weights."""
     from .layers import FCLayer
@@ -115,7 +144,10 @@ class GradReducer:
 
     def reduce(self):
         grads = [p.grad for p in self.params]
-        todo = [(v, g) for v, g in zip(self.views, grads) if g is not v]
+        # already in the buffer: the very view, or (when autograd's AccumulateGrad stored it) an alias of that view
+        todo = [(v, g) for v, g in zip(self.views, grads)
+                if g is not v and not (g is not None and g.data_ptr() == v.data_ptr() and g.shape == v.shape
+                                       and g.is_contiguous())]
         if todo:
             missing = [v for v, g in todo if g is None]
             if missing:                                 # a parameter without gradient this step counts as zero

@@ -138,7 +138,27 @@ class ModelFn(torch.autograd.Function):
         sink = _grad_sinks.get(id(ctx.params[0]))
         if sink is not None:         # data parallel: the gradients go straight into the all-reduce buffer (dist.GradReducer)
             out = sink(ctx.params, out)
+        if DIRECT_PARAM_GRADS and _plain_leaves(ctx.params):
+            # `.grad` is empty and nothing hooks the parameters: store the gradients here instead of sending them
+            # through ~110 AccumulateGrad nodes (each a task of the autograd engine; and a gradient that is a view of
+            # the all-reduce buffer would be CLONED there, because the buffer's own views keep it alive)
+            for p, g in zip(ctx.params, out):
+                if g is not None:
+                    p.grad = g
+            return (None,) * (1 + len(ctx.params))
         return (None,) + tuple(out)
+
+
+# I3D_DIRECT_PARAM_GRADS=0: hand the parameter gradients to autograd's AccumulateGrad nodes instead
+DIRECT_PARAM_GRADS = os.environ.get('I3D_DIRECT_PARAM_GRADS', '1') != '0'
+
+
+def _plain_leaves(params):
+    """no gradient to accumulate into, no tensor hooks, no post-accumulate hooks: `p.grad = g` is what autograd would do"""
+    for p in params:
+        if p.grad is not None or p._backward_hooks is not None or p._post_accumulate_grad_hooks is not None:
+            return False
+    return True
 
 
 _grad_sinks = {}       # id(first parameter of a model) -> callable(params, grads) -> grads

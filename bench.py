@@ -57,6 +57,9 @@ def parse():
                     help='N > 1: BatchNorm statistics over the global batch (exact single-process equivalence) instead of '
                          'per-rank statistics (DistributedDataParallel semantics, the default)')
     ap.add_argument('--no-sync-bn', action='store_true', help=argparse.SUPPRESS)   # former name of the default
+    ap.add_argument('--lead-probe', action='store_true',
+                    help='diagnostic: report how many steps the host runs ahead of the GPU (config.host_lead_steps)')
+    ap.add_argument('--no-prewarm', action='store_true', help='skip dist.warm_up before init_process_group (A/B)')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise RCCL and run the data-parallel code path even with one rank (self-test)')
     return ap.parse_args()
@@ -95,17 +98,18 @@ def main():
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
     use_dist = world > 1 or args.force_dist
+    amd = importlib.import_module('3dinfomax_amd')
+    ops = importlib.import_module('3dinfomax_amd.ops')
+    adist = importlib.import_module('3dinfomax_amd.dist')
     if use_dist:
+        if not args.no_prewarm:
+            adist.warm_up(dev)          # kernels, streams and autograd's thread before the communicator (dist.warm_up: 7 %)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         if args.backend == 'gloo':
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-
-    amd = importlib.import_module('3dinfomax_amd')
-    ops = importlib.import_module('3dinfomax_amd.ops')
-    adist = importlib.import_module('3dinfomax_amd.dist')
 
     # synthetic QM9-shaped data: `pool` global batches, each rank keeps its shard resident in HBM
     B, pool = args.batch, args.pool
@@ -154,10 +158,25 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+    if use_dist:       # RCCL prints its version banner through C stdio at communicator creation: push it out now, so that
+        import ctypes  # the JSON line is the last line of stdout
+        ctypes.CDLL(None).fflush(None)
     ops.KERNEL_TIMERS = {}
+    lead, lead_hist = [], []
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
+        if args.lead_probe:       # how many steps is the host ahead of the GPU? (0 = the GPU waits for the host)
+            ev = torch.cuda.Event()
+            ev.record()
+            lead.append(ev)
+            if i % 10 == 9:
+                pending = 0
+                for e in reversed(lead):
+                    if e.query():
+                        break
+                    pending += 1
+                lead_hist.append(pending)
     t_enqueue = time.perf_counter() - t0      # host time to enqueue the steps (== dt when host-bound)
     barrier()
     dt = time.perf_counter() - t0
@@ -283,6 +302,8 @@ def main():
                                optimizer='torch.optim.Adam(fused=True)' if args.torch_adam else 'infomax3d_amd.Adam (torch.optim.Adam subclass, torch._fused_adam_ kernel, cached tensor lists)',
                                global_batch=B * world, parallelism=f'dp{world}' if world > 1 else 'single',
                                sync_bn=(use_dist and args.sync_bn), final_loss=round(float(loss.item()), 5),
+                               **({'host_lead_steps_median': sorted(lead_hist)[len(lead_hist) // 2],
+                                   'host_lead_steps_min': min(lead_hist)} if lead_hist else {}),
                                host_enqueue_ms_per_step=round(t_enqueue / args.steps * 1e3, 3),
                                molecules_per_s_incl_batch_assembly_and_h2d=with_assembly),
                    roofline=roof)
