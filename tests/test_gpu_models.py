@@ -463,6 +463,46 @@ def test_adam_fast_path_is_torch_adam(amd):
     oa.step()
 
 
+def test_parameter_gradients_stored_by_the_model_node(amd, monkeypatch):
+    """tape.ModelFn stores `.grad` itself when the parameters are plain leaves: same values as through autograd's
+    AccumulateGrad nodes (I3D_DIRECT_PARAM_GRADS=0), gradient accumulation over two backward passes still sums, and a
+    tensor hook on a parameter still fires (both fall back to autograd's own accumulation)."""
+    tape = importlib.import_module('3dinfomax_amd.tape')
+    mols = synth.make_dataset(24, seed=21)
+    kw2 = dict(PNA_SMALL)
+    pna = amd.PNA(avg_d=1.0, device='cuda:0', **kw2).cuda().train()
+    _det_load(pna, 'pnaG')
+
+    def grads(direct, passes=1, hook=None):
+        monkeypatch.setattr(tape, 'DIRECT_PARAM_GRADS', direct)
+        pna.zero_grad()
+        handle = next(iter(pna.parameters())).register_hook(hook) if hook else None
+        for _ in range(passes):
+            g2, _ = make_batch(amd, mols)
+            (pna(g2) ** 2).sum().backward()
+        if handle is not None:
+            handle.remove()
+        return {k: p.grad.clone() for k, p in pna.named_parameters() if p.grad is not None}
+
+    a, b = grads(True), grads(False)
+    assert a.keys() == b.keys() and len(a) > 10
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    twice = grads(True, passes=2)
+    for k in a:
+        assert torch.allclose(twice[k], 2 * a[k], rtol=1e-5, atol=1e-6 * float(a[k].abs().max())), k
+    seen = []
+    hooked = grads(True, hook=lambda g: seen.append(g.shape))
+    assert len(seen) == 1
+    for k in a:
+        assert torch.equal(hooked[k], a[k]), k
+
+
+def test_dist_warm_up_runs(amd):
+    """dist.warm_up: the throw-away steps a data-parallel rank runs before it creates its communicator"""
+    importlib.import_module('3dinfomax_amd.dist').warm_up('cuda:0', steps=1)
+
+
 def test_missing_library_fails_loudly(amd, monkeypatch):
     L = importlib.import_module('3dinfomax_amd._lib')
     monkeypatch.setattr(L, '_lib', None)
