@@ -656,11 +656,12 @@ static int grid_for(long items) {
     return (int)b;
 }
 
-// Off by default: measured on MI355X the in-launch stage 2 costs what it saves on the GPU (ticket + poll + uncached
-// partial reads ~ 5 us vs a 4.5 us kernel + boundary) and only saves host launches (53 per step, ~0.18 ms);
-// I3D_FUSED_FINAL=1 enables it.
+// On by default (I3D_FUSED_FINAL=0: separate stage-2 launches).  Measured on MI355X the in-launch stage 2 costs on the
+// GPU what the extra kernel costs (ticket + poll + uncached partial reads ~ 5 us vs a 4.5 us kernel + boundary) and saves
+// the host 53 launches per step (~0.18 ms): -1.5 % step time at batch 512 / depth 4, at depth 7 and at batch 2048
+// (min and median of 4-6 interleaved runs per variant on one box, tools/ab.sh); bit-identical results.
 static bool fused_final() {
-    static const bool on = [] { const char* e = getenv("I3D_FUSED_FINAL"); return e != nullptr && e[0] == '1'; }();
+    static const bool on = [] { const char* e = getenv("I3D_FUSED_FINAL"); return e == nullptr || e[0] != '0'; }();
     return on;
 }
 

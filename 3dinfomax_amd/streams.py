@@ -95,6 +95,15 @@ def invalidate_step():
     _generation[0] += 1
 
 
+def on_side_stream(device):
+    """is this thread's current stream its side stream?"""
+    pool = getattr(_tls, 'pool', None)
+    if not pool:
+        return False
+    s = pool.get(device.index)
+    return s is not None and s.cuda_stream == torch._C._cuda_getCurrentRawStream(device.index)
+
+
 def side_stream_for(graph_event, device):
     """The side stream, already ordered after the step-start mark and the batch's own event - or None."""
     if not NET3D_STREAM or graph_event is None:

@@ -128,17 +128,25 @@ class ModelFn(torch.autograd.Function):
             _tls.tape = prev
         tape.release(out)
         ctx.tape, ctx.out_id, ctx.params = tape, id(out), params
+        ctx.on_side_stream = out.is_cuda and streams.on_side_stream(out.device)
         return out
 
     @staticmethod
     def backward(ctx, grad):
         streams.invalidate_step()
-        grads = ctx.tape.backward(ctx.out_id, grad.contiguous())
-        out = [grads[id(p)][0] if id(p) in grads else None for p in ctx.params]
-        sink = _grad_sinks.get(id(ctx.params[0]))
-        if sink is not None:         # data parallel: the gradients go straight into the all-reduce buffer (dist.GradReducer)
-            out = sink(ctx.params, out)
-        if DIRECT_PARAM_GRADS and _plain_leaves(ctx.params):
+        direct = DIRECT_PARAM_GRADS and _plain_leaves(ctx.params)
+        if direct and ASYNC_SIDE_BACKWARD and ctx.on_side_stream:
+            # The model ran next to another one on the side stream (streams.py: Net3D beside PNA) and autograd has made
+            # that stream current for this node: hand the whole backward pass to a helper thread and return, so that
+            # autograd's worker goes on with the other model's backward.  The two Python threads take turns at C-call
+            # granularity (every kernel launch releases the GIL); kernels, streams and their order are as before.  A
+            # callback at the end of the backward pass joins the helper and orders the caller's stream after it.
+            job = _Job(torch.cuda.current_stream(grad.device), ctx, grad.contiguous())
+            _helper().put(job)
+            torch.autograd.Variable._execution_engine.queue_callback(job.join)
+            return (None,) * (1 + len(ctx.params))
+        out = _model_backward(ctx, grad.contiguous())
+        if direct:
             # `.grad` is empty and nothing hooks the parameters: store the gradients here instead of sending them
             # through ~110 AccumulateGrad nodes (each a task of the autograd engine; and a gradient that is a view of
             # the all-reduce buffer would be CLONED there, because the buffer's own views keep it alive)
@@ -147,6 +155,74 @@ class ModelFn(torch.autograd.Function):
                     p.grad = g
             return (None,) * (1 + len(ctx.params))
         return (None,) + tuple(out)
+
+
+def _model_backward(ctx, grad):
+    grads = ctx.tape.backward(ctx.out_id, grad)
+    out = [grads[id(p)][0] if id(p) in grads else None for p in ctx.params]
+    sink = _grad_sinks.get(id(ctx.params[0]))
+    if sink is not None:         # data parallel: the gradients go straight into the all-reduce buffer (dist.GradReducer)
+        out = sink(ctx.params, out)
+    return out
+
+
+# I3D_ASYNC_SIDE_BACKWARD=1: the side-stream model's backward pass is enqueued by a helper thread while autograd's worker
+# goes on with the other model.  EXPERIMENTAL, off: measured on MI355X (tools/step_segments.py, tools/ab.sh) the two
+# Python threads hand the GIL back and forth at every kernel launch and the backward segment gets SLOWER (1.85-2.0 ms
+# against 1.46-1.6 ms); it needs the enqueue loop itself out of Python (a native whole-model composite) to pay off.
+ASYNC_SIDE_BACKWARD = os.environ.get('I3D_ASYNC_SIDE_BACKWARD', '0') == '1'
+
+
+class _Job:
+    """one model backward pass for the helper thread"""
+
+    def __init__(self, stream, ctx, grad):
+        self.stream, self.ctx, self.grad = stream, ctx, grad
+        self.done = threading.Event()
+        self.error = None
+        self.event = None
+
+    def run(self):
+        try:
+            with torch.no_grad(), torch.cuda.stream(self.stream):      # grad mode and current stream are per thread
+                out = _model_backward(self.ctx, self.grad)
+                for p, g in zip(self.ctx.params, out):
+                    if g is not None:
+                        p.grad = g
+                self.event = torch.cuda.Event()
+                self.event.record(self.stream)
+        except BaseException as e:      # re-raised in the thread that called backward()
+            self.error = e
+        finally:
+            self.ctx = self.grad = None
+            self.done.set()
+
+    def join(self):
+        """end-of-backward callback (runs with the caller's streams current)"""
+        self.done.wait()
+        if self.error is not None:
+            raise self.error
+        torch.cuda.current_stream(self.stream.device).wait_event(self.event)
+
+
+_helper_queue = None
+_helper_lock = threading.Lock()
+
+
+def _helper():
+    global _helper_queue
+    if _helper_queue is None:
+        with _helper_lock:
+            if _helper_queue is None:
+                import queue
+                q = queue.SimpleQueue()
+
+                def loop():
+                    while True:
+                        q.get().run()
+                threading.Thread(target=loop, name='i3d-side-backward', daemon=True).start()
+                _helper_queue = q
+    return _helper_queue
 
 
 # I3D_DIRECT_PARAM_GRADS=0: hand the parameter gradients to autograd's AccumulateGrad nodes instead

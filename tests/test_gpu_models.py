@@ -369,10 +369,13 @@ def test_training_step_is_bit_deterministic(amd, side_stream, monkeypatch):
     _training_step_is_bit_deterministic(amd)
 
 
-def test_net3d_side_stream_equals_single_stream(amd, monkeypatch):
+@pytest.mark.parametrize('async_backward', [False, True])
+def test_net3d_side_stream_equals_single_stream(amd, monkeypatch, async_backward):
     """Net3D next to PNA on a side stream (streams.py) gives the same bits as the single-stream schedule, over several
-    optimisation steps (parameter updates, BN buffers and the side effects on the graph included)."""
+    optimisation steps (parameter updates, BN buffers and the side effects on the graph included); also with the
+    side model's backward pass enqueued by the helper thread (tape.ASYNC_SIDE_BACKWARD)."""
     streams = importlib.import_module('3dinfomax_amd.streams')
+    monkeypatch.setattr(importlib.import_module('3dinfomax_amd.tape'), 'ASYNC_SIDE_BACKWARD', async_backward)
     mols = synth.make_dataset(128, seed=33)
     res = {}
     for mode in (True, False):

@@ -309,8 +309,8 @@ def test_act_bn_fwd_bwd_vs_torch(rows, feat, act, post):
 
 
 def test_in_launch_finalisation_matches_separate_launch():
-    """I3D_FUSED_FINAL=1 (stage 2 of the column reductions inside the stage-1 launch, last arrivers reduce) gives the same
-    bits as the default separate finalise launch; the switch is read once per process -> subprocess."""
+    """The default (stage 2 of the column reductions inside the stage-1 launch, last arrivers reduce) gives the same bits as
+    separate finalise launches (I3D_FUSED_FINAL=0); the switch is read once per process -> subprocess."""
     import os
     import subprocess
     import sys
