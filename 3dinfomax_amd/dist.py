@@ -133,7 +133,7 @@ class GradReducer:
         for m in modules:
             ps = [p for p in m.parameters() if p.requires_grad]
             if ps:
-                self._tape.register_grad_sink(ps, self._sink)
+                self._tape.register_grad_sink(ps, self._sink, self.view_of)
 
     def _sink(self, params, grads):
         dst = [self.view_of.get(id(p)) for p in params]

@@ -13,7 +13,7 @@ import torch
 
 import os
 
-from . import _lib, ops
+from . import _lib, ops, tape
 from . import layers as _layers
 from .layers import _bump, _keeps_pre, _set_workspaces
 
@@ -224,10 +224,8 @@ def backward(ctx, grad):
     ar = _Arena(total, dev)
     grads = []          # (gW, gbias, ggamma, gbeta) per block, forward order
 
-    def param_grads(W):
-        Fo = W.shape[0]
-        return (torch.empty_like(W), torch.empty(Fo, dtype=torch.float32, device=dev),
-                torch.empty(Fo, dtype=torch.float32, device=dev), torch.empty(Fo, dtype=torch.float32, device=dev))
+    def param_grads(k):       # (W, bias, gamma, beta) of block k: the model's persistent gradient buffers when it has them
+        return tuple(tape.grad_like(params[4 * k + j]) for j in range(4))
 
     def set_param_grads(c, g4):
         c.grad_W, c.grad_bias, c.grad_gamma, c.grad_beta = (t.data_ptr() for t in g4)
@@ -240,14 +238,14 @@ def backward(ctx, grad):
         c = a.postx[i - 1]
         Fo, Fi = dims_post[i]
         _set_workspaces(c.tail, Fo, dev)
-        g4 = param_grads(params[4 * (n_pre + i)])
+        g4 = param_grads(n_pre + i)
         post_g[i] = g4
         set_param_grads(c, g4)
         c.grad_y, c.grad_pre, c.grad_x = gy, ar.take(N * Fo), ar.take(N * Fi)
         gy = c.grad_x
     p = a.post
     _set_workspaces(p.tail, Fp0, dev)
-    g4 = param_grads(params[4 * n_pre])
+    g4 = param_grads(n_pre)
     post_g[0] = g4
     set_param_grads(p, g4)
     gh = torch.empty(N, Fh, dtype=torch.float32, device=dev)
@@ -261,14 +259,14 @@ def backward(ctx, grad):
         c = a.pre[i - 1]
         Fo, Fi = dims_pre[i]
         _set_workspaces(c.tail, Fo, dev)
-        g4 = param_grads(params[4 * i])
+        g4 = param_grads(i)
         pre_g[i] = g4
         set_param_grads(c, g4)
         c.grad_y, c.grad_pre, c.grad_x = gy, ar.take(E * Fo), ar.take(E * Fi)
         gy = c.grad_x
     e = a.edge
     _set_workspaces(e.tail, Fo0, dev)
-    g4 = param_grads(params[0])
+    g4 = param_grads(0)
     pre_g[0] = g4
     set_param_grads(e, g4)
     gq = torch.empty_like(q) if need_q else None

@@ -235,8 +235,8 @@ class FCFn(torch.autograd.Function):
         if ctx.cargs is not None:
             a, dev, f_out = ctx.cargs, x.device, W.shape[0]
             grad_pre = _f32((x.shape[0], f_out), dev)
-            gg, gb, gbias = _f32((f_out,), dev), _f32((f_out,), dev), _f32((f_out,), dev)
-            gW = torch.empty_like(W)
+            gg, gb, gbias = tape.grad_like(gamma), tape.grad_like(beta), tape.grad_for_bias_of(W, f_out)
+            gW = tape.grad_like(W)
             gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
             _set_workspaces(a.tail, f_out, dev)
             a.grad_y, a.grad_pre, a.grad_gamma, a.grad_beta = grad_y.data_ptr(), grad_pre.data_ptr(), gg.data_ptr(), gb.data_ptr()
@@ -438,8 +438,8 @@ class EdgeFCFn(torch.autograd.Function):
             a, dev, E = ctx.cargs, h.device, idx.num_edges
             grad_y = grad_y.contiguous()
             grad_pre, gP = _f32((E, Fo), dev), _f32((N, 2 * Fo), dev)
-            gg, gb, gbias = _f32((Fo,), dev), _f32((Fo,), dev), _f32((Fo,), dev)
-            gW, gh = torch.empty_like(W), torch.empty_like(h)
+            gg, gb, gbias = tape.grad_like(gamma), tape.grad_like(beta), tape.grad_for_bias_of(W, Fo)
+            gW, gh = tape.grad_like(W), torch.empty_like(h)
             gq = torch.empty_like(q) if (ctx.has_q and ctx.needs_input_grad[1]) else None
             if ctx.has_q and ctx.qmap is not None:
                 gQ = _f32((ctx.qmap.v_pad, Fo), dev)

@@ -145,7 +145,7 @@ class ModelFn(torch.autograd.Function):
             _helper().put(job)
             torch.autograd.Variable._execution_engine.queue_callback(job.join)
             return (None,) * (1 + len(ctx.params))
-        out = _model_backward(ctx, grad.contiguous())
+        out = _model_backward(ctx, grad.contiguous(), direct)
         if direct:
             # `.grad` is empty and nothing hooks the parameters: store the gradients here instead of sending them
             # through ~110 AccumulateGrad nodes (each a task of the autograd engine; and a gradient that is a view of
@@ -157,7 +157,79 @@ class ModelFn(torch.autograd.Function):
         return (None,) + tuple(out)
 
 
-def _model_backward(ctx, grad):
+class _GradPool:
+    """Persistent gradient buffers of one model: views of one flat buffer (the data-parallel all-reduce buffer when a
+    GradReducer is attached), handed to the weight-gradient kernels as their outputs, so a backward pass allocates
+    nothing per parameter and - data parallel - copies nothing into the all-reduce buffer."""
+
+    def __init__(self, params, views=None):
+        if views is None:
+            p0 = params[0]
+            sizes = [p.numel() for p in params]
+            flat = torch.empty(sum(sizes), dtype=p0.dtype, device=p0.device)
+            views = {id(p): v.view_as(p) for p, v in zip(params, flat.split(sizes))
+                     if p.dtype == p0.dtype and p.device == p0.device}
+        self.view_of = views
+        self.bias_of = {}       # id(weight) -> bias parameter of the same Linear / BatchNorm module
+        self.used = set()
+
+
+_pools = {}            # id(first parameter of a model) -> _GradPool
+
+
+def _pool_for(module_params):
+    key = id(module_params[0])
+    pool = _pools.get(key)
+    if pool is None:
+        sink_views = _grad_sink_views.get(key)
+        pool = _pools[key] = _GradPool(module_params, sink_views)
+    return pool
+
+
+def note_bias_pairs(module, params):
+    """called once per model (run_model): remember which bias belongs to which weight, for grad_for_bias_of"""
+    pool = _pool_for(params)
+    for m in module.modules():
+        w, b = getattr(m, 'weight', None), getattr(m, 'bias', None)
+        if isinstance(w, torch.nn.Parameter) and isinstance(b, torch.nn.Parameter):
+            pool.bias_of[id(w)] = b
+
+
+def grad_like(p):
+    """output buffer for the gradient of parameter `p`: its persistent view inside a model backward, else a new tensor"""
+    pool = getattr(_tls, 'pool', None)
+    if pool is not None:
+        v = pool.view_of.get(id(p))
+        if v is not None and id(p) not in pool.used:      # a parameter used twice gets a second, separate buffer
+            pool.used.add(id(p))
+            return v
+    return torch.empty_like(p)
+
+
+def grad_for_bias_of(weight, n):
+    """as grad_like for the bias that belongs to `weight` (the block Functions do not hold the bias parameter)"""
+    pool = getattr(_tls, 'pool', None)
+    if pool is not None:
+        b = pool.bias_of.get(id(weight))
+        if b is not None and b.numel() == n:
+            return grad_like(b)
+    return torch.empty(n, dtype=weight.dtype, device=weight.device)
+
+
+# I3D_PERSISTENT_GRADS=0: every backward pass allocates its parameter gradients
+PERSISTENT_GRADS = os.environ.get('I3D_PERSISTENT_GRADS', '1') != '0'
+
+
+def _model_backward(ctx, grad, direct=False):
+    if direct and PERSISTENT_GRADS:
+        # `.grad` of every parameter is empty (nothing to accumulate into, nobody holds last step's buffers through it)
+        pool = _pool_for(ctx.params)
+        pool.used.clear()
+        _tls.pool = pool
+        try:
+            return _model_backward(ctx, grad)
+        finally:
+            _tls.pool = None
     grads = ctx.tape.backward(ctx.out_id, grad)
     out = [grads[id(p)][0] if id(p) in grads else None for p in ctx.params]
     sink = _grad_sinks.get(id(ctx.params[0]))
@@ -185,7 +257,7 @@ class _Job:
     def run(self):
         try:
             with torch.no_grad(), torch.cuda.stream(self.stream):      # grad mode and current stream are per thread
-                out = _model_backward(self.ctx, self.grad)
+                out = _model_backward(self.ctx, self.grad, True)
                 for p, g in zip(self.ctx.params, out):
                     if g is not None:
                         p.grad = g
@@ -238,12 +310,17 @@ def _plain_leaves(params):
 
 
 _grad_sinks = {}       # id(first parameter of a model) -> callable(params, grads) -> grads
+_grad_sink_views = {}  # id(first parameter of a model) -> {id(parameter): its view in the sink's flat buffer}
 
 
-def register_grad_sink(params, fn):
+def register_grad_sink(params, fn, views=None):
     """`fn(params, grads)` receives the parameter gradients of the model whose first parameter is params[0] at the end of
-    its backward pass and returns the tensors autograd should store in `.grad`."""
+    its backward pass and returns the tensors autograd should store in `.grad`.  `views`: the sink's own per-parameter
+    buffers - the weight-gradient kernels then write into them directly (_GradPool)."""
     _grad_sinks[id(params[0])] = fn
+    if views is not None:
+        _grad_sink_views[id(params[0])] = views
+        _pools.pop(id(params[0]), None)
 
 
 # I3D_FUSED_MODEL=0: one autograd node per block (or per PNA layer) instead of one per model
@@ -261,4 +338,7 @@ def run_model(module, run):
     params = [p for p in cached if p.requires_grad]
     if not params or not params[0].is_cuda:
         return run()
+    if PERSISTENT_GRADS and module.__dict__.get('_i3d_pool_key') != id(params[0]):
+        note_bias_pairs(module, params)
+        module.__dict__['_i3d_pool_key'] = id(params[0])
     return ModelFn.apply(run, *params)
