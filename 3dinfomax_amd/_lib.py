@@ -23,7 +23,7 @@ _P = c_void_p
 class BnTail(ctypes.Structure):
     _fields_ = [('act', c_int), ('post_act', c_int), ('eps', c_float), ('momentum', c_float), ('gamma', _P),
                 ('beta', _P), ('running_mean', _P), ('running_var', _P), ('mean', _P), ('invstd', _P),
-                ('workspace', _P), ('gemm_workspace', _P), ('gemm_workspace_bytes', c_long)]
+                ('workspace', _P), ('gemm_workspace', _P), ('gemm_workspace_bytes', c_long), ('num_batches_tracked', _P)]
 
 
 class FcArgs(ctypes.Structure):
@@ -96,6 +96,7 @@ _SIGNATURES = {
                                              c_long, _P, c_long, c_int, c_int, c_int, c_int, _P, c_long, _P]),
     'i3d_colreduce_workspace_bytes': (c_long, [c_int, c_int]),
     'i3d_act_stats_fwd': (c_int, [_P, c_int, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    'i3d_act_stats_fwd_counted': (c_int, [_P, c_int, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     'i3d_bn_finalize_stats': (c_int, [_P, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
     'i3d_bn_apply_fwd': (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P]),
     'i3d_bn_eval_fwd': (c_int, [_P, c_int, c_int, _P, _P, c_float, _P, _P, c_int, _P, _P, _P]),

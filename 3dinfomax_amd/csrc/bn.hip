@@ -62,6 +62,7 @@ struct Final {
     float* out1;           // pair: fp32 results (may be null)
     float* out2;
     double* sums_out;      // fp64 results for the synchronised-BN all-reduce (may be null)
+    long long* batches_tracked;   // BatchNorm1d.num_batches_tracked (int64), incremented with the running statistics; may be null
     unsigned* counters;    // null: stage 2 is a separate launch (I3D_FUSED_FINAL=0)
 };
 
@@ -92,6 +93,7 @@ __device__ __forceinline__ void finalize_column(const Final& f, int c, double s1
             f.running_mean[c] = (float)((1.0 - f.momentum) * (double)f.running_mean[c] + f.momentum * (shift + m));
             f.running_var[c] = (float)((1.0 - f.momentum) * (double)f.running_var[c] + f.momentum * unbiased);
         }
+        if (c == 0 && f.batches_tracked != nullptr) *f.batches_tracked += 1;
     } else {
         if (f.sums_out != nullptr) {
             f.sums_out[c] = s1;
@@ -307,7 +309,8 @@ __device__ __forceinline__ bool reduce_partials(const float* __restrict__ partia
 
 __global__ void stats_final_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ pre_row0,
                                    int act, int rows, int feat, float eps, float momentum, float* mean, float* invstd,
-                                   float* running_mean, float* running_var, double* sums_out) {
+                                   float* running_mean, float* running_var, double* sums_out,
+                                   long long* batches_tracked) {
     int c;
     double s1, s2;
     if (!reduce_partials(partial, nblk, feat, c, s1, s2)) return;
@@ -329,6 +332,7 @@ __global__ void stats_final_kernel(const float* __restrict__ partial, int nblk, 
         running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * (shift + m));
         running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
     }
+    if (c == 0 && batches_tracked != nullptr) *batches_tracked += 1;
 }
 
 __global__ void stats_from_sums_kernel(const double* __restrict__ sums, int feat, float eps, float momentum, float* mean,
@@ -668,8 +672,10 @@ static bool fused_final() {
 static float* partial_of(void* workspace) { return (float*)((char*)workspace + WS_HEADER); }
 
 static Final stats_final_desc(void* workspace, const float* pre, int act, int rows, int feat, float eps, float momentum,
-                              float* mean, float* invstd, float* running_mean, float* running_var, double* sums_out) {
+                              float* mean, float* invstd, float* running_mean, float* running_var, double* sums_out,
+                              long long* batches_tracked = nullptr) {
     Final f = {};
+    f.batches_tracked = batches_tracked;
     f.kind = 0; f.feat = feat; f.rows = rows; f.act = act; f.eps = eps; f.momentum = momentum; f.pre_row0 = pre;
     f.mean = mean; f.invstd = invstd; f.running_mean = running_mean; f.running_var = running_var; f.sums_out = sums_out;
     f.counters = fused_final() ? (unsigned*)workspace : nullptr;
@@ -692,7 +698,8 @@ static void launch_reduction(const ReduceArgs& g, const Chunking& ch, const Fina
     if (f.counters != nullptr) return;
     if (f.kind == 0)
         hipLaunchKernelGGL(stats_final_kernel, dim3(cdiv(f.feat, FIN_COLS)), dim3(256), 0, s, g.partial, ch.nblk, f.pre_row0,
-                           f.act, f.rows, f.feat, f.eps, f.momentum, f.mean, f.invstd, f.running_mean, f.running_var, f.sums_out);
+                           f.act, f.rows, f.feat, f.eps, f.momentum, f.mean, f.invstd, f.running_mean, f.running_var, f.sums_out,
+                           f.batches_tracked);
     else
         hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(f.feat, FIN_COLS)), dim3(256), 0, s, g.partial, ch.nblk, f.feat, f.out1,
                            f.out2, f.sums_out);
@@ -710,6 +717,13 @@ extern "C" long i3d_colreduce_workspace_bytes(int rows, int feat) {
 extern "C" int i3d_act_stats_fwd(const float* pre, int rows, int feat, int act, float* x, float eps, float momentum,
                                  float* mean, float* invstd, float* running_mean, float* running_var,
                                  double* sums_out, void* workspace, void* stream) {
+    return i3d_act_stats_fwd_counted(pre, rows, feat, act, x, eps, momentum, mean, invstd, running_mean, running_var,
+                                     sums_out, nullptr, workspace, stream);
+}
+
+extern "C" int i3d_act_stats_fwd_counted(const float* pre, int rows, int feat, int act, float* x, float eps, float momentum,
+                                         float* mean, float* invstd, float* running_mean, float* running_var,
+                                         double* sums_out, long long* num_batches_tracked, void* workspace, void* stream) {
     I3D_CHECK_ARG(rows > 0 && feat > 0, "rows > 0 and feat > 0 required");
     I3D_CHECK_ARG(workspace != nullptr, "workspace required");
     hipStream_t s = (hipStream_t)stream;
@@ -718,7 +732,7 @@ extern "C" int i3d_act_stats_fwd(const float* pre, int rows, int feat, int act, 
     g.a = pre; g.out = x; g.rows = rows; g.feat = feat; g.act = act; g.post_act = I3D_ACT_NONE;
     g.partial = partial_of(workspace);
     launch_reduction<MODE_STATS>(g, ch, stats_final_desc(workspace, pre, act, rows, feat, eps, momentum, mean, invstd,
-                                                         running_mean, running_var, sums_out), s);
+                                                         running_mean, running_var, sums_out, num_batches_tracked), s);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }

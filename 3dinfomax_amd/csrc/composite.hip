@@ -19,8 +19,8 @@ using namespace i3d;
 static int tail_fwd(const I3dBnTail* t, int rows, int f_out, float* pre, float* xact, const float* residual, float* y,
                     void* stream) {
     // pre holds the Linear output.  xact == pre: activation in place (ReLU/none); else pre is kept for act'
-    TRY(i3d_act_stats_fwd(pre, rows, f_out, t->act, xact, t->eps, t->momentum, t->mean, t->invstd, t->running_mean,
-                          t->running_var, nullptr, t->workspace, stream));
+    TRY(i3d_act_stats_fwd_counted(pre, rows, f_out, t->act, xact, t->eps, t->momentum, t->mean, t->invstd, t->running_mean,
+                                  t->running_var, nullptr, t->num_batches_tracked, t->workspace, stream));
     return i3d_bn_apply_fwd(xact, rows, f_out, t->mean, t->invstd, t->gamma, t->beta, t->post_act, residual, y, stream);
 }
 

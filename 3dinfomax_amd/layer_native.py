@@ -15,7 +15,7 @@ import os
 
 from . import _lib, ops, tape
 from . import layers as _layers
-from .layers import _bump, _keeps_pre, _set_workspaces
+from .layers import _keeps_pre, _set_workspaces
 
 # I3D_NATIVE_LAYER=0: the layer as four block composites sequenced from Python (pna.PNALayerFn)
 NATIVE_LAYER = os.environ.get('I3D_NATIVE_LAYER', '1') != '0'
@@ -69,6 +69,8 @@ def _tail(tail, spec, gamma, beta, mean_ptr, invstd_ptr, feat, device):
     tail.gamma, tail.beta = gamma.data_ptr(), beta.data_ptr()
     tail.running_mean, tail.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
     tail.mean, tail.invstd = mean_ptr, invstd_ptr
+    nbt = bn.num_batches_tracked           # bumped by the statistics kernel
+    tail.num_batches_tracked = nbt.data_ptr() if nbt is not None else None
     _set_workspaces(tail, feat, device)
 
 
@@ -199,8 +201,6 @@ def forward(ctx, h, q, index, qmap, plan, params):
     L = _lib.load()
     _lib.check(L.i3d_pna_layer_fwd(ctypes.byref(a), ops._stream()), 'i3d_pna_layer_fwd')
     a.agg_event_start = a.agg_event_stop = None
-    for spec in plan.pre_specs + plan.post_specs:
-        _bump(spec.bn.num_batches_tracked)
     ctx.native = (a, ar, h, q, qmap, index, plan, params, (N, E, Fh, Fq, A, nG))
     return y_out
 

@@ -181,6 +181,8 @@ def _fill_tail(tail, spec: FCSpec, gamma, beta, mean, invstd, feat, device):
     tail.gamma, tail.beta = gamma.data_ptr(), beta.data_ptr()
     tail.running_mean, tail.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
     tail.mean, tail.invstd = mean.data_ptr(), invstd.data_ptr()
+    nbt = bn.num_batches_tracked           # bumped by the statistics kernel (no _foreach_add_ per model forward)
+    tail.num_batches_tracked = nbt.data_ptr() if (nbt is not None and nbt.is_cuda) else None
     _set_workspaces(tail, feat, device)
 
 
@@ -217,7 +219,6 @@ class FCFn(torch.autograd.Function):
             a.x, a.W, a.bias, a.residual = x.data_ptr(), W.data_ptr(), _ptr(b), _ptr(residual)
             a.xact, a.pre_keep, a.y = xact.data_ptr(), _ptr(pre_keep), y.data_ptr()
             _call('i3d_fc_bn_fwd', a)
-            _bump(spec.bn.num_batches_tracked)
             ctx.cargs, ctx.saved = a, (xact, pre_keep, mean, invstd)
             ctx.save_for_backward(x, W, gamma, beta)
             return y
@@ -321,7 +322,6 @@ class GroupedConcat2FCFn(torch.autograd.Function):
             c.deg_rows, c.deg_tile_group = rows.data_ptr(), tiles.data_ptr()
             c.WD, c.xact, c.pre_keep, c.y = WD.data_ptr(), xact.data_ptr(), _ptr(pre_keep), y.data_ptr()
             _call('i3d_grouped_fc_bn_fwd', c)
-            _bump(spec.bn.num_batches_tracked)
             ctx.cargs, ctx.saved = c, (xact, pre_keep, mean, invstd)
             ctx.spec, ctx.has_res, ctx.index, ctx.coef = spec, residual is not None, index, (flat, nG, nS)
             ctx.save_for_backward(h, a, W, WD, gamma, beta)
@@ -411,7 +411,6 @@ class EdgeFCFn(torch.autograd.Function):
             a.out_ptr, a.out_epos = index.out_ptr.data_ptr(), index.out_epos.data_ptr()
             a.P, a.Q, a.xact, a.pre_keep, a.y = P.data_ptr(), _ptr(Q), xact.data_ptr(), _ptr(pre_keep), y.data_ptr()
             _call('i3d_edge_fc_bn_fwd', a)
-            _bump(spec.bn.num_batches_tracked)
             ctx.cargs, ctx.saved = a, (xact, pre_keep, mean, invstd)
             ctx.spec, ctx.index, ctx.has_q = spec, index, q is not None
             ctx.save_for_backward(h, q if q is not None else h, W, gamma, beta)

@@ -172,6 +172,12 @@ long i3d_colreduce_workspace_bytes(int rows, int feat);
 int i3d_act_stats_fwd(const float* pre, int rows, int feat, int act, float* x, float eps, float momentum,
                       float* mean, float* invstd, float* running_mean, float* running_var, double* sums_out,
                       void* workspace, void* stream);
+/* as i3d_act_stats_fwd; additionally increments *num_batches_tracked (BatchNorm1d's int64 counter, may be NULL) in the
+ * kernel that updates the running statistics - reference models/base_layers.py:107-108 runs nn.BatchNorm1d in training
+ * mode, which bumps it once per forward */
+int i3d_act_stats_fwd_counted(const float* pre, int rows, int feat, int act, float* x, float eps, float momentum,
+                      float* mean, float* invstd, float* running_mean, float* running_var, double* sums_out, long long* num_batches_tracked,
+                      void* workspace, void* stream);
 /* fp64 sums [2*feat+1] = {sum x, sum x^2, count} (already all-reduced) -> mean, invstd, running stats update */
 int i3d_bn_finalize_stats(const double* sums, int feat, float eps, float momentum, float* mean, float* invstd,
                           float* running_mean, float* running_var, void* stream);
@@ -294,6 +300,7 @@ typedef struct {
     void* workspace; /* i3d_colreduce_workspace_bytes(rows, f_out) */
     void* gemm_workspace; /* scratch of the weight-gradient GEMMs of the backward (i3d_gemm_f32_ws), may be NULL */
     long gemm_workspace_bytes;
+    long long* num_batches_tracked; /* BatchNorm1d's int64 counter, incremented by the forward (may be NULL) */
 } I3dBnTail;
 
 typedef struct { /* y = tail(x W^T + b) */

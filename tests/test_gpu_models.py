@@ -501,6 +501,27 @@ def test_parameter_gradients_stored_by_the_model_node(amd, monkeypatch):
         assert torch.equal(hooked[k], a[k]), k
 
 
+@pytest.mark.parametrize('composite', [True, False])
+def test_num_batches_tracked_counts_forward_passes(amd, monkeypatch, composite):
+    """BatchNorm1d.num_batches_tracked goes up by one per training forward (the statistics kernel bumps it on the composite
+    paths, one multi-tensor add per model on the per-kernel path) and stays put in eval mode."""
+    layers = importlib.import_module('3dinfomax_amd.layers')
+    monkeypatch.setattr(layers, 'COMPOSITE', composite)
+    mols = synth.make_dataset(12, seed=3)
+    pna = amd.PNA(avg_d=1.0, device='cuda:0', **PNA_SMALL).cuda().train()
+    net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_SMALL).cuda().train()
+    for _ in range(3):
+        g2, g3 = make_batch(amd, mols)
+        (pna(g2).sum() + net(g3).sum()).backward()
+    pna.eval(), net.eval()
+    with torch.no_grad():
+        g2, g3 = make_batch(amd, mols)
+        pna(g2), net(g3)
+    torch.cuda.synchronize()
+    counters = [(k, int(v)) for m in (pna, net) for k, v in m.state_dict().items() if k.endswith('num_batches_tracked')]
+    assert len(counters) > 5 and all(v == 3 for _, v in counters), counters
+
+
 def test_dist_warm_up_runs(amd):
     """dist.warm_up: the throw-away steps a data-parallel rank runs before it creates its communicator"""
     importlib.import_module('3dinfomax_amd.dist').warm_up('cuda:0', steps=1)
