@@ -18,6 +18,7 @@ class Adam(torch.optim.Adam):
             kwargs['fused'] = self._all_cuda(params)
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kwargs)
         self._lists = None
+        self._steps_flat = None
 
     @staticmethod
     def _all_cuda(params):
@@ -46,6 +47,22 @@ class Adam(torch.optim.Adam):
             if any((not torch.is_tensor(s['step'])) or (not s['step'].is_cuda) for s in st):
                 return None
             lists.append((list(ps), [s['exp_avg'] for s in st], [s['exp_avg_sq'] for s in st], [s['step'] for s in st]))
+        # the step counters of all parameters become views of ONE tensor: a single add per step() instead of a
+        # multi-tensor add per group (same values, same dtype; state_dict() keeps working, load_state_dict() rebuilds)
+        every = [s for lst in lists if lst is not None for s in lst[3]]
+        if every and all(s.dtype == torch.float32 and s.device == every[0].device and s.numel() == 1 for s in every):
+            flat = torch.stack([s.reshape(()) for s in every])
+            i = 0
+            for lst in lists:
+                if lst is None:
+                    continue
+                for j, p in enumerate(lst[0]):
+                    view = flat[i].view(self.state[p]['step'].shape)
+                    self.state[p]['step'] = lst[3][j] = view
+                    i += 1
+            self._steps_flat = flat
+        else:
+            self._steps_flat = None
         return lists
 
     @torch.no_grad()
@@ -72,9 +89,12 @@ class Adam(torch.optim.Adam):
                 self._lists = None
                 return super().step()
             work.append((group, lst, grads))
+        if self._steps_flat is not None:
+            self._steps_flat.add_(1)
         for group, (ps, exp_avgs, exp_avg_sqs, steps), grads in work:
             beta1, beta2 = group['betas']
-            torch._foreach_add_(steps, 1)
+            if self._steps_flat is None:
+                torch._foreach_add_(steps, 1)
             torch._fused_adam_(ps, grads, exp_avgs, exp_avg_sqs, [], steps, amsgrad=False, lr=group['lr'], beta1=beta1,
                                beta2=beta2, weight_decay=group['weight_decay'], eps=group['eps'], maximize=False,
                                grad_scale=None, found_inf=None)
