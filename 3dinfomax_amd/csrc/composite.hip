@@ -162,7 +162,10 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
 extern "C" int i3d_event_create(void** event) {
     I3D_CHECK_ARG(event != nullptr, "null");
     hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) {
+    // timing-only events: no system-scope fence (cache write-back + invalidate) when they are recorded - the HIP API
+    // documents this flag for exactly that use ("can improve the accuracy of timing measurements")
+    if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess &&
+        hipEventCreateWithFlags(&e, hipEventReleaseToDevice) != hipSuccess && hipEventCreate(&e) != hipSuccess) {
         i3d::set_error("hipEventCreate failed");
         return I3D_ERR_LAUNCH;
     }
