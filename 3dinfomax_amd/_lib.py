@@ -62,6 +62,7 @@ class PnaLayerArgs(ctypes.Structure):
 _SIGNATURES = {
     'i3d_event_create': (c_int, [POINTER(c_void_p)]),
     'i3d_event_destroy': (c_int, [_P]),
+    'i3d_event_record': (c_int, [_P, _P]),
     'i3d_event_elapsed_ms': (c_int, [_P, _P, POINTER(c_float)]),
     'i3d_pna_layer_fwd': (c_int, [POINTER(PnaLayerArgs), _P]),
     'i3d_pna_layer_bwd': (c_int, [POINTER(PnaLayerArgs), _P]),

@@ -178,6 +178,15 @@ extern "C" int i3d_event_destroy(void* event) {
     return I3D_OK;
 }
 
+extern "C" int i3d_event_record(void* event, void* stream) {
+    I3D_CHECK_ARG(event != nullptr, "null");
+    if (hipEventRecord((hipEvent_t)event, (hipStream_t)stream) != hipSuccess) {
+        i3d::set_error("hipEventRecord failed");
+        return I3D_ERR_LAUNCH;
+    }
+    return I3D_OK;
+}
+
 extern "C" int i3d_event_elapsed_ms(void* start, void* stop, float* ms) {
     I3D_CHECK_ARG(start != nullptr && stop != nullptr && ms != nullptr, "null");
     if (hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) {

@@ -82,6 +82,10 @@ class RawEvent:
         check(_lib.load().i3d_event_create(ctypes.byref(h)), 'i3d_event_create')
         self.handle = h.value
 
+    def record(self):
+        """on the current stream"""
+        check(_lib.load().i3d_event_record(self.handle, _stream()), 'i3d_event_record')
+
     def elapsed_time(self, stop):
         ms = ctypes.c_float()
         check(_lib.load().i3d_event_elapsed_ms(self.handle, stop.handle, ctypes.byref(ms)), 'i3d_event_elapsed_ms')
@@ -161,7 +165,7 @@ def pna_aggregate_fwd(e, in_ptr, num_nodes, aggregators, scalers, avg_d_log=1.0,
     L = _lib.load()
     timed = KERNEL_TIMERS is not None
     if timed:   # bench.py: HIP events on the launch stream around the roofline kernel
-        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0, t1 = RawEvent(), RawEvent()
         t0.record()
     check(L.i3d_pna_aggregate_fwd(_p(e), _p(in_ptr), num_nodes, feat, int_array(aggregators), len(aggregators),
                                   int_array(scalers), len(scalers), int(force_scalers), float(avg_d_log), _p(out), _stream()),

@@ -410,6 +410,7 @@ typedef struct { /* one PNA layer, reference models/pna.py:199-216: pretrans edg
 /* timing events for measurements around a kernel inside a composite (thin wrappers of hipEvent_t) */
 int i3d_event_create(void** event);
 int i3d_event_destroy(void* event);
+int i3d_event_record(void* event, void* stream);
 int i3d_event_elapsed_ms(void* start, void* stop, float* ms);   /* both events must have completed */
 
 int i3d_pna_layer_fwd(const I3dPnaLayerArgs* args, void* stream);
