@@ -131,9 +131,8 @@ class GradReducer:
     def attach(self, modules):
         """route the gradients of these modules (whole-model tape nodes) into the buffer"""
         for m in modules:
-            ps = [p for p in m.parameters() if p.requires_grad]
-            if ps:
-                self._tape.register_grad_sink(ps, self._sink, self.view_of)
+            if any(p.requires_grad for p in m.parameters()):
+                self._tape.register_grad_sink(m, self._sink, self.view_of)
 
     def _sink(self, params, grads):
         dst = [self.view_of.get(id(p)) for p in params]

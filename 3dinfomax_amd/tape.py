@@ -118,7 +118,8 @@ class ModelFn(torch.autograd.Function):
     """run(*) under a tape as one autograd node; `params` are the leaves."""
 
     @staticmethod
-    def forward(ctx, run, *params):
+    def forward(ctx, run, state, *params):
+        ctx.state = state
         tape = Tape(params)
         prev = getattr(_tls, 'tape', None)
         _tls.tape = tape
@@ -144,7 +145,7 @@ class ModelFn(torch.autograd.Function):
             job = _Job(torch.cuda.current_stream(grad.device), ctx, grad.contiguous())
             _helper().put(job)
             torch.autograd.Variable._execution_engine.queue_callback(job.join)
-            return (None,) * (1 + len(ctx.params))
+            return (None,) * (2 + len(ctx.params))
         out = _model_backward(ctx, grad.contiguous(), direct)
         if direct:
             # `.grad` is empty and nothing hooks the parameters: store the gradients here instead of sending them
@@ -153,8 +154,8 @@ class ModelFn(torch.autograd.Function):
             for p, g in zip(ctx.params, out):
                 if g is not None:
                     p.grad = g
-            return (None,) * (1 + len(ctx.params))
-        return (None,) + tuple(out)
+            return (None,) * (2 + len(ctx.params))
+        return (None, None) + tuple(out)
 
 
 class _GradPool:
@@ -162,7 +163,8 @@ class _GradPool:
     GradReducer is attached), handed to the weight-gradient kernels as their outputs, so a backward pass allocates
     nothing per parameter and - data parallel - copies nothing into the all-reduce buffer."""
 
-    def __init__(self, params, views=None):
+    def __init__(self, module, params, views=None):
+        self.key = tuple(id(p) for p in params)
         if views is None:
             p0 = params[0]
             sizes = [p.numel() for p in params]
@@ -171,28 +173,42 @@ class _GradPool:
                      if p.dtype == p0.dtype and p.device == p0.device}
         self.view_of = views
         self.bias_of = {}       # id(weight) -> bias parameter of the same Linear / BatchNorm module
+        for m in module.modules():
+            w, b = getattr(m, 'weight', None), getattr(m, 'bias', None)
+            if isinstance(w, torch.nn.Parameter) and isinstance(b, torch.nn.Parameter):
+                self.bias_of[id(w)] = b
         self.used = set()
 
 
-_pools = {}            # id(first parameter of a model) -> _GradPool
+class _ModelState:
+    """what this file keeps per model; lives in the module's __dict__ (so it dies with the module: nothing is keyed by
+    the id() of an object that may be gone)"""
+
+    def __init__(self, module):
+        import weakref
+        self.module = weakref.ref(module)
+        self.pool = None
+        self.sink = None          # callable(params, grads) -> grads (dist.GradReducer)
+        self.sink_views = None    # {id(parameter): its view in the sink's flat buffer}
+
+    def __reduce__(self):          # copy.deepcopy(model) / pickling: the copy starts without state (model_state rebuilds it)
+        return (type(None), ())
+
+    def pool_for(self, params):
+        pool = self.pool
+        if pool is None or len(pool.key) != len(params) or pool.key != tuple(id(p) for p in params):
+            views = self.sink_views
+            if views is not None and any(id(p) not in views or views[id(p)].shape != p.shape for p in params):
+                views = None
+            pool = self.pool = _GradPool(self.module(), params, views)
+        return pool
 
 
-def _pool_for(module_params):
-    key = id(module_params[0])
-    pool = _pools.get(key)
-    if pool is None:
-        sink_views = _grad_sink_views.get(key)
-        pool = _pools[key] = _GradPool(module_params, sink_views)
-    return pool
-
-
-def note_bias_pairs(module, params):
-    """called once per model (run_model): remember which bias belongs to which weight, for grad_for_bias_of"""
-    pool = _pool_for(params)
-    for m in module.modules():
-        w, b = getattr(m, 'weight', None), getattr(m, 'bias', None)
-        if isinstance(w, torch.nn.Parameter) and isinstance(b, torch.nn.Parameter):
-            pool.bias_of[id(w)] = b
+def model_state(module):
+    st = module.__dict__.get('_i3d_state')
+    if st is None:
+        st = module.__dict__['_i3d_state'] = _ModelState(module)
+    return st
 
 
 def grad_like(p):
@@ -223,7 +239,7 @@ PERSISTENT_GRADS = os.environ.get('I3D_PERSISTENT_GRADS', '1') != '0'
 def _model_backward(ctx, grad, direct=False):
     if direct and PERSISTENT_GRADS:
         # `.grad` of every parameter is empty (nothing to accumulate into, nobody holds last step's buffers through it)
-        pool = _pool_for(ctx.params)
+        pool = ctx.state.pool_for(ctx.params)
         pool.used.clear()
         _tls.pool = pool
         try:
@@ -232,7 +248,7 @@ def _model_backward(ctx, grad, direct=False):
             _tls.pool = None
     grads = ctx.tape.backward(ctx.out_id, grad)
     out = [grads[id(p)][0] if id(p) in grads else None for p in ctx.params]
-    sink = _grad_sinks.get(id(ctx.params[0]))
+    sink = ctx.state.sink
     if sink is not None:         # data parallel: the gradients go straight into the all-reduce buffer (dist.GradReducer)
         out = sink(ctx.params, out)
     return out
@@ -309,18 +325,12 @@ def _plain_leaves(params):
     return True
 
 
-_grad_sinks = {}       # id(first parameter of a model) -> callable(params, grads) -> grads
-_grad_sink_views = {}  # id(first parameter of a model) -> {id(parameter): its view in the sink's flat buffer}
-
-
-def register_grad_sink(params, fn, views=None):
-    """`fn(params, grads)` receives the parameter gradients of the model whose first parameter is params[0] at the end of
-    its backward pass and returns the tensors autograd should store in `.grad`.  `views`: the sink's own per-parameter
-    buffers - the weight-gradient kernels then write into them directly (_GradPool)."""
-    _grad_sinks[id(params[0])] = fn
-    if views is not None:
-        _grad_sink_views[id(params[0])] = views
-        _pools.pop(id(params[0]), None)
+def register_grad_sink(module, fn, views=None):
+    """`fn(params, grads)` receives the parameter gradients of `module` at the end of its backward pass and returns the
+    tensors autograd should store in `.grad`.  `views` ({id(parameter): tensor}): the sink's own per-parameter buffers -
+    the weight-gradient kernels then write into them directly (_GradPool)."""
+    st = model_state(module)
+    st.sink, st.sink_views, st.pool = fn, views, None
 
 
 # I3D_FUSED_MODEL=0: one autograd node per block (or per PNA layer) instead of one per model
@@ -338,7 +348,4 @@ def run_model(module, run):
     params = [p for p in cached if p.requires_grad]
     if not params or not params[0].is_cuda:
         return run()
-    if PERSISTENT_GRADS and module.__dict__.get('_i3d_pool_key') != id(params[0]):
-        note_bias_pairs(module, params)
-        module.__dict__['_i3d_pool_key'] = id(params[0])
-    return ModelFn.apply(run, *params)
+    return ModelFn.apply(run, model_state(module), *params)
