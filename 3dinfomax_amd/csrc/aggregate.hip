@@ -81,9 +81,14 @@ pna_aggregate_fwd_kernel(const float4* __restrict__ e, const int* __restrict__ i
     if (D > 1) I3D_AGG_ACC(x1);
     if (D > 2) I3D_AGG_ACC(x2);
     if (D > 3) I3D_AGG_ACC(x3);
-    for (int j = 4; j < D; ++j) {
-        x = p[(long)j * FV];
-        I3D_AGG_ACC(x);
+    // longer segments (per-graph readouts: ~18 atoms; hub atoms): four more rows in flight per trip, same order
+    for (int j = 4; j < D; j += 4) {
+        const float4 y0 = p[(long)j * FV], y1 = p[(long)min(j + 1, D - 1) * FV], y2 = p[(long)min(j + 2, D - 1) * FV],
+                     y3 = p[(long)min(j + 3, D - 1) * FV];
+        I3D_AGG_ACC(y0);
+        if (j + 1 < D) I3D_AGG_ACC(y1);
+        if (j + 2 < D) I3D_AGG_ACC(y2);
+        if (j + 3 < D) I3D_AGG_ACC(y3);
     }
 #undef I3D_AGG_ACC
     const float fD = (float)D;
@@ -289,20 +294,31 @@ pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict
             }
         }
     }
-    for (int j = 4; j < D; ++j) {
-        float x[V];
-        if (V == 4) {
-            float4 xx = *reinterpret_cast<const float4*>(p + (long)j * F);
-            x[0] = xx.x; x[1 % V] = xx.y; x[2 % V] = xx.z; x[3 % V] = xx.w;
-        } else {
-            x[0] = p[(long)j * F];
+    for (int j0 = 4; j0 < D; j0 += 4) {      // four rows in flight per trip (readouts, hub atoms), same order
+        float xs[4][V];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long row = min(j0 + k, D - 1);
+            if (V == 4) {
+                float4 xx = *reinterpret_cast<const float4*>(p + row * F);
+                xs[k][0] = xx.x; xs[k][1 % V] = xx.y; xs[k][2 % V] = xx.z; xs[k][3 % V] = xx.w;
+            } else {
+                xs[k][0] = p[row * F];
+            }
         }
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            sum[i] += x[i];
-            sq[i] += x[i] * x[i];
-            if (x[i] > mx[i]) { mx[i] = x[i]; amax[i] = j; }
-            if (x[i] < mn[i]) { mn[i] = x[i]; amin[i] = j; }
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + k;
+            if (j < D) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    const float xv = xs[k][i];
+                    sum[i] += xv;
+                    sq[i] += xv * xv;
+                    if (xv > mx[i]) { mx[i] = xv; amax[i] = j; }
+                    if (xv < mn[i]) { mn[i] = xv; amin[i] = j; }
+                }
+            }
         }
     }
     const float fD = (float)D;
@@ -332,24 +348,32 @@ pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict
             else q[(long)jj * F] = r[0];
         }
     }
-    for (int j = 4; j < D; ++j) {
-        float x[V], r[V];
-        if (V == 4) {
-            float4 xx = *reinterpret_cast<const float4*>(p + (long)j * F);
-            x[0] = xx.x; x[1 % V] = xx.y; x[2 % V] = xx.z; x[3 % V] = xx.w;
-        } else {
-            x[0] = p[(long)j * F];
+    for (int j0 = 4; j0 < D; j0 += 4) {
+        float xs[4][V];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long row = min(j0 + k, D - 1);
+            if (V == 4) {
+                float4 xx = *reinterpret_cast<const float4*>(p + row * F);
+                xs[k][0] = xx.x; xs[k][1 % V] = xx.y; xs[k][2 % V] = xx.z; xs[k][3 % V] = xx.w;
+            } else {
+                xs[k][0] = p[row * F];
+            }
         }
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            r[i] = g_mean[i] + (kstd[i] + kvar[i]) * (x[i] - mean[i]);
-            if (j == amax[i]) r[i] += g_max[i];
-            if (j == amin[i]) r[i] += g_min[i];
-        }
-        if (V == 4) {
-            *reinterpret_cast<float4*>(q + (long)j * F) = make_float4(r[0], r[1 % V], r[2 % V], r[3 % V]);
-        } else {
-            q[(long)j * F] = r[0];
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + k;
+            if (j < D) {
+                float r[V];
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    r[i] = g_mean[i] + (kstd[i] + kvar[i]) * (xs[k][i] - mean[i]);
+                    if (j == amax[i]) r[i] += g_max[i];
+                    if (j == amin[i]) r[i] += g_min[i];
+                }
+                if (V == 4) *reinterpret_cast<float4*>(q + (long)j * F) = make_float4(r[0], r[1 % V], r[2 % V], r[3 % V]);
+                else q[(long)j * F] = r[0];
+            }
         }
     }
 }

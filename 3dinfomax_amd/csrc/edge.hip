@@ -92,14 +92,32 @@ segment_sum_kernel(const float* __restrict__ x, int ldx, const int* __restrict__
     float acc[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) acc[i] = 0.f;
-    for (int j = beg; j < end; ++j) {
-        long row = idx ? idx[j] : j;
-        const float* p = x + row * ldx + c;
-        if (V == 4) {
-            float4 a = *reinterpret_cast<const float4*>(p);
-            acc[0] += a.x; acc[1 % V] += a.y; acc[2 % V] += a.z; acc[3 % V] += a.w;
-        } else {
-            acc[0] += p[0];
+    // four rows per trip, loaded unconditionally (clamped index; the duplicates hit L1) so that four loads - and their
+    // four index loads - are in flight instead of one load-add per trip; the additions keep the order j = beg .. end-1
+    for (int j = beg; j < end; j += 4) {
+        long rows[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int jj = min(j + k, end - 1);
+            rows[k] = idx ? idx[jj] : jj;
+        }
+        float a[4][V];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float* p = x + rows[k] * ldx + c;
+            if (V == 4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(p);
+                a[k][0] = t4.x; a[k][1 % V] = t4.y; a[k][2 % V] = t4.z; a[k][3 % V] = t4.w;
+            } else {
+                a[k][0] = p[0];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (j + k < end) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) acc[i] += a[k][i];
+            }
         }
     }
     if (scale_mode == 1) {   // DGL fn.mean divides the sum by the in-degree

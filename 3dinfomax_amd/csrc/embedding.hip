@@ -40,13 +40,29 @@ embedding_sum_fwd_kernel(const int64_t* __restrict__ idx, const int* __restrict_
 #pragma unroll
     for (int i = 0; i < V; ++i) acc[i] = 0.f;
     const long ir = row_perm ? row_perm[r] : r;     // output row r reads index row row_perm[r]
-    for (int k = 0; k < n_cols; ++k) {
-        const float* p = tabs.t[k] + (long)idx[ir * n_cols + k] * feat + c;
-        if (V == 4) {
-            float4 v = *reinterpret_cast<const float4*>(p);
-            acc[0] += v.x; acc[1 % V] += v.y; acc[2 % V] += v.z; acc[3 % V] += v.w;
-        } else {
-            acc[0] += p[0];
+    // four tables per trip: their four index loads, then their four row loads are in flight together (a load-add per
+    // trip is a chain of 2 x n_cols dependent memory round trips); additions in table order
+    for (int k0 = 0; k0 < n_cols; k0 += 4) {
+        long rows_[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rows_[k] = idx[ir * n_cols + min(k0 + k, n_cols - 1)];
+        float a[4][V];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float* p = tabs.t[min(k0 + k, n_cols - 1)] + rows_[k] * feat + c;
+            if (V == 4) {
+                float4 v = *reinterpret_cast<const float4*>(p);
+                a[k][0] = v.x; a[k][1 % V] = v.y; a[k][2 % V] = v.z; a[k][3 % V] = v.w;
+            } else {
+                a[k][0] = p[0];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k0 + k < n_cols) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) acc[i] += a[k][i];
+            }
         }
     }
     float* o = out + (long)r * feat + c;
