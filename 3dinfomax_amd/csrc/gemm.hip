@@ -423,12 +423,25 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(SlabReduce a) {
     for (int i = 0; i < V; ++i) acc[i] = a.accumulate ? c[i] : 0.f;
     const long slice = (long)a.M * a.N;
     const float* p = a.slab + (long)m * a.N + n;
-    for (int z = a.seg_ptr[gi]; z < a.seg_ptr[gi + 1]; ++z) {
-        if (V == 4) {
-            float4 x = *reinterpret_cast<const float4*>(p + z * slice);
-            acc[0] += x.x; acc[1 % V] += x.y; acc[2 % V] += x.z; acc[3 % V] += x.w;
-        } else {
-            acc[0] += p[z * slice];
+    const int z_end = a.seg_ptr[gi + 1];
+    for (int z0 = a.seg_ptr[gi]; z0 < z_end; z0 += 4) {     // four slices in flight per trip, summed in slice order
+        float x[4][V];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float* q = p + (long)min(z0 + k, z_end - 1) * slice;
+            if (V == 4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(q);
+                x[k][0] = t4.x; x[k][1 % V] = t4.y; x[k][2 % V] = t4.z; x[k][3 % V] = t4.w;
+            } else {
+                x[k][0] = q[0];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (z0 + k < z_end) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) acc[i] += x[k][i];
+            }
         }
     }
     if (a.bias != nullptr) {
@@ -461,12 +474,26 @@ __global__ void __launch_bounds__(256) slab_reduce_small_kernel(SlabReduce a) {
         n = (int)(r - (long)m * NV) * V;
         const long slice = (long)a.M * a.N;
         const float* p = a.slab + (long)m * a.N + n;
-        for (int z = a.seg_ptr[gi] + zl; z < a.seg_ptr[gi + 1]; z += ZL) {
-            if (V == 4) {
-                float4 x = *reinterpret_cast<const float4*>(p + z * slice);
-                acc[0] += x.x; acc[1 % V] += x.y; acc[2 % V] += x.z; acc[3 % V] += x.w;
-            } else {
-                acc[0] += p[z * slice];
+        const int z_end = a.seg_ptr[gi + 1];
+        for (int z0 = a.seg_ptr[gi] + zl; z0 < z_end; z0 += 4 * ZL) {      // four of this lane's slices in flight per trip
+            float x[4][V];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int z = z0 + k * ZL;
+                const float* q = p + (long)(z < z_end ? z : z0) * slice;
+                if (V == 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(q);
+                    x[k][0] = t4.x; x[k][1 % V] = t4.y; x[k][2 % V] = t4.z; x[k][3 % V] = t4.w;
+                } else {
+                    x[k][0] = q[0];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (z0 + k * ZL < z_end) {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) acc[i] += x[k][i];
+                }
             }
         }
     }
