@@ -16,6 +16,66 @@ using namespace i3d;
         if (rc_ != I3D_OK) return rc_; \
     } while (0)
 
+// ---- weight gradients next to the data-gradient chain ---------------------------------------------------------------
+// The backward pass of a block is a chain (BatchNorm backward -> data gradient -> next block) of small kernels that each
+// occupy a fraction of the chip, plus weight-gradient GEMMs (dW = dY^T X and their split-K reductions, ~20 % of the step's
+// kernel time) that nothing downstream in the chain reads.  The composites enqueue those on a second HIP stream of their
+// own (one per caller stream, created on first use): fork = an event recorded on the caller's stream that the side stream
+// waits for, join = the caller's stream waits for the side stream before the composite (for a PNA layer: the whole layer)
+// returns, so every tensor the caller sees afterwards is complete and the caching allocator's stream-ordered reuse stays
+// valid.  All weight gradients of one caller stream share that stream's split-K scratch: they are serialised on the one
+// side stream.  Same kernels, same arguments, same order per stream: results are bit-identical.  I3D_WGRAD_STREAM=0: off.
+#include <map>
+#include <mutex>
+#include <utility>
+
+namespace {
+
+struct Aux {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+
+Aux* aux_for(hipStream_t main) {
+    static const bool on = [] { const char* e = getenv("I3D_WGRAD_STREAM"); return e == nullptr || e[0] != '0'; }();
+    if (!on) return nullptr;
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Aux*> table;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = table.find({dev, main});
+    if (it != table.end()) return it->second;
+    Aux* a = new Aux();
+    if (hipStreamCreateWithFlags(&a->s, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&a->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&a->join, hipEventDisableTiming) != hipSuccess) {
+        delete a;
+        a = nullptr;          // remembered: no retry on every call
+    }
+    table[{dev, main}] = a;
+    return a;
+}
+
+// the stream for the weight gradients that are enqueued next: the side stream, ordered after everything the caller's
+// stream holds now - or the caller's stream itself when there is no side stream
+void* fork_wgrad(Aux* x, void* main) {
+    if (x == nullptr) return main;
+    if (hipEventRecord(x->fork, (hipStream_t)main) != hipSuccess || hipStreamWaitEvent(x->s, x->fork, 0) != hipSuccess) return main;
+    return (void*)x->s;
+}
+
+int join_wgrad(Aux* x, void* main) {
+    if (x == nullptr) return I3D_OK;
+    if (hipEventRecord(x->join, x->s) != hipSuccess || hipStreamWaitEvent((hipStream_t)main, x->join, 0) != hipSuccess) {
+        i3d::set_error("joining the weight-gradient stream failed");
+        return I3D_ERR_LAUNCH;
+    }
+    return I3D_OK;
+}
+
+}  // namespace
+
 static int tail_fwd(const I3dBnTail* t, int rows, int f_out, float* pre, float* xact, const float* residual, float* y,
                     void* stream) {
     // pre holds the Linear output.  xact == pre: activation in place (ReLU/none); else pre is kept for act'
@@ -39,15 +99,21 @@ extern "C" int i3d_fc_bn_fwd(const I3dFcArgs* a, void* stream) {
     return tail_fwd(&a->tail, a->rows, a->f_out, lin, a->xact, a->residual, a->y, stream);
 }
 
-extern "C" int i3d_fc_bn_bwd(const I3dFcArgs* a, void* stream) {
-    I3D_CHECK_ARG(a != nullptr && a->rows > 0, "bad arguments");
+// `x`: side stream of the caller's stream (may be null); `join`: wait for it before returning (a PNA layer joins once)
+static int fc_bn_bwd(const I3dFcArgs* a, void* stream, Aux* x, bool join) {
     TRY(tail_bwd(&a->tail, a->rows, a->f_out, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre,
                  a->grad_bias, stream));
-    TRY(i3d_gemm_f32_ws(1, 0, a->f_out, a->f_in, a->rows, a->grad_pre, a->f_out, a->x, a->f_in, a->grad_W, a->ldw, nullptr, 0, a->tail.gemm_workspace, a->tail.gemm_workspace_bytes, stream));
+    void* ws_ = fork_wgrad(x, stream);
+    TRY(i3d_gemm_f32_ws(1, 0, a->f_out, a->f_in, a->rows, a->grad_pre, a->f_out, a->x, a->f_in, a->grad_W, a->ldw, nullptr, 0, a->tail.gemm_workspace, a->tail.gemm_workspace_bytes, ws_));
     if (a->grad_x != nullptr)
         TRY(i3d_gemm_f32(0, 0, a->rows, a->f_in, a->f_out, a->grad_pre, a->f_out, a->W, a->ldw, a->grad_x, a->f_in, nullptr,
                          0, stream));
-    return I3D_OK;
+    return join ? join_wgrad(x, stream) : I3D_OK;
+}
+
+extern "C" int i3d_fc_bn_bwd(const I3dFcArgs* a, void* stream) {
+    I3D_CHECK_ARG(a != nullptr && a->rows > 0, "bad arguments");
+    return fc_bn_bwd(a, stream, aux_for((hipStream_t)stream), true);
 }
 
 // ---- edge FC: [h_src | h_dst | q] -> Linear as node-level P + gather-combine -------------------------
@@ -68,8 +134,7 @@ extern "C" int i3d_edge_fc_bn_fwd(const I3dEdgeFcArgs* a, void* stream) {
     return tail_fwd(&a->tail, a->num_edges, Fo, lin, a->xact, nullptr, a->y, stream);
 }
 
-extern "C" int i3d_edge_fc_bn_bwd(const I3dEdgeFcArgs* a, void* stream) {
-    I3D_CHECK_ARG(a != nullptr && a->num_edges > 0 && a->num_nodes > 0, "bad arguments");
+static int edge_fc_bn_bwd(const I3dEdgeFcArgs* a, void* stream, Aux* x, bool join) {
     const int Fh = a->f_h, Fo = a->f_out, N = a->num_nodes, E = a->num_edges;
     TRY(tail_bwd(&a->tail, E, Fo, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre, a->grad_bias,
                  stream));
@@ -81,23 +146,31 @@ extern "C" int i3d_edge_fc_bn_bwd(const I3dEdgeFcArgs* a, void* stream) {
     const long wsb = a->tail.gemm_workspace_bytes;
     const long wdelta = (long)Fh - (long)Fo * a->ldw, wview = (long)(Fo - 1) * a->ldw + 2 * Fh;
     // d[W_s | W_d] = dP^T h (rows >= Fo of the [2Fo, Fh] result land in the second column block), dh = dP [W_s; W_d]
+    // the weight gradients (and, in table mode, everything behind dQ: only the caller reads grad_q) go to the side stream;
+    // the caller's stream continues with dh, the input of the next block's backward
+    void* wst = fork_wgrad(x, stream);
     TRY(i3d_gemm_f32_blocks(1, 0, 2 * Fo, Fh, N, a->grad_P, 2 * Fo, a->h, Fh, 0, 0, 0, a->grad_W, a->ldw, Fo, wdelta, 0, ws, wsb,
-                            stream));
+                            wst));
     TRY(i3d_gemm_f32_blocks(0, 0, N, Fh, 2 * Fo, a->grad_P, 2 * Fo, a->W, a->ldw, Fo, wdelta, wview, a->grad_h, Fh, 0, 0, 0,
                             nullptr, 0, stream));
     if (a->q != nullptr && a->q_rows > 0) {
         // table mode: dQ[v] = sum of dpre over the edges of category v (one-hot^T dpre), then two [V, .] products
         const int V = a->q_rows;
-        TRY(i3d_gemm_f32_ws(1, 0, a->v_pad, Fo, E, a->onehot, a->v_pad, a->grad_pre, Fo, a->grad_Q, Fo, nullptr, 0, ws, wsb, stream));
-        TRY(i3d_gemm_f32_ws(1, 0, Fo, a->f_q, V, a->grad_Q, Fo, a->q, a->f_q, a->grad_W + 2 * Fh, a->ldw, nullptr, 0, ws, wsb, stream));
+        TRY(i3d_gemm_f32_ws(1, 0, a->v_pad, Fo, E, a->onehot, a->v_pad, a->grad_pre, Fo, a->grad_Q, Fo, nullptr, 0, ws, wsb, wst));
+        TRY(i3d_gemm_f32_ws(1, 0, Fo, a->f_q, V, a->grad_Q, Fo, a->q, a->f_q, a->grad_W + 2 * Fh, a->ldw, nullptr, 0, ws, wsb, wst));
         if (a->grad_q != nullptr)
-            TRY(i3d_gemm_f32(0, 0, V, a->f_q, Fo, a->grad_Q, Fo, a->W + 2 * Fh, a->ldw, a->grad_q, a->f_q, nullptr, 0, stream));
+            TRY(i3d_gemm_f32(0, 0, V, a->f_q, Fo, a->grad_Q, Fo, a->W + 2 * Fh, a->ldw, a->grad_q, a->f_q, nullptr, 0, wst));
     } else if (a->q != nullptr) {
-        TRY(i3d_gemm_f32_ws(1, 0, Fo, a->f_q, E, a->grad_pre, Fo, a->q, a->f_q, a->grad_W + 2 * Fh, a->ldw, nullptr, 0, ws, wsb, stream));
+        TRY(i3d_gemm_f32_ws(1, 0, Fo, a->f_q, E, a->grad_pre, Fo, a->q, a->f_q, a->grad_W + 2 * Fh, a->ldw, nullptr, 0, ws, wsb, wst));
         if (a->grad_q != nullptr)
             TRY(i3d_gemm_f32(0, 0, E, a->f_q, Fo, a->grad_pre, Fo, a->W + 2 * Fh, a->ldw, a->grad_q, a->f_q, nullptr, 0, stream));
     }
-    return I3D_OK;
+    return join ? join_wgrad(x, stream) : I3D_OK;
+}
+
+extern "C" int i3d_edge_fc_bn_bwd(const I3dEdgeFcArgs* a, void* stream) {
+    I3D_CHECK_ARG(a != nullptr && a->num_edges > 0 && a->num_nodes > 0, "bad arguments");
+    return edge_fc_bn_bwd(a, stream, aux_for((hipStream_t)stream), true);
 }
 
 // ---- degree-grouped concat FC: [h | scaler blocks of a] -> Linear with per-degree combined weights -----------
@@ -112,20 +185,26 @@ extern "C" int i3d_grouped_fc_bn_fwd(const I3dGroupedFcArgs* a, void* stream) {
     return tail_fwd(&a->tail, N, Fo, lin, a->xact, a->residual, a->y, stream);
 }
 
-extern "C" int i3d_grouped_fc_bn_bwd(const I3dGroupedFcArgs* a, void* stream) {
-    I3D_CHECK_ARG(a != nullptr && a->num_nodes > 0 && a->n_groups > 0, "bad arguments");
+static int grouped_fc_bn_bwd(const I3dGroupedFcArgs* a, void* stream, Aux* x, bool join) {
     const int Fh = a->f_h, Fo = a->f_out, A = a->agg_width, N = a->num_nodes;
     TRY(tail_bwd(&a->tail, N, Fo, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre, a->grad_bias,
                  stream));
-    TRY(i3d_gemm_f32_ws(1, 0, Fo, Fh, N, a->grad_pre, Fo, a->h, Fh, a->grad_W, a->ldw, nullptr, 0, a->tail.gemm_workspace, a->tail.gemm_workspace_bytes, stream));
+    void* wst = fork_wgrad(x, stream);
+    TRY(i3d_gemm_f32_ws(1, 0, Fo, Fh, N, a->grad_pre, Fo, a->h, Fh, a->grad_W, a->ldw, nullptr, 0, a->tail.gemm_workspace, a->tail.gemm_workspace_bytes, wst));
     // dW_D = dY_D^T a_D over the rows of each in-degree group, all groups in one launch
     TRY(i3d_gemm_f32_rowsubset_multi(Fo, A, a->n_groups, a->group_start, a->group_count, a->grad_pre, Fo, a->agg, A,
                                      a->deg_rows, N, a->grad_WD, (long)Fo * A, A, 0, -1, 0, a->tail.gemm_workspace,
-                                     a->tail.gemm_workspace_bytes, stream));
-    TRY(i3d_pna_combine_weights_bwd(a->grad_WD, a->ldw, Fh, Fo, A, a->n_groups, a->n_scalers, a->coef, a->grad_W, stream));
+                                     a->tail.gemm_workspace_bytes, wst));
+    TRY(i3d_pna_combine_weights_bwd(a->grad_WD, a->ldw, Fh, Fo, A, a->n_groups, a->n_scalers, a->coef, a->grad_W, wst));
     TRY(i3d_gemm_f32(0, 0, N, Fh, Fo, a->grad_pre, Fo, a->W, a->ldw, a->grad_h, Fh, nullptr, 0, stream));
-    return i3d_gemm_f32_grouped(0, a->m_padded, A, Fo, a->grad_pre, Fo, N, a->deg_rows, a->deg_tile_group, a->WD, A,
-                                (long)Fo * A, a->grad_agg, A, 0, stream);
+    TRY(i3d_gemm_f32_grouped(0, a->m_padded, A, Fo, a->grad_pre, Fo, N, a->deg_rows, a->deg_tile_group, a->WD, A,
+                             (long)Fo * A, a->grad_agg, A, 0, stream));
+    return join ? join_wgrad(x, stream) : I3D_OK;
+}
+
+extern "C" int i3d_grouped_fc_bn_bwd(const I3dGroupedFcArgs* a, void* stream) {
+    I3D_CHECK_ARG(a != nullptr && a->num_nodes > 0 && a->n_groups > 0, "bad arguments");
+    return grouped_fc_bn_bwd(a, stream, aux_for((hipStream_t)stream), true);
 }
 
 // ---- one PNA layer ---------------------------------------------------------------------------------------
@@ -146,16 +225,17 @@ extern "C" int i3d_pna_layer_fwd(const I3dPnaLayerArgs* a, void* stream) {
 extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     I3D_CHECK_ARG(a != nullptr && a->n_pre_extra >= 0 && a->n_pre_extra <= I3D_MAX_EXTRA_FC && a->n_post_extra >= 0 &&
                       a->n_post_extra <= I3D_MAX_EXTRA_FC, "bad arguments");
-    for (int i = a->n_post_extra - 1; i >= 0; --i) TRY(i3d_fc_bn_bwd(&a->postx[i], stream));
-    TRY(i3d_grouped_fc_bn_bwd(&a->post, stream));
+    Aux* x = aux_for((hipStream_t)stream);     // the weight gradients of all blocks of the layer; joined once, at the end
+    for (int i = a->n_post_extra - 1; i >= 0; --i) TRY(fc_bn_bwd(&a->postx[i], stream, x, false));
+    TRY(grouped_fc_bn_bwd(&a->post, stream, x, false));
     TRY(i3d_pna_aggregate_bwd(a->post.grad_agg, a->msg, a->edge.in_ptr, a->edge.num_nodes, a->edge.f_out, a->aggregators,
                               a->n_aggregators, a->scalers, a->n_scalers, a->force_scalers, a->avg_d_log, a->grad_msg, stream));
-    for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(i3d_fc_bn_bwd(&a->pre[i], stream));
-    TRY(i3d_edge_fc_bn_bwd(&a->edge, stream));
+    for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd(&a->pre[i], stream, x, false));
+    TRY(edge_fc_bn_bwd(&a->edge, stream, x, false));
     const long n = (long)a->edge.num_nodes * a->edge.f_h;
     TRY(i3d_add_inplace(a->post.grad_h, a->edge.grad_h, n, stream));
     if (a->residual) TRY(i3d_add_inplace(a->post.grad_h, a->grad_out, n, stream));
-    return I3D_OK;
+    return join_wgrad(x, stream);
 }
 
 // ---- timing events -------------------------------------------------------------------------------------

@@ -522,6 +522,42 @@ def test_num_batches_tracked_counts_forward_passes(amd, monkeypatch, composite):
     assert len(counters) > 5 and all(v == 3 for _, v in counters), counters
 
 
+def test_weight_gradient_stream_gives_the_same_bits():
+    """The backward composites enqueue the weight-gradient GEMMs on a side stream of their own (composite.hip); with it
+    switched off (I3D_WGRAD_STREAM=0, read once per process -> subprocesses) three optimisation steps end in the same
+    bits."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import importlib, sys, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import helpers\n"
+        "amd = importlib.import_module('3dinfomax_amd')\n"
+        "mols = amd.synth.make_dataset(96, seed=21)\n"
+        "torch.manual_seed(7)\n"
+        "pna = amd.PNA(avg_d=1.0, device='cuda:0', **dict(helpers.PNA_YML, propagation_depth=2)).cuda().train()\n"
+        "net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **helpers.NET3D_YML).cuda().train()\n"
+        "loss_fn = amd.NTXent(tau=0.1)\n"
+        "params = list(pna.parameters()) + list(net.parameters())\n"
+        "optim = amd.Adam(params, lr=1e-3)\n"
+        "for _ in range(3):\n"
+        "    g2 = amd.batch([amd.bond_graph(m) for m in mols]).to('cuda:0')\n"
+        "    g3 = amd.batch([amd.complete_graph(m) for m in mols]).to('cuda:0')\n"
+        "    loss_fn(pna(g2), net(g3)).backward()\n"
+        "    optim.step(); optim.zero_grad()\n"
+        "torch.save([p.detach().cpu() for p in params], sys.argv[1])\n") % (root, os.path.join(root, 'tests'))
+    res = {}
+    for mode in ('0', '1'):
+        path = f'/tmp/i3d_wgrad_stream_{mode}.pt'
+        subprocess.run([sys.executable, '-c', code, path], check=True, env=dict(os.environ, I3D_WGRAD_STREAM=mode), timeout=600)
+        res[mode] = torch.load(path)
+    assert len(res['0']) > 50
+    for a, b in zip(res['0'], res['1']):
+        assert torch.equal(a, b)
+
+
 def test_dist_warm_up_runs(amd):
     """dist.warm_up: the throw-away steps a data-parallel rank runs before it creates its communicator"""
     importlib.import_module('3dinfomax_amd.dist').warm_up('cuda:0', steps=1)
