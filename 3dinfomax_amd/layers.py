@@ -501,22 +501,51 @@ class FCLayer(nn.Module):
         if self.bias:
             self.linear.bias.data.zero_()
 
+    # Every attribute below goes through nn.Module.__getattr__ (parameters, buffers and sub-modules live in dicts): ~14
+    # slow lookups and two dataclass constructions per call, ~18 calls per training step.  `hot(post_act)` caches
+    # (weight, bias, gamma, beta, spec); anything that can change what it holds drops the cache: train()/eval(),
+    # .to()/.cuda()/.float() (`_apply` replaces the buffer objects), a new sync group.  load_state_dict copies in place.
     def spec(self, post_act=None) -> FCSpec:
-        bn = None
-        if self.batch_norm is not None:
-            m = self.batch_norm
-            bn = BNSpec(m.running_mean, m.running_var, m.num_batches_tracked, m.momentum, m.eps, self.training,
-                        self.sync_group if self.training else None)
-        return FCSpec(self.activation, bn, post_act)
+        return self.hot(post_act)[4]
 
     def bn_affine(self):
-        if self.batch_norm is None:
-            return None, None
-        return self.batch_norm.weight, self.batch_norm.bias
+        h = self.hot(None)
+        return h[2], h[3]
+
+    def hot(self, post_act=None):
+        cache = self.__dict__.get('_i3d_hot')
+        if cache is None:
+            cache = self.__dict__['_i3d_hot'] = {}
+        h = cache.get(post_act)
+        if h is None:
+            bn, gamma, beta = None, None, None
+            if self.batch_norm is not None:
+                m = self.batch_norm
+                bn = BNSpec(m.running_mean, m.running_var, m.num_batches_tracked, m.momentum, m.eps, self.training,
+                            self.sync_group if self.training else None)
+                gamma, beta = m.weight, m.bias
+            h = cache[post_act] = (self.linear.weight, self.linear.bias, gamma, beta, FCSpec(self.activation, bn, post_act))
+        return h
+
+    def _drop_hot(self):
+        self.__dict__.pop('_i3d_hot', None)
+
+    def train(self, mode: bool = True):
+        self._drop_hot()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._drop_hot()
+        return super()._apply(fn, *args, **kwargs)
+
+    def __setattr__(self, name, value):
+        if name in ('sync_group', 'batch_norm', 'linear', 'activation'):
+            self.__dict__.pop('_i3d_hot', None)
+        super().__setattr__(name, value)
 
     def forward(self, x, residual=None, post_act=None):
-        gamma, beta = self.bn_affine()
-        return tape.apply(FCFn, x, self.linear.weight, self.linear.bias, gamma, beta, residual, self.spec(post_act))
+        W, b, gamma, beta, spec = self.hot(post_act)
+        return tape.apply(FCFn, x, W, b, gamma, beta, residual, spec)
 
 
 class MLP(nn.Module):
@@ -553,8 +582,8 @@ class MLP(nn.Module):
     # first layer fed by a fused input operator (edge gather / two-segment concat), rest plain
     def forward_edge(self, h, q, index, residual=None, qmap=None):
         fc0 = self.fully_connected[0]
-        gamma, beta = fc0.bn_affine()
-        x = tape.apply(EdgeFCFn, h, q, fc0.linear.weight, fc0.linear.bias, gamma, beta, index, fc0.spec(), qmap)
+        W, b, gamma, beta, spec = fc0.hot()
+        x = tape.apply(EdgeFCFn, h, q, W, b, gamma, beta, index, spec, qmap)
         for fc in list(self.fully_connected)[1:]:
             x = fc(x)
         return x

@@ -282,16 +282,26 @@ class PNALayer(nn.Module):
         avg = float(self.avg_d["log"])
         grouped = GROUPED_POSTTRANS and len(self.scalers) > 1 and h.shape[1] % 4 == 0
         if FUSED_LAYER and h.is_cuda:
+            # per call: only the per-degree scaler coefficients depend on the batch (cached on its index: the layers of a
+            # model share them); specs and parameters come from the FC layers' hot caches
+            fcs = self.__dict__.get('_i3d_fcs')
+            if fcs is None:
+                fcs = self.__dict__['_i3d_fcs'] = (list(self.pretrans.fully_connected), list(self.posttrans.fully_connected))
+            pre, post = fcs
+            hots = [fc.hot() for fc in pre + post]
             plan = _LayerPlan()
-            pre, post = list(self.pretrans.fully_connected), list(self.posttrans.fully_connected)
-            plan.pre_specs, plan.post_specs = [fc.spec() for fc in pre], [fc.spec() for fc in post]
+            plan.pre_specs, plan.post_specs = [t[4] for t in hots[:len(pre)]], [t[4] for t in hots[len(pre):]]
             plan.aggregators, plan.avg, plan.grouped, plan.residual = self.aggregators, avg, grouped, self.residual
             plan.agg_scalers = [ops.SCALER['identity']] if grouped else self.scalers
-            plan.coef = ([[_scaler_coef(s, D, avg) for s in self.scalers] for D, _, _ in idx.degree_groups()[2]]
-                         if grouped else None)
-            params = []
-            for fc in pre + post:
-                params += [fc.linear.weight, fc.linear.bias, *fc.bn_affine()]
+            plan.coef = None
+            if grouped:
+                key = (tuple(self.scalers), avg)
+                cache = idx.__dict__.setdefault('_i3d_coef', {})
+                plan.coef = cache.get(key)
+                if plan.coef is None:
+                    plan.coef = cache[key] = [[_scaler_coef(s, D, avg) for s in self.scalers]
+                                              for D, _, _ in idx.degree_groups()[2]]
+            params = [t for hot in hots for t in hot[:4]]
             h_new = tape.apply(PNALayerFn, h, ef_sorted if self.edge_features else None, idx,
                                      qmap if self.edge_features else None, plan, *params)
             g.ndata['feat'] = h_new
