@@ -11,7 +11,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from . import ops, streams, tape
+from . import net3d_native, ops, streams, tape
 from .graph import as_batched_graph
 from .layers import MLP, ReadoutFn, act_name, bn_counter_scope
 from .mol_encoder import AtomEncoder
@@ -70,6 +70,18 @@ class SegmentReduceFn(torch.autograd.Function):
     def backward(ctx, g):
         index, mean = ctx.cfg
         return ops.segment_bcast(g.contiguous(), index.in_ptr, index.dst_s, index.num_edges, mean=mean), None, None
+
+
+class Net3DFn(torch.autograd.Function):
+    """the whole network as one node (net3d_native.py)"""
+
+    @staticmethod
+    def forward(ctx, model, graph, *params):
+        return net3d_native.forward(ctx, model, graph, params)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return (None, None) + net3d_native.backward(ctx, grad)
 
 
 class Net3D(nn.Module):
@@ -135,6 +147,9 @@ class Net3D(nn.Module):
 
     def _forward(self, graph):
         g = as_batched_graph(graph)
+        if tape.active() is not None and net3d_native.eligible(self, g):
+            params = self.__dict__.get('_i3d_param_list') or list(self.parameters())
+            return tape.apply(Net3DFn, self, g, *params)
         idx = g.index()
         if self.use_node_features:
             h = self.atom_encoder(g.ndata['feat'])

@@ -558,6 +558,37 @@ def test_weight_gradient_stream_gives_the_same_bits():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('cfg', ['yml', 'deep'])
+def test_native_net3d_equals_block_path(amd, monkeypatch, cfg):
+    """Net3D as one tape node sequenced over raw pointers (net3d_native.py) gives the same bits as the per-block path:
+    output, side effects on the graph, every parameter gradient, BatchNorm buffers - and it is the path that runs."""
+    native = importlib.import_module('3dinfomax_amd.net3d_native')
+    kw = dict(NET3D_YML) if cfg == 'yml' else dict(NET3D_YML, propagation_depth=3, message_net_layers=2, update_net_layers=2,
+                                                     node_wise_output_layers=2, readout_layers=2, reduce_func='sum')
+    mols = synth.make_dataset(40, seed=17)
+    calls = []
+    real_forward = native.forward
+    monkeypatch.setattr(native, 'forward', lambda *a, **k: (calls.append(1), real_forward(*a, **k))[1])
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(native, 'NATIVE_NET3D', mode)
+        torch.manual_seed(11)
+        net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **kw).cuda().train()
+        outs = []
+        for _ in range(2):
+            _, g3 = make_batch(amd, mols)
+            z = net(g3)
+            (z * torch.linspace(-1, 1, z.shape[1], device='cuda:0')).sum().backward()
+            outs += [z.detach().clone(), g3.ndata['feat'].detach().clone(), g3.edata['d'].detach().clone()]
+        outs += [p.grad.clone() for p in net.parameters()] + [b.clone().float() for b in net.buffers()]
+        res[mode] = outs
+        net.zero_grad()
+    assert len(calls) == 2                      # the native path ran (both forward passes of the first model)
+    assert len(res[True]) == len(res[False]) > 20
+    for i, (a, b) in enumerate(zip(res[True], res[False])):
+        assert torch.equal(a, b), i
+
+
 def test_dist_warm_up_runs(amd):
     """dist.warm_up: the throw-away steps a data-parallel rank runs before it creates its communicator"""
     importlib.import_module('3dinfomax_amd.dist').warm_up('cuda:0', steps=1)
