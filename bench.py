@@ -265,9 +265,9 @@ def main():
         b2b, b2b_us = back_to_back(blocks)
         b2b12, b2b12_us = back_to_back(12)
         # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured with
-        # rocprofv3 on this kernel variant and batch shape (tools/k4_pmc_summary.py -> profiles/r01_k4_pmc_v2.txt)
+        # rocprofv3 on this kernel variant and batch shape (tools/k4_pmc_summary.py -> profiles/r01_k4_pmc_v3.txt)
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_k4_pmc_v2.json')
+        pmc = os.path.join(ROOT, 'profiles', 'r01_k4_pmc_v3.json')
         if os.path.exists(pmc):
             with open(pmc) as f:
                 p = json.load(f).get(f'fwd{blocks}_B512')
