@@ -517,14 +517,18 @@ class FCLayer(nn.Module):
         if cache is None:
             cache = self.__dict__['_i3d_hot'] = {}
         h = cache.get(post_act)
-        if h is None:
-            bn, gamma, beta = None, None, None
-            if self.batch_norm is not None:
-                m = self.batch_norm
-                bn = BNSpec(m.running_mean, m.running_var, m.num_batches_tracked, m.momentum, m.eps, self.training,
-                            self.sync_group if self.training else None)
-                gamma, beta = m.weight, m.bias
-            h = cache[post_act] = (self.linear.weight, self.linear.bias, gamma, beta, FCSpec(self.activation, bn, post_act))
+        if h is not None:
+            lp, bp = h[5], h[6]      # the sub-modules' parameter dicts: a re-assigned Parameter object invalidates the entry
+            if lp['weight'] is h[0] and lp['bias'] is h[1] and (bp is None or (bp['weight'] is h[2] and bp['bias'] is h[3])):
+                return h
+        bn, gamma, beta, bp = None, None, None, None
+        if self.batch_norm is not None:
+            m = self.batch_norm
+            bn = BNSpec(m.running_mean, m.running_var, m.num_batches_tracked, m.momentum, m.eps, self.training,
+                        self.sync_group if self.training else None)
+            gamma, beta, bp = m.weight, m.bias, m._parameters
+        lin = self.linear
+        h = cache[post_act] = (lin.weight, lin.bias, gamma, beta, FCSpec(self.activation, bn, post_act), lin._parameters, bp)
         return h
 
     def _drop_hot(self):
@@ -544,7 +548,7 @@ class FCLayer(nn.Module):
         super().__setattr__(name, value)
 
     def forward(self, x, residual=None, post_act=None):
-        W, b, gamma, beta, spec = self.hot(post_act)
+        W, b, gamma, beta, spec = self.hot(post_act)[:5]
         return tape.apply(FCFn, x, W, b, gamma, beta, residual, spec)
 
 
@@ -582,7 +586,7 @@ class MLP(nn.Module):
     # first layer fed by a fused input operator (edge gather / two-segment concat), rest plain
     def forward_edge(self, h, q, index, residual=None, qmap=None):
         fc0 = self.fully_connected[0]
-        W, b, gamma, beta, spec = fc0.hot()
+        W, b, gamma, beta, spec = fc0.hot()[:5]
         x = tape.apply(EdgeFCFn, h, q, W, b, gamma, beta, index, spec, qmap)
         for fc in list(self.fully_connected)[1:]:
             x = fc(x)

@@ -79,7 +79,7 @@ def _fc_floats(rows, fout, spec):
 
 
 def _fc_fwd(L, stream, ar, dev, fc, rows, x_ptr, residual=None, post_act=None, y_ptr=None):
-    W, b, gamma, beta, spec = fc.hot(post_act)
+    W, b, gamma, beta, spec = fc.hot(post_act)[:5]
     fout, fin = W.shape
     a = _lib.FcArgs()
     _tail(a.tail, spec, gamma, beta, ar.take(fout), ar.take(fout), fout, dev)
@@ -148,7 +148,7 @@ def forward(ctx, model, g, params):
         last_layer = li + 1 == n_layers
         lay = {'msg': [], 'upd': []}
         # message network: first layer on [h_src | h_dst | d] through the node-level products (edge.hip), then plain blocks
-        W, b, gamma, beta, spec = msg[0].hot()
+        W, b, gamma, beta, spec = msg[0].hot()[:5]
         Fo = W.shape[0]
         a = _lib.EdgeFcArgs()
         _tail(a.tail, spec, gamma, beta, ar.take(Fo), ar.take(Fo), Fo, dev)
@@ -204,7 +204,7 @@ def forward(ctx, model, g, params):
     x, fin = ro, R * H
     z = None
     for k, fc in enumerate(out):
-        W, b, gamma, beta, spec = fc.hot()
+        W, b, gamma, beta, spec = fc.hot()[:5]
         final = k + 1 == len(out)
         if final:
             z = torch.empty(B, W.shape[0], dtype=_F32, device=dev)

@@ -12,7 +12,7 @@ tape = importlib.import_module('3dinfomax_amd.tape')
 
 def test_fclayer_hot_cache_follows_mode_device_casts_and_sync_group():
     fc = layers.FCLayer(6, 4, activation='relu', batch_norm=True, batch_norm_momentum=0.93)
-    W, b, gamma, beta, spec = fc.hot()
+    W, b, gamma, beta, spec = fc.hot()[:5]
     assert W is fc.linear.weight and b is fc.linear.bias and gamma is fc.batch_norm.weight and beta is fc.batch_norm.bias
     assert spec.bn.training and spec.bn.running_mean is fc.batch_norm.running_mean and spec.act == 'relu'
     assert fc.hot() is fc.hot()                              # cached
@@ -34,6 +34,8 @@ def test_fclayer_hot_cache_follows_mode_device_casts_and_sync_group():
     cached = fc.hot()
     fc.load_state_dict(sd)
     assert fc.hot() is cached and torch.equal(cached[0], sd['linear.weight'])
+    fc.linear.weight = torch.nn.Parameter(torch.zeros(4, 6))   # a re-assigned Parameter object is noticed
+    assert fc.hot()[0] is fc.linear.weight and fc.hot() is not cached
     plain = layers.FCLayer(6, 4, activation='none', batch_norm=False)
     assert plain.hot()[2] is None and plain.hot()[4].bn is None
 
