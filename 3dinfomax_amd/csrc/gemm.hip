@@ -66,13 +66,13 @@ __device__ __forceinline__ int swz(int k, int idx) { return idx ^ ((((k) ^ (k >>
 // IM (k-contiguous operands only): the LDS image is idx-major, T[idx][BK + 2]: the 16-byte global load of 4 consecutive
 // k is stored with two 8-byte writes (instead of four transposing 4-byte writes) and a lane's MFMA operands for two
 // consecutive k-steps come from one 8-byte read; the row pitch BK + 2 keeps both conflict-free.
-template <int R, int LD, int BK, bool KC, bool IM = false>
+template <int R, int LD, int BK, bool KC, bool IM = false, int NT = 256>       // NT: threads of the workgroup
 struct TileStage {
     static constexpr int LDK = BK + 2;
     static constexpr int LDS_FLOATS = IM ? R * LDK : BK * LD;
     static constexpr int SLOTS = R * BK / 4;                 // float4 slots in a tile
     static constexpr int KQ = BK / 4;                        // float4 slots along k of one row
-    static constexpr int PER_THREAD = (SLOTS + 255) / 256;
+    static constexpr int PER_THREAD = (SLOTS + NT - 1) / NT;
     struct Regs { float4 v[PER_THREAD]; };                   // one K-tile in flight (the kernel keeps a ring of PF of them)
     unsigned base[PER_THREAD];   // loop-invariant byte offset of the slot (row part or idx part)
     int kloc[PER_THREAD];        // k of the slot inside a K-tile
@@ -85,7 +85,7 @@ struct TileStage {
                                             long delta = 0) {
 #pragma unroll
         for (int it = 0; it < PER_THREAD; ++it) {
-            const int s = threadIdx.x + it * 256;
+            const int s = threadIdx.x + it * NT;
             if (KC) {
                 const int idx = idx0 + s / KQ;
                 kloc[it] = (s % KQ) * 4;
@@ -140,7 +140,7 @@ struct TileStage {
     __device__ __forceinline__ void store(const Regs& r, float* __restrict__ T) const {
 #pragma unroll
         for (int it = 0; it < PER_THREAD; ++it) {
-            int s = threadIdx.x + it * 256;
+            int s = threadIdx.x + it * NT;
             if (s < SLOTS) {
                 if (IM) {
                     int idx = s / KQ, k = (s % KQ) * 4;
@@ -179,6 +179,7 @@ struct Shape {
     static constexpr int MT = MT_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, WM_T = WM_T_, WN_T = WN_T_, BK = BK_, PF = PF_;
     static constexpr bool KP = KP_;     // idx-major LDS image for k-contiguous operands (TileStage IM), 32x32x2 MFMA only
     static constexpr int BM = WAVES_M * WM_T * MT, BN = WAVES_N * WN_T * MT;
+    static constexpr int NT = 64 * WAVES_M * WAVES_N;      // threads of the workgroup
 };
 
 // blockIdx -> (m tile, n tile, z) such that the workgroups that run on one XCD (observed: linear block id % 8; a speed
@@ -204,8 +205,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     constexpr int LDA = (BM + 31) / 32 * 32, LDB = (BN + 31) / 32 * 32;
     constexpr int KSTEP = (MT == 16) ? 4 : 2;         // k per MFMA
     constexpr bool A_IM = S::KP && A_KC && MT == 32, B_IM = S::KP && B_KC && MT == 32;
-    typedef TileStage<BM, LDA, BK, A_KC, A_IM> StageA;
-    typedef TileStage<BN, LDB, BK, B_KC, B_IM> StageB;
+    typedef TileStage<BM, LDA, BK, A_KC, A_IM, S::NT> StageA;
+    typedef TileStage<BN, LDB, BK, B_KC, B_IM, S::NT> StageB;
     __shared__ __attribute__((aligned(16))) float As[2][StageA::LDS_FLOATS];
     __shared__ __attribute__((aligned(16))) float Bs[2][StageB::LDS_FLOATS];
 
@@ -384,7 +385,7 @@ gemm_f32_rowseg_kernel(GemmArgs g, SegTable segs) {
     int bx, by, bz;
     xcd_tile(bx, by, bz);
     const Seg sg = segs.s[bz];
-    for (int i = threadIdx.x; i < sg.k_end - sg.k_begin; i += 256) kidx[i] = g.k_rows[sg.k_begin + i];
+    for (int i = threadIdx.x; i < sg.k_end - sg.k_begin; i += S::NT) kidx[i] = g.k_rows[sg.k_begin + i];
     __syncthreads();
     if (g.slab != nullptr) {
         GemmArgs gl = g;
@@ -535,7 +536,7 @@ static void launch_slab_reduce(const SlabReduce& a, hipStream_t s) {
 //         2 weight gradient (both idx-contiguous), 3 (A idx-contiguous, B k-contiguous; not on the training path)
 template <class S>
 static void launch(const GemmArgs& g, int layout, int splits, bool vec, hipStream_t s) {
-    dim3 grid(cdiv(g.M, S::BM), cdiv(g.N, S::BN), splits), block(256);
+    dim3 grid(cdiv(g.M, S::BM), cdiv(g.N, S::BN), splits), block(S::NT);
 #define I3D_GEMM_LAUNCH(V, AK, BKC) hipLaunchKernelGGL((gemm_f32_kernel<S, V, AK, BKC>), grid, block, 0, s, g)
     switch (layout * 2 + (vec ? 1 : 0)) {
         case 0: I3D_GEMM_LAUNCH(false, true, true); break;
@@ -551,8 +552,8 @@ static void launch(const GemmArgs& g, int layout, int splits, bool vec, hipStrea
 template <class S>
 static void launch_rowseg(const GemmArgs& g, const SegTable& t, int n_segs, bool vec, hipStream_t s) {
     dim3 grid(cdiv(g.M, S::BM), cdiv(g.N, S::BN), n_segs);
-    if (vec) hipLaunchKernelGGL((gemm_f32_rowseg_kernel<S, true>), grid, dim3(256), 0, s, g, t);
-    else hipLaunchKernelGGL((gemm_f32_rowseg_kernel<S, false>), grid, dim3(256), 0, s, g, t);
+    if (vec) hipLaunchKernelGGL((gemm_f32_rowseg_kernel<S, true>), grid, dim3(S::NT), 0, s, g, t);
+    else hipLaunchKernelGGL((gemm_f32_rowseg_kernel<S, false>), grid, dim3(S::NT), 0, s, g, t);
 }
 
 // tile configurations; the numbering is part of the tuning entry i3d_gemm_f32_ex
@@ -560,6 +561,7 @@ static void launch_rowseg(const GemmArgs& g, const SegTable& t, int n_segs, bool
 //   4: 64x64x32 (32x32x2)    5: 128x64x16 (32x32x2)  6 / 7: as 2 with 1 / 2 K-tiles in flight instead of 4
 //   8: 32x32x32 (16x16x4): weight gradients of the narrow (hidden_dim 20) 3D network, K = number of edges
 //   9 / 10: as 2 / 0 with the idx-major LDS image (TileStage IM) for k-contiguous operands
+//   11: 64x32x16, two waves (32x32x2, idx-major image)   12: 32x32x16, one wave
 typedef Shape<32, 2, 2, 2, 2, 16, 2> Cfg0;
 typedef Shape<16, 4, 1, 4, 2, 16, 2> Cfg1;
 typedef Shape<32, 2, 2, 1, 1, 16, 4> Cfg2;
@@ -571,10 +573,12 @@ typedef Shape<32, 2, 2, 1, 1, 16, 2> Cfg7;
 typedef Shape<16, 2, 2, 1, 1, 32, 2> Cfg8;
 typedef Shape<32, 2, 2, 1, 1, 16, 4, true> Cfg9;       // as 2 with the idx-major LDS image for k-contiguous operands
 typedef Shape<32, 2, 2, 2, 2, 16, 2, true> Cfg10;      // as 0 with it
-constexpr int N_CFG = 11;
-static const int CFG_BM[N_CFG] = {Cfg0::BM, Cfg1::BM, Cfg2::BM, Cfg3::BM, Cfg4::BM, Cfg5::BM, Cfg6::BM, Cfg7::BM, Cfg8::BM, Cfg9::BM, Cfg10::BM};
-static const int CFG_BN[N_CFG] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN, Cfg9::BN, Cfg10::BN};
-static const int CFG_BK[N_CFG] = {Cfg0::BK, Cfg1::BK, Cfg2::BK, Cfg3::BK, Cfg4::BK, Cfg5::BK, Cfg6::BK, Cfg7::BK, Cfg8::BK, Cfg9::BK, Cfg10::BK};
+typedef Shape<32, 2, 1, 1, 1, 16, 4, true> Cfg11;      // 64x32 tile, two waves: N = 200 in 7 column tiles instead of 4 x 64
+typedef Shape<32, 1, 1, 1, 1, 16, 4, true> Cfg12;      // 32x32 tile, one wave
+constexpr int N_CFG = 13;
+static const int CFG_BM[N_CFG] = {Cfg0::BM, Cfg1::BM, Cfg2::BM, Cfg3::BM, Cfg4::BM, Cfg5::BM, Cfg6::BM, Cfg7::BM, Cfg8::BM, Cfg9::BM, Cfg10::BM, Cfg11::BM, Cfg12::BM};
+static const int CFG_BN[N_CFG] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN, Cfg9::BN, Cfg10::BN, Cfg11::BN, Cfg12::BN};
+static const int CFG_BK[N_CFG] = {Cfg0::BK, Cfg1::BK, Cfg2::BK, Cfg3::BK, Cfg4::BK, Cfg5::BK, Cfg6::BK, Cfg7::BK, Cfg8::BK, Cfg9::BK, Cfg10::BK, Cfg11::BK, Cfg12::BK};
 
 // the (A idx-contiguous, B k-contiguous) layout is computed as layout 2 would need B transposed: it only exists for
 // API completeness, through one configuration
@@ -669,6 +673,10 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     else cfg = 2;
     if (ex.tile_group != nullptr) cfg = 2;        // the group padding of m_rows is 64 rows
     if (cfg == 2 && (!trans_a || trans_b)) cfg = 9;   // a k-contiguous operand: idx-major LDS image (2-4 % faster, r01_gemm_bench_v5)
+    // N = 200 fills 6.25 of the 8 32-wide wave tiles of four 64-wide column tiles (a quarter of the waves do nothing
+    // useful); in 64x32 tiles of two waves it is 7 column tiles, 12 % padding: -18..-21 % on the long-K forward shapes
+    // (post4 [N,4F] x [F,4F]^T: 50 -> 41 us), slower when K is short (r01_gemm_bench_v6)
+    if (cfg == 9 && !trans_a && K >= 400 && (long)cdiv(N, 64) * 64 * 10 > (long)cdiv(N, 32) * 32 * 11) cfg = 11;
     if (force_cfg >= 0) {
         I3D_CHECK_ARG(force_cfg < N_CFG, "tile_cfg out of range");
         I3D_CHECK_ARG(ex.tile_group == nullptr || CFG_BM[force_cfg] == 64, "grouped GEMM needs 64-row tiles");
@@ -727,7 +735,9 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
         case 7: launch<Cfg7>(g, layout, splits, vec, s); break;
         case 8: launch<Cfg8>(g, layout, splits, vec, s); break;
         case 9: launch<Cfg9>(g, layout, splits, vec, s); break;
-        default: launch<Cfg10>(g, layout, splits, vec, s); break;
+        case 10: launch<Cfg10>(g, layout, splits, vec, s); break;
+        case 11: launch<Cfg11>(g, layout, splits, vec, s); break;
+        default: launch<Cfg12>(g, layout, splits, vec, s); break;
     }
     I3D_CHECK_LAUNCH();
     if (use_slab) {
