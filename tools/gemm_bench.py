@@ -25,6 +25,8 @@ SHAPES = [  # name, ta, tb, M, N, K
     ('wgrad  dY^T[F,E] X[E,F]  ', 1, 0, F, F, N_EDGES),
     ('wgrad  dY^T[F,N] agg     ', 1, 0, F, 12 * F, N_NODES),
     ('post4  agg[N,4F] W^T     ', 0, 1, N_NODES, F, 4 * F),
+    ('P2     X[N,F] [Ws|Wd]^T  ', 0, 1, N_NODES, 2 * F, F),
+    ('dP     dP[N,2F] [Ws;Wd]  ', 0, 0, N_NODES, F, 2 * F),
     ('dgrad4 dY[N,F] W[F,4F]   ', 0, 0, N_NODES, 4 * F, F),
     ('net3d  d[E3,20] W^T      ', 0, 1, 140000, 20, 20),
     ('net3d  wgrad [20,20]     ', 1, 0, 20, 20, 140000),
@@ -115,7 +117,7 @@ if __name__ == '__main__':
             print(f'{name} M={M:6d} N={N:5d} K={K:6d}  auto, fp32 atomics instead of scratch: {us:8.1f} us {tf:7.1f} TF', flush=True)
         if a.all_cfgs:
             wgrad = bool(ta)
-            for cfg in ((3, 2, 8, 1) if wgrad else (9, 11, 12)):
+            for cfg in ((3, 2, 8, 1) if wgrad else (2, 9, 11)):
                 for splits in ((8, 16, 32, 64, 128, 256) if wgrad else (1,)):
                     us, tf, err = run(lib, ta, tb, M, N, K, cfg, splits)
                     print(f'      cfg {cfg:2d} splits {splits:2d}: {us:8.1f} us {tf:7.1f} TF  err {err:.1e}', flush=True)
