@@ -138,21 +138,10 @@ static int edge_fc_bn_bwd(const I3dEdgeFcArgs* a, void* stream, Aux* x, bool joi
     const int Fh = a->f_h, Fo = a->f_out, N = a->num_nodes, E = a->num_edges;
     TRY(tail_bwd(&a->tail, E, Fo, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre, a->grad_bias,
                  stream));
-    // d P[src] (out-edges through the source index), d P[dst] (in-edges are contiguous): segmented sums, no atomics
-    TRY(i3d_segment_sum(a->grad_pre, Fo, a->out_ptr, a->out_epos, N, Fo, 0, a->grad_P, 2 * Fo, stream));
-    TRY(i3d_segment_sum(a->grad_pre, Fo, a->in_ptr, nullptr, N, Fo, 0, a->grad_P + Fo, 2 * Fo, stream));
-    // every column block of dW is written exactly once: no zero-fill (the split-K slices go through the scratch)
     void* ws = a->tail.gemm_workspace;
     const long wsb = a->tail.gemm_workspace_bytes;
-    const long wdelta = (long)Fh - (long)Fo * a->ldw, wview = (long)(Fo - 1) * a->ldw + 2 * Fh;
-    // d[W_s | W_d] = dP^T h (rows >= Fo of the [2Fo, Fh] result land in the second column block), dh = dP [W_s; W_d]
-    // the weight gradients (and, in table mode, everything behind dQ: only the caller reads grad_q) go to the side stream;
-    // the caller's stream continues with dh, the input of the next block's backward
+    // everything behind dQ needs grad_pre only: it starts on the side stream while the caller's stream sums dP
     void* wst = fork_wgrad(x, stream);
-    TRY(i3d_gemm_f32_blocks(1, 0, 2 * Fo, Fh, N, a->grad_P, 2 * Fo, a->h, Fh, 0, 0, 0, a->grad_W, a->ldw, Fo, wdelta, 0, ws, wsb,
-                            wst));
-    TRY(i3d_gemm_f32_blocks(0, 0, N, Fh, 2 * Fo, a->grad_P, 2 * Fo, a->W, a->ldw, Fo, wdelta, wview, a->grad_h, Fh, 0, 0, 0,
-                            nullptr, 0, stream));
     if (a->q != nullptr && a->q_rows > 0) {
         // table mode: dQ[v] = sum of dpre over the edges of category v (one-hot^T dpre), then two [V, .] products
         const int V = a->q_rows;
@@ -165,6 +154,18 @@ static int edge_fc_bn_bwd(const I3dEdgeFcArgs* a, void* stream, Aux* x, bool joi
         if (a->grad_q != nullptr)
             TRY(i3d_gemm_f32(0, 0, E, a->f_q, Fo, a->grad_pre, Fo, a->W + 2 * Fh, a->ldw, a->grad_q, a->f_q, nullptr, 0, stream));
     }
+    // d P[src] (out-edges through the source index), d P[dst] (in-edges are contiguous): segmented sums, no atomics
+    TRY(i3d_segment_sum(a->grad_pre, Fo, a->out_ptr, a->out_epos, N, Fo, 0, a->grad_P, 2 * Fo, stream));
+    TRY(i3d_segment_sum(a->grad_pre, Fo, a->in_ptr, nullptr, N, Fo, 0, a->grad_P + Fo, 2 * Fo, stream));
+    // every column block of dW is written exactly once: no zero-fill (the split-K slices go through the scratch)
+    const long wdelta = (long)Fh - (long)Fo * a->ldw, wview = (long)(Fo - 1) * a->ldw + 2 * Fh;
+    // d[W_s | W_d] = dP^T h (rows >= Fo of the [2Fo, Fh] result land in the second column block) on the side stream once
+    // dP is there; dh = dP [W_s; W_d], the input of the next block's backward, on the caller's stream
+    wst = fork_wgrad(x, stream);
+    TRY(i3d_gemm_f32_blocks(1, 0, 2 * Fo, Fh, N, a->grad_P, 2 * Fo, a->h, Fh, 0, 0, 0, a->grad_W, a->ldw, Fo, wdelta, 0, ws, wsb,
+                            wst));
+    TRY(i3d_gemm_f32_blocks(0, 0, N, Fh, 2 * Fo, a->grad_P, 2 * Fo, a->W, a->ldw, Fo, wdelta, wview, a->grad_h, Fh, 0, 0, 0,
+                            nullptr, 0, stream));
     return join ? join_wgrad(x, stream) : I3D_OK;
 }
 
