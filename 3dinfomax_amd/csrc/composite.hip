@@ -19,12 +19,14 @@ using namespace i3d;
 // ---- weight gradients next to the data-gradient chain ---------------------------------------------------------------
 // The backward pass of a block is a chain (BatchNorm backward -> data gradient -> next block) of small kernels that each
 // occupy a fraction of the chip, plus weight-gradient GEMMs (dW = dY^T X and their split-K reductions, ~20 % of the step's
-// kernel time) that nothing downstream in the chain reads.  The composites enqueue those on a second HIP stream of their
-// own (one per caller stream, created on first use): fork = an event recorded on the caller's stream that the side stream
-// waits for, join = the caller's stream waits for the side stream before the composite (for a PNA layer: the whole layer)
-// returns, so every tensor the caller sees afterwards is complete and the caching allocator's stream-ordered reuse stays
-// valid.  All weight gradients of one caller stream share that stream's split-K scratch: they are serialised on the one
-// side stream.  Same kernels, same arguments, same order per stream: results are bit-identical.  I3D_WGRAD_STREAM=0: off.
+// kernel time) that nothing downstream in the chain reads.  The PNA layer composite enqueues those on a second HIP stream
+// of its own (one per caller stream, created on first use): fork = an event recorded on the caller's stream that the side
+// stream waits for, join = the caller's stream waits for the side stream before the layer returns, so every tensor the
+// caller sees afterwards is complete and the caching allocator's stream-ordered reuse stays valid.  All weight gradients
+// of one caller stream share that stream's split-K scratch: they are serialised on the one side stream.  Same kernels,
+// same arguments, same order per stream: results are bit-identical.  A fork or join costs the host ~7 us
+// (tools/probes/forkjoin_probe.hip), so a layer forks twice and joins once, and the stand-alone block entry points (heads,
+// the 3D network - whose stream has slack anyway) stay on one stream.  I3D_WGRAD_STREAM=0: off.
 #include <map>
 #include <mutex>
 #include <utility>
@@ -99,21 +101,28 @@ extern "C" int i3d_fc_bn_fwd(const I3dFcArgs* a, void* stream) {
     return tail_fwd(&a->tail, a->rows, a->f_out, lin, a->xact, a->residual, a->y, stream);
 }
 
-// `x`: side stream of the caller's stream (may be null); `join`: wait for it before returning (a PNA layer joins once)
-static int fc_bn_bwd(const I3dFcArgs* a, void* stream, Aux* x, bool join) {
+// The backward of a block in two parts: the chain (BatchNorm backward, data gradient: what the next block's backward
+// waits for) on `stream`, and the weight gradients, which only need the block's grad_pre, on `wst` - the same stream for
+// the stand-alone entry points, the side stream for a PNA layer (which issues the weight gradients of several blocks behind
+// ONE fork: a fork or join costs the host ~7 us, tools/probes/forkjoin_probe.hip).
+static int fc_bn_bwd_chain(const I3dFcArgs* a, void* stream) {
     TRY(tail_bwd(&a->tail, a->rows, a->f_out, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre,
                  a->grad_bias, stream));
-    void* ws_ = fork_wgrad(x, stream);
-    TRY(i3d_gemm_f32_ws(1, 0, a->f_out, a->f_in, a->rows, a->grad_pre, a->f_out, a->x, a->f_in, a->grad_W, a->ldw, nullptr, 0, a->tail.gemm_workspace, a->tail.gemm_workspace_bytes, ws_));
     if (a->grad_x != nullptr)
         TRY(i3d_gemm_f32(0, 0, a->rows, a->f_in, a->f_out, a->grad_pre, a->f_out, a->W, a->ldw, a->grad_x, a->f_in, nullptr,
                          0, stream));
-    return join ? join_wgrad(x, stream) : I3D_OK;
+    return I3D_OK;
+}
+
+static int fc_bn_bwd_wgrad(const I3dFcArgs* a, void* wst) {
+    return i3d_gemm_f32_ws(1, 0, a->f_out, a->f_in, a->rows, a->grad_pre, a->f_out, a->x, a->f_in, a->grad_W, a->ldw, nullptr, 0,
+                           a->tail.gemm_workspace, a->tail.gemm_workspace_bytes, wst);
 }
 
 extern "C" int i3d_fc_bn_bwd(const I3dFcArgs* a, void* stream) {
     I3D_CHECK_ARG(a != nullptr && a->rows > 0, "bad arguments");
-    return fc_bn_bwd(a, stream, aux_for((hipStream_t)stream), true);
+    TRY(fc_bn_bwd_chain(a, stream));
+    return fc_bn_bwd_wgrad(a, stream);
 }
 
 // ---- edge FC: [h_src | h_dst | q] -> Linear as node-level P + gather-combine -------------------------
@@ -134,14 +143,33 @@ extern "C" int i3d_edge_fc_bn_fwd(const I3dEdgeFcArgs* a, void* stream) {
     return tail_fwd(&a->tail, a->num_edges, Fo, lin, a->xact, nullptr, a->y, stream);
 }
 
-static int edge_fc_bn_bwd(const I3dEdgeFcArgs* a, void* stream, Aux* x, bool join) {
+static int edge_fc_bn_bwd_chain(const I3dEdgeFcArgs* a, void* stream) {
     const int Fh = a->f_h, Fo = a->f_out, N = a->num_nodes, E = a->num_edges;
     TRY(tail_bwd(&a->tail, E, Fo, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre, a->grad_bias,
                  stream));
+    // d P[src] (out-edges through the source index), d P[dst] (in-edges are contiguous): segmented sums, no atomics
+    TRY(i3d_segment_sum(a->grad_pre, Fo, a->out_ptr, a->out_epos, N, Fo, 0, a->grad_P, 2 * Fo, stream));
+    return i3d_segment_sum(a->grad_pre, Fo, a->in_ptr, nullptr, N, Fo, 0, a->grad_P + Fo, 2 * Fo, stream);
+}
+
+// dh = dP [W_s; W_d], the input of the next block's backward
+static int edge_fc_bn_bwd_dgrad(const I3dEdgeFcArgs* a, void* stream) {
+    const int Fh = a->f_h, Fo = a->f_out, N = a->num_nodes;
+    const long wdelta = (long)Fh - (long)Fo * a->ldw, wview = (long)(Fo - 1) * a->ldw + 2 * Fh;
+    return i3d_gemm_f32_blocks(0, 0, N, Fh, 2 * Fo, a->grad_P, 2 * Fo, a->W, a->ldw, Fo, wdelta, wview, a->grad_h, Fh, 0, 0, 0,
+                               nullptr, 0, stream);
+}
+
+// weight gradients (and, in table mode, everything behind dQ: only the caller reads grad_q, after the join)
+static int edge_fc_bn_bwd_wgrad(const I3dEdgeFcArgs* a, void* wst) {
+    const int Fh = a->f_h, Fo = a->f_out, N = a->num_nodes, E = a->num_edges;
     void* ws = a->tail.gemm_workspace;
     const long wsb = a->tail.gemm_workspace_bytes;
-    // everything behind dQ needs grad_pre only: it starts on the side stream while the caller's stream sums dP
-    void* wst = fork_wgrad(x, stream);
+    const long wdelta = (long)Fh - (long)Fo * a->ldw;
+    // every column block of dW is written exactly once: no zero-fill (the split-K slices go through the scratch)
+    // d[W_s | W_d] = dP^T h (rows >= Fo of the [2Fo, Fh] result land in the second column block)
+    TRY(i3d_gemm_f32_blocks(1, 0, 2 * Fo, Fh, N, a->grad_P, 2 * Fo, a->h, Fh, 0, 0, 0, a->grad_W, a->ldw, Fo, wdelta, 0, ws, wsb,
+                            wst));
     if (a->q != nullptr && a->q_rows > 0) {
         // table mode: dQ[v] = sum of dpre over the edges of category v (one-hot^T dpre), then two [V, .] products
         const int V = a->q_rows;
@@ -152,26 +180,16 @@ static int edge_fc_bn_bwd(const I3dEdgeFcArgs* a, void* stream, Aux* x, bool joi
     } else if (a->q != nullptr) {
         TRY(i3d_gemm_f32_ws(1, 0, Fo, a->f_q, E, a->grad_pre, Fo, a->q, a->f_q, a->grad_W + 2 * Fh, a->ldw, nullptr, 0, ws, wsb, wst));
         if (a->grad_q != nullptr)
-            TRY(i3d_gemm_f32(0, 0, E, a->f_q, Fo, a->grad_pre, Fo, a->W + 2 * Fh, a->ldw, a->grad_q, a->f_q, nullptr, 0, stream));
+            TRY(i3d_gemm_f32(0, 0, E, a->f_q, Fo, a->grad_pre, Fo, a->W + 2 * Fh, a->ldw, a->grad_q, a->f_q, nullptr, 0, wst));
     }
-    // d P[src] (out-edges through the source index), d P[dst] (in-edges are contiguous): segmented sums, no atomics
-    TRY(i3d_segment_sum(a->grad_pre, Fo, a->out_ptr, a->out_epos, N, Fo, 0, a->grad_P, 2 * Fo, stream));
-    TRY(i3d_segment_sum(a->grad_pre, Fo, a->in_ptr, nullptr, N, Fo, 0, a->grad_P + Fo, 2 * Fo, stream));
-    // every column block of dW is written exactly once: no zero-fill (the split-K slices go through the scratch)
-    const long wdelta = (long)Fh - (long)Fo * a->ldw, wview = (long)(Fo - 1) * a->ldw + 2 * Fh;
-    // d[W_s | W_d] = dP^T h (rows >= Fo of the [2Fo, Fh] result land in the second column block) on the side stream once
-    // dP is there; dh = dP [W_s; W_d], the input of the next block's backward, on the caller's stream
-    wst = fork_wgrad(x, stream);
-    TRY(i3d_gemm_f32_blocks(1, 0, 2 * Fo, Fh, N, a->grad_P, 2 * Fo, a->h, Fh, 0, 0, 0, a->grad_W, a->ldw, Fo, wdelta, 0, ws, wsb,
-                            wst));
-    TRY(i3d_gemm_f32_blocks(0, 0, N, Fh, 2 * Fo, a->grad_P, 2 * Fo, a->W, a->ldw, Fo, wdelta, wview, a->grad_h, Fh, 0, 0, 0,
-                            nullptr, 0, stream));
-    return join ? join_wgrad(x, stream) : I3D_OK;
+    return I3D_OK;
 }
 
 extern "C" int i3d_edge_fc_bn_bwd(const I3dEdgeFcArgs* a, void* stream) {
     I3D_CHECK_ARG(a != nullptr && a->num_edges > 0 && a->num_nodes > 0, "bad arguments");
-    return edge_fc_bn_bwd(a, stream, aux_for((hipStream_t)stream), true);
+    TRY(edge_fc_bn_bwd_chain(a, stream));
+    TRY(edge_fc_bn_bwd_wgrad(a, stream));
+    return edge_fc_bn_bwd_dgrad(a, stream);
 }
 
 // ---- degree-grouped concat FC: [h | scaler blocks of a] -> Linear with per-degree combined weights -----------
@@ -186,26 +204,30 @@ extern "C" int i3d_grouped_fc_bn_fwd(const I3dGroupedFcArgs* a, void* stream) {
     return tail_fwd(&a->tail, N, Fo, lin, a->xact, a->residual, a->y, stream);
 }
 
-static int grouped_fc_bn_bwd(const I3dGroupedFcArgs* a, void* stream, Aux* x, bool join) {
+static int grouped_fc_bn_bwd_chain(const I3dGroupedFcArgs* a, void* stream) {
     const int Fh = a->f_h, Fo = a->f_out, A = a->agg_width, N = a->num_nodes;
     TRY(tail_bwd(&a->tail, N, Fo, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre, a->grad_bias,
                  stream));
-    void* wst = fork_wgrad(x, stream);
-    TRY(i3d_gemm_f32_ws(1, 0, Fo, Fh, N, a->grad_pre, Fo, a->h, Fh, a->grad_W, a->ldw, nullptr, 0, a->tail.gemm_workspace, a->tail.gemm_workspace_bytes, wst));
+    TRY(i3d_gemm_f32(0, 0, N, Fh, Fo, a->grad_pre, Fo, a->W, a->ldw, a->grad_h, Fh, nullptr, 0, stream));
+    return i3d_gemm_f32_grouped(0, a->m_padded, A, Fo, a->grad_pre, Fo, N, a->deg_rows, a->deg_tile_group, a->WD, A,
+                                (long)Fo * A, a->grad_agg, A, 0, stream);
+}
+
+static int grouped_fc_bn_bwd_wgrad(const I3dGroupedFcArgs* a, void* wst) {
+    const int Fh = a->f_h, Fo = a->f_out, A = a->agg_width, N = a->num_nodes;
+    TRY(i3d_gemm_f32_ws(1, 0, Fo, Fh, N, a->grad_pre, Fo, a->h, Fh, a->grad_W, a->ldw, nullptr, 0, a->tail.gemm_workspace,
+                        a->tail.gemm_workspace_bytes, wst));
     // dW_D = dY_D^T a_D over the rows of each in-degree group, all groups in one launch
     TRY(i3d_gemm_f32_rowsubset_multi(Fo, A, a->n_groups, a->group_start, a->group_count, a->grad_pre, Fo, a->agg, A,
                                      a->deg_rows, N, a->grad_WD, (long)Fo * A, A, 0, -1, 0, a->tail.gemm_workspace,
                                      a->tail.gemm_workspace_bytes, wst));
-    TRY(i3d_pna_combine_weights_bwd(a->grad_WD, a->ldw, Fh, Fo, A, a->n_groups, a->n_scalers, a->coef, a->grad_W, wst));
-    TRY(i3d_gemm_f32(0, 0, N, Fh, Fo, a->grad_pre, Fo, a->W, a->ldw, a->grad_h, Fh, nullptr, 0, stream));
-    TRY(i3d_gemm_f32_grouped(0, a->m_padded, A, Fo, a->grad_pre, Fo, N, a->deg_rows, a->deg_tile_group, a->WD, A,
-                             (long)Fo * A, a->grad_agg, A, 0, stream));
-    return join ? join_wgrad(x, stream) : I3D_OK;
+    return i3d_pna_combine_weights_bwd(a->grad_WD, a->ldw, Fh, Fo, A, a->n_groups, a->n_scalers, a->coef, a->grad_W, wst);
 }
 
 extern "C" int i3d_grouped_fc_bn_bwd(const I3dGroupedFcArgs* a, void* stream) {
     I3D_CHECK_ARG(a != nullptr && a->num_nodes > 0 && a->n_groups > 0, "bad arguments");
-    return grouped_fc_bn_bwd(a, stream, aux_for((hipStream_t)stream), true);
+    TRY(grouped_fc_bn_bwd_chain(a, stream));
+    return grouped_fc_bn_bwd_wgrad(a, stream);
 }
 
 // ---- one PNA layer ---------------------------------------------------------------------------------------
@@ -226,13 +248,25 @@ extern "C" int i3d_pna_layer_fwd(const I3dPnaLayerArgs* a, void* stream) {
 extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     I3D_CHECK_ARG(a != nullptr && a->n_pre_extra >= 0 && a->n_pre_extra <= I3D_MAX_EXTRA_FC && a->n_post_extra >= 0 &&
                       a->n_post_extra <= I3D_MAX_EXTRA_FC, "bad arguments");
-    Aux* x = aux_for((hipStream_t)stream);     // the weight gradients of all blocks of the layer; joined once, at the end
-    for (int i = a->n_post_extra - 1; i >= 0; --i) TRY(fc_bn_bwd(&a->postx[i], stream, x, false));
-    TRY(grouped_fc_bn_bwd(&a->post, stream, x, false));
+    // The chain on the caller's stream; the weight gradients on the side stream behind TWO forks: one right after the
+    // posttrans blocks' chain part (their weight gradients are the largest, and the aggregation backward and the pretrans
+    // chain run next to them), one when the edge block's dP exists (the later pretrans blocks' and the edge block's).
+    // Measured: a single early fork per block (4 per layer) costs the host 0.07 ms more per step, forking everything late
+    // (after the pretrans chain) costs the GPU 2 %.  One join, at the end.
+    Aux* x = aux_for((hipStream_t)stream);
+    for (int i = a->n_post_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_chain(&a->postx[i], stream));
+    TRY(grouped_fc_bn_bwd_chain(&a->post, stream));
+    void* wst = fork_wgrad(x, stream);
+    TRY(grouped_fc_bn_bwd_wgrad(&a->post, wst));
+    for (int i = a->n_post_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_wgrad(&a->postx[i], wst));
     TRY(i3d_pna_aggregate_bwd(a->post.grad_agg, a->msg, a->edge.in_ptr, a->edge.num_nodes, a->edge.f_out, a->aggregators,
                               a->n_aggregators, a->scalers, a->n_scalers, a->force_scalers, a->avg_d_log, a->grad_msg, stream));
-    for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd(&a->pre[i], stream, x, false));
-    TRY(edge_fc_bn_bwd(&a->edge, stream, x, false));
+    for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_chain(&a->pre[i], stream));
+    TRY(edge_fc_bn_bwd_chain(&a->edge, stream));
+    wst = fork_wgrad(x, stream);
+    for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_wgrad(&a->pre[i], wst));
+    TRY(edge_fc_bn_bwd_wgrad(&a->edge, wst));
+    TRY(edge_fc_bn_bwd_dgrad(&a->edge, stream));
     const long n = (long)a->edge.num_nodes * a->edge.f_h;
     TRY(i3d_add_inplace(a->post.grad_h, a->edge.grad_h, n, stream));
     if (a->residual) TRY(i3d_add_inplace(a->post.grad_h, a->grad_out, n, stream));
