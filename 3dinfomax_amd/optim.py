@@ -19,6 +19,7 @@ class Adam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kwargs)
         self._lists = None
         self._steps_flat = None
+        self._merged = None
 
     @staticmethod
     def _all_cuda(params):
@@ -72,6 +73,7 @@ class Adam(torch.optim.Adam):
         if self._lists is None or len(self._lists) != len(self.param_groups):
             out = super().step()              # torch initialises the state on its first call
             self._lists = self._build_lists()
+            self._merged = None
             return out
         work = []
         for group, lst in zip(self.param_groups, self._lists):
@@ -91,6 +93,20 @@ class Adam(torch.optim.Adam):
             work.append((group, lst, grads))
         if self._steps_flat is not None:
             self._steps_flat.add_(1)
+        if len(work) > 1 and self._steps_flat is not None:
+            # groups with identical hyper-parameters (the reference's BatchNorm / other split with weight_decay 0 in both,
+            # trainer/self_supervised_trainer.py:78-86) are ONE multi-tensor launch: same arithmetic per tensor
+            g0 = work[0][0]
+            key = (g0['lr'], g0['betas'], g0['weight_decay'], g0['eps'])
+            if all((g['lr'], g['betas'], g['weight_decay'], g['eps']) == key for g, _, _ in work[1:]):
+                merged = self._merged
+                if merged is None:
+                    merged = self._merged = tuple([t for _, lst, _ in work for t in lst[i]] for i in range(4))
+                grads = [t for _, _, gr in work for t in gr]
+                torch._fused_adam_(merged[0], grads, merged[1], merged[2], [], merged[3], amsgrad=False, lr=key[0],
+                                   beta1=key[1][0], beta2=key[1][1], weight_decay=key[2], eps=key[3], maximize=False,
+                                   grad_scale=None, found_inf=None)
+                return None
         for group, (ps, exp_avgs, exp_avg_sqs, steps), grads in work:
             beta1, beta2 = group['betas']
             if self._steps_flat is None:
@@ -103,7 +119,9 @@ class Adam(torch.optim.Adam):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._lists = None
+        self._merged = None
 
     def add_param_group(self, param_group):
         super().add_param_group(param_group)
         self._lists = None
+        self._merged = None

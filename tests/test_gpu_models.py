@@ -429,16 +429,18 @@ def _training_step_is_bit_deterministic(amd):
         assert torch.equal(a, b)
 
 
-def test_adam_fast_path_is_torch_adam(amd):
+@pytest.mark.parametrize('second_group_wd', [1e-3, 0])
+def test_adam_fast_path_is_torch_adam(amd, second_group_wd):
     """infomax3d_amd.Adam (cached tensor lists in front of torch._fused_adam_) against torch.optim.Adam(fused=True):
-    bit-identical parameters and state over several steps, a changing lr, and a state_dict round trip."""
+    bit-identical parameters and state over several steps, a changing lr, and a state_dict round trip; with two groups
+    of different and of identical hyper-parameters (the latter are merged into one multi-tensor launch)."""
     torch.manual_seed(0)
     shapes = [(200, 600), (200,), (7, 3), (1,), (64, 64)]
     pa = [torch.randn(s, device='cuda:0').requires_grad_() for s in shapes]
     pb = [p.detach().clone().requires_grad_() for p in pa]
 
     def groups(ps):
-        return [{'params': ps[:2], 'weight_decay': 0}, {'params': ps[2:], 'weight_decay': 1e-3}]
+        return [{'params': ps[:2], 'weight_decay': 0}, {'params': ps[2:], 'weight_decay': second_group_wd}]
     oa, ob = amd.Adam(groups(pa), lr=8e-5, fused=True), torch.optim.Adam(groups(pb), lr=8e-5, fused=True)
     for it in range(6):
         if it == 3:
