@@ -436,3 +436,29 @@ def test_ntxent_row_sharded_equals_full():
     total.backward()
     assert abs(total.item() - full.item()) < 1e-6 * abs(full.item())
     assert rel_err(s1.grad.cpu(), full1.grad.cpu()) < 1e-5 and rel_err(s2.grad.cpu(), full2.grad.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize('cfg', list(range(13)))
+def test_every_tile_configuration_on_awkward_shapes(cfg):
+    """i3d_gemm_f32_ex with a forced tile configuration (workgroups of 1, 2 and 4 waves, 16- and 32-wide MFMA tiles, both
+    LDS images) on shapes that are not multiples of anything, all four operand layouts, with bias and accumulate."""
+    from ctypes import c_void_p
+    L = importlib.import_module('3dinfomax_amd._lib')
+    lib = L.load()
+    st = c_void_p(torch.cuda.current_stream().cuda_stream)
+    ws = torch.empty(16 << 20, dtype=torch.uint8, device=DEV)
+    for (M, N, K) in ((131, 77, 53), (64, 200, 800), (1000, 33, 20), (37, 37, 1300)):
+        for ta in (0, 1):
+            for tb in (0, 1):
+                A = rnd(K, M, seed=1) if ta else rnd(M, K, seed=1)
+                B = rnd(N, K, seed=2) if tb else rnd(K, N, seed=2)
+                bias = rnd(1, N, seed=3).reshape(N)
+                C0 = rnd(M, N, seed=4)
+                Ag, Bg, bg, C = g(A), g(B), g(bias), g(C0)
+                splits = 3 if (ta and K > 1000) else 1
+                rc = lib.i3d_gemm_f32_ex(ta, tb, M, N, K, c_void_p(Ag.data_ptr()), Ag.shape[1], c_void_p(Bg.data_ptr()), Bg.shape[1],
+                                         c_void_p(C.data_ptr()), N, c_void_p(bg.data_ptr()), 1, cfg, splits,
+                                         c_void_p(ws.data_ptr()), 16 << 20, st)
+                assert rc == 0, (cfg, M, N, K, ta, tb, lib.i3d_last_error())
+                ref = C0.double() + (A.double().T if ta else A.double()) @ (B.double().T if tb else B.double()) + bias.double()
+                assert rel_err(C.cpu(), ref) < 2e-5, (cfg, M, N, K, ta, tb)
