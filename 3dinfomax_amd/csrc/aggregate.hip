@@ -442,7 +442,8 @@ extern "C" int i3d_pna_aggregate_fwd(const float* e, const int* in_ptr, int num_
         if (is_std_cfg(cfg))
             hipLaunchKernelGGL(pna_aggregate_fwd_kernel<1>, grid, dim3(256), 0, s, (const float4*)e, in_ptr,
                                num_nodes, FV, cfg, (float4*)out);
-        else if (is_ident_cfg(cfg))      // (two items per lane were tried: 9.4 us vs 8.7 us back to back - not better)
+        else if (is_ident_cfg(cfg))      // (tried, not better back to back at batch 512: two items per lane 9.4 us vs 8.7 us;
+            //                              one wavefront per node with scalar row-pointer loads 8.8 us vs 8.8 us)
             hipLaunchKernelGGL(pna_aggregate_fwd_kernel<2>, grid, dim3(256), 0, s, (const float4*)e, in_ptr,
                                num_nodes, FV, cfg, (float4*)out);
         else
