@@ -72,6 +72,11 @@ class FlatMolDataset:
 
     def assemble_2d(self, ids, device, pin=False):
         """The bond-graph half (pure numpy + three H2D copies; also usable on the CPU for tests)."""
+        return host_batch_to_device(self.assemble_host(ids), device, pin)
+
+    def assemble_host(self, ids):
+        """The host half of a batch: a dict of CPU tensors and plain ints, picklable - what a DataLoader worker process
+        hands to the training process (BatchStream)."""
         ids = np.asarray(ids, dtype=np.int64)
         n, e = self.n_atoms[ids], self.n_edges[ids]
         B, N, E = ids.shape[0], int(n.sum()), int(e.sum())
@@ -86,40 +91,74 @@ class FlatMolDataset:
         perm = self.perm[egi] + e_edge_off
         i32 = np.empty(2 * (N + 1) + 5 * E + (B + 1), dtype=np.int32)
         o = 0
+        cuts = []
 
         def put(a):
             nonlocal o
             i32[o:o + a.shape[0]] = a
-            sl = slice(o, o + a.shape[0])
+            cuts.append((o, o + a.shape[0]))
             o += a.shape[0]
-            return sl
         in_ptr = np.zeros(N + 1, dtype=np.int64)
         np.cumsum(self.indeg[ngi], out=in_ptr[1:])
         out_ptr = np.zeros(N + 1, dtype=np.int64)
         np.cumsum(self.outdeg[ngi], out=out_ptr[1:])
         graph_ptr = np.zeros(B + 1, dtype=np.int64)
         np.cumsum(n, out=graph_ptr[1:])
-        s_in, s_perm, s_src, s_dst = put(in_ptr), put(perm), put(src[perm]), put(dst[perm])
-        s_out, s_oe, s_gp = put(out_ptr), put(self.out_epos[egi] + e_edge_off), put(graph_ptr)
-        s_inv = put(self.inv_perm[egi] + e_edge_off)
+        for a in (in_ptr, perm, src[perm], dst[perm], out_ptr, self.out_epos[egi] + e_edge_off, graph_ptr,
+                  self.inv_perm[egi] + e_edge_off):
+            put(a)                                         # s_in, s_perm, s_src, s_dst, s_out, s_oe, s_gp, s_inv
         i64 = np.concatenate([src, dst, self.atom_feat[ngi].ravel(), self.bond_feat[egi].ravel()])
-        f32 = self.coords[ngi]
-        ti32, ti64, tf32 = torch.from_numpy(i32), torch.from_numpy(i64), torch.from_numpy(f32)
-        if pin:
-            ti32, ti64, tf32 = ti32.pin_memory(), ti64.pin_memory(), tf32.pin_memory()
-        d32 = ti32.to(device, non_blocking=True)
-        d64 = ti64.to(device, non_blocking=True)
-        xyz = tf32.to(device, non_blocking=True)
-        bnn = torch.from_numpy(n)
-        rows, tiles, groups = group_nodes_by_degree(self.indeg[ngi])
-        idx2 = GraphIndex(N, E, B, d32[s_in], d32[s_perm], d32[s_src], d32[s_dst], d32[s_out], d32[s_oe], d32[s_gp],
-                          d32[s_inv], int(self.indeg[ngi].max()) if E else 0,
-                          torch.from_numpy(rows).to(device, non_blocking=True),
-                          torch.from_numpy(tiles).to(device, non_blocking=True), groups)
-        g2 = BatchedMolGraph(d64[:E], d64[E:2 * E], N, bnn,
-                             ndata={'feat': d64[2 * E:2 * E + 9 * N].view(N, 9)},
-                             edata={'feat': d64[2 * E + 9 * N:].view(E, 3)}, index=idx2)
-        return g2, xyz, d32[s_gp], n, bnn
+        indeg = self.indeg[ngi]
+        rows, tiles, groups = group_nodes_by_degree(indeg)
+        return {'i32': torch.from_numpy(i32), 'i64': torch.from_numpy(i64), 'f32': torch.from_numpy(self.coords[ngi]),
+                'n': torch.from_numpy(n), 'rows': torch.from_numpy(rows), 'tiles': torch.from_numpy(tiles),
+                'groups': groups, 'cuts': cuts, 'dims': (B, N, E), 'max_indeg': int(indeg.max()) if E else 0}
+
+
+def host_batch_to_device(hb, device, pin=False):
+    """H2D copies of a host batch (FlatMolDataset.assemble_host) and the bond graph on `device`
+    -> (g2d, xyz, graph_ptr on device, atoms per molecule (numpy), the same as a tensor)."""
+    B, N, E = (int(v) for v in hb['dims'])      # (a DataLoader's default conversion turns tuples into lists)
+    ti32, ti64, tf32 = hb['i32'], hb['i64'], hb['f32']
+    if pin:
+        ti32, ti64, tf32 = ti32.pin_memory(), ti64.pin_memory(), tf32.pin_memory()
+    d32 = ti32.to(device, non_blocking=True)
+    d64 = ti64.to(device, non_blocking=True)
+    xyz = tf32.to(device, non_blocking=True)
+    bnn = hb['n']
+    s_in, s_perm, s_src, s_dst, s_out, s_oe, s_gp, s_inv = (slice(a, b) for a, b in hb['cuts'])
+    idx2 = GraphIndex(N, E, B, d32[s_in], d32[s_perm], d32[s_src], d32[s_dst], d32[s_out], d32[s_oe], d32[s_gp],
+                      d32[s_inv], int(hb['max_indeg']), hb['rows'].to(device, non_blocking=True),
+                      hb['tiles'].to(device, non_blocking=True), tuple(tuple(int(v) for v in gr) for gr in hb['groups']))
+    g2 = BatchedMolGraph(d64[:E], d64[E:2 * E], N, bnn,
+                         ndata={'feat': d64[2 * E:2 * E + 9 * N].view(N, 9)},
+                         edata={'feat': d64[2 * E + 9 * N:].view(E, 3)}, index=idx2)
+    return g2, xyz, d32[s_gp], bnn.numpy(), bnn
+
+
+class BatchStream(torch.utils.data.Dataset):
+    """Shuffled batches of a FlatMolDataset as host batches, for `torch.utils.data.DataLoader(stream, batch_size=None,
+    num_workers=k, pin_memory=True)`: the numpy assembly runs in the worker processes - where the reference runs its
+    per-molecule graph construction (DataLoader workers, train.py:589-600) - and the training process only issues the
+    H2D copies and the device-side complete-graph build (`to_device`).  Item i is batch i of a fixed, seeded sequence."""
+
+    def __init__(self, flat: 'FlatMolDataset', batch_size: int, steps: int, seed: int = 0, drop_last: bool = True):
+        self.flat, self.batch_size, self.steps, self.seed = flat, batch_size, steps, seed
+        self.per_epoch = max(len(flat) // batch_size, 1) if drop_last else -(-len(flat) // batch_size)
+
+    def __len__(self):
+        return self.steps
+
+    def __getitem__(self, i):
+        epoch, k = divmod(i, self.per_epoch)
+        order = np.random.default_rng(self.seed + epoch).permutation(len(self.flat))
+        return self.flat.assemble_host(order[k * self.batch_size:(k + 1) * self.batch_size])
+
+    @staticmethod
+    def to_device(hb, device):
+        """-> ([g2d], [g3d]) on `device` (the tensors of `hb` are pinned when the loader was built with pin_memory=True)"""
+        g2, xyz, graph_ptr_dev, n, bnn = host_batch_to_device(hb, device)
+        return [g2], [complete_graphs_on_device(xyz, graph_ptr_dev, n, bnn)]
 
 
 def complete_graphs_on_device(xyz, graph_ptr_dev, n_atoms_host, bnn) -> BatchedMolGraph:

@@ -52,6 +52,8 @@ def parse():
                          '(functional check of the N > 1 code path only)')
     ap.add_argument('--torch-adam', action='store_true', help='stock torch.optim.Adam(fused=True) instead of amd.Adam')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--loader-workers', type=int, default=4,
+                    help='DataLoader worker processes of the with-batch-assembly figure (0: assemble in the training thread)')
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--sync-bn', action='store_true',
                     help='N > 1: BatchNorm statistics over the global batch (exact single-process equivalence) instead of '
@@ -188,7 +190,7 @@ def main():
 
     # secondary figure (SURVEY.md 8d "also report with H2D/collate included", row f1): every step first assembles a
     # fresh batch from the flat dataset on the host (vectorised numpy), copies it and builds the 3D graphs on device
-    with_assembly = None
+    with_assembly = with_assembly_inline = None
     if not use_dist or world == 1:
         dataset = importlib.import_module('3dinfomax_amd.dataset')
         all_mols = [m for _, _, shard in batches for m in shard]
@@ -196,15 +198,18 @@ def main():
         rng = np.random.default_rng(0)
         n_asm = min(args.steps, 20)
 
-        def step_asm():
-            ids = rng.permutation(len(all_mols))[:B]
-            (a,), (b,) = flat.assemble(ids, dev)
+        def step_on(a, b):
             loss = loss_fn(pna(a), net(b), nodes_per_graph=a.batch_num_nodes())
             loss.backward()
             if use_dist:
                 adist.allreduce_grads(params)
             optim.step()
             optim.zero_grad()
+
+        def step_asm():
+            ids = rng.permutation(len(all_mols))[:B]
+            (a,), (b,) = flat.assemble(ids, dev)
+            step_on(a, b)
         for _ in range(3):
             step_asm()
         torch.cuda.synchronize()
@@ -212,7 +217,28 @@ def main():
         for _ in range(n_asm):
             step_asm()
         torch.cuda.synchronize()
-        with_assembly = round(n_asm * B / (time.perf_counter() - ta), 1)
+        with_assembly_inline = round(n_asm * B / (time.perf_counter() - ta), 1)
+        with_assembly = with_assembly_inline
+        # the same with the numpy half of the assembly in DataLoader worker processes (dataset.BatchStream) - where the
+        # reference runs its per-molecule graph construction: the training process only issues the H2D copies and the
+        # device-side complete-graph build
+        if args.loader_workers > 0:
+            n_ld = max(args.steps, 60)
+            stream = dataset.BatchStream(flat, B, steps=n_ld + 12, seed=1)
+            loader = torch.utils.data.DataLoader(stream, batch_size=None, num_workers=args.loader_workers, pin_memory=True,
+                                                 prefetch_factor=4)
+            it = iter(loader)
+            for _ in range(12):            # workers started, prefetch queue full
+                (a,), (b,) = dataset.BatchStream.to_device(next(it), dev)
+                step_on(a, b)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for hb in it:
+                (a,), (b,) = dataset.BatchStream.to_device(hb, dev)
+                step_on(a, b)
+            torch.cuda.synchronize()
+            with_assembly = round(n_ld * B / (time.perf_counter() - ta), 1)
+            del it, loader
 
     # roofline of the dominant HBM kernel: K4 PNA aggregation (forward), algorithmic bytes per SURVEY.md 8d
     ev = timers.get('pna_aggregate_fwd', [])
@@ -310,7 +336,8 @@ def main():
                                **({'host_lead_steps_median': sorted(lead_hist)[len(lead_hist) // 2],
                                    'host_lead_steps_min': min(lead_hist)} if lead_hist else {}),
                                host_enqueue_ms_per_step=round(t_enqueue / args.steps * 1e3, 3),
-                               molecules_per_s_incl_batch_assembly_and_h2d=with_assembly),
+                               molecules_per_s_incl_batch_assembly_and_h2d=with_assembly,
+                               molecules_per_s_incl_batch_assembly_in_the_training_thread=with_assembly_inline),
                    roofline=roof)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(batches[0][2], args.depth, args.cpu_steps)

@@ -61,3 +61,26 @@ def test_complete_graphs_built_on_device_equal_reference_construction():
     g2r, g3r = ref2.to('cuda:0'), ref3.to('cuda:0')
     assert torch.equal(za, pna(g2r))
     assert torch.allclose(zb, net(g3r), rtol=1e-5, atol=1e-6)
+
+
+def test_batch_stream_through_dataloader_workers_matches_direct_assembly():
+    """BatchStream: the numpy half of the assembly in DataLoader worker processes; the batches are the seeded sequence,
+    bit for bit what FlatMolDataset.assemble_host gives in-process, and the device half accepts them."""
+    mols = synth.make_dataset(90, seed=4)
+    ds = dataset.FlatMolDataset(mols)
+    stream = dataset.BatchStream(ds, batch_size=16, steps=7, seed=3)
+    loader = torch.utils.data.DataLoader(stream, batch_size=None, num_workers=2, prefetch_factor=2)
+    got = list(loader)
+    assert len(got) == 7
+    for i, hb in enumerate(got):
+        ref = stream[i]
+        norm = lambda v: [list(x) if isinstance(x, (list, tuple)) else x for x in v]
+        assert list(hb['dims']) == list(ref['dims']) and norm(hb['cuts']) == norm(ref['cuts']) and norm(hb['groups']) == norm(ref['groups'])
+        for k in ('i32', 'i64', 'f32', 'n', 'rows', 'tiles'):
+            assert torch.equal(hb[k], ref[k]), (i, k)
+    # batches 0.. of one epoch partition a permutation; the next epoch reshuffles
+    first_epoch = torch.cat([got[i]['n'] for i in range(5)])
+    assert first_epoch.numel() == 80
+    g2, xyz, gp, n, bnn = dataset.host_batch_to_device(got[0], 'cpu')
+    direct = ds.assemble_2d(np.random.default_rng(3).permutation(90)[:16], 'cpu')[0]
+    assert torch.equal(g2.ndata['feat'], direct.ndata['feat']) and torch.equal(g2.index().in_ptr, direct.index().in_ptr)
