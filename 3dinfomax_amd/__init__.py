@@ -38,6 +38,9 @@ def __getattr__(name):
     if name == 'Adam':
         from . import optim
         return optim.Adam
+    if name in ('dataset', 'dist', 'tape', 'streams', 'ops'):
+        import importlib
+        return importlib.import_module('.' + name, __name__)
     raise AttributeError(name)
 
 
