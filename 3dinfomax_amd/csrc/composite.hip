@@ -152,12 +152,13 @@ static int edge_fc_bn_bwd_chain(const I3dEdgeFcArgs* a, void* stream) {
     return i3d_segment_sum(a->grad_pre, Fo, a->in_ptr, nullptr, N, Fo, 0, a->grad_P + Fo, 2 * Fo, stream);
 }
 
-// dh = dP [W_s; W_d], the input of the next block's backward
-static int edge_fc_bn_bwd_dgrad(const I3dEdgeFcArgs* a, void* stream) {
+// dh = dP [W_s; W_d], the input of the next block's backward; `into` != null: added onto that buffer instead (a PNA layer
+// sums the edge block's dh into the posttrans block's: the GEMM epilogue does the addition, no separate kernel)
+static int edge_fc_bn_bwd_dgrad(const I3dEdgeFcArgs* a, void* stream, float* into = nullptr) {
     const int Fh = a->f_h, Fo = a->f_out, N = a->num_nodes;
     const long wdelta = (long)Fh - (long)Fo * a->ldw, wview = (long)(Fo - 1) * a->ldw + 2 * Fh;
-    return i3d_gemm_f32_blocks(0, 0, N, Fh, 2 * Fo, a->grad_P, 2 * Fo, a->W, a->ldw, Fo, wdelta, wview, a->grad_h, Fh, 0, 0, 0,
-                               nullptr, 0, stream);
+    return i3d_gemm_f32_blocks(0, 0, N, Fh, 2 * Fo, a->grad_P, 2 * Fo, a->W, a->ldw, Fo, wdelta, wview,
+                               into != nullptr ? into : a->grad_h, Fh, 0, 0, into != nullptr ? 1 : 0, nullptr, 0, stream);
 }
 
 // weight gradients (and, in table mode, everything behind dQ: only the caller reads grad_q, after the join)
@@ -266,9 +267,8 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     wst = fork_wgrad(x, stream);
     for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_wgrad(&a->pre[i], wst));
     TRY(edge_fc_bn_bwd_wgrad(&a->edge, wst));
-    TRY(edge_fc_bn_bwd_dgrad(&a->edge, stream));
+    TRY(edge_fc_bn_bwd_dgrad(&a->edge, stream, a->post.grad_h));       // post.grad_h += edge block's dh
     const long n = (long)a->edge.num_nodes * a->edge.f_h;
-    TRY(i3d_add_inplace(a->post.grad_h, a->edge.grad_h, n, stream));
     if (a->residual) TRY(i3d_add_inplace(a->post.grad_h, a->grad_out, n, stream));
     return join_wgrad(x, stream);
 }
