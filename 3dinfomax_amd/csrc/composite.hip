@@ -143,13 +143,21 @@ extern "C" int i3d_edge_fc_bn_fwd(const I3dEdgeFcArgs* a, void* stream) {
     return tail_fwd(&a->tail, a->num_edges, Fo, lin, a->xact, nullptr, a->y, stream);
 }
 
-static int edge_fc_bn_bwd_chain(const I3dEdgeFcArgs* a, void* stream) {
-    const int Fh = a->f_h, Fo = a->f_out, N = a->num_nodes, E = a->num_edges;
-    TRY(tail_bwd(&a->tail, E, Fo, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre, a->grad_bias,
-                 stream));
-    // d P[src] (out-edges through the source index), d P[dst] (in-edges are contiguous): segmented sums, no atomics
+static int edge_fc_bn_bwd_tail(const I3dEdgeFcArgs* a, void* stream) {
+    return tail_bwd(&a->tail, a->num_edges, a->f_out, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre,
+                    a->grad_bias, stream);
+}
+
+// d P[src] (out-edges through the source index), d P[dst] (in-edges are contiguous): segmented sums, no atomics
+static int edge_fc_bn_bwd_sums(const I3dEdgeFcArgs* a, void* stream) {
+    const int Fo = a->f_out, N = a->num_nodes;
     TRY(i3d_segment_sum(a->grad_pre, Fo, a->out_ptr, a->out_epos, N, Fo, 0, a->grad_P, 2 * Fo, stream));
     return i3d_segment_sum(a->grad_pre, Fo, a->in_ptr, nullptr, N, Fo, 0, a->grad_P + Fo, 2 * Fo, stream);
+}
+
+static int edge_fc_bn_bwd_chain(const I3dEdgeFcArgs* a, void* stream) {
+    TRY(edge_fc_bn_bwd_tail(a, stream));
+    return edge_fc_bn_bwd_sums(a, stream);
 }
 
 // dh = dP [W_s; W_d], the input of the next block's backward; `into` != null: added onto that buffer instead (a PNA layer
@@ -161,16 +169,21 @@ static int edge_fc_bn_bwd_dgrad(const I3dEdgeFcArgs* a, void* stream, float* int
                                into != nullptr ? into : a->grad_h, Fh, 0, 0, into != nullptr ? 1 : 0, nullptr, 0, stream);
 }
 
-// weight gradients (and, in table mode, everything behind dQ: only the caller reads grad_q, after the join)
-static int edge_fc_bn_bwd_wgrad(const I3dEdgeFcArgs* a, void* wst) {
-    const int Fh = a->f_h, Fo = a->f_out, N = a->num_nodes, E = a->num_edges;
+// d[W_s | W_d] = dP^T h (rows >= Fo of the [2Fo, Fh] result land in the second column block); every column block of dW is
+// written exactly once: no zero-fill (the split-K slices go through the scratch).  Needs dP.
+static int edge_fc_bn_bwd_wgrad_p(const I3dEdgeFcArgs* a, void* wst) {
+    const int Fh = a->f_h, Fo = a->f_out, N = a->num_nodes;
+    const long wdelta = (long)Fh - (long)Fo * a->ldw;
+    return i3d_gemm_f32_blocks(1, 0, 2 * Fo, Fh, N, a->grad_P, 2 * Fo, a->h, Fh, 0, 0, 0, a->grad_W, a->ldw, Fo, wdelta, 0,
+                               a->tail.gemm_workspace, a->tail.gemm_workspace_bytes, wst);
+}
+
+// the W_q column block and, in table mode, everything behind dQ (only the caller reads grad_q, after the join).  Needs
+// grad_pre only.
+static int edge_fc_bn_bwd_wgrad_q(const I3dEdgeFcArgs* a, void* wst) {
+    const int Fh = a->f_h, Fo = a->f_out, E = a->num_edges;
     void* ws = a->tail.gemm_workspace;
     const long wsb = a->tail.gemm_workspace_bytes;
-    const long wdelta = (long)Fh - (long)Fo * a->ldw;
-    // every column block of dW is written exactly once: no zero-fill (the split-K slices go through the scratch)
-    // d[W_s | W_d] = dP^T h (rows >= Fo of the [2Fo, Fh] result land in the second column block)
-    TRY(i3d_gemm_f32_blocks(1, 0, 2 * Fo, Fh, N, a->grad_P, 2 * Fo, a->h, Fh, 0, 0, 0, a->grad_W, a->ldw, Fo, wdelta, 0, ws, wsb,
-                            wst));
     if (a->q != nullptr && a->q_rows > 0) {
         // table mode: dQ[v] = sum of dpre over the edges of category v (one-hot^T dpre), then two [V, .] products
         const int V = a->q_rows;
@@ -184,6 +197,11 @@ static int edge_fc_bn_bwd_wgrad(const I3dEdgeFcArgs* a, void* wst) {
             TRY(i3d_gemm_f32(0, 0, E, a->f_q, Fo, a->grad_pre, Fo, a->W + 2 * Fh, a->ldw, a->grad_q, a->f_q, nullptr, 0, wst));
     }
     return I3D_OK;
+}
+
+static int edge_fc_bn_bwd_wgrad(const I3dEdgeFcArgs* a, void* wst) {
+    TRY(edge_fc_bn_bwd_wgrad_p(a, wst));
+    return edge_fc_bn_bwd_wgrad_q(a, wst);
 }
 
 extern "C" int i3d_edge_fc_bn_bwd(const I3dEdgeFcArgs* a, void* stream) {
@@ -246,14 +264,18 @@ extern "C" int i3d_pna_layer_fwd(const I3dPnaLayerArgs* a, void* stream) {
     return I3D_OK;
 }
 
+// I3D_WGRAD_FORKS=2: the later pretrans blocks' and the edge block's weight gradients behind one fork (after dP exists)
+// instead of two; measured: three forks per layer -1 % step time, +7 us of host time per layer (the host has the slack)
+static const bool THREE_FORKS = [] { const char* e = getenv("I3D_WGRAD_FORKS"); return e == nullptr || e[0] != '2'; }();
+
 extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     I3D_CHECK_ARG(a != nullptr && a->n_pre_extra >= 0 && a->n_pre_extra <= I3D_MAX_EXTRA_FC && a->n_post_extra >= 0 &&
                       a->n_post_extra <= I3D_MAX_EXTRA_FC, "bad arguments");
-    // The chain on the caller's stream; the weight gradients on the side stream behind TWO forks: one right after the
-    // posttrans blocks' chain part (their weight gradients are the largest, and the aggregation backward and the pretrans
-    // chain run next to them), one when the edge block's dP exists (the later pretrans blocks' and the edge block's).
-    // Measured: a single early fork per block (4 per layer) costs the host 0.07 ms more per step, forking everything late
-    // (after the pretrans chain) costs the GPU 2 %.  One join, at the end.
+    // The chain on the caller's stream; the weight gradients on the side stream behind three forks: right after the posttrans
+    // blocks' chain part (their weight gradients are the largest, and the aggregation backward and the pretrans chain run
+    // next to them), after the edge block's BatchNorm backward (the later pretrans blocks' and everything behind dQ need
+    // grad_pre only), and when the edge block's dP exists.  Measured: one fork per block (4 per layer) costs the host
+    // 0.07 ms more per step for nothing, forking everything late (after the pretrans chain) costs the GPU 2 %.  One join.
     Aux* x = aux_for((hipStream_t)stream);
     for (int i = a->n_post_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_chain(&a->postx[i], stream));
     TRY(grouped_fc_bn_bwd_chain(&a->post, stream));
@@ -263,10 +285,20 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     TRY(i3d_pna_aggregate_bwd(a->post.grad_agg, a->msg, a->edge.in_ptr, a->edge.num_nodes, a->edge.f_out, a->aggregators,
                               a->n_aggregators, a->scalers, a->n_scalers, a->force_scalers, a->avg_d_log, a->grad_msg, stream));
     for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_chain(&a->pre[i], stream));
-    TRY(edge_fc_bn_bwd_chain(&a->edge, stream));
-    wst = fork_wgrad(x, stream);
-    for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_wgrad(&a->pre[i], wst));
-    TRY(edge_fc_bn_bwd_wgrad(&a->edge, wst));
+    TRY(edge_fc_bn_bwd_tail(&a->edge, stream));
+    if (THREE_FORKS) {
+        wst = fork_wgrad(x, stream);       // the later pretrans blocks' and everything behind dQ: they need grad_pre only
+        for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_wgrad(&a->pre[i], wst));
+        TRY(edge_fc_bn_bwd_wgrad_q(&a->edge, wst));
+        TRY(edge_fc_bn_bwd_sums(&a->edge, stream));
+        wst = fork_wgrad(x, stream);
+        TRY(edge_fc_bn_bwd_wgrad_p(&a->edge, wst));
+    } else {
+        TRY(edge_fc_bn_bwd_sums(&a->edge, stream));
+        wst = fork_wgrad(x, stream);
+        for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_wgrad(&a->pre[i], wst));
+        TRY(edge_fc_bn_bwd_wgrad(&a->edge, wst));
+    }
     TRY(edge_fc_bn_bwd_dgrad(&a->edge, stream, a->post.grad_h));       // post.grad_h += edge block's dh
     const long n = (long)a->edge.num_nodes * a->edge.f_h;
     if (a->residual) TRY(i3d_add_inplace(a->post.grad_h, a->grad_out, n, stream));
