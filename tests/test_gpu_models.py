@@ -524,10 +524,10 @@ def test_num_batches_tracked_counts_forward_passes(amd, monkeypatch, composite):
     assert len(counters) > 5 and all(v == 3 for _, v in counters), counters
 
 
-def test_weight_gradient_stream_gives_the_same_bits():
-    """The backward composites enqueue the weight-gradient GEMMs on a side stream of their own (composite.hip); with it
-    switched off (I3D_WGRAD_STREAM=0, read once per process -> subprocesses) three optimisation steps end in the same
-    bits."""
+def test_process_level_switches_give_the_same_bits():
+    """Switches that are read once per process (-> subprocesses): the weight-gradient side stream of the backward
+    composites off / with two forks, freshly allocated parameter gradients, the in-launch finalisation off - three
+    optimisation steps end in the same bits as the default."""
     import os
     import subprocess
     import sys
@@ -551,13 +551,16 @@ def test_weight_gradient_stream_gives_the_same_bits():
         "    optim.step(); optim.zero_grad()\n"
         "torch.save([p.detach().cpu() for p in params], sys.argv[1])\n") % (root, os.path.join(root, 'tests'))
     res = {}
-    for mode in ('0', '1'):
-        path = f'/tmp/i3d_wgrad_stream_{mode}.pt'
-        subprocess.run([sys.executable, '-c', code, path], check=True, env=dict(os.environ, I3D_WGRAD_STREAM=mode), timeout=600)
-        res[mode] = torch.load(path)
-    assert len(res['0']) > 50
-    for a, b in zip(res['0'], res['1']):
-        assert torch.equal(a, b)
+    variants = {'default': {}, 'no_wgrad_stream': {'I3D_WGRAD_STREAM': '0'}, 'two_forks': {'I3D_WGRAD_FORKS': '2'},
+                'fresh_grads': {'I3D_PERSISTENT_GRADS': '0'}, 'separate_final': {'I3D_FUSED_FINAL': '0'}}
+    for name, env in variants.items():
+        path = f'/tmp/i3d_switch_{name}.pt'
+        subprocess.run([sys.executable, '-c', code, path], check=True, env=dict(os.environ, **env), timeout=600)
+        res[name] = torch.load(path)
+    assert len(res['default']) > 50
+    for name in variants:
+        for a, b in zip(res['default'], res[name]):
+            assert torch.equal(a, b), name
 
 
 @pytest.mark.parametrize('cfg', ['yml', 'deep'])
