@@ -135,11 +135,24 @@ class GradReducer:
                 self._tape.register_grad_sink(m, self._sink, self.view_of)
 
     def _sink(self, params, grads):
-        dst = [self.view_of.get(id(p)) for p in params]
-        pairs = [(d, g) for d, g in zip(dst, grads) if d is not None and g is not None and g is not d]
-        if pairs:
-            torch._foreach_copy_([d for d, _ in pairs], [g for _, g in pairs])
-        return [d if (d is not None and g is not None) else g for d, g in zip(dst, grads)]
+        """Gradients of one model backward -> what autograd should store / accumulate.
+
+        `p.grad` empty: the new gradient is copied into the parameter's slice of the flat buffer and the slice is handed
+        out.  `p.grad` already set (gradient accumulation over several backward passes, `zero_grad(set_to_none=False)`,
+        two forwards before one backward): the slice IS (or will be copied from) the accumulated value - it must not be
+        overwritten; the fresh gradient goes back to autograd, whose AccumulateGrad adds it onto `p.grad` in place."""
+        out, dst, src = [], [], []
+        for p, g in zip(params, grads):
+            d = self.view_of.get(id(p))
+            if d is None or g is None or g is d or p.grad is not None:
+                out.append(g)
+                continue
+            dst.append(d)
+            src.append(g)
+            out.append(d)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        return out
 
     def reduce(self):
         grads = [p.grad for p in self.params]

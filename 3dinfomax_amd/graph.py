@@ -189,6 +189,9 @@ def batch(graphs: List[BatchedMolGraph]) -> BatchedMolGraph:
     batch_num_nodes flattened."""
     srcs, dsts, bnn = [], [], []
     off = 0
+    # items may be DGL-like graphs (the reference's own datasets yield `dgl.DGLGraph`s and `from infomax3d_amd import *`
+    # rebinds the collate functions that land here): duck-typed through as_batched_graph, frames shared
+    graphs = [as_batched_graph(g) for g in graphs]
     for g in graphs:
         srcs.append(g._src + off)
         dsts.append(g._dst + off)

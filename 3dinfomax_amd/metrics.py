@@ -10,6 +10,7 @@ call signature; the value comes back as a 0-dim CPU tensor (`.item()` works as i
 (local-global losses) variants are outside the scope of this path and raise NotImplementedError.
 """
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -17,7 +18,15 @@ import torch.nn as nn
 
 from . import _lib, ops
 
-_cache = {'key': None, 'values': None}
+# one entry: (weakref(x1), weakref(x2), key, values).  The key alone (address, version, shape) is NOT an identity: each
+# training step's detached embeddings are new tensors with version 0, the same shape and - through the caching allocator -
+# very likely the same address, so the cache also requires that the very tensor OBJECTS are the ones it was filled from
+# (weak references: a dead tensor can never match, and the cache keeps no embedding alive).
+_cache = {'key': None, 'values': None, 'x1': None, 'x2': None}
+
+
+def _same_object(ref, t):
+    return ref is not None and ref() is t
 
 
 def _log(v):
@@ -28,7 +37,7 @@ def _log(v):
 def _all_metrics(x1, x2, threshold=0.5, t=2.0, alpha=2.0):
     key = (x1.data_ptr(), x1._version, tuple(x1.shape), x2.data_ptr(), x2._version, tuple(x2.shape), float(threshold), float(t),
            float(alpha))
-    if _cache['key'] == key:
+    if _cache['key'] == key and _same_object(_cache['x1'], x1) and _same_object(_cache['x2'], x2):
         return _cache['values']
     with torch.no_grad():
         z1, z2 = x1.detach().float().contiguous(), x2.detach().float().contiguous()
@@ -81,6 +90,7 @@ def _all_metrics(x1, x2, threshold=0.5, t=2.0, alpha=2.0):
     vals['mean_pred'], vals['std_pred'] = all_mean_std(s1, q1, B1)
     vals['mean_targets'], vals['std_targets'] = all_mean_std(s2, q2, B2)
     _cache['key'], _cache['values'] = key, vals
+    _cache['x1'], _cache['x2'] = weakref.ref(x1), weakref.ref(x2)
     return vals
 
 

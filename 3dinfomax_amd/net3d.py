@@ -148,7 +148,7 @@ class Net3D(nn.Module):
     def _forward(self, graph):
         g = as_batched_graph(graph)
         if tape.active() is not None and net3d_native.eligible(self, g):
-            params = self.__dict__.get('_i3d_param_list') or list(self.parameters())
+            params = tape._param_list(self)
             return tape.apply(Net3DFn, self, g, *params)
         idx = g.index()
         if self.use_node_features:

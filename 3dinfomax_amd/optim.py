@@ -14,6 +14,7 @@ import torch
 
 class Adam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kwargs):
+        params = list(params)      # a generator (`Adam(model.parameters())`) must survive the look at its devices below
         if 'fused' not in kwargs and 'foreach' not in kwargs:
             kwargs['fused'] = self._all_cuda(params)
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kwargs)
@@ -23,7 +24,6 @@ class Adam(torch.optim.Adam):
 
     @staticmethod
     def _all_cuda(params):
-        params = list(params)
         flat = []
         for p in params:
             flat += list(p['params']) if isinstance(p, dict) else [p]

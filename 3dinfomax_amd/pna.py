@@ -285,9 +285,12 @@ class PNALayer(nn.Module):
             # per call: only the per-degree scaler coefficients depend on the batch (cached on its index: the layers of a
             # model share them); specs and parameters come from the FC layers' hot caches
             fcs = self.__dict__.get('_i3d_fcs')
-            if fcs is None:
-                fcs = self.__dict__['_i3d_fcs'] = (list(self.pretrans.fully_connected), list(self.posttrans.fully_connected))
-            pre, post = fcs
+            mods = (self.pretrans.fully_connected._modules, self.posttrans.fully_connected._modules)
+            if fcs is None or any(len(k) != len(m) or any(m.get(n) is not fc for n, fc in k)
+                                  for k, m in zip(fcs[2], mods)):      # a replaced / added FC layer drops the cache
+                keyed = tuple(tuple(m.items()) for m in mods)
+                fcs = self.__dict__['_i3d_fcs'] = ([fc for _, fc in keyed[0]], [fc for _, fc in keyed[1]], keyed)
+            pre, post = fcs[0], fcs[1]
             hots = [fc.hot() for fc in pre + post]
             plan = _LayerPlan()
             plan.pre_specs, plan.post_specs = [t[4] for t in hots[:len(pre)]], [t[4] for t in hots[len(pre):]]

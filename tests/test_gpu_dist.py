@@ -93,3 +93,57 @@ def test_two_rank_sharded_step_equals_full_batch(tmp_path):
         grads_close({k: z[f'g/{tag}/{k}'] for k in ref}, ref, 2e-4, tag + ' ')
         for k, b in m.named_buffers():
             assert close(z[f'b/{tag}/{k}'], b.cpu(), 1e-5, 1e-6), k
+
+
+def _accum_worker(rank, port, path):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    amd = importlib.import_module('3dinfomax_amd')
+    adist = importlib.import_module('3dinfomax_amd.dist')
+    mols = amd.synth.make_dataset(12, seed=5)
+    pna, net = _models(amd)
+    loss_fn = amd.NTXent(tau=0.1)
+    adist.setup([pna, net], loss_fn, sync_bn=False)
+    params = list(pna.parameters()) + list(net.parameters())
+    red = adist.grad_reducer(params, modules=[pna, net])
+    g2, g3 = _batch(amd, mols)
+
+    def backward_once():
+        loss_fn(pna(g2.local_copy()), net(g3.local_copy())).backward()
+
+    out = {}
+    backward_once()                                   # .grad empty: straight into the all-reduce buffer
+    adist.allreduce_grads(params)
+    out.update({f'one/{i}': p.grad.cpu().numpy().copy() for i, p in enumerate(params)})
+    for p in params:
+        p.grad = None
+    backward_once()
+    backward_once()                                   # gradient accumulation: .grad is the buffer's view already
+    adist.allreduce_grads(params)
+    out.update({f'two/{i}': p.grad.cpu().numpy().copy() for i, p in enumerate(params)})
+    for p in params:                                  # zero_grad(set_to_none=False): zeros stay where they are
+        p.grad.zero_()
+    backward_once()
+    adist.allreduce_grads(params)
+    out.update({f'zeroed/{i}': p.grad.cpu().numpy().copy() for i, p in enumerate(params)})
+    out['in_buffer'] = np.array([p.grad.data_ptr() == v.data_ptr() for p, v in zip(red.params, red.views)])
+    np.savez(path, **out)
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_accumulates_instead_of_clobbering(tmp_path):
+    """with `.grad` already set the sink used to copy the new gradient over the accumulated one and autograd
+    then added the buffer onto itself (2 g_new instead of g_old + g_new)."""
+    path = str(tmp_path / 'acc.npz')
+    mp.spawn(_accum_worker, args=(_free_port(), path), nprocs=1, join=True)
+    z = np.load(path)
+    n = sum(1 for k in z.files if k.startswith('one/'))
+    assert n > 50 and bool(z['in_buffer'].all())
+    for i in range(n):
+        g = z[f'one/{i}']
+        scale = max(float(np.abs(g).max()), 1e-30)
+        # the BatchNorm running statistics differ between the passes, the batch statistics (train mode) do not: same bits
+        assert np.abs(z[f'two/{i}'] - 2 * g).max() <= 1e-6 * scale, i
+        assert np.abs(z[f'zeroed/{i}'] - g).max() <= 1e-6 * scale, i

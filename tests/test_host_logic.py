@@ -82,3 +82,43 @@ def test_grad_pool_hands_out_each_view_once_and_knows_the_bias_of_a_weight():
     tape.register_grad_sink(net, lambda ps, gs: gs, views)
     pool3 = tape.model_state(net).pool_for(params)
     assert all(pool3.view_of[id(p)] is views[id(p)] for p in params)
+
+
+def test_adam_accepts_a_parameter_generator():
+    """`Adam(model.parameters())` (a generator) used to be exhausted by the device check."""
+    lin = torch.nn.Linear(4, 3)
+    opt = amd.Adam(lin.parameters(), lr=1e-3)
+    assert len(opt.param_groups[0]['params']) == 2
+    lin(torch.randn(5, 4)).sum().backward()
+    opt.step()
+    opt2 = amd.Adam([{'params': [lin.weight]}, {'params': [lin.bias], 'weight_decay': 0}], lr=1e-3)
+    assert len(opt2.param_groups) == 2
+
+
+def test_param_list_cache_follows_replaced_heads_and_parameters():
+    """the tape's cached leaf list must notice a swapped sub-module / re-assigned Parameter."""
+    tape = importlib.import_module('3dinfomax_amd.tape')
+    m = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 2))
+    a = tape._param_list(m)
+    assert tape._param_list(m) is a and len(a) == 4
+    m[1] = torch.nn.Linear(4, 3)                       # fine-tuning: new output head
+    b = tape._param_list(m)
+    assert b is not a and any(p is m[1].weight for p in b) and not any(p is a[2] for p in b)
+    m[0].weight = torch.nn.Parameter(torch.zeros(4, 4))
+    c = tape._param_list(m)
+    assert c is not b and any(p is m[0].weight for p in c)
+    m.add_module('extra', torch.nn.Linear(2, 2))
+    assert len(tape._param_list(m)) == 6
+
+
+def test_metrics_cache_requires_the_very_tensor_objects():
+    """(address, version, shape) is not an identity - a new tensor at a recycled address must miss."""
+    M = importlib.import_module('3dinfomax_amd.metrics')
+    x = torch.zeros(2, 2)
+    import weakref
+    r = weakref.ref(x)
+    assert M._same_object(r, x) and not M._same_object(r, torch.zeros(2, 2)) and not M._same_object(None, x)
+    y = torch.zeros(2, 2)
+    r2 = weakref.ref(y)
+    del y
+    assert not M._same_object(r2, x)
