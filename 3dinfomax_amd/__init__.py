@@ -5,7 +5,8 @@ The package name starts with a digit, so import it with importlib.import_module(
 the alias module `infomax3d_amd` at the repository root.
 """
 from .graph import (BatchedMolGraph, GraphIndex, as_batched_graph, batch, bond_graph, complete_graph,  # noqa: F401
-                    conformer_collate, contrastive_collate)
+                    conformer_collate, contrastive_collate, graph_collate, s_norm_contrastive_collate,
+                    s_norm_graph_collate)
 from . import synth  # noqa: F401
 
 
@@ -47,6 +48,6 @@ def __getattr__(name):
 __all__ = ['PNA', 'PNAGNN', 'PNALayer', 'PNA_AGGREGATORS', 'PNA_SCALERS', 'PNAOriginal', 'PNAOriginalSimple',
            'PNAGNNOriginal', 'PNAGNNSimple', 'PNATower', 'PNASimpleLayer', 'MLPReadout', 'Net3D', 'Net3DLayer', 'NTXent',
            'NTXentMultiplePositives', 'FCLayer', 'MLP', 'AtomEncoder', 'BondEncoder', 'contrastive_collate',
-           'conformer_collate', 'BatchedMolGraph', 'batch', 'bond_graph', 'complete_graph', 'Adam', 'PositiveSimilarity',
+           'conformer_collate', 'graph_collate', 's_norm_graph_collate', 's_norm_contrastive_collate', 'BatchedMolGraph', 'batch', 'bond_graph', 'complete_graph', 'Adam', 'PositiveSimilarity',
            'NegativeSimilarity', 'ContrastiveAccuracy', 'TrueNegativeRate', 'TruePositiveRate', 'Uniformity', 'Alignment',
            'BatchVariance', 'DimensionCovariance']

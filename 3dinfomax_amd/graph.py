@@ -224,7 +224,7 @@ def complete_graph(mol, coords=None) -> BatchedMolGraph:
 
 
 def contrastive_collate(batch_items):
-    """Mirror of reference datasets/custom_collate.py:105-114 on BatchedMolGraph items."""
+    """Mirror of reference datasets/custom_collate.py:105-114 (items may be BatchedMolGraphs or DGL-like graphs)."""
     graphs, graphs3d, *targets = map(list, zip(*batch_items))
     if targets:
         return [batch(graphs)], [batch(graphs3d)], torch.stack(*targets).float()
@@ -235,6 +235,35 @@ def conformer_collate(batch_items):
     """Mirror of reference datasets/custom_collate.py:155-157."""
     graphs, confs = map(list, zip(*batch_items))
     return [batch(graphs)], [batch(confs)]
+
+
+def graph_collate(batch_items):
+    """Mirror of reference datasets/custom_collate.py:12-18 (the collate of the fine-tuning configs, e.g.
+    configs_clean/tune_QM9_homo.yml): ([batched graph], targets [B, T]); 1-d targets get a trailing axis."""
+    graphs, targets = map(list, zip(*batch_items))
+    targets = torch.stack(targets).float()
+    if len(targets.shape) == 1:
+        targets = targets.unsqueeze(-1)
+    return [batch(graphs)], targets
+
+
+def _snorm_n(graphs):
+    """sqrt(1 / n_atoms) per node, [N, 1] (reference datasets/custom_collate.py:45-47, 96-98: the graph-size
+    normalisation factor of the original PNA, models/pna_original.py:258-259)."""
+    sizes = [as_batched_graph(g).number_of_nodes() for g in graphs]
+    return torch.cat([torch.full((n, 1), 1.0 / float(n), dtype=torch.float32) for n in sizes]).sqrt()
+
+
+def s_norm_graph_collate(batch_items):
+    """Mirror of reference datasets/custom_collate.py:43-49: ([batched graph, snorm_n], targets)."""
+    graphs, targets = map(list, zip(*batch_items))
+    return [batch(graphs), _snorm_n(graphs)], torch.stack(targets).float()
+
+
+def s_norm_contrastive_collate(batch_items):
+    """Mirror of reference datasets/custom_collate.py:93-102: ([batched graph, snorm_n], [batched 3D graph])."""
+    graphs, graphs3d = map(list, zip(*batch_items))
+    return [batch(graphs), _snorm_n(graphs)], [batch(graphs3d)]
 
 
 def as_batched_graph(g) -> BatchedMolGraph:

@@ -89,8 +89,12 @@ def test_pna_and_net3d_vs_reference_fixture(amd, regime):
         assert rel_err(net(g3).cpu(), z[f'{regime}/net3d_out_eval']) < TOL
 
 
-def test_three_adam_steps_vs_reference_fixture(amd):
-    z = load('train3.npz')
+@pytest.mark.parametrize('fixture', ['train3.npz', 'trainer3.npz'])
+def test_three_adam_steps_vs_reference_fixture(amd, fixture):
+    # train3.npz: a hand-written loop around the reference modules; trainer3.npz: the same three steps driven through
+    # the reference's own SelfSupervisedTrainer.process_batch / forward_pass / initialize_optimizer and its
+    # contrastive_collate (tests/golden/gen_golden_host.py) - SURVEY.md row a13
+    z = load(fixture)
     mols = mols_from_npz(z)
     pna = amd.PNA(avg_d=1.0, device='cuda:0', **PNA_SMALL)
     net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_SMALL)
@@ -111,6 +115,14 @@ def test_three_adam_steps_vs_reference_fixture(amd):
         optim.zero_grad()
         losses.append(loss.item())
     np.testing.assert_allclose(losses, z['losses'], rtol=1e-4)      # loss within 1e-4 of the reference
+    if 'optim_group_sizes' in z.files:
+        assert list(z['optim_group_sizes']) == [len(g['params']) for g in optim.param_groups]
+    for tag, m in (('pna_sd_final', pna), ('net3d_sd_final', net)):
+        for k, p in m.named_parameters():
+            # weights only: a bias in front of a BatchNorm has an analytically zero gradient, Adam turns its rounding
+            # noise into +-lr steps in every implementation (tests/test_oracle_golden.py)
+            if k.endswith('.weight'):
+                assert close(p.detach(), z[f'{tag}/{k}'], 1e-4, 2e-5), k
 
 
 def _det_load(module, tag):

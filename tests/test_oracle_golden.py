@@ -74,8 +74,9 @@ def test_pna_net3d_small_match_reference(regime):
         assert rel_err(O.net3d_forward(g3, P3, cfg3, False)[0], z[f'{regime}/net3d_out_eval']) < TOL
 
 
-def test_three_adam_steps_match_reference():
-    z = load('train3.npz')
+@pytest.mark.parametrize('fixture', ['train3.npz', 'trainer3.npz'])      # hand loop / the reference Trainer's own step code
+def test_three_adam_steps_match_reference(fixture):
+    z = load(fixture)
     g2, g3 = _graphs(z)
     cfg2, cfg3 = O.pna_config(**PNA_SMALL), O.net3d_config(**NET3D_SMALL)
     P2 = O.require_grad(sd_from_npz(z, 'pna_sd'))
