@@ -39,7 +39,8 @@ class EdgeFcArgs(ctypes.Structure):
                 ('grad_Q', _P), ('h', _P), ('q', _P), ('W', _P), ('bias', _P), ('src_s', _P),
                 ('dst_s', _P), ('in_ptr', _P), ('out_ptr', _P), ('out_epos', _P), ('P', _P), ('Q', _P), ('xact', _P),
                 ('pre_keep', _P), ('y', _P), ('grad_y', _P), ('grad_pre', _P), ('grad_P', _P), ('grad_gamma', _P),
-                ('grad_beta', _P), ('grad_W', _P), ('grad_bias', _P), ('grad_h', _P), ('grad_q', _P)]
+                ('grad_beta', _P), ('grad_W', _P), ('grad_bias', _P), ('grad_h', _P), ('grad_q', _P),
+                ('grad_q_accumulate', c_int)]
 
 
 class GroupedFcArgs(ctypes.Structure):
@@ -56,10 +57,39 @@ class PnaLayerArgs(ctypes.Structure):
     _fields_ = [('edge', EdgeFcArgs), ('n_pre_extra', c_int), ('pre', FcArgs * 3), ('n_aggregators', c_int),
                 ('n_scalers', c_int), ('force_scalers', c_int), ('aggregators', c_int * 8), ('scalers', c_int * 4),
                 ('avg_d_log', c_float), ('msg', _P), ('grad_msg', _P), ('post', GroupedFcArgs), ('n_post_extra', c_int),
-                ('postx', FcArgs * 3), ('residual', c_int), ('grad_out', _P), ('agg_event_start', _P), ('agg_event_stop', _P)]
+                ('postx', FcArgs * 3), ('residual', c_int), ('grad_out', _P), ('agg_event_start', _P), ('agg_event_stop', _P),
+                ('fused_bn', c_int), ('stats_ws', _P), ('aff', _P * 4)]
+
+
+class FcParams(ctypes.Structure):
+    _fields_ = [('W', _P), ('bias', _P), ('gamma', _P), ('beta', _P), ('running_mean', _P), ('running_var', _P),
+                ('num_batches_tracked', _P), ('grad_W', _P), ('grad_bias', _P), ('grad_gamma', _P), ('grad_beta', _P),
+                ('f_in', c_int), ('f_out', c_int), ('act', c_int), ('eps', c_float), ('momentum', c_float)]
+
+
+class PnaModel(ctypes.Structure):
+    _fields_ = [('n_layers', c_int), ('hidden', c_int), ('n_pre', c_int), ('residual', c_int), ('n_aggregators', c_int),
+                ('aggregators', c_int * 8), ('n_scalers', c_int), ('scalers', c_int * 4), ('avg_d_log', c_float),
+                ('pre', (FcParams * 4) * 16), ('post', FcParams * 16), ('n_atom_tables', c_int), ('atom_dims', c_int * 16),
+                ('atom_tables', _P * 16), ('grad_atom_tables', _P), ('n_bond_tables', c_int), ('bond_dims', c_int * 16),
+                ('bond_tables', _P * 16), ('grad_bond_tables', _P), ('n_readout', c_int), ('readout_ops', c_int * 4),
+                ('n_head', c_int), ('head', FcParams * 4)]
+
+
+class PnaBatch(ctypes.Structure):
+    _fields_ = [('num_nodes', c_int), ('num_edges', c_int), ('num_graphs', c_int), ('atom_feat', _P), ('bond_feat', _P),
+                ('in_ptr', _P), ('perm', _P), ('src_s', _P), ('dst_s', _P), ('out_ptr', _P), ('out_epos', _P),
+                ('graph_ptr', _P), ('deg_rows', _P), ('deg_tile_group', _P), ('m_padded', c_int), ('n_groups', c_int),
+                ('group_degree', c_int * 32), ('group_start', c_int * 32), ('group_count', c_int * 32), ('comb', _P),
+                ('n_comb', c_int), ('v_pad', c_int)]
 
 
 _SIGNATURES = {
+    'i3d_pna_model_saved_floats': (c_long, [POINTER(PnaModel), POINTER(PnaBatch)]),
+    'i3d_pna_model_scratch_floats': (c_long, [POINTER(PnaModel), POINTER(PnaBatch)]),
+    'i3d_pna_model_fwd': (c_int, [POINTER(PnaModel), POINTER(PnaBatch), _P, _P, _P, _P, _P, _P, _P, POINTER(c_void_p)]),
+    'i3d_pna_model_bwd': (c_int, [_P, POINTER(PnaModel), _P, _P, _P, _P, c_long, _P]),
+    'i3d_pna_model_ctx_free': (c_int, [_P]),
     'i3d_event_create': (c_int, [POINTER(c_void_p)]),
     'i3d_event_destroy': (c_int, [_P]),
     'i3d_event_record': (c_int, [_P, _P]),
@@ -72,6 +102,17 @@ _SIGNATURES = {
     'i3d_edge_fc_bn_bwd': (c_int, [POINTER(EdgeFcArgs), _P]),
     'i3d_grouped_fc_bn_fwd': (c_int, [POINTER(GroupedFcArgs), _P]),
     'i3d_grouped_fc_bn_bwd': (c_int, [POINTER(GroupedFcArgs), _P]),
+    'i3d_pna_layer_stats_floats': (c_long, [c_int, c_int, c_int, c_int]),
+    'i3d_bn_finalize_partials': (c_int, [_P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'i3d_edge_stats_rows_per_tile': (c_int, [c_int]),
+    'i3d_edge_combine_act_stats': (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    'i3d_gemm_f32_fused': (c_int, [c_int, c_int, c_int, _P, c_int, c_long, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P,
+                                   _P, c_long, _P]),
+    'i3d_gemm_f32_wgrad_bn': (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P, c_long, _P]),
+    'i3d_pna_aggregate_fwd_aff': (c_int, [_P, _P, _P, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_int, c_float,
+                                          _P, _P]),
+    'i3d_pna_aggregate_bwd_aff': (c_int, [_P, _P, _P, _P, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_int,
+                                          c_float, _P, _P]),
     'i3d_abi_version': (c_int, []),
     'i3d_last_error': (c_char_p, []),
     'i3d_embedding_sum_fwd': (c_int, [_P, _P, c_int, c_int, POINTER(c_void_p), c_int, _P, _P]),

@@ -48,10 +48,17 @@ struct Stats4 {
 
 // MODE 0: any aggregator/scaler list   1: (mean,max,min,std) x (identity,amplification,attenuation), 12 blocks
 //      2: (mean,max,min,std) x identity, 4 blocks (degree-grouped posttrans: the scalers live in the combined weights)
+// aff (optional, [3F] = mean | scale | shift): the messages are read as (e - mean) * scale + shift - the BatchNorm of the
+// last pretrans block applied on the fly (fused_bn.hip), so the normalised message tensor never exists in memory
+__device__ __forceinline__ float4 aff4(const float4 x, const float4 mu, const float4 sc, const float4 sh) {
+    return make_float4((x.x - mu.x) * sc.x + sh.x, (x.y - mu.y) * sc.y + sh.y, (x.z - mu.z) * sc.z + sh.z,
+                       (x.w - mu.w) * sc.w + sh.w);
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256)
 pna_aggregate_fwd_kernel(const float4* __restrict__ e, const int* __restrict__ in_ptr, int N, int FV,
-                         AggCfg cfg, float4* __restrict__ out) {
+                         AggCfg cfg, float4* __restrict__ out, const float4* __restrict__ aff) {
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)N * FV) return;
     int v = (int)(t / FV), c = (int)(t - (long)v * FV);
@@ -68,7 +75,12 @@ pna_aggregate_fwd_kernel(const float4* __restrict__ e, const int* __restrict__ i
     // duplicates hit L1) so four loads are in flight instead of a dependent load-accumulate chain; the accumulation
     // order stays j = 0 .. D-1.
     float4 x = p[0];
-    const float4 x1 = p[(long)min(1, D - 1) * FV], x2 = p[(long)min(2, D - 1) * FV], x3 = p[(long)min(3, D - 1) * FV];
+    float4 x1 = p[(long)min(1, D - 1) * FV], x2 = p[(long)min(2, D - 1) * FV], x3 = p[(long)min(3, D - 1) * FV];
+    float4 a_mu, a_sc, a_sh;
+    if (aff != nullptr) {
+        a_mu = aff[c]; a_sc = aff[FV + c]; a_sh = aff[2 * FV + c];
+        x = aff4(x, a_mu, a_sc, a_sh); x1 = aff4(x1, a_mu, a_sc, a_sh); x2 = aff4(x2, a_mu, a_sc, a_sh); x3 = aff4(x3, a_mu, a_sc, a_sh);
+    }
     float4 sum = x, mx = x, mn = x;
     float4 sq = make_float4(x.x * x.x, x.y * x.y, x.z * x.z, x.w * x.w);
 #define I3D_AGG_ACC(X)                                                                                              \
@@ -83,8 +95,11 @@ pna_aggregate_fwd_kernel(const float4* __restrict__ e, const int* __restrict__ i
     if (D > 3) I3D_AGG_ACC(x3);
     // longer segments (per-graph readouts: ~18 atoms; hub atoms): four more rows in flight per trip, same order
     for (int j = 4; j < D; j += 4) {
-        const float4 y0 = p[(long)j * FV], y1 = p[(long)min(j + 1, D - 1) * FV], y2 = p[(long)min(j + 2, D - 1) * FV],
-                     y3 = p[(long)min(j + 3, D - 1) * FV];
+        float4 y0 = p[(long)j * FV], y1 = p[(long)min(j + 1, D - 1) * FV], y2 = p[(long)min(j + 2, D - 1) * FV],
+               y3 = p[(long)min(j + 3, D - 1) * FV];
+        if (aff != nullptr) {
+            y0 = aff4(y0, a_mu, a_sc, a_sh); y1 = aff4(y1, a_mu, a_sc, a_sh); y2 = aff4(y2, a_mu, a_sc, a_sh); y3 = aff4(y3, a_mu, a_sc, a_sh);
+        }
         I3D_AGG_ACC(y0);
         if (j + 1 < D) I3D_AGG_ACC(y1);
         if (j + 2 < D) I3D_AGG_ACC(y2);
@@ -195,7 +210,8 @@ __device__ __forceinline__ float& comp(T& a, int i) {
 template <int V, int MODE = 0>  // V = 4 (float4 items) or 1
 __global__ void __launch_bounds__(256)
 pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ e,
-                         const int* __restrict__ in_ptr, int N, int F, AggCfg cfg, float* __restrict__ ge) {
+                         const int* __restrict__ in_ptr, int N, int F, AggCfg cfg, float* __restrict__ ge,
+                         const float* __restrict__ aff) {
     const int FV = F / V;
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)N * FV) return;
@@ -281,6 +297,29 @@ pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict
             xr[jj][0] = p[row * F];
         }
     }
+    // messages as the forward saw them: (e - mean) * scale + shift (see pna_aggregate_fwd_kernel); the result is the
+    // gradient with respect to THAT value, the BatchNorm backward in front follows in its own kernel
+    float a_mu[V], a_sc[V], a_sh[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { a_mu[i] = 0.f; a_sc[i] = 1.f; a_sh[i] = 0.f; }
+    if (aff != nullptr) {
+        if (V == 4) {
+            const float4 m4 = *reinterpret_cast<const float4*>(aff + (long)c * 4);
+            const float4 s4 = *reinterpret_cast<const float4*>(aff + F + (long)c * 4);
+            const float4 h4 = *reinterpret_cast<const float4*>(aff + 2 * F + (long)c * 4);
+            a_mu[0] = m4.x; a_mu[1 % V] = m4.y; a_mu[2 % V] = m4.z; a_mu[3 % V] = m4.w;
+            a_sc[0] = s4.x; a_sc[1 % V] = s4.y; a_sc[2 % V] = s4.z; a_sc[3 % V] = s4.w;
+            a_sh[0] = h4.x; a_sh[1 % V] = h4.y; a_sh[2 % V] = h4.z; a_sh[3 % V] = h4.w;
+        } else {
+            a_mu[0] = aff[c]; a_sc[0] = aff[F + c]; a_sh[0] = aff[2 * F + c];
+        }
+    }
+    if (aff != nullptr) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int i = 0; i < V; ++i) xr[jj][i] = (xr[jj][i] - a_mu[i]) * a_sc[i] + a_sh[i];
+    }
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
         if (jj < D) {
@@ -304,6 +343,10 @@ pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict
                 xs[k][0] = xx.x; xs[k][1 % V] = xx.y; xs[k][2 % V] = xx.z; xs[k][3 % V] = xx.w;
             } else {
                 xs[k][0] = p[row * F];
+            }
+            if (aff != nullptr) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) xs[k][i] = (xs[k][i] - a_mu[i]) * a_sc[i] + a_sh[i];
             }
         }
 #pragma unroll
@@ -358,6 +401,10 @@ pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict
                 xs[k][0] = xx.x; xs[k][1 % V] = xx.y; xs[k][2 % V] = xx.z; xs[k][3 % V] = xx.w;
             } else {
                 xs[k][0] = p[row * F];
+            }
+            if (aff != nullptr) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) xs[k][i] = (xs[k][i] - a_mu[i]) * a_sc[i] + a_sh[i];
             }
         }
 #pragma unroll
@@ -429,6 +476,14 @@ using namespace i3d;
 extern "C" int i3d_pna_aggregate_fwd(const float* e, const int* in_ptr, int num_nodes, int feat,
                                      const int* aggregators, int n_aggregators, const int* scalers,
                                      int n_scalers, int force_scalers, float avg_d_log, float* out, void* stream) {
+    return i3d_pna_aggregate_fwd_aff(e, nullptr, in_ptr, num_nodes, feat, aggregators, n_aggregators, scalers, n_scalers,
+                                     force_scalers, avg_d_log, out, stream);
+}
+
+extern "C" int i3d_pna_aggregate_fwd_aff(const float* e, const float* aff, const int* in_ptr, int num_nodes, int feat,
+                                         const int* aggregators, int n_aggregators, const int* scalers,
+                                         int n_scalers, int force_scalers, float avg_d_log, float* out, void* stream) {
+    I3D_CHECK_ARG(aff == nullptr || (feat % 4 == 0 && (((uintptr_t)aff) & 15) == 0), "aff needs feat % 4 == 0 and 16-byte alignment");
     I3D_CHECK_ARG(num_nodes >= 0 && feat > 0, "num_nodes >= 0 and feat > 0 required");
     AggCfg cfg;
     I3D_CHECK_ARG(make_cfg(aggregators, n_aggregators, scalers, n_scalers, force_scalers, avg_d_log, cfg) == 0,
@@ -441,14 +496,14 @@ extern "C" int i3d_pna_aggregate_fwd(const float* e, const int* in_ptr, int num_
         dim3 grid(cdiv(items, 256));
         if (is_std_cfg(cfg))
             hipLaunchKernelGGL(pna_aggregate_fwd_kernel<1>, grid, dim3(256), 0, s, (const float4*)e, in_ptr,
-                               num_nodes, FV, cfg, (float4*)out);
+                               num_nodes, FV, cfg, (float4*)out, (const float4*)aff);
         else if (is_ident_cfg(cfg))      // (tried, not better back to back at batch 512: two items per lane 9.4 us vs 8.7 us;
             //                              one wavefront per node with scalar row-pointer loads 8.8 us vs 8.8 us)
             hipLaunchKernelGGL(pna_aggregate_fwd_kernel<2>, grid, dim3(256), 0, s, (const float4*)e, in_ptr,
-                               num_nodes, FV, cfg, (float4*)out);
+                               num_nodes, FV, cfg, (float4*)out, (const float4*)aff);
         else
             hipLaunchKernelGGL(pna_aggregate_fwd_kernel<0>, grid, dim3(256), 0, s, (const float4*)e, in_ptr,
-                               num_nodes, FV, cfg, (float4*)out);
+                               num_nodes, FV, cfg, (float4*)out, (const float4*)aff);
     } else {
         long items = (long)num_nodes * feat;
         hipLaunchKernelGGL(pna_aggregate_fwd_scalar_kernel, dim3(cdiv(items, 256)), dim3(256), 0, s, e, in_ptr,
@@ -461,6 +516,14 @@ extern "C" int i3d_pna_aggregate_fwd(const float* e, const int* in_ptr, int num_
 extern "C" int i3d_pna_aggregate_bwd(const float* grad_out, const float* e, const int* in_ptr, int num_nodes,
                                      int feat, const int* aggregators, int n_aggregators, const int* scalers,
                                      int n_scalers, int force_scalers, float avg_d_log, float* grad_e, void* stream) {
+    return i3d_pna_aggregate_bwd_aff(grad_out, e, nullptr, in_ptr, num_nodes, feat, aggregators, n_aggregators, scalers,
+                                     n_scalers, force_scalers, avg_d_log, grad_e, stream);
+}
+
+extern "C" int i3d_pna_aggregate_bwd_aff(const float* grad_out, const float* e, const float* aff, const int* in_ptr,
+                                         int num_nodes, int feat, const int* aggregators, int n_aggregators,
+                                         const int* scalers, int n_scalers, int force_scalers, float avg_d_log,
+                                         float* grad_e, void* stream) {
     I3D_CHECK_ARG(num_nodes >= 0 && feat > 0, "num_nodes >= 0 and feat > 0 required");
     AggCfg cfg;
     I3D_CHECK_ARG(make_cfg(aggregators, n_aggregators, scalers, n_scalers, force_scalers, avg_d_log, cfg) == 0,
@@ -471,17 +534,17 @@ extern "C" int i3d_pna_aggregate_bwd(const float* grad_out, const float* e, cons
         long items = (long)num_nodes * (feat / 4);
         if (is_std_cfg(cfg))
             hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 1>), dim3(cdiv(items, 256)), dim3(256), 0, s, grad_out, e, in_ptr,
-                               num_nodes, feat, cfg, grad_e);
+                               num_nodes, feat, cfg, grad_e, aff);
         else if (is_ident_cfg(cfg))
             hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 2>), dim3(cdiv(items, 256)), dim3(256), 0, s, grad_out, e, in_ptr,
-                               num_nodes, feat, cfg, grad_e);
+                               num_nodes, feat, cfg, grad_e, aff);
         else
             hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 0>), dim3(cdiv(items, 256)), dim3(256), 0, s, grad_out, e, in_ptr,
-                               num_nodes, feat, cfg, grad_e);
+                               num_nodes, feat, cfg, grad_e, aff);
     } else {
         long items = (long)num_nodes * feat;
         hipLaunchKernelGGL((pna_aggregate_bwd_kernel<1, 0>), dim3(cdiv(items, 256)), dim3(256), 0, s, grad_out, e, in_ptr,
-                           num_nodes, feat, cfg, grad_e);
+                           num_nodes, feat, cfg, grad_e, aff);
     }
     I3D_CHECK_LAUNCH();
     return I3D_OK;

@@ -27,6 +27,7 @@ using namespace i3d;
 // same arguments, same order per stream: results are bit-identical.  A fork or join costs the host ~7 us
 // (tools/probes/forkjoin_probe.hip), so a layer forks twice and joins once, and the stand-alone block entry points (heads,
 // the 3D network - whose stream has slack anyway) stay on one stream.  I3D_WGRAD_STREAM=0: off.
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -114,7 +115,12 @@ static int fc_bn_bwd_chain(const I3dFcArgs* a, void* stream) {
     return I3D_OK;
 }
 
-static int fc_bn_bwd_wgrad(const I3dFcArgs* a, void* wst) {
+// x_aff != null (fused BatchNorm): a->x is the RAW activation of the block in front, its BatchNorm output
+// (x - mean) * scale + shift was never materialised; the product is corrected in the slice reduction (gemm.hip)
+static int fc_bn_bwd_wgrad(const I3dFcArgs* a, void* wst, const float* x_aff = nullptr) {
+    if (x_aff != nullptr)
+        return i3d_gemm_f32_wgrad_bn(a->f_out, a->f_in, a->rows, a->grad_pre, a->f_out, a->x, a->f_in, a->grad_W, a->ldw,
+                                     a->grad_bias, x_aff, a->tail.gemm_workspace, a->tail.gemm_workspace_bytes, wst);
     return i3d_gemm_f32_ws(1, 0, a->f_out, a->f_in, a->rows, a->grad_pre, a->f_out, a->x, a->f_in, a->grad_W, a->ldw, nullptr, 0,
                            a->tail.gemm_workspace, a->tail.gemm_workspace_bytes, wst);
 }
@@ -190,7 +196,8 @@ static int edge_fc_bn_bwd_wgrad_q(const I3dEdgeFcArgs* a, void* wst) {
         TRY(i3d_gemm_f32_ws(1, 0, a->v_pad, Fo, E, a->onehot, a->v_pad, a->grad_pre, Fo, a->grad_Q, Fo, nullptr, 0, ws, wsb, wst));
         TRY(i3d_gemm_f32_ws(1, 0, Fo, a->f_q, V, a->grad_Q, Fo, a->q, a->f_q, a->grad_W + 2 * Fh, a->ldw, nullptr, 0, ws, wsb, wst));
         if (a->grad_q != nullptr)
-            TRY(i3d_gemm_f32(0, 0, V, a->f_q, Fo, a->grad_Q, Fo, a->W + 2 * Fh, a->ldw, a->grad_q, a->f_q, nullptr, 0, wst));
+            TRY(i3d_gemm_f32(0, 0, V, a->f_q, Fo, a->grad_Q, Fo, a->W + 2 * Fh, a->ldw, a->grad_q, a->f_q, nullptr,
+                             a->grad_q_accumulate, wst));
     } else if (a->q != nullptr) {
         TRY(i3d_gemm_f32_ws(1, 0, Fo, a->f_q, E, a->grad_pre, Fo, a->q, a->f_q, a->grad_W + 2 * Fh, a->ldw, nullptr, 0, ws, wsb, wst));
         if (a->grad_q != nullptr)
@@ -250,9 +257,79 @@ extern "C" int i3d_grouped_fc_bn_bwd(const I3dGroupedFcArgs* a, void* stream) {
 }
 
 // ---- one PNA layer ---------------------------------------------------------------------------------------
+// Fused-BatchNorm form of the layer (a->fused_bn, fused_bn.hip): the statistics of every block come out of the epilogue of
+// the kernel that produces its activation, the BatchNorm-apply of the pretrans blocks happens in the loads of their
+// consumers (next GEMM / aggregation kernel): per layer three statistics passes and two apply passes over [E, F] / [N, F]
+// tensors less than the block composites above, and edge.y / pre[i].y (the normalised activations) do not exist.  Only the
+// posttrans output - which the next layer gathers from - is materialised by i3d_bn_apply_fwd.
+static bool simple_act(int act) { return act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU; }
+
+static int finalize_stats(const I3dBnTail* t, const float* partial, int tiles, int feat, float* aff, void* stream) {
+    return i3d_bn_finalize_partials(partial, tiles, feat, t->eps, t->momentum, t->gamma, t->beta, t->mean, t->invstd,
+                                    t->running_mean, t->running_var, t->num_batches_tracked, aff, stream);
+}
+
+static int pna_layer_fwd_fused(const I3dPnaLayerArgs* a, void* stream) {
+    const I3dEdgeFcArgs* e = &a->edge;
+    const int Fh = e->f_h, Fo = e->f_out, N = e->num_nodes, E = e->num_edges;
+    I3D_CHECK_ARG(a->stats_ws != nullptr && a->n_post_extra == 0 && e->pre_keep == nullptr && simple_act(e->tail.act) &&
+                      e->tail.post_act == I3D_ACT_NONE && a->aff[0] != nullptr, "fused BatchNorm: unsupported block shape");
+    // edge block: P and Q as before, then gather-combine + activation + statistics in one pass
+    const long wdelta = (long)Fh - (long)Fo * e->ldw, wview = (long)(Fo - 1) * e->ldw + 2 * Fh;
+    TRY(i3d_gemm_f32_blocks(0, 1, N, 2 * Fo, Fh, e->h, Fh, e->W, e->ldw, Fo, wdelta, wview, e->P, 2 * Fo, 0, 0, 0, nullptr, 0,
+                            stream));
+    if (e->q != nullptr)
+        TRY(i3d_gemm_f32(0, 1, e->q_rows > 0 ? e->q_rows : E, Fo, e->f_q, e->q, e->f_q, e->W + 2 * Fh, e->ldw, e->Q, Fo,
+                         nullptr, 0, stream));
+    TRY(i3d_edge_combine_act_stats(e->P, 2 * Fo, e->q ? e->Q : nullptr, e->q_rows > 0 ? e->q_code : nullptr, e->bias, e->src_s,
+                                   e->dst_s, E, Fo, e->tail.act, e->xact, a->stats_ws, stream));
+    TRY(finalize_stats(&e->tail, a->stats_ws, cdiv(E, i3d_edge_stats_rows_per_tile(Fo)), Fo, a->aff[0], stream));
+    const float* x = e->xact;
+    const float* aff = a->aff[0];
+    int f_in = Fo;
+    for (int i = 0; i < a->n_pre_extra; ++i) {
+        const I3dFcArgs* c = &a->pre[i];
+        I3D_CHECK_ARG(c->pre_keep == nullptr && simple_act(c->tail.act) && c->tail.post_act == I3D_ACT_NONE &&
+                          a->aff[i + 1] != nullptr && c->rows == E && c->f_in == f_in, "fused BatchNorm: unsupported block shape");
+        // lin = BN_prev(x) W^T + b with the BatchNorm applied while x is staged; activation + statistics in the epilogue
+        TRY(i3d_gemm_f32_fused(E, c->f_out, f_in, x, f_in, E, c->W, c->ldw, c->xact, c->f_out, c->bias, 0, aff, c->tail.act,
+                               a->stats_ws, nullptr, nullptr, 0, stream));
+        TRY(finalize_stats(&c->tail, a->stats_ws, cdiv(E, 64), c->f_out, a->aff[i + 1], stream));
+        x = c->xact;
+        aff = a->aff[i + 1];
+        f_in = c->f_out;
+    }
+    if (a->agg_event_start != nullptr) hipEventRecord((hipEvent_t)a->agg_event_start, (hipStream_t)stream);
+    TRY(i3d_pna_aggregate_fwd_aff(x, aff, e->in_ptr, N, f_in, a->aggregators, a->n_aggregators, a->scalers, a->n_scalers,
+                                  a->force_scalers, a->avg_d_log, const_cast<float*>(a->post.agg), stream));
+    if (a->agg_event_stop != nullptr) hipEventRecord((hipEvent_t)a->agg_event_stop, (hipStream_t)stream);
+    // posttrans: lin = h W_h^T + b, += agg W_D^T per in-degree group with the statistics in that launch's epilogue (the
+    // degree groups cover every node - in-degree 0 included, with zero coefficients), then apply + residual
+    const I3dGroupedFcArgs* p = &a->post;
+    I3D_CHECK_ARG(p->pre_keep == nullptr && simple_act(p->tail.act), "fused BatchNorm: unsupported block shape");
+    const int A = p->agg_width, Fp = p->f_out;
+    TRY(i3d_gemm_f32(0, 1, N, Fp, p->f_h, p->h, p->f_h, p->W, p->ldw, p->xact, Fp, p->bias, 0, stream));
+    TRY(i3d_pna_combine_weights_fwd(p->W, p->ldw, p->f_h, Fp, A, p->n_groups, p->n_scalers, p->coef, p->WD, stream));
+    TRY(i3d_gemm_f32_fused(p->m_padded, Fp, A, p->agg, A, N, p->WD, A, p->xact, Fp, nullptr, 1, nullptr, p->tail.act,
+                           a->stats_ws, p->deg_rows, p->deg_tile_group, (long)Fp * A, stream));
+    TRY(finalize_stats(&p->tail, a->stats_ws, p->m_padded / 64, Fp, nullptr, stream));
+    return i3d_bn_apply_fwd(p->xact, N, Fp, p->tail.mean, p->tail.invstd, p->tail.gamma, p->tail.beta, p->tail.post_act,
+                            p->residual, p->y, stream);
+}
+
+extern "C" long i3d_pna_layer_stats_floats(int num_nodes, int num_edges, int m_padded, int f) {
+    (void)num_nodes;
+    const int rpt = i3d_edge_stats_rows_per_tile(f);
+    long tiles = cdiv(num_edges, rpt > 0 ? rpt : 1);
+    tiles = std::max<long>(tiles, cdiv(num_edges, 64));
+    tiles = std::max<long>(tiles, m_padded / 64 + 1);
+    return tiles * 3 * f;
+}
+
 extern "C" int i3d_pna_layer_fwd(const I3dPnaLayerArgs* a, void* stream) {
     I3D_CHECK_ARG(a != nullptr && a->n_pre_extra >= 0 && a->n_pre_extra <= I3D_MAX_EXTRA_FC && a->n_post_extra >= 0 &&
                       a->n_post_extra <= I3D_MAX_EXTRA_FC, "bad arguments");
+    if (a->fused_bn) return pna_layer_fwd_fused(a, stream);
     TRY(i3d_edge_fc_bn_fwd(&a->edge, stream));
     for (int i = 0; i < a->n_pre_extra; ++i) TRY(i3d_fc_bn_fwd(&a->pre[i], stream));
     if (a->agg_event_start != nullptr) hipEventRecord((hipEvent_t)a->agg_event_start, (hipStream_t)stream);
@@ -282,13 +359,18 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     void* wst = fork_wgrad(x, stream);
     TRY(grouped_fc_bn_bwd_wgrad(&a->post, wst));
     for (int i = a->n_post_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_wgrad(&a->postx[i], wst));
-    TRY(i3d_pna_aggregate_bwd(a->post.grad_agg, a->msg, a->edge.in_ptr, a->edge.num_nodes, a->edge.f_out, a->aggregators,
-                              a->n_aggregators, a->scalers, a->n_scalers, a->force_scalers, a->avg_d_log, a->grad_msg, stream));
+    // fused BatchNorm: a->msg is the last pretrans block's activation BEFORE its BatchNorm, applied on load (aff);
+    // pre[i].x / the aggregation read raw activations, so the weight gradients of pre[i] are corrected with aff[i]
+    const float* msg_aff = a->fused_bn ? a->aff[a->n_pre_extra] : nullptr;
+    const int f_msg = a->n_pre_extra > 0 ? a->pre[a->n_pre_extra - 1].f_out : a->edge.f_out;
+    TRY(i3d_pna_aggregate_bwd_aff(a->post.grad_agg, a->msg, msg_aff, a->edge.in_ptr, a->edge.num_nodes, f_msg, a->aggregators,
+                                  a->n_aggregators, a->scalers, a->n_scalers, a->force_scalers, a->avg_d_log, a->grad_msg,
+                                  stream));
     for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_chain(&a->pre[i], stream));
     TRY(edge_fc_bn_bwd_tail(&a->edge, stream));
     if (THREE_FORKS) {
         wst = fork_wgrad(x, stream);       // the later pretrans blocks' and everything behind dQ: they need grad_pre only
-        for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_wgrad(&a->pre[i], wst));
+        for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_wgrad(&a->pre[i], wst, a->fused_bn ? a->aff[i] : nullptr));
         TRY(edge_fc_bn_bwd_wgrad_q(&a->edge, wst));
         TRY(edge_fc_bn_bwd_sums(&a->edge, stream));
         wst = fork_wgrad(x, stream);
@@ -296,7 +378,7 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     } else {
         TRY(edge_fc_bn_bwd_sums(&a->edge, stream));
         wst = fork_wgrad(x, stream);
-        for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_wgrad(&a->pre[i], wst));
+        for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_wgrad(&a->pre[i], wst, a->fused_bn ? a->aff[i] : nullptr));
         TRY(edge_fc_bn_bwd_wgrad(&a->edge, wst));
     }
     TRY(edge_fc_bn_bwd_dgrad(&a->edge, stream, a->post.grad_h));       // post.grad_h += edge block's dh

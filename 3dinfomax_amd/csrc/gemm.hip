@@ -58,6 +58,13 @@ struct GemmArgs {
     float* slab;            // split-K / row segments: blockIdx.z slice z stores its partial tile to slab[z][M][N]
                             // (plain 16-byte stores), slab_reduce_kernel sums the slices in a fixed order: deterministic
                             // and cheaper than fp32 atomics on top of a zero-fill.  null: atomics.
+    // fused BatchNorm (FUSE variants of the forward layout only, see gemm_body):
+    const float* a_aff;     // [3K] mean | scale | shift: the A operand is read as (A[m][k] - mean[k]) * scale[k] + shift[k] -
+                            // the BatchNorm-apply of the block in front, folded into the LDS staging of the consumer
+    float* stats;           // [m tiles][3][N]: per 64-row tile and column {sum, M2 about the tile mean, row count} of the
+                            // values this launch stores (after bias / accumulate / epi_act): the BatchNorm statistics of
+                            // THIS block without a pass over its output (bn_finalize_partials_kernel combines the tiles)
+    int epi_act;            // activation applied to the stored value (I3D_ACT_*)
 };
 
 __device__ __forceinline__ int swz(int k, int idx) { return idx ^ ((((k) ^ (k >> 2)) & 1) << 4); }
@@ -137,6 +144,26 @@ struct TileStage {
         }
     }
 
+    // store for the fused BatchNorm-apply prologue (IM image of a k-contiguous operand): aff = LDS copy of [3][KP] mean |
+    // scale | shift (zeros beyond K, so out-of-range k stay finite and meet the zeros of the other operand)
+    __device__ __forceinline__ void store_aff(const Regs& r, float* __restrict__ T, const float* aff, int KP, int k0) const {
+        static_assert(IM, "affine prologue: idx-major image only");
+#pragma unroll
+        for (int it = 0; it < PER_THREAD; ++it) {
+            int s = threadIdx.x + it * NT;
+            if (s < SLOTS) {
+                const int idx = s / KQ, k = (s % KQ) * 4;
+                const int kg = min(k0 + k, KP - 4);
+                const float4 mu = *reinterpret_cast<const float4*>(aff + kg);
+                const float4 sc = *reinterpret_cast<const float4*>(aff + KP + kg);
+                const float4 sh = *reinterpret_cast<const float4*>(aff + 2 * KP + kg);
+                const float4 v = r.v[it];
+                *reinterpret_cast<float2*>(&T[idx * LDK + k]) = make_float2((v.x - mu.x) * sc.x + sh.x, (v.y - mu.y) * sc.y + sh.y);
+                *reinterpret_cast<float2*>(&T[idx * LDK + k + 2]) = make_float2((v.z - mu.z) * sc.z + sh.z, (v.w - mu.w) * sc.w + sh.w);
+            }
+        }
+    }
+
     __device__ __forceinline__ void store(const Regs& r, float* __restrict__ T) const {
 #pragma unroll
         for (int it = 0; it < PER_THREAD; ++it) {
@@ -197,7 +224,11 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz) {
     bz = w / (ny * nx);
 }
 
-template <class S, bool VEC, bool A_KC, bool B_KC, bool ROWS>
+// FUSE (forward layout, idx-major image, 64-row tiles only): bit 0 = BatchNorm-apply prologue on A (g.a_aff), bit 1 =
+// activation + per-tile column statistics of the stored values (g.epi_act, g.stats).  K <= FUSE_MAX_K for bit 0.
+constexpr int FUSE_MAX_K = 1024;
+
+template <class S, bool VEC, bool A_KC, bool B_KC, bool ROWS, int FUSE = 0>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int k_begin, const int k_end,
                                           float* __restrict__ Cout, const int* kidx, const bool first_split) {
     constexpr int MT = S::MT, WAVES_N = S::WAVES_N, WM_T = S::WM_T, WN_T = S::WN_T, BK = S::BK, PF = S::PF;
@@ -207,8 +238,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     constexpr bool A_IM = S::KP && A_KC && MT == 32, B_IM = S::KP && B_KC && MT == 32;
     typedef TileStage<BM, LDA, BK, A_KC, A_IM, S::NT> StageA;
     typedef TileStage<BN, LDB, BK, B_KC, B_IM, S::NT> StageB;
-    __shared__ __attribute__((aligned(16))) float As[2][StageA::LDS_FLOATS];
-    __shared__ __attribute__((aligned(16))) float Bs[2][StageB::LDS_FLOATS];
+    // one block of LDS: the operand double buffers, reused by the statistics epilogue as the [BM][BN + 1] output tile
+    constexpr int OPER_FLOATS = 2 * StageA::LDS_FLOATS + 2 * StageB::LDS_FLOATS;
+    constexpr int CT_PITCH = BN + 1;
+    constexpr int EPI_FLOATS = (FUSE & 2) ? BM * CT_PITCH + 2 * 4 * BN + BM : 0;
+    __shared__ __attribute__((aligned(16))) float smem[OPER_FLOATS > EPI_FLOATS ? OPER_FLOATS : EPI_FLOATS];
+    __shared__ __attribute__((aligned(16))) float affL[(FUSE & 1) ? 3 * FUSE_MAX_K : 4];
+    float* const As = smem;
+    float* const Bs = smem + 2 * StageA::LDS_FLOATS;
+    static_assert(FUSE == 0 || (A_IM && BM == 64), "fused variants: idx-major A image, 64-row tiles");
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -239,8 +277,18 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
         sa.template load<VEC, ROWS>(ra_[u], ra, g.a_bytes, g.lda, g.M, k_begin + u * BK, k_begin, k_end, kidx);
         sb.template load<VEC, ROWS>(rb_[u], rb, g.b_bytes, g.ldb, g.N, k_begin + u * BK, k_begin, k_end, kidx, g.b_split, g.b_delta);
     }
-    sa.store(ra_[0], As[0]);
-    sb.store(rb_[0], Bs[0]);
+    const int KP = (g.K + 3) & ~3;
+    if constexpr ((FUSE & 1) != 0) {          // per-k mean | scale | shift of the BatchNorm in front, zero-padded
+        for (int i = threadIdx.x; i < 3 * KP; i += S::NT) {
+            const int part = i / KP, k = i - part * KP;
+            affL[i] = k < g.K ? g.a_aff[part * g.K + k] : 0.f;
+        }
+        __syncthreads();
+        sa.store_aff(ra_[0], As, affL, KP, k_begin);
+    } else {
+        sa.store(ra_[0], As);
+    }
+    sb.store(rb_[0], Bs);
     __syncthreads();
     const int lt = lane % MT, lk = lane / MT;
     for (int kt = 0; kt < nk; kt += PF) {
@@ -253,8 +301,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
             sb.template load<VEC, ROWS>(rb_[u], rb, g.b_bytes, g.ldb, g.N, k_begin + (t + PF) * BK, k_begin, k_end, kidx, g.b_split,
                                         g.b_delta);
             if (t < nk) {
-                const float* as = As[cur];
-                const float* bs = Bs[cur];
+                const float* as = As + cur * StageA::LDS_FLOATS;
+                const float* bs = Bs + cur * StageB::LDS_FLOATS;
                 if constexpr (S::KP && MT == 32) {
                     // two k-steps per trip: lane half lk supplies k = 4 j + 2 lk (step 2j) and 4 j + 2 lk + 1 (step 2j+1)
 #pragma unroll
@@ -309,8 +357,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
                         }
                 }
             }
-            sa.store(ra_[(u + 1) % PF], As[cur ^ 1]);     // tile t+1 (zeros past the end)
-            sb.store(rb_[(u + 1) % PF], Bs[cur ^ 1]);
+            if constexpr ((FUSE & 1) != 0)
+                sa.store_aff(ra_[(u + 1) % PF], As + (cur ^ 1) * StageA::LDS_FLOATS, affL, KP, k_begin + (t + 1) * BK);
+            else
+                sa.store(ra_[(u + 1) % PF], As + (cur ^ 1) * StageA::LDS_FLOATS);     // tile t+1 (zeros past the end)
+            sb.store(rb_[(u + 1) % PF], Bs + (cur ^ 1) * StageB::LDS_FLOATS);
             __syncthreads();
         }
     }
@@ -319,17 +370,25 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     //   MT = 16: n = 4*(lane>>4) + 0..3 (one group);  MT = 32: n = 8*grp + 4*(lane>>5) + 0..3, grp = 0..3
     const bool add_bias = g.bias != nullptr && first_split;
     constexpr int GROUPS = (MT == 16) ? 1 : 4;
+    float* const Ct = smem;                               // statistics epilogue: [BM][CT_PITCH] stored values
+    float* const red = smem + BM * CT_PITCH;              // [2][4][BN]
+    float* const rvalid = red + 2 * 4 * BN;               // [BM] 1 / 0
 #pragma unroll
     for (int i = 0; i < WM_T; ++i) {
-        const int m = m0 + (wm * WM_T + i) * MT + lt;
-        if (m >= g.M) continue;
-        const int row = g.m_rows ? g.m_rows[m] : m;
+        const int ml = (wm * WM_T + i) * MT + lt;
+        const int m = m0 + ml;
+        int row = -1;
+        if (m < g.M) row = g.m_rows ? g.m_rows[m] : m;
+        if constexpr ((FUSE & 2) != 0) {
+            if (wn == 0 && lk == 0) rvalid[ml] = row >= 0 ? 1.f : 0.f;
+        }
         if (row < 0) continue;
 #pragma unroll
         for (int j = 0; j < WN_T; ++j) {
 #pragma unroll
             for (int grp = 0; grp < GROUPS; ++grp) {
-                const int n = n0 + (wn * WN_T + j) * MT + ((MT == 16) ? lk * 4 : 8 * grp + 4 * lk);
+                const int nl = (wn * WN_T + j) * MT + ((MT == 16) ? lk * 4 : 8 * grp + 4 * lk);
+                const int n = n0 + nl;
                 if (n >= g.N) continue;
                 float r[4] = {acc[i][j][4 * grp + 0], acc[i][j][4 * grp + 1], acc[i][j][4 * grp + 2], acc[i][j][4 * grp + 3]};
                 float* c = Cout + (long)row * g.ldc + n + (row >= g.c_split ? g.c_delta : 0);
@@ -338,6 +397,26 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (n + q < g.N) r[q] += g.bias[n + q];
+                }
+                if constexpr ((FUSE & 2) != 0) {
+                    // C (+)= ... then the activation; the stored values also go to the LDS tile for the column statistics
+                    if (g.accumulate) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (n + q < g.N) r[q] += c[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) r[q] = apply_act(r[q], g.epi_act);
+                    if (full && g.c_vec) {
+                        *reinterpret_cast<float4*>(c) = make_float4(r[0], r[1], r[2], r[3]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (n + q < g.N) c[q] = r[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Ct[ml * CT_PITCH + nl + q] = r[q];
+                    continue;
                 }
                 if (g.atomic_out) {
 #pragma unroll
@@ -356,6 +435,45 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
                         if (n + q < g.N) c[q] = g.accumulate ? c[q] + r[q] : r[q];
                 }
             }
+        }
+    }
+    if constexpr ((FUSE & 2) != 0) {
+        // per-tile column statistics: 4 row quarters x BN columns; sum -> tile mean -> M2 about it (no cancellation),
+        // every combination in a fixed order (deterministic)
+        static_assert(S::NT == 4 * BN, "statistics epilogue: four row quarters per column");
+        __syncthreads();
+        const int cl = threadIdx.x % BN, part = threadIdx.x / BN;
+        constexpr int RQ = BM / 4;
+        float x[RQ], v[RQ];
+        float s1 = 0.f, cnt = 0.f;
+#pragma unroll
+        for (int k = 0; k < RQ; ++k) {
+            const int ml = part * RQ + k;
+            v[k] = rvalid[ml];
+            x[k] = v[k] != 0.f ? Ct[ml * CT_PITCH + cl] : 0.f;
+            s1 += x[k];
+            cnt += v[k];
+        }
+        red[part * BN + cl] = s1;
+        red[4 * BN + part * BN + cl] = cnt;
+        __syncthreads();
+        const float tot = ((red[cl] + red[BN + cl]) + red[2 * BN + cl]) + red[3 * BN + cl];
+        const float n_rows = ((red[4 * BN + cl] + red[5 * BN + cl]) + red[6 * BN + cl]) + red[7 * BN + cl];
+        const float mean_t = n_rows > 0.f ? tot / n_rows : 0.f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < RQ; ++k) {
+            const float d = x[k] - mean_t;
+            if (v[k] != 0.f) m2 += d * d;
+        }
+        __syncthreads();
+        red[part * BN + cl] = m2;
+        __syncthreads();
+        if (part == 0 && n0 + cl < g.N) {
+            float* o = g.stats + (long)bx * 3 * g.N + n0 + cl;
+            o[0] = tot;
+            o[g.N] = ((red[cl] + red[BN + cl]) + red[2 * BN + cl]) + red[3 * BN + cl];
+            o[2 * g.N] = n_rows;
         }
     }
 }
@@ -407,6 +525,11 @@ struct SlabReduce {
     int c_split;       // rows >= c_split of C are displaced by c_delta floats (two-block outputs)
     long c_delta;
     int seg_ptr[34];
+    // weight gradient against a BatchNorm output that was never materialised (fused_bn.hip): the GEMM ran on the raw
+    // activation x, y = (x - mean) * scale + shift per column n, so  dW[m][n] = (sum - row[m] mean[n]) scale[n] + row[m] shift[n]
+    // with row[m] = sum over the rows of dY[:, m] (the bias gradient).  null: plain sum.
+    const float* post_aff;   // [3N] mean | scale | shift
+    const float* post_row;   // [M]
 };
 
 template <int V>
@@ -449,8 +572,24 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(SlabReduce a) {
 #pragma unroll
         for (int i = 0; i < V; ++i) acc[i] += a.bias[n + i];
     }
+    if (a.post_aff != nullptr) {
+        const float rw = a.post_row[m];
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+            acc[i] = (acc[i] - rw * a.post_aff[n + i]) * a.post_aff[a.N + n + i] + rw * a.post_aff[2 * a.N + n + i];
+    }
     if (V == 4) *reinterpret_cast<float4*>(c) = make_float4(acc[0], acc[1 % V], acc[2 % V], acc[3 % V]);
     else c[0] = acc[0];
+}
+
+// the same fix-up as a kernel of its own (the product did not go through the slab)
+__global__ void __launch_bounds__(256)
+wgrad_bn_fixup_kernel(float* __restrict__ C, int M, int N, int ldc, const float* __restrict__ aff, const float* __restrict__ row) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)M * N) return;
+    const int m = (int)(t / N), n = (int)(t - (long)m * N);
+    const float rw = row[m];
+    C[(long)m * ldc + n] = (C[(long)m * ldc + n] - rw * aff[n]) * aff[N + n] + rw * aff[2 * N + n];
 }
 
 // few outputs, many slices (the 20-wide 3D network: 400 outputs, ~270 slices): 16 lanes share the slices of one output
@@ -522,7 +661,7 @@ static void launch_slab_reduce(const SlabReduce& a, hipStream_t s) {
                     (((uintptr_t)a.C | (uintptr_t)a.slab) & 15) == 0;
     const long items = (long)a.n_groups * a.M * (v4 ? a.N / 4 : a.N);
     const int slices = a.seg_ptr[a.n_groups] - a.seg_ptr[0];
-    if (items <= 8192 && slices >= 4 * ZL) {
+    if (items <= 8192 && slices >= 4 * ZL && a.post_aff == nullptr) {
         dim3 grid(cdiv(items, 256 / ZL));
         if (v4) hipLaunchKernelGGL(slab_reduce_small_kernel<4>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(slab_reduce_small_kernel<1>, grid, dim3(256), 0, s, a);
@@ -588,6 +727,25 @@ gemm_f32_tt_kernel(GemmArgs g) {
     gemm_body<Cfg6, VEC, false, true, false>(g, blockIdx.x, blockIdx.y, 0, g.K, g.C, nullptr, true);
 }
 
+// forward layout (A and B k-contiguous, 16-byte loads) with the fused BatchNorm prologue / statistics epilogue
+template <class S, int FUSE>
+__global__ void __launch_bounds__(256)
+gemm_f32_fused_kernel(GemmArgs g) {
+    int bx, by, bz;
+    xcd_tile(bx, by, bz);
+    gemm_body<S, true, true, true, false, FUSE>(g, bx, by, 0, g.K, g.C, nullptr, true);
+}
+
+template <class S>
+static void launch_fused(const GemmArgs& g, int fuse, hipStream_t s) {
+    dim3 grid(cdiv(g.M, S::BM), cdiv(g.N, S::BN), 1), block(S::NT);
+    switch (fuse) {
+        case 1: hipLaunchKernelGGL((gemm_f32_fused_kernel<S, 1>), grid, block, 0, s, g); break;
+        case 2: hipLaunchKernelGGL((gemm_f32_fused_kernel<S, 2>), grid, block, 0, s, g); break;
+        default: hipLaunchKernelGGL((gemm_f32_fused_kernel<S, 3>), grid, block, 0, s, g); break;
+    }
+}
+
 struct Extra {
     const int* m_rows = nullptr;
     const int* k_rows = nullptr;
@@ -606,6 +764,8 @@ struct Extra {
     // two-block operands (GemmArgs::b_split ...); b_view_floats = addressable floats behind B when b_split is used
     int b_split = 0x7fffffff, c_split = 0x7fffffff;
     long b_delta = 0, c_delta = 0, b_view_floats = 0;
+    const float* post_aff = nullptr;   // SlabReduce::post_aff / post_row
+    const float* post_row = nullptr;
 };
 
 static int fill_views(GemmArgs& g, int trans_a, int trans_b, int M, int N, int K, int lda, int ldb, const Extra& ex) {
@@ -634,6 +794,7 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     g.accumulate = accumulate ? 1 : 0;
     g.m_rows = ex.m_rows; g.k_rows = nullptr; g.tile_group = ex.tile_group; g.b_group_stride = ex.b_group_stride;
     g.slab = nullptr;
+    g.a_aff = nullptr; g.stats = nullptr; g.epi_act = I3D_ACT_NONE;
     g.b_split = ex.b_split; g.b_delta = ex.b_delta; g.c_split = ex.c_split; g.c_delta = ex.c_delta;
     int rc = fill_views(g, trans_a, trans_b, M, N, K, lda, ldb, ex);
     if (rc != I3D_OK) return rc;
@@ -745,7 +906,12 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
         r.slab = g.slab; r.C = C; r.bias = bias; r.M = M; r.N = N; r.ldc = ldc; r.accumulate = accumulate ? 1 : 0;
         r.n_groups = 1; r.c_group_stride = 0; r.seg_ptr[0] = 0; r.seg_ptr[1] = splits;
         r.c_split = ex.c_split; r.c_delta = ex.c_delta;
+        r.post_aff = ex.post_aff; r.post_row = ex.post_row;
         launch_slab_reduce(r, s);
+        I3D_CHECK_LAUNCH();
+    } else if (ex.post_aff != nullptr) {
+        hipLaunchKernelGGL(wgrad_bn_fixup_kernel, dim3(cdiv((long)M * N, 256)), dim3(256), 0, s, C, M, N, ldc, ex.post_aff,
+                           ex.post_row);
         I3D_CHECK_LAUNCH();
     }
     return I3D_OK;
@@ -772,6 +938,7 @@ static int rowseg_impl(int M, int N, const float* A, int lda, const float* B, in
     g.accumulate = 1; g.atomic_out = 1; g.k_per_split = 0;
     g.m_rows = nullptr; g.k_rows = ex.k_rows; g.tile_group = nullptr; g.b_group_stride = 0;
     g.slab = nullptr;
+    g.a_aff = nullptr; g.stats = nullptr; g.epi_act = I3D_ACT_NONE;
     g.b_split = g.c_split = 0x7fffffff; g.b_delta = g.c_delta = 0;
     int rc = fill_views(g, 1, 0, M, N, k_hi, lda, ldb, ex);
     if (rc != I3D_OK) return rc;
@@ -854,6 +1021,7 @@ static int rowseg_impl(int M, int N, const float* A, int lda, const float* B, in
         r.slab = g.slab; r.C = C; r.bias = nullptr; r.M = M; r.N = N; r.ldc = ldc; r.accumulate = accumulate ? 1 : 0;
         r.n_groups = ex.n_groups; r.c_group_stride = ex.c_group_stride;
         r.c_split = 0x7fffffff; r.c_delta = 0;
+        r.post_aff = nullptr; r.post_row = nullptr;
         for (int gi = 0; gi < ex.n_groups; ++gi) r.seg_ptr[gi] = seg_first[gi];
         r.seg_ptr[ex.n_groups] = n_segs;
         launch_slab_reduce(r, s);
@@ -934,4 +1102,57 @@ extern "C" int i3d_gemm_f32_rowsubset_multi(int M, int N, int n_groups, const in
     ex.k_rows = k_rows; ex.k_rows_total = rows_total;
     ex.n_groups = n_groups; ex.group_start = group_start; ex.group_count = group_count; ex.c_group_stride = c_group_stride;
     return rowseg_impl(M, N, A, lda, B, ldb, C, ldc, accumulate, tile_cfg, seg_rows, ex, stream);
+}
+
+// C = act((op(A) W^T) + bias (+ C))  with the BatchNorm of the block in front applied to A on the fly (a_aff) and / or the
+// column statistics of the stored values produced per 64-row tile (stats): include/infomax3d_hip.h
+extern "C" int i3d_gemm_f32_fused(int M, int N, int K, const float* A, int lda, long a_rows_total, const float* W, int ldb,
+                                  float* C, int ldc, const float* bias, int accumulate, const float* a_aff, int epi_act,
+                                  float* stats, const int* m_rows, const int* tile_group, long b_group_stride,
+                                  void* stream) {
+    I3D_CHECK_ARG(M > 0 && N > 0 && K > 0, "empty GEMM");
+    I3D_CHECK_ARG(a_aff != nullptr || stats != nullptr, "nothing to fuse: use i3d_gemm_f32");
+    I3D_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "leading dimension too small");
+    I3D_CHECK_ARG(a_aff == nullptr || K <= FUSE_MAX_K, "BatchNorm prologue: K <= 1024");
+    I3D_CHECK_ARG((m_rows == nullptr) == (tile_group == nullptr), "grouped GEMM needs m_rows and tile_group");
+    I3D_CHECK_ARG(m_rows == nullptr || M % 64 == 0, "grouped GEMM needs 64-padded m_rows");
+    I3D_CHECK_ARG(epi_act == I3D_ACT_NONE || epi_act == I3D_ACT_RELU || epi_act == I3D_ACT_LEAKY_RELU || stats != nullptr,
+                  "epilogue activation needs the statistics variant");
+    const bool al = ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) == 0) && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 &&
+                    K % 4 == 0 && b_group_stride % 4 == 0;
+    I3D_CHECK_ARG(al, "fused GEMM needs 16-byte aligned operands and K, leading dimensions multiples of 4");
+    GemmArgs g;
+    g.A = A; g.B = W; g.C = C; g.bias = bias;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.accumulate = accumulate ? 1 : 0;
+    g.k_per_split = K; g.atomic_out = 0; g.c_vec = 1;
+    g.m_rows = m_rows; g.k_rows = nullptr; g.tile_group = tile_group; g.b_group_stride = b_group_stride;
+    g.b_split = g.c_split = 0x7fffffff; g.b_delta = g.c_delta = 0;
+    g.slab = nullptr;
+    g.a_aff = a_aff; g.stats = stats; g.epi_act = epi_act;
+    Extra ex;
+    ex.m_rows = m_rows; ex.a_rows_total = a_rows_total;
+    int rc = fill_views(g, 0, 1, M, N, K, lda, ldb, ex);
+    if (rc != I3D_OK) return rc;
+    const int fuse = (a_aff != nullptr ? 1 : 0) | (stats != nullptr ? 2 : 0);
+    hipStream_t s = (hipStream_t)stream;
+    // tile choice as in gemm_impl for the forward layout: 64x64 (idx-major image), 64x32 when K is long and N pads badly
+    const bool narrow = K >= 400 && (long)cdiv(N, 64) * 64 * 10 > (long)cdiv(N, 32) * 32 * 11;
+    if (narrow) launch_fused<Cfg11>(g, fuse, s);
+    else launch_fused<Cfg9>(g, fuse, s);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+// dW[f_out, f_in] = dY^T y  for  y = (x - mean) * scale + shift  (aff = mean | scale | shift over f_in) computed from the raw
+// x: the BatchNorm output y is never materialised (fused_bn.hip).  grad_bias[f_out] = column sums of dY.
+extern "C" int i3d_gemm_f32_wgrad_bn(int f_out, int f_in, int rows, const float* dY, int ldy, const float* x, int ldx,
+                                     float* dW, int ldw, const float* grad_bias, const float* aff, void* workspace,
+                                     long workspace_bytes, void* stream) {
+    I3D_CHECK_ARG(grad_bias != nullptr && aff != nullptr, "grad_bias and aff required");
+    Extra ex;
+    ex.workspace = workspace; ex.workspace_bytes = workspace_bytes;
+    ex.post_aff = aff; ex.post_row = grad_bias;
+    return gemm_impl(1, 0, f_out, f_in, rows, dY, ldy, x, ldx, dW, ldw, nullptr, 0, -1, 0, ex, stream);
 }

@@ -1,0 +1,435 @@
+// Whole-model host sequencing: the PNA forward / backward pass of a training step from ONE C call each.
+//
+// The step is ~270 kernel launches; measured on MI355X (tools/host_segments.py, tools/launch_floor.py) the launches
+// themselves cost the host ~0.8 ms per step, the Python around them (per-layer pointer arithmetic and ctypes struct fills,
+// the tape, ~20 small wrappers for encoders / readout / head, torch allocations) another ~1.8 ms - the step was bound by
+// the host, not by the GPU.  This file moves all of that below the C ABI: Python hands over the model description
+// (parameter / state / gradient pointers, built once per model), the batch description (sizes + index pointers) and two
+// buffers (saved activations, backward scratch); the memory layout, the argument structs of the layer composites
+// (composite.hip) and the launch order are computed here.  The kernels and their order are the ones the Python path
+// issues (fused-BatchNorm layer form, degree-grouped posttrans, bond table), the results are the same bits.
+//
+// Reference call chain replaced: PNA.forward -> PNAGNN.forward -> [PNALayer.forward]* -> readout -> MLP head
+// (models/pna.py:131-135, 161-166, 199-213, 127-129) and its autograd backward.
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace i3d;
+
+#define TRY(call)                 \
+    do {                          \
+        int rc_ = (call);         \
+        if (rc_ != I3D_OK) return rc_; \
+    } while (0)
+
+namespace {
+
+inline long al4(long n) { return (n + 3) & ~3L; }
+
+struct Bump {           // bump allocator over a caller-provided float buffer; base == null: sizing pass
+    float* base;
+    long used = 0;
+    explicit Bump(float* b) : base(b) {}
+    float* take(long n) {
+        float* p = base ? base + used : nullptr;
+        used += al4(n);
+        return p;
+    }
+};
+
+struct HeadSaved {
+    float* xact = nullptr;
+    float* y = nullptr;
+    float* mean = nullptr;
+    float* invstd = nullptr;
+};
+
+struct PnaCtx {
+    I3dPnaModel m;
+    I3dPnaBatch b;
+    std::vector<I3dPnaLayerArgs> layers;
+    std::vector<float*> h;          // h[0] = atom embedding, h[l + 1] = output of layer l (h[L] = the caller's node_emb)
+    float* bond_table = nullptr;    // [V, F]
+    int* codes = nullptr;           // [E]
+    float* onehot = nullptr;        // [E, v_pad]
+    float* readout = nullptr;       // [B, n_readout * F]
+    std::vector<HeadSaved> head;
+    std::vector<I3dFcArgs> head_args;
+    float* out = nullptr;           // [B, target]
+    float coef[128];
+    int n_scalers_cfg = 0;
+    long saved_floats = 0;
+};
+
+bool simple_act(int act) { return act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU; }
+
+void fill_tail(I3dBnTail& t, const I3dFcParams& p, float* mean, float* invstd) {
+    t.act = p.act;
+    t.post_act = I3D_ACT_NONE;
+    t.eps = p.eps;
+    t.momentum = p.momentum;
+    t.gamma = p.gamma;
+    t.beta = p.beta;
+    t.running_mean = p.running_mean;
+    t.running_var = p.running_var;
+    t.mean = mean;
+    t.invstd = invstd;
+    t.num_batches_tracked = p.num_batches_tracked;
+    t.workspace = nullptr;
+    t.gemm_workspace = nullptr;
+    t.gemm_workspace_bytes = 0;
+}
+
+void set_ws(I3dBnTail& t, void* bn_ws, void* gemm_ws, long gemm_ws_bytes) {
+    t.workspace = bn_ws;
+    t.gemm_workspace = gemm_ws;
+    t.gemm_workspace_bytes = gemm_ws_bytes;
+}
+
+// scaler coefficient of an in-degree group, reference models/pna.py:57-68 (np.log in float64, cast to fp32); D = 0: the
+// aggregate of a node without in-edges is a zero row, every coefficient 0
+float scaler_coef(int scaler, int D, float avg) {
+    if (D == 0) return 0.f;
+    if (scaler == I3D_SCALE_AMPLIFICATION) return (float)(std::log((double)D + 1.0) / (double)avg);
+    if (scaler == I3D_SCALE_ATTENUATION) return (float)((double)avg / std::log((double)D + 1.0));
+    return 1.f;
+}
+
+// dW = dY^T X as the Python-sequenced path issues it (ops.gemm): through the split-K scratch from 1024 rows on
+int wgrad(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, void* ws, long ws_bytes,
+          void* stream) {
+    if (K >= 1024) return i3d_gemm_f32_ws(1, 0, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, ws, ws_bytes, stream);
+    return i3d_gemm_f32(1, 0, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, stream);
+}
+
+int check_model(const I3dPnaModel* m, const I3dPnaBatch* b) {
+    I3D_CHECK_ARG(m != nullptr && b != nullptr, "null");
+    I3D_CHECK_ARG(m->n_layers >= 1 && m->n_layers <= I3D_MAX_LAYERS && m->n_pre >= 1 && m->n_pre <= I3D_MAX_EXTRA_FC + 1,
+                  "1..16 layers, 1..4 pretrans blocks");
+    I3D_CHECK_ARG(m->hidden > 0 && m->hidden % 4 == 0, "hidden_dim must be a multiple of 4");
+    I3D_CHECK_ARG(m->n_head >= 1 && m->n_head <= I3D_MAX_HEAD_FC && m->n_readout >= 1 && m->n_readout <= 4, "bad head");
+    I3D_CHECK_ARG(m->n_scalers >= 2 && m->n_scalers <= 4 && m->n_aggregators >= 1 && m->n_aggregators <= 8,
+                  "degree-grouped posttrans needs 2..4 scalers");
+    I3D_CHECK_ARG(b->num_nodes > 0 && b->num_edges > 0 && b->num_graphs > 0, "empty batch");
+    I3D_CHECK_ARG(b->n_groups >= 1 && b->n_groups <= 32 && b->n_groups * m->n_scalers <= 128 && b->m_padded % 64 == 0,
+                  "bad degree groups");
+    I3D_CHECK_ARG(b->n_comb >= 1 && b->v_pad >= b->n_comb && b->v_pad % 4 == 0, "bad bond table");
+    for (int l = 0; l < m->n_layers; ++l) {
+        for (int i = 0; i < m->n_pre; ++i) {
+            const I3dFcParams& p = m->pre[l][i];
+            I3D_CHECK_ARG(p.gamma != nullptr && simple_act(p.act) && p.f_out % 4 == 0 && p.f_in % 4 == 0 && p.f_in <= 3 * 1024,
+                          "pretrans block: BatchNorm, activation none / ReLU / LeakyReLU, widths multiples of 4");
+        }
+        const I3dFcParams& p = m->post[l];
+        I3D_CHECK_ARG(p.gamma != nullptr && simple_act(p.act) && p.f_out == m->hidden, "posttrans block");
+    }
+    return I3D_OK;
+}
+
+// Everything a forward pass keeps for the backward pass, laid out in `saved` (null: sizing).  Fills ctx.
+long plan_forward(PnaCtx& c, float* saved, float* node_emb, float* out) {
+    const I3dPnaModel& m = c.m;
+    const I3dPnaBatch& b = c.b;
+    const int N = b.num_nodes, E = b.num_edges, B = b.num_graphs, F = m.hidden, L = m.n_layers;
+    Bump ar(saved);
+    c.h.assign(L + 1, nullptr);
+    c.h[0] = ar.take((long)N * F);
+    c.bond_table = ar.take((long)b.n_comb * F);
+    c.codes = reinterpret_cast<int*>(ar.take(E));
+    c.onehot = ar.take((long)E * b.v_pad);
+    // per-degree scaler coefficients (shared by the layers)
+    c.n_scalers_cfg = m.n_scalers;
+    for (int g = 0; g < b.n_groups; ++g)
+        for (int s = 0; s < m.n_scalers; ++s) c.coef[g * m.n_scalers + s] = scaler_coef(m.scalers[s], b.group_degree[g], m.avg_d_log);
+    int f_max = F;
+    for (int l = 0; l < L; ++l)
+        for (int i = 0; i < m.n_pre; ++i) f_max = std::max(f_max, m.pre[l][i].f_out);
+    float* stats_ws = ar.take(i3d_pna_layer_stats_floats(N, E, b.m_padded, f_max));      // scratch, shared by all layers
+    c.layers.assign(L, I3dPnaLayerArgs());
+    for (int l = 0; l < L; ++l) {
+        I3dPnaLayerArgs& a = c.layers[l];
+        std::memset(&a, 0, sizeof(a));
+        a.fused_bn = 1;
+        a.stats_ws = stats_ws;
+        c.h[l + 1] = (l == L - 1) ? node_emb : ar.take((long)N * F);
+        // ---- pretrans block 0: edge gather-combine
+        I3dEdgeFcArgs& e = a.edge;
+        const I3dFcParams& p0 = m.pre[l][0];
+        const int Fo0 = p0.f_out;
+        fill_tail(e.tail, p0, ar.take(Fo0), ar.take(Fo0));
+        e.num_nodes = N; e.num_edges = E; e.f_h = F; e.f_q = F; e.f_out = Fo0; e.ldw = p0.f_in;
+        e.q_rows = b.n_comb; e.v_pad = b.v_pad; e.q_code = c.codes; e.onehot = c.onehot;
+        e.h = c.h[l]; e.q = c.bond_table; e.W = p0.W; e.bias = p0.bias;
+        e.src_s = b.src_s; e.dst_s = b.dst_s; e.in_ptr = b.in_ptr; e.out_ptr = b.out_ptr; e.out_epos = b.out_epos;
+        e.Q = ar.take((long)b.n_comb * Fo0);
+        e.P = ar.take((long)N * 2 * Fo0);
+        e.xact = ar.take((long)E * Fo0);
+        a.aff[0] = ar.take(3L * Fo0);
+        const float* x = e.xact;
+        int f_in = Fo0;
+        a.n_pre_extra = m.n_pre - 1;
+        for (int i = 1; i < m.n_pre; ++i) {
+            const I3dFcParams& p = m.pre[l][i];
+            I3dFcArgs& fc = a.pre[i - 1];
+            fill_tail(fc.tail, p, ar.take(p.f_out), ar.take(p.f_out));
+            fc.rows = E; fc.f_in = f_in; fc.f_out = p.f_out; fc.ldw = p.f_in;
+            fc.x = x; fc.W = p.W; fc.bias = p.bias;
+            fc.xact = ar.take((long)E * p.f_out);
+            a.aff[i] = ar.take(3L * p.f_out);
+            x = fc.xact;
+            f_in = p.f_out;
+        }
+        // ---- aggregation (identity block only: the scalers live in the per-degree weights)
+        a.n_aggregators = m.n_aggregators;
+        for (int i = 0; i < m.n_aggregators; ++i) a.aggregators[i] = m.aggregators[i];
+        a.n_scalers = 1; a.scalers[0] = I3D_SCALE_IDENTITY; a.force_scalers = 0; a.avg_d_log = m.avg_d_log;
+        a.msg = x;
+        const int A = m.n_aggregators * f_in;
+        // ---- posttrans: degree-grouped block
+        I3dGroupedFcArgs& g = a.post;
+        const I3dFcParams& pp = m.post[l];
+        fill_tail(g.tail, pp, ar.take(F), ar.take(F));
+        g.num_nodes = N; g.f_h = F; g.f_out = F; g.agg_width = A; g.ldw = pp.f_in;
+        g.n_groups = b.n_groups; g.n_scalers = m.n_scalers; g.m_padded = b.m_padded;
+        for (int k = 0; k < b.n_groups; ++k) { g.group_start[k] = b.group_start[k]; g.group_count[k] = b.group_count[k]; }
+        for (int k = 0; k < b.n_groups * m.n_scalers; ++k) g.coef[k] = c.coef[k];
+        g.h = c.h[l]; g.W = pp.W; g.bias = pp.bias;
+        g.agg = ar.take((long)N * A);
+        g.deg_rows = b.deg_rows; g.deg_tile_group = b.deg_tile_group;
+        g.WD = ar.take((long)b.n_groups * F * A);
+        g.xact = ar.take((long)N * F);
+        g.y = c.h[l + 1];
+        a.n_post_extra = 0;
+        a.residual = m.residual ? 1 : 0;
+        g.residual = m.residual ? c.h[l] : nullptr;
+    }
+    // ---- readout + head
+    c.readout = ar.take((long)B * m.n_readout * F);
+    c.head.assign(m.n_head, HeadSaved());
+    c.head_args.assign(m.n_head, I3dFcArgs());
+    const float* x = c.readout;
+    for (int i = 0; i < m.n_head; ++i) {
+        const I3dFcParams& p = m.head[i];
+        I3dFcArgs& fc = c.head_args[i];
+        std::memset(&fc, 0, sizeof(fc));
+        const bool last = i == m.n_head - 1;
+        float* y = last ? out : ar.take((long)B * p.f_out);
+        fc.rows = B; fc.f_in = p.f_in; fc.f_out = p.f_out; fc.ldw = p.f_in;
+        fc.x = x; fc.W = p.W; fc.bias = p.bias; fc.y = y;
+        if (p.gamma != nullptr) {
+            c.head[i].mean = ar.take(p.f_out);
+            c.head[i].invstd = ar.take(p.f_out);
+            fill_tail(fc.tail, p, c.head[i].mean, c.head[i].invstd);
+            fc.xact = ar.take((long)B * p.f_out);
+            if (!simple_act(p.act)) fc.pre_keep = ar.take((long)B * p.f_out);
+        } else if (p.act != I3D_ACT_NONE) {
+            fc.xact = ar.take((long)B * p.f_out);        // pre-activation, kept for the activation's derivative
+        }
+        c.head[i].xact = fc.xact;
+        c.head[i].y = y;
+        x = y;
+    }
+    c.out = out;
+    c.saved_floats = ar.used;
+    return ar.used;
+}
+
+}  // namespace
+
+extern "C" long i3d_pna_model_saved_floats(const I3dPnaModel* m, const I3dPnaBatch* b) {
+    if (check_model(m, b) != I3D_OK) return -1;
+    PnaCtx c;
+    c.m = *m;
+    c.b = *b;
+    return plan_forward(c, nullptr, nullptr, nullptr);
+}
+
+extern "C" long i3d_pna_model_scratch_floats(const I3dPnaModel* m, const I3dPnaBatch* b) {
+    if (check_model(m, b) != I3D_OK) return -1;
+    // mirrors the takes of i3d_pna_model_bwd
+    const long N = b->num_nodes, E = b->num_edges, B = b->num_graphs, F = m->hidden;
+    const long top = 2 * al4(N * F) + al4((long)b->n_comb * F);
+    long head = 0;
+    for (int i = 0; i < m->n_head; ++i) head += al4(B * (long)m->head[i].f_in) + al4(B * (long)m->head[i].f_out);
+    long layer = 0;
+    for (int l = 0; l < m->n_layers; ++l) {
+        const long f_msg = m->pre[l][m->n_pre - 1].f_out, A = m->n_aggregators * f_msg, Fo0 = m->pre[l][0].f_out;
+        long t = al4(N * F) + al4((long)b->n_groups * F * A) + al4(N * A) + al4(E * f_msg);
+        for (int i = 1; i < m->n_pre; ++i) t += al4(E * (long)m->pre[l][i].f_out) + al4(E * (long)m->pre[l][i].f_in);
+        t += al4(E * Fo0) + al4(N * 2 * Fo0) + al4(N * F) + al4((long)b->v_pad * Fo0);
+        layer = std::max(layer, t);
+    }
+    long oa = 0, ob = 0;
+    for (int k = 0; k < m->n_atom_tables; ++k) oa += m->atom_dims[k];
+    for (int k = 0; k < m->n_bond_tables; ++k) ob += m->bond_dims[k];
+    const long emb = al4(N * ((oa + 31) / 32 * 32)) + al4((long)b->n_comb * ((ob + 31) / 32 * 32));
+    return top + std::max(std::max(head, layer), emb);
+}
+
+extern "C" int i3d_pna_model_fwd(const I3dPnaModel* m, const I3dPnaBatch* b, float* saved, float* node_emb, float* edge_emb,
+                                 float* out, void* bn_workspace, void* const* agg_events, void* stream, void** ctx_out) {
+    TRY(check_model(m, b));
+    I3D_CHECK_ARG(saved != nullptr && node_emb != nullptr && out != nullptr && bn_workspace != nullptr && ctx_out != nullptr,
+                  "null buffer");
+    PnaCtx* c = new (std::nothrow) PnaCtx();
+    I3D_CHECK_ARG(c != nullptr, "out of host memory");
+    c->m = *m;
+    c->b = *b;
+    plan_forward(*c, saved, node_emb, out);
+    *ctx_out = c;
+    const int N = b->num_nodes, E = b->num_edges, B = b->num_graphs, F = m->hidden, L = m->n_layers;
+    // ---- encoders (reference commons/mol_encoder.py:34-42, 65-73; models/pna.py:162-163)
+    TRY(i3d_embedding_sum_fwd(b->atom_feat, nullptr, N, m->n_atom_tables, m->atom_tables, F, c->h[0], stream));
+    TRY(i3d_embedding_sum_fwd(b->comb, nullptr, b->n_comb, m->n_bond_tables, m->bond_tables, F, c->bond_table, stream));
+    int strides[8], s = 1;
+    for (int k = 0; k < m->n_bond_tables; ++k) { strides[k] = s; s *= m->bond_dims[k]; }
+    TRY(i3d_edge_codes(b->bond_feat, b->perm, E, m->n_bond_tables, strides, b->v_pad, c->codes, c->onehot, stream));
+    // ---- message passing layers
+    for (int l = 0; l < L; ++l) {
+        I3dPnaLayerArgs& a = c->layers[l];
+        set_ws(a.edge.tail, bn_workspace, nullptr, 0);
+        for (int i = 0; i < a.n_pre_extra; ++i) set_ws(a.pre[i].tail, bn_workspace, nullptr, 0);
+        set_ws(a.post.tail, bn_workspace, nullptr, 0);
+        a.agg_event_start = agg_events ? agg_events[2 * l] : nullptr;
+        a.agg_event_stop = agg_events ? agg_events[2 * l + 1] : nullptr;
+        TRY(i3d_pna_layer_fwd(&a, stream));
+        a.agg_event_start = a.agg_event_stop = nullptr;
+    }
+    // reference side effect (models/pna.py:163): edata['feat'] becomes the float bond embedding, edge-id order
+    if (edge_emb != nullptr)
+        TRY(i3d_embedding_sum_fwd(b->bond_feat, nullptr, E, m->n_bond_tables, m->bond_tables, F, edge_emb, stream));
+    // ---- readout + head (models/pna.py:133-134, 127-129)
+    TRY(i3d_segment_readout_fwd(c->h[L], b->graph_ptr, B, F, m->readout_ops, m->n_readout, c->readout, stream));
+    for (int i = 0; i < m->n_head; ++i) {
+        I3dFcArgs& fc = c->head_args[i];
+        const I3dFcParams& p = m->head[i];
+        if (p.gamma != nullptr) {
+            set_ws(fc.tail, bn_workspace, nullptr, 0);
+            TRY(i3d_fc_bn_fwd(&fc, stream));
+        } else if (p.act != I3D_ACT_NONE) {
+            TRY(i3d_gemm_f32(0, 1, B, p.f_out, p.f_in, fc.x, p.f_in, p.W, p.f_in, fc.xact, p.f_out, p.bias, 0, stream));
+            TRY(i3d_act_fwd(fc.xact, (long)B * p.f_out, p.act, fc.y, stream));
+        } else {
+            TRY(i3d_gemm_f32(0, 1, B, p.f_out, p.f_in, fc.x, p.f_in, p.W, p.f_in, fc.y, p.f_out, p.bias, 0, stream));
+        }
+    }
+    return I3D_OK;
+}
+
+extern "C" int i3d_pna_model_bwd(void* ctx, const I3dPnaModel* grads_from, const float* grad_out, float* scratch,
+                                 void* bn_workspace, void* gemm_workspace, long gemm_workspace_bytes, void* stream) {
+    I3D_CHECK_ARG(ctx != nullptr && grad_out != nullptr && scratch != nullptr && bn_workspace != nullptr, "null");
+    PnaCtx* c = static_cast<PnaCtx*>(ctx);
+    if (grads_from != nullptr) {       // the gradient buffers are chosen at backward time: take them (same model otherwise)
+        I3D_CHECK_ARG(grads_from->n_layers == c->m.n_layers && grads_from->n_pre == c->m.n_pre &&
+                          grads_from->n_head == c->m.n_head && grads_from->hidden == c->m.hidden, "different model");
+        c->m = *grads_from;
+    }
+    const I3dPnaModel& m = c->m;
+    I3D_CHECK_ARG(m.grad_atom_tables != nullptr && m.grad_bond_tables != nullptr && m.post[0].grad_W != nullptr,
+                  "gradient buffers not set");
+    const I3dPnaBatch& b = c->b;
+    const int N = b.num_nodes, E = b.num_edges, B = b.num_graphs, F = m.hidden, L = m.n_layers;
+    Bump top(scratch);
+    float* gh[2] = {top.take((long)N * F), top.take((long)N * F)};      // dL/dh, ping-pong between layers
+    float* grad_table = top.take((long)b.n_comb * F);                  // dL/d(bond table), summed over the layers
+    float* const rest = scratch + top.used;
+    // ---- head, last block first
+    {
+        Bump ar(rest);
+        const float* gy = grad_out;
+        for (int i = m.n_head - 1; i >= 0; --i) {
+            I3dFcArgs& fc = c->head_args[i];
+            const I3dFcParams& p = m.head[i];
+            float* gx = ar.take((long)B * p.f_in);
+            if (p.gamma != nullptr) {
+                set_ws(fc.tail, bn_workspace, gemm_workspace, gemm_workspace_bytes);
+                fc.grad_y = gy; fc.grad_pre = ar.take((long)B * p.f_out); fc.grad_x = gx;
+                fc.grad_W = p.grad_W; fc.grad_bias = p.grad_bias; fc.grad_gamma = p.grad_gamma; fc.grad_beta = p.grad_beta;
+                TRY(i3d_fc_bn_bwd(&fc, stream));
+            } else {
+                const float* gpre = gy;
+                if (p.act != I3D_ACT_NONE) {
+                    float* t = ar.take((long)B * p.f_out);
+                    TRY(i3d_act_bwd(gy, fc.xact, (long)B * p.f_out, p.act, t, stream));
+                    gpre = t;
+                }
+                TRY(i3d_gemm_f32(0, 0, B, p.f_in, p.f_out, gpre, p.f_out, p.W, p.f_in, gx, p.f_in, nullptr, 0, stream));
+                TRY(wgrad(p.f_out, p.f_in, B, gpre, p.f_out, fc.x, p.f_in, p.grad_W, p.f_in, gemm_workspace,
+                          gemm_workspace_bytes, stream));
+                TRY(i3d_colsum(gpre, nullptr, B, p.f_out, p.grad_bias, bn_workspace, stream));
+            }
+            gy = gx;
+        }
+        // readout backward -> dL/dh_L
+        TRY(i3d_segment_readout_bwd(gy, c->h[L], b.graph_ptr, B, F, m.readout_ops, m.n_readout, gh[L & 1], stream));
+    }
+    // ---- layers, last first
+    for (int l = L - 1; l >= 0; --l) {
+        I3dPnaLayerArgs& a = c->layers[l];
+        Bump ar(rest);
+        const float* grad_in = gh[(l + 1) & 1];
+        a.grad_out = grad_in;
+        I3dGroupedFcArgs& g = a.post;
+        const I3dFcParams& pp = m.post[l];
+        set_ws(g.tail, bn_workspace, gemm_workspace, gemm_workspace_bytes);
+        g.grad_W = pp.grad_W; g.grad_bias = pp.grad_bias; g.grad_gamma = pp.grad_gamma; g.grad_beta = pp.grad_beta;
+        g.grad_y = grad_in;
+        g.grad_pre = ar.take((long)N * F);
+        g.grad_WD = ar.take((long)b.n_groups * F * g.agg_width);
+        g.grad_h = gh[l & 1];
+        g.grad_agg = ar.take((long)N * g.agg_width);
+        const int f_msg = a.n_pre_extra > 0 ? a.pre[a.n_pre_extra - 1].f_out : a.edge.f_out;
+        a.grad_msg = ar.take((long)E * f_msg);
+        const float* gy = a.grad_msg;
+        for (int i = a.n_pre_extra - 1; i >= 0; --i) {
+            I3dFcArgs& fc = a.pre[i];
+            const I3dFcParams& p = m.pre[l][i + 1];
+            set_ws(fc.tail, bn_workspace, gemm_workspace, gemm_workspace_bytes);
+            fc.grad_W = p.grad_W; fc.grad_bias = p.grad_bias; fc.grad_gamma = p.grad_gamma; fc.grad_beta = p.grad_beta;
+            fc.grad_y = gy;
+            fc.grad_pre = ar.take((long)E * fc.f_out);
+            fc.grad_x = ar.take((long)E * fc.f_in);
+            gy = fc.grad_x;
+        }
+        I3dEdgeFcArgs& e = a.edge;
+        const I3dFcParams& p0 = m.pre[l][0];
+        set_ws(e.tail, bn_workspace, gemm_workspace, gemm_workspace_bytes);
+        e.grad_W = p0.grad_W; e.grad_bias = p0.grad_bias; e.grad_gamma = p0.grad_gamma; e.grad_beta = p0.grad_beta;
+        e.grad_y = gy;
+        e.grad_pre = ar.take((long)E * e.f_out);
+        e.grad_P = ar.take((long)N * 2 * e.f_out);
+        e.grad_h = ar.take((long)N * F);
+        e.grad_Q = ar.take((long)b.v_pad * e.f_out);
+        e.grad_q = grad_table;
+        e.grad_q_accumulate = (l == L - 1) ? 0 : 1;        // the bond table feeds every layer: its gradient is their sum
+        TRY(i3d_pna_layer_bwd(&a, stream));
+    }
+    // ---- encoders: embedding-table gradients as multi-hot^T dY (deterministic, csrc/edge.hip: multihot_kernel)
+    {
+        Bump ar(rest);
+        int offs[16], o = 0;
+        for (int k = 0; k < m.n_atom_tables; ++k) { offs[k] = o; o += m.atom_dims[k]; }
+        const int va = (o + 31) / 32 * 32;
+        float* hot = ar.take((long)N * va);
+        TRY(i3d_multihot(b.atom_feat, nullptr, N, m.n_atom_tables, offs, va, hot, stream));
+        TRY(wgrad(o, F, N, hot, va, gh[0], F, m.grad_atom_tables, F, gemm_workspace, gemm_workspace_bytes, stream));
+        o = 0;
+        for (int k = 0; k < m.n_bond_tables; ++k) { offs[k] = o; o += m.bond_dims[k]; }
+        const int vb = (o + 31) / 32 * 32;
+        float* hotb = ar.take((long)b.n_comb * vb);
+        TRY(i3d_multihot(b.comb, nullptr, b.n_comb, m.n_bond_tables, offs, vb, hotb, stream));
+        TRY(wgrad(o, F, b.n_comb, hotb, vb, grad_table, F, m.grad_bond_tables, F, gemm_workspace, gemm_workspace_bytes, stream));
+    }
+    return I3D_OK;
+}
+
+extern "C" int i3d_pna_model_ctx_free(void* ctx) {
+    delete static_cast<PnaCtx*>(ctx);
+    return I3D_OK;
+}

@@ -109,7 +109,7 @@ class FlatMolDataset:
             put(a)                                         # s_in, s_perm, s_src, s_dst, s_out, s_oe, s_gp, s_inv
         i64 = np.concatenate([src, dst, self.atom_feat[ngi].ravel(), self.bond_feat[egi].ravel()])
         indeg = self.indeg[ngi]
-        rows, tiles, groups = group_nodes_by_degree(indeg)
+        rows, tiles, groups = group_nodes_by_degree(indeg, include_zero=True)
         return {'i32': torch.from_numpy(i32), 'i64': torch.from_numpy(i64), 'f32': torch.from_numpy(self.coords[ngi]),
                 'n': torch.from_numpy(n), 'rows': torch.from_numpy(rows), 'tiles': torch.from_numpy(tiles),
                 'groups': groups, 'cuts': cuts, 'dims': (B, N, E), 'max_indeg': int(indeg.max()) if E else 0}

@@ -37,7 +37,7 @@ class GraphIndex:
     # nodes grouped by in-degree (degree-combined posttrans weights, csrc/grouped.hip); built lazily by degree_groups()
     deg_rows: Optional[torch.Tensor] = None        # [M_pad] node ids grouped by in-degree, each group padded to 64 with -1
     deg_tile_group: Optional[torch.Tensor] = None  # [M_pad/64] group of every 64-row tile
-    deg_groups: Optional[tuple] = None             # host: ((D, start, count), ...) for the in-degrees D > 0 present
+    deg_groups: Optional[tuple] = None             # host: ((D, start, count), ...) for the in-degrees present (0 included)
 
     def to(self, device):
         out = GraphIndex(self.num_nodes, self.num_edges, self.num_graphs,
@@ -55,7 +55,7 @@ class GraphIndex:
         batch was not assembled through build_index / dataset.assemble, which fill them in on the host)."""
         if self.deg_rows is None:
             indeg = np.diff(self.in_ptr.cpu().numpy().astype(np.int64))
-            rows, tiles, groups = group_nodes_by_degree(indeg)
+            rows, tiles, groups = group_nodes_by_degree(indeg, include_zero=True)
             dev = self.in_ptr.device
             self.deg_rows = torch.from_numpy(rows).to(dev)
             self.deg_tile_group = torch.from_numpy(tiles).to(dev)
@@ -63,12 +63,15 @@ class GraphIndex:
         return self.deg_rows, self.deg_tile_group, self.deg_groups
 
 
-def group_nodes_by_degree(indeg, pad=64):
-    """Node ids grouped by in-degree D > 0 (ascending D, ascending node id), every group padded with -1 to a multiple of
-    `pad` rows; tile -> group map; ((D, start, count), ...)."""
+def group_nodes_by_degree(indeg, pad=64, include_zero=False):
+    """Node ids grouped by in-degree (ascending D, ascending node id), every group padded with -1 to a multiple of
+    `pad` rows; tile -> group map; ((D, start, count), ...).  `include_zero`: nodes without in-edges form a group of their
+    own (D = 0, scaler coefficients 0: their aggregate is a zero row) so that the groups cover EVERY node - what the batch
+    index carries, because the fused posttrans GEMM takes its BatchNorm statistics from the grouped launch's epilogue."""
     indeg = np.asarray(indeg, dtype=np.int64)
     order = np.argsort(indeg, kind='stable')
-    order = order[indeg[order] > 0]
+    if not include_zero:
+        order = order[indeg[order] > 0]
     degs, counts = np.unique(indeg[order], return_counts=True)
     padded = (counts + pad - 1) // pad * pad
     starts = np.cumsum(padded) - padded
@@ -100,7 +103,7 @@ def build_index(src, dst, num_nodes, batch_num_nodes) -> GraphIndex:
     inv_perm = np.empty(E, dtype=np.int64)
     inv_perm[perm] = np.arange(E)
     i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.int32)))
-    rows, tiles, groups = group_nodes_by_degree(indeg)
+    rows, tiles, groups = group_nodes_by_degree(indeg, include_zero=True)
     return GraphIndex(int(num_nodes), int(E), int(bnn.shape[0]), i32(in_ptr), i32(perm), i32(src_s),
                       i32(dst_s), i32(out_ptr), i32(out_epos), i32(graph_ptr), i32(inv_perm),
                       int(indeg.max()) if E else 0, torch.from_numpy(rows), torch.from_numpy(tiles), groups)

@@ -19,6 +19,26 @@ from .layers import _keeps_pre, _set_workspaces
 
 # I3D_NATIVE_LAYER=0: the layer as four block composites sequenced from Python (pna.PNALayerFn)
 NATIVE_LAYER = os.environ.get('I3D_NATIVE_LAYER', '1') != '0'
+# I3D_FUSED_BN=0: round-1 form of the layer (statistics pass + apply pass per block); default: BatchNorm statistics in the
+# producers' epilogues, BatchNorm-apply in the consumers' loads (csrc/fused_bn.hip).  Same arithmetic up to summation order.
+FUSED_BN = os.environ.get('I3D_FUSED_BN', '1') != '0'
+_SIMPLE_ACTS = (None, 'relu', 'leakyrelu')
+KEEP_LAST_ARGS = None
+
+
+def fused_bn_ok(plan, params, n_pre, n_post):
+    if not FUSED_BN or n_post != 1:
+        return False
+    for spec in plan.pre_specs + plan.post_specs[:1]:
+        if spec.act not in _SIMPLE_ACTS:
+            return False
+    for spec in plan.pre_specs:
+        if spec.post_act is not None:
+            return False
+    for i in range(1, n_pre):          # BatchNorm prologue of the GEMM: K <= 1024
+        if params[4 * i].shape[1] > 1024:
+            return False
+    return True
 
 
 def _al(n):
@@ -91,11 +111,18 @@ def forward(ctx, h, q, index, qmap, plan, params):
     A = len(plan.aggregators) * Fmsg
     Fp0 = post_p[0][0].shape[0]
 
+    fused = fused_bn_ok(plan, params, n_pre, n_post)
+    L = _lib.load()
     # ---- size of the saved/scratch buffer
     total = _al(N * 2 * Fo0) + (_al((q_rows or E) * Fo0) if q is not None else 0)
     for i, spec in enumerate(plan.pre_specs):
         Fo = pre_p[i][0].shape[0]
-        total += _al(E * Fo) * (2 + (1 if _keeps_pre(spec) else 0)) + 2 * _al(Fo)
+        total += _al(E * Fo) * ((1 if fused else 2) + (1 if _keeps_pre(spec) else 0)) + 2 * _al(Fo) + (_al(3 * Fo) if fused else 0)
+    n_stats = 0
+    if fused:
+        f_max = max([pp[0].shape[0] for pp in pre_p] + [Fp0])
+        n_stats = int(L.i3d_pna_layer_stats_floats(N, E, rows_d.shape[0], f_max))
+        total += _al(n_stats)
     total += _al(N * A) + _al(nG * Fp0 * A)
     for i, spec in enumerate(plan.post_specs):
         Fo = post_p[i][0].shape[0]
@@ -105,6 +132,9 @@ def forward(ctx, h, q, index, qmap, plan, params):
     y_out = torch.empty(N, Fout, dtype=torch.float32, device=dev)
 
     a = _lib.PnaLayerArgs()
+    if fused:
+        a.fused_bn = 1
+        a.stats_ws = ar.take(n_stats)
     # ---- pretrans block 0: edge gather-combine
     e = a.edge
     W, b, ga, be = pre_p[0]
@@ -123,8 +153,12 @@ def forward(ctx, h, q, index, qmap, plan, params):
     e.xact = ar.take(E * Fo0)
     if _keeps_pre(spec):
         e.pre_keep = ar.take(E * Fo0)
-    e.y = ar.take(E * Fo0)
-    x_ptr, f_in = e.y, Fo0
+    if fused:              # the normalised activation is never written: the consumer applies aff while it loads xact
+        a.aff[0] = ar.take(3 * Fo0)
+        x_ptr, f_in = e.xact, Fo0
+    else:
+        e.y = ar.take(E * Fo0)
+        x_ptr, f_in = e.y, Fo0
     # ---- further pretrans blocks
     a.n_pre_extra = n_pre - 1
     for i in range(1, n_pre):
@@ -138,8 +172,12 @@ def forward(ctx, h, q, index, qmap, plan, params):
         c.xact = ar.take(E * Fo)
         if _keeps_pre(spec):
             c.pre_keep = ar.take(E * Fo)
-        c.y = ar.take(E * Fo)
-        x_ptr, f_in = c.y, Fo
+        if fused:
+            a.aff[i] = ar.take(3 * Fo)
+            x_ptr, f_in = c.xact, Fo
+        else:
+            c.y = ar.take(E * Fo)
+            x_ptr, f_in = c.y, Fo
     # ---- aggregation
     a.n_aggregators, a.n_scalers, a.force_scalers, a.avg_d_log = len(plan.aggregators), len(plan.agg_scalers), 0, plan.avg
     for i, v in enumerate(plan.aggregators):
@@ -198,10 +236,11 @@ def forward(ctx, h, q, index, qmap, plan, params):
         a.agg_event_start, a.agg_event_stop = t0.handle, t1.handle
         ops.KERNEL_TIMERS.setdefault('pna_aggregate_fwd', []).append(
             (t0, t1, N, E, Fmsg, len(plan.aggregators) * len(plan.agg_scalers) * Fmsg))
-    L = _lib.load()
     _lib.check(L.i3d_pna_layer_fwd(ctypes.byref(a), ops._stream()), 'i3d_pna_layer_fwd')
     a.agg_event_start = a.agg_event_stop = None
     ctx.native = (a, ar, h, q, qmap, index, plan, params, (N, E, Fh, Fq, A, nG))
+    if KEEP_LAST_ARGS is not None:      # tools/launch_floor.py: replay the C call without the Python around it
+        KEEP_LAST_ARGS.append((a, ctx.native))
     return y_out
 
 

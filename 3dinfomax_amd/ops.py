@@ -543,3 +543,83 @@ def gemm_rowsubset(A, B, k_rows, out):
                                              _p(k_rows), A.shape[0], _p(out), _ld(out), 0, _stream()),
           'i3d_gemm_f32_rowsubset')
     return out
+
+
+# ---- BatchNorm out of the memory path (csrc/fused_bn.hip) --------------------------------------------------
+def bn_finalize_partials(partial, n_tiles, feat, eps, momentum, gamma=None, beta=None, running_mean=None, running_var=None,
+                         num_batches_tracked=None, want_aff=True):
+    """per-tile partials [n_tiles, 3, feat] -> (mean, invstd, aff [3, feat] = mean | gamma invstd | beta or None)"""
+    _chk(partial)
+    dev = partial.device
+    mean = torch.empty(feat, dtype=torch.float32, device=dev)
+    invstd = torch.empty(feat, dtype=torch.float32, device=dev)
+    aff = torch.empty(3, feat, dtype=torch.float32, device=dev) if want_aff else None
+    check(_lib.load().i3d_bn_finalize_partials(_p(partial), n_tiles, feat, float(eps), float(momentum), _p(gamma), _p(beta),
+                                               _p(mean), _p(invstd), _p(running_mean), _p(running_var),
+                                               _p(num_batches_tracked), _p(aff), _stream()), 'i3d_bn_finalize_partials')
+    return mean, invstd, aff
+
+
+def edge_combine_act_stats(P, Q, bias, src_s, dst_s, act=None, q_code=None):
+    """x = act(P[src,:F] + P[dst,F:] + Q[code or row] + bias) [E, F] and its per-tile statistics -> (x, partial, n_tiles)"""
+    _chk(P)
+    E, feat = src_s.shape[0], P.shape[1] // 2
+    L = _lib.load()
+    rpt = L.i3d_edge_stats_rows_per_tile(feat)
+    n_tiles = (E + rpt - 1) // rpt
+    x = torch.empty(E, feat, dtype=torch.float32, device=P.device)
+    partial = torch.empty(n_tiles, 3, feat, dtype=torch.float32, device=P.device)
+    check(L.i3d_edge_combine_act_stats(_p(P), P.shape[1], _p(Q), _p(q_code), _p(bias), _p(src_s), _p(dst_s), E, feat, ACT[act],
+                                       _p(x), _p(partial), _stream()), 'i3d_edge_combine_act_stats')
+    return x, partial, n_tiles
+
+
+def gemm_fused(A, W, bias=None, a_aff=None, act=None, want_stats=True, out=None, accumulate=False, m_rows=None,
+               tile_group=None):
+    """out = act(A' W^T + bias (+ out)), A' = (A - mean) * scale + shift per column when a_aff [3, K] is given;
+    -> (out, partial [tiles, 3, N] or None, tiles).  W: [N, K], or [G, N, K] with m_rows / tile_group (grouped)."""
+    _chk(A)
+    K = A.shape[1]
+    if m_rows is not None:
+        M, N, stride, rows_total = m_rows.shape[0], W.shape[1], W.shape[1] * W.shape[2], A.shape[0]
+    else:
+        M, N, stride, rows_total = A.shape[0], W.shape[0], 0, A.shape[0]
+    if out is None:
+        assert not accumulate
+        out = torch.empty(rows_total, N, dtype=torch.float32, device=A.device)
+    tiles = (M + 63) // 64
+    partial = torch.empty(tiles, 3, N, dtype=torch.float32, device=A.device) if want_stats else None
+    check(_lib.load().i3d_gemm_f32_fused(M, N, K, _p(A), K, rows_total, _p(W), K, _p(out), N, _p(bias), int(accumulate),
+                                         _p(a_aff), ACT[act], _p(partial), _p(m_rows), _p(tile_group), stride, _stream()),
+          'i3d_gemm_f32_fused')
+    return out, partial, tiles
+
+
+def gemm_wgrad_bn(dY, x, grad_bias, aff):
+    """dW = dY^T ((x - mean) * scale + shift) from the raw x (aff [3, f_in]); grad_bias = column sums of dY"""
+    _chk(dY), _chk(x)
+    dW = torch.empty(dY.shape[1], x.shape[1], dtype=torch.float32, device=x.device)
+    check(_lib.load().i3d_gemm_f32_wgrad_bn(dY.shape[1], x.shape[1], x.shape[0], _p(dY), dY.shape[1], _p(x), x.shape[1], _p(dW),
+                                            x.shape[1], _p(grad_bias), _p(aff), _p(_gemm_workspace(x.device)),
+                                            GEMM_WORKSPACE_BYTES, _stream()), 'i3d_gemm_f32_wgrad_bn')
+    return dW
+
+
+def pna_aggregate_fwd_aff(e, aff, in_ptr, num_nodes, aggregators, scalers, avg_d_log, force_scalers=False):
+    _chk(e)
+    n_s = len(scalers) if (len(scalers) > 1 or force_scalers) else 1
+    out = torch.empty(num_nodes, n_s * len(aggregators) * e.shape[1], dtype=torch.float32, device=e.device)
+    check(_lib.load().i3d_pna_aggregate_fwd_aff(_p(e), _p(aff), _p(in_ptr), num_nodes, e.shape[1], int_array(aggregators),
+                                                len(aggregators), int_array(scalers), len(scalers), int(force_scalers),
+                                                float(avg_d_log), _p(out), _stream()), 'i3d_pna_aggregate_fwd_aff')
+    return out
+
+
+def pna_aggregate_bwd_aff(grad_out, e, aff, in_ptr, num_nodes, aggregators, scalers, avg_d_log, force_scalers=False):
+    _chk(grad_out), _chk(e)
+    ge = torch.zeros_like(e)
+    check(_lib.load().i3d_pna_aggregate_bwd_aff(_p(grad_out), _p(e), _p(aff), _p(in_ptr), num_nodes, e.shape[1],
+                                                int_array(aggregators), len(aggregators), int_array(scalers), len(scalers),
+                                                int(force_scalers), float(avg_d_log), _p(ge), _stream()),
+          'i3d_pna_aggregate_bwd_aff')
+    return ge

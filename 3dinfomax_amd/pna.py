@@ -19,7 +19,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import layer_native, ops, streams, tape
+from . import layer_native, ops, pna_native, streams, tape
 from .graph import as_batched_graph
 from .layers import (MLP, AggregateFn, Concat2FCFn, EdgeFCFn, EdgeTable, FCFn, GroupedConcat2FCFn, ReadoutFn,
                      bn_counter_scope)
@@ -41,7 +41,10 @@ EDGE_TABLE = os.environ.get('I3D_EDGE_TABLE', '1') != '0'
 
 
 def _scaler_coef(scaler_code, D, avg):
-    """reference models/pna.py:57-68: np.log in float64, then cast to the fp32 tensor's dtype."""
+    """reference models/pna.py:57-68: np.log in float64, then cast to the fp32 tensor's dtype.  D = 0 (the group of nodes
+    without in-edges, graph.group_nodes_by_degree): their aggregate is a zero row (DGL semantics), every coefficient 0."""
+    if D == 0:
+        return 0.0
     if scaler_code == ops.SCALER['amplification']:
         return float(np.float32(math.log(D + 1) / avg))
     if scaler_code == ops.SCALER['attenuation']:
@@ -84,10 +87,21 @@ class PNA(nn.Module):
                           mid_batch_norm=readout_batchnorm, out_dim=target_dim, layers=readout_layers,
                           batch_norm_momentum=batch_norm_momentum)
 
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float() replace the storage of parameters and buffers: the cached pointer descriptions of the
+        # whole-model sequencer (pna_native) are stale
+        self.__dict__.pop('_i3d_desc_fwd', None)
+        self.__dict__.pop('_i3d_desc_bwd', None)
+        return super()._apply(fn, *args, **kwargs)
+
     def forward(self, graph, *unused):
         g = as_batched_graph(graph)
         if self.training and g.device.type == 'cuda' and torch.is_grad_enabled():
             streams.note_step_start(g.device)       # lets an independent Net3D forward run next to this one
+        if pna_native.eligible(self, g):      # the whole forward (and later the whole backward) from one C call
+            out = pna_native.run(self, g)
+            if out is not None:
+                return out
         with bn_counter_scope():
             return tape.run_model(self, lambda: self._forward(g))     # one autograd node for the whole model
 

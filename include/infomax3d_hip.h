@@ -281,6 +281,40 @@ int i3d_row_axpy(const float* z, const float* coef, int rows, int dim, float* ou
 /* out[r,:] = coef[r] * z[r,:]   (graph-size normalisation h * snorm_n, reference models/pna_original.py:258-259) */
 int i3d_row_scale(const float* z, const float* coef, int rows, int dim, float* out, void* stream);
 
+/* ---- BatchNorm out of the memory path (csrc/fused_bn.hip, csrc/gemm.hip; reference models/base_layers.py:100-111) ----
+ * Column statistics as per-row-tile partials  partial[tile][3][feat] = {sum, M2 about the tile mean, row count},
+ * produced by the kernel that writes the activation; i3d_bn_finalize_partials merges them (fp64, fixed order) into
+ * mean / invstd / running statistics (momentum, unbiased running_var, num_batches_tracked += 1) and
+ * aff[3 feat] = mean | gamma * invstd | beta, which the CONSUMER of the activation applies while loading it. */
+int i3d_bn_finalize_partials(const float* partial, int n_tiles, int feat, float eps, float momentum, const float* gamma,
+                             const float* beta, float* mean, float* invstd, float* running_mean, float* running_var,
+                             long long* num_batches_tracked, float* aff, void* stream);
+/* x[j,:] = act(P[src_s[j], 0:feat] + P[dst_s[j], feat:2 feat] + Q[q_code ? q_code[j] : j, :] + bias) and the partials of x;
+ * a tile is i3d_edge_stats_rows_per_tile(feat) consecutive rows (reference models/pna.py:237-252 + base_layers.py:102-108) */
+int i3d_edge_stats_rows_per_tile(int feat);
+int i3d_edge_combine_act_stats(const float* P, int ldp, const float* Q, const int* q_code, const float* bias,
+                               const int* src_s, const int* dst_s, int num_edges, int feat, int act, float* x,
+                               float* partial, void* stream);
+/* C[M,N] = epi_act(A' W^T + bias (+ C)),  A' = (A - mean) * scale + shift per column k when a_aff ([3K]) is given (the
+ * BatchNorm of the block in front applied while A is staged), W [N,K] row-major; stats ([ceil(M/64)][3][N]) receives the
+ * partials of the stored values per 64-row tile.  Grouped form as i3d_gemm_f32_grouped (m_rows padded to 64 per group with
+ * -1, M = padded count, a_rows_total = physical rows of A / C).  Needs 16-byte aligned operands, K % 4 == 0. */
+int i3d_gemm_f32_fused(int M, int N, int K, const float* A, int lda, long a_rows_total, const float* W, int ldb, float* C,
+                       int ldc, const float* bias, int accumulate, const float* a_aff, int epi_act, float* stats,
+                       const int* m_rows, const int* tile_group, long b_group_stride, void* stream);
+/* dW[f_out,f_in] = dY^T y for y = (x - mean) * scale + shift (aff over f_in) computed from the raw x; grad_bias[f_out] =
+ * column sums of dY (already computed) */
+int i3d_gemm_f32_wgrad_bn(int f_out, int f_in, int rows, const float* dY, int ldy, const float* x, int ldx, float* dW,
+                          int ldw, const float* grad_bias, const float* aff, void* workspace, long workspace_bytes,
+                          void* stream);
+/* i3d_pna_aggregate_fwd / _bwd with the messages read as (e - mean) * scale + shift (aff [3 feat], may be NULL) */
+int i3d_pna_aggregate_fwd_aff(const float* e, const float* aff, const int* in_ptr, int num_nodes, int feat,
+                              const int* aggregators, int n_aggregators, const int* scalers, int n_scalers,
+                              int force_scalers, float avg_d_log, float* out, void* stream);
+int i3d_pna_aggregate_bwd_aff(const float* grad_out, const float* e, const float* aff, const int* in_ptr, int num_nodes,
+                              int feat, const int* aggregators, int n_aggregators, const int* scalers, int n_scalers,
+                              int force_scalers, float avg_d_log, float* grad_e, void* stream);
+
 /* ---- composites: one call enqueues a whole FCLayer-shaped block (forward or backward) ------------------------
  * "input operator -> Linear -> activation -> BatchNorm1d (training, local statistics) -> post-activation (+ residual)",
  * reference models/base_layers.py:100-111, with the three input operators of the PNA / Net3D layers.  Same kernels
@@ -353,6 +387,7 @@ typedef struct { /* y = tail(P[src,:F] + P[dst,F:] + q W_q^T + b),  P = h [W_s|W
     float* grad_bias;
     float* grad_h;
     float* grad_q;
+    int grad_q_accumulate; /* grad_q += ... instead of = (a q shared by several layers: the bond table) */
 } I3dEdgeFcArgs;
 
 typedef struct { /* y = tail(h W_h^T + b + agg[deg group] W_D^T),  W_D = sum_s coef[g][s] W_s  (models/pna.py:207-209, 229-233) */
@@ -405,7 +440,17 @@ typedef struct { /* one PNA layer, reference models/pna.py:199-216: pretrans edg
     const float* grad_out; /* [N, F] incoming gradient of the layer output (added to post.grad_h when residual) */
     void* agg_event_start; /* optional (i3d_event_create): recorded on the stream right before / after the forward */
     void* agg_event_stop;  /* aggregation kernel - the roofline measurement of bench.py */
+    /* fused BatchNorm (csrc/fused_bn.hip): statistics out of the producers' epilogues, BatchNorm-apply in the consumers'
+     * loads.  Then edge.y / pre[i].y are not written (may be NULL), msg = the xact of the last pretrans block, and the
+     * degree groups of `post` must cover every node (in-degree 0 included, zero coefficients).  Needs activations whose
+     * derivative follows from the output (none / ReLU / LeakyReLU), no post-activation, n_post_extra == 0. */
+    int fused_bn;
+    float* stats_ws;                   /* scratch, i3d_pna_layer_stats_floats(...) floats */
+    float* aff[I3D_MAX_EXTRA_FC + 1];  /* [3 f_out] mean | gamma invstd | beta of the edge block and of pre[i] (saved) */
 } I3dPnaLayerArgs;
+
+/* floats of I3dPnaLayerArgs.stats_ws for a layer with these dimensions (f = widest block output) */
+long i3d_pna_layer_stats_floats(int num_nodes, int num_edges, int m_padded, int f);
 
 /* timing events for measurements around a kernel inside a composite (thin wrappers of hipEvent_t) */
 int i3d_event_create(void** event);
@@ -421,6 +466,79 @@ int i3d_edge_fc_bn_fwd(const I3dEdgeFcArgs* args, void* stream);
 int i3d_edge_fc_bn_bwd(const I3dEdgeFcArgs* args, void* stream);
 int i3d_grouped_fc_bn_fwd(const I3dGroupedFcArgs* args, void* stream);
 int i3d_grouped_fc_bn_bwd(const I3dGroupedFcArgs* args, void* stream);
+
+/* ---- whole-model sequencing (csrc/model.hip): the PNA forward / backward of a training step from one C call each ----
+ * replaces PNA.forward -> PNAGNN.forward -> [PNALayer.forward]* -> readout -> head (reference models/pna.py:131-135,
+ * 161-166, 199-213, 127-129) and its autograd backward for the pre-training configuration: every block Linear ->
+ * activation (none / ReLU / LeakyReLU) -> BatchNorm1d in training mode with local statistics, >= 2 degree scalers
+ * (degree-grouped posttrans), categorical bond features (bond table), one posttrans block.  The memory layout of the
+ * saved activations and of the backward scratch is computed here (i3d_pna_model_saved_floats / _scratch_floats). */
+#define I3D_MAX_LAYERS 16
+#define I3D_MAX_HEAD_FC 4
+typedef struct { /* one FCLayer: Linear + optional BatchNorm1d (reference models/base_layers.py:23-111) */
+    const float* W;     /* [f_out, f_in] row-major, contiguous */
+    const float* bias;
+    const float* gamma; /* NULL: no BatchNorm */
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    long long* num_batches_tracked;
+    float* grad_W; /* outputs of the backward pass (written, not accumulated) */
+    float* grad_bias;
+    float* grad_gamma;
+    float* grad_beta;
+    int f_in, f_out, act;
+    float eps, momentum;
+} I3dFcParams;
+
+typedef struct {
+    int n_layers, hidden, n_pre, residual;
+    int n_aggregators, aggregators[8];
+    int n_scalers, scalers[4];
+    float avg_d_log;
+    I3dFcParams pre[I3D_MAX_LAYERS][I3D_MAX_EXTRA_FC + 1]; /* pretrans blocks (block 0: [h_src | h_dst | e] -> f_out) */
+    I3dFcParams post[I3D_MAX_LAYERS];                      /* posttrans block ([h | agg x scalers] -> hidden) */
+    int n_atom_tables, atom_dims[16];
+    const float* atom_tables[16];
+    float* grad_atom_tables; /* [sum atom_dims, hidden]: the table gradients, contiguous in table order */
+    int n_bond_tables, bond_dims[16];
+    const float* bond_tables[16];
+    float* grad_bond_tables;
+    int n_readout, readout_ops[4];
+    int n_head;
+    I3dFcParams head[I3D_MAX_HEAD_FC];
+} I3dPnaModel;
+
+typedef struct {
+    int num_nodes, num_edges, num_graphs;
+    const int64_t* atom_feat; /* [N, n_atom_tables] */
+    const int64_t* bond_feat; /* [E, n_bond_tables], edge-id order */
+    const int* in_ptr;        /* the destination-sorted index of 3dinfomax_amd/graph.py: GraphIndex */
+    const int* perm;
+    const int* src_s;
+    const int* dst_s;
+    const int* out_ptr;
+    const int* out_epos;
+    const int* graph_ptr;
+    const int* deg_rows; /* nodes grouped by in-degree (0 included), groups padded to 64 with -1 */
+    const int* deg_tile_group;
+    int m_padded, n_groups;
+    int group_degree[32], group_start[32], group_count[32];
+    const int64_t* comb; /* [n_comb, n_bond_tables]: every combination of the categorical bond features (device) */
+    int n_comb, v_pad;
+} I3dPnaBatch;
+
+long i3d_pna_model_saved_floats(const I3dPnaModel* model, const I3dPnaBatch* batch);   /* -1: not supported */
+long i3d_pna_model_scratch_floats(const I3dPnaModel* model, const I3dPnaBatch* batch);
+/* out [B, f_out of the last head block]; node_emb [N, hidden] (the graph's ndata['feat'] side effect); edge_emb [E, hidden]
+ * or NULL (edata['feat'] side effect); agg_events: NULL or 2 * n_layers events recorded around the aggregation kernels;
+ * *ctx_out: host-side context for i3d_pna_model_bwd (valid while `saved` is), freed with i3d_pna_model_ctx_free */
+int i3d_pna_model_fwd(const I3dPnaModel* model, const I3dPnaBatch* batch, float* saved, float* node_emb, float* edge_emb,
+                      float* out, void* bn_workspace, void* const* agg_events, void* stream, void** ctx_out);
+/* grads_from: the same model with its grad_* members set (they are chosen at backward time), or NULL to use the forward's */
+int i3d_pna_model_bwd(void* ctx, const I3dPnaModel* grads_from, const float* grad_out, float* scratch, void* bn_workspace,
+                      void* gemm_workspace, long gemm_workspace_bytes, void* stream);
+int i3d_pna_model_ctx_free(void* ctx);
 
 /* ---- contrastive monitoring metrics -------------------------------------------------
  * replaces the nine metric modules of configs_clean/pre-train_QM9.yml:15-24 (reference trainer/metrics.py:161-174,

@@ -1,0 +1,97 @@
+"""Where the host time of a step goes (perf_counter around the big pieces; no profiler overhead).
+    python tools/host_segments.py [--steps 200]"""
+import argparse
+import collections
+import importlib
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+ACC = collections.defaultdict(float)
+CNT = collections.defaultdict(int)
+ON = [False]
+
+
+def wrap(obj, name, label):
+    fn = getattr(obj, name)
+
+    def timed(*a, **k):
+        if not ON[0]:
+            return fn(*a, **k)
+        t0 = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            ACC[label] += time.perf_counter() - t0
+            CNT[label] += 1
+    setattr(obj, name, timed)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=200)
+    a = ap.parse_args()
+    amd = importlib.import_module('3dinfomax_amd')
+    mods = {n: importlib.import_module('3dinfomax_amd.' + n) for n in
+            ('pna', 'net3d', 'losses', 'tape', 'layer_native', 'net3d_native', 'optim', 'layers', 'ops', 'streams')}
+    dev = torch.device('cuda:0')
+    mols = amd.synth.make_dataset(512, seed=1000)
+    g2 = amd.batch([amd.bond_graph(m) for m in mols]).to(dev)
+    g3 = amd.batch([amd.complete_graph(m) for m in mols]).to(dev)
+    torch.manual_seed(123)
+    pna = amd.PNA(avg_d=1.0, device=dev, **bench.PNA_KW).to(dev).train()
+    net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **bench.NET3D_KW).to(dev).train()
+    loss_fn = amd.NTXent(tau=0.1)
+    named = list(pna.named_parameters()) + list(net.named_parameters())
+    optim = amd.Adam([{'params': [p for k, p in named if 'batch_norm' in k], 'weight_decay': 0},
+                      {'params': [p for k, p in named if 'batch_norm' not in k]}], lr=8e-5, fused=True)
+    wrap(mods['pna'].PNA, 'forward', 'fwd: PNA.forward')
+    wrap(mods['net3d'].Net3D, 'forward', 'fwd: Net3D.forward')
+    wrap(mods['losses'].NTXent, 'forward', 'fwd: NTXent.forward')
+    wrap(mods['layer_native'], 'forward', 'fwd:   PNA layers (layer_native.forward, 4x)')
+    wrap(mods['layer_native'], 'backward', 'bwd:   PNA layers (layer_native.backward, 4x)')
+    wrap(mods['net3d_native'], 'forward', 'fwd:   Net3D native forward')
+    wrap(mods['net3d_native'], 'backward', 'bwd:   Net3D native backward')
+    wrap(mods['tape'], '_model_backward', 'bwd: model backward (tape, both models)')
+    wrap(mods['losses'].NTXentFn, 'backward', 'bwd: NTXentFn.backward')
+    wrap(mods['pna'].PNAGNN, 'forward', 'fwd:  PNAGNN.forward (embeddings + layers)')
+    wrap(mods['layers'].MLP, 'forward', 'fwd:  MLP.forward (heads)')
+
+    def step():
+        t0 = time.perf_counter()
+        x, y = g2.local_copy(), g3.local_copy()
+        loss = loss_fn(pna(x), net(y), nodes_per_graph=x.batch_num_nodes())
+        t1 = time.perf_counter()
+        loss.backward()
+        t2 = time.perf_counter()
+        optim.step()
+        t3 = time.perf_counter()
+        optim.zero_grad()
+        t4 = time.perf_counter()
+        if ON[0]:
+            for k, v in (('STEP fwd+loss', t1 - t0), ('STEP backward', t2 - t1), ('STEP adam', t3 - t2), ('STEP zero_grad', t4 - t3)):
+                ACC[k] += v
+                CNT[k] += 1
+
+    for _ in range(30):
+        step()
+    torch.cuda.synchronize()
+    ON[0] = True
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    print(f'{a.steps} steps: host enqueue {1e3 * host / a.steps:.3f} ms/step, with GPU drain {1e3 * total / a.steps:.3f} ms/step')
+    for k in sorted(ACC):
+        print(f'  {k:58s} {1e3 * ACC[k] / a.steps:7.3f} ms/step  ({CNT[k] / a.steps:.1f} calls)')
+
+
+if __name__ == '__main__':
+    main()
