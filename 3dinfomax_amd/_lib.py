@@ -23,7 +23,8 @@ _P = c_void_p
 class BnTail(ctypes.Structure):
     _fields_ = [('act', c_int), ('post_act', c_int), ('eps', c_float), ('momentum', c_float), ('gamma', _P),
                 ('beta', _P), ('running_mean', _P), ('running_var', _P), ('mean', _P), ('invstd', _P),
-                ('workspace', _P), ('gemm_workspace', _P), ('gemm_workspace_bytes', c_long), ('num_batches_tracked', _P)]
+                ('workspace', _P), ('gemm_workspace', _P), ('gemm_workspace_bytes', c_long), ('num_batches_tracked', _P),
+                ('bias_partial', _P)]
 
 
 class FcArgs(ctypes.Structure):
@@ -113,6 +114,10 @@ _SIGNATURES = {
                                           _P, _P]),
     'i3d_pna_aggregate_bwd_aff': (c_int, [_P, _P, _P, _P, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_int,
                                           c_float, _P, _P]),
+    'i3d_bn_bias_partial_floats': (c_long, [c_int]),
+    'i3d_bn_bwd_deferred_bias': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_long,
+                                         _P, _P, _P]),
+    'i3d_bn_bias_finalize': (c_int, [_P, c_int, c_int, _P, _P]),
     'i3d_abi_version': (c_int, []),
     'i3d_last_error': (c_char_p, []),
     'i3d_embedding_sum_fwd': (c_int, [_P, _P, c_int, c_int, POINTER(c_void_p), c_int, _P, _P]),

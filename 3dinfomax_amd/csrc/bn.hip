@@ -6,11 +6,25 @@
 // running_var.  All column reductions are two-stage and deterministic: stage 1 reduces a row chunk per
 // workgroup (fp32, shifted by row 0 so E[x^2]-E[x]^2 does not cancel), stage 2 sums the chunk partials in
 // fp64 and finalises.  HBM-bound: one read (+ one write when an activation is fused) per pass.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace i3d {
 
-constexpr int MAX_PARTIAL_BLOCKS = 256;
+constexpr int MAX_PARTIAL_BLOCKS = 256;      // capacity of the partial buffer / of the in-launch finalisation (raise for A/B runs)
+// row chunks actually used (<= MAX_PARTIAL_BLOCKS): I3D_PARTIAL_BLOCKS, default 256 = one workgroup per CU.  Measured at
+// batch 512 (tools/ab_partial_blocks.sh, profiles/r02_ab_partial_blocks.txt): 512 / 1024 chunks make every reduction
+// SLOWER (apply+colsum 22.4 -> 24.2 -> 27.2 us with the in-launch finalisation, 12.1 -> 10.5 -> 13.1 us without) - the
+// per-workgroup epilogue (LDS combine, uncached partial stores) and the longer finalisation outweigh the extra waves.
+static int partial_blocks() {
+    static const int n = [] {
+        const char* e = getenv("I3D_PARTIAL_BLOCKS");
+        int v = e ? atoi(e) : 256;
+        return v < 32 ? 32 : (v > MAX_PARTIAL_BLOCKS ? MAX_PARTIAL_BLOCKS : v);
+    }();
+    return n;
+}
 constexpr int RU = 4;                     // rows per thread in flight in the streaming kernels   // ~ one partial block per CU; stage 2 reduces them with 8 lanes per column
 
 struct Chunking {
@@ -30,7 +44,7 @@ static Chunking make_chunking(int rows, int feat) {
     c.tpr = c.cv < 256 ? c.cv : 256;
     c.rl = 256 / c.tpr;
     c.ncolblk = cdiv(c.cv, c.tpr);
-    int rpb = cdiv(rows, MAX_PARTIAL_BLOCKS);
+    int rpb = cdiv(rows, partial_blocks());
     int min_rpb = c.rl * 4;
     if (rpb < min_rpb) rpb = min_rpb;
     c.rpb = rpb;
@@ -794,6 +808,30 @@ extern "C" int i3d_bn_bwd(const float* grad_y, const float* x, const float* pre,
                           int post_act, const float* mean, const float* invstd, const float* gamma,
                           const float* beta, float* grad_gamma, float* grad_beta, float* grad_pre, float* grad_bias,
                           double* sums_out, const double* sums_in, long total_rows, void* workspace, void* stream) {
+    return i3d_bn_bwd_deferred_bias(grad_y, x, pre, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta,
+                                    grad_pre, grad_bias, sums_out, sums_in, total_rows, workspace, nullptr, stream);
+}
+
+extern "C" long i3d_bn_bias_partial_floats(int feat) { return (long)MAX_PARTIAL_BLOCKS * 2 * feat; }
+
+// grad_bias = column sums of grad_pre from the row-chunk partials the data-gradient pass left in bias_partial
+extern "C" int i3d_bn_bias_finalize(const float* bias_partial, int rows, int feat, float* grad_bias, void* stream) {
+    I3D_CHECK_ARG(bias_partial != nullptr && rows > 0 && feat > 0 && grad_bias != nullptr, "bad arguments");
+    const Chunking ch = make_chunking(rows, feat);
+    hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, bias_partial, ch.nblk,
+                       feat, grad_bias, (float*)nullptr, (double*)nullptr);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+// bias_partial != null (and grad_bias != null): the data-gradient pass stores the row-chunk partials of the bias gradient
+// there and does NOT finalise them - the in-launch finalisation is a ~10 us serial tail on the backward chain for a value
+// only the optimizer needs; the caller runs i3d_bn_bias_finalize later (the layer composite: on its side stream).
+extern "C" int i3d_bn_bwd_deferred_bias(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
+                                        int post_act, const float* mean, const float* invstd, const float* gamma,
+                                        const float* beta, float* grad_gamma, float* grad_beta, float* grad_pre,
+                                        float* grad_bias, double* sums_out, const double* sums_in, long total_rows,
+                                        void* workspace, float* bias_partial, void* stream) {
     I3D_CHECK_ARG(rows > 0 && feat > 0, "rows > 0 and feat > 0 required");
     I3D_CHECK_ARG(workspace != nullptr, "workspace required");
     I3D_CHECK_ARG(act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU || pre != nullptr, "pre required for this activation");
@@ -827,10 +865,16 @@ extern "C" int i3d_bn_bwd(const float* grad_y, const float* x, const float* pre,
     if (grad_bias != nullptr) {     // data gradient and its column sums (bias gradient of the Linear in front) in one pass
         b.items = 0;
         dim3 grid(ch.nblk, ch.ncolblk);
-        const Final f = pair_final_desc(workspace, feat, grad_bias, nullptr, nullptr);
-        if (ch.V == 4) hipLaunchKernelGGL(bn_bwd_apply_colsum_kernel<4>, grid, dim3(256), 0, s, b, ch, rows, partial, f);
-        else hipLaunchKernelGGL(bn_bwd_apply_colsum_kernel<1>, grid, dim3(256), 0, s, b, ch, rows, partial, f);
+        Final f = pair_final_desc(workspace, feat, grad_bias, nullptr, nullptr);
+        float* bias_part = partial;
+        if (bias_partial != nullptr) {       // deferred: partials to the caller's buffer, no finalisation here
+            f.counters = nullptr;
+            bias_part = bias_partial;
+        }
+        if (ch.V == 4) hipLaunchKernelGGL(bn_bwd_apply_colsum_kernel<4>, grid, dim3(256), 0, s, b, ch, rows, bias_part, f);
+        else hipLaunchKernelGGL(bn_bwd_apply_colsum_kernel<1>, grid, dim3(256), 0, s, b, ch, rows, bias_part, f);
         I3D_CHECK_LAUNCH();
+        if (bias_partial != nullptr) return I3D_OK;
         if (f.counters == nullptr) {
             hipLaunchKernelGGL(pair_final_kernel, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, s, partial, ch.nblk, feat, grad_bias,
                                (float*)nullptr, (double*)nullptr);

@@ -90,8 +90,15 @@ static int tail_fwd(const I3dBnTail* t, int rows, int f_out, float* pre, float* 
 // BN/activation backward; grad_bias = column sums of grad_pre from the same pass
 static int tail_bwd(const I3dBnTail* t, int rows, int f_out, const float* grad_y, const float* xact, const float* pre,
                     float* grad_gamma, float* grad_beta, float* grad_pre, float* grad_bias, void* stream) {
-    return i3d_bn_bwd(grad_y, xact, pre, rows, f_out, t->act, t->post_act, t->mean, t->invstd, t->gamma, t->beta,
-                      grad_gamma, grad_beta, grad_pre, grad_bias, nullptr, nullptr, rows, t->workspace, stream);
+    return i3d_bn_bwd_deferred_bias(grad_y, xact, pre, rows, f_out, t->act, t->post_act, t->mean, t->invstd, t->gamma, t->beta,
+                                    grad_gamma, grad_beta, grad_pre, grad_bias, nullptr, nullptr, rows, t->workspace,
+                                    t->bias_partial, stream);
+}
+
+// the deferred half of tail_bwd: first thing on the stream the block's weight gradients run on
+static int bias_final(const I3dBnTail* t, int rows, int f_out, float* grad_bias, void* wst) {
+    if (t->bias_partial == nullptr || grad_bias == nullptr) return I3D_OK;
+    return i3d_bn_bias_finalize(t->bias_partial, rows, f_out, grad_bias, wst);
 }
 
 // ---- plain FC ------------------------------------------------------------------------------------------
@@ -118,6 +125,7 @@ static int fc_bn_bwd_chain(const I3dFcArgs* a, void* stream) {
 // x_aff != null (fused BatchNorm): a->x is the RAW activation of the block in front, its BatchNorm output
 // (x - mean) * scale + shift was never materialised; the product is corrected in the slice reduction (gemm.hip)
 static int fc_bn_bwd_wgrad(const I3dFcArgs* a, void* wst, const float* x_aff = nullptr) {
+    TRY(bias_final(&a->tail, a->rows, a->f_out, a->grad_bias, wst));
     if (x_aff != nullptr)
         return i3d_gemm_f32_wgrad_bn(a->f_out, a->f_in, a->rows, a->grad_pre, a->f_out, a->x, a->f_in, a->grad_W, a->ldw,
                                      a->grad_bias, x_aff, a->tail.gemm_workspace, a->tail.gemm_workspace_bytes, wst);
@@ -188,6 +196,7 @@ static int edge_fc_bn_bwd_wgrad_p(const I3dEdgeFcArgs* a, void* wst) {
 // grad_pre only.
 static int edge_fc_bn_bwd_wgrad_q(const I3dEdgeFcArgs* a, void* wst) {
     const int Fh = a->f_h, Fo = a->f_out, E = a->num_edges;
+    TRY(bias_final(&a->tail, E, Fo, a->grad_bias, wst));
     void* ws = a->tail.gemm_workspace;
     const long wsb = a->tail.gemm_workspace_bytes;
     if (a->q != nullptr && a->q_rows > 0) {
@@ -241,6 +250,7 @@ static int grouped_fc_bn_bwd_chain(const I3dGroupedFcArgs* a, void* stream) {
 
 static int grouped_fc_bn_bwd_wgrad(const I3dGroupedFcArgs* a, void* wst) {
     const int Fh = a->f_h, Fo = a->f_out, A = a->agg_width, N = a->num_nodes;
+    TRY(bias_final(&a->tail, N, Fo, a->grad_bias, wst));
     TRY(i3d_gemm_f32_ws(1, 0, Fo, Fh, N, a->grad_pre, Fo, a->h, Fh, a->grad_W, a->ldw, nullptr, 0, a->tail.gemm_workspace,
                         a->tail.gemm_workspace_bytes, wst));
     // dW_D = dY_D^T a_D over the rows of each in-degree group, all groups in one launch

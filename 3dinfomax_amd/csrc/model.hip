@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -66,6 +67,16 @@ struct PnaCtx {
     long saved_floats = 0;
 };
 
+// I3D_DEFER_BIAS=1: the bias gradients are finalised from row-chunk partials on the weight-gradient stream instead of
+// inside the data-gradient pass (I3dBnTail.bias_partial).  Off by default: measured on one box (tools/ab.sh, 4 interleaved
+// runs of 300 steps) 2.816 ms deferred against 2.787 ms in-launch - it takes ~10 us per BatchNorm off the main stream's
+// chain but adds three small launches per layer to the side stream, whose join is what the next layer waits for: at batch
+// 512 the backward pass is bound by the TOTAL work of the two streams, not by the chain.
+bool defer_bias() {
+    static const bool on = [] { const char* e = getenv("I3D_DEFER_BIAS"); return e != nullptr && e[0] == '1'; }();
+    return on;
+}
+
 bool simple_act(int act) { return act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU; }
 
 void fill_tail(I3dBnTail& t, const I3dFcParams& p, float* mean, float* invstd) {
@@ -83,6 +94,7 @@ void fill_tail(I3dBnTail& t, const I3dFcParams& p, float* mean, float* invstd) {
     t.workspace = nullptr;
     t.gemm_workspace = nullptr;
     t.gemm_workspace_bytes = 0;
+    t.bias_partial = nullptr;
 }
 
 void set_ws(I3dBnTail& t, void* bn_ws, void* gemm_ws, long gemm_ws_bytes) {
@@ -259,9 +271,10 @@ extern "C" long i3d_pna_model_scratch_floats(const I3dPnaModel* m, const I3dPnaB
     long layer = 0;
     for (int l = 0; l < m->n_layers; ++l) {
         const long f_msg = m->pre[l][m->n_pre - 1].f_out, A = m->n_aggregators * f_msg, Fo0 = m->pre[l][0].f_out;
-        long t = al4(N * F) + al4((long)b->n_groups * F * A) + al4(N * A) + al4(E * f_msg);
-        for (int i = 1; i < m->n_pre; ++i) t += al4(E * (long)m->pre[l][i].f_out) + al4(E * (long)m->pre[l][i].f_in);
-        t += al4(E * Fo0) + al4(N * 2 * Fo0) + al4(N * F) + al4((long)b->v_pad * Fo0);
+        long t = al4(N * F) + al4((long)b->n_groups * F * A) + al4(N * A) + al4(E * f_msg) + al4(i3d_bn_bias_partial_floats(F));
+        for (int i = 1; i < m->n_pre; ++i)
+            t += al4(E * (long)m->pre[l][i].f_out) + al4(E * (long)m->pre[l][i].f_in) + al4(i3d_bn_bias_partial_floats(m->pre[l][i].f_out));
+        t += al4(E * Fo0) + al4(N * 2 * Fo0) + al4(N * F) + al4((long)b->v_pad * Fo0) + al4(i3d_bn_bias_partial_floats(Fo0));
         layer = std::max(layer, t);
     }
     long oa = 0, ob = 0;
@@ -384,6 +397,7 @@ extern "C" int i3d_pna_model_bwd(void* ctx, const I3dPnaModel* grads_from, const
         g.grad_WD = ar.take((long)b.n_groups * F * g.agg_width);
         g.grad_h = gh[l & 1];
         g.grad_agg = ar.take((long)N * g.agg_width);
+        g.tail.bias_partial = defer_bias() ? ar.take(i3d_bn_bias_partial_floats(F)) : nullptr;
         const int f_msg = a.n_pre_extra > 0 ? a.pre[a.n_pre_extra - 1].f_out : a.edge.f_out;
         a.grad_msg = ar.take((long)E * f_msg);
         const float* gy = a.grad_msg;
@@ -395,6 +409,7 @@ extern "C" int i3d_pna_model_bwd(void* ctx, const I3dPnaModel* grads_from, const
             fc.grad_y = gy;
             fc.grad_pre = ar.take((long)E * fc.f_out);
             fc.grad_x = ar.take((long)E * fc.f_in);
+            fc.tail.bias_partial = defer_bias() ? ar.take(i3d_bn_bias_partial_floats(fc.f_out)) : nullptr;
             gy = fc.grad_x;
         }
         I3dEdgeFcArgs& e = a.edge;
@@ -406,6 +421,7 @@ extern "C" int i3d_pna_model_bwd(void* ctx, const I3dPnaModel* grads_from, const
         e.grad_P = ar.take((long)N * 2 * e.f_out);
         e.grad_h = ar.take((long)N * F);
         e.grad_Q = ar.take((long)b.v_pad * e.f_out);
+        e.tail.bias_partial = defer_bias() ? ar.take(i3d_bn_bias_partial_floats(e.f_out)) : nullptr;
         e.grad_q = grad_table;
         e.grad_q_accumulate = (l == L - 1) ? 0 : 1;        // the bond table feeds every layer: its gradient is their sum
         TRY(i3d_pna_layer_bwd(&a, stream));

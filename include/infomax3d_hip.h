@@ -315,6 +315,14 @@ int i3d_pna_aggregate_bwd_aff(const float* grad_out, const float* e, const float
                               int feat, const int* aggregators, int n_aggregators, const int* scalers, int n_scalers,
                               int force_scalers, float avg_d_log, float* grad_e, void* stream);
 
+/* i3d_bn_bwd with the finalisation of grad_bias deferred (bias_partial != NULL): see I3dBnTail.bias_partial */
+long i3d_bn_bias_partial_floats(int feat);
+int i3d_bn_bwd_deferred_bias(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act, int post_act,
+                             const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             float* grad_gamma, float* grad_beta, float* grad_pre, float* grad_bias, double* sums_out,
+                             const double* sums_in, long total_rows, void* workspace, float* bias_partial, void* stream);
+int i3d_bn_bias_finalize(const float* bias_partial, int rows, int feat, float* grad_bias, void* stream);
+
 /* ---- composites: one call enqueues a whole FCLayer-shaped block (forward or backward) ------------------------
  * "input operator -> Linear -> activation -> BatchNorm1d (training, local statistics) -> post-activation (+ residual)",
  * reference models/base_layers.py:100-111, with the three input operators of the PNA / Net3D layers.  Same kernels
@@ -335,6 +343,8 @@ typedef struct {
     void* gemm_workspace; /* scratch of the weight-gradient GEMMs of the backward (i3d_gemm_f32_ws), may be NULL */
     long gemm_workspace_bytes;
     long long* num_batches_tracked; /* BatchNorm1d's int64 counter, incremented by the forward (may be NULL) */
+    float* bias_partial; /* backward, optional (i3d_bn_bias_partial_floats(f_out) floats): the bias gradient is finalised
+                          * from these partials next to the weight gradients instead of inside the data-gradient pass */
 } I3dBnTail;
 
 typedef struct { /* y = tail(x W^T + b) */
