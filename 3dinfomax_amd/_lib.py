@@ -59,7 +59,7 @@ class PnaLayerArgs(ctypes.Structure):
                 ('n_scalers', c_int), ('force_scalers', c_int), ('aggregators', c_int * 8), ('scalers', c_int * 4),
                 ('avg_d_log', c_float), ('msg', _P), ('grad_msg', _P), ('post', GroupedFcArgs), ('n_post_extra', c_int),
                 ('postx', FcArgs * 3), ('residual', c_int), ('grad_out', _P), ('agg_event_start', _P), ('agg_event_stop', _P),
-                ('fused_bn', c_int), ('stats_ws', _P), ('aff', _P * 4)]
+                ('fused_bn', c_int), ('defer_join', c_int), ('stats_ws', _P), ('aff', _P * 4)]
 
 
 class FcParams(ctypes.Structure):
@@ -118,6 +118,7 @@ _SIGNATURES = {
     'i3d_bn_bwd_deferred_bias': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_long,
                                          _P, _P, _P]),
     'i3d_bn_bias_finalize': (c_int, [_P, c_int, c_int, _P, _P]),
+    'i3d_wgrad_stream_join': (c_int, [_P]),
     'i3d_abi_version': (c_int, []),
     'i3d_last_error': (c_char_p, []),
     'i3d_embedding_sum_fwd': (c_int, [_P, _P, c_int, c_int, POINTER(c_void_p), c_int, _P, _P]),

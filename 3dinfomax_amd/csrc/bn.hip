@@ -486,6 +486,7 @@ struct BwdApplyArgs {
     const float* sum_dy;      // [feat]  (train only)
     const float* sum_dy_xhat; // [feat]
     float* grad_pre;
+    float* zero_out;          // [feat] or null: filled with zeros by the first row block (see i3d_bn_bwd: exact-zero bias gradient)
     const float* inv_n_ptr;   // device 1/N (synchronised BN) or null -> inv_n
     long items;
     int feat, act, post_act, eval_mode;
@@ -498,6 +499,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BwdApplyArgs g, RowTi
     const int cvi = blockIdx.y * rt.tpr + cl;
     if (rlane >= rt.rl || cvi >= rt.cv) return;
     const int c0 = cvi * V, F = g.feat;
+    if (g.zero_out != nullptr && blockIdx.x == 0 && rlane == 0) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) g.zero_out[c0 + i] = 0.f;
+    }
     const float inv_n = g.inv_n_ptr ? g.inv_n_ptr[0] : g.inv_n;
     float mu[V], is[V], ga[V], be[V], k1[V], k2[V];
 #pragma unroll
@@ -683,6 +688,12 @@ static bool fused_final() {
     return on;
 }
 
+// I3D_EXACT_ZERO_BIAS_GRAD=0: sum the analytically-zero bias gradients up as the reference does (A/B, parity studies)
+static bool exact_zero_bias_grad() {
+    static const bool on = [] { const char* e = getenv("I3D_EXACT_ZERO_BIAS_GRAD"); return e == nullptr || e[0] != '0'; }();
+    return on;
+}
+
 static float* partial_of(void* workspace) { return (float*)((char*)workspace + WS_HEADER); }
 
 static Final stats_final_desc(void* workspace, const float* pre, int act, int rows, int feat, float eps, float momentum,
@@ -862,6 +873,18 @@ extern "C" int i3d_bn_bwd_deferred_bias(const float* grad_y, const float* x, con
     b.mean = mean; b.invstd = invstd; b.gamma = gamma; b.beta = beta;
     b.sum_dy = sum_dy; b.sum_dy_xhat = sum_dy_xhat; b.grad_pre = grad_pre; b.feat = feat; b.act = act;
     b.post_act = post_act; b.eval_mode = 0; b.inv_n = 1.f / (float)total_rows; b.eps = 0.f;
+    b.zero_out = nullptr;
+    if (grad_bias != nullptr && act == I3D_ACT_NONE && sums_in == nullptr && exact_zero_bias_grad()) {
+        // No activation between the Linear and the BatchNorm: the bias gradient is the column sum of the BatchNorm input
+        // gradient  s (dy - mean(dy) - xhat mean(dy xhat))  over the rows the statistics were taken over, which is
+        // IDENTICALLY zero (sum xhat = 0).  The reference sums it up in fp32 and gets rounding noise (~1e-9 of the scale,
+        // which its Adam turns into +-lr steps on a bias the BatchNorm removes anyway); here it is the exact value, and the
+        // data-gradient pass loses its reduction and the ~10 us finalisation tail.
+        b.zero_out = grad_bias;
+        launch_bwd_apply(b, rows, feat, s);
+        I3D_CHECK_LAUNCH();
+        return I3D_OK;
+    }
     if (grad_bias != nullptr) {     // data gradient and its column sums (bias gradient of the Linear in front) in one pass
         b.items = 0;
         dim3 grid(ch.nblk, ch.ncolblk);
@@ -909,7 +932,7 @@ extern "C" int i3d_bn_eval_bwd(const float* grad_y, const float* x, const float*
     b.grad_y = grad_y; b.x = x; b.pre = (act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU) ? nullptr : pre;
     b.mean = running_mean; b.invstd = running_var; b.gamma = gamma; b.beta = beta; b.sum_dy = nullptr;
     b.sum_dy_xhat = nullptr; b.grad_pre = grad_pre; b.feat = feat; b.act = act; b.post_act = post_act;
-    b.inv_n_ptr = nullptr; b.eval_mode = 1; b.inv_n = 0.f; b.eps = eps;
+    b.inv_n_ptr = nullptr; b.eval_mode = 1; b.inv_n = 0.f; b.eps = eps; b.zero_out = nullptr;
     launch_bwd_apply(b, rows, feat, s);
     I3D_CHECK_LAUNCH();
     return I3D_OK;

@@ -394,8 +394,11 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     TRY(edge_fc_bn_bwd_dgrad(&a->edge, stream, a->post.grad_h));       // post.grad_h += edge block's dh
     const long n = (long)a->edge.num_nodes * a->edge.f_h;
     if (a->residual) TRY(i3d_add_inplace(a->post.grad_h, a->grad_out, n, stream));
+    if (a->defer_join) return I3D_OK;
     return join_wgrad(x, stream);
 }
+
+extern "C" int i3d_wgrad_stream_join(void* stream) { return join_wgrad(aux_for((hipStream_t)stream), stream); }
 
 // ---- timing events -------------------------------------------------------------------------------------
 extern "C" int i3d_event_create(void** event) {

@@ -77,6 +77,15 @@ bool defer_bias() {
     return on;
 }
 
+// I3D_WGRAD_JOIN=layer: the backward pass of every layer waits for its weight gradients (round-1 behaviour).  Default
+// `model`: one join at the end of the model's backward - the weight-gradient stream turned out to be the critical path
+// of a layer (~214 us of GEMMs per layer behind the first fork against ~150 us left on the chain), a join per layer
+// makes the chain of the NEXT layer wait for it.  Costs scratch: what that stream reads or writes is kept per layer.
+bool join_per_layer() {
+    static const bool on = [] { const char* e = getenv("I3D_WGRAD_JOIN"); return e != nullptr && e[0] == 'l'; }();
+    return on;
+}
+
 bool simple_act(int act) { return act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU; }
 
 void fill_tail(I3dBnTail& t, const I3dFcParams& p, float* mean, float* invstd) {
@@ -117,6 +126,16 @@ int wgrad(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
           void* stream) {
     if (K >= 1024) return i3d_gemm_f32_ws(1, 0, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, ws, ws_bytes, stream);
     return i3d_gemm_f32(1, 0, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, stream);
+}
+
+// floats of the buffers of layer l's backward pass that the weight-gradient stream reads or writes
+long side_floats(const I3dPnaModel& m, const I3dPnaBatch& b, int l) {
+    const long N = b.num_nodes, E = b.num_edges, F = m.hidden;
+    const long f_msg = m.pre[l][m.n_pre - 1].f_out, A = m.n_aggregators * f_msg, Fo0 = m.pre[l][0].f_out;
+    long t = al4(N * F) + al4((long)b.n_groups * F * A) + al4(i3d_bn_bias_partial_floats((int)F));
+    for (int i = 1; i < m.n_pre; ++i) t += al4(E * (long)m.pre[l][i].f_out) + al4(i3d_bn_bias_partial_floats(m.pre[l][i].f_out));
+    t += al4(E * Fo0) + al4(N * 2 * Fo0) + al4((long)b.v_pad * Fo0) + al4(i3d_bn_bias_partial_floats((int)Fo0));
+    return t;
 }
 
 int check_model(const I3dPnaModel* m, const I3dPnaBatch* b) {
@@ -281,7 +300,9 @@ extern "C" long i3d_pna_model_scratch_floats(const I3dPnaModel* m, const I3dPnaB
     for (int k = 0; k < m->n_atom_tables; ++k) oa += m->atom_dims[k];
     for (int k = 0; k < m->n_bond_tables; ++k) ob += m->bond_dims[k];
     const long emb = al4(N * ((oa + 31) / 32 * 32)) + al4((long)b->n_comb * ((ob + 31) / 32 * 32));
-    return top + std::max(std::max(head, layer), emb);
+    long side = 0;          // generous: the per-layer sets are taken in addition to the shared region
+    for (int l = 0; l < m->n_layers; ++l) side += side_floats(*m, *b, l);
+    return top + side + std::max(std::max(head, layer), emb);
 }
 
 extern "C" int i3d_pna_model_fwd(const I3dPnaModel* m, const I3dPnaBatch* b, float* saved, float* node_emb, float* edge_emb,
@@ -351,6 +372,11 @@ extern "C" int i3d_pna_model_bwd(void* ctx, const I3dPnaModel* grads_from, const
     Bump top(scratch);
     float* gh[2] = {top.take((long)N * F), top.take((long)N * F)};      // dL/dh, ping-pong between layers
     float* grad_table = top.take((long)b.n_comb * F);                  // dL/d(bond table), summed over the layers
+    // buffers the weight-gradient stream reads or writes: one set per layer unless every layer joins that stream
+    const bool per_layer_join = join_per_layer();
+    std::vector<float*> side(L, nullptr);
+    if (!per_layer_join)
+        for (int l = 0; l < L; ++l) side[l] = top.take(side_floats(m, b, l));
     float* const rest = scratch + top.used;
     // ---- head, last block first
     {
@@ -386,6 +412,9 @@ extern "C" int i3d_pna_model_bwd(void* ctx, const I3dPnaModel* grads_from, const
     for (int l = L - 1; l >= 0; --l) {
         I3dPnaLayerArgs& a = c->layers[l];
         Bump ar(rest);
+        Bump own(side[l]);
+        Bump& sd = per_layer_join ? ar : own;       // where the side stream's buffers of this layer live
+        a.defer_join = per_layer_join ? 0 : 1;
         const float* grad_in = gh[(l + 1) & 1];
         a.grad_out = grad_in;
         I3dGroupedFcArgs& g = a.post;
@@ -393,11 +422,11 @@ extern "C" int i3d_pna_model_bwd(void* ctx, const I3dPnaModel* grads_from, const
         set_ws(g.tail, bn_workspace, gemm_workspace, gemm_workspace_bytes);
         g.grad_W = pp.grad_W; g.grad_bias = pp.grad_bias; g.grad_gamma = pp.grad_gamma; g.grad_beta = pp.grad_beta;
         g.grad_y = grad_in;
-        g.grad_pre = ar.take((long)N * F);
-        g.grad_WD = ar.take((long)b.n_groups * F * g.agg_width);
+        g.grad_pre = sd.take((long)N * F);
+        g.grad_WD = sd.take((long)b.n_groups * F * g.agg_width);
         g.grad_h = gh[l & 1];
         g.grad_agg = ar.take((long)N * g.agg_width);
-        g.tail.bias_partial = defer_bias() ? ar.take(i3d_bn_bias_partial_floats(F)) : nullptr;
+        g.tail.bias_partial = defer_bias() ? sd.take(i3d_bn_bias_partial_floats(F)) : nullptr;
         const int f_msg = a.n_pre_extra > 0 ? a.pre[a.n_pre_extra - 1].f_out : a.edge.f_out;
         a.grad_msg = ar.take((long)E * f_msg);
         const float* gy = a.grad_msg;
@@ -407,9 +436,9 @@ extern "C" int i3d_pna_model_bwd(void* ctx, const I3dPnaModel* grads_from, const
             set_ws(fc.tail, bn_workspace, gemm_workspace, gemm_workspace_bytes);
             fc.grad_W = p.grad_W; fc.grad_bias = p.grad_bias; fc.grad_gamma = p.grad_gamma; fc.grad_beta = p.grad_beta;
             fc.grad_y = gy;
-            fc.grad_pre = ar.take((long)E * fc.f_out);
+            fc.grad_pre = sd.take((long)E * fc.f_out);
             fc.grad_x = ar.take((long)E * fc.f_in);
-            fc.tail.bias_partial = defer_bias() ? ar.take(i3d_bn_bias_partial_floats(fc.f_out)) : nullptr;
+            fc.tail.bias_partial = defer_bias() ? sd.take(i3d_bn_bias_partial_floats(fc.f_out)) : nullptr;
             gy = fc.grad_x;
         }
         I3dEdgeFcArgs& e = a.edge;
@@ -417,15 +446,16 @@ extern "C" int i3d_pna_model_bwd(void* ctx, const I3dPnaModel* grads_from, const
         set_ws(e.tail, bn_workspace, gemm_workspace, gemm_workspace_bytes);
         e.grad_W = p0.grad_W; e.grad_bias = p0.grad_bias; e.grad_gamma = p0.grad_gamma; e.grad_beta = p0.grad_beta;
         e.grad_y = gy;
-        e.grad_pre = ar.take((long)E * e.f_out);
-        e.grad_P = ar.take((long)N * 2 * e.f_out);
+        e.grad_pre = sd.take((long)E * e.f_out);
+        e.grad_P = sd.take((long)N * 2 * e.f_out);
         e.grad_h = ar.take((long)N * F);
-        e.grad_Q = ar.take((long)b.v_pad * e.f_out);
-        e.tail.bias_partial = defer_bias() ? ar.take(i3d_bn_bias_partial_floats(e.f_out)) : nullptr;
+        e.grad_Q = sd.take((long)b.v_pad * e.f_out);
+        e.tail.bias_partial = defer_bias() ? sd.take(i3d_bn_bias_partial_floats(e.f_out)) : nullptr;
         e.grad_q = grad_table;
         e.grad_q_accumulate = (l == L - 1) ? 0 : 1;        // the bond table feeds every layer: its gradient is their sum
         TRY(i3d_pna_layer_bwd(&a, stream));
     }
+    if (!per_layer_join) TRY(i3d_wgrad_stream_join(stream));
     // ---- encoders: embedding-table gradients as multi-hot^T dY (deterministic, csrc/edge.hip: multihot_kernel)
     {
         Bump ar(rest);

@@ -455,6 +455,8 @@ typedef struct { /* one PNA layer, reference models/pna.py:199-216: pretrans edg
      * degree groups of `post` must cover every node (in-degree 0 included, zero coefficients).  Needs activations whose
      * derivative follows from the output (none / ReLU / LeakyReLU), no post-activation, n_post_extra == 0. */
     int fused_bn;
+    int defer_join; /* backward: do not wait for the weight-gradient stream at the end of the layer; the caller keeps every
+                     * buffer that stream reads or writes alive and calls i3d_wgrad_stream_join before it consumes them */
     float* stats_ws;                   /* scratch, i3d_pna_layer_stats_floats(...) floats */
     float* aff[I3D_MAX_EXTRA_FC + 1];  /* [3 f_out] mean | gamma invstd | beta of the edge block and of pre[i] (saved) */
 } I3dPnaLayerArgs;
@@ -468,6 +470,8 @@ int i3d_event_destroy(void* event);
 int i3d_event_record(void* event, void* stream);
 int i3d_event_elapsed_ms(void* start, void* stop, float* ms);   /* both events must have completed */
 
+/* makes `stream` wait for everything its weight-gradient side stream holds (I3dPnaLayerArgs.defer_join) */
+int i3d_wgrad_stream_join(void* stream);
 int i3d_pna_layer_fwd(const I3dPnaLayerArgs* args, void* stream);
 int i3d_pna_layer_bwd(const I3dPnaLayerArgs* args, void* stream);
 int i3d_fc_bn_fwd(const I3dFcArgs* args, void* stream);
