@@ -52,6 +52,7 @@ def parse():
                          '(functional check of the N > 1 code path only)')
     ap.add_argument('--torch-adam', action='store_true', help='stock torch.optim.Adam(fused=True) instead of amd.Adam')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-families', action='store_true', help='skip the per-family roofline block (tools/family_bench.py)')
     ap.add_argument('--loader-workers', type=int, default=4,
                     help='DataLoader worker processes of the with-batch-assembly figure (0: assemble in the training thread)')
     ap.add_argument('--cpu-steps', type=int, default=3)
@@ -68,7 +69,9 @@ def parse():
 
 
 def cpu_baseline(mols, depth, steps):
-    """Oracle (CPU restatement of the reference path) on the same workload, bounded sample."""
+    """Oracle (CPU restatement of the reference path, torch CPU eager) on the same workload, bounded sample: one timed step
+    per thread setting (8 / 16 / 32 / 64 / all cores: torch's CPU eager mode is oversubscribed with every core of a large
+    host), `steps` more at the best setting; the best rate is reported with its thread count."""
     from oracle import pna3d_oracle as O
     cfg2 = O.pna_config(**dict(PNA_KW, propagation_depth=depth))
     cfg3 = O.net3d_config(**NET3D_KW)
@@ -77,14 +80,29 @@ def cpu_baseline(mols, depth, steps):
     optim = torch.optim.Adam([{'params': [p for k, p in named if 'batch_norm' in k], 'weight_decay': 0},
                               {'params': [p for k, p in named if 'batch_norm' not in k]}], lr=8e-5)
     g2, g3 = O.graphs_from_molecules(mols)
-    O.train_step(g2, g3, P2, cfg2, P3, cfg3, optim, 0.1)        # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        O.train_step(g2, g3, P2, cfg2, P3, cfg3, optim, 0.1)
-    dt = (time.perf_counter() - t0) / steps
-    return dict(value=len(mols) / dt, unit='molecules/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'{steps} steps of batch {len(mols)} (depth {depth}, fp32, torch CPU eager, '
-                       f'{torch.get_num_threads()} threads), {dt:.3f} s/step')
+    all_cores = torch.get_num_threads()
+    settings = sorted({t for t in (8, 16, 32, 64, all_cores) if t <= all_cores})
+
+    def timed(n):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            O.train_step(g2, g3, P2, cfg2, P3, cfg3, optim, 0.1)
+        return (time.perf_counter() - t0) / n
+
+    torch.set_num_threads(settings[-1])
+    timed(1)                                                    # warm-up (allocator, thread pools)
+    sweep = {}
+    for t in settings:
+        torch.set_num_threads(t)
+        sweep[t] = timed(1)
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    dt = min(sweep[best], timed(max(steps - 1, 1)))
+    torch.set_num_threads(all_cores)
+    return dict(value=len(mols) / dt, unit='molecules/s', cores=best, kind='port',
+                sample=f'batch {len(mols)} (depth {depth}, fp32, torch CPU eager): one step per thread setting, '
+                       f'{max(steps - 1, 1)} more at the best; best {best} threads {dt:.3f} s/step',
+                thread_sweep_s_per_step={str(t): round(v, 3) for t, v in sweep.items()}, host_cores=all_cores)
 
 
 def main():
@@ -165,9 +183,12 @@ def main():
         ctypes.CDLL(None).fflush(None)
     ops.KERNEL_TIMERS = {}
     lead, lead_hist = [], []
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # per-step device times (median)
+    marks[0].record()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
+        marks[i + 1].record()
         if args.lead_probe:       # how many steps is the host ahead of the GPU? (0 = the GPU waits for the host)
             ev = torch.cuda.Event()
             ev.record()
@@ -183,6 +204,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timers, ops.KERNEL_TIMERS = ops.KERNEL_TIMERS, None
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -322,6 +344,26 @@ def main():
                          '20 launches per event pair after the timed region; reference_shaped_12F: the [N,12F] kernel of '
                          'SURVEY.md 8(d) (I3D_GROUPED_POSTTRANS=0 path); traffic: rocprofv3 PMC bytes per launch')
 
+    families = step_line = None
+    if rank == 0 and roof is not None and not args.no_families:
+        fb = importlib.import_module('tools.family_bench')
+        meas = fb.measure(amd, ops, batches[0][0], dev)
+        families = meas['families']
+        sh = meas['shapes']
+        fwd, dgrad, wgrad = fb.layer_flops(sh['N'], sh['E'], sh['m_padded'], sh['F'])
+        flops = args.depth * (fwd + dgrad + wgrad)
+        ms = dt / args.steps * 1e3
+        # bytes: every [E,F] / [N,F] / [N,4F] activation of a layer written once and read once per consumer in the fused
+        # form (forward 6 + backward 14 passes over [E,F], 8 + 14 over [N,F], 2 + 2 over [N,4F])
+        byts = args.depth * 4.0 * sh['F'] * (20 * sh['E'] + 22 * sh['N'] + 4 * 4 * sh['N'])
+        step_line = dict(executed_mfma_flops_per_step=int(flops), achieved_tflops=round(flops / ms / 1e9, 1),
+                         frac_of_mfma_peak=round(flops / ms / 1e9 / fb.MFMA_F32_PEAK_TF, 3),
+                         ms_at_mfma_peak=round(flops / fb.MFMA_F32_PEAK_TF / 1e9, 3),
+                         algorithmic_bytes_per_step=int(byts), ms_at_hbm_peak=round(byts / HBM_PEAK_GBS / 1e6, 3),
+                         note='PNA layers only (heads, encoders, Net3D, NT-Xent are < 2 % of the flops); the step is neither '
+                              'MFMA- nor HBM-bound: it is ~250 dependent launches of 5-50 us on two streams')
+        roof['families'] = families
+        roof['step'] = step_line
     if rank == 0:
         mol_per_s = args.steps * B * world / dt
         out = dict(metric='molecules/sec pretraining step (PNA+Net3D, QM9-50k); PNA-agg HBM GB/s vs peak',
@@ -336,6 +378,8 @@ def main():
                                **({'host_lead_steps_median': sorted(lead_hist)[len(lead_hist) // 2],
                                    'host_lead_steps_min': min(lead_hist)} if lead_hist else {}),
                                host_enqueue_ms_per_step=round(t_enqueue / args.steps * 1e3, 3),
+                               ms_per_step_median=round(step_ms[len(step_ms) // 2], 3),
+                               ms_per_step_p10_p90=[round(step_ms[len(step_ms) // 10], 3), round(step_ms[(9 * len(step_ms)) // 10], 3)],
                                molecules_per_s_incl_batch_assembly_and_h2d=with_assembly,
                                molecules_per_s_incl_batch_assembly_in_the_training_thread=with_assembly_inline),
                    roofline=roof)

@@ -1,0 +1,147 @@
+"""Per-family roofline fractions of the pre-training step, measured live with HIP events (20 launches per event pair, on
+the shapes of a resident batch): the MFMA GEMMs of a PNA layer (forward, data gradient, weight gradient), the BatchNorm
+passes, the aggregation kernel K4 (also on a batch whose working set is beyond the 256 MiB Infinity Cache).
+bench.py imports `measure` and puts the result into its JSON line (`roofline.families`, `roofline.step`); stand-alone:
+
+    python tools/family_bench.py [--batch 512]
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA peak of MI355X
+HBM_PEAK_GBS = 8000.0
+
+
+def _time(fn, reps=20):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3          # us
+
+
+def layer_flops(N, E, m_pad, F, n_comb=60):
+    """MFMA flops of one PNA layer (hidden F, pretrans 2 blocks, grouped posttrans): forward, data gradients, weight gradients"""
+    fwd = 2.0 * N * 2 * F * F + 2.0 * n_comb * F * F + 2.0 * E * F * F + 2.0 * N * F * F + 2.0 * m_pad * 4 * F * F
+    dgrad = 2.0 * E * F * F + 2.0 * N * 2 * F * F + 2.0 * N * F * F + 2.0 * m_pad * 4 * F * F
+    wgrad = 2.0 * E * F * F + 2.0 * N * 2 * F * F + 2.0 * N * F * F + 2.0 * N * 4 * F * F + 2.0 * E * 64 * F
+    return fwd, dgrad, wgrad
+
+
+def measure(amd, ops, g2, dev, F=200, big_batch=8192):
+    """-> dict(families=..., shapes=...) for the bond graph `g2` (a resident batch)"""
+    idx = g2.index()
+    N, E = idx.num_nodes, idx.num_edges
+    rows_d, tiles_d, groups = idx.degree_groups()
+    m_pad, nG = rows_d.shape[0], len(groups)
+    rnd = lambda *s: torch.randn(*s, device=dev)
+    out = {}
+
+    # ---- GEMM family (fp32 MFMA): the shapes of one layer, forward / dgrad / wgrad
+    h, x1, agg = rnd(N, F), rnd(E, F).abs(), rnd(N, 4 * F)
+    W1, W2, W3 = rnd(F, 3 * F) * 0.05, rnd(F, F) * 0.07, rnd(F, 13 * F) * 0.02
+    WD = rnd(nG, F, 4 * F) * 0.03
+    aff = torch.stack([x1.mean(0), torch.ones(F, device=dev), torch.zeros(F, device=dev)])
+    bias = rnd(F)
+    dY_e, dY_n, dP = rnd(E, F) * 0.1, rnd(N, F) * 0.1, rnd(N, 2 * F) * 0.1
+    Wsd = torch.cat([W1[:, :F], W1[:, F:2 * F]], 0).contiguous()                # [2F, F]
+    lin3 = rnd(N, F)
+    gemms = {
+        'fwd P  [N,F]x[2F,F]^T': (lambda: ops.gemm(h, Wsd, trans_b=True), 2.0 * N * 2 * F * F),
+        'fwd FC2 [E,F]x[F,F]^T + BN prologue + statistics': (lambda: ops.gemm_fused(x1, W2, bias, aff, None), 2.0 * E * F * F),
+        'fwd post h [N,F]x[F,F]^T': (lambda: ops.gemm(h, W3[:, :F], trans_b=True, bias=bias), 2.0 * N * F * F),
+        'fwd post agg grouped [N,4F]->F + statistics': (
+            lambda: ops.gemm_fused(agg, WD, None, None, None, out=lin3, accumulate=True, m_rows=rows_d, tile_group=tiles_d),
+            2.0 * m_pad * 4 * F * F),
+        'dgrad FC2 [E,F]x[F,F]': (lambda: ops.gemm(dY_e, W2), 2.0 * E * F * F),
+        'dgrad P [N,2F]x[2F,F]': (lambda: ops.gemm(dP, Wsd), 2.0 * N * 2 * F * F),
+        'dgrad post agg grouped [N,F]->4F': (lambda: ops.gemm_grouped(dY_n, rows_d, tiles_d, WD, agg, trans_b=False, accumulate=False),
+                                              2.0 * m_pad * 4 * F * F),
+        'wgrad FC2 [F,F] K=E (BN fix-up)': (lambda: ops.gemm_wgrad_bn(dY_e, x1, bias, aff), 2.0 * E * F * F),
+        'wgrad P [2F,F] K=N': (lambda: ops.gemm(dP, h, trans_a=True), 2.0 * N * 2 * F * F),
+        'wgrad post h [F,F] K=N': (lambda: ops.gemm(dY_n, h, trans_a=True), 2.0 * N * F * F),
+    }
+    rows, tot_us, tot_fl = [], 0.0, 0.0
+    for name, (fn, fl) in gemms.items():
+        us = _time(fn)
+        rows.append(dict(kernel=name, us=round(us, 2), tflops=round(fl / us / 1e6, 1), frac=round(fl / us / 1e6 / MFMA_F32_PEAK_TF, 3)))
+        tot_us += us
+        tot_fl += fl
+    out['gemm'] = dict(bound='mfma', peak=MFMA_F32_PEAK_TF, unit='TFLOP/s', achieved=round(tot_fl / tot_us / 1e6, 1),
+                       frac=round(tot_fl / tot_us / 1e6 / MFMA_F32_PEAK_TF, 3), kernels=rows,
+                       note='flop-weighted over the ten GEMM shapes of one PNA layer (forward, data gradient, weight gradient), '
+                            'each launched 20 times back to back between one event pair')
+
+    # ---- BatchNorm family (HBM): producer-fused statistics, backward reduction + apply, apply + residual
+    P, Q = rnd(N, 2 * F), rnd(60, F)
+    code = torch.randint(0, 60, (E,), device=dev, dtype=torch.int32)
+    gamma, beta = torch.ones(F, device=dev), torch.zeros(F, device=dev)
+    xact, partial, tiles = ops.edge_combine_act_stats(P, Q, bias, idx.src_s, idx.dst_s, 'relu', code)
+    mean, invstd, _ = ops.bn_finalize_partials(partial, tiles, F, 1e-5, 0.1, gamma, beta)
+    gb = torch.empty(F, device=dev)
+    bn = {
+        'edge gather-combine + ReLU + statistics [E,F]': (lambda: ops.edge_combine_act_stats(P, Q, bias, idx.src_s, idx.dst_s, 'relu', code),
+                                                          4.0 * E * F * 3),
+        'statistics finalisation': (lambda: ops.bn_finalize_partials(partial, tiles, F, 1e-5, 0.1, gamma, beta), 4.0 * tiles * 3 * F),
+        'backward reduction + data gradient [E,F] (ReLU block)': (
+            lambda: ops.bn_bwd(dY_e, xact, None, 'relu', None, mean, invstd, gamma, beta, grad_bias=gb), 4.0 * E * F * 5),
+        'apply + residual [N,F]': (lambda: ops.bn_apply_fwd(lin3, mean, invstd, gamma, beta, None, h), 4.0 * N * F * 3),
+    }
+    rows, tot_us, tot_b = [], 0.0, 0.0
+    for name, (fn, byts) in bn.items():
+        us = _time(fn)
+        rows.append(dict(kernel=name, us=round(us, 2), gbs=round(byts / us / 1e3, 1), frac=round(byts / us / 1e3 / HBM_PEAK_GBS, 3)))
+        tot_us += us
+        tot_b += byts
+    out['batchnorm'] = dict(bound='hbm', peak=HBM_PEAK_GBS, unit='GB/s', achieved=round(tot_b / tot_us / 1e3, 1),
+                            frac=round(tot_b / tot_us / 1e3 / HBM_PEAK_GBS, 3), kernels=rows,
+                            note='algorithmic bytes (one read per input tensor, one write per output tensor) / event time; at batch 512 the '
+                                 'tensors (13.5 MB each) sit in the 256 MiB Infinity Cache, the kernels are bound by launch + finalisation latency')
+
+    # ---- K4 (HBM): forward with the BatchNorm applied on load, backward; batch 512 and a batch beyond the Infinity Cache
+    aggs, ident = ops.agg_codes(['mean', 'max', 'min', 'std']), ops.scaler_codes(['identity'])
+
+    def k4(index, tag):
+        n, e = index.num_nodes, index.num_edges
+        msg, gout = torch.randn(e, F, device=dev), torch.randn(n, 4 * F, device=dev)
+        us_f = _time(lambda: ops.pna_aggregate_fwd_aff(msg, aff, index.in_ptr, n, aggs, ident, 1.0))
+        us_b = _time(lambda: ops.pna_aggregate_bwd_aff(gout, msg, aff, index.in_ptr, n, aggs, ident, 1.0))
+        bf = 4.0 * e * F + 4.0 * n * 4 * F + 4.0 * (n + 1)
+        bb = 4.0 * n * 4 * F + 2 * 4.0 * e * F + 4.0 * (n + 1)
+        return {f'fwd {tag}': dict(us=round(us_f, 2), gbs=round(bf / us_f / 1e3, 1), frac=round(bf / us_f / 1e3 / HBM_PEAK_GBS, 3),
+                                   algorithmic_bytes=int(bf)),
+                f'bwd {tag}': dict(us=round(us_b, 2), gbs=round(bb / us_b / 1e3, 1), frac=round(bb / us_b / 1e3 / HBM_PEAK_GBS, 3),
+                                   algorithmic_bytes=int(bb))}
+    k = k4(idx, f'B={idx.num_graphs}')
+    if big_batch:
+        mols = amd.synth.make_dataset(big_batch, seed=77)
+        big = amd.batch([amd.bond_graph(m) for m in mols]).to(dev).index()
+        k.update(k4(big, f'B={big_batch} (working set {(4.0 * big.num_edges * F + 16.0 * big.num_nodes * F) / 2 ** 20:.0f} MiB > 256 MiB Infinity Cache)'))
+    out['k4_aggregation'] = dict(bound='hbm', peak=HBM_PEAK_GBS, unit='GB/s', kernels=k,
+                                 note='[N,4F] form as launched by the step, messages normalised on load (aff); back to back')
+    return dict(families=out, shapes=dict(N=N, E=E, m_padded=m_pad, degree_groups=nG, F=F))
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=512)
+    a = ap.parse_args()
+    amd = importlib.import_module('3dinfomax_amd')
+    ops = importlib.import_module('3dinfomax_amd.ops')
+    dev = torch.device('cuda:0')
+    g2 = amd.batch([amd.bond_graph(m) for m in amd.synth.make_dataset(a.batch, seed=1000)]).to(dev)
+    print(json.dumps(measure(amd, ops, g2, dev), indent=1))
