@@ -357,6 +357,17 @@ extern "C" int i3d_pna_model_fwd(const I3dPnaModel* m, const I3dPnaBatch* b, flo
 
 extern "C" int i3d_pna_model_bwd(void* ctx, const I3dPnaModel* grads_from, const float* grad_out, float* scratch,
                                  void* bn_workspace, void* gemm_workspace, long gemm_workspace_bytes, void* stream) {
+    return i3d_pna_model_bwd_part(ctx, grads_from, grad_out, scratch, bn_workspace, gemm_workspace, gemm_workspace_bytes, 0, 0,
+                                  stream);
+}
+
+// part 0: the whole backward pass.  Data parallel, to overlap the gradient all-reduce with the rest of the backward pass:
+// part 1 = head + layers [split, L) and a join of the weight-gradient stream (their parameter gradients are final when the
+// call returns, in stream order); part 2 = layers [0, split) + encoders (same ctx, same scratch: the state in between
+// - dL/dh, the bond-table gradient - lives in the scratch).
+extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, const float* grad_out, float* scratch,
+                                      void* bn_workspace, void* gemm_workspace, long gemm_workspace_bytes, int part, int split,
+                                      void* stream) {
     I3D_CHECK_ARG(ctx != nullptr && grad_out != nullptr && scratch != nullptr && bn_workspace != nullptr, "null");
     PnaCtx* c = static_cast<PnaCtx*>(ctx);
     if (grads_from != nullptr) {       // the gradient buffers are chosen at backward time: take them (same model otherwise)
@@ -369,6 +380,8 @@ extern "C" int i3d_pna_model_bwd(void* ctx, const I3dPnaModel* grads_from, const
                   "gradient buffers not set");
     const I3dPnaBatch& b = c->b;
     const int N = b.num_nodes, E = b.num_edges, B = b.num_graphs, F = m.hidden, L = m.n_layers;
+    I3D_CHECK_ARG(part >= 0 && part <= 2 && (part == 0 || (split > 0 && split < L)), "bad part / split");
+    const int l_hi = part == 2 ? split : L, l_lo = part == 1 ? split : 0;      // layers [l_lo, l_hi) in this call
     Bump top(scratch);
     float* gh[2] = {top.take((long)N * F), top.take((long)N * F)};      // dL/dh, ping-pong between layers
     float* grad_table = top.take((long)b.n_comb * F);                  // dL/d(bond table), summed over the layers
@@ -379,7 +392,7 @@ extern "C" int i3d_pna_model_bwd(void* ctx, const I3dPnaModel* grads_from, const
         for (int l = 0; l < L; ++l) side[l] = top.take(side_floats(m, b, l));
     float* const rest = scratch + top.used;
     // ---- head, last block first
-    {
+    if (part != 2) {
         Bump ar(rest);
         const float* gy = grad_out;
         for (int i = m.n_head - 1; i >= 0; --i) {
@@ -409,7 +422,7 @@ extern "C" int i3d_pna_model_bwd(void* ctx, const I3dPnaModel* grads_from, const
         TRY(i3d_segment_readout_bwd(gy, c->h[L], b.graph_ptr, B, F, m.readout_ops, m.n_readout, gh[L & 1], stream));
     }
     // ---- layers, last first
-    for (int l = L - 1; l >= 0; --l) {
+    for (int l = l_hi - 1; l >= l_lo; --l) {
         I3dPnaLayerArgs& a = c->layers[l];
         Bump ar(rest);
         Bump own(side[l]);
@@ -456,6 +469,7 @@ extern "C" int i3d_pna_model_bwd(void* ctx, const I3dPnaModel* grads_from, const
         TRY(i3d_pna_layer_bwd(&a, stream));
     }
     if (!per_layer_join) TRY(i3d_wgrad_stream_join(stream));
+    if (part == 1) return I3D_OK;
     // ---- encoders: embedding-table gradients as multi-hot^T dY (deterministic, csrc/edge.hip: multihot_kernel)
     {
         Bump ar(rest);

@@ -15,6 +15,8 @@ The three collective helpers below call RCCL directly for the "nccl" backend.  F
 2-process-on-one-GPU parity test) device tensors are staged through the host and reduce-scatter is emulated with
 all-reduce + slice, because gloo implements neither on HIP tensors.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -56,6 +58,44 @@ def reduce_scatter_rows(g, group=None):
     out = torch.empty((per,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
     dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM, group=group)
     return out
+
+
+def _row_index(counts, pad, device):
+    """rows of the padded gather layout [world * pad, ...] that are real, in rank order"""
+    key = (tuple(counts), pad, str(device))
+    idx = _row_index_cache.get(key)
+    if idx is None:
+        idx = torch.cat([torch.arange(c, dtype=torch.int64) + r * pad for r, c in enumerate(counts)]).to(device)
+        _row_index_cache.clear()
+        _row_index_cache[key] = idx
+    return idx
+
+
+_row_index_cache = {}
+
+
+def all_gather_rows_var(x, counts, group=None):
+    """all-gather along dim 0 with a different number of rows per rank (`counts`, known on every rank: the shard plan is a
+    function of the global batch): every rank contributes its rows padded to max(counts), the real rows are picked out."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    assert len(counts) == world and x.shape[0] == counts[rank], (counts, rank, x.shape)
+    pad = max(counts)
+    if pad == min(counts):
+        return all_gather_rows(x, group)
+    xp = torch.zeros((pad,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    xp[:x.shape[0]] = x
+    return all_gather_rows(xp, group).index_select(0, _row_index(counts, pad, x.device))
+
+
+def reduce_scatter_rows_var(g, counts, group=None):
+    """backward of all_gather_rows_var: g [sum(counts), ...] -> this rank's rows of the sum over ranks"""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    pad = max(counts)
+    if pad == min(counts):
+        return reduce_scatter_rows(g, group)
+    gp = torch.zeros((world * pad,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+    gp.index_copy_(0, _row_index(counts, pad, g.device), g.contiguous())
+    return reduce_scatter_rows(gp, group)[:counts[rank]]
 
 
 def warm_up(device, steps=2):
@@ -108,6 +148,10 @@ def setup(modules, loss=None, group=None, sync_bn=False, broadcast=True):
     return group
 
 
+# I3D_OVERLAP_ALLREDUCE=0: one all-reduce of the whole gradient buffer after the backward pass (round-1 behaviour)
+OVERLAP_ALLREDUCE = os.environ.get('I3D_OVERLAP_ALLREDUCE', '1') != '0'
+
+
 class GradReducer:
     """C2: SUM all-reduce of all parameter gradients through ONE persistent flat buffer.
 
@@ -126,6 +170,12 @@ class GradReducer:
         self.flat = torch.zeros(sum(sizes), dtype=p0.dtype, device=p0.device)
         self.views = [v.view_as(p) for v, p in zip(self.flat.split(sizes), self.params)]
         self.view_of = {id(p): v for p, v in zip(self.params, self.views)}
+        self.span_of, o = {}, 0
+        for p, n in zip(self.params, sizes):
+            self.span_of[id(p)] = (o, o + n)
+            o += n
+        self._pending, self._launched = [], []        # async all-reduces of this step, element ranges they cover
+        self.overlap = OVERLAP_ALLREDUCE
         self._tape = tape
 
     def attach(self, modules):
@@ -133,6 +183,27 @@ class GradReducer:
         for m in modules:
             if any(p.requires_grad for p in m.parameters()):
                 self._tape.register_grad_sink(m, self._sink, self.view_of)
+                self._tape.model_state(m).reducer = self
+
+    def launch_async(self, params):
+        """Start the all-reduce of the gradients of `params` NOW (they are final in stream order and live in the flat
+        buffer): a model backward calls this for the part of its parameters that is done while the rest of the backward pass
+        is still to be enqueued (pna_native.PNAModelFn: head + upper half of the layers), so the collective runs next to it.
+        Contiguous runs of the flat buffer become one collective each."""
+        spans = sorted(self.span_of[id(p)] for p in params if id(p) in self.span_of)
+        merged = []
+        for a, b in spans:
+            if merged and merged[-1][1] == a:
+                merged[-1][1] = b
+            else:
+                merged.append([a, b])
+        for a, b in merged:
+            t = self.flat[a:b]
+            if _is_gloo(self.group):
+                all_reduce_sum(t, self.group)                       # host-staged, synchronous: same arithmetic
+            else:
+                self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._launched.append((a, b))
 
     def _sink(self, params, grads):
         """Gradients of one model backward -> what autograd should store / accumulate.
@@ -167,7 +238,27 @@ class GradReducer:
             have = [(v, g) for v, g in todo if g is not None]
             if have:
                 torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        all_reduce_sum(self.flat, self.group)
+        if self._launched and not todo:
+            # part of the buffer is already being reduced (launch_async): the complement now, then wait for the early ones
+            o = 0
+            for a, b in sorted(self._launched) + [(self.flat.numel(), self.flat.numel())]:
+                if a > o:
+                    all_reduce_sum(self.flat[o:a], self.group)
+                o = max(o, b)
+            for w in self._pending:
+                w.wait()
+        else:
+            for w in self._pending:          # (gradients arrived another way after all: reduce everything again is wrong -
+                w.wait()                     #  the early ranges are already summed; only the rest is reduced below)
+            if self._launched:
+                o = 0
+                for a, b in sorted(self._launched) + [(self.flat.numel(), self.flat.numel())]:
+                    if a > o:
+                        all_reduce_sum(self.flat[o:a], self.group)
+                    o = max(o, b)
+            else:
+                all_reduce_sum(self.flat, self.group)
+        self._pending, self._launched = [], []
         if todo:
             for p, v in zip(self.params, self.views):
                 p.grad = v
@@ -198,7 +289,43 @@ def global_loss(loss_share, group=None):
     return all_reduce_sum(loss_share.detach().clone(), group if group is not None else dist.group.WORLD)
 
 
-def shard_molecules(mols, rank, world):
-    """Contiguous, equally sized molecule ranges of the (already shuffled) global batch."""
-    per = len(mols) // world
-    return mols[rank * per:(rank + 1) * per]
+def shard_plan(sizes, world):
+    """Partition of a global batch over `world` ranks, deterministic (every rank computes the same plan from the same
+    batch): molecule counts differ by at most one (nothing is dropped), and the ATOM counts are balanced - molecules are
+    dealt largest first in snake order (0..w-1, w-1..0, ...), because the work of a rank follows its atoms (edges ~ atoms,
+    complete-graph edges ~ atoms^2).  -> list of index lists (ascending inside a rank)."""
+    n = len(sizes)
+    cap = [n // world + (1 if r < n % world else 0) for r in range(world)]
+    order = sorted(range(n), key=lambda i: (-int(sizes[i]), i))
+    plan = [[] for _ in range(world)]
+    r, step = 0, 1
+    for i in order:
+        while len(plan[r]) >= cap[r]:                 # a full rank is skipped (only the +1 remainder ranks differ)
+            r, step = _snake_next(r, step, world)
+        plan[r].append(i)
+        r, step = _snake_next(r, step, world)
+    return [sorted(p) for p in plan]
+
+
+def _snake_next(r, step, world):
+    if world == 1:
+        return 0, 1
+    nr = r + step
+    if nr < 0 or nr >= world:
+        return r, -step                               # turn around: the end rank takes two in a row
+    return nr, step
+
+
+def shard_molecules(mols, rank, world, balance=None):
+    """This rank's molecules of the (already shuffled) global batch.  balance=None: contiguous ranges, the first
+    len(mols) % world ranks hold one molecule more (nothing is dropped); balance='atoms': shard_plan on `n_atoms`."""
+    if balance == 'atoms':
+        return [mols[i] for i in shard_plan([m.n_atoms for m in mols], world)[rank]]
+    n = len(mols)
+    start = rank * (n // world) + min(rank, n % world)
+    return mols[start:start + n // world + (1 if rank < n % world else 0)]
+
+
+def shard_counts(n, world):
+    """molecules per rank of both shard_molecules modes"""
+    return [n // world + (1 if r < n % world else 0) for r in range(world)]

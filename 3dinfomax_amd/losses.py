@@ -15,18 +15,23 @@ from . import ops
 
 
 class _AllGatherRowsFn(torch.autograd.Function):
-    """all_gather along dim 0 (equal shard sizes); backward = reduce_scatter(sum) of the gathered gradient."""
+    """all_gather along dim 0; backward = reduce_scatter(sum) of the gathered gradient.  `counts` (rows per rank, known on
+    every rank) allows shards of different sizes (dist.shard_plan does not drop the remainder of a batch)."""
 
     @staticmethod
-    def forward(ctx, x, group):
+    def forward(ctx, x, group, counts=None):
         from . import dist as adist
-        ctx.group = group
+        ctx.group, ctx.counts = group, counts
+        if counts is not None:
+            return adist.all_gather_rows_var(x, counts, group)
         return adist.all_gather_rows(x, group)
 
     @staticmethod
     def backward(ctx, g):
         from . import dist as adist
-        return adist.reduce_scatter_rows(g, ctx.group), None
+        if ctx.counts is not None:
+            return adist.reduce_scatter_rows_var(g, ctx.counts, ctx.group), None, None
+        return adist.reduce_scatter_rows(g, ctx.group), None, None
 
 
 class NTXentFn(torch.autograd.Function):
@@ -97,10 +102,16 @@ class _NTXentBase(_Loss):
         self.norm, self.tau = norm, tau
         self.uniformity_reg, self.variance_reg, self.covariance_reg = uniformity_reg, variance_reg, covariance_reg
         self.group = None
+        self.shard_counts = None
 
     def attach_group(self, group):
         """Enable the data-parallel form (all-gathered negatives) on a torch.distributed process group."""
         self.group = group
+        return self
+
+    def set_shard_counts(self, counts):
+        """molecules per rank of the current global batch when they differ (dist.shard_counts / shard_plan); None: equal"""
+        self.shard_counts = list(counts) if counts is not None else None
         return self
 
     def _contrastive(self, z1, z2, conf):
@@ -109,8 +120,15 @@ class _NTXentBase(_Loss):
             import torch.distributed as dist
             world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
             if world > 1:
-                z2 = _AllGatherRowsFn.apply(z2, self.group)
-                pos_offset, global_batch = rank * z1.shape[0], world * z1.shape[0]
+                counts = self.shard_counts
+                if counts is not None and (len(counts) != world or counts[rank] != z1.shape[0]):
+                    raise ValueError(f'shard counts {counts} do not describe this batch ({z1.shape[0]} rows on rank {rank})')
+                if counts is not None and max(counts) != min(counts):
+                    z2 = _AllGatherRowsFn.apply(z2, self.group, [c * conf for c in counts])
+                    pos_offset, global_batch = sum(counts[:rank]), sum(counts)
+                else:
+                    z2 = _AllGatherRowsFn.apply(z2, self.group)
+                    pos_offset, global_batch = rank * z1.shape[0], world * z1.shape[0]
         return NTXentFn.apply(z1, z2, float(self.tau), float(self._eps), conf, pos_offset, global_batch)
 
     def _regularisers(self, loss, z1, z2):

@@ -300,9 +300,27 @@ class PNAModelFn(torch.autograd.Function):
         L = _lib.load()
         n_scratch = L.i3d_pna_model_scratch_floats(ctypes.byref(desc.struct), ctypes.byref(ctx.batch))
         scratch = torch.empty(n_scratch, dtype=torch.float32, device=dev)
-        _lib.check(L.i3d_pna_model_bwd(ctx.handle.ptr, ctypes.byref(desc.struct), grad.contiguous().data_ptr(), scratch.data_ptr(),
-                                       ops._workspace(desc.bn_feat, dev).data_ptr(), ops._gemm_workspace(dev).data_ptr(),
-                                       ops.GEMM_WORKSPACE_BYTES, ops._stream()), 'i3d_pna_model_bwd')
+        grad = grad.contiguous()
+        bn_ws, gemm_ws = ops._workspace(desc.bn_feat, dev).data_ptr(), ops._gemm_workspace(dev).data_ptr()
+
+        def part(k, split):
+            _lib.check(L.i3d_pna_model_bwd_part(ctx.handle.ptr, ctypes.byref(desc.struct), grad.data_ptr(), scratch.data_ptr(), bn_ws,
+                                                gemm_ws, ops.GEMM_WORKSPACE_BYTES, k, split, ops._stream()), 'i3d_pna_model_bwd_part')
+
+        red = ctx.state.reducer
+        n_layers = desc.struct.n_layers
+        if (red is not None and red.overlap and n_layers >= 2 and key is not None and ctx.state.sink_views is views
+                and _world(red.group) > 1):
+            # data parallel: the gradients of the head and of the upper half of the layers are final after part 1 - their
+            # all-reduce (RCCL, its own stream) runs next to the lower half of the backward pass
+            split = n_layers // 2
+            part(1, split)
+            gnn = module.node_gnn
+            early = [p for layer in list(gnn.mp_layers)[split:] for p in layer.parameters()] + list(module.output.parameters())
+            red.launch_async(early)
+            part(2, split)
+        else:
+            part(0, 0)
         out = [views[id(p)] for p in params]
         sink = ctx.state.sink
         if sink is not None:         # data parallel: the gradients go (or already are) in the all-reduce buffer
@@ -313,6 +331,11 @@ class PNAModelFn(torch.autograd.Function):
                 p.grad = gr
             return (None,) * (3 + len(params))
         return (None, None, None) + tuple(out)
+
+
+def _world(group):
+    import torch.distributed as dist
+    return dist.get_world_size(group) if dist.is_initialized() else 1
 
 
 def run(module, g):

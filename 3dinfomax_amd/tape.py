@@ -190,6 +190,7 @@ class _ModelState:
         self.pool = None
         self.sink = None          # callable(params, grads) -> grads (dist.GradReducer)
         self.sink_views = None    # {id(parameter): its view in the sink's flat buffer}
+        self.reducer = None       # the dist.GradReducer itself (early, overlapped all-reduce of finished gradients)
 
     def __reduce__(self):          # copy.deepcopy(model) / pickling: the copy starts without state (model_state rebuilds it)
         return (type(None), ())

@@ -136,7 +136,8 @@ def main():
     batches = []
     for i in range(pool):
         mols = amd.synth.make_dataset(B * world, seed=1000 + i)
-        shard = mols[rank * B:(rank + 1) * B]
+        # molecules sharded by rank, balanced by atom count (dist.shard_plan; equal molecule counts here: B per rank)
+        shard = adist.shard_molecules(mols, rank, world, balance='atoms') if world > 1 else mols
         g2 = amd.batch([amd.bond_graph(m) for m in shard]).to(dev)
         g3 = amd.batch([amd.complete_graph(m) for m in shard]).to(dev)
         batches.append((g2, g3, shard))
@@ -344,6 +345,29 @@ def main():
                          '20 launches per event pair after the timed region; reference_shaped_12F: the [N,12F] kernel of '
                          'SURVEY.md 8(d) (I3D_GROUPED_POSTTRANS=0 path); traffic: rocprofv3 PMC bytes per launch')
 
+    # per-collective times of the data-parallel step (20 back-to-back calls per event pair, after the timed region)
+    collectives = None
+    if use_dist:
+        def timed_coll(fn, reps=20):
+            fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return round(a.elapsed_time(b) / reps * 1e3, 1)
+        zloc = torch.randn(B, PNA_KW['target_dim'], device=dev)
+        zfull = torch.randn(B * world, PNA_KW['target_dim'], device=dev)
+        red = adist.grad_reducer(params)
+        collectives = dict(
+            allgather_embeddings_us=timed_coll(lambda: adist.all_gather_rows(zloc)),
+            reduce_scatter_embedding_grads_us=timed_coll(lambda: adist.reduce_scatter_rows(zfull)),
+            allreduce_all_gradients_us=timed_coll(lambda: adist.all_reduce_sum(red.flat)),
+            gradient_bytes=int(red.flat.numel() * 4), overlapped_with_backward=bool(red.overlap and world > 1),
+            note='the gradient all-reduce of the head and the upper half of the PNA layers is started in the middle of the '
+                 'backward pass (dist.GradReducer.launch_async), the rest after it')
     families = step_line = None
     if rank == 0 and roof is not None and not args.no_families:
         fb = importlib.import_module('tools.family_bench')
@@ -383,6 +407,8 @@ def main():
                                molecules_per_s_incl_batch_assembly_and_h2d=with_assembly,
                                molecules_per_s_incl_batch_assembly_in_the_training_thread=with_assembly_inline),
                    roofline=roof)
+        if collectives is not None:
+            out['collectives'] = collectives
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(batches[0][2], args.depth, args.cpu_steps)
         print(json.dumps(out), flush=True)

@@ -552,6 +552,10 @@ int i3d_pna_model_fwd(const I3dPnaModel* model, const I3dPnaBatch* batch, float*
 /* grads_from: the same model with its grad_* members set (they are chosen at backward time), or NULL to use the forward's */
 int i3d_pna_model_bwd(void* ctx, const I3dPnaModel* grads_from, const float* grad_out, float* scratch, void* bn_workspace,
                       void* gemm_workspace, long gemm_workspace_bytes, void* stream);
+/* the backward pass in two calls (data parallel: the all-reduce of the first part's gradients runs next to the second):
+ * part 1 = head + layers [split, n_layers), part 2 = layers [0, split) + encoders; part 0 = everything */
+int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, const float* grad_out, float* scratch, void* bn_workspace,
+                           void* gemm_workspace, long gemm_workspace_bytes, int part, int split, void* stream);
 int i3d_pna_model_ctx_free(void* ctx);
 
 /* ---- contrastive monitoring metrics -------------------------------------------------

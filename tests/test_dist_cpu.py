@@ -88,3 +88,55 @@ def test_sharded_ntxent_and_collectives_match_single_process():
     out = mgr.dict()
     mp.spawn(_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def test_shard_plan_balances_atoms_and_drops_nothing():
+    adist = importlib.import_module('3dinfomax_amd.dist')
+    rng = __import__('numpy').random.default_rng(0)
+    for n, world in ((512, 8), (13, 2), (500, 8), (7, 8), (64, 3)):
+        sizes = rng.integers(3, 60, size=n).tolist()
+        plan = adist.shard_plan(sizes, world)
+        assert sorted(i for p in plan for i in p) == list(range(n))
+        assert [len(p) for p in plan] == adist.shard_counts(n, world)
+        atoms = [sum(sizes[i] for i in p) for p in plan]
+        if n >= 4 * world:
+            assert max(atoms) - min(atoms) <= max(sizes), (n, world, atoms)
+        assert plan == adist.shard_plan(sizes, world)                      # deterministic: every rank computes the same plan
+    mols = list(range(11))
+    assert [adist.shard_molecules(mols, r, 3) for r in range(3)] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10]]
+
+
+def _var_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    adist = importlib.import_module('3dinfomax_amd.dist')
+    losses = importlib.import_module('3dinfomax_amd.losses')
+    from oracle import pna3d_oracle as O
+    counts, dim = [7, 4], 8
+    B = sum(counts)
+    g = torch.Generator().manual_seed(1)
+    z1, z2, W = torch.randn(B, dim, generator=g), torch.randn(B, dim, generator=g), torch.randn(dim, dim, generator=g)
+    Wr = W.clone().requires_grad_(True)
+    full = O.ntxent(z1 @ Wr, z2 @ Wr, tau=0.1)
+    full.backward()
+    lo = sum(counts[:rank])
+    Ws = W.clone().requires_grad_(True)
+    a, b_local = z1[lo:lo + counts[rank]] @ Ws, z2[lo:lo + counts[rank]] @ Ws
+    b_full = losses._AllGatherRowsFn.apply(b_local, dist.group.WORLD, counts)      # shards of different sizes
+    share = _share(a, b_full, lo, B)
+    share.backward()
+    adist.allreduce_grads([Ws])
+    total = adist.global_loss(share)
+    ok = (b_full.shape[0] == B and abs(total.item() - full.item()) < 1e-5 * abs(full.item())
+          and torch.allclose(Ws.grad, Wr.grad, rtol=1e-4, atol=1e-6))
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_sharded_ntxent_with_uneven_shards():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_var_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
+    assert dict(out) == {0: True, 1: True}

@@ -147,3 +147,74 @@ def test_grad_reducer_accumulates_instead_of_clobbering(tmp_path):
         # the BatchNorm running statistics differ between the passes, the batch statistics (train mode) do not: same bits
         assert np.abs(z[f'two/{i}'] - 2 * g).max() <= 1e-6 * scale, i
         assert np.abs(z[f'zeroed/{i}'] - g).max() <= 1e-6 * scale, i
+
+
+def _uneven_worker(rank, port, path):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    amd = importlib.import_module('3dinfomax_amd')
+    adist = importlib.import_module('3dinfomax_amd.dist')
+    native = importlib.import_module('3dinfomax_amd.pna_native')
+    mols = amd.synth.make_dataset(13, seed=33)                      # 13 molecules on 2 ranks: 7 + 6, nothing dropped
+    plan = adist.shard_plan([m.n_atoms for m in mols], WORLD)
+    pna, net = _models(amd)
+    loss_fn = amd.NTXent(tau=0.1)
+    adist.setup([pna, net], loss_fn, sync_bn=False)                 # per-rank BatchNorm statistics (DistributedDataParallel semantics)
+    loss_fn.set_shard_counts([len(p) for p in plan])
+    params = list(pna.parameters()) + list(net.parameters())
+    red = adist.grad_reducer(params, modules=[pna, net])
+    calls = []
+    real = red.launch_async
+    red.launch_async = lambda ps: (calls.append(len(ps)), real(ps))[1]
+    g2, g3 = _batch(amd, [mols[i] for i in plan[rank]])
+    assert native.eligible(pna, g2)                                 # the whole-model C sequencer is the path that runs
+    share = loss_fn(pna(g2), net(g3))
+    share.backward()
+    adist.allreduce_grads(params)
+    total = adist.global_loss(share)
+    if rank == 0:
+        out = {'loss': total.item(), 'early_params': np.array(calls)}
+        for tag, m in (('pna', pna), ('net', net)):
+            for k, p in m.named_parameters():
+                out[f'g/{tag}/{k}'] = p.grad.cpu().numpy()
+        np.savez(path, **out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_uneven_shards_local_bn_and_early_allreduce(tmp_path):
+    """Atom-balanced shards of different sizes (dist.shard_plan: 7 + 6 molecules), per-rank BatchNorm statistics, the
+    gradient all-reduce of the head and the upper layers started in the middle of the PNA backward pass
+    (GradReducer.launch_async): loss and summed gradients equal the single-process emulation - both shards through the
+    same weights, every shard's 2D rows scored against ALL 3D rows."""
+    amd = importlib.import_module('3dinfomax_amd')
+    adist = importlib.import_module('3dinfomax_amd.dist')
+    losses = importlib.import_module('3dinfomax_amd.losses')
+    from helpers import grads_close
+    path = str(tmp_path / 'uneven.npz')
+    mp.spawn(_uneven_worker, args=(_free_port(), path), nprocs=WORLD, join=True)
+    z = np.load(path)
+    assert list(z['early_params']) and int(z['early_params'][0]) > 8          # the early bucket was launched
+    mols = amd.synth.make_dataset(13, seed=33)
+    sizes = [m.n_atoms for m in mols]
+    plan = adist.shard_plan(sizes, WORLD)
+    assert sorted(i for p in plan for i in p) == list(range(13)) and [len(p) for p in plan] == [7, 6]
+    atoms = [sum(sizes[i] for i in p) for p in plan]
+    assert abs(atoms[0] - atoms[1]) <= max(sizes)                              # balanced by atoms, not only by count
+    pna, net = _models(amd)
+    z2, z3 = [], []
+    for p in plan:
+        g2, g3 = _batch(amd, [mols[i] for i in p])
+        z2.append(pna(g2))
+        z3.append(net(g3))
+    z3_full = torch.cat(z3)
+    total, off = 0, 0
+    for r, p in enumerate(plan):
+        total = total + losses.NTXentFn.apply(z2[r], z3_full, 0.1, 1e-8, 1, off, 13)
+        off += len(p)
+    total.backward()
+    assert abs(float(z['loss']) - total.item()) < 1e-5 * abs(total.item())
+    for tag, m in (('pna', pna), ('net', net)):
+        ref = {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}
+        grads_close({k: z[f'g/{tag}/{k}'] for k in ref}, ref, 2e-4, tag + ' ')
