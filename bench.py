@@ -52,6 +52,9 @@ def parse():
                          '(functional check of the N > 1 code path only)')
     ap.add_argument('--torch-adam', action='store_true', help='stock torch.optim.Adam(fused=True) instead of amd.Adam')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='qm9', choices=['qm9', 'qmugs'],
+                    help='qm9: BASELINE.json configs[1] (the metric); qmugs: configs[3] shape - QMugs-shaped molecules (~55 atoms), '
+                         '3 conformers per molecule, NTXentMultiplePositives, batch 500, PNA depth 7 (pre-train_QMugs.yml), fp32')
     ap.add_argument('--no-families', action='store_true', help='skip the per-family roofline block (tools/family_bench.py)')
     ap.add_argument('--loader-workers', type=int, default=4,
                     help='DataLoader worker processes of the with-batch-assembly figure (0: assemble in the training thread)')
@@ -132,20 +135,31 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     # synthetic QM9-shaped data: `pool` global batches, each rank keeps its shard resident in HBM
+    qmugs = args.workload == 'qmugs'
+    if qmugs:          # configs_clean/pre-train_QMugs.yml: batch_size 500, num_conformers 3, propagation_depth 7
+        if args.batch == 512:
+            args.batch = 500
+        if args.depth == 4:
+            args.depth = 7
+        args.no_families = True
     B, pool = args.batch, args.pool
     batches = []
     for i in range(pool):
-        mols = amd.synth.make_dataset(B * world, seed=1000 + i)
+        mols = amd.synth.make_dataset(B * world, seed=1000 + i, kind='qmugs' if qmugs else 'qm9')
         # molecules sharded by rank, balanced by atom count (dist.shard_plan; equal molecule counts here: B per rank)
         shard = adist.shard_molecules(mols, rank, world, balance='atoms') if world > 1 else mols
         g2 = amd.batch([amd.bond_graph(m) for m in shard]).to(dev)
-        g3 = amd.batch([amd.complete_graph(m) for m in shard]).to(dev)
+        if qmugs:      # conformer_collate: the conformers of a molecule are consecutive graphs
+            rng = np.random.default_rng(2000 + i)
+            g3 = amd.batch([amd.complete_graph(m, c) for m in shard for c in amd.synth.conformers(m, rng, 3)]).to(dev)
+        else:
+            g3 = amd.batch([amd.complete_graph(m) for m in shard]).to(dev)
         batches.append((g2, g3, shard))
 
     torch.manual_seed(123)
     pna = amd.PNA(avg_d=1.0, device=dev, **dict(PNA_KW, propagation_depth=args.depth)).to(dev).train()
     net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_KW).to(dev).train()
-    loss_fn = amd.NTXent(tau=0.1)
+    loss_fn = amd.NTXentMultiplePositives(tau=0.1) if qmugs else amd.NTXent(tau=0.1)
     named = list(pna.named_parameters()) + list(net.named_parameters())
     params = [p for _, p in named]
     # reference trainer/self_supervised_trainer.py:78-86: BN params in their own group
@@ -214,7 +228,7 @@ def main():
     # secondary figure (SURVEY.md 8d "also report with H2D/collate included", row f1): every step first assembles a
     # fresh batch from the flat dataset on the host (vectorised numpy), copies it and builds the 3D graphs on device
     with_assembly = with_assembly_inline = None
-    if not use_dist or world == 1:
+    if (not use_dist or world == 1) and not qmugs:
         dataset = importlib.import_module('3dinfomax_amd.dataset')
         all_mols = [m for _, _, shard in batches for m in shard]
         flat = dataset.FlatMolDataset(all_mols)
@@ -394,8 +408,13 @@ def main():
                    value=round(mol_per_s, 1), unit='molecules/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
                    vs_baseline=None, dtype='f32', data='synthetic',
-                   config=dict(workload=f'PNA hidden=200 depth={args.depth} + Net3D hidden=20 + NT-Xent tau=0.1, '
-                                        f'QM9-shaped synthetic molecules, batch {B}/GPU, fp32, Adam',
+                   config=dict(workload=(f'configs[3] shape in fp32: PNA hidden=200 depth={args.depth} + Net3D hidden=20 + '
+                                         f'NTXentMultiplePositives tau=0.1, QMugs-shaped synthetic molecules, 3 conformers, batch {B}/GPU, Adam'
+                                         if qmugs else
+                                         f'PNA hidden=200 depth={args.depth} + Net3D hidden=20 + NT-Xent tau=0.1, '
+                                         f'QM9-shaped synthetic molecules, batch {B}/GPU, fp32, Adam'),
+                               atoms_per_batch=int(batches[0][0].number_of_nodes()),
+                               complete_graph_edges_per_batch=int(batches[0][1].number_of_edges()),
                                optimizer='torch.optim.Adam(fused=True)' if args.torch_adam else 'infomax3d_amd.Adam (torch.optim.Adam subclass, torch._fused_adam_ kernel, cached tensor lists)',
                                global_batch=B * world, parallelism=f'dp{world}' if world > 1 else 'single',
                                sync_bn=(use_dist and args.sync_bn), final_loss=round(float(loss.item()), 5),
@@ -409,7 +428,7 @@ def main():
                    roofline=roof)
         if collectives is not None:
             out['collectives'] = collectives
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not qmugs:
             out['cpu_baseline'] = cpu_baseline(batches[0][2], args.depth, args.cpu_steps)
         print(json.dumps(out), flush=True)
     if use_dist:

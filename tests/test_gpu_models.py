@@ -295,8 +295,8 @@ def test_edge_case_batches_vs_oracle(amd, case):
 SMOOTH = dict(aggregators=['mean', 'sum', 'std', 'var'], readout_aggregators=['mean', 'sum'])
 
 
-@pytest.mark.parametrize('variant', ['as_configured', 'smooth'])
-def test_qmugs_conformers_multiple_positives_vs_oracle(amd, variant):
+@pytest.mark.parametrize('variant,n_mols', [('as_configured', 10), ('smooth', 10), ('as_configured', 64), ('smooth', 64)])
+def test_qmugs_conformers_multiple_positives_vs_oracle(amd, variant, n_mols):
     """Gradient check at scale, two variants: `as_configured` keeps the max/min aggregators and readouts - fp32
     rounding may flip the arg-max of a near-tie between two atoms, so the gradients are held to a relative L2 bound;
     `smooth` swaps them for mean/sum/std/var (no arg-max anywhere) and holds every gradient to the strict max-norm
@@ -305,7 +305,8 @@ def test_qmugs_conformers_multiple_positives_vs_oracle(amd, variant):
     BASELINE config 4 shape (pre-train_QMugs.yml): QMugs-shaped molecules (degrees <= 6, up to ~100 atoms here),
     3 conformers per molecule batched with conformer_collate, NTXentMultiplePositives - fp32 parity vs the oracle."""
     rng = np.random.default_rng(3)
-    mols = [m for m in synth.make_dataset(40, seed=11, kind='qmugs') if m.n_atoms <= 100][:10]
+    mols = [m for m in synth.make_dataset(4 * n_mols, seed=11, kind='qmugs') if m.n_atoms <= 100][:n_mols]
+    assert len(mols) == n_mols
     confs = [synth.conformers(m, rng, 3) for m in mols]
     items = [(amd.bond_graph(m), amd.batch([amd.complete_graph(m, c) for c in cs])) for m, cs in zip(mols, confs)]
     (g2,), (g3,) = amd.conformer_collate(items)
