@@ -120,6 +120,9 @@ _SIGNATURES = {
                                          _P, _P, _P]),
     'i3d_bn_bias_finalize': (c_int, [_P, c_int, c_int, _P, _P]),
     'i3d_wgrad_stream_join': (c_int, [_P]),
+    'i3d_adam_chunk_elems': (c_int, []),
+    'i3d_adam_chunk_bytes': (c_int, []),
+    'i3d_adam_step': (c_int, [_P, c_int, _P, c_int, c_double, c_double, c_double, c_double, c_double, c_double, c_double, _P]),
     'i3d_abi_version': (c_int, []),
     'i3d_last_error': (c_char_p, []),
     'i3d_embedding_sum_fwd': (c_int, [_P, _P, c_int, c_int, POINTER(c_void_p), c_int, _P, _P]),

@@ -9,7 +9,46 @@ tensors of PNA + Net3D, as much as a sixth of the whole step on this host); here
 list is rebuilt.  Anything outside the plain case (closure, amsgrad, maximize, capturable, tensor lr, CPU or mixed
 devices, a parameter without gradient) goes through torch's own `step()`.
 """
+import ctypes
+import math
+import os
+import struct
+
 import torch
+
+# I3D_NATIVE_ADAM=0: torch._fused_adam_ (three multi-tensor launches of ~50 workgroups) instead of csrc/adam.hip
+NATIVE_ADAM = os.environ.get('I3D_NATIVE_ADAM', '1') != '0'
+
+
+class _NativeTable:
+    """device-resident chunk table of csrc/adam.hip for one set of (param, grad, exp_avg, exp_avg_sq) tensors"""
+
+    def __init__(self, ps, grads, exp_avgs, exp_avg_sqs):
+        from . import _lib
+        L = _lib.load()
+        ch, rec = L.i3d_adam_chunk_elems(), L.i3d_adam_chunk_bytes()
+        assert rec == 40
+        buf = bytearray()
+        for p, g, m, v in zip(ps, grads, exp_avgs, exp_avg_sqs):
+            n = p.numel()
+            for o in range(0, n, ch):
+                buf += struct.pack('<QQQQiI', p.data_ptr() + 4 * o, g.data_ptr() + 4 * o, m.data_ptr() + 4 * o,
+                                   v.data_ptr() + 4 * o, min(ch, n - o), 0)
+        self.n_chunks = len(buf) // rec
+        self.table = torch.frombuffer(buf, dtype=torch.uint8).clone().to(ps[0].device)
+        self.grads = list(grads)                                  # identity of these objects = validity of the table
+        self.grad_ptrs = [g.data_ptr() for g in grads]
+        self.param_ptrs = [p.data_ptr() for p in ps]
+
+    def valid_for(self, ps, grads):
+        if len(grads) != len(self.grads):
+            return False
+        for a, b in zip(grads, self.grads):
+            if a is not b:
+                # a different tensor object may still be the same memory (views re-created by autograd)
+                return ([g.data_ptr() for g in grads] == self.grad_ptrs and [p.data_ptr() for p in ps] == self.param_ptrs
+                        and all(g.is_contiguous() for g in grads))
+        return True
 
 
 class Adam(torch.optim.Adam):
@@ -21,6 +60,8 @@ class Adam(torch.optim.Adam):
         self._lists = None
         self._steps_flat = None
         self._merged = None
+        self._native = None          # (_NativeTable, host step count)
+        self._host_step = None
 
     @staticmethod
     def _all_cuda(params):
@@ -74,6 +115,8 @@ class Adam(torch.optim.Adam):
             out = super().step()              # torch initialises the state on its first call
             self._lists = self._build_lists()
             self._merged = None
+            self._native = None
+            self._host_step = None
             return out
         work = []
         for group, lst in zip(self.param_groups, self._lists):
@@ -91,8 +134,11 @@ class Adam(torch.optim.Adam):
                 self._lists = None
                 return super().step()
             work.append((group, lst, grads))
+        if NATIVE_ADAM and self._steps_flat is not None and self._native_step(work):
+            return None
         if self._steps_flat is not None:
             self._steps_flat.add_(1)
+        self._host_step = None
         if len(work) > 1 and self._steps_flat is not None:
             # groups with identical hyper-parameters (the reference's BatchNorm / other split with weight_decay 0 in both,
             # trainer/self_supervised_trainer.py:78-86) are ONE multi-tensor launch: same arithmetic per tensor
@@ -116,12 +162,44 @@ class Adam(torch.optim.Adam):
                                grad_scale=None, found_inf=None)
         return None
 
+    def _native_step(self, work):
+        """every group with the same hyper-parameters, contiguous fp32 tensors: ONE launch of csrc/adam.hip for all
+        parameters (and their step counters).  Returns False when it does not apply (torch's kernel runs instead)."""
+        g0 = work[0][0]
+        key = (g0['lr'], g0['betas'], g0['weight_decay'], g0['eps'])
+        for g, _, _ in work[1:]:
+            if (g['lr'], g['betas'], g['weight_decay'], g['eps']) != key:
+                return False
+        ps = [t for _, lst, _ in work for t in lst[0]]
+        grads = [t for _, _, gr in work for t in gr]
+        nat = self._native
+        if nat is None or not nat.valid_for(ps, grads):
+            ms = [t for _, lst, _ in work for t in lst[1]]
+            vs = [t for _, lst, _ in work for t in lst[2]]
+            if not all(t.is_contiguous() and t.dtype == torch.float32 for t in ps + grads + ms + vs):
+                return False
+            nat = self._native = _NativeTable(ps, grads, ms, vs)
+        if self._host_step is None:                 # one read-back after construction / load_state_dict / a torch step
+            self._host_step = int(round(float(self._steps_flat[0].item())))
+        t = self._host_step + 1
+        from . import _lib, ops
+        beta1, beta2 = key[1]
+        bc1, bc2s = 1 - beta1 ** t, math.sqrt(1 - beta2 ** t)
+        _lib.check(_lib.load().i3d_adam_step(nat.table.data_ptr(), nat.n_chunks, self._steps_flat.data_ptr(),
+                                             self._steps_flat.numel(), float(key[0]), float(beta1), float(beta2), float(key[2]),
+                                             float(key[3]), bc1, bc2s, ops._stream()), 'i3d_adam_step')
+        self._host_step = t
+        return True
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._lists = None
         self._merged = None
+        self._native = None
+        self._host_step = None
 
     def add_param_group(self, param_group):
         super().add_param_group(param_group)
         self._lists = None
         self._merged = None
+        self._native = None

@@ -415,7 +415,7 @@ def main():
                                          f'QM9-shaped synthetic molecules, batch {B}/GPU, fp32, Adam'),
                                atoms_per_batch=int(batches[0][0].number_of_nodes()),
                                complete_graph_edges_per_batch=int(batches[0][1].number_of_edges()),
-                               optimizer='torch.optim.Adam(fused=True)' if args.torch_adam else 'infomax3d_amd.Adam (torch.optim.Adam subclass, torch._fused_adam_ kernel, cached tensor lists)',
+                               optimizer='torch.optim.Adam(fused=True)' if args.torch_adam else 'infomax3d_amd.Adam (torch.optim.Adam subclass: same state and update expressions, one launch of csrc/adam.hip for all parameter tensors)',
                                global_batch=B * world, parallelism=f'dp{world}' if world > 1 else 'single',
                                sync_bn=(use_dist and args.sync_bn), final_loss=round(float(loss.item()), 5),
                                **({'host_lead_steps_median': sorted(lead_hist)[len(lead_hist) // 2],

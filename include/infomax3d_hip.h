@@ -558,6 +558,17 @@ int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, const float
                            void* gemm_workspace, long gemm_workspace_bytes, int part, int split, void* stream);
 int i3d_pna_model_ctx_free(void* ctx);
 
+/* ---- Adam step of all parameter tensors in one launch (csrc/adam.hip; reference: torch.optim.Adam built by name,
+ * train.py:189, stepped at trainer/trainer.py:120).  chunk_table: device array of n_chunks records {float* param,
+ * const float* grad, float* exp_avg, float* exp_avg_sq, int n} (i3d_adam_chunk_bytes() bytes each, n <=
+ * i3d_adam_chunk_elems()); steps: the n_steps per-parameter step counters (fp32), incremented by the launch;
+ * bias_correction1 = 1 - beta1^t, bias_correction2_sqrt = sqrt(1 - beta2^t) for the step t being taken.
+ * The update is torch's fused Adam expression for expression (L2 weight decay; no amsgrad / maximize / grad scaling). */
+int i3d_adam_chunk_elems(void);
+int i3d_adam_chunk_bytes(void);
+int i3d_adam_step(const void* chunk_table, int n_chunks, float* steps, int n_steps, double lr, double beta1, double beta2,
+                  double weight_decay, double eps, double bias_correction1, double bias_correction2_sqrt, void* stream);
+
 /* ---- contrastive monitoring metrics -------------------------------------------------
  * replaces the nine metric modules of configs_clean/pre-train_QM9.yml:15-24 (reference trainer/metrics.py:161-174,
  * 212-333, 443-463; commons/losses.py:946-959), evaluated every log_iterations steps by
