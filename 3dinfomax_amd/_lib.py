@@ -123,6 +123,9 @@ _SIGNATURES = {
     'i3d_adam_chunk_elems': (c_int, []),
     'i3d_adam_chunk_bytes': (c_int, []),
     'i3d_adam_step': (c_int, [_P, c_int, _P, c_int, c_double, c_double, c_double, c_double, c_double, c_double, c_double, _P]),
+    'i3d_ntxent_loss_scratch_floats': (c_long, [c_int, c_int]),
+    'i3d_ntxent_loss_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P]),
+    'i3d_ntxent_loss_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     'i3d_abi_version': (c_int, []),
     'i3d_last_error': (c_char_p, []),
     'i3d_embedding_sum_fwd': (c_int, [_P, _P, c_int, c_int, POINTER(c_void_p), c_int, _P, _P]),

@@ -353,7 +353,10 @@ extern "C" int i3d_pna_layer_fwd(const I3dPnaLayerArgs* a, void* stream) {
 
 // I3D_WGRAD_FORKS=2: the later pretrans blocks' and the edge block's weight gradients behind one fork (after dP exists)
 // instead of two; measured: three forks per layer -1 % step time, +7 us of host time per layer (the host has the slack)
-static const bool THREE_FORKS = [] { const char* e = getenv("I3D_WGRAD_FORKS"); return e == nullptr || e[0] != '2'; }();
+// Round 2: with ONE join per model backward (model.hip) the side stream runs behind anyway; two forks measured 2.477 ms
+// against 2.493 ms with three (tools/ab.sh, 3 interleaved runs) - the third fork only costs the host its two event calls.
+// Default: 2 forks; I3D_WGRAD_FORKS=3 restores three.
+static const bool THREE_FORKS = [] { const char* e = getenv("I3D_WGRAD_FORKS"); return e != nullptr && e[0] == '3'; }();
 
 extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     I3D_CHECK_ARG(a != nullptr && a->n_pre_extra >= 0 && a->n_pre_extra <= I3D_MAX_EXTRA_FC && a->n_post_extra >= 0 &&

@@ -231,3 +231,51 @@ extern "C" int i3d_row_scale(const float* z, const float* coef, int rows, int di
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }
+
+// ---- the whole loss from one C call per direction (host sequencing only: the kernels above + the similarity GEMMs) ----
+// scratch layout (floats): n1[b1] | n2[b2c] | row_sum[b1] | row_pos[b1] | sim[b1, b2c]  (kept for the backward pass)
+extern "C" long i3d_ntxent_loss_scratch_floats(int b1, int b2c) {
+    auto al = [](long n) { return (n + 3) & ~3L; };
+    return al(b1) + al(b2c) + 2 * al(b1) + al((long)b1 * b2c);
+}
+
+extern "C" int i3d_ntxent_loss_fwd(const float* z1, const float* z2, int b1, int b2, int conf, int dim, int pos_offset, float tau,
+                                   float eps, float loss_scale, float* scratch, float* loss, void* stream) {
+    I3D_CHECK_ARG(z1 != nullptr && z2 != nullptr && scratch != nullptr && loss != nullptr && b1 > 0 && b2 > 0 && conf > 0, "bad arguments");
+    auto al = [](long n) { return (n + 3) & ~3L; };
+    const int b2c = b2 * conf;
+    float* n1 = scratch;
+    float* n2 = n1 + al(b1);
+    float* row_sum = n2 + al(b2c);
+    float* row_pos = row_sum + al(b1);
+    float* sim = row_pos + al(b1);
+    int rc;
+    if ((rc = i3d_row_norms(z1, b1, dim, n1, stream)) != I3D_OK) return rc;
+    if ((rc = i3d_row_norms(z2, b2c, dim, n2, stream)) != I3D_OK) return rc;
+    if ((rc = i3d_gemm_f32(0, 1, b1, b2c, dim, z1, dim, z2, dim, sim, b2c, nullptr, 0, stream)) != I3D_OK) return rc;
+    return i3d_ntxent_fwd(sim, n1, n2, b1, b2, conf, pos_offset, tau, eps, loss_scale, row_sum, row_pos, loss, stream);
+}
+
+// dz1 [b1, dim], dz2 [b2c, dim]; work: b1*b2c + b1 + b2c floats (dsim, ca, cb); grad_scale_dev: the upstream scalar gradient
+extern "C" int i3d_ntxent_loss_bwd(const float* z1, const float* z2, int b1, int b2, int conf, int dim, int pos_offset, float tau,
+                                   float eps, float loss_scale, const float* scratch, const float* grad_scale_dev, float* work,
+                                   float* dz1, float* dz2, void* stream) {
+    I3D_CHECK_ARG(z1 != nullptr && z2 != nullptr && scratch != nullptr && work != nullptr && dz1 != nullptr && dz2 != nullptr, "null");
+    auto al = [](long n) { return (n + 3) & ~3L; };
+    const int b2c = b2 * conf;
+    const float* n1 = scratch;
+    const float* n2 = n1 + al(b1);
+    const float* row_sum = n2 + al(b2c);
+    const float* row_pos = row_sum + al(b1);
+    const float* sim = row_pos + al(b1);
+    float* dsim = work;
+    float* ca = dsim + al((long)b1 * b2c);
+    float* cb = ca + al(b1);
+    int rc;
+    if ((rc = i3d_ntxent_bwd(sim, n1, n2, row_sum, row_pos, b1, b2, conf, pos_offset, tau, eps, loss_scale, grad_scale_dev, dsim, ca,
+                             cb, stream)) != I3D_OK) return rc;
+    if ((rc = i3d_gemm_f32(0, 0, b1, dim, b2c, dsim, b2c, z2, dim, dz1, dim, nullptr, 0, stream)) != I3D_OK) return rc;
+    if ((rc = i3d_row_axpy(z1, ca, b1, dim, dz1, stream)) != I3D_OK) return rc;
+    if ((rc = i3d_gemm_f32(1, 0, b2c, dim, b1, dsim, b2c, z1, dim, dz2, dim, nullptr, 0, stream)) != I3D_OK) return rc;
+    return i3d_row_axpy(z2, cb, b2c, dim, dz2, stream);
+}

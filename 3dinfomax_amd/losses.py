@@ -11,7 +11,12 @@ import torch
 from torch import Tensor
 from torch.nn.modules.loss import _Loss
 
-from . import ops
+import os
+
+from . import _lib, ops
+
+# I3D_LOSS_COMPOSITE=0: the loss as ~5 C calls per direction sequenced from Python (same kernels, same bits)
+LOSS_COMPOSITE = os.environ.get('I3D_LOSS_COMPOSITE', '1') != '0'
 
 
 class _AllGatherRowsFn(torch.autograd.Function):
@@ -41,17 +46,41 @@ class NTXentFn(torch.autograd.Function):
     def forward(ctx, z1, z2, tau, eps, conf, pos_offset, global_batch):
         z1, z2 = z1.contiguous(), z2.contiguous()
         b1, b2 = z1.shape[0], z2.shape[0] // conf
+        if LOSS_COMPOSITE and z1.is_cuda and z1.dtype == torch.float32 and z2.dtype == torch.float32:
+            # row norms, similarity GEMM (MFMA) and the fused exp / row-sum / log kernel from ONE C call (csrc/ntxent.hip)
+            L = _lib.load()
+            scratch = torch.empty(L.i3d_ntxent_loss_scratch_floats(b1, b2 * conf), dtype=torch.float32, device=z1.device)
+            loss = torch.empty(1, dtype=torch.float32, device=z1.device)
+            _lib.check(L.i3d_ntxent_loss_fwd(z1.data_ptr(), z2.data_ptr(), b1, b2, conf, z1.shape[1], pos_offset, float(tau),
+                                             float(eps), 1.0 / global_batch, scratch.data_ptr(), loss.data_ptr(), ops._stream()),
+                       'i3d_ntxent_loss_fwd')
+            ctx.cfg = (tau, eps, conf, pos_offset, global_batch, b1, b2)
+            ctx.composite = True
+            ctx.save_for_backward(z1, z2, scratch)
+            return loss.reshape(())
         n1, n2 = ops.row_norms(z1), ops.row_norms(z2)
         sim = ops.gemm(z1, z2, trans_b=True)                      # [b1, b2*conf] on the MFMA GEMM
         row_sum, row_pos, loss = ops.ntxent_fwd(sim, n1, n2, b1, b2, conf, pos_offset, tau, eps, 1.0 / global_batch)
         ctx.cfg = (tau, eps, conf, pos_offset, global_batch, b1, b2)
+        ctx.composite = False
         ctx.save_for_backward(z1, z2, n1, n2, sim, row_sum, row_pos)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, grad_out):
-        z1, z2, n1, n2, sim, row_sum, row_pos = ctx.saved_tensors
         tau, eps, conf, pos_offset, global_batch, b1, b2 = ctx.cfg
+        if ctx.composite:
+            z1, z2, scratch = ctx.saved_tensors
+            L = _lib.load()
+            b2c = b2 * conf
+            work = torch.empty(b1 * b2c + b1 + b2c + 12, dtype=torch.float32, device=z1.device)
+            dz1, dz2 = torch.empty_like(z1), torch.empty_like(z2)
+            gs = grad_out.contiguous().float()
+            _lib.check(L.i3d_ntxent_loss_bwd(z1.data_ptr(), z2.data_ptr(), b1, b2, conf, z1.shape[1], pos_offset, float(tau),
+                                             float(eps), 1.0 / global_batch, scratch.data_ptr(), gs.data_ptr(), work.data_ptr(),
+                                             dz1.data_ptr(), dz2.data_ptr(), ops._stream()), 'i3d_ntxent_loss_bwd')
+            return dz1, dz2, None, None, None, None, None
+        z1, z2, n1, n2, sim, row_sum, row_pos = ctx.saved_tensors
         # the upstream scalar gradient is multiplied in on the device (no host read-back, no extra elementwise op)
         dsim, ca, cb = ops.ntxent_bwd(sim, n1, n2, row_sum, row_pos, b1, b2, conf, pos_offset, tau, eps,
                                       1.0 / global_batch, grad_out.contiguous().float())

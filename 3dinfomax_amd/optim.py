@@ -107,8 +107,35 @@ class Adam(torch.optim.Adam):
             self._steps_flat = None
         return lists
 
-    @torch.no_grad()
+    def _native_fast(self):
+        """steady state of the one-launch kernel: same gradient tensor objects as last step, same hyper-parameters ->
+        straight to the launch (no tensor lists, no torch.no_grad context: nothing here touches autograd)"""
+        nat = self._native
+        for p, g in zip(nat.params, nat.grads):
+            if p.grad is not g:
+                return False
+        key = nat.key
+        for group in self.param_groups:
+            if (group['lr'], group['betas'], group['weight_decay'], group['eps']) != key or len(group['params']) != nat.group_sizes[id(group)]:
+                return False
+        t = self._host_step + 1
+        from . import _lib, ops
+        beta1, beta2 = key[1]
+        _lib.check(_lib.load().i3d_adam_step(nat.table.data_ptr(), nat.n_chunks, self._steps_flat.data_ptr(),
+                                             self._steps_flat.numel(), float(key[0]), float(beta1), float(beta2), float(key[2]),
+                                             float(key[3]), 1 - beta1 ** t, math.sqrt(1 - beta2 ** t), ops._stream()),
+                   'i3d_adam_step')
+        self._host_step = t
+        return True
+
     def step(self, closure=None):
+        if (closure is None and NATIVE_ADAM and self._native is not None and self._host_step is not None
+                and self._steps_flat is not None and self._native_fast()):
+            return None
+        return self._step_general(closure)
+
+    @torch.no_grad()
+    def _step_general(self, closure=None):
         if closure is not None:
             return super().step(closure)
         if self._lists is None or len(self._lists) != len(self.param_groups):
@@ -179,6 +206,8 @@ class Adam(torch.optim.Adam):
             if not all(t.is_contiguous() and t.dtype == torch.float32 for t in ps + grads + ms + vs):
                 return False
             nat = self._native = _NativeTable(ps, grads, ms, vs)
+            nat.params, nat.key = ps, key
+            nat.group_sizes = {id(g): len(g['params']) for g in self.param_groups}
         if self._host_step is None:                 # one read-back after construction / load_state_dict / a torch step
             self._host_step = int(round(float(self._steps_flat[0].item())))
         t = self._host_step + 1

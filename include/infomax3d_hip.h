@@ -276,6 +276,16 @@ int i3d_ntxent_fwd(const float* sim, const float* n1, const float* n2, int b1, i
 int i3d_ntxent_bwd(const float* sim, const float* n1, const float* n2, const float* row_sum, const float* row_pos,
                    int b1, int b2, int conf, int pos_offset, float tau, float eps, float grad_scale,
                    const float* grad_scale_dev, float* dsim, float* ca, float* cb, void* stream);
+/* the whole loss from one call per direction (row norms, similarity GEMM, i3d_ntxent_fwd / i3d_ntxent_bwd, the two
+ * gradient GEMMs and their normalisation terms; reference commons/losses.py:143-155, 225-247).  scratch
+ * (i3d_ntxent_loss_scratch_floats(b1, b2 * conf) floats) is written by the forward and read by the backward; work:
+ * b1 * b2c + b1 + b2c (+ alignment) floats.  z1 [b1, dim] local rows, z2 [b2 * conf, dim] the (gathered) other view. */
+long i3d_ntxent_loss_scratch_floats(int b1, int b2c);
+int i3d_ntxent_loss_fwd(const float* z1, const float* z2, int b1, int b2, int conf, int dim, int pos_offset, float tau,
+                        float eps, float loss_scale, float* scratch, float* loss, void* stream);
+int i3d_ntxent_loss_bwd(const float* z1, const float* z2, int b1, int b2, int conf, int dim, int pos_offset, float tau,
+                        float eps, float loss_scale, const float* scratch, const float* grad_scale_dev, float* work, float* dz1,
+                        float* dz2, void* stream);
 /* out[r,:] += coef[r] * z[r,:] */
 int i3d_row_axpy(const float* z, const float* coef, int rows, int dim, float* out, void* stream);
 /* out[r,:] = coef[r] * z[r,:]   (graph-size normalisation h * snorm_n, reference models/pna_original.py:258-259) */

@@ -577,12 +577,15 @@ def test_process_level_switches_give_the_same_bits():
         "    optim.step(); optim.zero_grad()\n"
         "torch.save([p.detach().cpu() for p in params], sys.argv[1])\n") % (root, os.path.join(root, 'tests'))
     res = {}
-    variants = {'default': {}, 'no_wgrad_stream': {'I3D_WGRAD_STREAM': '0'}, 'two_forks': {'I3D_WGRAD_FORKS': '2'},
+    variants = {'default': {}, 'no_wgrad_stream': {'I3D_WGRAD_STREAM': '0'}, 'three_forks': {'I3D_WGRAD_FORKS': '3'},
+                'join_per_layer': {'I3D_WGRAD_JOIN': 'layer'}, 'python_sequenced_loss': {'I3D_LOSS_COMPOSITE': '0'},
+                'torch_adam_kernel': None,
                 'fresh_grads': {'I3D_PERSISTENT_GRADS': '0'}, 'separate_final': {'I3D_FUSED_FINAL': '0'},
                 # the whole PNA pass from one C call per direction (csrc/model.hip) vs. sequenced layer by layer from Python
                 'python_sequenced_model': {'I3D_NATIVE_MODEL': '0'},
                 'python_sequenced_fresh_grads': {'I3D_NATIVE_MODEL': '0', 'I3D_PERSISTENT_GRADS': '0'},
                 'autograd_param_grads': {'I3D_DIRECT_PARAM_GRADS': '0'}}
+    variants = {k: v for k, v in variants.items() if v is not None}
     for name, env in variants.items():
         path = f'/tmp/i3d_switch_{name}.pt'
         subprocess.run([sys.executable, '-c', code, path], check=True, env=dict(os.environ, **env), timeout=600)
