@@ -247,14 +247,19 @@ def main():
             ids = rng.permutation(len(all_mols))[:B]
             (a,), (b,) = flat.assemble(ids, dev)
             step_on(a, b)
-        for _ in range(3):
+        for _ in range(8):            # pinned staging slots, copy stream, allocator pools of the copy stream populated
             step_asm()
         torch.cuda.synchronize()
         ta = time.perf_counter()
+        per = []
         for _ in range(n_asm):
+            tb = time.perf_counter()
             step_asm()
+            per.append(time.perf_counter() - tb)
         torch.cuda.synchronize()
         with_assembly_inline = round(n_asm * B / (time.perf_counter() - ta), 1)
+        if os.environ.get('I3D_BENCH_DEBUG'):
+            print('assembly steps, host ms:', ' '.join(f'{1e3 * v:.2f}' for v in per), file=sys.stderr)
         with_assembly = with_assembly_inline
         # the same with the numpy half of the assembly in DataLoader worker processes (dataset.BatchStream) - where the
         # reference runs its per-molecule graph construction: the training process only issues the H2D copies and the
