@@ -8,7 +8,7 @@ import re
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_long, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'lib', 'lib3dinfomax_hip.so')
+LIB_PATH = os.environ.get('I3D_LIB_PATH') or os.path.join(HERE, 'lib', 'lib3dinfomax_hip.so')      # (override: kernel probes of tools/probes)
 HEADER_PATH = os.path.join(os.path.dirname(HERE), 'include', 'infomax3d_hip.h')
 
 # constants of include/infomax3d_hip.h

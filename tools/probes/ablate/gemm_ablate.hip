@@ -1,0 +1,1166 @@
+// Dense tower GEMMs on the fp32 matrix cores of gfx950.
+//
+// Replaces aten::addmm / aten::mm behind nn.Linear in FCLayer (reference models/base_layers.py:101)
+// for the forward (Y = X W^T + b), the data gradient (dX = dY W) and the weight gradient
+// (dW = dY^T X).  Exact fp32: v_mfma_f32_16x16x4_f32 / v_mfma_f32_32x32x2_f32 are bit-for-bit an fp32 fmaf
+// chain (MI355X guide 3), so parity with the reference's CPU fp32 matmul is a summation-order question only.
+//
+// Structure (wave64, 4 waves / workgroup):
+//  * both operand tiles are staged in LDS k-major  T[k][idx]  (idx = m or n), so the MFMA fragment of a lane
+//    is one conflict-free ds_read_b32: for the 16-wide MFMA the two 16-lane halves of a 32-lane group are
+//    steered to different bank halves by XOR-ing bit 4 of idx with ((k ^ (k>>2)) & 1); a 32-wide fragment read is
+//    a permutation of 32 consecutive banks either way.
+//  * register-staged pipeline with a ring of PF K-tiles in flight: the loads of tile t+PF are issued before the
+//    MFMAs of tile t, tile t+1 is written to the other LDS buffer afterwards: one barrier per K-tile.  Every load
+//    of the loop is issued unconditionally (tiles past the end read out of bounds and return 0): a load inside a
+//    branch makes the compiler's vmcnt bookkeeping fall back to vmcnt(0) at the join, which drains the ring.
+//  * loads go through buffer descriptors: lanes outside the matrix pass an offset beyond num_records and the
+//    hardware returns 0 - no per-lane branch around a load (MI355X guide 5 trap (c)); the operand layouts are
+//    template parameters, per-slot address parts are hoisted out of the K loop.
+//  * the MFMA is issued with (W-fragment, X-fragment) so the accumulator holds C^T tiles: a lane owns 4
+//    consecutive output columns of one row -> the epilogue (bias, accumulate, split-K atomics) is 16-byte accesses.
+//  * k-contiguous operands (X[m][k], W[n][k]) are loaded with 16-byte loads along k and transposed on the
+//    LDS write; idx-contiguous operands (dY^T, W for dX) are loaded along idx and written as b128.
+//  * split-K (grid.z) with fp32 atomics ONLY for the row-reduction GEMMs of the backward pass.
+//  * row indirection (m_rows / k_rows) and per-m-tile weight selection (tile_group) for the degree-grouped
+//    posttrans GEMMs of the PNA layer (i3d_gemm_f32_grouped): rows of one in-degree share the combined weight
+//    W_D = W_id + amp(D) W_amp + att(D) W_att, which cuts K from 12F to 4F.
+#include "../../../3dinfomax_amd/csrc/common.h"
+#include <algorithm>
+
+namespace i3d {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    int M, N, K;
+    int lda, ldb, ldc;
+    int accumulate;  // C += ...
+    int k_per_split; // multiple of BK
+    int atomic_out;  // split-K: atomicAdd into C
+    int c_vec;       // 16-byte access to C allowed
+    unsigned a_bytes, b_bytes;  // extent of the operand views in bytes (buffer descriptor num_records)
+    const int* m_rows;      // [M] or null: logical row m lives at row m_rows[m] of A (k-contiguous A only) and of C;
+                            //          -1 = padding row (loads return 0, nothing is stored)
+    const int* k_rows;      // row-segment kernel: reduction index k lives at row k_rows[k] of both operands
+    const int* tile_group;  // [ceil(M/BM)] or null: B of m-tile t is g.B + tile_group[t] * b_group_stride
+    long b_group_stride;    // floats
+    // two-block operands (the [W_s | W_d] halves of an edge-MLP weight addressed as ONE matrix, P trick of edge.hip):
+    // B index (n when B is k-contiguous, k otherwise) >= b_split adds b_delta floats to the address; C rows >= c_split
+    // add c_delta.  split = INT_MAX: plain operand.
+    int b_split, c_split;
+    long b_delta, c_delta;
+    float* slab;            // split-K / row segments: blockIdx.z slice z stores its partial tile to slab[z][M][N]
+                            // (plain 16-byte stores), slab_reduce_kernel sums the slices in a fixed order: deterministic
+                            // and cheaper than fp32 atomics on top of a zero-fill.  null: atomics.
+    // fused BatchNorm (FUSE variants of the forward layout only, see gemm_body):
+    const float* a_aff;     // [3K] mean | scale | shift: the A operand is read as (A[m][k] - mean[k]) * scale[k] + shift[k] -
+                            // the BatchNorm-apply of the block in front, folded into the LDS staging of the consumer
+    float* stats;           // [m tiles][3][N]: per 64-row tile and column {sum, M2 about the tile mean, row count} of the
+                            // values this launch stores (after bias / accumulate / epi_act): the BatchNorm statistics of
+                            // THIS block without a pass over its output (bn_finalize_partials_kernel combines the tiles)
+    int epi_act;            // activation applied to the stored value (I3D_ACT_*)
+};
+
+__device__ __forceinline__ int swz(int k, int idx) { return idx ^ ((((k) ^ (k >> 2)) & 1) << 4); }
+
+// KC: the operand is k-contiguous (T[idx*ld + k]); otherwise idx-contiguous (T[k*ld + idx])
+// IM (k-contiguous operands only): the LDS image is idx-major, T[idx][BK + 2]: the 16-byte global load of 4 consecutive
+// k is stored with two 8-byte writes (instead of four transposing 4-byte writes) and a lane's MFMA operands for two
+// consecutive k-steps come from one 8-byte read; the row pitch BK + 2 keeps both conflict-free.
+template <int R, int LD, int BK, bool KC, bool IM = false, int NT = 256>       // NT: threads of the workgroup
+struct TileStage {
+    static constexpr int LDK = BK + 2;
+    static constexpr int LDS_FLOATS = IM ? R * LDK : BK * LD;
+    static constexpr int SLOTS = R * BK / 4;                 // float4 slots in a tile
+    static constexpr int KQ = BK / 4;                        // float4 slots along k of one row
+    static constexpr int PER_THREAD = (SLOTS + NT - 1) / NT;
+    struct Regs { float4 v[PER_THREAD]; };                   // one K-tile in flight (the kernel keeps a ring of PF of them)
+    unsigned base[PER_THREAD];   // loop-invariant byte offset of the slot (row part or idx part)
+    int kloc[PER_THREAD];        // k of the slot inside a K-tile
+    int iloc[PER_THREAD];        // idx of the slot (idx-contiguous: first of 4)
+    bool ok[PER_THREAD];
+
+    // KC : slot -> (idx = s / KQ, kq = s % KQ), 4 consecutive k of one row
+    // else: slot -> (k = s / (R/4), iq = s % (R/4)), 4 consecutive idx of one k
+    __device__ __forceinline__ void prepare(int ld, int idx0, int idx_max, const int* __restrict__ rows, int split = 0x7fffffff,
+                                            long delta = 0) {
+#pragma unroll
+        for (int it = 0; it < PER_THREAD; ++it) {
+            const int s = threadIdx.x + it * NT;
+            if (KC) {
+                const int idx = idx0 + s / KQ;
+                kloc[it] = (s % KQ) * 4;
+                int row = -1;
+                if (idx < idx_max && s < SLOTS) row = rows ? rows[idx] : idx;
+                ok[it] = row >= 0;
+                iloc[it] = idx;
+                base[it] = (unsigned)((long)max(row, 0) * ld + kloc[it] + (idx >= split ? delta : 0)) * 4u;
+            } else {
+                kloc[it] = s / (R / 4);
+                iloc[it] = idx0 + (s % (R / 4)) * 4;
+                ok[it] = iloc[it] < idx_max && s < SLOTS;
+                base[it] = (unsigned)iloc[it] * 4u;
+            }
+        }
+    }
+
+    // ROWS: kidx is an LDS copy of k_rows[k_begin .. k_end) (LDS reads count on lgkmcnt, so they do not drain the
+    // in-order vmcnt queue of the tiles already in flight)
+    template <bool VEC, bool ROWS>
+    __device__ __forceinline__ void load(Regs& r, __amdgpu_buffer_rsrc_t rsrc, unsigned oob, int ld, int idx_max, int k0,
+                                         int k_begin, int k_end, const int* kidx, int split = 0x7fffffff,
+                                         long delta = 0) const {
+#pragma unroll
+        for (int it = 0; it < PER_THREAD; ++it) {
+            const int k = k0 + kloc[it];
+            unsigned off;
+            const bool valid = ok[it] && k < k_end;
+            if (KC) {
+                off = base[it] + (unsigned)k0 * 4u;
+            } else {
+                int krow = k;
+                if (ROWS) krow = kidx[max(min(k, k_end - 1) - k_begin, 0)];
+                off = (unsigned)((long)krow * ld + (k >= split ? delta : 0)) * 4u + base[it];
+            }
+            if (VEC) {   // contiguous extent is a multiple of 4: a valid first element implies a valid float4
+                auto q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, valid ? off : oob, 0, 0);
+                static_assert(sizeof(q) == 16, "b128 load");
+                r.v[it] = __builtin_bit_cast(float4, q);
+            } else {
+                float e[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool oku = valid && (KC ? (k + u < k_end) : (iloc[it] + u < idx_max));
+                    e[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oku ? off + 4u * u : oob, 0, 0));
+                }
+                r.v[it] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+    }
+
+    // store for the fused BatchNorm-apply prologue (IM image of a k-contiguous operand): aff = LDS copy of [3][KP] mean |
+    // scale | shift (zeros beyond K, so out-of-range k stay finite and meet the zeros of the other operand)
+    __device__ __forceinline__ void store_aff(const Regs& r, float* __restrict__ T, const float* aff, int KP, int k0) const {
+        static_assert(IM, "affine prologue: idx-major image only");
+#pragma unroll
+        for (int it = 0; it < PER_THREAD; ++it) {
+            int s = threadIdx.x + it * NT;
+            if (s < SLOTS) {
+                const int idx = s / KQ, k = (s % KQ) * 4;
+                const int kg = min(k0 + k, KP - 4);
+                const float4 mu = *reinterpret_cast<const float4*>(aff + kg);
+                const float4 sc = *reinterpret_cast<const float4*>(aff + KP + kg);
+                const float4 sh = *reinterpret_cast<const float4*>(aff + 2 * KP + kg);
+                const float4 v = r.v[it];
+                *reinterpret_cast<float2*>(&T[idx * LDK + k]) = make_float2((v.x - mu.x) * sc.x + sh.x, (v.y - mu.y) * sc.y + sh.y);
+                *reinterpret_cast<float2*>(&T[idx * LDK + k + 2]) = make_float2((v.z - mu.z) * sc.z + sh.z, (v.w - mu.w) * sc.w + sh.w);
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(const Regs& r, float* __restrict__ T) const {
+#pragma unroll
+        for (int it = 0; it < PER_THREAD; ++it) {
+            int s = threadIdx.x + it * NT;
+            if (s < SLOTS) {
+                if (IM) {
+                    int idx = s / KQ, k = (s % KQ) * 4;
+                    *reinterpret_cast<float2*>(&T[idx * LDK + k]) = make_float2(r.v[it].x, r.v[it].y);
+                    *reinterpret_cast<float2*>(&T[idx * LDK + k + 2]) = make_float2(r.v[it].z, r.v[it].w);
+                } else if (KC) {
+                    int idx = s / KQ, k = (s % KQ) * 4;
+                    T[(k + 0) * LD + swz(k + 0, idx)] = r.v[it].x;
+                    T[(k + 1) * LD + swz(k + 1, idx)] = r.v[it].y;
+                    T[(k + 2) * LD + swz(k + 2, idx)] = r.v[it].z;
+                    T[(k + 3) * LD + swz(k + 3, idx)] = r.v[it].w;
+                } else {
+                    int k = s / (R / 4), idx = (s % (R / 4)) * 4;
+                    *reinterpret_cast<float4*>(&T[k * LD + swz(k, idx)]) = r.v[it];
+                }
+            }
+        }
+    }
+};
+
+template <int MT> struct Acc;
+template <> struct Acc<16> { typedef floatx4 type; static constexpr int REGS = 4; };
+template <> struct Acc<32> { typedef floatx16 type; static constexpr int REGS = 16; };
+
+// Row-subset / segmented reductions (weight gradients of the degree groups): blockIdx.z walks a table of
+// (k range, output offset) segments, every segment accumulates with atomics into its group's output.
+constexpr int MAX_SEGS = 96;
+constexpr int SEG_MAX_K = 2048;          // k_rows of one segment are staged in LDS
+struct Seg { int k_begin, k_end; long c_off; };
+struct SegTable { Seg s[MAX_SEGS]; };
+
+// Tile shape: MT = MFMA tile (16: v_mfma_f32_16x16x4_f32, 32: v_mfma_f32_32x32x2_f32), a wave computes WM_T x WN_T
+// such tiles; PF = K-tiles in flight per workgroup.
+template <int MT_, int WAVES_M_, int WAVES_N_, int WM_T_, int WN_T_, int BK_, int PF_, bool KP_ = false>
+struct Shape {
+    static constexpr int MT = MT_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, WM_T = WM_T_, WN_T = WN_T_, BK = BK_, PF = PF_;
+    static constexpr bool KP = KP_;     // idx-major LDS image for k-contiguous operands (TileStage IM), 32x32x2 MFMA only
+    static constexpr int BM = WAVES_M * WM_T * MT, BN = WAVES_N * WN_T * MT;
+    static constexpr int NT = 64 * WAVES_M * WAVES_N;      // threads of the workgroup
+};
+
+// blockIdx -> (m tile, n tile, z) such that the workgroups that run on one XCD (observed: linear block id % 8; a speed
+// assumption only) are CONSECUTIVE work items in (z, m tile, n tile) order: the n-tiles of one m-tile - which read
+// the same rows of A - and the tiles of one K split - which read the same rows of both operands - then share that
+// XCD's L2 instead of each pulling their own copy through the fabric (the L2s of the 8 XCDs are separate).
+__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz) {
+    const int nx = gridDim.x, ny = gridDim.y;
+    const int total = nx * ny * gridDim.z;
+    const int id = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const int q = total / 8, r = total % 8, xcd = id % 8;
+    const int w = xcd * q + min(xcd, r) + id / 8;      // XCD x owns q (+1 if x < r) consecutive items
+    by = w % ny;
+    bx = (w / ny) % nx;
+    bz = w / (ny * nx);
+}
+
+// FUSE (forward layout, idx-major image, 64-row tiles only): bit 0 = BatchNorm-apply prologue on A (g.a_aff), bit 1 =
+// activation + per-tile column statistics of the stored values (g.epi_act, g.stats).  K <= FUSE_MAX_K for bit 0.
+constexpr int FUSE_MAX_K = 1024;
+
+template <class S, bool VEC, bool A_KC, bool B_KC, bool ROWS, int FUSE = 0>
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int k_begin, const int k_end,
+                                          float* __restrict__ Cout, const int* kidx, const bool first_split) {
+    constexpr int MT = S::MT, WAVES_N = S::WAVES_N, WM_T = S::WM_T, WN_T = S::WN_T, BK = S::BK, PF = S::PF;
+    constexpr int BM = S::BM, BN = S::BN;
+    constexpr int LDA = (BM + 31) / 32 * 32, LDB = (BN + 31) / 32 * 32;
+    constexpr int KSTEP = (MT == 16) ? 4 : 2;         // k per MFMA
+    constexpr bool A_IM = S::KP && A_KC && MT == 32, B_IM = S::KP && B_KC && MT == 32;
+    typedef TileStage<BM, LDA, BK, A_KC, A_IM, S::NT> StageA;
+    typedef TileStage<BN, LDB, BK, B_KC, B_IM, S::NT> StageB;
+    // one block of LDS: the operand double buffers, reused by the statistics epilogue as the [BM][BN + 1] output tile
+    constexpr int OPER_FLOATS = 2 * StageA::LDS_FLOATS + 2 * StageB::LDS_FLOATS;
+    constexpr int CT_PITCH = BN + 1;
+    constexpr int EPI_FLOATS = (FUSE & 2) ? BM * CT_PITCH + 2 * 4 * BN + BM : 0;
+    __shared__ __attribute__((aligned(16))) float smem[OPER_FLOATS > EPI_FLOATS ? OPER_FLOATS : EPI_FLOATS];
+    __shared__ __attribute__((aligned(16))) float affL[(FUSE & 1) ? 3 * FUSE_MAX_K : 4];
+    float* const As = smem;
+    float* const Bs = smem + 2 * StageA::LDS_FLOATS;
+    static_assert(FUSE == 0 || (A_IM && BM == 64), "fused variants: idx-major A image, 64-row tiles");
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = bx * BM, n0 = by * BN;
+
+    typename Acc<MT>::type acc[WM_T][WN_T];
+#pragma unroll
+    for (int i = 0; i < WM_T; ++i)
+#pragma unroll
+        for (int j = 0; j < WN_T; ++j)
+#pragma unroll
+            for (int r = 0; r < Acc<MT>::REGS; ++r) acc[i][j][r] = 0.f;
+
+    StageA sa;
+    StageB sb;
+    typename StageA::Regs ra_[PF];
+    typename StageB::Regs rb_[PF];
+    // descriptors are built from kernel arguments / blockIdx only (wave-uniform: no waterfall loops, guide T20)
+    const float* Bp = g.B;
+    if (g.tile_group != nullptr) Bp += (long)g.tile_group[bx] * g.b_group_stride;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bp), 0, g.b_bytes, 0x00020000);
+    sa.prepare(g.lda, m0, g.M, g.m_rows);
+    sb.prepare(g.ldb, n0, g.N, nullptr, g.b_split, g.b_delta);
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        sa.template load<VEC, ROWS>(ra_[u], ra, g.a_bytes, g.lda, g.M, k_begin + u * BK, k_begin, k_end, kidx);
+        sb.template load<VEC, ROWS>(rb_[u], rb, g.b_bytes, g.ldb, g.N, k_begin + u * BK, k_begin, k_end, kidx, g.b_split, g.b_delta);
+    }
+    const int KP = (g.K + 3) & ~3;
+    if constexpr ((FUSE & 1) != 0) {          // per-k mean | scale | shift of the BatchNorm in front, zero-padded
+        for (int i = threadIdx.x; i < 3 * KP; i += S::NT) {
+            const int part = i / KP, k = i - part * KP;
+            affL[i] = k < g.K ? g.a_aff[part * g.K + k] : 0.f;
+        }
+        __syncthreads();
+        sa.store_aff(ra_[0], As, affL, KP, k_begin);
+    } else {
+        sa.store(ra_[0], As);
+    }
+    sb.store(rb_[0], Bs);
+    __syncthreads();
+    const int lt = lane % MT, lk = lane / MT;
+    for (int kt = 0; kt < nk; kt += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            // tile t is in LDS buffer t & 1; ring slot u (tile t) was written to LDS one iteration ago and is free
+            const int t = kt + u;
+            const int cur = (PF % 2 == 0) ? (u & 1) : (t & 1);
+#ifndef I3D_ABLATE_NOLOAD
+            sa.template load<VEC, ROWS>(ra_[u], ra, g.a_bytes, g.lda, g.M, k_begin + (t + PF) * BK, k_begin, k_end, kidx);
+            sb.template load<VEC, ROWS>(rb_[u], rb, g.b_bytes, g.ldb, g.N, k_begin + (t + PF) * BK, k_begin, k_end, kidx, g.b_split,
+                                        g.b_delta);
+#endif
+            if (t < nk) {
+                const float* as = As + cur * StageA::LDS_FLOATS;
+                const float* bs = Bs + cur * StageB::LDS_FLOATS;
+                if constexpr (S::KP && MT == 32) {
+                    // two k-steps per trip: lane half lk supplies k = 4 j + 2 lk (step 2j) and 4 j + 2 lk + 1 (step 2j+1)
+#pragma unroll
+                    for (int j4 = 0; j4 < BK / 4; ++j4) {
+                        const int k0 = 4 * j4 + 2 * lk;
+                        float a0[WM_T], a1[WM_T], b0[WN_T], b1[WN_T];
+#pragma unroll
+                        for (int i = 0; i < WM_T; ++i) {
+                            const int idx = (wm * WM_T + i) * MT + lt;
+                            if constexpr (A_IM) {
+                                const float2 v = *reinterpret_cast<const float2*>(&as[idx * StageA::LDK + k0]);
+                                a0[i] = v.x; a1[i] = v.y;
+                            } else {
+                                a0[i] = as[k0 * LDA + swz(k0, idx)];
+                                a1[i] = as[(k0 + 1) * LDA + swz(k0 + 1, idx)];
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < WN_T; ++j) {
+                            const int idx = (wn * WN_T + j) * MT + lt;
+                            if constexpr (B_IM) {
+                                const float2 v = *reinterpret_cast<const float2*>(&bs[idx * StageB::LDK + k0]);
+                                b0[j] = v.x; b1[j] = v.y;
+                            } else {
+                                b0[j] = bs[k0 * LDB + swz(k0, idx)];
+                                b1[j] = bs[(k0 + 1) * LDB + swz(k0 + 1, idx)];
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < WM_T; ++i)
+#pragma unroll
+                            for (int j = 0; j < WN_T; ++j) {
+#ifdef I3D_ABLATE_NOMFMA
+                                acc[i][j][0] += b0[j] * a0[i] + b1[j] * a1[i];
+#else
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[j], a0[i], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[j], a1[i], acc[i][j], 0, 0, 0);
+#endif
+                            }
+                    }
+                } else
+#pragma unroll
+                for (int kk = 0; kk < BK / KSTEP; ++kk) {
+                    const int kr = kk * KSTEP + lk;
+                    float af[WM_T], bf[WN_T];
+#pragma unroll
+                    for (int i = 0; i < WM_T; ++i) af[i] = as[kr * LDA + swz(kr, (wm * WM_T + i) * MT + lt)];
+#pragma unroll
+                    for (int j = 0; j < WN_T; ++j) bf[j] = bs[kr * LDB + swz(kr, (wn * WN_T + j) * MT + lt)];
+#pragma unroll
+                    for (int i = 0; i < WM_T; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN_T; ++j) {
+                            if constexpr (MT == 16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j], af[i], acc[i][j], 0, 0, 0);
+                        }
+                }
+            }
+#ifndef I3D_ABLATE_NOSTORE
+            if constexpr ((FUSE & 1) != 0)
+                sa.store_aff(ra_[(u + 1) % PF], As + (cur ^ 1) * StageA::LDS_FLOATS, affL, KP, k_begin + (t + 1) * BK);
+            else
+                sa.store(ra_[(u + 1) % PF], As + (cur ^ 1) * StageA::LDS_FLOATS);     // tile t+1 (zeros past the end)
+            sb.store(rb_[(u + 1) % PF], Bs + (cur ^ 1) * StageB::LDS_FLOATS);
+            __syncthreads();
+#endif
+        }
+    }
+
+    // epilogue.  D[row = n][col = m]; a lane owns one m (lane % MT) and groups of 4 consecutive n:
+    //   MT = 16: n = 4*(lane>>4) + 0..3 (one group);  MT = 32: n = 8*grp + 4*(lane>>5) + 0..3, grp = 0..3
+    const bool add_bias = g.bias != nullptr && first_split;
+    constexpr int GROUPS = (MT == 16) ? 1 : 4;
+    float* const Ct = smem;                               // statistics epilogue: [BM][CT_PITCH] stored values
+    float* const red = smem + BM * CT_PITCH;              // [2][4][BN]
+    float* const rvalid = red + 2 * 4 * BN;               // [BM] 1 / 0
+#pragma unroll
+    for (int i = 0; i < WM_T; ++i) {
+        const int ml = (wm * WM_T + i) * MT + lt;
+        const int m = m0 + ml;
+        int row = -1;
+        if (m < g.M) row = g.m_rows ? g.m_rows[m] : m;
+        if constexpr ((FUSE & 2) != 0) {
+            if (wn == 0 && lk == 0) rvalid[ml] = row >= 0 ? 1.f : 0.f;
+        }
+        if (row < 0) continue;
+#pragma unroll
+        for (int j = 0; j < WN_T; ++j) {
+#pragma unroll
+            for (int grp = 0; grp < GROUPS; ++grp) {
+                const int nl = (wn * WN_T + j) * MT + ((MT == 16) ? lk * 4 : 8 * grp + 4 * lk);
+                const int n = n0 + nl;
+                if (n >= g.N) continue;
+                float r[4] = {acc[i][j][4 * grp + 0], acc[i][j][4 * grp + 1], acc[i][j][4 * grp + 2], acc[i][j][4 * grp + 3]};
+                float* c = Cout + (long)row * g.ldc + n + (row >= g.c_split ? g.c_delta : 0);
+                const bool full = (n + 3 < g.N);
+                if (add_bias) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < g.N) r[q] += g.bias[n + q];
+                }
+                if constexpr ((FUSE & 2) != 0) {
+                    // C (+)= ... then the activation; the stored values also go to the LDS tile for the column statistics
+                    if (g.accumulate) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (n + q < g.N) r[q] += c[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) r[q] = apply_act(r[q], g.epi_act);
+                    if (full && g.c_vec) {
+                        *reinterpret_cast<float4*>(c) = make_float4(r[0], r[1], r[2], r[3]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (n + q < g.N) c[q] = r[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Ct[ml * CT_PITCH + nl + q] = r[q];
+                    continue;
+                }
+                if (g.atomic_out) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < g.N) unsafeAtomicAdd(c + q, r[q]);
+                } else if (full && g.c_vec) {
+                    float4 o = make_float4(r[0], r[1], r[2], r[3]);
+                    if (g.accumulate) {
+                        float4 old = *reinterpret_cast<const float4*>(c);
+                        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                    }
+                    *reinterpret_cast<float4*>(c) = o;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < g.N) c[q] = g.accumulate ? c[q] + r[q] : r[q];
+                }
+            }
+        }
+    }
+    if constexpr ((FUSE & 2) != 0) {
+        // per-tile column statistics: 4 row quarters x BN columns; sum -> tile mean -> M2 about it (no cancellation),
+        // every combination in a fixed order (deterministic)
+        static_assert(S::NT == 4 * BN, "statistics epilogue: four row quarters per column");
+        __syncthreads();
+        const int cl = threadIdx.x % BN, part = threadIdx.x / BN;
+        constexpr int RQ = BM / 4;
+        float x[RQ], v[RQ];
+        float s1 = 0.f, cnt = 0.f;
+#pragma unroll
+        for (int k = 0; k < RQ; ++k) {
+            const int ml = part * RQ + k;
+            v[k] = rvalid[ml];
+            x[k] = v[k] != 0.f ? Ct[ml * CT_PITCH + cl] : 0.f;
+            s1 += x[k];
+            cnt += v[k];
+        }
+        red[part * BN + cl] = s1;
+        red[4 * BN + part * BN + cl] = cnt;
+        __syncthreads();
+        const float tot = ((red[cl] + red[BN + cl]) + red[2 * BN + cl]) + red[3 * BN + cl];
+        const float n_rows = ((red[4 * BN + cl] + red[5 * BN + cl]) + red[6 * BN + cl]) + red[7 * BN + cl];
+        const float mean_t = n_rows > 0.f ? tot / n_rows : 0.f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < RQ; ++k) {
+            const float d = x[k] - mean_t;
+            if (v[k] != 0.f) m2 += d * d;
+        }
+        __syncthreads();
+        red[part * BN + cl] = m2;
+        __syncthreads();
+        if (part == 0 && n0 + cl < g.N) {
+            float* o = g.stats + (long)bx * 3 * g.N + n0 + cl;
+            o[0] = tot;
+            o[g.N] = ((red[cl] + red[BN + cl]) + red[2 * BN + cl]) + red[3 * BN + cl];
+            o[2 * g.N] = n_rows;
+        }
+    }
+}
+
+template <class S, bool VEC, bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(256)
+gemm_f32_kernel(GemmArgs g) {
+    int bx, by, bz;
+    xcd_tile(bx, by, bz);
+    const int k_begin = bz * g.k_per_split;
+    const int k_end = min(g.K, k_begin + g.k_per_split);
+    if (g.slab != nullptr) {           // every slice writes (zeros for an empty one): the reduction reads them all
+        GemmArgs gl = g;
+        gl.ldc = g.N; gl.accumulate = 0; gl.atomic_out = 0; gl.c_vec = (g.N % 4 == 0); gl.bias = nullptr;
+        gl.c_split = 0x7fffffff; gl.c_delta = 0;
+        gemm_body<S, VEC, A_KC, B_KC, false>(gl, bx, by, min(k_begin, g.K), k_end, g.slab + (long)bz * g.M * g.N, nullptr, false);
+        return;
+    }
+    if (k_begin >= k_end && !(bz == 0)) return;
+    gemm_body<S, VEC, A_KC, B_KC, false>(g, bx, by, k_begin, k_end, g.C, nullptr, bz == 0);
+}
+
+template <class S, bool VEC>
+__global__ void __launch_bounds__(256)
+gemm_f32_rowseg_kernel(GemmArgs g, SegTable segs) {
+    __shared__ int kidx[SEG_MAX_K];
+    int bx, by, bz;
+    xcd_tile(bx, by, bz);
+    const Seg sg = segs.s[bz];
+    for (int i = threadIdx.x; i < sg.k_end - sg.k_begin; i += S::NT) kidx[i] = g.k_rows[sg.k_begin + i];
+    __syncthreads();
+    if (g.slab != nullptr) {
+        GemmArgs gl = g;
+        gl.ldc = g.N; gl.accumulate = 0; gl.atomic_out = 0; gl.c_vec = (g.N % 4 == 0);
+        gl.c_split = 0x7fffffff; gl.c_delta = 0;
+        gemm_body<S, VEC, false, false, true>(gl, bx, by, sg.k_begin, sg.k_end, g.slab + (long)bz * g.M * g.N, kidx, false);
+        return;
+    }
+    gemm_body<S, VEC, false, false, true>(g, bx, by, sg.k_begin, sg.k_end, g.C + sg.c_off, kidx, false);
+}
+
+// C_g[m, n] (+)= sum_{z in [seg_ptr[g], seg_ptr[g+1])} slab[z][m][n]   (fixed order: deterministic)
+struct SlabReduce {
+    const float* slab;
+    float* C;
+    const float* bias;
+    int M, N, ldc, accumulate, n_groups;
+    long c_group_stride;
+    int c_split;       // rows >= c_split of C are displaced by c_delta floats (two-block outputs)
+    long c_delta;
+    int seg_ptr[34];
+    // weight gradient against a BatchNorm output that was never materialised (fused_bn.hip): the GEMM ran on the raw
+    // activation x, y = (x - mean) * scale + shift per column n, so  dW[m][n] = (sum - row[m] mean[n]) scale[n] + row[m] shift[n]
+    // with row[m] = sum over the rows of dY[:, m] (the bias gradient).  null: plain sum.
+    const float* post_aff;   // [3N] mean | scale | shift
+    const float* post_row;   // [M]
+};
+
+template <int V>
+__global__ void __launch_bounds__(256) slab_reduce_kernel(SlabReduce a) {
+    const int NV = a.N / V;
+    const long per_group = (long)a.M * NV;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per_group * a.n_groups) return;
+    const int gi = (int)(t / per_group);
+    const long r = t - gi * per_group;
+    const int m = (int)(r / NV), n = (int)(r - (long)m * NV) * V;
+    float* c = a.C + gi * a.c_group_stride + (long)m * a.ldc + n + (m >= a.c_split ? a.c_delta : 0);
+    float acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = a.accumulate ? c[i] : 0.f;
+    const long slice = (long)a.M * a.N;
+    const float* p = a.slab + (long)m * a.N + n;
+    const int z_end = a.seg_ptr[gi + 1];
+    for (int z0 = a.seg_ptr[gi]; z0 < z_end; z0 += 4) {     // four slices in flight per trip, summed in slice order
+        float x[4][V];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float* q = p + (long)min(z0 + k, z_end - 1) * slice;
+            if (V == 4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(q);
+                x[k][0] = t4.x; x[k][1 % V] = t4.y; x[k][2 % V] = t4.z; x[k][3 % V] = t4.w;
+            } else {
+                x[k][0] = q[0];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (z0 + k < z_end) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) acc[i] += x[k][i];
+            }
+        }
+    }
+    if (a.bias != nullptr) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] += a.bias[n + i];
+    }
+    if (a.post_aff != nullptr) {
+        const float rw = a.post_row[m];
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+            acc[i] = (acc[i] - rw * a.post_aff[n + i]) * a.post_aff[a.N + n + i] + rw * a.post_aff[2 * a.N + n + i];
+    }
+    if (V == 4) *reinterpret_cast<float4*>(c) = make_float4(acc[0], acc[1 % V], acc[2 % V], acc[3 % V]);
+    else c[0] = acc[0];
+}
+
+// the same fix-up as a kernel of its own (the product did not go through the slab)
+__global__ void __launch_bounds__(256)
+wgrad_bn_fixup_kernel(float* __restrict__ C, int M, int N, int ldc, const float* __restrict__ aff, const float* __restrict__ row) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)M * N) return;
+    const int m = (int)(t / N), n = (int)(t - (long)m * N);
+    const float rw = row[m];
+    C[(long)m * ldc + n] = (C[(long)m * ldc + n] - rw * aff[n]) * aff[N + n] + rw * aff[2 * N + n];
+}
+
+// few outputs, many slices (the 20-wide 3D network: 400 outputs, ~270 slices): 16 lanes share the slices of one output
+// item and are combined through LDS in lane order (still a fixed summation order)
+constexpr int ZL = 16;
+template <int V>
+__global__ void __launch_bounds__(256) slab_reduce_small_kernel(SlabReduce a) {
+    __shared__ float sm[256 / ZL][ZL][V];
+    const int NV = a.N / V;
+    const long per_group = (long)a.M * NV;
+    const int il = threadIdx.x / ZL, zl = threadIdx.x % ZL;
+    const long t = (long)blockIdx.x * (256 / ZL) + il;
+    const bool live = t < per_group * a.n_groups;
+    int gi = 0, m = 0, n = 0;
+    float acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = 0.f;
+    if (live) {
+        gi = (int)(t / per_group);
+        const long r = t - gi * per_group;
+        m = (int)(r / NV);
+        n = (int)(r - (long)m * NV) * V;
+        const long slice = (long)a.M * a.N;
+        const float* p = a.slab + (long)m * a.N + n;
+        const int z_end = a.seg_ptr[gi + 1];
+        for (int z0 = a.seg_ptr[gi] + zl; z0 < z_end; z0 += 4 * ZL) {      // four of this lane's slices in flight per trip
+            float x[4][V];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int z = z0 + k * ZL;
+                const float* q = p + (long)(z < z_end ? z : z0) * slice;
+                if (V == 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(q);
+                    x[k][0] = t4.x; x[k][1 % V] = t4.y; x[k][2 % V] = t4.z; x[k][3 % V] = t4.w;
+                } else {
+                    x[k][0] = q[0];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (z0 + k * ZL < z_end) {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) acc[i] += x[k][i];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) sm[il][zl][i] = acc[i];
+    __syncthreads();
+    if (!live || zl != 0) return;
+    float* c = a.C + gi * a.c_group_stride + (long)m * a.ldc + n + (m >= a.c_split ? a.c_delta : 0);
+    float tot[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) tot[i] = a.accumulate ? c[i] : 0.f;
+    for (int k = 0; k < ZL; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) tot[i] += sm[il][k][i];
+    if (a.bias != nullptr) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) tot[i] += a.bias[n + i];
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) c[i] = tot[i];
+}
+
+static void launch_slab_reduce(const SlabReduce& a, hipStream_t s) {
+    const bool v4 = a.N % 4 == 0 && a.ldc % 4 == 0 && a.c_group_stride % 4 == 0 && a.c_delta % 4 == 0 &&
+                    (((uintptr_t)a.C | (uintptr_t)a.slab) & 15) == 0;
+    const long items = (long)a.n_groups * a.M * (v4 ? a.N / 4 : a.N);
+    const int slices = a.seg_ptr[a.n_groups] - a.seg_ptr[0];
+    if (items <= 8192 && slices >= 4 * ZL && a.post_aff == nullptr) {
+        dim3 grid(cdiv(items, 256 / ZL));
+        if (v4) hipLaunchKernelGGL(slab_reduce_small_kernel<4>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(slab_reduce_small_kernel<1>, grid, dim3(256), 0, s, a);
+        return;
+    }
+    if (v4) hipLaunchKernelGGL(slab_reduce_kernel<4>, dim3(cdiv(items, 256)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(slab_reduce_kernel<1>, dim3(cdiv(items, 256)), dim3(256), 0, s, a);
+}
+
+// layout: 0 forward (A and B k-contiguous), 1 data gradient (A k-contiguous, B idx-contiguous),
+//         2 weight gradient (both idx-contiguous), 3 (A idx-contiguous, B k-contiguous; not on the training path)
+template <class S>
+static void launch(const GemmArgs& g, int layout, int splits, bool vec, hipStream_t s) {
+    dim3 grid(cdiv(g.M, S::BM), cdiv(g.N, S::BN), splits), block(S::NT);
+#define I3D_GEMM_LAUNCH(V, AK, BKC) hipLaunchKernelGGL((gemm_f32_kernel<S, V, AK, BKC>), grid, block, 0, s, g)
+    switch (layout * 2 + (vec ? 1 : 0)) {
+        case 0: I3D_GEMM_LAUNCH(false, true, true); break;
+        case 1: I3D_GEMM_LAUNCH(true, true, true); break;
+        case 2: I3D_GEMM_LAUNCH(false, true, false); break;
+        case 3: I3D_GEMM_LAUNCH(true, true, false); break;
+        case 4: I3D_GEMM_LAUNCH(false, false, false); break;
+        default: I3D_GEMM_LAUNCH(true, false, false); break;
+    }
+#undef I3D_GEMM_LAUNCH
+}
+
+template <class S>
+static void launch_rowseg(const GemmArgs& g, const SegTable& t, int n_segs, bool vec, hipStream_t s) {
+    dim3 grid(cdiv(g.M, S::BM), cdiv(g.N, S::BN), n_segs);
+    if (vec) hipLaunchKernelGGL((gemm_f32_rowseg_kernel<S, true>), grid, dim3(S::NT), 0, s, g, t);
+    else hipLaunchKernelGGL((gemm_f32_rowseg_kernel<S, false>), grid, dim3(S::NT), 0, s, g, t);
+}
+
+// tile configurations; the numbering is part of the tuning entry i3d_gemm_f32_ex
+//   0: 128x128x16 (32x32x2)  1: 256x32x16 (16x16x4)  2: 64x64x16 (32x32x2)  3: 32x64x32 (16x16x4)
+//   4: 64x64x32 (32x32x2)    5: 128x64x16 (32x32x2)  6 / 7: as 2 with 1 / 2 K-tiles in flight instead of 4
+//   8: 32x32x32 (16x16x4): weight gradients of the narrow (hidden_dim 20) 3D network, K = number of edges
+//   9 / 10: as 2 / 0 with the idx-major LDS image (TileStage IM) for k-contiguous operands
+//   11: 64x32x16, two waves (32x32x2, idx-major image)   12: 32x32x16, one wave
+typedef Shape<32, 2, 2, 2, 2, 16, 2> Cfg0;
+typedef Shape<16, 4, 1, 4, 2, 16, 2> Cfg1;
+typedef Shape<32, 2, 2, 1, 1, 16, 4> Cfg2;
+typedef Shape<16, 2, 2, 1, 2, 32, 2> Cfg3;
+typedef Shape<32, 2, 2, 1, 1, 32, 2> Cfg4;
+typedef Shape<32, 2, 2, 2, 1, 16, 4> Cfg5;
+typedef Shape<32, 2, 2, 1, 1, 16, 1> Cfg6;
+typedef Shape<32, 2, 2, 1, 1, 16, 2> Cfg7;
+typedef Shape<16, 2, 2, 1, 1, 32, 2> Cfg8;
+typedef Shape<32, 2, 2, 1, 1, 16, 4, true> Cfg9;       // as 2 with the idx-major LDS image for k-contiguous operands
+typedef Shape<32, 2, 2, 2, 2, 16, 2, true> Cfg10;      // as 0 with it
+typedef Shape<32, 2, 1, 1, 1, 16, 4, true> Cfg11;      // 64x32 tile, two waves: N = 200 in 7 column tiles instead of 4 x 64
+typedef Shape<32, 1, 1, 1, 1, 16, 4, true> Cfg12;      // 32x32 tile, one wave
+constexpr int N_CFG = 13;
+static const int CFG_BM[N_CFG] = {Cfg0::BM, Cfg1::BM, Cfg2::BM, Cfg3::BM, Cfg4::BM, Cfg5::BM, Cfg6::BM, Cfg7::BM, Cfg8::BM, Cfg9::BM, Cfg10::BM, Cfg11::BM, Cfg12::BM};
+static const int CFG_BN[N_CFG] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN, Cfg9::BN, Cfg10::BN, Cfg11::BN, Cfg12::BN};
+static const int CFG_BK[N_CFG] = {Cfg0::BK, Cfg1::BK, Cfg2::BK, Cfg3::BK, Cfg4::BK, Cfg5::BK, Cfg6::BK, Cfg7::BK, Cfg8::BK, Cfg9::BK, Cfg10::BK, Cfg11::BK, Cfg12::BK};
+
+// the (A idx-contiguous, B k-contiguous) layout is computed as layout 2 would need B transposed: it only exists for
+// API completeness, through one configuration
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+gemm_f32_tt_kernel(GemmArgs g) {
+    gemm_body<Cfg6, VEC, false, true, false>(g, blockIdx.x, blockIdx.y, 0, g.K, g.C, nullptr, true);
+}
+
+// forward layout (A and B k-contiguous, 16-byte loads) with the fused BatchNorm prologue / statistics epilogue
+template <class S, int FUSE>
+__global__ void __launch_bounds__(256)
+gemm_f32_fused_kernel(GemmArgs g) {
+    int bx, by, bz;
+    xcd_tile(bx, by, bz);
+    gemm_body<S, true, true, true, false, FUSE>(g, bx, by, 0, g.K, g.C, nullptr, true);
+}
+
+template <class S>
+static void launch_fused(const GemmArgs& g, int fuse, hipStream_t s) {
+    dim3 grid(cdiv(g.M, S::BM), cdiv(g.N, S::BN), 1), block(S::NT);
+    switch (fuse) {
+        case 1: hipLaunchKernelGGL((gemm_f32_fused_kernel<S, 1>), grid, block, 0, s, g); break;
+        case 2: hipLaunchKernelGGL((gemm_f32_fused_kernel<S, 2>), grid, block, 0, s, g); break;
+        default: hipLaunchKernelGGL((gemm_f32_fused_kernel<S, 3>), grid, block, 0, s, g); break;
+    }
+}
+
+struct Extra {
+    const int* m_rows = nullptr;
+    const int* k_rows = nullptr;
+    const int* tile_group = nullptr;
+    long b_group_stride = 0;
+    long a_rows_total = -1;   // number of physical rows of A / C when m_rows is used (for the descriptor extent)
+    long k_rows_total = -1;   // number of physical rows of the operands when k_rows is used
+    // row-subset reductions: n_groups disjoint ranges [start, start + count) of k_rows, one output per group
+    int n_groups = 0;
+    const int* group_start = nullptr;
+    const int* group_count = nullptr;
+    long c_group_stride = 0;
+    // scratch for the two-stage split-K / row-segment reduction (slices x M x N floats); null or too small: atomics
+    void* workspace = nullptr;
+    long workspace_bytes = 0;
+    // two-block operands (GemmArgs::b_split ...); b_view_floats = addressable floats behind B when b_split is used
+    int b_split = 0x7fffffff, c_split = 0x7fffffff;
+    long b_delta = 0, c_delta = 0, b_view_floats = 0;
+    const float* post_aff = nullptr;   // SlabReduce::post_aff / post_row
+    const float* post_row = nullptr;
+};
+
+static int fill_views(GemmArgs& g, int trans_a, int trans_b, int M, int N, int K, int lda, int ldb, const Extra& ex) {
+    long a_rows = trans_a ? K : M, a_cols = trans_a ? M : K, b_rows = trans_b ? N : K, b_cols = trans_b ? K : N;
+    if (!trans_a && ex.m_rows) a_rows = ex.a_rows_total;
+    if (trans_a && ex.k_rows) a_rows = ex.k_rows_total;
+    if (!trans_b && ex.k_rows) b_rows = ex.k_rows_total;
+    const long ab = a_rows > 0 ? ((a_rows - 1) * lda + a_cols) * 4 : 0, bb = b_rows > 0 ? ((b_rows - 1) * ldb + b_cols) * 4 : 0;
+    I3D_CHECK_ARG(ab < (1L << 32) - 16 && bb < (1L << 32) - 16, "operand view larger than 4 GiB (32-bit buffer offsets)");
+    g.a_bytes = (unsigned)ab;
+    g.b_bytes = (unsigned)bb;
+    return I3D_OK;
+}
+
+static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                     float* C, int ldc, const float* bias, int accumulate, int force_cfg, int force_splits,
+                     const Extra& ex, void* stream) {
+    I3D_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "negative dimension");
+    I3D_CHECK_ARG(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, "leading dimension too small");
+    if (M == 0 || N == 0) return I3D_OK;
+    hipStream_t s = (hipStream_t)stream;
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.accumulate = accumulate ? 1 : 0;
+    g.m_rows = ex.m_rows; g.k_rows = nullptr; g.tile_group = ex.tile_group; g.b_group_stride = ex.b_group_stride;
+    g.slab = nullptr;
+    g.a_aff = nullptr; g.stats = nullptr; g.epi_act = I3D_ACT_NONE;
+    g.b_split = ex.b_split; g.b_delta = ex.b_delta; g.c_split = ex.c_split; g.c_delta = ex.c_delta;
+    int rc = fill_views(g, trans_a, trans_b, M, N, K, lda, ldb, ex);
+    if (rc != I3D_OK) return rc;
+    if (ex.b_view_floats > 0) {
+        I3D_CHECK_ARG(ex.b_view_floats * 4 < (1L << 32) - 16, "operand view larger than 4 GiB (32-bit buffer offsets)");
+        g.b_bytes = (unsigned)(ex.b_view_floats * 4);
+    }
+    const bool a_al = (((uintptr_t)A & 15) == 0) && (lda % 4 == 0), b_al = (((uintptr_t)B & 15) == 0) && (ldb % 4 == 0);
+    g.c_vec = (((uintptr_t)C & 15) == 0) && (ldc % 4 == 0);
+    // fast path: 16-byte loads need aligned pointers / leading dimensions and contiguous extents that are
+    // multiples of 4 (K for k-contiguous operands, M or N for the others)
+    const bool vec = a_al && b_al && ((trans_a ? M : K) % 4 == 0) && ((trans_b ? K : N) % 4 == 0) &&
+                     (ex.b_group_stride % 4 == 0) && (ex.b_delta % 4 == 0);
+    if (ex.c_delta % 4 != 0) g.c_vec = 0;
+    const int layout = trans_a ? (trans_b ? 3 : 2) : (trans_b ? 0 : 1);
+
+    if (layout == 3) {
+        I3D_CHECK_ARG(ex.m_rows == nullptr && ex.tile_group == nullptr, "row indirection needs a k-contiguous A");
+        g.k_per_split = K; g.atomic_out = 0;
+        dim3 grid(cdiv(M, Cfg6::BM), cdiv(N, Cfg6::BN), 1);
+        if (vec) hipLaunchKernelGGL((gemm_f32_tt_kernel<true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_f32_tt_kernel<false>), grid, dim3(256), 0, s, g);
+        I3D_CHECK_LAUNCH();
+        return I3D_OK;
+    }
+
+    // tile configuration, measured on MI355X at the step's shapes (tools/gemm_bench.py, profiles/r01_gemm_bench_*.log):
+    // the batch is small for a 256-CU chip, so many 64x64 tiles beat fewer big ones until there are thousands of tiles.
+    int cfg;
+    const long tiles64 = (long)cdiv(M, 64) * cdiv(N, 64);
+    const bool have_ws = ex.workspace != nullptr && (((uintptr_t)ex.workspace & 15) == 0) && ex.m_rows == nullptr;
+    if (trans_a && M <= 32 && N <= 32) cfg = 8;
+    else if (trans_a && have_ws && tiles64 <= 16) cfg = 8;   // small weight gradients: 32x32 tiles, slices through the scratch
+    else if (N <= 32) cfg = 1;
+    else if (tiles64 >= 4096) cfg = 0;
+    else if (trans_a && tiles64 < 512) cfg = 3;   // weight gradients: few output tiles, long K
+    else cfg = 2;
+    if (ex.tile_group != nullptr) cfg = 2;        // the group padding of m_rows is 64 rows
+    if (cfg == 2 && (!trans_a || trans_b)) cfg = 9;   // a k-contiguous operand: idx-major LDS image (2-4 % faster, r01_gemm_bench_v5)
+    // N = 200 fills 6.25 of the 8 32-wide wave tiles of four 64-wide column tiles (a quarter of the waves do nothing
+    // useful); in 64x32 tiles of two waves it is 7 column tiles, 12 % padding: -18..-21 % on the long-K forward shapes
+    // (post4 [N,4F] x [F,4F]^T: 50 -> 41 us), slower when K is short (r01_gemm_bench_v6)
+    if (cfg == 9 && !trans_a && K >= 400 && (long)cdiv(N, 64) * 64 * 10 > (long)cdiv(N, 32) * 32 * 11) cfg = 11;
+    if (force_cfg >= 0) {
+        I3D_CHECK_ARG(force_cfg < N_CFG, "tile_cfg out of range");
+        I3D_CHECK_ARG(ex.tile_group == nullptr || CFG_BM[force_cfg] == 64, "grouped GEMM needs 64-row tiles");
+        cfg = force_cfg;
+    }
+    const int bm = CFG_BM[cfg], bn = CFG_BN[cfg], BK = CFG_BK[cfg];
+    int tiles = cdiv(M, bm) * cdiv(N, bn);
+    int splits = 1;
+    // split-K ONLY for the row-reduction GEMMs of the backward pass (trans_a: dW = dY^T X, K = number of rows).
+    // Forward GEMMs stay single-pass and bit-deterministic, so that the arg-max/arg-min routing of the aggregators and
+    // readouts cannot flip from run to run on near-ties.  With scratch the slices are summed in a fixed order by
+    // slab_reduce_kernel (>= 1024 of K per slice, up to ~800 workgroups); without it they are fp32 atomics on top of a
+    // zero-fill (not free: up to ~512 workgroups, >= 512 of K per slice).
+    if (trans_a && have_ws && tiles < 800 && K >= 2048) {
+        splits = (800 + tiles / 2) / tiles;
+        int max_splits = K / 1024;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    } else if (trans_a && tiles < 512 && K >= 1024) {
+        splits = (512 + tiles - 1) / tiles;
+        int max_splits = K / 512;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    }
+    if (force_splits > 0) splits = force_splits;
+    int kps = cdiv(cdiv(K, splits), BK) * BK;
+    if (kps < BK) kps = BK;
+    splits = K > 0 ? cdiv(K, kps) : 1;
+    g.k_per_split = kps;
+    g.atomic_out = splits > 1;
+    const bool use_slab = splits > 1 && ex.workspace != nullptr && (long)splits * M * N * 4 <= ex.workspace_bytes &&
+                          (((uintptr_t)ex.workspace & 15) == 0) && ex.m_rows == nullptr;
+    if (use_slab) {
+        g.slab = (float*)ex.workspace;
+        g.atomic_out = 0;
+    }
+    if (splits > 1 && !accumulate && !use_slab) {
+        // atomics accumulate on top of zeros (a two-block C: both blocks)
+        const int m1 = std::min(M, ex.c_split);
+        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), m1, s);
+        if (e == hipSuccess && M > m1)
+            e = hipMemset2DAsync(C + (long)m1 * ldc + ex.c_delta, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M - m1, s);
+        if (e != hipSuccess) {
+            set_error("i3d_gemm_f32: memset failed");
+            return I3D_ERR_LAUNCH;
+        }
+    }
+    switch (cfg) {
+        case 0: launch<Cfg0>(g, layout, splits, vec, s); break;
+        case 1: launch<Cfg1>(g, layout, splits, vec, s); break;
+        case 2: launch<Cfg2>(g, layout, splits, vec, s); break;
+        case 3: launch<Cfg3>(g, layout, splits, vec, s); break;
+        case 4: launch<Cfg4>(g, layout, splits, vec, s); break;
+        case 5: launch<Cfg5>(g, layout, splits, vec, s); break;
+        case 6: launch<Cfg6>(g, layout, splits, vec, s); break;
+        case 7: launch<Cfg7>(g, layout, splits, vec, s); break;
+        case 8: launch<Cfg8>(g, layout, splits, vec, s); break;
+        case 9: launch<Cfg9>(g, layout, splits, vec, s); break;
+        case 10: launch<Cfg10>(g, layout, splits, vec, s); break;
+        case 11: launch<Cfg11>(g, layout, splits, vec, s); break;
+        default: launch<Cfg12>(g, layout, splits, vec, s); break;
+    }
+    I3D_CHECK_LAUNCH();
+    if (use_slab) {
+        SlabReduce r;
+        r.slab = g.slab; r.C = C; r.bias = bias; r.M = M; r.N = N; r.ldc = ldc; r.accumulate = accumulate ? 1 : 0;
+        r.n_groups = 1; r.c_group_stride = 0; r.seg_ptr[0] = 0; r.seg_ptr[1] = splits;
+        r.c_split = ex.c_split; r.c_delta = ex.c_delta;
+        r.post_aff = ex.post_aff; r.post_row = ex.post_row;
+        launch_slab_reduce(r, s);
+        I3D_CHECK_LAUNCH();
+    } else if (ex.post_aff != nullptr) {
+        hipLaunchKernelGGL(wgrad_bn_fixup_kernel, dim3(cdiv((long)M * N, 256)), dim3(256), 0, s, C, M, N, ldc, ex.post_aff,
+                           ex.post_row);
+        I3D_CHECK_LAUNCH();
+    }
+    return I3D_OK;
+}
+
+// C_g[M,N] (+)= sum_{j in group g} A[k_rows[j], 0:M]^T B[k_rows[j], 0:N] for all groups in ONE launch: the reduction
+// ranges are cut into <= MAX_SEGS segments of <= SEG_MAX_K rows, each a blockIdx.z slice that accumulates with atomics.
+static int rowseg_impl(int M, int N, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int accumulate,
+                       int force_cfg, int force_seg_rows, const Extra& ex, void* stream) {
+    I3D_CHECK_ARG(M > 0 && N > 0 && ex.n_groups > 0 && ex.k_rows != nullptr, "bad arguments");
+    I3D_CHECK_ARG(lda >= M && ldb >= N && ldc >= N, "leading dimension too small");
+    hipStream_t s = (hipStream_t)stream;
+    long total = 0;
+    int k_hi = 0;
+    for (int gi = 0; gi < ex.n_groups; ++gi) {
+        I3D_CHECK_ARG(ex.group_start[gi] >= 0 && ex.group_count[gi] >= 0, "bad group range");
+        total += ex.group_count[gi];
+        k_hi = std::max(k_hi, ex.group_start[gi] + ex.group_count[gi]);
+    }
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = nullptr;
+    g.M = M; g.N = N; g.K = k_hi;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.accumulate = 1; g.atomic_out = 1; g.k_per_split = 0;
+    g.m_rows = nullptr; g.k_rows = ex.k_rows; g.tile_group = nullptr; g.b_group_stride = 0;
+    g.slab = nullptr;
+    g.a_aff = nullptr; g.stats = nullptr; g.epi_act = I3D_ACT_NONE;
+    g.b_split = g.c_split = 0x7fffffff; g.b_delta = g.c_delta = 0;
+    int rc = fill_views(g, 1, 0, M, N, k_hi, lda, ldb, ex);
+    if (rc != I3D_OK) return rc;
+    g.c_vec = (((uintptr_t)C & 15) == 0) && (ldc % 4 == 0);
+    // upper bound of the number of segments (>= 512 rows each unless forced): enough scratch -> two-stage reduction
+    const bool want_slab = ex.workspace != nullptr && (((uintptr_t)ex.workspace & 15) == 0) && ex.n_groups <= 32;
+    if (!accumulate && !want_slab) {
+        for (int gi = 0; gi < ex.n_groups; ++gi) {
+            float* Cg = C + gi * ex.c_group_stride;
+            hipError_t e = (ldc == N) ? hipMemsetAsync(Cg, 0, (size_t)M * N * sizeof(float), s)
+                                      : hipMemset2DAsync(Cg, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s);
+            if (e != hipSuccess) {
+                set_error("i3d_gemm_f32_rowsubset: memset failed");
+                return I3D_ERR_LAUNCH;
+            }
+        }
+    }
+    if (total == 0) {
+        if (!accumulate && want_slab)
+            for (int gi = 0; gi < ex.n_groups; ++gi)
+                if (hipMemset2DAsync(C + gi * ex.c_group_stride, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s) != hipSuccess)
+                    return I3D_ERR_LAUNCH;
+        return I3D_OK;
+    }
+    int cfg = want_slab ? 2 : 3;      // measured (tools/gemm_bench.py): 64x64 tiles once the epilogue is a plain store
+    if (force_cfg >= 0) {
+        I3D_CHECK_ARG(force_cfg >= 2 && force_cfg <= 4, "row-subset GEMM: tile_cfg must be 2, 3 or 4");
+        cfg = force_cfg;
+    }
+    const int BK = CFG_BK[cfg];
+    const int tiles = cdiv(M, CFG_BM[cfg]) * cdiv(N, CFG_BN[cfg]);
+    // the atomics of the epilogue are the expensive part of a segment: ~1000 workgroups, >= 1024 rows per segment
+    long want = std::max<long>(ex.n_groups, (1024 + tiles / 2) / tiles);
+    long seg_rows = std::max<long>(want_slab ? 512 : 1024, (long)cdiv((int)cdiv((int)total, (int)want), BK) * BK);
+    if (force_seg_rows > 0) seg_rows = (long)cdiv(force_seg_rows, BK) * BK;
+    SegTable t;
+    int seg_first[33];          // first segment of every group (segments of a group are consecutive table entries)
+    int n_segs;
+    for (;;) {
+        if (seg_rows > SEG_MAX_K) seg_rows = SEG_MAX_K;
+        n_segs = 0;
+        bool fits = true;
+        for (int gi = 0; gi < ex.n_groups && fits; ++gi) {
+            const int b = ex.group_start[gi], e = b + ex.group_count[gi];
+            if (gi < 33) seg_first[gi] = n_segs;
+            for (int k = b; k < e; k += (int)seg_rows) {
+                if (n_segs == MAX_SEGS) { fits = false; break; }
+                t.s[n_segs++] = Seg{k, std::min<int>(e, k + (int)seg_rows), gi * ex.c_group_stride};
+            }
+        }
+        if (fits) break;
+        I3D_CHECK_ARG(seg_rows < SEG_MAX_K, "row-subset GEMM: more than MAX_SEGS * SEG_MAX_K rows");
+        seg_rows *= 2;
+    }
+    const bool vec = (((uintptr_t)A & 15) == 0) && (lda % 4 == 0) && (((uintptr_t)B & 15) == 0) && (ldb % 4 == 0) &&
+                     (M % 4 == 0) && (N % 4 == 0);
+    const bool use_slab = want_slab && (long)n_segs * M * N * 4 <= ex.workspace_bytes;
+    if (use_slab) {
+        g.slab = (float*)ex.workspace;
+        g.atomic_out = 0;
+    } else if (want_slab && !accumulate) {       // scratch too small after all: atomics on top of zeros
+        for (int gi = 0; gi < ex.n_groups; ++gi) {
+            float* Cg = C + gi * ex.c_group_stride;
+            hipError_t e = (ldc == N) ? hipMemsetAsync(Cg, 0, (size_t)M * N * sizeof(float), s)
+                                      : hipMemset2DAsync(Cg, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s);
+            if (e != hipSuccess) {
+                set_error("i3d_gemm_f32_rowsubset: memset failed");
+                return I3D_ERR_LAUNCH;
+            }
+        }
+    }
+    switch (cfg) {
+        case 2: launch_rowseg<Cfg2>(g, t, n_segs, vec, s); break;
+        case 3: launch_rowseg<Cfg3>(g, t, n_segs, vec, s); break;
+        default: launch_rowseg<Cfg4>(g, t, n_segs, vec, s); break;
+    }
+    I3D_CHECK_LAUNCH();
+    if (use_slab) {
+        SlabReduce r;
+        r.slab = g.slab; r.C = C; r.bias = nullptr; r.M = M; r.N = N; r.ldc = ldc; r.accumulate = accumulate ? 1 : 0;
+        r.n_groups = ex.n_groups; r.c_group_stride = ex.c_group_stride;
+        r.c_split = 0x7fffffff; r.c_delta = 0;
+        r.post_aff = nullptr; r.post_row = nullptr;
+        for (int gi = 0; gi < ex.n_groups; ++gi) r.seg_ptr[gi] = seg_first[gi];
+        r.seg_ptr[ex.n_groups] = n_segs;
+        launch_slab_reduce(r, s);
+        I3D_CHECK_LAUNCH();
+    }
+    return I3D_OK;
+}
+
+}  // namespace i3d
+
+using namespace i3d;
+
+extern "C" int i3d_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
+                            int ldb, float* C, int ldc, const float* bias, int accumulate, void* stream) {
+    return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, -1, 0, Extra(), stream);
+}
+
+extern "C" int i3d_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
+                               int ldb, float* C, int ldc, const float* bias, int accumulate, int tile_cfg,
+                               int splits, void* workspace, long workspace_bytes, void* stream) {
+    Extra ex;
+    ex.workspace = workspace; ex.workspace_bytes = workspace_bytes;
+    return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, tile_cfg, splits, ex, stream);
+}
+
+extern "C" int i3d_gemm_f32_ws(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
+                               int ldb, float* C, int ldc, const float* bias, int accumulate, void* workspace,
+                               long workspace_bytes, void* stream) {
+    Extra ex;
+    ex.workspace = workspace; ex.workspace_bytes = workspace_bytes;
+    return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, -1, 0, ex, stream);
+}
+
+// i3d_gemm_f32_ws with a two-block B and/or C (include/infomax3d_hip.h)
+extern "C" int i3d_gemm_f32_blocks(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
+                                   int ldb, int b_split, long b_delta, long b_view_floats, float* C, int ldc, int c_split,
+                                   long c_delta, int accumulate, void* workspace, long workspace_bytes, void* stream) {
+    Extra ex;
+    ex.workspace = workspace; ex.workspace_bytes = workspace_bytes;
+    if (b_split > 0) { ex.b_split = b_split; ex.b_delta = b_delta; ex.b_view_floats = b_view_floats; }
+    if (c_split > 0) { ex.c_split = c_split; ex.c_delta = c_delta; }
+    I3D_CHECK_ARG(!(trans_a && trans_b), "layout not supported");
+    return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, nullptr, accumulate, -1, 0, ex, stream);
+}
+
+// C[m_rows[m], :] (+)= A[m_rows[m], :] * op(B_g),  g = tile_group[m / 64];  m_rows is padded with -1 to 64 per group
+extern "C" int i3d_gemm_f32_grouped(int trans_b, int m_padded, int N, int K, const float* A, int lda, long a_rows_total,
+                                    const int* m_rows, const int* tile_group, const float* B, int ldb,
+                                    long b_group_stride, float* C, int ldc, int accumulate, void* stream) {
+    I3D_CHECK_ARG(m_rows != nullptr && tile_group != nullptr && m_padded % 64 == 0, "grouped GEMM needs 64-padded m_rows");
+    Extra ex;
+    ex.m_rows = m_rows; ex.tile_group = tile_group; ex.b_group_stride = b_group_stride; ex.a_rows_total = a_rows_total;
+    return gemm_impl(0, trans_b, m_padded, N, K, A, lda, B, ldb, C, ldc, nullptr, accumulate, -1, 0, ex, stream);
+}
+
+// C[M,N] = sum_{j < n_rows} A[k_rows[j], 0:M]^T * B[k_rows[j], 0:N]   (weight gradient over a subset of rows)
+extern "C" int i3d_gemm_f32_rowsubset(int M, int N, int n_rows, const float* A, int lda, const float* B, int ldb,
+                                      const int* k_rows, long rows_total, float* C, int ldc, int accumulate,
+                                      void* stream) {
+    I3D_CHECK_ARG(k_rows != nullptr && n_rows >= 0, "k_rows required");
+    const int start = 0;
+    Extra ex;
+    ex.k_rows = k_rows; ex.k_rows_total = rows_total;
+    ex.n_groups = 1; ex.group_start = &start; ex.group_count = &n_rows; ex.c_group_stride = 0;
+    return rowseg_impl(M, N, A, lda, B, ldb, C, ldc, accumulate, -1, 0, ex, stream);
+}
+
+// C_g[M,N] = sum_{group_start[g] <= j < group_start[g] + group_count[g]} A[k_rows[j], 0:M]^T B[k_rows[j], 0:N],
+// C_g = C + g * c_group_stride: the weight gradients of all in-degree groups in one launch.
+extern "C" int i3d_gemm_f32_rowsubset_multi(int M, int N, int n_groups, const int* group_start, const int* group_count,
+                                            const float* A, int lda, const float* B, int ldb, const int* k_rows,
+                                            long rows_total, float* C, long c_group_stride, int ldc, int accumulate,
+                                            int tile_cfg, int seg_rows, void* workspace, long workspace_bytes,
+                                            void* stream) {
+    I3D_CHECK_ARG(k_rows != nullptr && group_start != nullptr && group_count != nullptr && n_groups > 0, "bad arguments");
+    Extra ex;
+    ex.workspace = workspace; ex.workspace_bytes = workspace_bytes;
+    ex.k_rows = k_rows; ex.k_rows_total = rows_total;
+    ex.n_groups = n_groups; ex.group_start = group_start; ex.group_count = group_count; ex.c_group_stride = c_group_stride;
+    return rowseg_impl(M, N, A, lda, B, ldb, C, ldc, accumulate, tile_cfg, seg_rows, ex, stream);
+}
+
+// C = act((op(A) W^T) + bias (+ C))  with the BatchNorm of the block in front applied to A on the fly (a_aff) and / or the
+// column statistics of the stored values produced per 64-row tile (stats): include/infomax3d_hip.h
+extern "C" int i3d_gemm_f32_fused(int M, int N, int K, const float* A, int lda, long a_rows_total, const float* W, int ldb,
+                                  float* C, int ldc, const float* bias, int accumulate, const float* a_aff, int epi_act,
+                                  float* stats, const int* m_rows, const int* tile_group, long b_group_stride,
+                                  void* stream) {
+    I3D_CHECK_ARG(M > 0 && N > 0 && K > 0, "empty GEMM");
+    I3D_CHECK_ARG(a_aff != nullptr || stats != nullptr, "nothing to fuse: use i3d_gemm_f32");
+    I3D_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "leading dimension too small");
+    I3D_CHECK_ARG(a_aff == nullptr || K <= FUSE_MAX_K, "BatchNorm prologue: K <= 1024");
+    I3D_CHECK_ARG((m_rows == nullptr) == (tile_group == nullptr), "grouped GEMM needs m_rows and tile_group");
+    I3D_CHECK_ARG(m_rows == nullptr || M % 64 == 0, "grouped GEMM needs 64-padded m_rows");
+    I3D_CHECK_ARG(epi_act == I3D_ACT_NONE || epi_act == I3D_ACT_RELU || epi_act == I3D_ACT_LEAKY_RELU || stats != nullptr,
+                  "epilogue activation needs the statistics variant");
+    const bool al = ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) == 0) && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 &&
+                    K % 4 == 0 && b_group_stride % 4 == 0;
+    I3D_CHECK_ARG(al, "fused GEMM needs 16-byte aligned operands and K, leading dimensions multiples of 4");
+    GemmArgs g;
+    g.A = A; g.B = W; g.C = C; g.bias = bias;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.accumulate = accumulate ? 1 : 0;
+    g.k_per_split = K; g.atomic_out = 0; g.c_vec = 1;
+    g.m_rows = m_rows; g.k_rows = nullptr; g.tile_group = tile_group; g.b_group_stride = b_group_stride;
+    g.b_split = g.c_split = 0x7fffffff; g.b_delta = g.c_delta = 0;
+    g.slab = nullptr;
+    g.a_aff = a_aff; g.stats = stats; g.epi_act = epi_act;
+    Extra ex;
+    ex.m_rows = m_rows; ex.a_rows_total = a_rows_total;
+    int rc = fill_views(g, 0, 1, M, N, K, lda, ldb, ex);
+    if (rc != I3D_OK) return rc;
+    const int fuse = (a_aff != nullptr ? 1 : 0) | (stats != nullptr ? 2 : 0);
+    hipStream_t s = (hipStream_t)stream;
+    // tile choice as in gemm_impl for the forward layout: 64x64 (idx-major image), 64x32 when K is long and N pads badly
+    const bool narrow = K >= 400 && (long)cdiv(N, 64) * 64 * 10 > (long)cdiv(N, 32) * 32 * 11;
+    if (narrow) launch_fused<Cfg11>(g, fuse, s);
+    else launch_fused<Cfg9>(g, fuse, s);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+// dW[f_out, f_in] = dY^T y  for  y = (x - mean) * scale + shift  (aff = mean | scale | shift over f_in) computed from the raw
+// x: the BatchNorm output y is never materialised (fused_bn.hip).  grad_bias[f_out] = column sums of dY.
+extern "C" int i3d_gemm_f32_wgrad_bn(int f_out, int f_in, int rows, const float* dY, int ldy, const float* x, int ldx,
+                                     float* dW, int ldw, const float* grad_bias, const float* aff, void* workspace,
+                                     long workspace_bytes, void* stream) {
+    I3D_CHECK_ARG(grad_bias != nullptr && aff != nullptr, "grad_bias and aff required");
+    Extra ex;
+    ex.workspace = workspace; ex.workspace_bytes = workspace_bytes;
+    ex.post_aff = aff; ex.post_row = grad_bias;
+    return gemm_impl(1, 0, f_out, f_in, rows, dY, ldy, x, ldx, dW, ldw, nullptr, 0, -1, 0, ex, stream);
+}
