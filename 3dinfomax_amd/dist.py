@@ -175,7 +175,9 @@ class GradReducer:
             self.span_of[id(p)] = (o, o + n)
             o += n
         self._pending, self._launched = [], []        # async all-reduces of this step, element ranges they cover
+        self.early_spans = []                         # [start, end) element ranges reduced early, fixed by the model structure
         self.overlap = OVERLAP_ALLREDUCE
+        self._agreed = None                           # None: not checked yet; True / False: every rank has the same early plan
         self._tape = tape
 
     def attach(self, modules):
@@ -184,20 +186,33 @@ class GradReducer:
             if any(p.requires_grad for p in m.parameters()):
                 self._tape.register_grad_sink(m, self._sink, self.view_of)
                 self._tape.model_state(m).reducer = self
+                self._plan_early(m)
 
-    def launch_async(self, params):
-        """Start the all-reduce of the gradients of `params` NOW (they are final in stream order and live in the flat
-        buffer): a model backward calls this for the part of its parameters that is done while the rest of the backward pass
-        is still to be enqueued (pna_native.PNAModelFn: head + upper half of the layers), so the collective runs next to it.
-        Contiguous runs of the flat buffer become one collective each."""
-        spans = sorted(self.span_of[id(p)] for p in params if id(p) in self.span_of)
-        merged = []
+    def _plan_early(self, module):
+        """The slices of the flat buffer that are reduced EARLY (while the backward pass is still running) are a function of
+        the model structure alone - head + upper half of the message-passing layers of a PNA - so that every rank issues the
+        same collectives in the same order whichever code path its backward pass takes (a rank that fell back to the
+        Python-sequenced path reduces the same slices, later)."""
+        gnn = getattr(module, 'node_gnn', None)
+        layers = list(getattr(gnn, 'mp_layers', [])) if gnn is not None else []
+        if len(layers) < 2 or not hasattr(module, 'output'):
+            return
+        early = [p for layer in layers[len(layers) // 2:] for p in layer.parameters()] + list(module.output.parameters())
+        spans = sorted(self.span_of[id(p)] for p in early if id(p) in self.span_of)
         for a, b in spans:
-            if merged and merged[-1][1] == a:
-                merged[-1][1] = b
+            if self.early_spans and self.early_spans[-1][1] == a:
+                self.early_spans[-1][1] = b
             else:
-                merged.append([a, b])
-        for a, b in merged:
+                self.early_spans.append([a, b])
+        self.early_spans.sort()
+
+    def launch_async(self, params=None):
+        """Start the all-reduce of the EARLY slices now (their gradients are final in stream order and live in the flat
+        buffer): a model backward calls this after the part of the pass that produces them (pna_native.PNAModelFn: head +
+        upper half of the layers) while the rest is still to be enqueued, so the collective runs next to it."""
+        if self._launched or not self._agreed:       # (no early collective before the ranks have agreed on the plan)
+            return
+        for a, b in self.early_spans:
             t = self.flat[a:b]
             if _is_gloo(self.group):
                 all_reduce_sum(t, self.group)                       # host-staged, synchronous: same arithmetic
@@ -238,26 +253,28 @@ class GradReducer:
             have = [(v, g) for v, g in todo if g is not None]
             if have:
                 torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        if self._launched and not todo:
-            # part of the buffer is already being reduced (launch_async): the complement now, then wait for the early ones
+        if self._agreed is None and dist.get_world_size(self.group) > 1:
+            # once, in the first reduce() (a point every rank passes with nothing else in flight): do all ranks hold the same
+            # early plan?  A rank whose reducer was created without its modules has none - then nobody splits the reduction.
+            mine = torch.tensor([len(self.early_spans), sum(b - a for a, b in self.early_spans),
+                                 self.early_spans[0][0] if self.early_spans else -1], dtype=torch.float64)
+            both = torch.cat([mine, -mine]).to(self.flat.device if not _is_gloo(self.group) else 'cpu')
+            dist.all_reduce(both, op=dist.ReduceOp.MAX, group=self.group)
+            both = both.cpu()
+            self._agreed = bool(self.overlap and self.early_spans and torch.equal(both[:3], -both[3:]))
+        if self._agreed and dist.get_world_size(self.group) > 1:
+            # the same collectives in the same order on every rank: the early slices (now, if the backward pass did not
+            # start them), then the complement; then wait for the early ones
+            self.launch_async()
             o = 0
-            for a, b in sorted(self._launched) + [(self.flat.numel(), self.flat.numel())]:
+            for a, b in self.early_spans + [[self.flat.numel(), self.flat.numel()]]:
                 if a > o:
                     all_reduce_sum(self.flat[o:a], self.group)
                 o = max(o, b)
             for w in self._pending:
                 w.wait()
         else:
-            for w in self._pending:          # (gradients arrived another way after all: reduce everything again is wrong -
-                w.wait()                     #  the early ranges are already summed; only the rest is reduced below)
-            if self._launched:
-                o = 0
-                for a, b in sorted(self._launched) + [(self.flat.numel(), self.flat.numel())]:
-                    if a > o:
-                        all_reduce_sum(self.flat[o:a], self.group)
-                    o = max(o, b)
-            else:
-                all_reduce_sum(self.flat, self.group)
+            all_reduce_sum(self.flat, self.group)
         self._pending, self._launched = [], []
         if todo:
             for p, v in zip(self.params, self.views):

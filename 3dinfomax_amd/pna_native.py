@@ -309,15 +309,13 @@ class PNAModelFn(torch.autograd.Function):
 
         red = ctx.state.reducer
         n_layers = desc.struct.n_layers
-        if (red is not None and red.overlap and n_layers >= 2 and key is not None and ctx.state.sink_views is views
-                and _world(red.group) > 1):
+        if (red is not None and red._agreed and n_layers >= 2 and key is not None
+                and ctx.state.sink_views is views and _world(red.group) > 1):
             # data parallel: the gradients of the head and of the upper half of the layers are final after part 1 - their
             # all-reduce (RCCL, its own stream) runs next to the lower half of the backward pass
             split = n_layers // 2
             part(1, split)
-            gnn = module.node_gnn
-            early = [p for layer in list(gnn.mp_layers)[split:] for p in layer.parameters()] + list(module.output.parameters())
-            red.launch_async(early)
+            red.launch_async()               # the slices of layers [split, L) + head (GradReducer._plan_early: the same split)
             part(2, split)
         else:
             part(0, 0)

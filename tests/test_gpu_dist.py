@@ -167,12 +167,18 @@ def _uneven_worker(rank, port, path):
     red = adist.grad_reducer(params, modules=[pna, net])
     calls = []
     real = red.launch_async
-    red.launch_async = lambda ps: (calls.append(len(ps)), real(ps))[1]
+    red.launch_async = lambda *a: (calls.append(sum(b - a_ for a_, b in red.early_spans) if not red._launched else 0), real(*a))[1]
     g2, g3 = _batch(amd, [mols[i] for i in plan[rank]])
     assert native.eligible(pna, g2)                                 # the whole-model C sequencer is the path that runs
-    share = loss_fn(pna(g2), net(g3))
-    share.backward()
-    adist.allreduce_grads(params)
+    # step 1: the ranks agree on the early plan inside the first reduce() (no early collective before that); step 2 (the one
+    # that is checked; same weights: no optimizer step in between) runs the split backward pass with the early all-reduce
+    for _ in range(2):
+        for p in params:
+            p.grad = None
+        share = loss_fn(pna(g2.local_copy()), net(g3.local_copy()))
+        share.backward()
+        adist.allreduce_grads(params)
+    assert red._agreed is True
     total = adist.global_loss(share)
     if rank == 0:
         out = {'loss': total.item(), 'early_params': np.array(calls)}
@@ -195,7 +201,8 @@ def test_two_rank_uneven_shards_local_bn_and_early_allreduce(tmp_path):
     path = str(tmp_path / 'uneven.npz')
     mp.spawn(_uneven_worker, args=(_free_port(), path), nprocs=WORLD, join=True)
     z = np.load(path)
-    assert list(z['early_params']) and int(z['early_params'][0]) > 8          # the early bucket was launched
+    # the early slices (head + upper half of the layers: > 10 k gradient elements) were started from inside the backward pass
+    assert list(z['early_params']) and int(z['early_params'][0]) > 10000
     mols = amd.synth.make_dataset(13, seed=33)
     sizes = [m.n_atoms for m in mols]
     plan = adist.shard_plan(sizes, WORLD)
