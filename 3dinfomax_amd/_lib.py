@@ -62,6 +62,16 @@ class PnaLayerArgs(ctypes.Structure):
                 ('fused_bn', c_int), ('defer_join', c_int), ('stats_ws', _P), ('aff', _P * 4)]
 
 
+class Net3dEdgeArgs(ctypes.Structure):
+    _fields_ = [('tail_in', BnTail), ('tail_msg', BnTail), ('num_nodes', c_int), ('num_edges', c_int), ('hidden', c_int),
+                ('n_enc', c_int), ('reduce_mean', c_int), ('ld_w_in', c_int), ('ld_w_msg', c_int), ('d_raw', _P), ('perm', _P),
+                ('dst_s', _P), ('in_ptr', _P), ('emb', _P), ('W_in', _P), ('b_in', _P), ('W_msg', _P), ('b_msg', _P),
+                ('w_gate', _P), ('b_gate', _P), ('stats', _P), ('aff_in', _P), ('aff_msg', _P), ('x_msg', _P), ('d_out', _P),
+                ('msg', _P), ('m_sum', _P), ('grad_m_sum', _P), ('grad_ya', _P), ('partial', _P), ('grad_W_in', _P),
+                ('grad_b_in', _P), ('grad_gamma_in', _P), ('grad_beta_in', _P), ('grad_W_msg', _P), ('grad_b_msg', _P),
+                ('grad_gamma_msg', _P), ('grad_beta_msg', _P), ('grad_w_gate', _P), ('grad_b_gate', _P), ('grad_emb', _P)]
+
+
 class FcParams(ctypes.Structure):
     _fields_ = [('W', _P), ('bias', _P), ('gamma', _P), ('beta', _P), ('running_mean', _P), ('running_var', _P),
                 ('num_batches_tracked', _P), ('grad_W', _P), ('grad_bias', _P), ('grad_gamma', _P), ('grad_beta', _P),
@@ -96,6 +106,11 @@ _SIGNATURES = {
     'i3d_event_destroy': (c_int, [_P]),
     'i3d_event_record': (c_int, [_P, _P]),
     'i3d_event_elapsed_ms': (c_int, [_P, _P, POINTER(c_float)]),
+    'i3d_net3d_edge_supported': (c_int, [c_int, c_int]),
+    'i3d_net3d_edge_stats_floats': (c_long, [c_int, c_int]),
+    'i3d_net3d_edge_bwd_floats': (c_long, [c_int, c_int, c_int]),
+    'i3d_net3d_edge_fwd': (c_int, [POINTER(Net3dEdgeArgs), _P]),
+    'i3d_net3d_edge_bwd': (c_int, [POINTER(Net3dEdgeArgs), _P]),
     'i3d_pna_layer_fwd': (c_int, [POINTER(PnaLayerArgs), _P]),
     'i3d_pna_layer_bwd': (c_int, [POINTER(PnaLayerArgs), _P]),
     'i3d_fc_bn_fwd': (c_int, [POINTER(FcArgs), _P]),

@@ -21,6 +21,7 @@ from .layer_native import _Arena, _al, _tail
 from .layers import _composite_ok, _keeps_pre, _set_workspaces
 
 NATIVE_NET3D = os.environ.get('I3D_NATIVE_NET3D', '1') != '0'
+FUSED_EDGE = os.environ.get('I3D_NET3D_FUSED_EDGE', '1') != '0'      # the edge stage in one lane per edge (csrc/net3d_edge.hip)
 _F32 = torch.float32
 
 
@@ -59,6 +60,48 @@ def eligible(model, g):
     elif last[4].act is not None or not last[0].is_contiguous() or last[1] is None:
         return False
     return len(layers) >= 1 and all(len(m) >= 1 and len(u) >= 1 for m, _, u, _ in layers)
+
+
+def fused_edge_ok(model):
+    """the structure net3d_edge.hip is written for: one propagation layer with one message block on the broadcast node
+    embedding, SiLU activations, a hidden width / Fourier order the kernels are built for (cached on the module)"""
+    ok = model.__dict__.get('_i3d_fused_edge')
+    if ok is None:
+        edge_in, layers, nw, out = _blocks(model)
+        ok = False
+        if len(layers) == 1 and len(layers[0][0]) == 1:
+            H = model.node_embedding.shape[0]
+            w_in, spec_in = edge_in.hot('silu')[0], edge_in.hot('silu')[4]
+            w_m, spec_m = layers[0][0][0].hot()[0], layers[0][0][0].hot()[4]
+            n_enc = model.fourier_encodings
+            din = 2 * n_enc + 1 if n_enc > 0 else 1
+            ok = (tuple(w_in.shape) == (H, din) and tuple(w_m.shape) == (H, 3 * H) and spec_in.act == 'silu'
+                  and spec_m.act == 'silu' and spec_m.post_act is None
+                  and bool(_lib.load().i3d_net3d_edge_supported(H, n_enc)))
+        model.__dict__['_i3d_fused_edge'] = ok
+    return ok and FUSED_EDGE
+
+
+def _edge_stage_fwd(L, stream, ar, dev, model, g, idx, d_raw, edge_in, msg_fc, se, reduce_mean, N, E, H):
+    """the fused edge stage: -> (argument struct, m_sum pointer, d_out tensor)"""
+    a = _lib.Net3dEdgeArgs()
+    W_in, b_in, g_in, be_in, spec_in = edge_in.hot('silu')[:5]
+    W_m, b_m, g_m, be_m, spec_m = msg_fc.hot()[:5]
+    _tail(a.tail_in, spec_in, g_in, be_in, ar.take(H), ar.take(H), H, dev)
+    _tail(a.tail_msg, spec_m, g_m, be_m, ar.take(H), ar.take(H), H, dev)
+    a.num_nodes, a.num_edges, a.hidden, a.n_enc, a.reduce_mean = N, E, H, model.fourier_encodings, int(reduce_mean)
+    a.ld_w_in, a.ld_w_msg = W_in.stride(0), W_m.stride(0)
+    a.d_raw, a.perm, a.dst_s, a.in_ptr = d_raw.data_ptr(), idx.perm.data_ptr(), idx.dst_s.data_ptr(), idx.in_ptr.data_ptr()
+    a.emb = model.node_embedding.data_ptr()
+    a.W_in, a.b_in, a.W_msg, a.b_msg = W_in.data_ptr(), b_in.data_ptr(), W_m.data_ptr(), b_m.data_ptr()
+    a.w_gate, a.b_gate = se.weight.data_ptr(), se.bias.data_ptr()
+    a.stats = ar.take(int(L.i3d_net3d_edge_stats_floats(E, H)))
+    a.aff_in, a.aff_msg = ar.take(3 * H), ar.take(3 * H)
+    a.x_msg, a.msg, a.m_sum = ar.take(E * H), ar.take(E * H), ar.take(N * H)
+    d_out = torch.empty(E, H, dtype=_F32, device=dev)
+    a.d_out = d_out.data_ptr()
+    _chk(L.i3d_net3d_edge_fwd(ctypes.byref(a), stream), 'i3d_net3d_edge_fwd')
+    return a, a.m_sum, d_out, (W_in, b_in, g_in, be_in, W_m, b_m, g_m, be_m, se.weight, se.bias)
 
 
 class _Rec:
@@ -105,15 +148,20 @@ def forward(ctx, model, g, params):
     L = _lib.load()
     stream = ops._stream()
 
+    fused = fused_edge_ok(model)
     # ---- scratch size
-    total = _al(N * H) + _al(E) + (_al(E * enc_dim) if n_enc > 0 else 0)
-    total += _fc_floats(E, H, edge_in.hot('silu')[4])
+    total = _al(N * H)
+    if fused:
+        total += 4 * _al(H) + 2 * _al(3 * H) + _al(int(L.i3d_net3d_edge_stats_floats(E, H))) + 2 * _al(E * H) + 2 * _al(N * H)
+    else:
+        total += _al(E) + (_al(E * enc_dim) if n_enc > 0 else 0) + _fc_floats(E, H, edge_in.hot('silu')[4])
     for msg, se, upd, _ in layers:
-        Fo = msg[0].hot()[0].shape[0]
-        total += _al(N * 2 * Fo) + _al(E * Fo) + _fc_floats(E, Fo, msg[0].hot()[4])
-        for fc in msg[1:]:
-            total += _fc_floats(E, fc.hot()[0].shape[0], fc.hot()[4])
-        total += _al(E * H) * 2 + _al(E) + _al(N * H) * 2           # d_next, gated message, gate, m_sum, u
+        if not fused:
+            Fo = msg[0].hot()[0].shape[0]
+            total += _al(N * 2 * Fo) + _al(E * Fo) + _fc_floats(E, Fo, msg[0].hot()[4])
+            for fc in msg[1:]:
+                total += _fc_floats(E, fc.hot()[0].shape[0], fc.hot()[4])
+            total += _al(E * H) * 2 + _al(E) + _al(N * H) * 2           # d_next, gated message, gate, m_sum, u
         for fc in upd:
             total += _fc_floats(N, fc.hot()[0].shape[0], fc.hot()[4])
     for fc in nw:
@@ -131,14 +179,16 @@ def forward(ctx, model, g, params):
     emb = model.node_embedding
     h = ar.take(N * H)
     _chk(L.i3d_broadcast_row(emb.data_ptr(), N, H, h, stream), 'i3d_broadcast_row')
-    dperm = ar.take(E)
-    _chk(L.i3d_gather_rows(d_raw.data_ptr(), idx.perm.data_ptr(), E, 1, dperm, stream), 'i3d_gather_rows')
-    enc = dperm
-    if n_enc > 0:
-        enc = ar.take(E * enc_dim)
-        _chk(L.i3d_fourier_encode(dperm, E, n_enc, enc, stream), 'i3d_fourier_encode')
-    tr['edge_in'] = _fc_fwd(L, stream, ar, dev, edge_in, E, enc, post_act='silu')   # reference :80-81: d = silu(edge_input(d))
-    d = tr['edge_in'].y
+    d_out = d = None
+    if not fused:
+        dperm = ar.take(E)
+        _chk(L.i3d_gather_rows(d_raw.data_ptr(), idx.perm.data_ptr(), E, 1, dperm, stream), 'i3d_gather_rows')
+        enc = dperm
+        if n_enc > 0:
+            enc = ar.take(E * enc_dim)
+            _chk(L.i3d_fourier_encode(dperm, E, n_enc, enc, stream), 'i3d_fourier_encode')
+        tr['edge_in'] = _fc_fwd(L, stream, ar, dev, edge_in, E, enc, post_act='silu')   # reference :80-81: d = silu(edge_input(d))
+        d = tr['edge_in'].y
 
     # the node embeddings the network leaves on the graph are a tensor: the block that produces them writes into it
     last_h_fc = nw[-1] if nw else layers[-1][2][-1]
@@ -147,6 +197,23 @@ def forward(ctx, model, g, params):
     for li, (msg, se, upd, reduce_mean) in enumerate(layers):
         last_layer = li + 1 == n_layers
         lay = {'msg': [], 'upd': []}
+        if fused:
+            # edge input block, message block, gate and reduce in net3d_edge.hip; the graph's distance embedding comes out
+            # in edge-id order
+            lay['fused'], m_sum, d_out, ctx.fused_params = _edge_stage_fwd(L, stream, ar, dev, model, g, idx, d_raw, edge_in,
+                                                                           msg[0], se, reduce_mean, N, E, H)
+            u = ar.take(N * H)
+            _chk(L.i3d_add(m_sum, h, N * H, u, stream), 'i3d_add')
+            x = u
+            for k, fc in enumerate(upd):
+                final = k + 1 == len(upd)
+                y_ptr = h_out.data_ptr() if (final and not nw) else None
+                r = _fc_fwd(L, stream, ar, dev, fc, N, x, residual=h if final else None, y_ptr=y_ptr)     # reference :120-125
+                lay['upd'].append(r)
+                x = r.y
+            tr['layers'].append(lay)
+            h = x
+            break
         # message network: first layer on [h_src | h_dst | d] through the node-level products (edge.hip), then plain blocks
         W, b, gamma, beta, spec = msg[0].hot()[:5]
         Fo = W.shape[0]
@@ -193,8 +260,9 @@ def forward(ctx, model, g, params):
         h = r.y
     # side effects of the reference forward: final node embeddings and (edge-id order) distance embeddings on the graph
     g.ndata['feat'] = h_out
-    d_out = torch.empty(E, H, dtype=_F32, device=dev)
-    _chk(L.i3d_gather_rows(d, idx.inv_perm.data_ptr(), E, H, d_out.data_ptr(), stream), 'i3d_gather_rows')
+    if d_out is None:
+        d_out = torch.empty(E, H, dtype=_F32, device=dev)
+        _chk(L.i3d_gather_rows(d, idx.inv_perm.data_ptr(), E, H, d_out.data_ptr(), stream), 'i3d_gather_rows')
     g.edata['d'] = d_out
 
     # ---- readout and output network
@@ -216,7 +284,8 @@ def forward(ctx, model, g, params):
                                 stream), 'i3d_gemm_f32')
             r = _Rec('linear', rows=B, fin=fin, fout=W.shape[0], x=x, extra=(W, b))
         tr['out'].append(r)
-    ctx.native = (ar, tr, idx, emb, (N, E, B, H), codes, h_out)
+    # (the fused backward re-reads the raw distances and the distance embedding: both kept alive here)
+    ctx.native = (ar, tr, idx, emb, (N, E, B, H), codes, h_out, (d_raw, d_out) if fused else None)
     ctx.params = params
     return z
 
@@ -236,29 +305,54 @@ def _fc_bwd(L, stream, ar, dev, r, grad_y, grads, need_x=True):
     return a.grad_x
 
 
-def _bwd_floats(tr, N, E, H):
+def _edge_stage_bwd(L, stream, ar, dev, a, gu, gh_l, emb, grads, ctx, N, E, H, ws_h):
+    """backward of the fused edge stage: fills the gradients of the edge-input block, the message block, the gate and the
+    node embedding (node-level part: column sums of gh_l; edge part added by the kernels)"""
+    model_params = ctx.fused_params           # (W_in, b_in, g_in, be_in, W_m, b_m, g_m, be_m, sw, sb)
+    bufs = [tape.grad_like(t) for t in model_params]
+    for t, b in zip(model_params, bufs):
+        grads[id(t)] = b
+    (a.grad_W_in, a.grad_b_in, a.grad_gamma_in, a.grad_beta_in, a.grad_W_msg, a.grad_b_msg, a.grad_gamma_msg, a.grad_beta_msg,
+     a.grad_w_gate, a.grad_b_gate) = [b.data_ptr() for b in bufs]
+    gemb = tape.grad_like(emb)
+    grads[id(emb)] = gemb
+    _chk(L.i3d_colsum(gh_l, None, N, H, gemb.data_ptr(), ws_h, stream), 'i3d_colsum')
+    a.grad_emb = gemb.data_ptr()
+    a.grad_m_sum = gu
+    a.grad_ya = ar.take(E * H)
+    a.partial = ar.take(int(L.i3d_net3d_edge_bwd_floats(E, H, a.n_enc)))
+    _chk(L.i3d_net3d_edge_bwd(ctypes.byref(a), stream), 'i3d_net3d_edge_bwd')
+
+
+def _bwd_floats(tr, N, E, H, L):
     def fc(r):
         return _al(r.rows * r.fout) + _al(r.rows * r.fin)
-    total = 64 + fc(tr['edge_in']) + _al(N * H)
+    total = 64 + _al(N * H)
+    if 'edge_in' in tr:
+        total += fc(tr['edge_in'])
     for r in tr['out']:
         total += fc(r) if r.kind == 'fc' else _al(r.rows * r.fin)
     for r in tr['nw']:
         total += fc(r)
     for lay in tr['layers']:
         total += sum(fc(r) for r in lay['upd'] + lay['msg'])
+        if 'fused' in lay:
+            a = lay['fused']
+            total += _al(N * H) + _al(E * H) + _al(int(L.i3d_net3d_edge_bwd_floats(E, H, a.n_enc)))
+            continue
         Fo = lay['edge'].fout
         total += 2 * _al(N * H) + 3 * _al(E * H) + _al(E) + _al(E * Fo) + _al(N * 2 * Fo)
     return total
 
 
 def backward(ctx, grad_z):
-    ar_f, tr, idx, emb, (N, E, B, H), codes, h_out = ctx.native
+    ar_f, tr, idx, emb, (N, E, B, H), codes, h_out, _edge_keep = ctx.native
     dev = grad_z.device
     grad_z = grad_z.contiguous()
     L = _lib.load()
     stream = ops._stream()
     grads = {}
-    ar = _Arena(_bwd_floats(tr, N, E, H), dev)
+    ar = _Arena(_bwd_floats(tr, N, E, H, L), dev)
     ws_h = ops._workspace(H, dev).data_ptr()
 
     # ---- output network
@@ -289,6 +383,11 @@ def backward(ctx, grad_z):
         gu = gh
         for r in reversed(lay['upd']):
             gu = _fc_bwd(L, stream, ar, dev, r, gu, grads)
+        if 'fused' in lay:
+            gh_l = ar.take(N * H)
+            _chk(L.i3d_add(gh, gu, N * H, gh_l, stream), 'i3d_add')
+            _edge_stage_bwd(L, stream, ar, dev, lay['fused'], gu, gh_l, emb, grads, ctx, N, E, H, ws_h)
+            return tuple(grads.get(id(p)) for p in ctx.params)
         gate = lay['gate']
         sw, sb, reduce_mean = gate.extra
         # h enters the layer three times: the residual of the last update block (gradient = gh), the sum m_sum + h

@@ -474,6 +474,57 @@ typedef struct { /* one PNA layer, reference models/pna.py:199-216: pretrans edg
 /* floats of I3dPnaLayerArgs.stats_ws for a layer with these dimensions (f = widest block output) */
 long i3d_pna_layer_stats_floats(int num_nodes, int num_edges, int m_padded, int f);
 
+/* ---- the edge stage of the 3D network, one lane per edge (net3d_edge.hip) ---------------------------------------
+ * reference models/net3d.py:57-81 + 100-118 for propagation_depth 1, one message block, broadcast node embedding:
+ *   e0 = post(BN_in(act(W_in fourier(d) + b_in))),  m = BN_msg(act(W_msg [emb | emb | e0] + b_msg)),
+ *   m_sum[v] = mean/sum over the in-edges of m * sigmoid(w_gate . m + b_gate)
+ * Forward fills d_out (e0 in edge-id order: what the reference leaves in graph.edata['d']), x_msg, aff_*, tail_*.mean /
+ * invstd (running statistics updated), m_sum.  Backward reads them and grad_m_sum and fills the grad_* members
+ * (grad_emb is accumulated into: the caller has put the node-level part there). */
+typedef struct {
+    I3dBnTail tail_in;   /* edge-input block: act, post_act, BatchNorm over [E, hidden] (workspace members unused) */
+    I3dBnTail tail_msg;  /* message block: act, BatchNorm (post_act must be none) */
+    int num_nodes, num_edges, hidden, n_enc, reduce_mean;
+    int ld_w_in, ld_w_msg;
+    const float* d_raw;  /* [E] distances, edge-id order */
+    const int* perm;     /* [E] edge id of the j-th edge in destination-sorted order */
+    const int* dst_s;    /* [E] destination node, destination-sorted */
+    const int* in_ptr;   /* [N + 1] */
+    const float* emb;    /* [hidden] */
+    const float* W_in;   /* [hidden, 2 n_enc + 1 (1 when n_enc == 0)] */
+    const float* b_in;
+    const float* W_msg;  /* [hidden, 3 hidden] */
+    const float* b_msg;
+    const float* w_gate; /* [hidden] */
+    const float* b_gate; /* [1] */
+    float* stats;        /* scratch, i3d_net3d_edge_stats_floats(E, hidden) floats */
+    float* aff_in;       /* [3 hidden] saved */
+    float* aff_msg;      /* [3 hidden] saved */
+    float* x_msg;        /* [E, hidden] saved: activation output of the message block, destination-sorted */
+    float* d_out;        /* [E, hidden] saved + graph side effect, edge-id order */
+    float* msg;          /* [E, hidden] scratch (forward) */
+    float* m_sum;        /* [N, hidden] out */
+    const float* grad_m_sum; /* [N, hidden] */
+    float* grad_ya;      /* scratch [E, hidden] (backward) */
+    float* partial;      /* scratch, i3d_net3d_edge_bwd_floats(E, hidden, n_enc) floats (backward) */
+    float* grad_W_in;
+    float* grad_b_in;
+    float* grad_gamma_in;
+    float* grad_beta_in;
+    float* grad_W_msg;
+    float* grad_b_msg;
+    float* grad_gamma_msg;
+    float* grad_beta_msg;
+    float* grad_w_gate;
+    float* grad_b_gate;
+    float* grad_emb;     /* += */
+} I3dNet3dEdgeArgs;
+int i3d_net3d_edge_supported(int hidden, int n_enc);   /* 1 when the kernels are built for this combination */
+long i3d_net3d_edge_stats_floats(int num_edges, int hidden);
+long i3d_net3d_edge_bwd_floats(int num_edges, int hidden, int n_enc);
+int i3d_net3d_edge_fwd(const I3dNet3dEdgeArgs* args, void* stream);
+int i3d_net3d_edge_bwd(const I3dNet3dEdgeArgs* args, void* stream);
+
 /* timing events for measurements around a kernel inside a composite (thin wrappers of hipEvent_t) */
 int i3d_event_create(void** event);
 int i3d_event_destroy(void* event);

@@ -608,23 +608,56 @@ def test_native_net3d_equals_block_path(amd, monkeypatch, cfg):
     real_forward = native.forward
     monkeypatch.setattr(native, 'forward', lambda *a, **k: (calls.append(1), real_forward(*a, **k))[1])
     res = {}
+    monkeypatch.setattr(native, 'FUSED_EDGE', False)      # the fused edge stage is a different summation order: below
     for mode in (True, False):
         monkeypatch.setattr(native, 'NATIVE_NET3D', mode)
-        torch.manual_seed(11)
-        net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **kw).cuda().train()
-        outs = []
-        for _ in range(2):
-            _, g3 = make_batch(amd, mols)
-            z = net(g3)
-            (z * torch.linspace(-1, 1, z.shape[1], device='cuda:0')).sum().backward()
-            outs += [z.detach().clone(), g3.ndata['feat'].detach().clone(), g3.edata['d'].detach().clone()]
-        outs += [p.grad.clone() for p in net.parameters()] + [b.clone().float() for b in net.buffers()]
-        res[mode] = outs
-        net.zero_grad()
+        res[mode] = _net3d_two_steps(amd, kw, mols)
     assert len(calls) == 2                      # the native path ran (both forward passes of the first model)
     assert len(res[True]) == len(res[False]) > 20
     for i, (a, b) in enumerate(zip(res[True], res[False])):
         assert torch.equal(a, b), i
+
+
+def _net3d_two_steps(amd, kw, mols):
+    torch.manual_seed(11)
+    net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **kw).cuda().train()
+    outs = []
+    for _ in range(2):
+        _, g3 = make_batch(amd, mols)
+        z = net(g3)
+        (z * torch.linspace(-1, 1, z.shape[1], device='cuda:0')).sum().backward()
+        outs += [z.detach().clone(), g3.ndata['feat'].detach().clone(), g3.edata['d'].detach().clone()]
+    outs += [p.grad.clone() for p in net.parameters()] + [b.clone().float() for b in net.buffers()]
+    return outs
+
+
+@pytest.mark.parametrize('cfg', ['yml', 'sum', 'raw_distance', 'large'])
+def test_fused_net3d_edge_stage_matches_block_path(amd, monkeypatch, cfg):
+    """The edge stage of the 3D network in one lane per edge (csrc/net3d_edge.hip: Fourier features, edge-input block,
+    message block, gate, reduce - and their backward with the weight gradients on the MFMA unit) against the per-block
+    kernels: output, node / distance embeddings left on the graph, every parameter gradient, BatchNorm buffers.  Same
+    arithmetic in a different summation order: outputs and embeddings within 1e-5 of the tensor's scale (the acceptance
+    bound of the path is 1e-4); gradients (summed over two steps) within 3e-4 of the scale + 5e-5 - several are small
+    differences of large sums (a bias in front of a BatchNorm), and against a float64 torch model both paths sit at the
+    same distance (tools/probes/dbg_n3.py)."""
+    native = importlib.import_module('3dinfomax_amd.net3d_native')
+    kw = {'yml': dict(NET3D_YML), 'sum': dict(NET3D_YML, reduce_func='sum'),
+          'raw_distance': dict(NET3D_YML, fourier_encodings=0), 'large': dict(NET3D_YML)}[cfg]
+    mols = synth.make_dataset(700 if cfg == 'large' else 40, seed=23)      # 'large': several edge chunks per block, ragged tail
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(native, 'FUSED_EDGE', fused)
+        res[fused] = _net3d_two_steps(amd, kw, mols)
+    net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **kw).cuda().train()
+    assert native.fused_edge_ok(net) is False and native.FUSED_EDGE is False
+    monkeypatch.setattr(native, 'FUSED_EDGE', True)
+    assert native.fused_edge_ok(net) is True                   # the structure is eligible: the fused stage is what ran above
+    assert len(res[True]) == len(res[False]) > 20
+    for i, (a, b) in enumerate(zip(res[True], res[False])):
+        assert a.shape == b.shape
+        scale = b.abs().max().item() + 1e-12
+        tol = 1e-5 * scale + 1e-7 if i < 6 else 3e-4 * scale + 5e-5
+        assert (a - b).abs().max().item() <= tol, (i, (a - b).abs().max().item(), scale)
 
 
 def test_dist_warm_up_runs(amd):
