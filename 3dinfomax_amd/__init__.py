@@ -39,6 +39,9 @@ def __getattr__(name):
     if name == 'Adam':
         from . import optim
         return optim.Adam
+    if name in ('set_matmul_precision', 'get_matmul_precision'):
+        from . import ops
+        return getattr(ops, name)
     if name in ('dataset', 'dist', 'tape', 'streams', 'ops'):
         import importlib
         return importlib.import_module('.' + name, __name__)

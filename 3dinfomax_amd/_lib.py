@@ -106,6 +106,8 @@ _SIGNATURES = {
     'i3d_event_destroy': (c_int, [_P]),
     'i3d_event_record': (c_int, [_P, _P]),
     'i3d_event_elapsed_ms': (c_int, [_P, _P, POINTER(c_float)]),
+    'i3d_set_matmul_precision': (c_int, [c_int]),
+    'i3d_get_matmul_precision': (c_int, []),
     'i3d_net3d_edge_supported': (c_int, [c_int, c_int]),
     'i3d_net3d_edge_stats_floats': (c_long, [c_int, c_int]),
     'i3d_net3d_edge_bwd_floats': (c_long, [c_int, c_int, c_int]),
@@ -226,6 +228,11 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    # I3D_MATMUL_PRECISION=bf16: the trainer of the reference has no knob for it (ops.set_matmul_precision otherwise)
+    prec = os.environ.get('I3D_MATMUL_PRECISION', 'fp32').lower()
+    if prec not in ('fp32', 'bf16'):
+        raise HipLibraryError(f'I3D_MATMUL_PRECISION={prec!r}: fp32 or bf16')
+    lib.i3d_set_matmul_precision(int(prec == 'bf16'))
     _lib = lib
     return lib
 

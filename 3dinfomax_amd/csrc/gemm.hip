@@ -228,7 +228,21 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz) {
 // activation + per-tile column statistics of the stored values (g.epi_act, g.stats).  K <= FUSE_MAX_K for bit 0.
 constexpr int FUSE_MAX_K = 1024;
 
-template <class S, bool VEC, bool A_KC, bool B_KC, bool ROWS, int FUSE = 0>
+// BF16 (i3d_set_matmul_precision(1)): the operands are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) when a
+// lane reads its MFMA fragments from the fp32 LDS image and multiplied on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16 /
+// v_mfma_f32_16x16x32_bf16: one instruction per K-tile instead of 8) - fp32 accumulation, fp32 bias / epilogue /
+// statistics, fp32 tensors in HBM.  Shapes whose K-tile is one such instruction (MT 32 + BK 16, MT 16 + BK 32).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <class S> constexpr bool bf16_shape() { return (S::MT == 32 && S::BK == 16) || (S::MT == 16 && S::BK == 32); }
+
+__device__ __forceinline__ bf16x8 to_bf16x8(const float* f) {
+    bf16x8 r;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r[q] = (__bf16)f[q];
+    return r;
+}
+
+template <class S, bool VEC, bool A_KC, bool B_KC, bool ROWS, int FUSE = 0, bool BF16 = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int k_begin, const int k_end,
                                           float* __restrict__ Cout, const int* kidx, const bool first_split) {
     constexpr int MT = S::MT, WAVES_N = S::WAVES_N, WM_T = S::WM_T, WN_T = S::WN_T, BK = S::BK, PF = S::PF;
@@ -303,7 +317,51 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
             if (t < nk) {
                 const float* as = As + cur * StageA::LDS_FLOATS;
                 const float* bs = Bs + cur * StageB::LDS_FLOATS;
-                if constexpr (S::KP && MT == 32) {
+                if constexpr (BF16) {
+                    static_assert(bf16_shape<S>(), "bf16 MFMA: the K-tile is one instruction");
+                    // lane (lt, lk) supplies k = 8 lk .. 8 lk + 7 of row lt of its tiles
+                    const int k0 = 8 * lk;
+                    bf16x8 a8[WM_T], b8[WN_T];
+#pragma unroll
+                    for (int i = 0; i < WM_T; ++i) {
+                        const int idx = (wm * WM_T + i) * MT + lt;
+                        float f[8];
+                        if constexpr (A_IM) {
+#pragma unroll
+                            for (int q = 0; q < 8; q += 2) {
+                                const float2 v = *reinterpret_cast<const float2*>(&as[idx * StageA::LDK + k0 + q]);
+                                f[q] = v.x; f[q + 1] = v.y;
+                            }
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) f[q] = as[(k0 + q) * LDA + swz(k0 + q, idx)];
+                        }
+                        a8[i] = to_bf16x8(f);
+                    }
+#pragma unroll
+                    for (int j = 0; j < WN_T; ++j) {
+                        const int idx = (wn * WN_T + j) * MT + lt;
+                        float f[8];
+                        if constexpr (B_IM) {
+#pragma unroll
+                            for (int q = 0; q < 8; q += 2) {
+                                const float2 v = *reinterpret_cast<const float2*>(&bs[idx * StageB::LDK + k0 + q]);
+                                f[q] = v.x; f[q + 1] = v.y;
+                            }
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) f[q] = bs[(k0 + q) * LDB + swz(k0 + q, idx)];
+                        }
+                        b8[j] = to_bf16x8(f);
+                    }
+#pragma unroll
+                    for (int i = 0; i < WM_T; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN_T; ++j) {
+                            if constexpr (MT == 16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8[j], a8[i], acc[i][j], 0, 0, 0);
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[j], a8[i], acc[i][j], 0, 0, 0);
+                        }
+                } else if constexpr (S::KP && MT == 32) {
                     // two k-steps per trip: lane half lk supplies k = 4 j + 2 lk (step 2j) and 4 j + 2 lk + 1 (step 2j+1)
 #pragma unroll
                     for (int j4 = 0; j4 < BK / 4; ++j4) {
@@ -478,7 +536,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     }
 }
 
-template <class S, bool VEC, bool A_KC, bool B_KC>
+template <class S, bool VEC, bool A_KC, bool B_KC, bool BF16 = false>
 __global__ void __launch_bounds__(256)
 gemm_f32_kernel(GemmArgs g) {
     int bx, by, bz;
@@ -489,14 +547,15 @@ gemm_f32_kernel(GemmArgs g) {
         GemmArgs gl = g;
         gl.ldc = g.N; gl.accumulate = 0; gl.atomic_out = 0; gl.c_vec = (g.N % 4 == 0); gl.bias = nullptr;
         gl.c_split = 0x7fffffff; gl.c_delta = 0;
-        gemm_body<S, VEC, A_KC, B_KC, false>(gl, bx, by, min(k_begin, g.K), k_end, g.slab + (long)bz * g.M * g.N, nullptr, false);
+        gemm_body<S, VEC, A_KC, B_KC, false, 0, BF16>(gl, bx, by, min(k_begin, g.K), k_end, g.slab + (long)bz * g.M * g.N, nullptr,
+                                                      false);
         return;
     }
     if (k_begin >= k_end && !(bz == 0)) return;
-    gemm_body<S, VEC, A_KC, B_KC, false>(g, bx, by, k_begin, k_end, g.C, nullptr, bz == 0);
+    gemm_body<S, VEC, A_KC, B_KC, false, 0, BF16>(g, bx, by, k_begin, k_end, g.C, nullptr, bz == 0);
 }
 
-template <class S, bool VEC>
+template <class S, bool VEC, bool BF16 = false>
 __global__ void __launch_bounds__(256)
 gemm_f32_rowseg_kernel(GemmArgs g, SegTable segs) {
     __shared__ int kidx[SEG_MAX_K];
@@ -509,10 +568,10 @@ gemm_f32_rowseg_kernel(GemmArgs g, SegTable segs) {
         GemmArgs gl = g;
         gl.ldc = g.N; gl.accumulate = 0; gl.atomic_out = 0; gl.c_vec = (g.N % 4 == 0);
         gl.c_split = 0x7fffffff; gl.c_delta = 0;
-        gemm_body<S, VEC, false, false, true>(gl, bx, by, sg.k_begin, sg.k_end, g.slab + (long)bz * g.M * g.N, kidx, false);
+        gemm_body<S, VEC, false, false, true, 0, BF16>(gl, bx, by, sg.k_begin, sg.k_end, g.slab + (long)bz * g.M * g.N, kidx, false);
         return;
     }
-    gemm_body<S, VEC, false, false, true>(g, bx, by, sg.k_begin, sg.k_end, g.C + sg.c_off, kidx, false);
+    gemm_body<S, VEC, false, false, true, 0, BF16>(g, bx, by, sg.k_begin, sg.k_end, g.C + sg.c_off, kidx, false);
 }
 
 // C_g[m, n] (+)= sum_{z in [seg_ptr[g], seg_ptr[g+1])} slab[z][m][n]   (fixed order: deterministic)
@@ -673,9 +732,22 @@ static void launch_slab_reduce(const SlabReduce& a, hipStream_t s) {
 
 // layout: 0 forward (A and B k-contiguous), 1 data gradient (A k-contiguous, B idx-contiguous),
 //         2 weight gradient (both idx-contiguous), 3 (A idx-contiguous, B k-contiguous; not on the training path)
+// process-level: 0 = fp32 MFMA (exact fp32 products), 1 = bf16 MFMA on bf16-rounded operands (i3d_set_matmul_precision)
+static int g_matmul_bf16 = 0;
+
 template <class S>
 static void launch(const GemmArgs& g, int layout, int splits, bool vec, hipStream_t s) {
     dim3 grid(cdiv(g.M, S::BM), cdiv(g.N, S::BN), splits), block(S::NT);
+    if constexpr (bf16_shape<S>()) {
+        if (g_matmul_bf16 && vec) {      // (the unaligned variants are not on the training path: they stay fp32)
+            switch (layout) {
+                case 0: hipLaunchKernelGGL((gemm_f32_kernel<S, true, true, true, true>), grid, block, 0, s, g); break;
+                case 1: hipLaunchKernelGGL((gemm_f32_kernel<S, true, true, false, true>), grid, block, 0, s, g); break;
+                default: hipLaunchKernelGGL((gemm_f32_kernel<S, true, false, false, true>), grid, block, 0, s, g); break;
+            }
+            return;
+        }
+    }
 #define I3D_GEMM_LAUNCH(V, AK, BKC) hipLaunchKernelGGL((gemm_f32_kernel<S, V, AK, BKC>), grid, block, 0, s, g)
     switch (layout * 2 + (vec ? 1 : 0)) {
         case 0: I3D_GEMM_LAUNCH(false, true, true); break;
@@ -691,6 +763,12 @@ static void launch(const GemmArgs& g, int layout, int splits, bool vec, hipStrea
 template <class S>
 static void launch_rowseg(const GemmArgs& g, const SegTable& t, int n_segs, bool vec, hipStream_t s) {
     dim3 grid(cdiv(g.M, S::BM), cdiv(g.N, S::BN), n_segs);
+    if constexpr (bf16_shape<S>()) {
+        if (g_matmul_bf16 && vec) {
+            hipLaunchKernelGGL((gemm_f32_rowseg_kernel<S, true, true>), grid, dim3(S::NT), 0, s, g, t);
+            return;
+        }
+    }
     if (vec) hipLaunchKernelGGL((gemm_f32_rowseg_kernel<S, true>), grid, dim3(S::NT), 0, s, g, t);
     else hipLaunchKernelGGL((gemm_f32_rowseg_kernel<S, false>), grid, dim3(S::NT), 0, s, g, t);
 }
@@ -728,17 +806,25 @@ gemm_f32_tt_kernel(GemmArgs g) {
 }
 
 // forward layout (A and B k-contiguous, 16-byte loads) with the fused BatchNorm prologue / statistics epilogue
-template <class S, int FUSE>
+template <class S, int FUSE, bool BF16 = false>
 __global__ void __launch_bounds__(256)
 gemm_f32_fused_kernel(GemmArgs g) {
     int bx, by, bz;
     xcd_tile(bx, by, bz);
-    gemm_body<S, true, true, true, false, FUSE>(g, bx, by, 0, g.K, g.C, nullptr, true);
+    gemm_body<S, true, true, true, false, FUSE, BF16>(g, bx, by, 0, g.K, g.C, nullptr, true);
 }
 
 template <class S>
 static void launch_fused(const GemmArgs& g, int fuse, hipStream_t s) {
     dim3 grid(cdiv(g.M, S::BM), cdiv(g.N, S::BN), 1), block(S::NT);
+    if (g_matmul_bf16) {
+        switch (fuse) {
+            case 1: hipLaunchKernelGGL((gemm_f32_fused_kernel<S, 1, true>), grid, block, 0, s, g); break;
+            case 2: hipLaunchKernelGGL((gemm_f32_fused_kernel<S, 2, true>), grid, block, 0, s, g); break;
+            default: hipLaunchKernelGGL((gemm_f32_fused_kernel<S, 3, true>), grid, block, 0, s, g); break;
+        }
+        return;
+    }
     switch (fuse) {
         case 1: hipLaunchKernelGGL((gemm_f32_fused_kernel<S, 1>), grid, block, 0, s, g); break;
         case 2: hipLaunchKernelGGL((gemm_f32_fused_kernel<S, 2>), grid, block, 0, s, g); break;
@@ -1033,6 +1119,14 @@ static int rowseg_impl(int M, int N, const float* A, int lda, const float* B, in
 }  // namespace i3d
 
 using namespace i3d;
+
+extern "C" int i3d_set_matmul_precision(int bf16) {
+    I3D_CHECK_ARG(bf16 == 0 || bf16 == 1, "0: fp32 MFMA, 1: bf16 MFMA on bf16-rounded operands");
+    g_matmul_bf16 = bf16;
+    return I3D_OK;
+}
+
+extern "C" int i3d_get_matmul_precision(void) { return g_matmul_bf16; }
 
 extern "C" int i3d_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
                             int ldb, float* C, int ldc, const float* bias, int accumulate, void* stream) {

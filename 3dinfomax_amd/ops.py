@@ -214,6 +214,22 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
+def set_matmul_precision(dtype):
+    """'fp32' (default): exact fp32 products; 'bf16': bf16-rounded operands on the bf16 matrix pipe, fp32 accumulation
+    (every GEMM of the library, process-level).  Returns the previous setting."""
+    L = _lib.load()
+    prev = 'bf16' if L.i3d_get_matmul_precision() else 'fp32'
+    name = {torch.float32: 'fp32', torch.bfloat16: 'bf16'}.get(dtype, dtype)
+    if name not in ('fp32', 'bf16'):
+        raise ValueError(f'matmul precision {dtype!r}: fp32 or bf16')
+    check(L.i3d_set_matmul_precision(int(name == 'bf16')), 'i3d_set_matmul_precision')
+    return prev
+
+
+def get_matmul_precision():
+    return 'bf16' if _lib.load().i3d_get_matmul_precision() else 'fp32'
+
+
 def gemm(A, B, trans_a=False, trans_b=False, out=None, bias=None, accumulate=False):
     """out[M,N] = (accumulate ? out : 0) + op(A) op(B) + bias.  A, B, out: 2-D fp32, unit inner stride
     (row slices / column slices of a contiguous tensor are fine: the row stride is the leading dimension)."""

@@ -55,6 +55,9 @@ def parse():
     ap.add_argument('--workload', default='qm9', choices=['qm9', 'qmugs'],
                     help='qm9: BASELINE.json configs[1] (the metric); qmugs: configs[3] shape - QMugs-shaped molecules (~55 atoms), '
                          '3 conformers per molecule, NTXentMultiplePositives, batch 500, PNA depth 7 (pre-train_QMugs.yml), fp32')
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
+                    help='matmul precision: fp32 (configs[1], default) or bf16 operands on the bf16 matrix pipe with fp32 '
+                         'accumulation, fp32 tensors / BatchNorm statistics / master weights (configs[3])')
     ap.add_argument('--no-families', action='store_true', help='skip the per-family roofline block (tools/family_bench.py)')
     ap.add_argument('--loader-workers', type=int, default=4,
                     help='DataLoader worker processes of the with-batch-assembly figure (0: assemble in the training thread)')
@@ -124,6 +127,7 @@ def main():
     amd = importlib.import_module('3dinfomax_amd')
     ops = importlib.import_module('3dinfomax_amd.ops')
     adist = importlib.import_module('3dinfomax_amd.dist')
+    ops.set_matmul_precision(args.dtype)
     if use_dist:
         if not args.no_prewarm:
             adist.warm_up(dev)          # kernels, streams and autograd's thread before the communicator (dist.warm_up: 7 %)
@@ -400,8 +404,8 @@ def main():
         # form (forward 6 + backward 14 passes over [E,F], 8 + 14 over [N,F], 2 + 2 over [N,4F])
         byts = args.depth * 4.0 * sh['F'] * (20 * sh['E'] + 22 * sh['N'] + 4 * 4 * sh['N'])
         step_line = dict(executed_mfma_flops_per_step=int(flops), achieved_tflops=round(flops / ms / 1e9, 1),
-                         frac_of_mfma_peak=round(flops / ms / 1e9 / fb.MFMA_F32_PEAK_TF, 3),
-                         ms_at_mfma_peak=round(flops / fb.MFMA_F32_PEAK_TF / 1e9, 3),
+                         frac_of_mfma_peak=round(flops / ms / 1e9 / (fb.MFMA_BF16_PEAK_TF if args.dtype == 'bf16' else fb.MFMA_F32_PEAK_TF), 3),
+                         ms_at_mfma_peak=round(flops / (fb.MFMA_BF16_PEAK_TF if args.dtype == 'bf16' else fb.MFMA_F32_PEAK_TF) / 1e9, 3),
                          algorithmic_bytes_per_step=int(byts), ms_at_hbm_peak=round(byts / HBM_PEAK_GBS / 1e6, 3),
                          note='PNA layers only (heads, encoders, Net3D, NT-Xent are < 2 % of the flops); the step is neither '
                               'MFMA- nor HBM-bound: it is ~250 dependent launches of 5-50 us on two streams')
@@ -412,12 +416,16 @@ def main():
         out = dict(metric='molecules/sec pretraining step (PNA+Net3D, QM9-50k); PNA-agg HBM GB/s vs peak',
                    value=round(mol_per_s, 1), unit='molecules/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
-                   vs_baseline=None, dtype='f32', data='synthetic',
-                   config=dict(workload=(f'configs[3] shape in fp32: PNA hidden=200 depth={args.depth} + Net3D hidden=20 + '
+                   vs_baseline=None, dtype='f32' if args.dtype == 'fp32' else 'bf16', data='synthetic',
+                   config=dict(precision=('fp32 (exact fp32 products on the fp32 matrix pipe)' if args.dtype == 'fp32' else
+                                          'bf16 matmul operands (rounded when a lane reads its MFMA fragments) on '
+                                          'v_mfma_f32_*_bf16, fp32 accumulation; tensors in HBM, BatchNorm statistics, '
+                                          'master weights, Adam in fp32; the hidden-20 products of the 3D network stay fp32'),
+                               workload=(f'configs[3] shape: PNA hidden=200 depth={args.depth} + Net3D hidden=20 + '
                                          f'NTXentMultiplePositives tau=0.1, QMugs-shaped synthetic molecules, 3 conformers, batch {B}/GPU, Adam'
                                          if qmugs else
                                          f'PNA hidden=200 depth={args.depth} + Net3D hidden=20 + NT-Xent tau=0.1, '
-                                         f'QM9-shaped synthetic molecules, batch {B}/GPU, fp32, Adam'),
+                                         f'QM9-shaped synthetic molecules, batch {B}/GPU, Adam'),
                                atoms_per_batch=int(batches[0][0].number_of_nodes()),
                                complete_graph_edges_per_batch=int(batches[0][1].number_of_edges()),
                                optimizer='torch.optim.Adam(fused=True)' if args.torch_adam else 'infomax3d_amd.Adam (torch.optim.Adam subclass: same state and update expressions, one launch of csrc/adam.hip for all parameter tensors)',

@@ -109,6 +109,13 @@ int i3d_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float* A, 
 int i3d_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                     float* C, int ldc, const float* bias, int accumulate, int tile_cfg, int splits, void* workspace,
                     long workspace_bytes, void* stream);
+/* Precision of every GEMM of the library (process-level; the reference's switch is the trainer's `dtype`, configs[3] of
+ * BASELINE.json): 0 (default) = exact fp32 products on the fp32 matrix pipe; 1 = the operands are rounded to bf16
+ * (round-to-nearest-even) as a lane reads its fragments and multiplied with v_mfma_f32_*_bf16, accumulation / bias /
+ * epilogue / BatchNorm statistics / tensors in memory stay fp32 (the master weights are the fp32 parameters). */
+int i3d_set_matmul_precision(int bf16);
+int i3d_get_matmul_precision(void);
+
 /* i3d_gemm_f32 with scratch: when the reduction dimension is split over workgroups (weight gradients), the slices are
  * written to workspace[slices][M][N] and summed in a fixed order by a second kernel (deterministic, no zero-fill, no
  * atomics).  workspace NULL or too small: fp32 atomics as i3d_gemm_f32. */

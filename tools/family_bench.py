@@ -19,6 +19,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA peak of MI355X
+MFMA_BF16_PEAK_TF = 2500.0    # dense bf16 MFMA peak (same guide); used when ops.get_matmul_precision() == 'bf16'
 HBM_PEAK_GBS = 8000.0
 
 
@@ -76,13 +77,14 @@ def measure(amd, ops, g2, dev, F=200, big_batch=8192):
         'wgrad post h [F,F] K=N': (lambda: ops.gemm(dY_n, h, trans_a=True), 2.0 * N * F * F),
     }
     rows, tot_us, tot_fl = [], 0.0, 0.0
+    peak_tf = MFMA_BF16_PEAK_TF if ops.get_matmul_precision() == 'bf16' else MFMA_F32_PEAK_TF
     for name, (fn, fl) in gemms.items():
         us = _time(fn)
-        rows.append(dict(kernel=name, us=round(us, 2), tflops=round(fl / us / 1e6, 1), frac=round(fl / us / 1e6 / MFMA_F32_PEAK_TF, 3)))
+        rows.append(dict(kernel=name, us=round(us, 2), tflops=round(fl / us / 1e6, 1), frac=round(fl / us / 1e6 / peak_tf, 3)))
         tot_us += us
         tot_fl += fl
-    out['gemm'] = dict(bound='mfma', peak=MFMA_F32_PEAK_TF, unit='TFLOP/s', achieved=round(tot_fl / tot_us / 1e6, 1),
-                       frac=round(tot_fl / tot_us / 1e6 / MFMA_F32_PEAK_TF, 3), kernels=rows,
+    out['gemm'] = dict(bound='mfma', peak=peak_tf, unit='TFLOP/s', achieved=round(tot_fl / tot_us / 1e6, 1),
+                       frac=round(tot_fl / tot_us / 1e6 / peak_tf, 3), kernels=rows,
                        note='flop-weighted over the ten GEMM shapes of one PNA layer (forward, data gradient, weight gradient), '
                             'each launched 20 times back to back between one event pair')
 
