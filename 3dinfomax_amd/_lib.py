@@ -67,7 +67,7 @@ class Net3dEdgeArgs(ctypes.Structure):
                 ('n_enc', c_int), ('reduce_mean', c_int), ('ld_w_in', c_int), ('ld_w_msg', c_int), ('d_raw', _P), ('perm', _P),
                 ('dst_s', _P), ('in_ptr', _P), ('emb', _P), ('W_in', _P), ('b_in', _P), ('W_msg', _P), ('b_msg', _P),
                 ('w_gate', _P), ('b_gate', _P), ('stats', _P), ('aff_in', _P), ('aff_msg', _P), ('x_msg', _P), ('d_out', _P),
-                ('msg', _P), ('m_sum', _P), ('grad_m_sum', _P), ('grad_ya', _P), ('partial', _P), ('grad_W_in', _P),
+                ('msg', _P), ('m_sum', _P), ('grad_m_sum', _P), ('grad_ya', _P), ('grad_lin', _P), ('partial', _P), ('grad_W_in', _P),
                 ('grad_b_in', _P), ('grad_gamma_in', _P), ('grad_beta_in', _P), ('grad_W_msg', _P), ('grad_b_msg', _P),
                 ('grad_gamma_msg', _P), ('grad_beta_msg', _P), ('grad_w_gate', _P), ('grad_b_gate', _P), ('grad_emb', _P)]
 

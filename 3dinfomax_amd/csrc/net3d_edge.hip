@@ -18,9 +18,9 @@
 //             F2  e0 (stored, edge-id order), x_msg (stored), its statistics -> finalisation
 //             F3  m, gate, msg (stored) -> i3d_segment_sum
 //   backward  B1  sums of the message BatchNorm + the gate's parameter gradients        -> R1
-//             B2  gradient through the message block: dW_e and dc on the MFMA unit (a wave's 64 edges are the K
-//                 dimension of v_mfma_f32_32x32x2_f32, a ones column gives the column sum), grad of e0 -> through post
-//                 activation (stored), sums of the input BatchNorm                       -> R2
+//             B2a gradient through the message block (stored): dW_e and dc on the MFMA unit (a wave's 64 edges are the K
+//                 dimension of v_mfma_f32_32x32x2_f32, a ones column gives the column sum)
+//             B2b grad of e0 -> through the post activation (stored), sums of the input BatchNorm     -> R2
 //             B3  gradient through the edge-input block: dW_in | db_in on the MFMA unit  -> R3
 // Every pass recomputes the cheap part of the chain (Fourier features, the [H, 2 n_enc + 1] product) from the distance.
 // Deterministic: per-lane -> wave tree -> wave order -> block order sums, no atomics.
@@ -41,7 +41,11 @@ constexpr int odd(int n) { return n | 1; }   // row stride of an MFMA operand ti
 // The weights are loop-invariant LDS reads: without this the compiler hoists all ~600 of them out of the per-edge loops
 // into registers and spills.  A compiler-level memory barrier at the top of an iteration keeps them as LDS broadcasts.
 #define N3_NO_HOIST() __asm__ volatile("" ::: "memory")
-constexpr int MAX_BWD_BLOCKS = 256;  // one block per CU; the R kernels add this many partial rows per column
+// <= 168 registers per lane (3 waves per SIMD): the 3D network runs on a stream of its own next to the 2D network - a wave
+// that takes the whole register file of its SIMD (the unrolled 20-wide code schedules to 470 registers when allowed to)
+// shuts the other stream out of every CU for the length of the kernel
+#define N3_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
+constexpr int MAX_BWD_BLOCKS = 512;  // two blocks per CU; the R kernels add this many partial rows per column
 
 template <int H, int NENC>
 struct Dims {
@@ -74,6 +78,7 @@ struct EdgeK {                       // kernel argument (by value)
     float* msg;
     const float* grad_m_sum;
     float* grad_ya;
+    float* grad_lin;
     float* partial;
 };
 
@@ -218,7 +223,7 @@ __device__ __forceinline__ void write_tile_partial(float* partial, int tile, con
 
 // F1: statistics of xa = act(W_in f + b_in)
 template <int H, int NENC>
-__global__ void __launch_bounds__(TB) n3_stats_in_kernel(EdgeK p) {
+__global__ void __launch_bounds__(TB) N3_OCC n3_stats_in_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
     __shared__ Wts<H, DIN> w;
     __shared__ float pivot[H];
@@ -262,7 +267,7 @@ __global__ void __launch_bounds__(TB) n3_stats_in_kernel(EdgeK p) {
 
 // F2: e0 -> d_out (edge-id order), x_msg = act(c + W_e e0) (stored, destination-sorted) and its statistics
 template <int H, int NENC>
-__global__ void __launch_bounds__(TB) n3_msg_pre_kernel(EdgeK p) {
+__global__ void __launch_bounds__(TB) N3_OCC n3_msg_pre_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
     __shared__ Wts<H, DIN> w;
     __shared__ float pivot[H];
@@ -324,7 +329,7 @@ __device__ __forceinline__ float gate_of(const Wts<H, DIN>& w, const float* m) {
 
 // F3: msg = m * gate, m = BN_msg(x_msg)
 template <int H, int NENC>
-__global__ void __launch_bounds__(TB) n3_gate_kernel(EdgeK p) {
+__global__ void __launch_bounds__(TB) N3_OCC n3_gate_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
     __shared__ Wts<H, DIN> w;
     const int tid = threadIdx.x;
@@ -360,7 +365,7 @@ __device__ __forceinline__ void grad_m(const Wts<H, DIN>& w, const EdgeK& p, lon
 
 // B1: partial[block] = sum gm | sum gm xhat_m | sum gg m | sum gg
 template <int H, int NENC>
-__global__ void __launch_bounds__(TB) n3_bwd_sums_kernel(EdgeK p) {
+__global__ void __launch_bounds__(TB) N3_OCC n3_bwd_sums_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
     constexpr int NC = 3 * H + 1;
     __shared__ Wts<H, DIN> w;
@@ -437,15 +442,13 @@ __device__ __forceinline__ void write_outer(const f32x16& acc, float* scratch, f
     }
 }
 
-// B2: gradient through the message block and the post activation of the input block
-//   partial[block] = [H][H + 1] (dW_e | dc)  |  sum gya [H]  |  sum gya xhat_a [H]
+// B2a: gradient through the message block: glin (stored), partial[block] = [H][H + 1] (dW_e | dc)
 template <int H, int NENC>
-__global__ void __launch_bounds__(TB) n3_bwd_msg_kernel(EdgeK p) {
+__global__ void __launch_bounds__(TB) N3_OCC n3_bwd_msg_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
     constexpr int NB = H + 1, NP = H * NB + 2 * H;
     __shared__ Wts<H, DIN> w;
     __shared__ float tiles[tile_floats<H, NB>()];      // also the accumulator exchange (4 * 1024 floats) at the end
-    __shared__ float red[4 * 2 * H];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     load_weights(w, p, tid);
     __syncthreads();
@@ -456,9 +459,6 @@ __global__ void __launch_bounds__(TB) n3_bwd_msg_kernel(EdgeK p) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float s[2 * H];
-#pragma unroll
-    for (int c = 0; c < 2 * H; ++c) s[c] = 0.f;
     for (long base = j0; base < jend; base += TB) {
         N3_NO_HOIST();
         const long j = base + tid;
@@ -468,16 +468,9 @@ __global__ void __launch_bounds__(TB) n3_bwd_msg_kernel(EdgeK p) {
         for (int c = 0; c < H; ++c) { glin[c] = 0.f; e0x[c] = 0.f; }
         e0x[H] = 1.f;
         if (valid) {
-            const int eid = p.perm[j];
-            // ya = BN_in(xa), recomputed from the distance (needed for the derivative of the post activation)
-            float f[DIN], a[H], xa[H], ya[H];
-            fourier<NENC>(p.d_raw[eid], f);
-            lin_in<H, DIN>(w, f, ACT, a, xa);
-            bn_apply<H>(w.aff_in, xa, ya);
-            N3_NO_HOIST();
             float xm[H], m[H], gm[H], gg, lin[H];
             load_row<H>(p.x_msg + j * H, xm);
-            load_row<H>(p.d_out + (long)eid * H, e0x);
+            load_row<H>(p.d_out + (long)p.perm[j] * H, e0x);
             bn_apply<H>(w.aff_msg, xm, m);
             grad_m<H, DIN>(w, p, j, m, gm, gg);
             lin_msg<H, DIN>(w, e0x, lin);
@@ -487,32 +480,57 @@ __global__ void __launch_bounds__(TB) n3_bwd_msg_kernel(EdgeK p) {
                 const float gx = w.aff_msg[H + c] * (gm[c] - w.gs_msg[c] * p.inv_rows - xh * (w.gs_msg[H + c] * p.inv_rows));
                 glin[c] = gx * act_grad(lin[c], ACT);
             }
-            // grad of e0 = W_e^T glin, then through the post activation
-            float gya[H];
-#pragma unroll
-            for (int k = 0; k < H; ++k) {
-                N3_NO_HOIST();
-                float ge = 0.f;
-#pragma unroll
-                for (int o = 0; o < H; ++o) ge = fmaf(w.w_e[o * H + k], glin[o], ge);
-                gya[k] = ge * act_grad(ya[k], ACT);
-                const float xh = (xa[k] - w.aff_in[k]) * w.istd_in[k];
-                s[k] += gya[k];
-                s[H + k] = fmaf(gya[k], xh, s[H + k]);
-            }
-            store_row<H>(p.grad_ya + j * H, gya);
+            store_row<H>(p.grad_lin + j * H, glin);
         }
         outer_accumulate<H, NB>(tile_a, tile_b, glin, e0x, valid, lane, acc);
     }
-    float* out = p.partial + (long)blockIdx.x * NP;
-    write_outer<H, NB>(acc, tiles, out, tid);
+    write_outer<H, NB>(acc, tiles, p.partial + (long)blockIdx.x * NP, tid);
+}
+
+// B2b: grad of e0 = W_e^T glin, through the post activation (needs ya = BN_in(xa), recomputed from the distance): gya
+// (stored), partial[block][H (H + 1) ...] = sum gya [H] | sum gya xhat_a [H]
+template <int H, int NENC>
+__global__ void __launch_bounds__(TB) N3_OCC n3_bwd_post_kernel(EdgeK p) {
+    constexpr int DIN = Dims<H, NENC>::DIN;
+    constexpr int NB = H + 1, NP = H * NB + 2 * H;
+    __shared__ Wts<H, DIN> w;
+    __shared__ float red[4 * 2 * H];
+    const int tid = threadIdx.x;
+    load_weights(w, p, tid);
+    __syncthreads();
+    const long j0 = (long)blockIdx.x * p.rows_per_block;
+    const long jend = min(j0 + p.rows_per_block, (long)p.E);
+    float s[2 * H];
+#pragma unroll
+    for (int c = 0; c < 2 * H; ++c) s[c] = 0.f;
+    for (long j = j0 + tid; j < jend; j += TB) {
+        N3_NO_HOIST();
+        float f[DIN], a[H], xa[H], ya[H], glin[H], gya[H];
+        fourier<NENC>(p.d_raw[p.perm[j]], f);
+        lin_in<H, DIN>(w, f, ACT, a, xa);
+        bn_apply<H>(w.aff_in, xa, ya);
+        load_row<H>(p.grad_lin + j * H, glin);
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            N3_NO_HOIST();
+            float ge = 0.f;
+#pragma unroll
+            for (int o = 0; o < H; ++o) ge = fmaf(w.w_e[o * H + k], glin[o], ge);
+            gya[k] = ge * act_grad(ya[k], ACT);
+            const float xh = (xa[k] - w.aff_in[k]) * w.istd_in[k];
+            s[k] += gya[k];
+            s[H + k] = fmaf(gya[k], xh, s[H + k]);
+        }
+        store_row<H>(p.grad_ya + j * H, gya);
+    }
     block_sum_cols<2 * H>(s, red, tid);
-    if (tid < 2 * H) out[H * NB + tid] = red[tid] + red[2 * H + tid] + red[4 * H + tid] + red[6 * H + tid];
+    if (tid < 2 * H)
+        p.partial[(long)blockIdx.x * NP + H * NB + tid] = red[tid] + red[2 * H + tid] + red[4 * H + tid] + red[6 * H + tid];
 }
 
 // B3: gradient through the edge-input block: partial[block] = [H][DIN + 1] (dW_in | db_in)
 template <int H, int NENC>
-__global__ void __launch_bounds__(TB) n3_bwd_in_kernel(EdgeK p) {
+__global__ void __launch_bounds__(TB) N3_OCC n3_bwd_in_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
     constexpr int NB = DIN + 1, NP = H * NB;
     __shared__ Wts<H, DIN> w;
@@ -555,20 +573,34 @@ __global__ void __launch_bounds__(TB) n3_bwd_in_kernel(EdgeK p) {
 }
 
 // ---- R kernels: one block adds the partial rows of the pass (block order) and writes the parameter gradients
-__device__ __forceinline__ void reduce_rows(const float* partial, int n_rows, int n_cols, float* tot, int tid, int nthreads) {
-    for (int c = tid; c < n_cols; c += nthreads) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int r = 0;
-        for (; r + 4 <= n_rows; r += 4) {
-            a0 += partial[(long)r * n_cols + c];
-            a1 += partial[(long)(r + 1) * n_cols + c];
-            a2 += partial[(long)(r + 2) * n_cols + c];
-            a3 += partial[(long)(r + 3) * n_cols + c];
+// tot[c] = sum over the rows of partial[row][c] (fixed order).  The block's threads form `groups` row groups (a power of
+// two) x `cw` columns; group g adds rows g, g + groups, ...; the groups are added in group order.  scratch: nthreads floats.
+__device__ __forceinline__ void reduce_rows(const float* partial, int n_rows, int n_cols, float* tot, float* scratch, int tid,
+                                            int nthreads) {
+    int cw = 32;
+    while (cw < n_cols && cw < nthreads) cw <<= 1;
+    const int groups = nthreads / cw;
+    const int c0 = tid % cw, grp = tid / cw;
+    for (int cb = 0; cb < n_cols; cb += cw) {
+        const int c = cb + c0;
+        float a0 = 0.f, a1 = 0.f;
+        if (c < n_cols) {
+            int r = grp;
+            for (; r + groups < n_rows; r += 2 * groups) {
+                a0 += partial[(long)r * n_cols + c];
+                a1 += partial[(long)(r + groups) * n_cols + c];
+            }
+            if (r < n_rows) a0 += partial[(long)r * n_cols + c];
         }
-        for (; r < n_rows; ++r) a0 += partial[(long)r * n_cols + c];
-        tot[c] = (a0 + a1) + (a2 + a3);
+        scratch[tid] = a0 + a1;
+        __syncthreads();
+        if (grp == 0 && c < n_cols) {
+            float t = 0.f;
+            for (int q = 0; q < groups; ++q) t += scratch[q * cw + c0];
+            tot[c] = t;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 }
 
 struct ReduceK {
@@ -590,8 +622,9 @@ struct ReduceK {
 
 __global__ void __launch_bounds__(1024) n3_reduce_sums_kernel(ReduceK q) {      // R1
     __shared__ float tot[3 * 32 + 1];
+    __shared__ float scratch[1024];
     const int H = q.H, tid = threadIdx.x;
-    reduce_rows(q.partial, q.n_rows, 3 * H + 1, tot, tid, 1024);
+    reduce_rows(q.partial, q.n_rows, 3 * H + 1, tot, scratch, tid, 1024);
     if (tid < H) {
         q.grad_beta[tid] = tot[tid];
         q.grad_gamma[tid] = tot[H + tid];
@@ -604,8 +637,9 @@ __global__ void __launch_bounds__(1024) n3_reduce_sums_kernel(ReduceK q) {      
 
 __global__ void __launch_bounds__(1024) n3_reduce_msg_kernel(ReduceK q) {       // R2
     __shared__ float tot[32 * 33 + 64];
+    __shared__ float scratch[1024];
     const int H = q.H, NB = H + 1, tid = threadIdx.x;
-    reduce_rows(q.partial, q.n_rows, H * NB + 2 * H, tot, tid, 1024);
+    reduce_rows(q.partial, q.n_rows, H * NB + 2 * H, tot, scratch, tid, 1024);
     // message weights [H, 3H] = [W_s | W_d | W_e]: dW_s = dW_d = dc (x) emb, dW_e from the MFMA accumulators, db = dc
     for (int t = tid; t < H * H; t += 1024) {
         const int o = t / H, k = t - o * H;
@@ -635,8 +669,9 @@ __global__ void __launch_bounds__(1024) n3_reduce_msg_kernel(ReduceK q) {       
 
 __global__ void __launch_bounds__(1024) n3_reduce_in_kernel(ReduceK q) {        // R3
     __shared__ float tot[32 * 33];
+    __shared__ float scratch[1024];
     const int H = q.H, NB = q.DIN + 1, tid = threadIdx.x;
-    reduce_rows(q.partial, q.n_rows, H * NB, tot, tid, 1024);
+    reduce_rows(q.partial, q.n_rows, H * NB, tot, scratch, tid, 1024);
     for (int t = tid; t < H * q.DIN; t += 1024) {
         const int o = t / q.DIN, k = t - o * q.DIN;
         q.grad_W_in[(long)o * q.ld_w_in + k] = tot[o * NB + k];
@@ -673,7 +708,7 @@ EdgeK kernel_args(const I3dNet3dEdgeArgs* a) {
     p.W_in = a->W_in; p.b_in = a->b_in; p.W_msg = a->W_msg; p.b_msg = a->b_msg; p.w_gate = a->w_gate; p.b_gate = a->b_gate;
     p.aff_in = a->aff_in; p.aff_msg = a->aff_msg; p.invstd_in = a->tail_in.invstd; p.invstd_msg = a->tail_msg.invstd;
     p.x_msg = a->x_msg; p.d_out = a->d_out; p.msg = a->msg;
-    p.grad_m_sum = a->grad_m_sum; p.grad_ya = a->grad_ya;
+    p.grad_m_sum = a->grad_m_sum; p.grad_ya = a->grad_ya; p.grad_lin = a->grad_lin;
     return p;
 }
 
@@ -746,7 +781,7 @@ extern "C" int i3d_net3d_edge_fwd(const I3dNet3dEdgeArgs* a, void* stream_) {
 
 extern "C" int i3d_net3d_edge_bwd(const I3dNet3dEdgeArgs* a, void* stream_) {
     if (int rc = check_common(a)) return rc;
-    I3D_CHECK_ARG(a->grad_m_sum && a->grad_ya && a->partial, "null backward buffer");
+    I3D_CHECK_ARG(a->grad_m_sum && a->grad_ya && a->grad_lin && a->partial, "null backward buffer");
     I3D_CHECK_ARG(a->grad_W_in && a->grad_b_in && a->grad_gamma_in && a->grad_beta_in && a->grad_W_msg && a->grad_b_msg &&
                       a->grad_gamma_msg && a->grad_beta_msg && a->grad_w_gate && a->grad_b_gate && a->grad_emb,
                   "null gradient buffer");
@@ -771,6 +806,8 @@ extern "C" int i3d_net3d_edge_bwd(const I3dNet3dEdgeArgs* a, void* stream_) {
     I3D_CHECK_LAUNCH();
     p.gsum_msg = gsum;
     N3_DISPATCH(n3_bwd_msg_kernel, dim3(pl.bwd_blocks), dim3(TB), stream, p);
+    I3D_CHECK_LAUNCH();
+    N3_DISPATCH(n3_bwd_post_kernel, dim3(pl.bwd_blocks), dim3(TB), stream, p);
     I3D_CHECK_LAUNCH();
     q.gsum = gsum + 2 * H; q.grad_gamma = a->grad_gamma_in; q.grad_beta = a->grad_beta_in;
     hipLaunchKernelGGL(n3_reduce_msg_kernel, dim3(1), dim3(1024), 0, stream, q);
