@@ -239,11 +239,12 @@ extern "C" int i3d_grouped_fc_bn_fwd(const I3dGroupedFcArgs* a, void* stream) {
     return tail_fwd(&a->tail, N, Fo, lin, a->xact, a->residual, a->y, stream);
 }
 
-static int grouped_fc_bn_bwd_chain(const I3dGroupedFcArgs* a, void* stream) {
+// grad_h_accumulate: grad_h already holds a gradient w.r.t. h (the residual's: grad_h aliases grad_y), add to it
+static int grouped_fc_bn_bwd_chain(const I3dGroupedFcArgs* a, void* stream, int grad_h_accumulate = 0) {
     const int Fh = a->f_h, Fo = a->f_out, A = a->agg_width, N = a->num_nodes;
     TRY(tail_bwd(&a->tail, N, Fo, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre, a->grad_bias,
                  stream));
-    TRY(i3d_gemm_f32(0, 0, N, Fh, Fo, a->grad_pre, Fo, a->W, a->ldw, a->grad_h, Fh, nullptr, 0, stream));
+    TRY(i3d_gemm_f32(0, 0, N, Fh, Fo, a->grad_pre, Fo, a->W, a->ldw, a->grad_h, Fh, nullptr, grad_h_accumulate, stream));
     return i3d_gemm_f32_grouped(0, a->m_padded, A, Fo, a->grad_pre, Fo, N, a->deg_rows, a->deg_tile_group, a->WD, A,
                                 (long)Fo * A, a->grad_agg, A, 0, stream);
 }
@@ -368,7 +369,15 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     // 0.07 ms more per step for nothing, forking everything late (after the pretrans chain) costs the GPU 2 %.  One join.
     Aux* x = aux_for((hipStream_t)stream);
     for (int i = a->n_post_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_chain(&a->postx[i], stream));
-    TRY(grouped_fc_bn_bwd_chain(&a->post, stream));
+    // residual layer whose caller passes ONE buffer as grad_out and post.grad_h: dh = dh_out + (layer's own terms), the
+    // first of which is accumulated on top of dh_out instead of a separate add at the end.  Only without extra posttrans
+    // blocks (then post.grad_y IS grad_out and its last reader, the BatchNorm backward, runs before that GEMM).
+    const bool inplace = a->residual && a->post.grad_h == a->grad_out && a->n_post_extra == 0;
+    I3D_CHECK_ARG(a->post.grad_h != a->grad_out || inplace, "grad_h may alias grad_out only for a residual layer without extra blocks");
+    TRY(grouped_fc_bn_bwd_chain(&a->post, stream, inplace ? 1 : 0));
+    const long n = (long)a->edge.num_nodes * a->edge.f_h;
+    // separate buffers: the residual's term right here, so that both forms add in the same order (dh_out + dlin W_h) + ...
+    if (a->residual && !inplace) TRY(i3d_add_inplace(a->post.grad_h, a->grad_out, n, stream));
     void* wst = fork_wgrad(x, stream);
     TRY(grouped_fc_bn_bwd_wgrad(&a->post, wst));
     for (int i = a->n_post_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_wgrad(&a->postx[i], wst));
@@ -395,8 +404,6 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
         TRY(edge_fc_bn_bwd_wgrad(&a->edge, wst));
     }
     TRY(edge_fc_bn_bwd_dgrad(&a->edge, stream, a->post.grad_h));       // post.grad_h += edge block's dh
-    const long n = (long)a->edge.num_nodes * a->edge.f_h;
-    if (a->residual) TRY(i3d_add_inplace(a->post.grad_h, a->grad_out, n, stream));
     if (a->defer_join) return I3D_OK;
     return join_wgrad(x, stream);
 }

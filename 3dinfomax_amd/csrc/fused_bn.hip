@@ -24,6 +24,7 @@ constexpr int FIN_COLS = 8, FIN_LANES = 32;
 //   2. M2 = sum over tiles of  M2_b + (S_b - n_b mean)^2 / n_b  (the parallel-axis term, exact algebra; 1 / n_b of a row
 //      count <= 64 through the fp32 reciprocal, 6e-8 relative) -> LDS -> lane 0 adds the 32 values in lane order.
 constexpr int FIN_KEEP = 16;      // tiles per lane kept in registers between the passes (more: re-read, L2-resident)
+constexpr int FIN_TAIL = 8;       // tiles per lane and trip of the re-read loops
 
 __global__ void __launch_bounds__(256)
 bn_finalize_partials_kernel(const float* __restrict__ partial, int n_tiles, int feat, float eps, float momentum,
@@ -47,11 +48,21 @@ bn_finalize_partials_kernel(const float* __restrict__ partial, int n_tiles, int 
     for (int k = 0; k < FIN_KEEP; ++k) {
         if (kn[k] > 0.f) { n_l += (double)kn[k]; s_l += (double)ks[k]; }
     }
+    // beyond the kept tiles (batches of several thousand molecules, the 3D network's edges): FIN_TAIL independent loads in
+    // flight per trip - one load per trip made this loop 100 us at 2000 tiles
     if (live) {
-        for (int b = ly + FIN_KEEP * FIN_LANES; b < n_tiles; b += FIN_LANES) {
-            const float* p = partial + (long)b * 3 * feat + c;
-            const float nb = p[2 * feat];
-            if (nb > 0.f) { n_l += (double)nb; s_l += (double)p[0]; }
+        for (int b0 = ly + FIN_KEEP * FIN_LANES; b0 < n_tiles; b0 += FIN_TAIL * FIN_LANES) {
+            float ts[FIN_TAIL], tn[FIN_TAIL];
+#pragma unroll
+            for (int u = 0; u < FIN_TAIL; ++u) {
+                const int b = b0 + u * FIN_LANES;
+                const bool ok = b < n_tiles;
+                const float* p = partial + (long)(ok ? b : 0) * 3 * feat + c;
+                ts[u] = p[0]; tn[u] = ok ? p[2 * feat] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < FIN_TAIL; ++u)
+                if (tn[u] > 0.f) { n_l += (double)tn[u]; s_l += (double)ts[u]; }
         }
     }
     sm[0][ly][cx] = n_l; sm[1][ly][cx] = s_l;
@@ -70,12 +81,21 @@ bn_finalize_partials_kernel(const float* __restrict__ partial, int n_tiles, int 
         }
     }
     if (live) {
-        for (int b = ly + FIN_KEEP * FIN_LANES; b < n_tiles; b += FIN_LANES) {
-            const float* p = partial + (long)b * 3 * feat + c;
-            const float nb = p[2 * feat];
-            if (nb > 0.f) {
-                const double d = (double)p[0] - (double)nb * mu;
-                m2_l += (double)p[feat] + d * d * (double)__frcp_rn(nb);
+        for (int b0 = ly + FIN_KEEP * FIN_LANES; b0 < n_tiles; b0 += FIN_TAIL * FIN_LANES) {
+            float ts[FIN_TAIL], tm[FIN_TAIL], tn[FIN_TAIL];
+#pragma unroll
+            for (int u = 0; u < FIN_TAIL; ++u) {
+                const int b = b0 + u * FIN_LANES;
+                const bool ok = b < n_tiles;
+                const float* p = partial + (long)(ok ? b : 0) * 3 * feat + c;
+                ts[u] = p[0]; tm[u] = p[feat]; tn[u] = ok ? p[2 * feat] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < FIN_TAIL; ++u) {
+                if (tn[u] > 0.f) {
+                    const double d = (double)ts[u] - (double)tn[u] * mu;
+                    m2_l += (double)tm[u] + d * d * (double)__frcp_rn(tn[u]);
+                }
             }
         }
     }

@@ -65,6 +65,7 @@ struct PnaCtx {
     float coef[128];
     int n_scalers_cfg = 0;
     long saved_floats = 0;
+    int gh_cur = 0;                 // which of the two dL/dh buffers holds the gradient after the layers done so far (backward)
 };
 
 // I3D_DEFER_BIAS=1: the bias gradients are finalised from row-chunk partials on the weight-gradient stream instead of
@@ -420,6 +421,7 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
         }
         // readout backward -> dL/dh_L
         TRY(i3d_segment_readout_bwd(gy, c->h[L], b.graph_ptr, B, F, m.readout_ops, m.n_readout, gh[L & 1], stream));
+        c->gh_cur = L & 1;
     }
     // ---- layers, last first
     for (int l = l_hi - 1; l >= l_lo; --l) {
@@ -428,7 +430,10 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
         Bump own(side[l]);
         Bump& sd = per_layer_join ? ar : own;       // where the side stream's buffers of this layer live
         a.defer_join = per_layer_join ? 0 : 1;
-        const float* grad_in = gh[(l + 1) & 1];
+        // a residual layer accumulates dL/dh_in on top of the incoming gradient IN PLACE (dh_in = dh_out + ...: the separate
+        // add pass over [N, F] is gone, composite.hip: i3d_pna_layer_bwd); others ping-pong between the two buffers
+        const int cur = c->gh_cur, nxt = a.residual ? cur : cur ^ 1;
+        const float* grad_in = gh[cur];
         a.grad_out = grad_in;
         I3dGroupedFcArgs& g = a.post;
         const I3dFcParams& pp = m.post[l];
@@ -437,7 +442,7 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
         g.grad_y = grad_in;
         g.grad_pre = sd.take((long)N * F);
         g.grad_WD = sd.take((long)b.n_groups * F * g.agg_width);
-        g.grad_h = gh[l & 1];
+        g.grad_h = gh[nxt];
         g.grad_agg = ar.take((long)N * g.agg_width);
         g.tail.bias_partial = defer_bias() ? sd.take(i3d_bn_bias_partial_floats(F)) : nullptr;
         const int f_msg = a.n_pre_extra > 0 ? a.pre[a.n_pre_extra - 1].f_out : a.edge.f_out;
@@ -467,6 +472,7 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
         e.grad_q = grad_table;
         e.grad_q_accumulate = (l == L - 1) ? 0 : 1;        // the bond table feeds every layer: its gradient is their sum
         TRY(i3d_pna_layer_bwd(&a, stream));
+        c->gh_cur = nxt;
     }
     if (!per_layer_join) TRY(i3d_wgrad_stream_join(stream));
     if (part == 1) return I3D_OK;
@@ -478,7 +484,7 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
         const int va = (o + 31) / 32 * 32;
         float* hot = ar.take((long)N * va);
         TRY(i3d_multihot(b.atom_feat, nullptr, N, m.n_atom_tables, offs, va, hot, stream));
-        TRY(wgrad(o, F, N, hot, va, gh[0], F, m.grad_atom_tables, F, gemm_workspace, gemm_workspace_bytes, stream));
+        TRY(wgrad(o, F, N, hot, va, gh[c->gh_cur], F, m.grad_atom_tables, F, gemm_workspace, gemm_workspace_bytes, stream));
         o = 0;
         for (int k = 0; k < m.n_bond_tables; ++k) { offs[k] = o; o += m.bond_dims[k]; }
         const int vb = (o + 31) / 32 * 32;
