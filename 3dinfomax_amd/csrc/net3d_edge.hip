@@ -87,6 +87,7 @@ struct Wts {                         // LDS copy of the parameters of the stage
     float w_in[H * DIN];
     float b_in[H];
     float w_e[H * H];
+    float w_et[H * H];               // transposed: the backward product reads contiguous rows too
     float c[H];
     float aff_in[3 * H];
     float aff_msg[3 * H];
@@ -101,7 +102,11 @@ struct Wts {                         // LDS copy of the parameters of the stage
 template <int H, int DIN>
 __device__ __forceinline__ void load_weights(Wts<H, DIN>& w, const EdgeK& p, int tid) {
     for (int i = tid; i < H * DIN; i += TB) w.w_in[i] = p.W_in[(i / DIN) * p.ld_w_in + (i % DIN)];
-    for (int i = tid; i < H * H; i += TB) w.w_e[i] = p.W_msg[(i / H) * p.ld_w_msg + 2 * H + (i % H)];
+    for (int i = tid; i < H * H; i += TB) {
+        const float v = p.W_msg[(i / H) * p.ld_w_msg + 2 * H + (i % H)];
+        w.w_e[i] = v;
+        w.w_et[(i % H) * H + (i / H)] = v;
+    }
     for (int i = tid; i < 3 * H; i += TB) {
         w.aff_in[i] = p.aff_in[i];
         w.aff_msg[i] = p.aff_msg[i];
@@ -124,19 +129,25 @@ __device__ __forceinline__ void load_weights(Wts<H, DIN>& w, const EdgeK& p, int
     if (tid == 0) w.b_g = p.b_gate[0];
 }
 
-// reference commons/utils.py:103-110 (same expression order as edge.hip fourier_encode_kernel)
+// reference commons/utils.py:103-110: [sin(d / 2^k)]_k | [cos(d / 2^k)]_k | d.  ONE accurate sincos of the smallest angle
+// d / 2^(n-1), the others by angle doubling (sin 2t = 2 sin t cos t, cos 2t = 1 - 2 sin^2 t): each doubling at most doubles
+// the absolute error, 2^(n-1) ulp = 5e-7 at n = 4 - the four passes that need the features recompute them from the
+// distance, and eight range-reduced sinf / cosf per edge and pass were a third of their instruction count
 template <int NENC>
 __device__ __forceinline__ void fourier(float x, float* f) {
     if constexpr (NENC == 0) {
         f[0] = x;
     } else {
-        float scale = 1.f;
+        float sn, cs;
+        sincosf(x / (float)(1 << (NENC - 1)), &sn, &cs);
+        f[NENC - 1] = sn;
+        f[2 * NENC - 1] = cs;
 #pragma unroll
-        for (int k = 0; k < NENC; ++k) {
-            const float v = x / scale;
-            f[k] = sinf(v);
-            f[NENC + k] = cosf(v);
-            scale *= 2.f;
+        for (int k = NENC - 2; k >= 0; --k) {
+            const float s2 = 2.f * sn * cs, c2 = fmaf(-2.f * sn, sn, 1.f);
+            sn = s2; cs = c2;
+            f[k] = sn;
+            f[NENC + k] = cs;
         }
         f[2 * NENC] = x;
     }
@@ -515,7 +526,7 @@ __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_post_kernel(EdgeK p) {
             N3_NO_HOIST();
             float ge = 0.f;
 #pragma unroll
-            for (int o = 0; o < H; ++o) ge = fmaf(w.w_e[o * H + k], glin[o], ge);
+            for (int o = 0; o < H; ++o) ge = fmaf(w.w_et[k * H + o], glin[o], ge);
             gya[k] = ge * act_grad(ya[k], ACT);
             const float xh = (xa[k] - w.aff_in[k]) * w.istd_in[k];
             s[k] += gya[k];
