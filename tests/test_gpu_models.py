@@ -639,7 +639,7 @@ def test_fused_net3d_edge_stage_matches_block_path(amd, monkeypatch, cfg):
     arithmetic in a different summation order: outputs and embeddings within 1e-5 of the tensor's scale (the acceptance
     bound of the path is 1e-4); gradients (summed over two steps) within 3e-4 of the scale + 5e-5 - several are small
     differences of large sums (a bias in front of a BatchNorm), and against a float64 torch model both paths sit at the
-    same distance (tools/probes/dbg_n3.py)."""
+    same distance (tools/probes/net3d_edge_vs_fp64.py)."""
     native = importlib.import_module('3dinfomax_amd.net3d_native')
     kw = {'yml': dict(NET3D_YML), 'sum': dict(NET3D_YML, reduce_func='sum'),
           'raw_distance': dict(NET3D_YML, fourier_encodings=0), 'large': dict(NET3D_YML)}[cfg]

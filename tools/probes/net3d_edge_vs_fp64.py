@@ -1,3 +1,7 @@
+"""Parameter gradients of the 3D network: fused edge stage (csrc/net3d_edge.hip) and per-block path, each against a float64
+torch model of the same network (reference models/net3d.py structure of the pre-training configs).  RED=sum|mean.
+    python tools/probes/net3d_edge_vs_fp64.py
+"""
 import importlib, sys, math, torch
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 amd = importlib.import_module('3dinfomax_amd')
