@@ -908,14 +908,15 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     }
 
     // tile configuration, measured on MI355X at the step's shapes (tools/gemm_bench.py, profiles/r01_gemm_bench_*.log):
-    // the batch is small for a 256-CU chip, so many 64x64 tiles beat fewer big ones until there are thousands of tiles.
+    // many 64x64 tiles beat fewer big ones - also with thousands of tiles (batch 4096, `gemm_bench.py --nodes 67434 --edges
+    // 133440 --all-cfgs --wide-sweep`, profiles/r02_gemm_sweep_B4096.log: the 128x128 tiling the first version switched
+    // to at >= 4096 tiles is 20-30 % slower than 64x64 on every shape of the step).
     int cfg;
     const long tiles64 = (long)cdiv(M, 64) * cdiv(N, 64);
     const bool have_ws = ex.workspace != nullptr && (((uintptr_t)ex.workspace & 15) == 0) && ex.m_rows == nullptr;
     if (trans_a && M <= 32 && N <= 32) cfg = 8;
     else if (trans_a && have_ws && tiles64 <= 16) cfg = 8;   // small weight gradients: 32x32 tiles, slices through the scratch
     else if (N <= 32) cfg = 1;
-    else if (tiles64 >= 4096) cfg = 0;
     else if (trans_a && tiles64 < 512) cfg = 3;   // weight gradients: few output tiles, long K
     else cfg = 2;
     if (ex.tile_group != nullptr) cfg = 2;        // the group padding of m_rows is 64 rows
@@ -938,7 +939,10 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     // slab_reduce_kernel (>= 1024 of K per slice, up to ~800 workgroups); without it they are fp32 atomics on top of a
     // zero-fill (not free: up to ~512 workgroups, >= 512 of K per slice).
     if (trans_a && have_ws && tiles < 800 && K >= 2048) {
-        splits = (800 + tiles / 2) / tiles;
+        // ~800 workgroups at batch 512 (K = 8-17 k rows); with K in the 100 k (batch 4096) more, shorter slices win:
+        // [200,200] K = 133 k: 16 slices 192 us, 64 slices 166 us
+        const int target = K >= 65536 ? 3072 : (K >= 32768 ? 1600 : 800);
+        splits = (target + tiles / 2) / tiles;
         int max_splits = K / 1024;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;

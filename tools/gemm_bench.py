@@ -107,9 +107,17 @@ def run_rowseg(lib, cfg, seg_rows, reps=20, scratch=True):
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--all-cfgs', action='store_true')
+    ap.add_argument('--nodes', type=int, default=N_NODES, help='atoms of the batch (batch 4096: 67434, QMugs shape: 24300)')
+    ap.add_argument('--edges', type=int, default=N_EDGES, help='directed bonds of the batch (batch 4096: 133440, QMugs: 49000)')
+    ap.add_argument('--wide-sweep', action='store_true', help='with --all-cfgs: every tile configuration, more split counts')
+    ap.add_argument('--no-rowseg', action='store_true')
     a = ap.parse_args()
     lib = L.load()
-    for name, ta, tb, M, N, K in SHAPES:
+    shapes = [(n, ta, tb, {N_NODES: a.nodes, N_EDGES: a.edges}.get(M, M), N, {N_NODES: a.nodes, N_EDGES: a.edges}.get(K, K))
+              for n, ta, tb, M, N, K in SHAPES]
+    if a.nodes != N_NODES:
+        shapes = [sh for sh in shapes if 'net3d' not in sh[0] and 'head' not in sh[0] and 'sim' not in sh[0] and '12F' not in sh[0]]
+    for name, ta, tb, M, N, K in shapes:
         us, tf, err = run(lib, ta, tb, M, N, K, -1, 0)
         print(f'{name} M={M:6d} N={N:5d} K={K:6d}  auto: {us:8.1f} us {tf:7.1f} TF  err {err:.1e}', flush=True)
         if ta:
@@ -117,10 +125,13 @@ if __name__ == '__main__':
             print(f'{name} M={M:6d} N={N:5d} K={K:6d}  auto, fp32 atomics instead of scratch: {us:8.1f} us {tf:7.1f} TF', flush=True)
         if a.all_cfgs:
             wgrad = bool(ta)
-            for cfg in ((3, 2, 8, 1) if wgrad else (2, 9, 11)):
+            cfgs = ((3, 2, 8, 1) if wgrad else (2, 9, 11)) if not a.wide_sweep else ((3, 2, 8, 0, 5, 4, 7) if wgrad else (0, 2, 4, 5, 7, 9, 10, 11, 12))
+            for cfg in cfgs:
                 for splits in ((8, 16, 32, 64, 128, 256) if wgrad else (1,)):
                     us, tf, err = run(lib, ta, tb, M, N, K, cfg, splits)
                     print(f'      cfg {cfg:2d} splits {splits:2d}: {us:8.1f} us {tf:7.1f} TF  err {err:.1e}', flush=True)
+    if a.no_rowseg:
+        sys.exit(0)
     for cfg, seg in ((-1, 0), (3, 256), (3, 512), (3, 1024), (3, 2048), (2, 512), (2, 1024), (4, 512), (4, 1024), (4, 2048)):
         us, tf, err = run_rowseg(lib, cfg, seg)
         us2, _, _ = run_rowseg(lib, cfg, seg, scratch=False)
