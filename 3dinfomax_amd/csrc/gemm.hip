@@ -732,6 +732,18 @@ static void launch_slab_reduce(const SlabReduce& a, hipStream_t s) {
 
 // layout: 0 forward (A and B k-contiguous), 1 data gradient (A k-contiguous, B idx-contiguous),
 //         2 weight gradient (both idx-contiguous), 3 (A idx-contiguous, B k-contiguous; not on the training path)
+// 64x32 tiles of two waves instead of 64x64: when N pads much better in 32-wide column tiles (200 -> 224 vs 256) and the
+// launch is small enough for the larger number of smaller workgroups to matter
+static bool narrow_pays(int N, long tiles64) {
+    return tiles64 < 1100 && (long)cdiv(N, 64) * 64 * 10 > (long)cdiv(N, 32) * 32 * 11;
+}
+// the fused (BatchNorm prologue / statistics epilogue) forward GEMM at K < 400 keeps 64x64 tiles: measured 2.464 ms per
+// step with the narrow tiling against 2.426 ms without (tools/ab.sh, 4 interleaved runs); I3D_FUSED_NARROW=1 selects it
+static bool fuse_narrow_short_k() {
+    static const bool on = [] { const char* e = getenv("I3D_FUSED_NARROW"); return e != nullptr && e[0] == '1'; }();
+    return on;
+}
+
 // process-level: 0 = fp32 MFMA (exact fp32 products), 1 = bf16 MFMA on bf16-rounded operands (i3d_set_matmul_precision)
 static int g_matmul_bf16 = 0;
 
@@ -924,7 +936,10 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     // N = 200 fills 6.25 of the 8 32-wide wave tiles of four 64-wide column tiles (a quarter of the waves do nothing
     // useful); in 64x32 tiles of two waves it is 7 column tiles, 12 % padding: -18..-21 % on the long-K forward shapes
     // (post4 [N,4F] x [F,4F]^T: 50 -> 41 us), slower when K is short (r01_gemm_bench_v6)
-    if (cfg == 9 && !trans_a && K >= 400 && (long)cdiv(N, 64) * 64 * 10 > (long)cdiv(N, 32) * 32 * 11) cfg = 11;
+    // Round 2 sweeps (profiles/r02_gemm_sweep_*.log): it also wins at K = 200 while the launch has few tiles (batch 512:
+    // P 17.5 -> 15.2 us, [E,F]x[F,F] 25.9 -> 24.0 us), and loses at every K once there are > ~1000 64x64 tiles (QMugs
+    // shape, post4: 96 vs 87 us): the tile count decides, not K.
+    if (cfg == 9 && !trans_a && narrow_pays(N, tiles64)) cfg = 11;
     if (force_cfg >= 0) {
         I3D_CHECK_ARG(force_cfg < N_CFG, "tile_cfg out of range");
         I3D_CHECK_ARG(ex.tile_group == nullptr || CFG_BM[force_cfg] == 64, "grouped GEMM needs 64-row tiles");
@@ -1236,7 +1251,7 @@ extern "C" int i3d_gemm_f32_fused(int M, int N, int K, const float* A, int lda, 
     const int fuse = (a_aff != nullptr ? 1 : 0) | (stats != nullptr ? 2 : 0);
     hipStream_t s = (hipStream_t)stream;
     // tile choice as in gemm_impl for the forward layout: 64x64 (idx-major image), 64x32 when K is long and N pads badly
-    const bool narrow = K >= 400 && (long)cdiv(N, 64) * 64 * 10 > (long)cdiv(N, 32) * 32 * 11;
+    const bool narrow = narrow_pays(N, (long)cdiv(M, 64) * cdiv(N, 64)) && (K >= 400 || fuse_narrow_short_k());
     if (narrow) launch_fused<Cfg11>(g, fuse, s);
     else launch_fused<Cfg9>(g, fuse, s);
     I3D_CHECK_LAUNCH();
