@@ -59,7 +59,7 @@ class PnaLayerArgs(ctypes.Structure):
                 ('n_scalers', c_int), ('force_scalers', c_int), ('aggregators', c_int * 8), ('scalers', c_int * 4),
                 ('avg_d_log', c_float), ('msg', _P), ('grad_msg', _P), ('post', GroupedFcArgs), ('n_post_extra', c_int),
                 ('postx', FcArgs * 3), ('residual', c_int), ('grad_out', _P), ('agg_event_start', _P), ('agg_event_stop', _P),
-                ('fused_bn', c_int), ('defer_join', c_int), ('stats_ws', _P), ('aff', _P * 4)]
+                ('fused_bn', c_int), ('defer_join', c_int), ('stats_ws', _P), ('aff', _P * 4), ('weights_ready', c_int)]
 
 
 class Net3dEdgeArgs(ctypes.Structure):
@@ -113,6 +113,8 @@ _SIGNATURES = {
     'i3d_net3d_edge_bwd_floats': (c_long, [c_int, c_int, c_int]),
     'i3d_net3d_edge_fwd': (c_int, [POINTER(Net3dEdgeArgs), _P]),
     'i3d_net3d_edge_bwd': (c_int, [POINTER(Net3dEdgeArgs), _P]),
+    'i3d_wgrad_stream_fork': (c_int, [_P, POINTER(_P)]),
+    'i3d_pna_layer_weights_fwd': (c_int, [POINTER(PnaLayerArgs), _P]),
     'i3d_pna_layer_fwd': (c_int, [POINTER(PnaLayerArgs), _P]),
     'i3d_pna_layer_bwd': (c_int, [POINTER(PnaLayerArgs), _P]),
     'i3d_fc_bn_fwd': (c_int, [POINTER(FcArgs), _P]),

@@ -289,7 +289,7 @@ static int pna_layer_fwd_fused(const I3dPnaLayerArgs* a, void* stream) {
     const long wdelta = (long)Fh - (long)Fo * e->ldw, wview = (long)(Fo - 1) * e->ldw + 2 * Fh;
     TRY(i3d_gemm_f32_blocks(0, 1, N, 2 * Fo, Fh, e->h, Fh, e->W, e->ldw, Fo, wdelta, wview, e->P, 2 * Fo, 0, 0, 0, nullptr, 0,
                             stream));
-    if (e->q != nullptr)
+    if (e->q != nullptr && !a->weights_ready)
         TRY(i3d_gemm_f32(0, 1, e->q_rows > 0 ? e->q_rows : E, Fo, e->f_q, e->q, e->f_q, e->W + 2 * Fh, e->ldw, e->Q, Fo,
                          nullptr, 0, stream));
     TRY(i3d_edge_combine_act_stats(e->P, 2 * Fo, e->q ? e->Q : nullptr, e->q_rows > 0 ? e->q_code : nullptr, e->bias, e->src_s,
@@ -320,12 +320,30 @@ static int pna_layer_fwd_fused(const I3dPnaLayerArgs* a, void* stream) {
     I3D_CHECK_ARG(p->pre_keep == nullptr && simple_act(p->tail.act), "fused BatchNorm: unsupported block shape");
     const int A = p->agg_width, Fp = p->f_out;
     TRY(i3d_gemm_f32(0, 1, N, Fp, p->f_h, p->h, p->f_h, p->W, p->ldw, p->xact, Fp, p->bias, 0, stream));
-    TRY(i3d_pna_combine_weights_fwd(p->W, p->ldw, p->f_h, Fp, A, p->n_groups, p->n_scalers, p->coef, p->WD, stream));
+    if (!a->weights_ready)
+        TRY(i3d_pna_combine_weights_fwd(p->W, p->ldw, p->f_h, Fp, A, p->n_groups, p->n_scalers, p->coef, p->WD, stream));
     TRY(i3d_gemm_f32_fused(p->m_padded, Fp, A, p->agg, A, N, p->WD, A, p->xact, Fp, nullptr, 1, nullptr, p->tail.act,
                            a->stats_ws, p->deg_rows, p->deg_tile_group, (long)Fp * A, stream));
     TRY(finalize_stats(&p->tail, a->stats_ws, p->m_padded / 64, Fp, nullptr, stream));
     return i3d_bn_apply_fwd(p->xact, N, Fp, p->tail.mean, p->tail.invstd, p->tail.gamma, p->tail.beta, p->tail.post_act,
                             p->residual, p->y, stream);
+}
+
+extern "C" int i3d_pna_layer_weights_fwd(const I3dPnaLayerArgs* a, void* stream) {
+    I3D_CHECK_ARG(a != nullptr && a->fused_bn, "fused_bn layers only");
+    const I3dEdgeFcArgs* e = &a->edge;
+    const I3dGroupedFcArgs* p = &a->post;
+    if (e->q != nullptr)
+        TRY(i3d_gemm_f32(0, 1, e->q_rows > 0 ? e->q_rows : e->num_edges, e->f_out, e->f_q, e->q, e->f_q, e->W + 2 * e->f_h, e->ldw,
+                         e->Q, e->f_out, nullptr, 0, stream));
+    return i3d_pna_combine_weights_fwd(p->W, p->ldw, p->f_h, p->f_out, p->agg_width, p->n_groups, p->n_scalers, p->coef, p->WD,
+                                       stream);
+}
+
+extern "C" int i3d_wgrad_stream_fork(void* stream, void** side) {
+    I3D_CHECK_ARG(side != nullptr, "null");
+    *side = fork_wgrad(aux_for((hipStream_t)stream), stream);
+    return I3D_OK;
 }
 
 extern "C" long i3d_pna_layer_stats_floats(int num_nodes, int num_edges, int m_padded, int f) {

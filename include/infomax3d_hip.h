@@ -476,6 +476,8 @@ typedef struct { /* one PNA layer, reference models/pna.py:199-216: pretrans edg
                      * buffer that stream reads or writes alive and calls i3d_wgrad_stream_join before it consumes them */
     float* stats_ws;                   /* scratch, i3d_pna_layer_stats_floats(...) floats */
     float* aff[I3D_MAX_EXTRA_FC + 1];  /* [3 f_out] mean | gamma invstd | beta of the edge block and of pre[i] (saved) */
+    int weights_ready; /* forward (fused_bn): edge.Q and post.WD - products of parameters and the bond table only - are already
+                        * there (i3d_pna_layer_weights_fwd, e.g. on the side stream while the layers before this one run) */
 } I3dPnaLayerArgs;
 
 /* floats of I3dPnaLayerArgs.stats_ws for a layer with these dimensions (f = widest block output) */
@@ -541,6 +543,10 @@ int i3d_event_elapsed_ms(void* start, void* stop, float* ms);   /* both events m
 
 /* makes `stream` wait for everything its weight-gradient side stream holds (I3dPnaLayerArgs.defer_join) */
 int i3d_wgrad_stream_join(void* stream);
+/* the side stream of `stream`, ordered behind everything `stream` holds now (*side == stream when there is none) */
+int i3d_wgrad_stream_fork(void* stream, void** side);
+/* the parameter-only products of a fused_bn layer's forward: edge.Q = q W_q^T and post.WD = sum_s coef W_s */
+int i3d_pna_layer_weights_fwd(const I3dPnaLayerArgs* args, void* stream);
 int i3d_pna_layer_fwd(const I3dPnaLayerArgs* args, void* stream);
 int i3d_pna_layer_bwd(const I3dPnaLayerArgs* args, void* stream);
 int i3d_fc_bn_fwd(const I3dFcArgs* args, void* stream);
