@@ -21,7 +21,7 @@ def per_kernel(db, counter, pattern):
     for name, grid, v in rows:
         if not re.search(pattern, name):
             continue
-        short = re.sub(r'\(.*', '', name).replace('void ', '').replace('i3d::', '')
+        short = re.sub(r'\(.*', '', name.replace('(anonymous namespace)::', '')).replace('void ', '').replace('i3d::', '')
         short = re.sub(r'Shape<([^>]*)>', lambda m: 'Shape<' + m.group(1).replace(' ', '') + '>', short)
         out.setdefault((short[:70], grid), []).append(v)
     return out
