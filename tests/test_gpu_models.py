@@ -4,6 +4,7 @@ Bar: BASELINE.json:north_star - node embeddings and loss within 1e-4 relative fp
 import copy
 import importlib
 
+import math
 import numpy as np
 import pytest
 import torch
@@ -671,3 +672,36 @@ def test_missing_library_fails_loudly(amd, monkeypatch):
     monkeypatch.setattr(L, 'LIB_PATH', '/nonexistent/lib3dinfomax_hip.so')
     with pytest.raises(L.HipLibraryError):
         L.load()
+
+
+def test_full_size_batch_properties(amd):
+    """configs[1] at its full size (512 molecules, hidden 200, depth 4 + Net3D + NT-Xent), through properties that do not
+    need the oracle at that size: (1) reordering the molecules of the batch reorders the rows of both embeddings and
+    leaves the loss unchanged (BatchNorm statistics and NT-Xent are sums over the batch: only the summation order moves,
+    1e-5); (2) two copies of one molecule get bit-identical rows (every kernel computes a row / node / edge from its own
+    inputs and batch-wide statistics only, whatever tile it lands in); (3) the parameter gradients of the reordered batch
+    agree (relative L2 2e-3: arg-max near-ties of the max / min aggregators may move single rows)."""
+    mols = synth.make_dataset(511, seed=31)
+    mols = mols + [mols[7]]                                   # molecule 7 twice: rows 7 and 511
+    perm = np.random.default_rng(5).permutation(512)
+
+    def step(order):
+        torch.manual_seed(9)
+        pna = amd.PNA(avg_d=1.0, device='cuda:0', **dict(PNA_YML, propagation_depth=4)).cuda().train()
+        net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_YML).cuda().train()
+        g2, g3 = make_batch(amd, [mols[i] for i in order])
+        z2, z3 = pna(g2), net(g3)
+        loss = amd.NTXent(tau=0.1)(z2, z3)
+        loss.backward()
+        grads = torch.cat([p.grad.flatten() for p in list(pna.parameters()) + list(net.parameters())])
+        return z2.detach(), z3.detach(), loss.item(), grads
+
+    z2, z3, loss, grads = step(range(512))
+    assert z2.shape == (512, 256) and z3.shape == (512, 256) and math.isfinite(loss)
+    assert torch.equal(z2[7], z2[511]) and torch.equal(z3[7], z3[511])
+    z2p, z3p, lossp, gradsp = step(perm)
+    idx = torch.from_numpy(perm).cuda()
+    for a, b in ((z2[idx], z2p), (z3[idx], z3p)):
+        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+    assert abs(loss - lossp) <= 1e-5 * abs(loss)
+    assert ((grads - gradsp).norm() / grads.norm()).item() <= 2e-3
