@@ -632,7 +632,7 @@ def _net3d_two_steps(amd, kw, mols):
     return outs
 
 
-@pytest.mark.parametrize('cfg', ['yml', 'sum', 'raw_distance', 'large'])
+@pytest.mark.parametrize('cfg', ['yml', 'sum', 'raw_distance', 'large', 'hidden16'])
 def test_fused_net3d_edge_stage_matches_block_path(amd, monkeypatch, cfg):
     """The edge stage of the 3D network in one lane per edge (csrc/net3d_edge.hip: Fourier features, edge-input block,
     message block, gate, reduce - and their backward with the weight gradients on the MFMA unit) against the per-block
@@ -643,7 +643,8 @@ def test_fused_net3d_edge_stage_matches_block_path(amd, monkeypatch, cfg):
     same distance (tools/probes/net3d_edge_vs_fp64.py)."""
     native = importlib.import_module('3dinfomax_amd.net3d_native')
     kw = {'yml': dict(NET3D_YML), 'sum': dict(NET3D_YML, reduce_func='sum'),
-          'raw_distance': dict(NET3D_YML, fourier_encodings=0), 'large': dict(NET3D_YML)}[cfg]
+          'raw_distance': dict(NET3D_YML, fourier_encodings=0), 'large': dict(NET3D_YML),
+          'hidden16': dict(NET3D_YML, hidden_dim=16, hidden_edge_dim=16, fourier_encodings=2)}[cfg]
     mols = synth.make_dataset(700 if cfg == 'large' else 40, seed=23)      # 'large': several edge chunks per block, ragged tail
     res = {}
     for fused in (True, False):
