@@ -65,6 +65,9 @@ struct PnaCtx {
     float coef[128];
     int n_scalers_cfg = 0;
     long saved_floats = 0;
+    float* hot_atoms = nullptr;     // [N, va] / [n_comb, vb] multi-hot matrices of the encoders' weight gradients (functions of
+    float* hot_bonds = nullptr;     // the batch's categorical features only: built on the side stream during the forward pass)
+    bool hot_ready = false;
     int gh_cur = 0;                 // which of the two dL/dh buffers holds the gradient after the layers done so far (backward)
 };
 
@@ -73,6 +76,19 @@ struct PnaCtx {
 // runs of 300 steps) 2.816 ms deferred against 2.787 ms in-launch - it takes ~10 us per BatchNorm off the main stream's
 // chain but adds three small launches per layer to the side stream, whose join is what the next layer waits for: at batch
 // 512 the backward pass is bound by the TOTAL work of the two streams, not by the chain.
+// the [rows, v] multi-hot matrices of the atom / bond-combination features (columns: the concatenated vocabularies, padded
+// to 32): embedding-table gradients are their transposes times dL/d(embedding)
+int encoder_multihot(const PnaCtx& c, float* hot_atoms, float* hot_bonds, void* stream) {
+    const I3dPnaModel& m = c.m;
+    const I3dPnaBatch& b = c.b;
+    int offs[16], o = 0;
+    for (int k = 0; k < m.n_atom_tables; ++k) { offs[k] = o; o += m.atom_dims[k]; }
+    TRY(i3d_multihot(b.atom_feat, nullptr, b.num_nodes, m.n_atom_tables, offs, (o + 31) / 32 * 32, hot_atoms, stream));
+    o = 0;
+    for (int k = 0; k < m.n_bond_tables; ++k) { offs[k] = o; o += m.bond_dims[k]; }
+    return i3d_multihot(b.comb, nullptr, b.n_comb, m.n_bond_tables, offs, (o + 31) / 32 * 32, hot_bonds, stream);
+}
+
 bool hoist_weights() {
     static const bool on = [] { const char* e = getenv("I3D_HOIST_WEIGHTS"); return e == nullptr || e[0] != '0'; }();
     return on;
@@ -272,6 +288,13 @@ long plan_forward(PnaCtx& c, float* saved, float* node_emb, float* out) {
         x = y;
     }
     c.out = out;
+    {
+        long oa = 0, ob = 0;
+        for (int k = 0; k < m.n_atom_tables; ++k) oa += m.atom_dims[k];
+        for (int k = 0; k < m.n_bond_tables; ++k) ob += m.bond_dims[k];
+        c.hot_atoms = ar.take((long)N * ((oa + 31) / 32 * 32));
+        c.hot_bonds = ar.take((long)b.n_comb * ((ob + 31) / 32 * 32));
+    }
     c.saved_floats = ar.used;
     return ar.used;
 }
@@ -338,6 +361,8 @@ extern "C" int i3d_pna_model_fwd(const I3dPnaModel* m, const I3dPnaBatch* b, flo
         TRY(i3d_wgrad_stream_fork(stream, &side));
         if (side != stream) {
             for (int l = 1; l < L; ++l) TRY(i3d_pna_layer_weights_fwd(&c->layers[l], side));
+            TRY(encoder_multihot(*c, c->hot_atoms, c->hot_bonds, side));      // needed by the backward pass only
+            c->hot_ready = true;
             hoisted = true;
         }
     }
@@ -497,18 +522,19 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
     // ---- encoders: embedding-table gradients as multi-hot^T dY (deterministic, csrc/edge.hip: multihot_kernel)
     {
         Bump ar(rest);
-        int offs[16], o = 0;
-        for (int k = 0; k < m.n_atom_tables; ++k) { offs[k] = o; o += m.atom_dims[k]; }
-        const int va = (o + 31) / 32 * 32;
-        float* hot = ar.take((long)N * va);
-        TRY(i3d_multihot(b.atom_feat, nullptr, N, m.n_atom_tables, offs, va, hot, stream));
-        TRY(wgrad(o, F, N, hot, va, gh[c->gh_cur], F, m.grad_atom_tables, F, gemm_workspace, gemm_workspace_bytes, stream));
-        o = 0;
-        for (int k = 0; k < m.n_bond_tables; ++k) { offs[k] = o; o += m.bond_dims[k]; }
-        const int vb = (o + 31) / 32 * 32;
-        float* hotb = ar.take((long)b.n_comb * vb);
-        TRY(i3d_multihot(b.comb, nullptr, b.n_comb, m.n_bond_tables, offs, vb, hotb, stream));
-        TRY(wgrad(o, F, b.n_comb, hotb, vb, grad_table, F, m.grad_bond_tables, F, gemm_workspace, gemm_workspace_bytes, stream));
+        int oa = 0, ob = 0;
+        for (int k = 0; k < m.n_atom_tables; ++k) oa += m.atom_dims[k];
+        for (int k = 0; k < m.n_bond_tables; ++k) ob += m.bond_dims[k];
+        const int va = (oa + 31) / 32 * 32, vb = (ob + 31) / 32 * 32;
+        float* hot = c->hot_atoms;
+        float* hotb = c->hot_bonds;
+        if (!c->hot_ready) {            // not built during the forward pass (no side stream): here, into scratch
+            hot = ar.take((long)N * va);
+            hotb = ar.take((long)b.n_comb * vb);
+            TRY(encoder_multihot(*c, hot, hotb, stream));
+        }
+        TRY(wgrad(oa, F, N, hot, va, gh[c->gh_cur], F, m.grad_atom_tables, F, gemm_workspace, gemm_workspace_bytes, stream));
+        TRY(wgrad(ob, F, b.n_comb, hotb, vb, grad_table, F, m.grad_bond_tables, F, gemm_workspace, gemm_workspace_bytes, stream));
     }
     return I3D_OK;
 }
