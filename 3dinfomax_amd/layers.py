@@ -630,6 +630,24 @@ class EmbeddingSumFn(torch.autograd.Function):
         return (None, None, *grads)
 
 
+class EmbeddingSumPadFn(torch.autograd.Function):
+    """the `padding=True` form of the encoders (reference commons/mol_encoder.py:22-23, 36-37): tables with one extra row 0,
+    looked up at idx + 1 (-1 -> row 0); row 0 takes part in the sum but, being `padding_idx`, receives no gradient"""
+
+    @staticmethod
+    def forward(ctx, idx, row_perm, *tables):
+        ctx.idx, ctx.row_perm = idx + 1, row_perm
+        ctx.dims = [t.shape[0] for t in tables]
+        return ops.embedding_sum_fwd(ctx.idx, [t.contiguous() for t in tables], row_perm)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grads = ops.embedding_sum_bwd(ctx.idx, grad_out.contiguous(), ctx.dims, ctx.row_perm)
+        for g in grads:
+            g[0].zero_()
+        return (None, None, *grads)
+
+
 class AggregateFn(torch.autograd.Function):
     """K4: segmented mean/max/min/std x degree scalers (reference models/pna.py:206, 221-235)."""
 

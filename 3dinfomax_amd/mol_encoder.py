@@ -6,7 +6,7 @@ from math import sqrt
 import torch
 
 from . import tape
-from .layers import EmbeddingSumFn
+from .layers import EmbeddingSumFn, EmbeddingSumPadFn
 from .synth import ATOM_FEATURE_DIMS, BOND_FEATURE_DIMS
 
 # ogb.utils.features.get_atom_feature_dims()/get_bond_feature_dims() (ogb >= 1.3); used from ogb when installed
@@ -23,12 +23,11 @@ class _Encoder(torch.nn.Module):
     _list_name = None
 
     def _build(self, dims, emb_dim, padding):
-        if padding:
-            raise NotImplementedError('padding=True is not on the accelerated path')
         self.padding = padding
         lst = torch.nn.ModuleList()
         for dim in dims:
-            emb = torch.nn.Embedding(dim, emb_dim)
+            # reference :22-27: one extra row with padding_idx=0, then xavier over the WHOLE table (row 0 included)
+            emb = torch.nn.Embedding(dim + 1, emb_dim, padding_idx=0) if padding else torch.nn.Embedding(dim, emb_dim)
             torch.nn.init.xavier_uniform_(emb.weight.data)
             lst.append(emb)
         return lst
@@ -41,7 +40,7 @@ class _Encoder(torch.nn.Module):
         return [emb.weight for emb in getattr(self, self._list_name)]
 
     def forward(self, x, perm=None):
-        return tape.apply(EmbeddingSumFn, x.contiguous(), perm, *self._tables())
+        return tape.apply(EmbeddingSumPadFn if self.padding else EmbeddingSumFn, x.contiguous(), perm, *self._tables())
 
 
 class AtomEncoder(_Encoder):

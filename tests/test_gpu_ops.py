@@ -268,6 +268,29 @@ def test_embedding_sum_fwd_bwd_with_row_perm(rows, multihot, monkeypatch):
         assert all(torch.equal(a, b) for a, b in zip(grads, again))
 
 
+def test_padding_encoders_match_the_reference_module():
+    """AtomEncoder / BondEncoder(padding=True), reference commons/mol_encoder.py:12-42, 47-73: one extra row per table with
+    padding_idx 0, xavier over the whole table, features looked up at x + 1 (-1 -> row 0), no gradient for row 0"""
+    amd = importlib.import_module('3dinfomax_amd')
+    for cls, list_name in ((amd.AtomEncoder, 'atom_embedding_list'), (amd.BondEncoder, 'bond_embedding_list')):
+        torch.manual_seed(4)
+        enc = cls(emb_dim=40, padding=True).to(DEV)
+        tabs = getattr(enc, list_name)
+        dims = [e.num_embeddings - 1 for e in tabs]
+        assert all(e.padding_idx == 0 for e in tabs) and enc.dims == [d + 1 for d in dims]
+        gen = torch.Generator().manual_seed(8)
+        x = torch.stack([torch.randint(-1, d, (700,), generator=gen) for d in dims], 1)      # -1: missing feature
+        ref_tabs = [e.weight.detach().cpu().clone().requires_grad_(True) for e in tabs]
+        ref = sum(F.embedding(x[:, k] + 1, ref_tabs[k], padding_idx=0) for k in range(len(dims)))
+        cot = rnd(700, 40, seed=41)
+        (ref * cot).sum().backward()
+        out = enc(g(x))
+        (out * g(cot)).sum().backward()
+        assert rel_err(out.detach().cpu(), ref.detach()) < 1e-6
+        for e, t in zip(tabs, ref_tabs):
+            assert torch.all(e.weight.grad[0] == 0) and rel_err(e.weight.grad.cpu(), t.grad) < 1e-5
+
+
 # ---- BatchNorm -------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('rows,feat', [(5000, 200), (300, 20), (17, 7), (70000, 20)])
 @pytest.mark.parametrize('act,post', [('relu', None), (None, None), ('silu', 'silu')])
