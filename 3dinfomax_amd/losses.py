@@ -43,9 +43,21 @@ class NTXentFn(torch.autograd.Function):
     """loss_share = sum_i -log(pos_i / (rowsum_i - pos_i)) / global_batch  over the local rows of z1."""
 
     @staticmethod
-    def forward(ctx, z1, z2, tau, eps, conf, pos_offset, global_batch):
+    def forward(ctx, z1, z2, tau, eps, conf, pos_offset, global_batch, norm=True):
         z1, z2 = z1.contiguous(), z2.contiguous()
         b1, b2 = z1.shape[0], z2.shape[0] // conf
+        ctx.norm = norm
+        if not norm:
+            # reference commons/losses.py:147-150 / :236-239 skipped: the same kernels with unit norms and no epsilon;
+            # the backward then has no norm term (the row_axpy corrections)
+            n1 = torch.ones(z1.shape[0], dtype=torch.float32, device=z1.device)
+            n2 = torch.ones(z2.shape[0], dtype=torch.float32, device=z2.device)
+            sim = ops.gemm(z1, z2, trans_b=True)
+            row_sum, row_pos, loss = ops.ntxent_fwd(sim, n1, n2, b1, b2, conf, pos_offset, tau, 0.0, 1.0 / global_batch)
+            ctx.cfg = (tau, 0.0, conf, pos_offset, global_batch, b1, b2)
+            ctx.composite = False
+            ctx.save_for_backward(z1, z2, n1, n2, sim, row_sum, row_pos)
+            return loss.reshape(())
         if LOSS_COMPOSITE and z1.is_cuda and z1.dtype == torch.float32 and z2.dtype == torch.float32:
             # row norms, similarity GEMM (MFMA) and the fused exp / row-sum / log kernel from ONE C call (csrc/ntxent.hip)
             L = _lib.load()
@@ -79,16 +91,17 @@ class NTXentFn(torch.autograd.Function):
             _lib.check(L.i3d_ntxent_loss_bwd(z1.data_ptr(), z2.data_ptr(), b1, b2, conf, z1.shape[1], pos_offset, float(tau),
                                              float(eps), 1.0 / global_batch, scratch.data_ptr(), gs.data_ptr(), work.data_ptr(),
                                              dz1.data_ptr(), dz2.data_ptr(), ops._stream()), 'i3d_ntxent_loss_bwd')
-            return dz1, dz2, None, None, None, None, None
+            return dz1, dz2, None, None, None, None, None, None
         z1, z2, n1, n2, sim, row_sum, row_pos = ctx.saved_tensors
         # the upstream scalar gradient is multiplied in on the device (no host read-back, no extra elementwise op)
         dsim, ca, cb = ops.ntxent_bwd(sim, n1, n2, row_sum, row_pos, b1, b2, conf, pos_offset, tau, eps,
                                       1.0 / global_batch, grad_out.contiguous().float())
         dz1 = ops.gemm(dsim, z2)                                  # dS z2
-        ops.row_axpy(z1, ca, dz1)
         dz2 = ops.gemm(dsim, z1, trans_a=True)                    # dS^T z1
-        ops.row_axpy(z2, cb, dz2)
-        return dz1, dz2, None, None, None, None, None
+        if ctx.norm:
+            ops.row_axpy(z1, ca, dz1)
+            ops.row_axpy(z2, cb, dz2)
+        return dz1, dz2, None, None, None, None, None, None
 
 
 # Optional regularisers (weights 0 in every BASELINE config, so they are plain differentiable torch expressions here,
@@ -126,8 +139,6 @@ class _NTXentBase(_Loss):
 
     def __init__(self, norm: bool = True, tau: float = 0.5, uniformity_reg=0, variance_reg=0, covariance_reg=0):
         super().__init__()
-        if not norm:
-            raise NotImplementedError('norm=False is not on the accelerated path (every reference config uses norm=True)')
         self.norm, self.tau = norm, tau
         self.uniformity_reg, self.variance_reg, self.covariance_reg = uniformity_reg, variance_reg, covariance_reg
         self.group = None
@@ -158,7 +169,7 @@ class _NTXentBase(_Loss):
                 else:
                     z2 = _AllGatherRowsFn.apply(z2, self.group)
                     pos_offset, global_batch = rank * z1.shape[0], world * z1.shape[0]
-        return NTXentFn.apply(z1, z2, float(self.tau), float(self._eps), conf, pos_offset, global_batch)
+        return NTXentFn.apply(z1, z2, float(self.tau), float(self._eps), conf, pos_offset, global_batch, bool(self.norm))
 
     def _regularisers(self, loss, z1, z2):
         if self.variance_reg > 0:

@@ -445,6 +445,23 @@ def test_ntxent_fwd_bwd_vs_oracle(B, dim, conf):
     assert rel_err(b.grad.cpu(), z2.grad) < 2e-5
 
 
+@pytest.mark.parametrize('B,dim,conf', [(64, 64, 1), (48, 32, 3)])
+def test_ntxent_without_normalisation_vs_oracle(B, dim, conf):
+    """norm=False (reference commons/losses.py:147, :236 skipped): raw dot products over tau; small embeddings so that
+    exp(sim / tau) stays finite, as it has to in the reference too"""
+    losses = importlib.import_module('3dinfomax_amd.losses')
+    z1 = (rnd(B, dim, seed=94) * 0.15).requires_grad_(True)
+    z2 = (rnd(B * conf, dim, seed=95) * 0.15).requires_grad_(True)
+    ref = O.ntxent(z1, z2, 0.5, norm=False) if conf == 1 else O.ntxent_multiple_positives(z1, z2, 0.5, norm=False)
+    ref.backward()
+    a, b = g(z1.detach()).requires_grad_(True), g(z2.detach()).requires_grad_(True)
+    loss_mod = losses.NTXent(norm=False, tau=0.5) if conf == 1 else losses.NTXentMultiplePositives(norm=False, tau=0.5)
+    loss = loss_mod(a, b)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+    assert rel_err(a.grad.cpu(), z1.grad) < 2e-5 and rel_err(b.grad.cpu(), z2.grad) < 2e-5
+
+
 def test_ntxent_row_sharded_equals_full():
     """Data-parallel form on one device: shares over row shards with pos_offset sum to the full loss/grads."""
     losses = importlib.import_module('3dinfomax_amd.losses')
