@@ -95,7 +95,22 @@ class PnaBatch(ctypes.Structure):
                 ('n_comb', c_int), ('v_pad', c_int)]
 
 
+class WgradProblem(ctypes.Structure):
+    _fields_ = [('A', _P), ('B', _P), ('rows', _P), ('rows_total', c_long), ('lda', c_int), ('ldb', c_int), ('M', c_int),
+                ('N', c_int), ('k_begin', c_int), ('k_count', c_int)]
+
+
+class WgradOutput(ctypes.Structure):
+    _fields_ = [('kind', c_int), ('n_groups', c_int), ('first_problem', c_int), ('ldc', c_int), ('c_split', c_int),
+                ('n_scalers', c_int), ('c_delta', c_long), ('scaler_stride', c_long), ('C', _P), ('aff', _P), ('row', _P),
+                ('coef', POINTER(c_float))]
+
+
 _SIGNATURES = {
+    'i3d_wgrad_multi_supported': (c_int, [POINTER(WgradProblem), c_int, POINTER(WgradOutput), c_int]),
+    'i3d_wgrad_multi_workspace_bytes': (c_long, [c_int]),
+    'i3d_wgrad_multi_min_workspace_bytes': (c_long, [POINTER(WgradProblem), c_int]),
+    'i3d_wgrad_multi': (c_int, [POINTER(WgradProblem), c_int, POINTER(WgradOutput), c_int, _P, c_long, _P]),
     'i3d_pna_model_saved_floats': (c_long, [POINTER(PnaModel), POINTER(PnaBatch)]),
     'i3d_pna_model_scratch_floats': (c_long, [POINTER(PnaModel), POINTER(PnaBatch)]),
     'i3d_pna_model_fwd': (c_int, [POINTER(PnaModel), POINTER(PnaBatch), _P, _P, _P, _P, _P, _P, _P, POINTER(c_void_p)]),

@@ -28,6 +28,8 @@ using namespace i3d;
 // (tools/probes/forkjoin_probe.hip), so a layer forks twice and joins once, and the stand-alone block entry points (heads,
 // the 3D network - whose stream has slack anyway) stay on one stream.  I3D_WGRAD_STREAM=0: off.
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -267,6 +269,95 @@ extern "C" int i3d_grouped_fc_bn_bwd(const I3dGroupedFcArgs* a, void* stream) {
     return grouped_fc_bn_bwd_wgrad(a, stream);
 }
 
+// ---- all weight gradients of a PNA layer behind ONE fork, from ONE launch + one reduction (wgrad.hip) ---------------
+// posttrans h-block | per-degree posttrans blocks folded into the scaler blocks | later pretrans blocks (BatchNorm fix-up in
+// the fused form) | [W_s | W_d] of the edge block | dQ of the bond table; then the two [V, .] products behind dQ.  Returns
+// 1 when it took the layer, 0 when the layer's shape is not covered (the caller issues the per-block launches), < 0: error.
+// I3D_WGRAD_MULTI=0: off.
+static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_run) {
+    static const bool on = [] { const char* e = getenv("I3D_WGRAD_MULTI"); return e == nullptr || e[0] != '0'; }();
+    const I3dEdgeFcArgs* e = &a->edge;
+    const I3dGroupedFcArgs* g = &a->post;
+    if (!on || a->n_post_extra != 0 || e->q == nullptr || e->q_rows <= 0 || i3d_get_matmul_precision() != 0) return 0;
+    const int Fh = e->f_h, Fo = e->f_out, N = e->num_nodes, E = e->num_edges, A = g->agg_width;
+    I3dWgradProblem pr[40];
+    I3dWgradOutput out[8];
+    float coef[128];
+    std::memset(pr, 0, sizeof(pr));
+    std::memset(out, 0, sizeof(out));
+    int np = 0, no = 0;
+    auto problem = [&](const float* Ap, int lda, int M, const float* Bp, int ldb, int Nn, long rows_total, const int* rows,
+                       int k_begin, int k_count) {
+        I3dWgradProblem& p = pr[np++];
+        p.A = Ap; p.B = Bp; p.rows = rows; p.rows_total = rows_total; p.lda = lda; p.ldb = ldb; p.M = M; p.N = Nn;
+        p.k_begin = k_begin; p.k_count = k_count;
+    };
+    // posttrans: dW_h = dlin^T h
+    out[no].kind = I3D_WGRAD_PLAIN; out[no].n_groups = 1; out[no].first_problem = np; out[no].C = g->grad_W; out[no].ldc = g->ldw;
+    ++no;
+    problem(g->grad_pre, g->f_out, g->f_out, g->h, Fh, Fh, N, nullptr, 0, N);
+    // posttrans: dW_s = sum_D c_s(D) dlin_D^T a_D over the in-degree groups with a non-zero coefficient
+    {
+        I3dWgradOutput& o = out[no];
+        o.kind = I3D_WGRAD_COMBINE; o.first_problem = np; o.C = g->grad_W + Fh; o.ldc = g->ldw;
+        o.n_scalers = g->n_scalers; o.scaler_stride = A; o.coef = coef;
+        int ng = 0;
+        for (int k = 0; k < g->n_groups; ++k) {
+            bool any = false;
+            for (int s = 0; s < g->n_scalers; ++s) any = any || g->coef[k * g->n_scalers + s] != 0.f;
+            if (!any || g->group_count[k] == 0 || np >= 36) {
+                if (any && g->group_count[k] != 0) return 0;       // more groups than the problem table holds
+                continue;
+            }
+            for (int s = 0; s < g->n_scalers; ++s) coef[ng * g->n_scalers + s] = g->coef[k * g->n_scalers + s];
+            problem(g->grad_pre, g->f_out, g->f_out, g->agg, A, A, N, g->deg_rows, g->group_start[k], g->group_count[k]);
+            ++ng;
+        }
+        if (ng == 0) return 0;
+        o.n_groups = ng;
+        ++no;
+    }
+    // later pretrans blocks: dW = dpre^T BN(x) from the raw x (fused form) or dpre^T x
+    for (int i = a->n_pre_extra - 1; i >= 0; --i) {
+        const I3dFcArgs* c = &a->pre[i];
+        I3dWgradOutput& o = out[no++];
+        o.n_groups = 1; o.first_problem = np; o.C = c->grad_W; o.ldc = c->ldw;
+        if (a->fused_bn) { o.kind = I3D_WGRAD_BN; o.aff = a->aff[i]; o.row = c->grad_bias; }
+        else o.kind = I3D_WGRAD_PLAIN;
+        problem(c->grad_pre, c->f_out, c->f_out, c->x, c->f_in, c->f_in, c->rows, nullptr, 0, c->rows);
+    }
+    // edge block: d[W_s | W_d] = dP^T h (rows >= Fo of the [2 Fo, Fh] product are the second column block of dW)
+    {
+        I3dWgradOutput& o = out[no++];
+        o.kind = I3D_WGRAD_PLAIN; o.n_groups = 1; o.first_problem = np; o.C = e->grad_W; o.ldc = e->ldw;
+        o.c_split = Fo; o.c_delta = (long)Fh - (long)Fo * e->ldw;
+        problem(e->grad_P, 2 * Fo, 2 * Fo, e->h, Fh, Fh, N, nullptr, 0, N);
+    }
+    // bond table: dQ = onehot^T dpre
+    {
+        I3dWgradOutput& o = out[no++];
+        o.kind = I3D_WGRAD_PLAIN; o.n_groups = 1; o.first_problem = np; o.C = e->grad_Q; o.ldc = Fo;
+        problem(e->onehot, e->v_pad, e->v_pad, e->grad_pre, Fo, Fo, E, nullptr, 0, E);
+    }
+    void* ws = e->tail.gemm_workspace;
+    const long wsb = e->tail.gemm_workspace_bytes;
+    if (ws == nullptr || !i3d_wgrad_multi_supported(pr, np, out, no) || i3d_wgrad_multi_min_workspace_bytes(pr, np) > wsb) return 0;
+    if (dry_run) return 1;                             // the layer is covered
+    TRY(bias_final(&g->tail, N, g->f_out, g->grad_bias, wst));
+    for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(bias_final(&a->pre[i].tail, a->pre[i].rows, a->pre[i].f_out, a->pre[i].grad_bias, wst));
+    TRY(bias_final(&e->tail, E, Fo, e->grad_bias, wst));
+    TRY(i3d_wgrad_multi(pr, np, out, no, ws, wsb, wst));
+    const int V = e->q_rows;
+    TRY(i3d_gemm_f32_ws(1, 0, Fo, e->f_q, V, e->grad_Q, Fo, e->q, e->f_q, e->grad_W + 2 * Fh, e->ldw, nullptr, 0, ws, wsb, wst));
+    if (e->grad_q != nullptr)
+        TRY(i3d_gemm_f32(0, 0, V, e->f_q, Fo, e->grad_Q, Fo, e->W + 2 * Fh, e->ldw, e->grad_q, e->f_q, nullptr, e->grad_q_accumulate, wst));
+    return 1;
+}
+
+// the cheap part of the decision, taken before the chain is enqueued (the expensive part - alignment, scratch - is
+// re-checked by pna_layer_wgrad_multi itself; dry_run: decide only)
+static bool wgrad_multi_layer_ok(const I3dPnaLayerArgs* a);
+
 // ---- one PNA layer ---------------------------------------------------------------------------------------
 // Fused-BatchNorm form of the layer (a->fused_bn, fused_bn.hip): the statistics of every block come out of the epilogue of
 // the kernel that produces its activation, the BatchNorm-apply of the pretrans blocks happens in the loads of their
@@ -396,9 +487,15 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     const long n = (long)a->edge.num_nodes * a->edge.f_h;
     // separate buffers: the residual's term right here, so that both forms add in the same order (dh_out + dlin W_h) + ...
     if (a->residual && !inplace) TRY(i3d_add_inplace(a->post.grad_h, a->grad_out, n, stream));
-    void* wst = fork_wgrad(x, stream);
-    TRY(grouped_fc_bn_bwd_wgrad(&a->post, wst));
-    for (int i = a->n_post_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_wgrad(&a->postx[i], wst));
+    // round 3: every weight gradient of the layer from one launch behind ONE fork (after dP exists) when the layer's shape
+    // allows it; otherwise the per-block launches behind two / three forks
+    const bool multi = wgrad_multi_layer_ok(a);
+    void* wst = stream;
+    if (!multi) {
+        wst = fork_wgrad(x, stream);
+        TRY(grouped_fc_bn_bwd_wgrad(&a->post, wst));
+        for (int i = a->n_post_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_wgrad(&a->postx[i], wst));
+    }
     // fused BatchNorm: a->msg is the last pretrans block's activation BEFORE its BatchNorm, applied on load (aff);
     // pre[i].x / the aggregation read raw activations, so the weight gradients of pre[i] are corrected with aff[i]
     const float* msg_aff = a->fused_bn ? a->aff[a->n_pre_extra] : nullptr;
@@ -408,7 +505,13 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
                                   stream));
     for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_chain(&a->pre[i], stream));
     TRY(edge_fc_bn_bwd_tail(&a->edge, stream));
-    if (THREE_FORKS) {
+    if (multi) {
+        TRY(edge_fc_bn_bwd_sums(&a->edge, stream));
+        wst = fork_wgrad(x, stream);
+        const int took = pna_layer_wgrad_multi(a, wst, false);
+        if (took < 0) return took;
+        I3D_CHECK_ARG(took == 1, "weight-gradient launch refused a layer it had accepted");
+    } else if (THREE_FORKS) {
         wst = fork_wgrad(x, stream);       // the later pretrans blocks' and everything behind dQ: they need grad_pre only
         for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_wgrad(&a->pre[i], wst, a->fused_bn ? a->aff[i] : nullptr));
         TRY(edge_fc_bn_bwd_wgrad_q(&a->edge, wst));
@@ -425,6 +528,8 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     if (a->defer_join) return I3D_OK;
     return join_wgrad(x, stream);
 }
+
+static bool wgrad_multi_layer_ok(const I3dPnaLayerArgs* a) { return pna_layer_wgrad_multi(a, nullptr, true) == 1; }
 
 extern "C" int i3d_wgrad_stream_join(void* stream) { return join_wgrad(aux_for((hipStream_t)stream), stream); }
 

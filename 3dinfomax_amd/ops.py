@@ -71,7 +71,7 @@ def _gemm_workspace(device):
 
 
 # I3D_GEMM_SCRATCH=0: fp32 atomics on top of a zero-fill instead of the two-stage reduction (A/B switch)
-GEMM_WORKSPACE_BYTES = (48 << 20) if os.environ.get('I3D_GEMM_SCRATCH', '1') != '0' else 0
+GEMM_WORKSPACE_BYTES = (160 << 20) if os.environ.get('I3D_GEMM_SCRATCH', '1') != '0' else 0
 
 
 class RawEvent:
@@ -639,3 +639,42 @@ def pna_aggregate_bwd_aff(grad_out, e, aff, in_ptr, num_nodes, aggregators, scal
                                                 int(force_scalers), float(avg_d_log), _p(ge), _stream()),
           'i3d_pna_aggregate_bwd_aff')
     return ge
+
+
+WGRAD_PLAIN, WGRAD_BN, WGRAD_COMBINE = 0, 1, 2
+
+
+def wgrad_multi(problems, outputs):
+    """All weight gradients of a layer from one launch + one fixed-order reduction (csrc/wgrad.hip).
+
+    problems: dicts {A [rows, M], B [rows, N], rows (int32 index or None), k_begin, k_count};
+    outputs: dicts {kind, first_problem, n_groups, C (tensor, written in place), ldc, c_split, c_delta, aff, row, coef
+    (list of n_groups * n_scalers floats), n_scalers, scaler_stride}."""
+    L = _lib.load()
+    pa = (_lib.WgradProblem * len(problems))()
+    keep = []
+    for d, p in zip(problems, pa):
+        A, B = _chk(d['A']), _chk(d['B'])
+        p.A, p.B = A.data_ptr(), B.data_ptr()
+        p.rows = d['rows'].data_ptr() if d.get('rows') is not None else None
+        p.rows_total = A.shape[0]
+        p.lda, p.ldb = d.get('lda', A.shape[1]), d.get('ldb', B.shape[1])
+        p.M, p.N = d.get('M', A.shape[1]), d.get('N', B.shape[1])
+        p.k_begin = d.get('k_begin', 0)
+        p.k_count = d.get('k_count', A.shape[0] if d.get('rows') is None else d['rows'].shape[0])
+    oa = (_lib.WgradOutput * len(outputs))()
+    for d, o in zip(outputs, oa):
+        o.kind, o.n_groups, o.first_problem = d.get('kind', WGRAD_PLAIN), d.get('n_groups', 1), d['first_problem']
+        C = _chk(d['C'])
+        o.C, o.ldc = C.data_ptr() + 4 * d.get('c_offset', 0), d.get('ldc', C.shape[-1])
+        o.c_split, o.c_delta = d.get('c_split', 0), d.get('c_delta', 0)
+        o.n_scalers, o.scaler_stride = d.get('n_scalers', 1), d.get('scaler_stride', 0)
+        o.aff = d['aff'].data_ptr() if d.get('aff') is not None else None
+        o.row = d['row'].data_ptr() if d.get('row') is not None else None
+        if d.get('coef') is not None:
+            arr = _float_array(d['coef'])
+            keep.append(arr)
+            o.coef = arr
+    dev = problems[0]['A'].device
+    check(L.i3d_wgrad_multi(pa, len(problems), oa, len(outputs), _p(_gemm_workspace(dev)), GEMM_WORKSPACE_BYTES, _stream()),
+          'i3d_wgrad_multi')

@@ -324,6 +324,47 @@ int i3d_gemm_f32_fused(int M, int N, int K, const float* A, int lda, long a_rows
 int i3d_gemm_f32_wgrad_bn(int f_out, int f_in, int rows, const float* dY, int ldy, const float* x, int ldx, float* dW,
                           int ldw, const float* grad_bias, const float* aff, void* workspace, long workspace_bytes,
                           void* stream);
+/* ---- all weight gradients of a layer in ONE launch + one fixed-order reduction (csrc/wgrad.hip) ----------------------
+ * Replaces autograd's dW = dY^T X of every nn.Linear of a PNA layer (reference models/base_layers.py:101; the Linears of
+ * models/pna.py:186-197) - round 2 issued them as ~10 launches per layer.  A problem is one product
+ *     P[M,N] = sum_{k_begin <= k < k_begin + k_count} A[row(k), 0:M]^T B[row(k), 0:N],   row(k) = rows ? rows[k] : k
+ * (rows[k] = -1: padding, contributes nothing; rows_total = physical rows of A and B).  An output takes the products of
+ * n_groups consecutive problems (first_problem ...), all of one shape:
+ *   I3D_WGRAD_PLAIN   (n_groups 1)  C[m, n] = P, rows m >= c_split displaced by c_delta floats (c_split 0: none)
+ *   I3D_WGRAD_BN      (n_groups 1)  C = (P - row[m] mean[n]) scale[n] + row[m] shift[n], aff = mean | scale | shift [3N]:
+ *                     the product against a BatchNorm output that was never materialised (i3d_gemm_f32_wgrad_bn)
+ *   I3D_WGRAD_COMBINE               C[m, s * scaler_stride + n] = sum_g coef[g * n_scalers + s] P_g  (host coef): the
+ *                     per-degree posttrans gradients folded into the scaler blocks (i3d_pna_combine_weights_bwd); at
+ *                     most one such output per call
+ * Needs M, N, lda, ldb, ldc multiples of 4 and 16-byte aligned pointers (i3d_wgrad_multi_supported), and
+ * i3d_wgrad_multi_workspace_bytes(units) of scratch for `units` K-slice panels (more scratch = shorter slices, up to
+ * I3D_WGRAD_UNITS = 256 by default).  Deterministic: every slice is summed in a fixed order. */
+#define I3D_WGRAD_PLAIN 0
+#define I3D_WGRAD_BN 1
+#define I3D_WGRAD_COMBINE 2
+typedef struct {
+    const float* A;
+    const float* B;
+    const int* rows;
+    long rows_total;
+    int lda, ldb, M, N;
+    int k_begin, k_count;
+} I3dWgradProblem;
+typedef struct {
+    int kind, n_groups, first_problem;
+    int ldc, c_split, n_scalers;
+    long c_delta, scaler_stride;
+    float* C;
+    const float* aff;
+    const float* row;
+    const float* coef; /* host */
+} I3dWgradOutput;
+int i3d_wgrad_multi_supported(const I3dWgradProblem* problems, int n_problems, const I3dWgradOutput* outputs, int n_outputs);
+long i3d_wgrad_multi_workspace_bytes(int max_units);
+long i3d_wgrad_multi_min_workspace_bytes(const I3dWgradProblem* problems, int n_problems); /* with the longest slices */
+int i3d_wgrad_multi(const I3dWgradProblem* problems, int n_problems, const I3dWgradOutput* outputs, int n_outputs,
+                    void* workspace, long workspace_bytes, void* stream);
+
 /* i3d_pna_aggregate_fwd / _bwd with the messages read as (e - mean) * scale + shift (aff [3 feat], may be NULL) */
 int i3d_pna_aggregate_fwd_aff(const float* e, const float* aff, const int* in_ptr, int num_nodes, int feat,
                               const int* aggregators, int n_aggregators, const int* scalers, int n_scalers,

@@ -502,3 +502,83 @@ def test_every_tile_configuration_on_awkward_shapes(cfg):
                 assert rc == 0, (cfg, M, N, K, ta, tb, lib.i3d_last_error())
                 ref = C0.double() + (A.double().T if ta else A.double()) @ (B.double().T if tb else B.double()) + bias.double()
                 assert rel_err(C.cpu(), ref) < 2e-5, (cfg, M, N, K, ta, tb)
+
+
+# ---- all weight gradients of a layer in one launch (csrc/wgrad.hip) ------------------------------------------
+def _padded_groups(counts, n_rows, seed):
+    """node ids grouped like graph.group_nodes_by_degree: every group padded to 64 with -1"""
+    perm = torch.randperm(n_rows, generator=torch.Generator().manual_seed(seed))
+    rows, starts, o = [], [], 0
+    for c in counts:
+        pad = (c + 63) // 64 * 64
+        starts.append(len(rows))
+        rows += perm[o:o + c].tolist() + [-1] * (pad - c)
+        o += c
+    return torch.tensor(rows, dtype=torch.int32), starts
+
+
+@pytest.mark.parametrize('F,N,E', [(200, 3001, 6007), (40, 500, 1100), (16, 130, 70), (208, 2100, 900)])
+def test_wgrad_multi_matches_fp64(F, N, E):
+    """the five products of a PNA layer's backward (posttrans h-block, per-degree blocks folded into the scaler blocks,
+    pretrans block against a never-materialised BatchNorm output, the two-block [W_s | W_d] gradient, the bond table's
+    one-hot product) from ONE call, against fp64 torch; reference op: autograd of nn.Linear, models/base_layers.py:101"""
+    A4, S = 4 * F, 3
+    dpost, h, agg = rnd(N, F, seed=1, scale=0.1), rnd(N, F, seed=2), rnd(N, A4, seed=3)
+    dpre2, x1 = rnd(E, F, seed=4, scale=0.1), rnd(E, F, seed=5)
+    dP = rnd(N, 2 * F, seed=6, scale=0.1)
+    dpre1 = rnd(E, F, seed=7, scale=0.1)
+    V = 64
+    onehot = torch.zeros(E, V)
+    onehot[torch.arange(E), torch.randint(0, 60, (E,), generator=torch.Generator().manual_seed(8))] = 1.0
+    counts = [N // 2, N // 7, N - N // 2 - N // 7 - 5, 5]
+    deg_rows, starts = _padded_groups(counts, N, seed=9)
+    coef = [1.0, 0.7, 1.4, 1.0, 1.1, 0.9, 1.0, 1.6, 0.6, 1.0, 1.8, 0.55]
+    aff, row = rnd(3 * F, seed=10), rnd(F, seed=11)
+    ldw = F + S * A4
+    gW_post = torch.full((F, ldw), float('nan'))
+    gW2 = torch.full((F, F), float('nan'))
+    gW1 = torch.full((F, 3 * F), float('nan'))
+    gQ = torch.full((V, F), float('nan'))
+    d = dict(dpost=g(dpost), h=g(h), agg=g(agg), dpre2=g(dpre2), x1=g(x1), dP=g(dP), dpre1=g(dpre1), onehot=g(onehot),
+             rows=g(deg_rows), aff=g(aff), row=g(row), gW_post=g(gW_post), gW2=g(gW2), gW1=g(gW1), gQ=g(gQ))
+    problems = [dict(A=d['dpost'], B=d['h'])]
+    for s0, c in zip(starts, counts):
+        problems.append(dict(A=d['dpost'], B=d['agg'], rows=d['rows'], k_begin=s0, k_count=c))
+    problems += [dict(A=d['dpre2'], B=d['x1']), dict(A=d['dP'], B=d['h']), dict(A=d['onehot'], B=d['dpre1'])]
+    G = len(counts)
+    outputs = [dict(first_problem=0, C=d['gW_post'], ldc=ldw),
+               dict(kind=ops.WGRAD_COMBINE, first_problem=1, n_groups=G, C=d['gW_post'], c_offset=F, ldc=ldw, coef=coef,
+                    n_scalers=S, scaler_stride=A4),
+               dict(kind=ops.WGRAD_BN, first_problem=1 + G, C=d['gW2'], aff=d['aff'], row=d['row']),
+               dict(first_problem=2 + G, C=d['gW1'], ldc=3 * F, c_split=F, c_delta=F - F * 3 * F),
+               dict(first_problem=3 + G, C=d['gQ'])]
+    ops.wgrad_multi(problems, outputs)
+    torch.cuda.synchronize()
+    D = lambda t: t.double()
+    ref_h = D(dpost).T @ D(h)
+    ref_blocks = torch.zeros(S, F, A4, dtype=torch.float64)
+    for gi, (s0, c) in enumerate(zip(starts, counts)):
+        idx = deg_rows[s0:s0 + c].long()
+        wd = D(dpost[idx]).T @ D(agg[idx])
+        for s in range(S):
+            ref_blocks[s] += coef[gi * S + s] * wd
+    got = d['gW_post'].cpu()
+    assert rel_err(got[:, :F], ref_h) < 1e-5
+    for s in range(S):
+        assert rel_err(got[:, F + s * A4:F + (s + 1) * A4], ref_blocks[s]) < 1e-5
+    mean, scale, shift = D(aff[:F]), D(aff[F:2 * F]), D(aff[2 * F:])
+    ref2 = D(dpre2).T @ ((D(x1) - mean) * scale + shift)
+    ref2_fix = (D(dpre2).T @ D(x1) - D(row)[:, None] * mean[None]) * scale[None] + D(row)[:, None] * shift[None]
+    assert rel_err(d['gW2'].cpu(), ref2_fix) < 1e-5
+    del ref2
+    refP = D(dP).T @ D(h)                                  # [2F, F]: rows >= F land in the second column block of dW1
+    g1 = d['gW1'].cpu()
+    assert rel_err(g1[:, :F], refP[:F]) < 1e-5 and rel_err(g1[:, F:2 * F], refP[F:]) < 1e-5
+    assert torch.isnan(g1[:, 2 * F:]).all()              # the W_q block is someone else's: untouched
+    assert rel_err(d['gQ'].cpu(), D(onehot).T @ D(dpre1)) < 1e-5
+    # bit-deterministic: the slices are summed in a fixed order
+    first = [d[k].clone() for k in ('gW_post', 'gW2', 'gW1', 'gQ')]
+    ops.wgrad_multi(problems, outputs)
+    torch.cuda.synchronize()
+    for a, k in zip(first, ('gW_post', 'gW2', 'gW1', 'gQ')):
+        assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(d[k]))
