@@ -176,6 +176,8 @@ class GradReducer:
             o += n
         self._pending, self._launched = [], []        # async all-reduces of this step, element ranges they cover
         self.early_spans = []                         # [start, end) element ranges reduced early, fixed by the model structure
+        self.early_module = None                      # id() of the ONE module whose backward pass may start them
+        self._late, self._late_used = None, False     # gradients that arrive for a slice AFTER its early all-reduce started
         self.overlap = OVERLAP_ALLREDUCE
         self._agreed = None                           # None: not checked yet; True / False: every rank has the same early plan
         self._tape = tape
@@ -197,6 +199,13 @@ class GradReducer:
         layers = list(getattr(gnn, 'mp_layers', [])) if gnn is not None else []
         if len(layers) < 2 or not hasattr(module, 'output'):
             return
+        if self.early_spans:
+            # ONE module per reducer starts collectives from inside its backward pass: with two, a rank whose second module
+            # fell back to the Python-sequenced path would issue that module's early slices in reduce(), i.e. in another
+            # order than a rank that started them in the backward pass - RCCL needs the same order everywhere.  The other
+            # modules' gradients travel with the complement.
+            return
+        self.early_module = id(module)
         early = [p for layer in layers[len(layers) // 2:] for p in layer.parameters()] + list(module.output.parameters())
         spans = sorted(self.span_of[id(p)] for p in early if id(p) in self.span_of)
         for a, b in spans:
@@ -206,11 +215,15 @@ class GradReducer:
                 self.early_spans.append([a, b])
         self.early_spans.sort()
 
-    def launch_async(self, params=None):
+    def launch_async(self, module=None):
         """Start the all-reduce of the EARLY slices now (their gradients are final in stream order and live in the flat
         buffer): a model backward calls this after the part of the pass that produces them (pna_native.PNAModelFn: head +
-        upper half of the layers) while the rest is still to be enqueued, so the collective runs next to it."""
+        upper half of the layers) while the rest is still to be enqueued, so the collective runs next to it.  `module`: the
+        caller - only the module the plan was made for may start it (another module's backward pass says nothing about
+        whether THOSE gradients are final); None: reduce() itself."""
         if self._launched or not self._agreed:       # (no early collective before the ranks have agreed on the plan)
+            return
+        if module is not None and id(module) != self.early_module:
             return
         for a, b in self.early_spans:
             t = self.flat[a:b]
@@ -230,6 +243,18 @@ class GradReducer:
         out, dst, src = [], [], []
         for p, g in zip(params, grads):
             d = self.view_of.get(id(p))
+            if d is not None and g is not None and g is not d and p.grad is not None and self._in_flight(id(p)):
+                # a second backward pass of this step (gradient accumulation) delivers a gradient for a slice whose all-reduce
+                # has already been started by the first: adding it onto `p.grad` - the slice - would race with the collective
+                # and leave "reduced first pass + local second pass".  It is summed in a side buffer, reduced on its own in
+                # reduce() and added to the slice afterwards.
+                if self._late is None:
+                    self._late = torch.zeros_like(self.flat)
+                a, b = self.span_of[id(p)]
+                self._late[a:b].view_as(p).add_(g)
+                self._late_used = True
+                out.append(None)
+                continue
             if d is None or g is None or g is d or p.grad is not None:
                 out.append(g)
                 continue
@@ -239,6 +264,12 @@ class GradReducer:
         if dst:
             torch._foreach_copy_(dst, src)
         return out
+
+    def _in_flight(self, pid):
+        if not self._launched:
+            return False
+        a, b = self.span_of[pid]
+        return any(a < hi and lo < b for lo, hi in self._launched)
 
     def reduce(self):
         grads = [p.grad for p in self.params]
@@ -271,8 +302,16 @@ class GradReducer:
                 if a > o:
                     all_reduce_sum(self.flat[o:a], self.group)
                 o = max(o, b)
+            if self._late_used:                       # (every rank ran the same number of backward passes: same decision)
+                for a, b in self._launched:
+                    all_reduce_sum(self._late[a:b], self.group)
             for w in self._pending:
                 w.wait()
+            if self._late_used:
+                for a, b in self._launched:
+                    self.flat[a:b].add_(self._late[a:b])
+                self._late.zero_()
+                self._late_used = False
         else:
             all_reduce_sum(self.flat, self.group)
         self._pending, self._launched = [], []

@@ -143,6 +143,7 @@ class _NTXentBase(_Loss):
         self.uniformity_reg, self.variance_reg, self.covariance_reg = uniformity_reg, variance_reg, covariance_reg
         self.group = None
         self.shard_counts = None
+        self._equal_checked = {}       # local row count -> True once every rank has been seen to hold the same
 
     def attach_group(self, group):
         """Enable the data-parallel form (all-gathered negatives) on a torch.distributed process group."""
@@ -167,6 +168,17 @@ class _NTXentBase(_Loss):
                     z2 = _AllGatherRowsFn.apply(z2, self.group, [c * conf for c in counts])
                     pos_offset, global_batch = sum(counts[:rank]), sum(counts)
                 else:
+                    if counts is None and z1.shape[0] not in self._equal_checked:
+                        # equal shards are ASSUMED when no counts were given (all_gather_into_tensor / reduce_scatter_tensor
+                        # with different row counts per rank hang or corrupt silently): checked once per local batch size -
+                        # e.g. the last partial batch of an epoch sharded with the remainder kept
+                        n = torch.tensor([z1.shape[0], -z1.shape[0]], dtype=torch.float64,
+                                         device='cpu' if dist.get_backend(self.group) == 'gloo' else z1.device)
+                        dist.all_reduce(n, op=dist.ReduceOp.MAX, group=self.group)
+                        if float(n[0]) != -float(n[1]):
+                            raise ValueError(f'ranks hold different numbers of molecules ({z1.shape[0]} here, {int(-n[1])}..'
+                                             f'{int(n[0])} over the group): pass them with loss.set_shard_counts(dist.shard_counts(...))')
+                        self._equal_checked[z1.shape[0]] = True
                     z2 = _AllGatherRowsFn.apply(z2, self.group)
                     pos_offset, global_batch = rank * z1.shape[0], world * z1.shape[0]
         return NTXentFn.apply(z1, z2, float(self.tau), float(self._eps), conf, pos_offset, global_batch, bool(self.norm))

@@ -41,8 +41,8 @@ class _NativeTable:
         self.param_ptrs = [p.data_ptr() for p in ps]
 
     def valid_for(self, ps, grads):
-        if len(grads) != len(self.grads):
-            return False
+        if len(grads) != len(self.grads) or [p.data_ptr() for p in ps] != self.param_ptrs:
+            return False                  # (a parameter whose storage moved: the table points at the old memory)
         for a, b in zip(grads, self.grads):
             if a is not b:
                 # a different tensor object may still be the same memory (views re-created by autograd)
@@ -62,6 +62,7 @@ class Adam(torch.optim.Adam):
         self._merged = None
         self._native = None          # (_NativeTable, host step count)
         self._host_step = None
+        self._steps_unequal = False
 
     @staticmethod
     def _all_cuda(params):
@@ -76,6 +77,7 @@ class Adam(torch.optim.Adam):
                 and not group.get('decoupled_weight_decay', False))
 
     def _build_lists(self):
+        self._steps_unequal = False
         lists = []
         for group in self.param_groups:
             ps = group['params']
@@ -111,8 +113,10 @@ class Adam(torch.optim.Adam):
         """steady state of the one-launch kernel: same gradient tensor objects as last step, same hyper-parameters ->
         straight to the launch (no tensor lists, no torch.no_grad context: nothing here touches autograd)"""
         nat = self._native
-        for p, g in zip(nat.params, nat.grads):
-            if p.grad is not g:
+        for p, g, ptr in zip(nat.params, nat.grads, nat.param_ptrs):
+            # same gradient objects AND the parameter's storage is the one the chunk table points into (a swap of
+            # `p.data` - .to(), a checkpoint surgery - keeps p and p.grad alive but moves the memory)
+            if p.grad is not g or p.data_ptr() != ptr:
                 return False
         key = nat.key
         for group in self.param_groups:
@@ -192,6 +196,8 @@ class Adam(torch.optim.Adam):
     def _native_step(self, work):
         """every group with the same hyper-parameters, contiguous fp32 tensors: ONE launch of csrc/adam.hip for all
         parameters (and their step counters).  Returns False when it does not apply (torch's kernel runs instead)."""
+        if self._steps_unequal:
+            return False
         g0 = work[0][0]
         key = (g0['lr'], g0['betas'], g0['weight_decay'], g0['eps'])
         for g, _, _ in work[1:]:
@@ -206,10 +212,20 @@ class Adam(torch.optim.Adam):
             if not all(t.is_contiguous() and t.dtype == torch.float32 for t in ps + grads + ms + vs):
                 return False
             nat = self._native = _NativeTable(ps, grads, ms, vs)
-            nat.params, nat.key = ps, key
-            nat.group_sizes = {id(g): len(g['params']) for g in self.param_groups}
+            nat.params = ps
+        # the table holds pointers only: hyper-parameters (an LR scheduler moves group['lr'] - the reference's WarmUpWrapper
+        # / ReduceLROnPlateau) and re-created gradient views refresh the fast path's keys instead of switching it off
+        nat.key, nat.grads = key, list(grads)
+        nat.group_sizes = {id(g): len(g['params']) for g in self.param_groups}
         if self._host_step is None:                 # one read-back after construction / load_state_dict / a torch step
-            self._host_step = int(round(float(self._steps_flat[0].item())))
+            # ONE step count for the whole launch: torch's kernel uses each parameter's own `step` for the bias
+            # corrections, and they differ after add_param_group on a trained optimizer, a checkpoint in which some
+            # parameters were skipped, unfreezing during fine-tuning - then torch's per-parameter kernel runs
+            steps = self._steps_flat.cpu()
+            if not bool((steps == steps[0]).all()):
+                self._steps_unequal = True          # (remembered: no read-back per step; cleared with the tensor lists)
+                return False
+            self._host_step = int(round(float(steps[0].item())))
         t = self._host_step + 1
         from . import _lib, ops
         beta1, beta2 = key[1]

@@ -78,6 +78,8 @@ def _structure_ok(module):
     hidden = gnn.atom_encoder.atom_embedding_list[0].embedding_dim
     if hidden % 4 or len(first.scalers) < 2 or not first.edge_features:
         return False
+    if getattr(gnn.atom_encoder, 'padding', False) or getattr(gnn.bond_encoder, 'padding', False):
+        return False     # padding=True encoders (extra row 0, lookup at x + 1, no gradient for row 0): layers.EmbeddingSumPadFn only
     n_comb = 1
     for d in gnn.bond_encoder.dims:
         n_comb *= d
@@ -320,7 +322,7 @@ class PNAModelFn(torch.autograd.Function):
             # all-reduce (RCCL, its own stream) runs next to the lower half of the backward pass
             split = n_layers // 2
             part(1, split)
-            red.launch_async()               # the slices of layers [split, L) + head (GradReducer._plan_early: the same split)
+            red.launch_async(module)         # the slices of layers [split, L) + head (GradReducer._plan_early: the same split)
             part(2, split)
         else:
             part(0, 0)

@@ -71,6 +71,8 @@ def parse():
     ap.add_argument('--no-prewarm', action='store_true', help='skip dist.warm_up before init_process_group (A/B)')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise RCCL and run the data-parallel code path even with one rank (self-test)')
+    ap.add_argument('--no-extra-workloads', action='store_true',
+                    help='skip the short windows of the other BASELINE.json configs after the timed region (config.extra_workloads)')
     return ap.parse_args()
 
 
@@ -109,6 +111,97 @@ def cpu_baseline(mols, depth, steps):
                 sample=f'batch {len(mols)} (depth {depth}, fp32, torch CPU eager): one step per thread setting, '
                        f'{max(steps - 1, 1)} more at the best; best {best} threads {dt:.3f} s/step',
                 thread_sweep_s_per_step={str(t): round(v, 3) for t, v in sweep.items()}, host_cores=all_cores)
+
+
+def extra_workloads(amd, ops, dev, depth):
+    """Short windows of the OTHER BASELINE.json configurations after the main timed region (N = 1), so that the driver's
+    default line carries a number for each: configs[3] shape (QMugs-shaped molecules, 3 conformers,
+    NTXentMultiplePositives, PNA depth 7; fp32 and bf16 matmul mode), configs[4] (fine-tune: PNA only, L1 loss, readout
+    min/max/mean/sum, depth 7, batch 1024: reference configs_clean/tune_QM9_homo.yml:47-75, trainer/trainer.py:111-124) and
+    the per-epoch validation pass (trainer/trainer.py:72-78, 126-165: the 2D model in eval() under no_grad over
+    validation-sized batches).  ms per step = device time between two events around the window, inputs resident."""
+    out = {}
+
+    def window(step, warm, n):
+        for i in range(warm):
+            step(i)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        a.record()
+        for i in range(n):
+            step(warm + i)
+        b.record()
+        host = (time.perf_counter() - t0) / n * 1e3
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n, host
+
+    def adam(named):
+        return amd.Adam([{'params': [p for k, p in named if 'batch_norm' in k], 'weight_decay': 0},
+                         {'params': [p for k, p in named if 'batch_norm' not in k]}], lr=8e-5, fused=True)
+
+    # ---- configs[3] shape
+    B3 = 500
+    mols = amd.synth.make_dataset(B3, seed=3000, kind='qmugs')
+    rng = np.random.default_rng(3001)
+    g2 = amd.batch([amd.bond_graph(m) for m in mols]).to(dev)
+    g3 = amd.batch([amd.complete_graph(m, c) for m in mols for c in amd.synth.conformers(m, rng, 3)]).to(dev)
+    for dtype in ('fp32', 'bf16'):
+        prev = ops.set_matmul_precision(dtype)
+        torch.manual_seed(123)
+        pna = amd.PNA(avg_d=1.0, device=dev, **dict(PNA_KW, propagation_depth=7)).to(dev).train()
+        net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_KW).to(dev).train()
+        loss_fn = amd.NTXentMultiplePositives(tau=0.1)
+        optim = adam(list(pna.named_parameters()) + list(net.named_parameters()))
+
+        def step(i):
+            a, b = g2.local_copy(), g3.local_copy()
+            loss_fn(pna(a), net(b)).backward()
+            optim.step()
+            optim.zero_grad()
+        ms, host = window(step, 5, 15)
+        out[f'qmugs_shape_{dtype}'] = dict(ms_per_step=round(ms, 3), molecules_per_s=round(B3 / ms * 1e3, 1), host_enqueue_ms=round(host, 3),
+                                           batch=B3, conformers=3, depth=7, atoms=int(g2.number_of_nodes()),
+                                           complete_graph_edges=int(g3.number_of_edges()), matmul=dtype)
+        ops.set_matmul_precision(prev)
+        del pna, net, optim
+    del g2, g3
+    # ---- configs[4]: fine-tune step, PNA only
+    B4 = 1024
+    mols = amd.synth.make_dataset(B4, seed=4000)
+    g2 = amd.batch([amd.bond_graph(m) for m in mols]).to(dev)
+    targets = torch.randn(B4, 1, device=dev)
+    torch.manual_seed(123)
+    tune_kw = dict(PNA_KW, target_dim=1, batch_norm_momentum=0.1, propagation_depth=7, readout_aggregators=['min', 'max', 'mean', 'sum'])
+    pna = amd.PNA(avg_d=1.0, device=dev, **tune_kw).to(dev).train()
+    optim = amd.Adam(list(pna.parameters()), lr=7e-5, weight_decay=1e-11, fused=True)
+    l1 = torch.nn.L1Loss()
+
+    def tune_step(i):
+        l1(pna(g2.local_copy()), targets).backward()
+        optim.step()
+        optim.zero_grad()
+    ms, host = window(tune_step, 5, 20)
+    out['finetune_pna_only'] = dict(ms_per_step=round(ms, 3), molecules_per_s=round(B4 / ms * 1e3, 1), host_enqueue_ms=round(host, 3),
+                                    batch=B4, depth=7, loss='L1Loss', readout='min/max/mean/sum', atoms=int(g2.number_of_nodes()))
+    del pna, optim
+    # ---- validation pass: eval-mode forward of the pre-training 2D model, batch 512
+    B5 = 512
+    mols = amd.synth.make_dataset(B5, seed=5000)
+    g2 = amd.batch([amd.bond_graph(m) for m in mols]).to(dev)
+    torch.manual_seed(123)
+    pna = amd.PNA(avg_d=1.0, device=dev, **dict(PNA_KW, propagation_depth=depth)).to(dev).train()
+    with torch.no_grad():
+        pna(g2.local_copy())                      # running statistics that are not the initial ones
+    pna.eval()
+
+    def eval_step(i):
+        with torch.no_grad():
+            pna(g2.local_copy())
+    ms, host = window(eval_step, 5, 30)
+    out['eval_forward_2d'] = dict(ms_per_step=round(ms, 3), molecules_per_s=round(B5 / ms * 1e3, 1), host_enqueue_ms=round(host, 3),
+                                  batch=B5, depth=depth)
+    return out
 
 
 def main():
@@ -450,6 +543,9 @@ def main():
                    roofline=roof)
         if collectives is not None:
             out['collectives'] = collectives
+        if world == 1 and not use_dist and not qmugs and not args.no_extra_workloads and args.dtype == 'fp32':
+            del batches[1:]
+            out['config']['extra_workloads'] = extra_workloads(amd, ops, dev, args.depth)
         if world == 1 and not args.no_cpu_baseline and not qmugs:
             out['cpu_baseline'] = cpu_baseline(batches[0][2], args.depth, args.cpu_steps)
         print(json.dumps(out), flush=True)

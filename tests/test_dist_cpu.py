@@ -140,3 +140,52 @@ def test_sharded_ntxent_with_uneven_shards():
     out = mgr.dict()
     mp.spawn(_var_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def _accum_worker(rank, port, out):
+    """GradReducer with an early (overlapped) all-reduce and a SECOND backward pass before reduce() (gradient
+    accumulation): the early slice must end as sum over ranks of (first + second), not reduced(first) + local(second)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    adist = importlib.import_module('3dinfomax_amd.dist')
+    g = torch.Generator().manual_seed(5)
+    params = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in ((4, 3), (5,), (2, 6), (7,))]
+    grads = [[torch.randn(WORLD, 2, *p.shape, generator=g)] for p in params]          # [rank][pass]
+    red = adist.GradReducer(params)
+    owner = torch.nn.Linear(1, 1)                       # stands for the module whose backward starts the early slices
+    other = torch.nn.Linear(1, 1)
+    red.early_spans = [list(red.span_of[id(params[2])]), list(red.span_of[id(params[3])])]
+    red.early_spans = [[red.early_spans[0][0], red.early_spans[1][1]]]
+    red.early_module = id(owner)
+    red._agreed = True
+    # first backward pass: the gradients land in the flat buffer, the early slice is started - but not by another module
+    first = red._sink(params, [gr[0][rank, 0].clone() for gr in grads])
+    for p, v in zip(params, first):
+        p.grad = v
+    red.launch_async(other)
+    ok = red._launched == []
+    red.launch_async(owner)
+    ok = ok and red._launched == [tuple(red.early_spans[0])]
+    # second backward pass before reduce(): what the sink hands back is what autograd's AccumulateGrad would add to p.grad
+    second = red._sink(params, [gr[0][rank, 1].clone() for gr in grads])
+    for p, v in zip(params, second):
+        if v is not None:
+            p.grad.add_(v)
+    ok = ok and second[2] is None and second[3] is None and second[0] is not None
+    red.reduce()
+    for p, gr in zip(params, grads):
+        want = gr[0].sum(dim=(0, 1))
+        ok = ok and torch.allclose(p.grad, want, rtol=1e-5, atol=1e-6)
+    # the next step starts clean
+    ok = ok and red._launched == [] and not red._late_used and float(red._late.abs().sum()) == 0.0
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_early_all_reduce_with_gradient_accumulation():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_accum_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
+    assert dict(out) == {0: True, 1: True}

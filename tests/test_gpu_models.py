@@ -518,6 +518,75 @@ def test_adam_fast_path_is_torch_adam(amd, second_group_wd, native, monkeypatch)
     oa.step()
 
 
+def test_native_adam_with_unequal_step_counts_a_moved_parameter_and_an_lr_schedule(amd):
+    """The one-launch Adam takes ONE step count for its bias corrections: parameters whose `step` differs (a parameter
+    that had no gradient for some steps, add_param_group on a trained optimizer, unfreezing) must get torch's
+    per-parameter arithmetic; a parameter whose storage was swapped (`p.data = ...`) must not be updated through the old
+    pointers; a learning-rate schedule must not switch the steady-state fast path off."""
+    optim_mod = importlib.import_module('3dinfomax_amd.optim')
+    torch.manual_seed(1)
+    shapes = [(64, 40), (40,), (9, 5)]
+    pa = [torch.randn(s, device='cuda:0').requires_grad_() for s in shapes]
+    pb = [p.detach().clone().requires_grad_() for p in pa]
+    oa, ob = amd.Adam(pa, lr=1e-3), torch.optim.Adam(pb, lr=1e-3, fused=True)
+
+    def step(skip_last=False, lr=None):
+        gs = [torch.randn(s, device='cuda:0') for s in shapes]
+        for o in (oa, ob):
+            if lr is not None:
+                for gr in o.param_groups:
+                    gr['lr'] = lr
+        for i, (p, q, g_) in enumerate(zip(pa, pb, gs)):
+            none = skip_last and i == len(shapes) - 1
+            p.grad, q.grad = (None, None) if none else (g_.clone(), g_.clone())
+        oa.step()
+        ob.step()
+
+    def close():
+        return all((p - q).abs().max().item() <= 4e-7 * max(q.abs().max().item(), 1e-30) for p, q in zip(pa, pb))
+    for _ in range(3):
+        step()
+    assert close() and oa._native is not None and oa._host_step == 3
+    for _ in range(2):
+        step(skip_last=True)                 # torch skips the parameter: its step counter lags behind now
+    for _ in range(3):
+        step()
+    assert [float(oa.state[p]['step']) for p in pa] == [8.0, 8.0, 6.0] == [float(ob.state[q]['step']) for q in pb]
+    assert close(), 'unequal step counts: the bias corrections must be per parameter'
+    # an lr schedule: after one general step the fast path is back
+    oa2, ob2 = oa, ob
+    pa2 = [torch.randn(s, device='cuda:0').requires_grad_() for s in shapes]
+    pb2 = [p.detach().clone().requires_grad_() for p in pa2]
+    pa[:], pb[:] = pa2, pb2
+    oa, ob = amd.Adam(pa, lr=1e-3), torch.optim.Adam(pb, lr=1e-3, fused=True)
+    grads = [torch.randn(s, device='cuda:0') for s in shapes]
+
+    def step_same_objects(lr):
+        for o in (oa, ob):
+            for gr in o.param_groups:
+                gr['lr'] = lr
+        for p, q, g_ in zip(pa, pb, grads):
+            if p.grad is None:
+                p.grad, q.grad = g_.clone(), g_.clone()
+        oa.step()
+        ob.step()
+    for it in range(6):
+        step_same_objects(1e-3 * (it + 1))
+    assert close()
+    assert oa._native_fast.__self__ is oa and oa._native.key[0] == 6e-3, 'hyper-parameter key follows the schedule'
+    calls = []
+    real = oa._step_general
+    oa._step_general = lambda closure=None: (calls.append(1), real(closure))[1]
+    step_same_objects(6e-3)
+    assert calls == [], 'steady state goes straight to the launch'
+    # swap a parameter's storage: the next step must see it
+    pa[0].data = pa[0].data.clone()
+    pb[0].data = pb[0].data.clone()
+    step_same_objects(6e-3)
+    assert calls == [1] and close()
+    del oa2, ob2, optim_mod
+
+
 def test_parameter_gradients_stored_by_the_model_node(amd, monkeypatch):
     """tape.ModelFn stores `.grad` itself when the parameters are plain leaves: same values as through autograd's
     AccumulateGrad nodes (I3D_DIRECT_PARAM_GRADS=0), gradient accumulation over two backward passes still sums, and a
