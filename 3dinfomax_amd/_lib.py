@@ -59,7 +59,8 @@ class PnaLayerArgs(ctypes.Structure):
                 ('n_scalers', c_int), ('force_scalers', c_int), ('aggregators', c_int * 8), ('scalers', c_int * 4),
                 ('avg_d_log', c_float), ('msg', _P), ('grad_msg', _P), ('post', GroupedFcArgs), ('n_post_extra', c_int),
                 ('postx', FcArgs * 3), ('residual', c_int), ('grad_out', _P), ('agg_event_start', _P), ('agg_event_stop', _P),
-                ('fused_bn', c_int), ('defer_join', c_int), ('stats_ws', _P), ('aff', _P * 4), ('weights_ready', c_int)]
+                ('fused_bn', c_int), ('defer_join', c_int), ('stats_ws', _P), ('aff', _P * 4), ('weights_ready', c_int),
+                ('eval_mode', c_int)]
 
 
 class Net3dEdgeArgs(ctypes.Structure):
@@ -79,7 +80,7 @@ class FcParams(ctypes.Structure):
 
 
 class PnaModel(ctypes.Structure):
-    _fields_ = [('n_layers', c_int), ('hidden', c_int), ('n_pre', c_int), ('residual', c_int), ('n_aggregators', c_int),
+    _fields_ = [('training', c_int), ('n_layers', c_int), ('hidden', c_int), ('n_pre', c_int), ('residual', c_int), ('n_aggregators', c_int),
                 ('aggregators', c_int * 8), ('n_scalers', c_int), ('scalers', c_int * 4), ('avg_d_log', c_float),
                 ('pre', (FcParams * 4) * 16), ('post', FcParams * 16), ('n_atom_tables', c_int), ('atom_dims', c_int * 16),
                 ('atom_tables', _P * 16), ('grad_atom_tables', _P), ('n_bond_tables', c_int), ('bond_dims', c_int * 16),
@@ -95,6 +96,11 @@ class PnaBatch(ctypes.Structure):
                 ('n_comb', c_int), ('v_pad', c_int)]
 
 
+class BnEvalAff(ctypes.Structure):
+    _fields_ = [('running_mean', _P), ('running_var', _P), ('gamma', _P), ('beta', _P), ('aff', _P), ('feat', c_int),
+                ('eps', c_float)]
+
+
 class WgradProblem(ctypes.Structure):
     _fields_ = [('A', _P), ('B', _P), ('rows', _P), ('rows_total', c_long), ('lda', c_int), ('ldb', c_int), ('M', c_int),
                 ('N', c_int), ('k_begin', c_int), ('k_count', c_int)]
@@ -107,6 +113,7 @@ class WgradOutput(ctypes.Structure):
 
 
 _SIGNATURES = {
+    'i3d_bn_eval_aff_multi': (c_int, [POINTER(BnEvalAff), c_int, _P]),
     'i3d_wgrad_multi_supported': (c_int, [POINTER(WgradProblem), c_int, POINTER(WgradOutput), c_int]),
     'i3d_wgrad_multi_workspace_bytes': (c_long, [c_int]),
     'i3d_wgrad_multi_min_workspace_bytes': (c_long, [POINTER(WgradProblem), c_int]),

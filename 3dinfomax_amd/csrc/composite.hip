@@ -366,7 +366,9 @@ static bool wgrad_multi_layer_ok(const I3dPnaLayerArgs* a);
 // posttrans output - which the next layer gathers from - is materialised by i3d_bn_apply_fwd.
 static bool simple_act(int act) { return act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU; }
 
-static int finalize_stats(const I3dBnTail* t, const float* partial, int tiles, int feat, float* aff, void* stream) {
+static int finalize_stats(const I3dBnTail* t, const float* partial, int tiles, int feat, float* aff, void* stream,
+                          int eval_mode = 0) {
+    if (eval_mode) return I3D_OK;      // running statistics: the affine vectors are already there, nothing is updated
     return i3d_bn_finalize_partials(partial, tiles, feat, t->eps, t->momentum, t->gamma, t->beta, t->mean, t->invstd,
                                     t->running_mean, t->running_var, t->num_batches_tracked, aff, stream);
 }
@@ -385,7 +387,7 @@ static int pna_layer_fwd_fused(const I3dPnaLayerArgs* a, void* stream) {
                          nullptr, 0, stream));
     TRY(i3d_edge_combine_act_stats(e->P, 2 * Fo, e->q ? e->Q : nullptr, e->q_rows > 0 ? e->q_code : nullptr, e->bias, e->src_s,
                                    e->dst_s, E, Fo, e->tail.act, e->xact, a->stats_ws, stream));
-    TRY(finalize_stats(&e->tail, a->stats_ws, cdiv(E, i3d_edge_stats_rows_per_tile(Fo)), Fo, a->aff[0], stream));
+    TRY(finalize_stats(&e->tail, a->stats_ws, cdiv(E, i3d_edge_stats_rows_per_tile(Fo)), Fo, a->aff[0], stream, a->eval_mode));
     const float* x = e->xact;
     const float* aff = a->aff[0];
     int f_in = Fo;
@@ -396,7 +398,7 @@ static int pna_layer_fwd_fused(const I3dPnaLayerArgs* a, void* stream) {
         // lin = BN_prev(x) W^T + b with the BatchNorm applied while x is staged; activation + statistics in the epilogue
         TRY(i3d_gemm_f32_fused(E, c->f_out, f_in, x, f_in, E, c->W, c->ldw, c->xact, c->f_out, c->bias, 0, aff, c->tail.act,
                                a->stats_ws, nullptr, nullptr, 0, stream));
-        TRY(finalize_stats(&c->tail, a->stats_ws, cdiv(E, 64), c->f_out, a->aff[i + 1], stream));
+        TRY(finalize_stats(&c->tail, a->stats_ws, cdiv(E, 64), c->f_out, a->aff[i + 1], stream, a->eval_mode));
         x = c->xact;
         aff = a->aff[i + 1];
         f_in = c->f_out;
@@ -415,6 +417,9 @@ static int pna_layer_fwd_fused(const I3dPnaLayerArgs* a, void* stream) {
         TRY(i3d_pna_combine_weights_fwd(p->W, p->ldw, p->f_h, Fp, A, p->n_groups, p->n_scalers, p->coef, p->WD, stream));
     TRY(i3d_gemm_f32_fused(p->m_padded, Fp, A, p->agg, A, N, p->WD, A, p->xact, Fp, nullptr, 1, nullptr, p->tail.act,
                            a->stats_ws, p->deg_rows, p->deg_tile_group, (long)Fp * A, stream));
+    if (a->eval_mode)
+        return i3d_bn_eval_fwd(p->xact, N, Fp, p->tail.running_mean, p->tail.running_var, p->tail.eps, p->tail.gamma, p->tail.beta,
+                               p->tail.post_act, p->residual, p->y, stream);
     TRY(finalize_stats(&p->tail, a->stats_ws, p->m_padded / 64, Fp, nullptr, stream));
     return i3d_bn_apply_fwd(p->xact, N, Fp, p->tail.mean, p->tail.invstd, p->tail.gamma, p->tail.beta, p->tail.post_act,
                             p->residual, p->y, stream);

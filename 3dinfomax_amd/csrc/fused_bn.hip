@@ -14,6 +14,7 @@
 //     never materialised.
 // Deterministic: fixed tile -> lane -> tree order everywhere, no atomics.
 #include "common.h"
+#include <algorithm>
 
 namespace i3d {
 
@@ -257,9 +258,41 @@ edge_combine_act_stats_kernel(const float* __restrict__ P, int ldp, const float*
     }
 }
 
+// eval mode: the affine vectors mean | gamma / sqrt(var + eps) | beta of up to 64 BatchNorms from their running
+// statistics, one launch (they depend on parameters and buffers only)
+struct EvalAffTable {
+    int n;
+    I3dBnEvalAff e[64];
+};
+
+__global__ void __launch_bounds__(256) bn_eval_aff_kernel(const EvalAffTable t) {
+    const I3dBnEvalAff& e = t.e[blockIdx.y];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= e.feat) return;
+    e.aff[c] = e.running_mean[c];
+    e.aff[e.feat + c] = e.gamma[c] / sqrtf(e.running_var[c] + e.eps);
+    e.aff[2 * e.feat + c] = e.beta[c];
+}
+
 }  // namespace i3d
 
 using namespace i3d;
+
+extern "C" int i3d_bn_eval_aff_multi(const I3dBnEvalAff* entries, int n, void* stream) {
+    I3D_CHECK_ARG(entries != nullptr && n >= 1 && n <= 64, "1..64 entries");
+    EvalAffTable t;
+    t.n = n;
+    int fmax = 0;
+    for (int i = 0; i < n; ++i) {
+        I3D_CHECK_ARG(entries[i].feat > 0 && entries[i].aff != nullptr && entries[i].running_mean != nullptr &&
+                          entries[i].running_var != nullptr && entries[i].gamma != nullptr && entries[i].beta != nullptr, "null");
+        t.e[i] = entries[i];
+        fmax = std::max(fmax, entries[i].feat);
+    }
+    hipLaunchKernelGGL(bn_eval_aff_kernel, dim3(cdiv(fmax, 256), n), dim3(256), 0, (hipStream_t)stream, t);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
 
 extern "C" int i3d_bn_finalize_partials(const float* partial, int n_tiles, int feat, float eps, float momentum,
                                         const float* gamma, const float* beta, float* mean, float* invstd,

@@ -366,8 +366,21 @@ extern "C" int i3d_pna_model_fwd(const I3dPnaModel* m, const I3dPnaBatch* b, flo
             hoisted = true;
         }
     }
+    const int eval_mode = m->training ? 0 : 1;
+    if (eval_mode) {      // every BatchNorm in front of a consumer that applies it on load: its affine vector from the running statistics
+        I3dBnEvalAff ea[64];
+        int n = 0;
+        for (int l = 0; l < L; ++l)
+            for (int i = 0; i < m->n_pre; ++i) {
+                const I3dFcParams& p = m->pre[l][i];
+                I3D_CHECK_ARG(n < 64, "eval mode: at most 64 pretrans BatchNorms");
+                ea[n++] = I3dBnEvalAff{p.running_mean, p.running_var, p.gamma, p.beta, c->layers[l].aff[i], p.f_out, p.eps};
+            }
+        TRY(i3d_bn_eval_aff_multi(ea, n, stream));
+    }
     for (int l = 0; l < L; ++l) {
         I3dPnaLayerArgs& a = c->layers[l];
+        a.eval_mode = eval_mode;
         a.weights_ready = (hoisted && l >= 1) ? 1 : 0;
         if (hoisted && l == 1) TRY(i3d_wgrad_stream_join(stream));
         set_ws(a.edge.tail, bn_workspace, nullptr, 0);
@@ -386,7 +399,13 @@ extern "C" int i3d_pna_model_fwd(const I3dPnaModel* m, const I3dPnaBatch* b, flo
     for (int i = 0; i < m->n_head; ++i) {
         I3dFcArgs& fc = c->head_args[i];
         const I3dFcParams& p = m->head[i];
-        if (p.gamma != nullptr) {
+        if (p.gamma != nullptr && eval_mode) {
+            float* lin = fc.pre_keep ? fc.pre_keep : fc.xact;
+            TRY(i3d_gemm_f32(0, 1, B, p.f_out, p.f_in, fc.x, p.f_in, p.W, p.f_in, lin, p.f_out, p.bias, 0, stream));
+            if (p.act != I3D_ACT_NONE) TRY(i3d_act_fwd(lin, (long)B * p.f_out, p.act, fc.xact, stream));
+            TRY(i3d_bn_eval_fwd(fc.xact, B, p.f_out, p.running_mean, p.running_var, p.eps, p.gamma, p.beta, I3D_ACT_NONE, nullptr,
+                                fc.y, stream));
+        } else if (p.gamma != nullptr) {
             set_ws(fc.tail, bn_workspace, nullptr, 0);
             TRY(i3d_fc_bn_fwd(&fc, stream));
         } else if (p.act != I3D_ACT_NONE) {

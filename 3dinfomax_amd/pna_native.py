@@ -37,7 +37,12 @@ def _fc_ok(fc, need_bn):
 
 def eligible(module, g):
     """cheap per-call checks; the structural ones are cached on the module"""
-    if not (NATIVE_MODEL and layer_native.FUSED_BN and layer_native.NATIVE_LAYER and module.training and torch.is_grad_enabled()):
+    if not (NATIVE_MODEL and layer_native.FUSED_BN and layer_native.NATIVE_LAYER):
+        return False
+    # training mode (with or without autograd: the reference's inference.py runs train-mode BatchNorm under no_grad), or
+    # eval mode without autograd - the validation pass of trainer/trainer.py:72-78 (BatchNorm with running statistics,
+    # forward only: csrc/model.hip I3dPnaModel.training = 0)
+    if not module.training and torch.is_grad_enabled():
         return False
     if tape.active() is not None or not tape.FUSED_MODEL:
         return False
@@ -56,8 +61,12 @@ def eligible(module, g):
     for fc in ent[2]:                            # dist.setup(sync_bn=True) may attach a group after the first forward
         if fc.sync_group is not None:
             return False
-    if not _layers._composite_ok(ent[2][0].hot()[4]):      # the gate of the block composites (training, local statistics)
-        return False
+    for fc in ent[2]:                            # every block in the model's mode (a frozen BatchNorm inside a training model:
+        bn = fc.batch_norm                       # the per-block path)
+        if fc.training != module.training or (bn is not None and bn.training != module.training):
+            return False
+    if not _layers.COMPOSITE or (module.training and not _layers._composite_ok(ent[2][0].hot()[4])):
+        return False                             # the gate of the block composites (local statistics)
     feat = g.ndata.get('feat')
     ef = g.edata.get('feat')
     if feat is None or ef is None or not feat.is_cuda or feat.dtype != torch.int64 or ef.dtype != torch.int64:
@@ -137,6 +146,7 @@ def _describe(module, grads=None):
     m = _lib.PnaModel()
     first = gnn.mp_layers[0]
     hidden = gnn.atom_encoder.atom_embedding_list[0].embedding_dim
+    m.training = 1
     m.n_layers, m.hidden, m.residual = len(gnn.mp_layers), hidden, 1 if first.residual else 0
     m.n_pre = len(first.pretrans.fully_connected)
     m.n_aggregators = len(first.aggregators)
@@ -236,6 +246,7 @@ class PNAModelFn(torch.autograd.Function):
             desc = _describe(module)
             desc.param_ids = ids
             module.__dict__['_i3d_desc_fwd'] = desc
+        desc.struct.training = 1 if module.training else 0
         atom_feat, bond_feat = g.ndata['feat'].contiguous(), g.edata['feat'].contiguous()
         b, comb = _batch_struct(g, idx, gnn)
         b.atom_feat, b.bond_feat = atom_feat.data_ptr(), bond_feat.data_ptr()

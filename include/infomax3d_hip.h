@@ -519,7 +519,22 @@ typedef struct { /* one PNA layer, reference models/pna.py:199-216: pretrans edg
     float* aff[I3D_MAX_EXTRA_FC + 1];  /* [3 f_out] mean | gamma invstd | beta of the edge block and of pre[i] (saved) */
     int weights_ready; /* forward (fused_bn): edge.Q and post.WD - products of parameters and the bond table only - are already
                         * there (i3d_pna_layer_weights_fwd, e.g. on the side stream while the layers before this one run) */
+    int eval_mode;     /* forward (fused_bn) in eval(): BatchNorm with the running statistics (reference: nn.BatchNorm1d in eval
+                        * mode, trainer/trainer.py:75 model.eval()) - aff[i] already hold mean | gamma / sqrt(var + eps) | beta
+                        * (i3d_bn_eval_aff_multi), no statistics are finalised, no running statistic is touched */
 } I3dPnaLayerArgs;
+
+/* eval-mode affine vector of one BatchNorm: aff [3 feat] = running_mean | gamma / sqrt(running_var + eps) | beta */
+typedef struct {
+    const float* running_mean;
+    const float* running_var;
+    const float* gamma;
+    const float* beta;
+    float* aff;
+    int feat;
+    float eps;
+} I3dBnEvalAff;
+int i3d_bn_eval_aff_multi(const I3dBnEvalAff* entries /* host */, int n, void* stream);
 
 /* floats of I3dPnaLayerArgs.stats_ws for a layer with these dimensions (f = widest block output) */
 long i3d_pna_layer_stats_floats(int num_nodes, int num_edges, int m_padded, int f);
@@ -622,6 +637,8 @@ typedef struct { /* one FCLayer: Linear + optional BatchNorm1d (reference models
 } I3dFcParams;
 
 typedef struct {
+    int training; /* 1: BatchNorm with batch statistics (running statistics updated); 0: eval mode, forward only (the
+                   * validation pass of trainer/trainer.py:72-78) */
     int n_layers, hidden, n_pre, residual;
     int n_aggregators, aggregators[8];
     int n_scalers, scalers[4];

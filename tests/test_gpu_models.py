@@ -587,6 +587,51 @@ def test_native_adam_with_unequal_step_counts_a_moved_parameter_and_an_lr_schedu
     del oa2, ob2, optim_mod
 
 
+def test_eval_and_no_grad_forward_through_the_native_sequencer(amd, monkeypatch):
+    """The validation pass of the reference (trainer/trainer.py:72-78: model.eval() under no_grad) and inference.py's
+    train-mode forward under no_grad run through the whole-model C sequencer: same output and node embeddings as the
+    per-block path, eval mode leaves every BatchNorm buffer untouched, train mode under no_grad updates them."""
+    native = importlib.import_module('3dinfomax_amd.pna_native')
+    mols = synth.make_dataset(48, seed=33)
+    pna = amd.PNA(avg_d=1.0, device='cuda:0', **dict(PNA_YML, propagation_depth=3)).cuda().train()
+    _det_load(pna, 'pnaEval')
+    calls = []
+    real_run = native.run
+    monkeypatch.setattr(native, 'run', lambda *a, **k: (calls.append(1), real_run(*a, **k))[1])
+    sd0 = {k: v.clone() for k, v in pna.state_dict().items()}
+
+    def fwd(native_on, train):
+        pna.load_state_dict(sd0)
+        pna.train(train)
+        monkeypatch.setattr(native, 'NATIVE_MODEL', native_on)
+        g2, _ = make_batch(amd, mols)
+        with torch.no_grad():
+            out = pna(g2)
+        return out.clone(), g2.ndata['feat'].clone(), {k: v.clone() for k, v in pna.state_dict().items()}
+    for train in (False, True):
+        n0 = len(calls)
+        a = fwd(True, train)
+        assert len(calls) == n0 + 1, 'the native sequencer must take this call'
+        b = fwd(False, train)
+        assert len(calls) == n0 + 1
+        assert rel_err(a[0].cpu(), b[0].cpu()) < 1e-5 and rel_err(a[1].cpu(), b[1].cpu()) < 1e-5
+        for k in sd0:
+            if 'running' in k or 'num_batches' in k:
+                if train:
+                    assert close(a[2][k].cpu(), b[2][k].cpu(), 1e-5, 1e-7), k
+                    if 'num_batches' in k:
+                        assert int(a[2][k]) == int(sd0[k]) + 1
+                else:
+                    assert torch.equal(a[2][k], sd0[k]), k
+    # eval mode WITH autograd (gradients through frozen statistics) stays on the per-block path
+    pna.eval()
+    monkeypatch.setattr(native, 'NATIVE_MODEL', True)
+    g2, _ = make_batch(amd, mols)
+    n0 = len(calls)
+    pna(g2).sum().backward()
+    assert len(calls) == n0
+
+
 def test_parameter_gradients_stored_by_the_model_node(amd, monkeypatch):
     """tape.ModelFn stores `.grad` itself when the parameters are plain leaves: same values as through autograd's
     AccumulateGrad nodes (I3D_DIRECT_PARAM_GRADS=0), gradient accumulation over two backward passes still sums, and a
