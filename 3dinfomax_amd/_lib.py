@@ -124,6 +124,8 @@ _SIGNATURES = {
     'i3d_pna_model_bwd': (c_int, [_P, POINTER(PnaModel), _P, _P, _P, _P, c_long, _P]),
     'i3d_pna_model_bwd_part': (c_int, [_P, POINTER(PnaModel), _P, _P, _P, _P, c_long, c_int, c_int, _P]),
     'i3d_pna_model_ctx_free': (c_int, [_P]),
+    'i3d_pna_messages_normalized': (c_int, [_P, _P, c_long, c_int, _P, _P]),
+    'i3d_pna_model_debug_messages': (c_int, [_P, c_int, _P, _P]),
     'i3d_event_create': (c_int, [POINTER(c_void_p)]),
     'i3d_event_destroy': (c_int, [_P]),
     'i3d_event_record': (c_int, [_P, _P]),

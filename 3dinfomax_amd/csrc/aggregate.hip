@@ -567,6 +567,26 @@ extern "C" int i3d_pna_aggregate_bwd_aff(const float* grad_out, const float* e, 
     return I3D_OK;
 }
 
+// debug / test entry: the messages exactly as the aggregation kernels see them, (e - mean) * scale + shift with the same
+// expression (and the same -ffp-contract=off build) - a test derives the kernels' arg-max / arg-min choices from them
+__global__ void __launch_bounds__(256) pna_messages_kernel(const float* __restrict__ e, const float* __restrict__ aff, long rows,
+                                                           int F, float* __restrict__ out) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * F) return;
+    const int c = (int)(t % F);
+    float a_mu = 0.f, a_sc = 1.f, a_sh = 0.f;
+    if (aff != nullptr) { a_mu = aff[c]; a_sc = aff[F + c]; a_sh = aff[2 * F + c]; }
+    out[t] = aff != nullptr ? (e[t] - a_mu) * a_sc + a_sh : e[t];
+}
+
+extern "C" int i3d_pna_messages_normalized(const float* e, const float* aff, long rows, int feat, float* out, void* stream) {
+    I3D_CHECK_ARG(e != nullptr && out != nullptr && rows >= 0 && feat > 0, "bad arguments");
+    if (rows == 0) return I3D_OK;
+    hipLaunchKernelGGL(pna_messages_kernel, dim3(cdiv(rows * feat, 256)), dim3(256), 0, (hipStream_t)stream, e, aff, rows, feat, out);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
 // ---- K6: per-graph readout = the same segmented reduction driven by graph_ptr, no scalers ---------------
 // reference models/pna.py:133-134, models/net3d.py:73-74 (dgl.readout_nodes for op in readout_aggregators + cat)
 extern "C" int i3d_segment_readout_fwd(const float* x, const int* graph_ptr, int num_graphs, int feat, const int* ops,

@@ -558,6 +558,17 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
     return I3D_OK;
 }
 
+// test entry: the messages of layer `layer` as its aggregation kernels read them (saved activation of the last pretrans
+// block with its BatchNorm applied on load), [E, f_msg] in destination-sorted order
+extern "C" int i3d_pna_model_debug_messages(void* ctx, int layer, float* out, void* stream) {
+    I3D_CHECK_ARG(ctx != nullptr && out != nullptr, "null");
+    PnaCtx* c = static_cast<PnaCtx*>(ctx);
+    I3D_CHECK_ARG(layer >= 0 && layer < c->m.n_layers, "layer out of range");
+    const I3dPnaLayerArgs& a = c->layers[layer];
+    const int f_msg = a.n_pre_extra > 0 ? a.pre[a.n_pre_extra - 1].f_out : a.edge.f_out;
+    return i3d_pna_messages_normalized(a.msg, a.aff[a.n_pre_extra], a.edge.num_edges, f_msg, out, stream);
+}
+
 extern "C" int i3d_pna_model_ctx_free(void* ctx) {
     delete static_cast<PnaCtx*>(ctx);
     return I3D_OK;

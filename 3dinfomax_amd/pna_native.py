@@ -363,3 +363,16 @@ def run(module, g):
     g.ndata['feat'] = node_emb           # reference models/pna.py:213
     g.edata['feat'] = edge_emb           # reference models/pna.py:163
     return out
+
+
+def debug_messages(out, layer, num_edges, feat):
+    """test hook: the messages of `layer` as the aggregation kernels of the forward pass that produced `out` read them,
+    [E, feat] in destination-sorted order (csrc/model.hip: i3d_pna_model_debug_messages)"""
+    node = out.grad_fn
+    handle = getattr(node, 'handle', None)
+    if handle is None:
+        raise RuntimeError('not the output of the native PNA sequencer (or its backward pass has already run)')
+    msg = torch.empty(num_edges, feat, dtype=torch.float32, device=out.device)
+    _lib.check(_lib.load().i3d_pna_model_debug_messages(handle.ptr, layer, msg.data_ptr(), ops._stream()),
+               'i3d_pna_model_debug_messages')
+    return msg

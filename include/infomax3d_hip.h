@@ -690,6 +690,11 @@ int i3d_pna_model_bwd(void* ctx, const I3dPnaModel* grads_from, const float* gra
 int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, const float* grad_out, float* scratch, void* bn_workspace,
                            void* gemm_workspace, long gemm_workspace_bytes, int part, int split, void* stream);
 int i3d_pna_model_ctx_free(void* ctx);
+/* test entries: out [rows, feat] = (e - mean) * scale + shift exactly as i3d_pna_aggregate_*_aff read the messages
+ * (aff = mean | scale | shift, NULL: a copy); the messages of one layer of a forward pass from its context, [E, f_msg] in
+ * destination-sorted order - the tests derive the kernels' arg-max / arg-min routing from them */
+int i3d_pna_messages_normalized(const float* e, const float* aff, long rows, int feat, float* out, void* stream);
+int i3d_pna_model_debug_messages(void* ctx, int layer, float* out, void* stream);
 
 /* ---- Adam step of all parameter tensors in one launch (csrc/adam.hip; reference: torch.optim.Adam built by name,
  * train.py:189, stepped at trainer/trainer.py:120).  chunk_table: device array of n_chunks records {float* param,

@@ -87,9 +87,9 @@ def _csr_by_dst(dst, n):
     return deg, order, rowptr
 
 
-def degree_bucketed_reduce(msgs, dst, n, reduce_fn, out_dim):
+def degree_bucketed_reduce(msgs, dst, n, reduce_fn, out_dim, with_nodes=False):
     """update_all with a UDF reduce: one call per distinct in-degree D>0, mailbox [n_D, D, F] ordered by
-    edge id; isolated nodes get zeros."""
+    edge id; isolated nodes get zeros.  with_nodes: reduce_fn(mailbox, D, nodes) (test routing, see pna_reduce)."""
     deg, order, rowptr = _csr_by_dst(dst, n)
     out = torch.zeros(n, out_dim, dtype=msgs.dtype)
     for D in sorted(set(deg.tolist())):
@@ -97,32 +97,54 @@ def degree_bucketed_reduce(msgs, dst, n, reduce_fn, out_dim):
             continue
         nodes = torch.nonzero(deg == D).flatten()
         eids = order[rowptr[nodes][:, None] + torch.arange(D)[None, :]]
-        out = out.index_copy(0, nodes, reduce_fn(msgs[eids], D))
+        out = out.index_copy(0, nodes, reduce_fn(msgs[eids], D, nodes) if with_nodes else reduce_fn(msgs[eids], D))
     return out
 
 
-def segment_readout(x, batch_num_nodes, op):
-    """dgl.readout_nodes: per-graph segment reduce in batch order."""
-    outs, start = [], 0
-    for n in batch_num_nodes:
+def first_argext(h, largest=True):
+    """index of the FIRST maximum / minimum along dim -2 (what torch.max / torch.min(dim) route their gradient to on CPU,
+    SURVEY.md Appendix A, and what the HIP kernels pick)"""
+    ext = h.max(dim=-2, keepdim=True)[0] if largest else h.min(dim=-2, keepdim=True)[0]
+    return (h == ext).to(torch.uint8).argmax(dim=-2)
+
+
+def routed_ext(h, idx):
+    """max / min along dim -2 with the gradient routed to the GIVEN position idx [..., F] (test infrastructure: the GPU
+    parity tests pass the positions the HIP kernels picked, so that a near-tie that fp32 rounding resolves differently on
+    the two sides does not move whole gradient rows; the forward value differs from the true extremum by the tie's gap)"""
+    return h.gather(-2, idx.unsqueeze(-2)).squeeze(-2)
+
+
+def segment_readout(x, batch_num_nodes, op, route=None, capture=None):
+    """dgl.readout_nodes: per-graph segment reduce in batch order.  route: {'max': [B, F], 'min': [B, F]} positions inside
+    each graph the max / min gradients are routed to (tests); capture: receives this side's own first-extremum positions."""
+    outs, start, own = [], 0, []
+    for b, n in enumerate(batch_num_nodes):
         seg = x[start:start + n]
         start += n
+        if op in ('max', 'min') and capture is not None:
+            own.append(first_argext(seg, op == 'max'))
+        if op in ('max', 'min') and route is not None and op in route:
+            outs.append(routed_ext(seg, route[op][b]))
+            continue
         outs.append({'sum': lambda s: s.sum(0), 'mean': lambda s: s.mean(0),
                      'max': lambda s: s.max(0)[0], 'min': lambda s: s.min(0)[0]}[op](seg))
+    if own:
+        capture[op] = torch.stack(own, 0)
     return torch.stack(outs, 0)
 
 
 # ------------------------------------------------------------------------------------------
 # PNA: reference models/pna.py
 # ------------------------------------------------------------------------------------------
-def aggregate(h, name):
-    """reference models/pna.py:17-50; h is a mailbox [n, D, F]."""
+def aggregate(h, name, route=None):
+    """reference models/pna.py:17-50; h is a mailbox [n, D, F].  route (tests): [n, F] positions for max / min."""
     if name == 'mean':
         return torch.mean(h, dim=-2)
     if name == 'max':
-        return torch.max(h, dim=-2)[0]
+        return routed_ext(h, route) if route is not None else torch.max(h, dim=-2)[0]
     if name == 'min':
-        return torch.min(h, dim=-2)[0]
+        return routed_ext(h, route) if route is not None else torch.min(h, dim=-2)[0]
     if name == 'sum':
         return torch.sum(h, dim=-2)
     if name in ('var', 'std'):
@@ -144,26 +166,35 @@ def scale(h, name, D, avg_d_log=1.0):
     raise ValueError(name)
 
 
-def pna_reduce(mailbox, D, aggregators, scalers, avg_d_log=1.0):
-    """reference models/pna.py:221-235 (reduce_func)."""
-    h = torch.cat([aggregate(mailbox, a) for a in aggregators], dim=-1)
+def pna_reduce(mailbox, D, aggregators, scalers, avg_d_log=1.0, route=None):
+    """reference models/pna.py:221-235 (reduce_func).  route (tests): {'max': [n, F], 'min': [n, F]} mailbox positions."""
+    h = torch.cat([aggregate(mailbox, a, route.get(a) if route is not None else None) for a in aggregators], dim=-1)
     if len(scalers) > 1:   # reference quirk: a single scaler is never applied (:232)
         h = torch.cat([scale(h, s, D, avg_d_log) for s in scalers], dim=-1)
     return h
 
 
-def pna_layer(h, ef, src, dst, P, prefix, cfg, training, capture=None):
-    """reference models/pna.py:199-252 (PNALayer.forward / pretrans_edges)."""
+def pna_layer(h, ef, src, dst, P, prefix, cfg, training, capture=None, route=None):
+    """reference models/pna.py:199-252 (PNALayer.forward / pretrans_edges).  route (tests): {'max': [N, F], 'min': [N, F]}
+    mailbox positions the max / min gradients of every node are routed to; capture receives this side's own choices."""
     n = h.shape[0]
     z = torch.cat([h[src], h[dst], ef], dim=-1)                          # :249
     e = mlp(z, P, f'{prefix}.pretrans', cfg['pretrans_layers'], cfg['activation'], cfg['last_activation'],
             cfg['mid_batch_norm'], cfg['last_batch_norm'], cfg['batch_norm_momentum'], training)   # :252
     n_out = len(cfg['aggregators']) * (len(cfg['scalers']) if len(cfg['scalers']) > 1 else 1) * h.shape[1]
-    agg = degree_bucketed_reduce(e, dst, n,
-                                 lambda mb, D: pna_reduce(mb, D, cfg['aggregators'], cfg['scalers']), n_out)  # :206
+    own = {'max': torch.zeros(n, e.shape[1], dtype=torch.long), 'min': torch.zeros(n, e.shape[1], dtype=torch.long)}
+
+    def reduce_fn(mb, D, nodes):
+        if capture is not None:
+            own['max'][nodes] = first_argext(mb.detach(), True)
+            own['min'][nodes] = first_argext(mb.detach(), False)
+        r = {k: v[nodes].clamp(max=D - 1) for k, v in route.items()} if route is not None else None
+        return pna_reduce(mb, D, cfg['aggregators'], cfg['scalers'], route=r)
+    agg = degree_bucketed_reduce(e, dst, n, reduce_fn, n_out, with_nodes=True)  # :206
     if capture is not None:
         capture['e'] = e
         capture['agg'] = agg
+        capture['argext'] = own
     hcat = torch.cat([h, agg], dim=-1)                                    # :207
     out = mlp(hcat, P, f'{prefix}.posttrans', cfg['posttrans_layers'], cfg['activation'], cfg['last_activation'],
               cfg['mid_batch_norm'], cfg['last_batch_norm'], cfg['batch_norm_momentum'], training)   # :209
@@ -172,7 +203,7 @@ def pna_layer(h, ef, src, dst, P, prefix, cfg, training, capture=None):
     return out
 
 
-def pna_forward(graph, P, cfg, training=True, capture=None):
+def pna_forward(graph, P, cfg, training=True, capture=None, route=None):
     """reference models/pna.py:131-135 (PNA.forward) and :161-166 (PNAGNN.forward).
 
     graph: dict(src, dst [E] int64; atom_feat [N,9]; bond_feat [E,3]; batch_num_nodes list[int]).
@@ -183,8 +214,11 @@ def pna_forward(graph, P, cfg, training=True, capture=None):
         cap = None
         if capture is not None:
             cap = capture.setdefault(f'layer{l}', {})
-        h = pna_layer(h, ef, graph['src'], graph['dst'], P, f'node_gnn.mp_layers.{l}', cfg, training, cap)
-    r = torch.cat([segment_readout(h, graph['batch_num_nodes'], op) for op in cfg['readout_aggregators']], dim=-1)
+        h = pna_layer(h, ef, graph['src'], graph['dst'], P, f'node_gnn.mp_layers.{l}', cfg, training, cap,
+                      route.get(f'layer{l}') if route is not None else None)
+    rcap = capture.setdefault('readout', {}) if capture is not None else None
+    r = torch.cat([segment_readout(h, graph['batch_num_nodes'], op, route.get('readout') if route is not None else None, rcap)
+                   for op in cfg['readout_aggregators']], dim=-1)
     out = mlp(r, P, 'output', cfg.get('readout_layers', 2), 'relu', 'none', cfg.get('readout_batchnorm', True), False,
               cfg['batch_norm_momentum'], training)                       # :127-129
     return out, h

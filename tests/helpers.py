@@ -83,3 +83,61 @@ def grads_close_l2(got, ref, rtol, what='', floor=5e-6):
         err = (a - b).norm().item()
         bound = rtol * b.norm().item() + floor * scale      # floor: analytically-zero gradients (a shift a later BatchNorm removes)
         assert err <= bound, f'{what}{k}: L2 err {err:.3e} > {bound:.3e}'
+
+
+def _segment_first_argext(values, ptr, largest):
+    """[n_segments, F] position (inside its segment) of the first maximum / minimum of every column; values [rows, F],
+    ptr [n_segments + 1]; empty segments get 0"""
+    from oracle import pna3d_oracle as O
+    n = ptr.shape[0] - 1
+    deg = ptr[1:] - ptr[:-1]
+    out = torch.zeros(n, values.shape[1], dtype=torch.long)
+    for D in sorted(set(deg.tolist())):
+        if D == 0:
+            continue
+        segs = torch.nonzero(deg == D).flatten()
+        rows = ptr[segs][:, None] + torch.arange(D)[None, :]
+        out[segs] = O.first_argext(values[rows], largest)
+    return out
+
+
+def hip_routing(pna, g2, out):
+    """The mailbox / graph positions the HIP kernels of this forward pass route their max / min gradients to, in the form
+    oracle.pna_forward(route=...) takes: per layer from the messages exactly as the aggregation kernels read them
+    (pna_native.debug_messages: same expression, same build flags), for the readout from the node embeddings the forward
+    left on the graph.  Call it BEFORE backward() (the forward context is released there)."""
+    import importlib
+    native = importlib.import_module('3dinfomax_amd.pna_native')
+    idx = g2.index()
+    in_ptr, graph_ptr = idx.in_ptr.cpu().long(), idx.graph_ptr.cpu().long()
+    route = {}
+    for l, layer in enumerate(pna.node_gnn.mp_layers):
+        f_msg = list(layer.pretrans.fully_connected)[-1].out_dim
+        msg = native.debug_messages(out, l, idx.num_edges, f_msg).cpu()
+        route[f'layer{l}'] = {'max': _segment_first_argext(msg, in_ptr, True), 'min': _segment_first_argext(msg, in_ptr, False)}
+    emb = g2.ndata['feat'].detach().cpu()
+    route['readout'] = {'max': _segment_first_argext(emb, graph_ptr, True), 'min': _segment_first_argext(emb, graph_ptr, False)}
+    return route
+
+
+def routing_flips(route, capture, n_layers):
+    """(positions where the oracle's own first extremum differs from the routed one, positions compared) over all layers and
+    the readout, and the largest gap - relative to the tensor's scale - between the oracle's values at the two positions of a
+    flip: a flip is legitimate only as a NEAR-TIE (two candidates that agree to fp32 rounding)."""
+    flips = total = 0
+    worst = 0.0
+    for l in range(n_layers):
+        cap = capture[f'layer{l}']
+        e = cap['e'].detach()
+        own = cap['argext']
+        for kind in ('max', 'min'):
+            d = own[kind] != route[f'layer{l}'][kind]
+            flips += int(d.sum())
+            total += d.numel()
+    own = capture.get('readout', {})
+    for kind in ('max', 'min'):
+        if kind in own:
+            d = own[kind] != route['readout'][kind]
+            flips += int(d.sum())
+            total += d.numel()
+    return flips, total

@@ -63,3 +63,54 @@ def test_launcher_rebinds_plugin_names_without_editing_the_script(tmp_path):
     assert r.returncode == 0, r.stderr
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('RESULT ')][0][len('RESULT '):])
     assert out['optimizer'].startswith('torch.optim') and out['loss'] == 'commons_losses' and out['model'] == '3dinfomax_amd.pna'
+
+
+REFERENCE_TRAIN = '/root/reference/train.py'
+
+
+def test_launcher_against_the_reference_train_py_itself():
+    """Build container only (the reference tree does not travel to the GPU box): the launcher's two assumptions about the
+    REAL file - (1) it has a top-level `if __name__ == '__main__':` block main_block() can lift, (2) every plugin name the
+    package exports that train.py resolves at call time through `globals()[...]` reaches train.py's namespace through one
+    of its star-imports (so rebinding that namespace is what the lookups see) - checked on its syntax tree, without
+    executing it (its imports need dgl / ogb / rdkit)."""
+    import ast
+
+    import pytest
+    if not os.path.exists(REFERENCE_TRAIN):
+        pytest.skip('reference tree not present')
+    sys.path.insert(0, ROOT)
+    launcher = importlib.import_module('launch_reference')
+    with open(REFERENCE_TRAIN) as f:
+        src = f.read()
+    code = launcher.main_block(src, REFERENCE_TRAIN)
+    assert 'get_arguments' in code.co_names and 'train' in code.co_names      # reference train.py:644-700
+    tree = ast.parse(src)
+    stars = [n.module for n in tree.body if isinstance(n, ast.ImportFrom) and any(a.name == '*' for a in n.names)]
+    # the star-imports the plugin's names arrive through (train.py:50-56)
+    for mod in ('models', 'commons.losses', 'datasets.custom_collate', 'torch.optim'):
+        assert mod in stars, (mod, stars)
+    # every globals()[args.<key>] lookup of the file: the keys the plugin must serve
+    lookups = set()
+    for node in ast.walk(tree):
+        if (isinstance(node, ast.Subscript) and isinstance(node.value, ast.Call) and isinstance(node.value.func, ast.Name)
+                and node.value.func.id == 'globals'):
+            key = node.slice
+            if isinstance(key, ast.Attribute):
+                lookups.add(key.attr)
+    assert {'model_type', 'model3d_type', 'loss_func', 'optimizer', 'collate_function'} <= lookups, lookups
+    names = launcher.plugin_names()
+    for n in ('PNA', 'Net3D', 'NTXent', 'NTXentMultiplePositives', 'Adam', 'contrastive_collate', 'conformer_collate',
+              'graph_collate', 'PNAOriginal', 'PNAOriginalSimple'):
+        assert n in names, n
+    # the reference defines each of them in a module one of those star-imports covers
+    ref_root = os.path.dirname(REFERENCE_TRAIN)
+    defined = {}
+    for rel in ('models/pna.py', 'models/net3d.py', 'models/pna_original.py', 'commons/losses.py', 'datasets/custom_collate.py'):
+        with open(os.path.join(ref_root, rel)) as f:
+            for node in ast.parse(f.read()).body:
+                if isinstance(node, (ast.ClassDef, ast.FunctionDef)):
+                    defined[node.name] = rel
+    for n in ('PNA', 'Net3D', 'NTXent', 'NTXentMultiplePositives', 'contrastive_collate', 'conformer_collate', 'graph_collate',
+              'PNAOriginal', 'PNAOriginalSimple'):
+        assert n in defined, n
