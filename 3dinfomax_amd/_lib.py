@@ -101,6 +101,15 @@ class BnEvalAff(ctypes.Structure):
                 ('eps', c_float)]
 
 
+ALL_GATHER_F32 = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p)
+ALL_REDUCE_F64 = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_long, c_void_p)
+
+
+class Collectives(ctypes.Structure):
+    _fields_ = [('world', c_int), ('all_gather_f32', ALL_GATHER_F32), ('all_reduce_f64', ALL_REDUCE_F64), ('user', _P),
+                ('scratch', _P), ('scratch_bytes', c_long)]
+
+
 class WgradProblem(ctypes.Structure):
     _fields_ = [('A', _P), ('B', _P), ('rows', _P), ('rows_total', c_long), ('lda', c_int), ('ldb', c_int), ('M', c_int),
                 ('N', c_int), ('k_begin', c_int), ('k_count', c_int)]
@@ -114,6 +123,13 @@ class WgradOutput(ctypes.Structure):
 
 _SIGNATURES = {
     'i3d_bn_eval_aff_multi': (c_int, [POINTER(BnEvalAff), c_int, _P]),
+    'i3d_set_collectives': (c_int, [POINTER(Collectives)]),
+    'i3d_collectives_world': (c_int, []),
+    'i3d_rccl_available': (c_int, []),
+    'i3d_rccl_unique_id': (c_int, [ctypes.c_char_p]),
+    'i3d_rccl_init': (c_int, [ctypes.c_char_p, c_int, c_int, POINTER(c_void_p)]),
+    'i3d_rccl_destroy': (c_int, [_P]),
+    'i3d_set_collectives_rccl': (c_int, [_P, c_int, _P, c_long]),
     'i3d_wgrad_multi_supported': (c_int, [POINTER(WgradProblem), c_int, POINTER(WgradOutput), c_int]),
     'i3d_wgrad_multi_workspace_bytes': (c_long, [c_int]),
     'i3d_wgrad_multi_min_workspace_bytes': (c_long, [POINTER(WgradProblem), c_int]),

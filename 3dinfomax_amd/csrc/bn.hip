@@ -350,9 +350,11 @@ __global__ void stats_final_kernel(const float* __restrict__ partial, int nblk, 
 }
 
 __global__ void stats_from_sums_kernel(const double* __restrict__ sums, int feat, float eps, float momentum, float* mean,
-                                       float* invstd, float* running_mean, float* running_var) {
+                                       float* invstd, float* running_mean, float* running_var,
+                                       long long* batches_tracked = nullptr) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= feat) return;
+    if (c == 0 && batches_tracked != nullptr) *batches_tracked += 1;
     double n = sums[2 * feat];
     double m = sums[c] / n;
     double var = sums[feat + c] / n - m * m;
@@ -730,6 +732,8 @@ static void launch_reduction(const ReduceArgs& g, const Chunking& ch, const Fina
                            f.out2, f.sums_out);
 }
 
+__global__ void set_double_kernel(double* p, double v) { *p = v; }
+
 }  // namespace i3d
 
 using namespace i3d;
@@ -752,6 +756,21 @@ extern "C" int i3d_act_stats_fwd_counted(const float* pre, int rows, int feat, i
     I3D_CHECK_ARG(rows > 0 && feat > 0, "rows > 0 and feat > 0 required");
     I3D_CHECK_ARG(workspace != nullptr, "workspace required");
     hipStream_t s = (hipStream_t)stream;
+    if (const I3dCollectives* coll = sums_out == nullptr ? collectives() : nullptr) {
+        // synchronised BatchNorm (comm.hip): un-shifted fp64 [sum, sum of squares, count] of this rank -> all-reduce on this
+        // stream -> mean / invstd / running statistics over all ranks
+        I3D_CHECK_ARG(coll->scratch_bytes >= (long)(2 * feat + 1) * 8, "collective scratch too small");
+        double* s64 = (double*)coll->scratch;
+        int rc = i3d_act_stats_fwd_counted(pre, rows, feat, act, x, eps, momentum, mean, invstd, nullptr, nullptr, s64, nullptr,
+                                           workspace, stream);
+        if (rc != I3D_OK) return rc;
+        rc = coll->all_reduce_f64(coll->user, s64, 2 * feat + 1, stream);
+        if (rc != I3D_OK) return rc;
+        hipLaunchKernelGGL(stats_from_sums_kernel, dim3(cdiv(feat, 128)), dim3(128), 0, s, s64, feat, eps, momentum, mean, invstd,
+                           running_mean, running_var, num_batches_tracked);
+        I3D_CHECK_LAUNCH();
+        return I3D_OK;
+    }
     Chunking ch = make_chunking(rows, feat);
     ReduceArgs g = {};
     g.a = pre; g.out = x; g.rows = rows; g.feat = feat; g.act = act; g.post_act = I3D_ACT_NONE;
@@ -847,6 +866,22 @@ extern "C" int i3d_bn_bwd_deferred_bias(const float* grad_y, const float* x, con
     I3D_CHECK_ARG(workspace != nullptr, "workspace required");
     I3D_CHECK_ARG(act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU || pre != nullptr, "pre required for this activation");
     hipStream_t s = (hipStream_t)stream;
+    if (const I3dCollectives* coll = (sums_out == nullptr && sums_in == nullptr) ? collectives() : nullptr) {
+        // synchronised BatchNorm (comm.hip): this rank's fp64 [sum dy, sum dy xhat] and row count -> all-reduce on this
+        // stream -> the data gradient from the sums over all ranks; grad_gamma / grad_beta keep this rank's share (the
+        // gradient all-reduce adds the ranks up)
+        I3D_CHECK_ARG(coll->scratch_bytes >= (long)(2 * feat + 1) * 8, "collective scratch too small");
+        double* s64 = (double*)coll->scratch;
+        int rc = i3d_bn_bwd_deferred_bias(grad_y, x, pre, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta,
+                                          nullptr, nullptr, s64, nullptr, rows, workspace, nullptr, stream);
+        if (rc != I3D_OK) return rc;
+        hipLaunchKernelGGL(set_double_kernel, dim3(1), dim3(1), 0, s, s64 + 2 * feat, (double)rows);
+        I3D_CHECK_LAUNCH();
+        rc = coll->all_reduce_f64(coll->user, s64, 2 * feat + 1, stream);
+        if (rc != I3D_OK) return rc;
+        return i3d_bn_bwd_deferred_bias(grad_y, x, pre, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta,
+                                        grad_pre, grad_bias, nullptr, s64, 0, workspace, bias_partial, stream);
+    }
     Chunking ch = make_chunking(rows, feat);
     float* partial = partial_of(workspace);
     if (sums_in == nullptr) {   // phase 1: column sums of dy and dy*xhat

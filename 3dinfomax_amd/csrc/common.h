@@ -10,6 +10,9 @@ namespace i3d {
 
 void set_error(const char* fmt, ...);
 
+// the process-wide collective table of synchronised BatchNorm (comm.hip), null when none is set
+const I3dCollectives* collectives();
+
 // Every C-ABI entry point returns 0 on success.  Launch errors are reported through
 // hipGetLastError() right after the launch (no device synchronisation: the caller's stream
 // stays asynchronous) and turned into a message retrievable with i3d_last_error().

@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256)
 bn_finalize_partials_kernel(const float* __restrict__ partial, int n_tiles, int feat, float eps, float momentum,
                             const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean,
                             float* __restrict__ invstd, float* running_mean, float* running_var,
-                            long long* batches_tracked, float* __restrict__ aff) {
+                            long long* batches_tracked, float* __restrict__ aff, float* __restrict__ triple_out = nullptr) {
     __shared__ double sm[2][FIN_LANES][FIN_COLS];
     const int cx = threadIdx.x & (FIN_COLS - 1), ly = threadIdx.x / FIN_COLS;
     const int c = blockIdx.x * FIN_COLS + cx;
@@ -106,6 +106,12 @@ bn_finalize_partials_kernel(const float* __restrict__ partial, int n_tiles, int 
     double m2 = 0.0;
 #pragma unroll
     for (int k = 0; k < FIN_LANES; ++k) m2 += sm[0][k][cx];
+    if (triple_out != nullptr) {        // synchronised BatchNorm: this rank's tiles merged into ONE {sum, M2, count} "tile"
+        triple_out[c] = (float)tot;
+        triple_out[feat + c] = (float)m2;
+        triple_out[2 * feat + c] = (float)n;
+        return;
+    }
     const double nn = n > 0.0 ? n : 1.0;
     const double var = m2 / nn;
     const float muf = (float)mu, is = (float)(1.0 / sqrt(var + (double)eps));
@@ -300,9 +306,24 @@ extern "C" int i3d_bn_finalize_partials(const float* partial, int n_tiles, int f
                                         float* aff, void* stream) {
     I3D_CHECK_ARG(partial != nullptr && n_tiles > 0 && feat > 0 && mean != nullptr && invstd != nullptr, "bad arguments");
     I3D_CHECK_ARG(aff == nullptr || (gamma != nullptr && beta != nullptr), "aff needs gamma and beta");
+    if (const I3dCollectives* coll = collectives()) {
+        // synchronised BatchNorm (comm.hip): local tiles -> one {sum, M2, count} triple -> all-gather on this stream -> the
+        // same exact merge over the ranks' triples (the parallel-axis theorem does not care whose tiles they are)
+        I3D_CHECK_ARG(coll->scratch_bytes >= (long)(1 + coll->world) * 3 * feat * 4, "collective scratch too small");
+        float* send = (float*)coll->scratch;
+        float* recv = send + 3L * feat;
+        hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial,
+                           n_tiles, feat, eps, momentum, gamma, beta, mean, invstd, (float*)nullptr, (float*)nullptr,
+                           (long long*)nullptr, (float*)nullptr, send);
+        I3D_CHECK_LAUNCH();
+        const int rc = coll->all_gather_f32(coll->user, send, recv, 3L * feat, stream);
+        if (rc != I3D_OK) return rc;
+        partial = recv;
+        n_tiles = coll->world;
+    }
     hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial,
                        n_tiles, feat, eps, momentum, gamma, beta, mean, invstd, running_mean, running_var,
-                       num_batches_tracked, aff);
+                       num_batches_tracked, aff, (float*)nullptr);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }

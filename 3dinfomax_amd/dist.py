@@ -127,14 +127,113 @@ def warm_up(device, steps=2):
     torch.cuda.synchronize(device)
 
 
+# I3D_NATIVE_SYNC_BN=0: synchronised BatchNorm only on the per-block Python path (round-2 behaviour)
+NATIVE_SYNC_BN = os.environ.get('I3D_NATIVE_SYNC_BN', '1') != '0'
+_native_sync = None      # (group, keep-alive objects) while the library's process-wide collectives are set
+
+
+def native_sync_active():
+    return _native_sync is not None
+
+
+def enable_native_sync(group, device):
+    """Synchronised BatchNorm from INSIDE the C sequencers (csrc/comm.hip): the library's BatchNorm entry points run their
+    collectives themselves, on the stream they are called on, while a process-wide collective table is set.  RCCL
+    ("nccl" backend): a communicator of the library's own, its id distributed through `group`; "gloo" (tests: ranks
+    sharing a GPU): host-staged callbacks.  Returns False when it cannot be set up (the per-block path then synchronises)."""
+    global _native_sync
+    from . import _lib
+    L = _lib.load()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    scratch = torch.zeros(1 << 20, dtype=torch.uint8, device=device)
+    if not _is_gloo(group):
+        if not L.i3d_rccl_available():
+            return False
+        import ctypes
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(L.i3d_rccl_unique_id(buf), 'i3d_rccl_unique_id')
+        box = [bytes(buf.raw)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not dist.group.WORLD else 0, group=group)
+        comm = ctypes.c_void_p()
+        torch.cuda.synchronize(device)
+        _lib.check(L.i3d_rccl_init(box[0], rank, world, ctypes.byref(comm)), 'i3d_rccl_init')
+        _lib.check(L.i3d_set_collectives_rccl(comm, world, scratch.data_ptr(), scratch.numel()), 'i3d_set_collectives_rccl')
+        _native_sync = (group, (scratch, comm))
+    else:
+        base = scratch.data_ptr()
+
+        def view(ptr, count, dtype):
+            n = count * (8 if dtype == torch.float64 else 4)
+            return scratch[ptr - base:ptr - base + n].view(dtype)
+
+        def all_gather(_user, send, recv, count, stream):
+            try:
+                torch.cuda.synchronize(device)          # (functional path: the stream's producers are done)
+                mine = view(send, count, torch.float32).cpu()
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine, group=group)
+                view(recv, count * world, torch.float32).copy_(torch.cat(parts))
+                torch.cuda.synchronize(device)
+                return 0
+            except Exception:      # noqa: BLE001 - reported through the C return code
+                import traceback
+                traceback.print_exc()
+                return -2
+
+        def all_reduce(_user, buf, count, stream):
+            try:
+                torch.cuda.synchronize(device)
+                t = view(buf, count, torch.float64)
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                t.copy_(h)
+                torch.cuda.synchronize(device)
+                return 0
+            except Exception:      # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return -2
+        cb_g, cb_r = _lib.ALL_GATHER_F32(all_gather), _lib.ALL_REDUCE_F64(all_reduce)
+        c = _lib.Collectives(world, cb_g, cb_r, None, scratch.data_ptr(), scratch.numel())
+        import ctypes
+        _lib.check(L.i3d_set_collectives(ctypes.byref(c)), 'i3d_set_collectives')
+        _native_sync = (group, (scratch, cb_g, cb_r, c))
+    # ONE stream issues the collectives of a communicator, in the same order on every rank: the 3D network joins the
+    # 2D network's stream, and its fused edge stage (whose backward reduces its BatchNorm sums in kernels of its own)
+    # gives way to the block path
+    from . import net3d_native, streams
+    streams.NET3D_STREAM = False
+    net3d_native.FUSED_EDGE = False
+    return True
+
+
+def disable_native_sync():
+    global _native_sync
+    if _native_sync is not None:
+        from . import _lib
+        _lib.load().i3d_set_collectives(None)
+        _native_sync = None
+
+
 def setup(modules, loss=None, group=None, sync_bn=False, broadcast=True):
-    """Attach `group` to every FCLayer (sync-BN) of `modules` and to the loss; broadcast rank-0 weights."""
+    """Attach `group` to every FCLayer (sync-BN) of `modules` and to the loss; broadcast rank-0 weights.
+
+    sync_bn: BatchNorm statistics over all ranks (the reference's statistics are over the whole batch it is given).  With
+    the library's own collectives (enable_native_sync) every code path - whole-model sequencer included - synchronises
+    inside the C calls and the modules need no group; otherwise the per-block Python path does it (FCLayer.sync_group)."""
     from .layers import FCLayer
     group = group if group is not None else dist.group.WORLD
+    native = False
+    if sync_bn and NATIVE_SYNC_BN:
+        dev = next((p.device for m in modules for p in m.parameters() if p.is_cuda), None)
+        native = dev is not None and enable_native_sync(group, dev)
+    elif not sync_bn:
+        disable_native_sync()
     for m in modules:
         for sub in m.modules():
             if isinstance(sub, FCLayer):
-                sub.sync_group = group if sync_bn else None
+                sub.sync_group = group if (sync_bn and not native) else None
         if broadcast:
             for t in list(m.parameters()) + list(m.buffers()):
                 if _is_gloo(group) and t.is_cuda:

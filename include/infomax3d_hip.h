@@ -324,6 +324,32 @@ int i3d_gemm_f32_fused(int M, int N, int K, const float* A, int lda, long a_rows
 int i3d_gemm_f32_wgrad_bn(int f_out, int f_in, int rows, const float* dY, int ldy, const float* x, int ldx, float* dW,
                           int ldw, const float* grad_bias, const float* aff, void* workspace, long workspace_bytes,
                           void* stream);
+/* ---- synchronised BatchNorm from inside the sequencers: process-wide collectives (csrc/comm.hip) ---------------------
+ * The reference's BatchNorm statistics are over the whole batch (models/base_layers.py:87, 100-111); with the batch
+ * sharded over ranks, i3d_bn_finalize_partials, i3d_act_stats_fwd[_counted] (sums_out NULL) and i3d_bn_bwd[_deferred_bias]
+ * (sums_out / sums_in NULL) synchronise their statistics over the ranks WHILE a collective table is set: local merge ->
+ * collective on the caller's stream -> finalisation over all ranks (running statistics = global, grad_gamma / grad_beta =
+ * this rank's share: the gradient all-reduce sums them).  world 1 runs the same sequence (self-test).
+ *   all_gather_f32: recv[world][count] <- every rank's send[count];  all_reduce_f64: buf[count] summed in place
+ *   scratch: device memory of the table's own (>= (4 + 3 world) * widest BatchNorm * 8 bytes; 1 MiB is plenty)
+ * RCCL provider: rank 0 i3d_rccl_unique_id -> (caller broadcasts the 128 bytes) -> every rank i3d_rccl_init ->
+ * i3d_set_collectives_rccl.  i3d_set_collectives(NULL): off.  One training per process. */
+typedef struct {
+    int world;
+    int (*all_gather_f32)(void* user, const float* send, float* recv, long count, void* stream);
+    int (*all_reduce_f64)(void* user, double* buf, long count, void* stream);
+    void* user;
+    void* scratch;
+    long scratch_bytes;
+} I3dCollectives;
+int i3d_set_collectives(const I3dCollectives* c /* host; copied */);
+int i3d_collectives_world(void); /* 0: none set */
+int i3d_rccl_available(void);
+int i3d_rccl_unique_id(char* out128 /* host */);
+int i3d_rccl_init(const char* id128 /* host */, int rank, int world, void** comm);
+int i3d_rccl_destroy(void* comm);
+int i3d_set_collectives_rccl(void* comm, int world, void* scratch, long scratch_bytes);
+
 /* ---- all weight gradients of a layer in ONE launch + one fixed-order reduction (csrc/wgrad.hip) ----------------------
  * Replaces autograd's dW = dY^T X of every nn.Linear of a PNA layer (reference models/base_layers.py:101; the Linears of
  * models/pna.py:186-197) - round 2 issued them as ~10 launches per layer.  A problem is one product

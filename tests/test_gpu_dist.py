@@ -45,17 +45,22 @@ def _batch(amd, mols):
             amd.batch([amd.complete_graph(m) for m in mols]).to('cuda:0'))
 
 
-def _worker(rank, port, path):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+def _worker(rank, port, path, native_sync):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), I3D_NATIVE_SYNC_BN='1' if native_sync else '0')
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     dist.init_process_group('gloo', rank=rank, world_size=WORLD)
     amd = importlib.import_module('3dinfomax_amd')
     adist = importlib.import_module('3dinfomax_amd.dist')
+    native = importlib.import_module('3dinfomax_amd.pna_native')
+    calls = []
+    real_run = native.run
+    native.run = lambda *a, **k: (calls.append(1), real_run(*a, **k))[1]
     mols = amd.synth.make_dataset(16, seed=21)
     pna, net = _models(amd)
     loss_fn = amd.NTXent(tau=0.1)
     adist.setup([pna, net], loss_fn, sync_bn=True)      # global-batch BN statistics: equals the single-process step
+    assert adist.native_sync_active() == native_sync
     g2, g3 = _batch(amd, adist.shard_molecules(mols, rank, WORLD))
     params = list(pna.parameters()) + list(net.parameters())
     if rank == 0:    # one rank delivers its gradients straight into the all-reduce buffer, the other through the copy path
@@ -64,6 +69,8 @@ def _worker(rank, port, path):
     share.backward()
     adist.allreduce_grads(params)
     total = adist.global_loss(share)
+    # the library's own collectives: the whole-model C sequencer takes the synchronised step (round 2: per-block path only)
+    assert len(calls) == (1 if native_sync else 0), calls
     if rank == 0:
         out = {'loss': total.item()}
         for tag, m in (('pna', pna), ('net', net)):
@@ -75,12 +82,15 @@ def _worker(rank, port, path):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_step_equals_full_batch(tmp_path):
+@pytest.mark.parametrize('native_sync', [True, False])
+def test_two_rank_sharded_step_equals_full_batch(tmp_path, native_sync):
+    """native_sync: BatchNorm synchronised inside the C sequencers (csrc/comm.hip, here with host-staged callbacks: RCCL
+    refuses two ranks on one device) - the whole-model sequencer runs; False: the per-block Python path of round 2."""
     assert torch.cuda.is_available()
     amd = importlib.import_module('3dinfomax_amd')
     from helpers import close, grads_close
     path = str(tmp_path / 'dp.npz')
-    mp.spawn(_worker, args=(_free_port(), path), nprocs=WORLD, join=True)
+    mp.spawn(_worker, args=(_free_port(), path, native_sync), nprocs=WORLD, join=True)
     z = np.load(path)
     mols = amd.synth.make_dataset(16, seed=21)
     pna, net = _models(amd)
@@ -225,3 +235,61 @@ def test_two_rank_uneven_shards_local_bn_and_early_allreduce(tmp_path):
     for tag, m in (('pna', pna), ('net', net)):
         ref = {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}
         grads_close({k: z[f'g/{tag}/{k}'] for k in ref}, ref, 2e-4, tag + ' ')
+
+
+def _rccl_worker(rank, port, path):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    amd = importlib.import_module('3dinfomax_amd')
+    adist = importlib.import_module('3dinfomax_amd.dist')
+    native = importlib.import_module('3dinfomax_amd.pna_native')
+    calls = []
+    real_run = native.run
+    native.run = lambda *a, **k: (calls.append(1), real_run(*a, **k))[1]
+    mols = amd.synth.make_dataset(16, seed=21)
+    pna, net = _models(amd)
+    loss_fn = amd.NTXent(tau=0.1)
+    adist.setup([pna, net], loss_fn, sync_bn=True)
+    ok = adist.native_sync_active() and importlib.import_module('3dinfomax_amd._lib').load().i3d_collectives_world() == 1
+    g2, g3 = _batch(amd, mols)
+    params = list(pna.parameters()) + list(net.parameters())
+    adist.grad_reducer(params, modules=[pna, net])
+    share = loss_fn(pna(g2), net(g3))
+    share.backward()
+    adist.allreduce_grads(params)
+    torch.cuda.synchronize()
+    out = {'loss': share.item(), 'ok': ok and len(calls) == 1}
+    for tag, m in (('pna', pna), ('net', net)):
+        for k, p in m.named_parameters():
+            out[f'g/{tag}/{k}'] = p.grad.cpu().numpy()
+        for k, b in m.named_buffers():
+            out[f'b/{tag}/{k}'] = b.cpu().numpy()
+    np.savez(path, **out)
+    adist.disable_native_sync()
+    dist.destroy_process_group()
+
+
+def test_rccl_provider_of_the_native_collectives_on_one_rank(tmp_path):
+    """The RCCL side of csrc/comm.hip (run-time binding, communicator of the library's own from a broadcast id,
+    ncclAllGather / ncclAllReduce enqueued on the sequencer's stream) on the one GPU a test box has: a world of one rank
+    runs every collective of the synchronised step and must reproduce the plain step."""
+    amd = importlib.import_module('3dinfomax_amd')
+    from helpers import close, grads_close
+    path = str(tmp_path / 'rccl1.npz')
+    mp.spawn(_rccl_worker, args=(_free_port(), path), nprocs=1, join=True)
+    z = np.load(path)
+    assert bool(z['ok'])
+    mols = amd.synth.make_dataset(16, seed=21)
+    pna, net = _models(amd)
+    g2, g3 = _batch(amd, mols)
+    loss = amd.NTXent(tau=0.1)(pna(g2), net(g3))
+    loss.backward()
+    assert abs(float(z['loss']) - loss.item()) < 1e-5 * abs(loss.item())
+    for tag, m in (('pna', pna), ('net', net)):
+        ref = {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}
+        grads_close({k: z[f'g/{tag}/{k}'] for k in ref}, ref, 2e-4, tag + ' ')
+        for k, b in m.named_buffers():
+            assert close(z[f'b/{tag}/{k}'], b.cpu(), 1e-5, 1e-6), k
