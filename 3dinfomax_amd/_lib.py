@@ -60,7 +60,7 @@ class PnaLayerArgs(ctypes.Structure):
                 ('avg_d_log', c_float), ('msg', _P), ('grad_msg', _P), ('post', GroupedFcArgs), ('n_post_extra', c_int),
                 ('postx', FcArgs * 3), ('residual', c_int), ('grad_out', _P), ('agg_event_start', _P), ('agg_event_stop', _P),
                 ('fused_bn', c_int), ('defer_join', c_int), ('stats_ws', _P), ('aff', _P * 4), ('weights_ready', c_int),
-                ('eval_mode', c_int)]
+                ('wgrad_split', c_int), ('eval_mode', c_int)]
 
 
 class Net3dEdgeArgs(ctypes.Structure):

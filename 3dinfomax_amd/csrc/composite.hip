@@ -52,7 +52,16 @@ Aux* aux_for(hipStream_t main) {
     auto it = table.find({dev, main});
     if (it != table.end()) return it->second;
     Aux* a = new Aux();
-    if (hipStreamCreateWithFlags(&a->s, hipStreamNonBlocking) != hipSuccess ||
+    // I3D_WGRAD_PRIORITY=low: the side stream at the lowest priority the device offers - the kernels of the backward CHAIN (the
+    // critical path: the main stream is busy back to back through the whole step) get the CUs first, the weight gradients
+    // fill in
+    static const bool low = [] { const char* e = getenv("I3D_WGRAD_PRIORITY"); return e != nullptr && e[0] == 'l'; }();
+    int lo = 0, hi = 0;
+    hipError_t made = hipErrorUnknown;
+    if (low && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
+        made = hipStreamCreateWithPriority(&a->s, hipStreamNonBlocking, lo);
+    if (made != hipSuccess) made = hipStreamCreateWithFlags(&a->s, hipStreamNonBlocking);
+    if (made != hipSuccess ||
         hipEventCreateWithFlags(&a->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&a->join, hipEventDisableTiming) != hipSuccess) {
         delete a;
@@ -274,7 +283,7 @@ extern "C" int i3d_grouped_fc_bn_bwd(const I3dGroupedFcArgs* a, void* stream) {
 // the fused form) | [W_s | W_d] of the edge block | dQ of the bond table; then the two [V, .] products behind dQ.  Returns
 // 1 when it took the layer, 0 when the layer's shape is not covered (the caller issues the per-block launches), < 0: error.
 // I3D_WGRAD_MULTI=0: off.
-static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_run) {
+static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_run, int part = 0) {
     static const bool on = [] { const char* e = getenv("I3D_WGRAD_MULTI"); return e == nullptr || e[0] != '0'; }();
     const I3dEdgeFcArgs* e = &a->edge;
     const I3dGroupedFcArgs* g = &a->post;
@@ -292,12 +301,17 @@ static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_r
         p.A = Ap; p.B = Bp; p.rows = rows; p.rows_total = rows_total; p.lda = lda; p.ldb = ldb; p.M = M; p.N = Nn;
         p.k_begin = k_begin; p.k_count = k_count;
     };
+    // part 1: the posttrans products only (they need the posttrans chain's dlin only: the LAST layer of a backward pass
+    // issues them early, next to the rest of its chain, so that only part 2 is left when the chain ends); part 2: the rest
+    const bool do_post = part != 2, do_pre = part != 1;
     // posttrans: dW_h = dlin^T h
-    out[no].kind = I3D_WGRAD_PLAIN; out[no].n_groups = 1; out[no].first_problem = np; out[no].C = g->grad_W; out[no].ldc = g->ldw;
-    ++no;
-    problem(g->grad_pre, g->f_out, g->f_out, g->h, Fh, Fh, N, nullptr, 0, N);
+    if (do_post) {
+        out[no].kind = I3D_WGRAD_PLAIN; out[no].n_groups = 1; out[no].first_problem = np; out[no].C = g->grad_W; out[no].ldc = g->ldw;
+        ++no;
+        problem(g->grad_pre, g->f_out, g->f_out, g->h, Fh, Fh, N, nullptr, 0, N);
+    }
     // posttrans: dW_s = sum_D c_s(D) dlin_D^T a_D over the in-degree groups with a non-zero coefficient
-    {
+    if (do_post) {
         I3dWgradOutput& o = out[no];
         o.kind = I3D_WGRAD_COMBINE; o.first_problem = np; o.C = g->grad_W + Fh; o.ldc = g->ldw;
         o.n_scalers = g->n_scalers; o.scaler_stride = A; o.coef = coef;
@@ -318,7 +332,7 @@ static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_r
         ++no;
     }
     // later pretrans blocks: dW = dpre^T BN(x) from the raw x (fused form) or dpre^T x
-    for (int i = a->n_pre_extra - 1; i >= 0; --i) {
+    for (int i = a->n_pre_extra - 1; i >= 0 && do_pre; --i) {
         const I3dFcArgs* c = &a->pre[i];
         I3dWgradOutput& o = out[no++];
         o.n_groups = 1; o.first_problem = np; o.C = c->grad_W; o.ldc = c->ldw;
@@ -327,14 +341,14 @@ static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_r
         problem(c->grad_pre, c->f_out, c->f_out, c->x, c->f_in, c->f_in, c->rows, nullptr, 0, c->rows);
     }
     // edge block: d[W_s | W_d] = dP^T h (rows >= Fo of the [2 Fo, Fh] product are the second column block of dW)
-    {
+    if (do_pre) {
         I3dWgradOutput& o = out[no++];
         o.kind = I3D_WGRAD_PLAIN; o.n_groups = 1; o.first_problem = np; o.C = e->grad_W; o.ldc = e->ldw;
         o.c_split = Fo; o.c_delta = (long)Fh - (long)Fo * e->ldw;
         problem(e->grad_P, 2 * Fo, 2 * Fo, e->h, Fh, Fh, N, nullptr, 0, N);
     }
     // bond table: dQ = onehot^T dpre
-    {
+    if (do_pre) {
         I3dWgradOutput& o = out[no++];
         o.kind = I3D_WGRAD_PLAIN; o.n_groups = 1; o.first_problem = np; o.C = e->grad_Q; o.ldc = Fo;
         problem(e->onehot, e->v_pad, e->v_pad, e->grad_pre, Fo, Fo, E, nullptr, 0, E);
@@ -343,10 +357,12 @@ static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_r
     const long wsb = e->tail.gemm_workspace_bytes;
     if (ws == nullptr || !i3d_wgrad_multi_supported(pr, np, out, no) || i3d_wgrad_multi_min_workspace_bytes(pr, np) > wsb) return 0;
     if (dry_run) return 1;                             // the layer is covered
-    TRY(bias_final(&g->tail, N, g->f_out, g->grad_bias, wst));
-    for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(bias_final(&a->pre[i].tail, a->pre[i].rows, a->pre[i].f_out, a->pre[i].grad_bias, wst));
-    TRY(bias_final(&e->tail, E, Fo, e->grad_bias, wst));
+    if (do_post) TRY(bias_final(&g->tail, N, g->f_out, g->grad_bias, wst));
+    for (int i = a->n_pre_extra - 1; i >= 0 && do_pre; --i)
+        TRY(bias_final(&a->pre[i].tail, a->pre[i].rows, a->pre[i].f_out, a->pre[i].grad_bias, wst));
+    if (do_pre) TRY(bias_final(&e->tail, E, Fo, e->grad_bias, wst));
     TRY(i3d_wgrad_multi(pr, np, out, no, ws, wsb, wst));
+    if (!do_pre) return 1;
     const int V = e->q_rows;
     TRY(i3d_gemm_f32_ws(1, 0, Fo, e->f_q, V, e->grad_Q, Fo, e->q, e->f_q, e->grad_W + 2 * Fh, e->ldw, nullptr, 0, ws, wsb, wst));
     if (e->grad_q != nullptr)
@@ -496,6 +512,12 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     // allows it; otherwise the per-block launches behind two / three forks
     const bool multi = wgrad_multi_layer_ok(a);
     void* wst = stream;
+    if (multi && a->wgrad_split) {
+        wst = fork_wgrad(x, stream);
+        const int took = pna_layer_wgrad_multi(a, wst, false, 1);
+        if (took < 0) return took;
+        I3D_CHECK_ARG(took == 1, "weight-gradient launch refused a layer it had accepted");
+    }
     if (!multi) {
         wst = fork_wgrad(x, stream);
         TRY(grouped_fc_bn_bwd_wgrad(&a->post, wst));
@@ -513,7 +535,7 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     if (multi) {
         TRY(edge_fc_bn_bwd_sums(&a->edge, stream));
         wst = fork_wgrad(x, stream);
-        const int took = pna_layer_wgrad_multi(a, wst, false);
+        const int took = pna_layer_wgrad_multi(a, wst, false, a->wgrad_split ? 2 : 0);
         if (took < 0) return took;
         I3D_CHECK_ARG(took == 1, "weight-gradient launch refused a layer it had accepted");
     } else if (THREE_FORKS) {

@@ -108,6 +108,14 @@ bool join_per_layer() {
     return on;
 }
 
+// I3D_WGRAD_SPLIT_LAST=1: the first layer's weight gradients (the last ones of a backward pass) as two launches, the
+// posttrans products early.  Off: measured 2.289 ms split against 2.253 ms in one launch (tools/ab.sh, 3 interleaved runs) -
+// the early launch takes CUs from the chain it was meant to hide behind.
+bool split_last_wgrad() {
+    static const bool on = [] { const char* e = getenv("I3D_WGRAD_SPLIT_LAST"); return e != nullptr && e[0] == '1'; }();
+    return on;
+}
+
 bool simple_act(int act) { return act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU; }
 
 void fill_tail(I3dBnTail& t, const I3dFcParams& p, float* mean, float* invstd) {
@@ -450,6 +458,11 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
     float* grad_table = top.take((long)b.n_comb * F);                  // dL/d(bond table), summed over the layers
     // buffers the weight-gradient stream reads or writes: one set per layer unless every layer joins that stream
     const bool per_layer_join = join_per_layer();
+    // the last 16 MB of the weight-gradient scratch belong to the launches the MAIN stream issues while the side stream is
+    // busy (the atom tables' gradient at the end); the side stream's launches see the front part only
+    const long tail_bytes = (!per_layer_join && gemm_workspace != nullptr && gemm_workspace_bytes >= (64L << 20)) ? (16L << 20) : 0;
+    char* const tail_ws = tail_bytes > 0 ? (char*)gemm_workspace + (gemm_workspace_bytes - tail_bytes) / 256 * 256 : nullptr;
+    const long side_ws_bytes = tail_bytes > 0 ? (long)(tail_ws - (char*)gemm_workspace) : gemm_workspace_bytes;
     std::vector<float*> side(L, nullptr);
     if (!per_layer_join)
         for (int l = 0; l < L; ++l) side[l] = top.take(side_floats(m, b, l));
@@ -492,6 +505,7 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
         Bump own(side[l]);
         Bump& sd = per_layer_join ? ar : own;       // where the side stream's buffers of this layer live
         a.defer_join = per_layer_join ? 0 : 1;
+        a.wgrad_split = (l == 0 && !per_layer_join && split_last_wgrad()) ? 1 : 0;
         // a residual layer accumulates dL/dh_in on top of the incoming gradient IN PLACE (dh_in = dh_out + ...: the separate
         // add pass over [N, F] is gone, composite.hip: i3d_pna_layer_bwd); others ping-pong between the two buffers
         const int cur = c->gh_cur, nxt = a.residual ? cur : cur ^ 1;
@@ -499,7 +513,7 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
         a.grad_out = grad_in;
         I3dGroupedFcArgs& g = a.post;
         const I3dFcParams& pp = m.post[l];
-        set_ws(g.tail, bn_workspace, gemm_workspace, gemm_workspace_bytes);
+        set_ws(g.tail, bn_workspace, gemm_workspace, side_ws_bytes);
         g.grad_W = pp.grad_W; g.grad_bias = pp.grad_bias; g.grad_gamma = pp.grad_gamma; g.grad_beta = pp.grad_beta;
         g.grad_y = grad_in;
         g.grad_pre = sd.take((long)N * F);
@@ -513,7 +527,7 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
         for (int i = a.n_pre_extra - 1; i >= 0; --i) {
             I3dFcArgs& fc = a.pre[i];
             const I3dFcParams& p = m.pre[l][i + 1];
-            set_ws(fc.tail, bn_workspace, gemm_workspace, gemm_workspace_bytes);
+            set_ws(fc.tail, bn_workspace, gemm_workspace, side_ws_bytes);
             fc.grad_W = p.grad_W; fc.grad_bias = p.grad_bias; fc.grad_gamma = p.grad_gamma; fc.grad_beta = p.grad_beta;
             fc.grad_y = gy;
             fc.grad_pre = sd.take((long)E * fc.f_out);
@@ -523,7 +537,7 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
         }
         I3dEdgeFcArgs& e = a.edge;
         const I3dFcParams& p0 = m.pre[l][0];
-        set_ws(e.tail, bn_workspace, gemm_workspace, gemm_workspace_bytes);
+        set_ws(e.tail, bn_workspace, gemm_workspace, side_ws_bytes);
         e.grad_W = p0.grad_W; e.grad_bias = p0.grad_bias; e.grad_gamma = p0.grad_gamma; e.grad_beta = p0.grad_beta;
         e.grad_y = gy;
         e.grad_pre = sd.take((long)E * e.f_out);
@@ -536,9 +550,14 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
         TRY(i3d_pna_layer_bwd(&a, stream));
         c->gh_cur = nxt;
     }
-    if (!per_layer_join) TRY(i3d_wgrad_stream_join(stream));
-    if (part == 1) return I3D_OK;
-    // ---- encoders: embedding-table gradients as multi-hot^T dY (deterministic, csrc/edge.hip: multihot_kernel)
+    if (part == 1) {
+        if (!per_layer_join) TRY(i3d_wgrad_stream_join(stream));
+        return I3D_OK;
+    }
+    // ---- encoders: embedding-table gradients as multi-hot^T dY (deterministic, csrc/edge.hip: multihot_kernel).  The atom
+    // tables' needs dL/dh_0 only - the chain's own result - so it runs BEFORE the join, next to the first layer's weight
+    // gradients (round 2: after it, 30 us at the very end of the step); its split-K slices go through a slice of the scratch
+    // of its own (the side stream's launches own the front of it).  The bond tables' needs the side stream's grad_table.
     {
         Bump ar(rest);
         int oa = 0, ob = 0;
@@ -552,7 +571,10 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
             hotb = ar.take((long)b.n_comb * vb);
             TRY(encoder_multihot(*c, hot, hotb, stream));
         }
-        TRY(wgrad(oa, F, N, hot, va, gh[c->gh_cur], F, m.grad_atom_tables, F, gemm_workspace, gemm_workspace_bytes, stream));
+        const bool own_ws = tail_bytes > 0;
+        if (own_ws) TRY(wgrad(oa, F, N, hot, va, gh[c->gh_cur], F, m.grad_atom_tables, F, tail_ws, tail_bytes - 256, stream));
+        if (!per_layer_join) TRY(i3d_wgrad_stream_join(stream));
+        if (!own_ws) TRY(wgrad(oa, F, N, hot, va, gh[c->gh_cur], F, m.grad_atom_tables, F, gemm_workspace, gemm_workspace_bytes, stream));
         TRY(wgrad(ob, F, b.n_comb, hotb, vb, grad_table, F, m.grad_bond_tables, F, gemm_workspace, gemm_workspace_bytes, stream));
     }
     return I3D_OK;

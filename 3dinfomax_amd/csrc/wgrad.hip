@@ -446,25 +446,27 @@ extern "C" int i3d_wgrad_multi(const I3dWgradProblem* problems, int n_problems, 
 #else
     const long max_units = workspace_bytes / ((long)WG_UNIT_FLOATS * 4);
 #endif
-    // rows per K-slice: the smallest multiple of 16 with at most `target` units (I3D_WGRAD_UNITS, default 256 = one per
-    // CU) that fit the scratch; a slice is long enough for the panel store (173 KB) to be a small part of its work
+    // rows per K-slice of a full panel: the smallest multiple of 16 with at most I3D_WGRAD_UNITS (default 256 = one unit
+    // per CU: one round of workgroups) units that fit the scratch - measured at batch 512 (tools/ab.sh, step time): 256 rows
+    // (~370 units) 2.39 ms, 384 rows (~240) 2.25-2.29, 512 rows (~180) 2.37, this rule (~360 rows, ~250 units) 2.24.
+    // I3D_WGRAD_ROWS fixes the length instead (doubled only while the slabs do not fit).
+    static const int fixed_rows = env_int("I3D_WGRAD_ROWS", 0) / WG_BK * WG_BK;
     static const int target_units = env_int("I3D_WGRAD_UNITS", 256);
-    static const int min_rows = std::max(WG_BK, env_int("I3D_WGRAD_MIN_ROWS", 128) / WG_BK * WG_BK);
-    const int max_slice = WG_MAX_SLICE;
-    const long target = std::min<long>(max_units, target_units);
-    I3D_CHECK_ARG(plan_units(problems, n_problems, max_slice) <= max_units, "scratch too small");
-    int kps = max_slice;
-    {
-        int lo = min_rows / WG_BK, hi = max_slice / WG_BK;          // smallest kps with units <= target
-        if (plan_units(problems, n_problems, max_slice) <= target) {
-            while (lo < hi) {
-                const int mid = (lo + hi) / 2;
-                if (plan_units(problems, n_problems, mid * WG_BK) <= target) hi = mid;
-                else lo = mid + 1;
-            }
-            kps = lo * WG_BK;
+    int kps;
+    if (fixed_rows > 0) {
+        kps = std::min(WG_MAX_SLICE, fixed_rows);
+        while (kps < WG_MAX_SLICE && plan_units(problems, n_problems, kps) > max_units) kps = std::min(WG_MAX_SLICE, kps * 2);
+    } else {
+        const long target = std::min<long>(max_units, target_units);
+        int lo = 128 / WG_BK, hi = WG_MAX_SLICE / WG_BK;
+        while (lo < hi) {
+            const int mid = (lo + hi) / 2;
+            if (plan_units(problems, n_problems, mid * WG_BK) <= target) hi = mid;
+            else lo = mid + 1;
         }
+        kps = lo * WG_BK;
     }
+    I3D_CHECK_ARG(plan_units(problems, n_problems, kps) <= max_units, "scratch too small");
     WgArgs a;
     WgReduceArgs r;
     a.slab = (float*)workspace;

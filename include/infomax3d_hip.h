@@ -545,6 +545,9 @@ typedef struct { /* one PNA layer, reference models/pna.py:199-216: pretrans edg
     float* aff[I3D_MAX_EXTRA_FC + 1];  /* [3 f_out] mean | gamma invstd | beta of the edge block and of pre[i] (saved) */
     int weights_ready; /* forward (fused_bn): edge.Q and post.WD - products of parameters and the bond table only - are already
                         * there (i3d_pna_layer_weights_fwd, e.g. on the side stream while the layers before this one run) */
+    int wgrad_split;   /* backward: issue the posttrans weight gradients as soon as the posttrans chain is done and the rest at the
+                        * end, as two launches (the last layer of a backward pass: nothing runs next to its weight gradients
+                        * once the chain has ended); 0: one launch at the end of the layer */
     int eval_mode;     /* forward (fused_bn) in eval(): BatchNorm with the running statistics (reference: nn.BatchNorm1d in eval
                         * mode, trainer/trainer.py:75 model.eval()) - aff[i] already hold mean | gamma / sqrt(var + eps) | beta
                         * (i3d_bn_eval_aff_multi), no statistics are finalised, no running statistic is touched */
