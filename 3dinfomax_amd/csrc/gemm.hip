@@ -73,10 +73,17 @@ __device__ __forceinline__ int swz(int k, int idx) { return idx ^ ((((k) ^ (k >>
 // IM (k-contiguous operands only): the LDS image is idx-major, T[idx][BK + 2]: the 16-byte global load of 4 consecutive
 // k is stored with two 8-byte writes (instead of four transposing 4-byte writes) and a lane's MFMA operands for two
 // consecutive k-steps come from one 8-byte read; the row pitch BK + 2 keeps both conflict-free.
-template <int R, int LD, int BK, bool KC, bool IM = false, int NT = 256>       // NT: threads of the workgroup
+// IH (k-contiguous operands, bf16 matmul mode): the LDS image is idx-major in BF16, T16[idx][BK + 8] - the operand is rounded
+// ONCE, when the tile is staged (the 16-byte global load of 4 consecutive k becomes one 8-byte write), and a lane's MFMA
+// fragment (8 consecutive k of one row) is ONE ds_read_b128: half the LDS bytes of the fp32 image, an eighth of its
+// fragment reads (round 2 kept the fp32 image and converted at every fragment read).  Row pitch BK + 8 halves = 12 / 20 /
+// 36 dwords: the 16 lanes of a b128 access group land on disjoint banks.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <int R, int LD, int BK, bool KC, bool IM = false, int NT = 256, bool IH = false>       // NT: threads of the workgroup
 struct TileStage {
     static constexpr int LDK = BK + 2;
-    static constexpr int LDS_FLOATS = IM ? R * LDK : BK * LD;
+    static constexpr int LDKH = BK + 8;                      // bf16 image: row pitch in halves
+    static constexpr int LDS_FLOATS = IH ? R * LDKH / 2 : (IM ? R * LDK : BK * LD);
     static constexpr int SLOTS = R * BK / 4;                 // float4 slots in a tile
     static constexpr int KQ = BK / 4;                        // float4 slots along k of one row
     static constexpr int PER_THREAD = (SLOTS + NT - 1) / NT;
@@ -146,8 +153,14 @@ struct TileStage {
 
     // store for the fused BatchNorm-apply prologue (IM image of a k-contiguous operand): aff = LDS copy of [3][KP] mean |
     // scale | shift (zeros beyond K, so out-of-range k stay finite and meet the zeros of the other operand)
+    __device__ __forceinline__ static void put_bf16x4(float* __restrict__ T, int idx, int k, float a, float b, float c, float d) {
+        bf16x4 h;
+        h[0] = (__bf16)a; h[1] = (__bf16)b; h[2] = (__bf16)c; h[3] = (__bf16)d;
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(T) + idx * LDKH + k) = h;
+    }
+
     __device__ __forceinline__ void store_aff(const Regs& r, float* __restrict__ T, const float* aff, int KP, int k0) const {
-        static_assert(IM, "affine prologue: idx-major image only");
+        static_assert(IM || IH, "affine prologue: idx-major image only");
 #pragma unroll
         for (int it = 0; it < PER_THREAD; ++it) {
             int s = threadIdx.x + it * NT;
@@ -158,6 +171,11 @@ struct TileStage {
                 const float4 sc = *reinterpret_cast<const float4*>(aff + KP + kg);
                 const float4 sh = *reinterpret_cast<const float4*>(aff + 2 * KP + kg);
                 const float4 v = r.v[it];
+                if constexpr (IH) {
+                    put_bf16x4(T, idx, k, (v.x - mu.x) * sc.x + sh.x, (v.y - mu.y) * sc.y + sh.y, (v.z - mu.z) * sc.z + sh.z,
+                               (v.w - mu.w) * sc.w + sh.w);
+                    continue;
+                }
                 *reinterpret_cast<float2*>(&T[idx * LDK + k]) = make_float2((v.x - mu.x) * sc.x + sh.x, (v.y - mu.y) * sc.y + sh.y);
                 *reinterpret_cast<float2*>(&T[idx * LDK + k + 2]) = make_float2((v.z - mu.z) * sc.z + sh.z, (v.w - mu.w) * sc.w + sh.w);
             }
@@ -169,7 +187,9 @@ struct TileStage {
         for (int it = 0; it < PER_THREAD; ++it) {
             int s = threadIdx.x + it * NT;
             if (s < SLOTS) {
-                if (IM) {
+                if (IH) {
+                    put_bf16x4(T, s / KQ, (s % KQ) * 4, r.v[it].x, r.v[it].y, r.v[it].z, r.v[it].w);
+                } else if (IM) {
                     int idx = s / KQ, k = (s % KQ) * 4;
                     *reinterpret_cast<float2*>(&T[idx * LDK + k]) = make_float2(r.v[it].x, r.v[it].y);
                     *reinterpret_cast<float2*>(&T[idx * LDK + k + 2]) = make_float2(r.v[it].z, r.v[it].w);
@@ -233,7 +253,7 @@ constexpr int FUSE_MAX_K = 1024;
 // v_mfma_f32_16x16x32_bf16: one instruction per K-tile instead of 8) - fp32 accumulation, fp32 bias / epilogue /
 // statistics, fp32 tensors in HBM.  Shapes whose K-tile is one such instruction (MT 32 + BK 16, MT 16 + BK 32).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-template <class S> constexpr bool bf16_shape() { return (S::MT == 32 && S::BK == 16) || (S::MT == 16 && S::BK == 32); }
+template <class S> constexpr bool bf16_shape() { return (S::MT == 32 && S::BK % 16 == 0) || (S::MT == 16 && S::BK % 32 == 0); }
 
 __device__ __forceinline__ bf16x8 to_bf16x8(const float* f) {
     bf16x8 r;
@@ -249,9 +269,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     constexpr int BM = S::BM, BN = S::BN;
     constexpr int LDA = (BM + 31) / 32 * 32, LDB = (BN + 31) / 32 * 32;
     constexpr int KSTEP = (MT == 16) ? 4 : 2;         // k per MFMA
-    constexpr bool A_IM = S::KP && A_KC && MT == 32, B_IM = S::KP && B_KC && MT == 32;
-    typedef TileStage<BM, LDA, BK, A_KC, A_IM, S::NT> StageA;
-    typedef TileStage<BN, LDB, BK, B_KC, B_IM, S::NT> StageB;
+    constexpr bool A_IH = BF16 && VEC && S::KP && A_KC && MT == 32, B_IH = BF16 && VEC && S::KP && B_KC && MT == 32;   // bf16 images
+    constexpr bool A_IM = S::KP && A_KC && MT == 32 && !A_IH, B_IM = S::KP && B_KC && MT == 32 && !B_IH;
+    typedef TileStage<BM, LDA, BK, A_KC, A_IM, S::NT, A_IH> StageA;
+    typedef TileStage<BN, LDB, BK, B_KC, B_IM, S::NT, B_IH> StageB;
     // one block of LDS: the operand double buffers, reused by the statistics epilogue as the [BM][BN + 1] output tile
     constexpr int OPER_FLOATS = 2 * StageA::LDS_FLOATS + 2 * StageB::LDS_FLOATS;
     constexpr int CT_PITCH = BN + 1;
@@ -260,7 +281,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     __shared__ __attribute__((aligned(16))) float affL[(FUSE & 1) ? 3 * FUSE_MAX_K : 4];
     float* const As = smem;
     float* const Bs = smem + 2 * StageA::LDS_FLOATS;
-    static_assert(FUSE == 0 || (A_IM && BM == 64), "fused variants: idx-major A image, 64-row tiles");
+    static_assert(FUSE == 0 || ((A_IM || A_IH) && BM == 64), "fused variants: idx-major A image, 64-row tiles");
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -318,49 +339,61 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
                 const float* as = As + cur * StageA::LDS_FLOATS;
                 const float* bs = Bs + cur * StageB::LDS_FLOATS;
                 if constexpr (BF16) {
-                    static_assert(bf16_shape<S>(), "bf16 MFMA: the K-tile is one instruction");
-                    // lane (lt, lk) supplies k = 8 lk .. 8 lk + 7 of row lt of its tiles
-                    const int k0 = 8 * lk;
-                    bf16x8 a8[WM_T], b8[WN_T];
+                    static_assert(bf16_shape<S>(), "bf16 MFMA: the K-tile is a whole number of instructions");
+                    constexpr int KI = (MT == 32) ? 16 : 32;       // k per instruction
 #pragma unroll
-                    for (int i = 0; i < WM_T; ++i) {
-                        const int idx = (wm * WM_T + i) * MT + lt;
-                        float f[8];
-                        if constexpr (A_IM) {
+                    for (int ks = 0; ks < BK / KI; ++ks) {
+                        // lane (lt, lk) supplies k = ks KI + 8 lk .. + 7 of row lt of its tiles
+                        const int k0 = ks * KI + 8 * lk;
+                        bf16x8 a8[WM_T], b8[WN_T];
 #pragma unroll
-                            for (int q = 0; q < 8; q += 2) {
-                                const float2 v = *reinterpret_cast<const float2*>(&as[idx * StageA::LDK + k0 + q]);
-                                f[q] = v.x; f[q + 1] = v.y;
+                        for (int i = 0; i < WM_T; ++i) {
+                            const int idx = (wm * WM_T + i) * MT + lt;
+                            if constexpr (A_IH) {
+                                a8[i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(as) + idx * StageA::LDKH + k0);
+                            } else {
+                                float f[8];
+                                if constexpr (A_IM) {
+#pragma unroll
+                                    for (int q = 0; q < 8; q += 2) {
+                                        const float2 v = *reinterpret_cast<const float2*>(&as[idx * StageA::LDK + k0 + q]);
+                                        f[q] = v.x; f[q + 1] = v.y;
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int q = 0; q < 8; ++q) f[q] = as[(k0 + q) * LDA + swz(k0 + q, idx)];
+                                }
+                                a8[i] = to_bf16x8(f);
                             }
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) f[q] = as[(k0 + q) * LDA + swz(k0 + q, idx)];
                         }
-                        a8[i] = to_bf16x8(f);
-                    }
-#pragma unroll
-                    for (int j = 0; j < WN_T; ++j) {
-                        const int idx = (wn * WN_T + j) * MT + lt;
-                        float f[8];
-                        if constexpr (B_IM) {
-#pragma unroll
-                            for (int q = 0; q < 8; q += 2) {
-                                const float2 v = *reinterpret_cast<const float2*>(&bs[idx * StageB::LDK + k0 + q]);
-                                f[q] = v.x; f[q + 1] = v.y;
-                            }
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) f[q] = bs[(k0 + q) * LDB + swz(k0 + q, idx)];
-                        }
-                        b8[j] = to_bf16x8(f);
-                    }
-#pragma unroll
-                    for (int i = 0; i < WM_T; ++i)
 #pragma unroll
                         for (int j = 0; j < WN_T; ++j) {
-                            if constexpr (MT == 16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8[j], a8[i], acc[i][j], 0, 0, 0);
-                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[j], a8[i], acc[i][j], 0, 0, 0);
+                            const int idx = (wn * WN_T + j) * MT + lt;
+                            if constexpr (B_IH) {
+                                b8[j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(bs) + idx * StageB::LDKH + k0);
+                            } else {
+                                float f[8];
+                                if constexpr (B_IM) {
+#pragma unroll
+                                    for (int q = 0; q < 8; q += 2) {
+                                        const float2 v = *reinterpret_cast<const float2*>(&bs[idx * StageB::LDK + k0 + q]);
+                                        f[q] = v.x; f[q + 1] = v.y;
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int q = 0; q < 8; ++q) f[q] = bs[(k0 + q) * LDB + swz(k0 + q, idx)];
+                                }
+                                b8[j] = to_bf16x8(f);
+                            }
                         }
+#pragma unroll
+                        for (int i = 0; i < WM_T; ++i)
+#pragma unroll
+                            for (int j = 0; j < WN_T; ++j) {
+                                if constexpr (MT == 16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8[j], a8[i], acc[i][j], 0, 0, 0);
+                                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[j], a8[i], acc[i][j], 0, 0, 0);
+                            }
+                    }
                 } else if constexpr (S::KP && MT == 32) {
                     // two k-steps per trip: lane half lk supplies k = 4 j + 2 lk (step 2j) and 4 j + 2 lk + 1 (step 2j+1)
 #pragma unroll
@@ -804,10 +837,22 @@ typedef Shape<32, 2, 2, 1, 1, 16, 4, true> Cfg9;       // as 2 with the idx-majo
 typedef Shape<32, 2, 2, 2, 2, 16, 2, true> Cfg10;      // as 0 with it
 typedef Shape<32, 2, 1, 1, 1, 16, 4, true> Cfg11;      // 64x32 tile, two waves: N = 200 in 7 column tiles instead of 4 x 64
 typedef Shape<32, 1, 1, 1, 1, 16, 4, true> Cfg12;      // 32x32 tile, one wave
-constexpr int N_CFG = 13;
-static const int CFG_BM[N_CFG] = {Cfg0::BM, Cfg1::BM, Cfg2::BM, Cfg3::BM, Cfg4::BM, Cfg5::BM, Cfg6::BM, Cfg7::BM, Cfg8::BM, Cfg9::BM, Cfg10::BM, Cfg11::BM, Cfg12::BM};
-static const int CFG_BN[N_CFG] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN, Cfg9::BN, Cfg10::BN, Cfg11::BN, Cfg12::BN};
-static const int CFG_BK[N_CFG] = {Cfg0::BK, Cfg1::BK, Cfg2::BK, Cfg3::BK, Cfg4::BK, Cfg5::BK, Cfg6::BK, Cfg7::BK, Cfg8::BK, Cfg9::BK, Cfg10::BK, Cfg11::BK, Cfg12::BK};
+// bf16 matmul mode, operands with a bf16 LDS image: with one cheap MFMA per 16 k the K-tile's barrier and staging are what
+// a tile costs - longer K-tiles (2 / 4 instructions per tile and barrier)
+typedef Shape<32, 2, 2, 1, 1, 32, 2, true> Cfg13;      // as 9, K-tile 32
+typedef Shape<32, 2, 1, 1, 1, 32, 2, true> Cfg14;      // as 11, K-tile 32
+typedef Shape<32, 2, 2, 1, 1, 64, 2, true> Cfg15;      // as 9, K-tile 64
+typedef Shape<32, 2, 1, 1, 1, 64, 2, true> Cfg16;      // as 11, K-tile 64
+constexpr int N_CFG = 17;
+static const int CFG_BM[N_CFG] = {Cfg0::BM, Cfg1::BM, Cfg2::BM, Cfg3::BM, Cfg4::BM, Cfg5::BM, Cfg6::BM, Cfg7::BM, Cfg8::BM, Cfg9::BM, Cfg10::BM, Cfg11::BM, Cfg12::BM, Cfg13::BM, Cfg14::BM, Cfg15::BM, Cfg16::BM};
+static const int CFG_BN[N_CFG] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN, Cfg9::BN, Cfg10::BN, Cfg11::BN, Cfg12::BN, Cfg13::BN, Cfg14::BN, Cfg15::BN, Cfg16::BN};
+static const int CFG_BK[N_CFG] = {Cfg0::BK, Cfg1::BK, Cfg2::BK, Cfg3::BK, Cfg4::BK, Cfg5::BK, Cfg6::BK, Cfg7::BK, Cfg8::BK, Cfg9::BK, Cfg10::BK, Cfg11::BK, Cfg12::BK, Cfg13::BK, Cfg14::BK, Cfg15::BK, Cfg16::BK};
+
+// K-tile of the bf16-image configurations (I3D_BF16_BK = 16 | 32 | 64; default 32)
+static int bf16_bk() {
+    static const int v = [] { const char* e = getenv("I3D_BF16_BK"); const int x = e ? atoi(e) : 32; return (x == 16 || x == 64) ? x : 32; }();
+    return v;
+}
 
 // the (A idx-contiguous, B k-contiguous) layout is computed as layout 2 would need B transposed: it only exists for
 // API completeness, through one configuration
@@ -940,6 +985,8 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     // P 17.5 -> 15.2 us, [E,F]x[F,F] 25.9 -> 24.0 us), and loses at every K once there are > ~1000 64x64 tiles (QMugs
     // shape, post4: 96 vs 87 us): the tile count decides, not K.
     if (cfg == 9 && !trans_a && narrow_pays(N, tiles64)) cfg = 11;
+    if (g_matmul_bf16 && vec && (cfg == 9 || cfg == 11) && bf16_bk() != 16)      // bf16 LDS image: longer K-tiles
+        cfg = (cfg == 9 ? 13 : 14) + (bf16_bk() == 64 ? 2 : 0);
     if (force_cfg >= 0) {
         I3D_CHECK_ARG(force_cfg < N_CFG, "tile_cfg out of range");
         I3D_CHECK_ARG(ex.tile_group == nullptr || CFG_BM[force_cfg] == 64, "grouped GEMM needs 64-row tiles");
@@ -1003,7 +1050,11 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
         case 9: launch<Cfg9>(g, layout, splits, vec, s); break;
         case 10: launch<Cfg10>(g, layout, splits, vec, s); break;
         case 11: launch<Cfg11>(g, layout, splits, vec, s); break;
-        default: launch<Cfg12>(g, layout, splits, vec, s); break;
+        case 12: launch<Cfg12>(g, layout, splits, vec, s); break;
+        case 13: launch<Cfg13>(g, layout, splits, vec, s); break;
+        case 14: launch<Cfg14>(g, layout, splits, vec, s); break;
+        case 15: launch<Cfg15>(g, layout, splits, vec, s); break;
+        default: launch<Cfg16>(g, layout, splits, vec, s); break;
     }
     I3D_CHECK_LAUNCH();
     if (use_slab) {
@@ -1252,7 +1303,13 @@ extern "C" int i3d_gemm_f32_fused(int M, int N, int K, const float* A, int lda, 
     hipStream_t s = (hipStream_t)stream;
     // tile choice as in gemm_impl for the forward layout: 64x64 (idx-major image), 64x32 when K is long and N pads badly
     const bool narrow = narrow_pays(N, (long)cdiv(M, 64) * cdiv(N, 64)) && (K >= 400 || fuse_narrow_short_k());
-    if (narrow) launch_fused<Cfg11>(g, fuse, s);
+    if (g_matmul_bf16 && bf16_bk() == 32) {
+        if (narrow) launch_fused<Cfg14>(g, fuse, s);
+        else launch_fused<Cfg13>(g, fuse, s);
+    } else if (g_matmul_bf16 && bf16_bk() == 64) {
+        if (narrow) launch_fused<Cfg16>(g, fuse, s);
+        else launch_fused<Cfg15>(g, fuse, s);
+    } else if (narrow) launch_fused<Cfg11>(g, fuse, s);
     else launch_fused<Cfg9>(g, fuse, s);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
