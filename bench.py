@@ -438,18 +438,25 @@ def main():
         null_us = float(np.median([a.elapsed_time(b) for a, b in null_ms[10:]]) * 1e3)
         b2b, b2b_us = back_to_back(blocks)
         b2b12, b2b12_us = back_to_back(12)
-        # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured with
-        # rocprofv3 on this kernel variant and batch shape (tools/k4_pmc_summary.py -> profiles/r01_k4_pmc_v3.txt)
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_k4_pmc_v3.json')
+        # HBM traffic per launch from this round's PMC passes over THIS command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE around
+        # bench.py, FETCH_SIZE x2 gfx950 correction, tools/pmc_summary.py -> profiles/r03_step_k4_pmc.json): the kernel variant
+        # the step launches (messages normalised on load), the same synthetic batches (same seeds -> same N, E)
+        traffic = traffic_bwd = None
+        pmc = os.path.join(ROOT, 'profiles', 'r03_step_k4_pmc.json')
         if os.path.exists(pmc):
             with open(pmc) as f:
-                p = json.load(f).get(f'fwd{blocks}_B512')
-            if p:
-                traffic = int(byts.mean() * p['traffic_MB'] / p['algorithmic_MB'])
+                pj = json.load(f)
+            want = f'pna_aggregate_fwd_kernel<{2 if blocks == 4 else 1}>'
+            rows = [r for k, v in pj.items() if k.startswith(want) for r in v]
+            if rows:
+                traffic = int(1e6 * sum(r['traffic_MB'] * r['dispatches'] for r in rows) / sum(r['dispatches'] for r in rows))
+            rows = [r for k, v in pj.items() if k.startswith('pna_aggregate_bwd_kernel<4,2>') or k.startswith('pna_aggregate_bwd_kernel<4, 2>')
+                    for r in v]
+            if rows:
+                traffic_bwd = int(1e6 * sum(r['traffic_MB'] * r['dispatches'] for r in rows) / sum(r['dispatches'] for r in rows))
         roof = dict(bound='hbm', kernel=f'pna_aggregate_fwd_kernel ({blocks} output blocks [N,{blocks}F], as launched by the step)',
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
-                    unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                    unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_backward_kernel=traffic_bwd,
                     launches=len(ev), avg_us=round(float(ms.mean() * 1e3), 2),
                     algorithmic_bytes_per_launch=int(byts.mean()),
                     # the contract figure is the reference-defined op ([N,12F] written); the fused form the
@@ -468,7 +475,7 @@ def main():
                          'event_pair_null_kernel_us (dispatch + completion signalling: the part of avg_us that is not the '
                          'kernel; rocprofv3 kernel time in profiles/); *_back_to_back: '
                          '20 launches per event pair after the timed region; reference_shaped_12F: the [N,12F] kernel of '
-                         'SURVEY.md 8(d) (I3D_GROUPED_POSTTRANS=0 path); traffic: rocprofv3 PMC bytes per launch')
+                         'SURVEY.md 8(d) (I3D_GROUPED_POSTTRANS=0 path); traffic: rocprofv3 PMC bytes per launch of the step\'s own kernels (profiles/r03_step_k4_pmc.txt), traffic_backward_kernel: the same for pna_aggregate_bwd_kernel<4,2>')
 
     # per-collective times of the data-parallel step (20 back-to-back calls per event pair, after the timed region)
     collectives = None

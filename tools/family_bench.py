@@ -72,10 +72,31 @@ def measure(amd, ops, g2, dev, F=200, big_batch=8192):
         'dgrad P [N,2F]x[2F,F]': (lambda: ops.gemm(dP, Wsd), 2.0 * N * 2 * F * F),
         'dgrad post agg grouped [N,F]->4F': (lambda: ops.gemm_grouped(dY_n, rows_d, tiles_d, WD, agg, trans_b=False, accumulate=False),
                                               2.0 * m_pad * 4 * F * F),
-        'wgrad FC2 [F,F] K=E (BN fix-up)': (lambda: ops.gemm_wgrad_bn(dY_e, x1, bias, aff), 2.0 * E * F * F),
-        'wgrad P [2F,F] K=N': (lambda: ops.gemm(dP, h, trans_a=True), 2.0 * N * 2 * F * F),
-        'wgrad post h [F,F] K=N': (lambda: ops.gemm(dY_n, h, trans_a=True), 2.0 * N * F * F),
     }
+    # all weight gradients of the layer: ONE launch + one reduction (csrc/wgrad.hip) in fp32; the per-product launches of
+    # round 2 in the bf16 matmul mode (the panel kernel has no bf16 form yet)
+    onehot = torch.zeros(E, 64, device=dev)
+    onehot[torch.arange(E, device=dev), torch.randint(0, 60, (E,), device=dev)] = 1.0
+    gW3, gW2, gW1, gQ = torch.empty(F, 13 * F, device=dev), torch.empty(F, F, device=dev), torch.empty(F, 3 * F, device=dev), torch.empty(64, F, device=dev)
+    if ops.get_matmul_precision() == 'fp32':
+        coef = [c for D, _, _ in groups for c in ((1.0, float(np.log(D + 1)), 1.0 / float(np.log(D + 1))) if D > 0 else (0.0, 0.0, 0.0))]
+        live = [(s0, cnt, coef[3 * k:3 * k + 3]) for k, (D, s0, cnt) in enumerate(groups) if D > 0 and cnt > 0]
+        problems = [dict(A=dY_n, B=h)] + [dict(A=dY_n, B=agg, rows=rows_d, k_begin=s0, k_count=cnt) for s0, cnt, _ in live]
+        problems += [dict(A=dY_e, B=x1), dict(A=dP, B=h), dict(A=onehot, B=dY_e)]
+        G = len(live)
+        outputs = [dict(first_problem=0, C=gW3, ldc=13 * F),
+                   dict(kind=ops.WGRAD_COMBINE, first_problem=1, n_groups=G, C=gW3, c_offset=F, ldc=13 * F,
+                        coef=[c for _, _, cs in live for c in cs], n_scalers=3, scaler_stride=4 * F),
+                   dict(kind=ops.WGRAD_BN, first_problem=1 + G, C=gW2, aff=aff.reshape(-1), row=bias),
+                   dict(first_problem=2 + G, C=gW1, ldc=3 * F, c_split=F, c_delta=F - F * 3 * F),
+                   dict(first_problem=3 + G, C=gQ)]
+        gemms['wgrad: all five products of the layer, one launch + one reduction (K = N / E rows)'] = (
+            lambda: ops.wgrad_multi(problems, outputs),
+            2.0 * E * F * F + 2.0 * N * 2 * F * F + 2.0 * N * F * F + 2.0 * N * 4 * F * F + 2.0 * E * 64 * F)
+    else:
+        gemms['wgrad FC2 [F,F] K=E (BN fix-up)'] = (lambda: ops.gemm_wgrad_bn(dY_e, x1, bias, aff), 2.0 * E * F * F)
+        gemms['wgrad P [2F,F] K=N'] = (lambda: ops.gemm(dP, h, trans_a=True), 2.0 * N * 2 * F * F)
+        gemms['wgrad post h [F,F] K=N'] = (lambda: ops.gemm(dY_n, h, trans_a=True), 2.0 * N * F * F)
     rows, tot_us, tot_fl = [], 0.0, 0.0
     peak_tf = MFMA_BF16_PEAK_TF if ops.get_matmul_precision() == 'bf16' else MFMA_F32_PEAK_TF
     for name, (fn, fl) in gemms.items():
@@ -85,7 +106,7 @@ def measure(amd, ops, g2, dev, F=200, big_batch=8192):
         tot_fl += fl
     out['gemm'] = dict(bound='mfma', peak=peak_tf, unit='TFLOP/s', achieved=round(tot_fl / tot_us / 1e6, 1),
                        frac=round(tot_fl / tot_us / 1e6 / peak_tf, 3), kernels=rows,
-                       note='flop-weighted over the ten GEMM shapes of one PNA layer (forward, data gradient, weight gradient), '
+                       note='flop-weighted over the GEMM launches of one PNA layer (forward, data gradient, all weight gradients), '
                             'each launched 20 times back to back between one event pair')
 
     # ---- BatchNorm family (HBM): producer-fused statistics, backward reduction + apply, apply + residual

@@ -27,9 +27,10 @@ def per_kernel(db, counter, pattern):
     return out
 
 
-def main(fetch_db, write_db, pattern):
+def main(fetch_db, write_db, pattern, json_out=None):
     f = per_kernel(fetch_db, 'FETCH_SIZE', pattern)
     w = per_kernel(write_db, 'WRITE_SIZE', pattern)
+    res = {}
     print('# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python tools/family_bench.py   (one pass per counter)')
     print('# KiB per dispatch averaged over the dispatches of (kernel, grid); fetch x2 (gfx950 wide-read correction), MB = 1e6 bytes')
     print(f'{"kernel":72s} {"grid":>9s} {"n":>4s} {"fetch_MB":>9s} {"write_MB":>9s} {"total_MB":>9s}')
@@ -38,7 +39,13 @@ def main(fetch_db, write_db, pattern):
         fm = 2.0 * sum(fv) / max(len(fv), 1) * 1024 / 1e6
         wm = sum(wv) / max(len(wv), 1) * 1024 / 1e6
         print(f'{key[0]:72s} {key[1]:9d} {max(len(fv), len(wv)):4d} {fm:9.2f} {wm:9.2f} {fm + wm:9.2f}')
+        res.setdefault(key[0], []).append(dict(grid=key[1], dispatches=max(len(fv), len(wv)), fetch_MB=round(fm, 3),
+                                               write_MB=round(wm, 3), traffic_MB=round(fm + wm, 3)))
+    if json_out:
+        import json
+        with open(json_out, 'w') as fh:
+            json.dump(res, fh, indent=1)
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else '.')
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else '.', sys.argv[4] if len(sys.argv) > 4 else None)
