@@ -336,7 +336,7 @@ extern "C" long i3d_pna_model_scratch_floats(const I3dPnaModel* m, const I3dPnaB
     long oa = 0, ob = 0;
     for (int k = 0; k < m->n_atom_tables; ++k) oa += m->atom_dims[k];
     for (int k = 0; k < m->n_bond_tables; ++k) ob += m->bond_dims[k];
-    const long emb = al4(N * ((oa + 31) / 32 * 32)) + al4((long)b->n_comb * ((ob + 31) / 32 * 32));
+    const long emb = al4(N * ((oa + 31) / 32 * 32)) + al4((long)b->n_comb * ((ob + 31) / 32 * 32)) + al4(((oa + 3) / 4 * 4) * F);
     long side = 0;          // generous: the per-layer sets are taken in addition to the shared region
     for (int l = 0; l < m->n_layers; ++l) side += side_floats(*m, *b, l);
     return top + side + std::max(std::max(head, layer), emb);
@@ -572,9 +572,23 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
             TRY(encoder_multihot(*c, hot, hotb, stream));
         }
         const bool own_ws = tail_bytes > 0;
-        if (own_ws) TRY(wgrad(oa, F, N, hot, va, gh[c->gh_cur], F, m.grad_atom_tables, F, tail_ws, tail_bytes - 256, stream));
+        // 173 atom categories: not a multiple of 4, and a product whose M is not takes the GEMM's 4-byte-load variant (66 us
+        // against 12 us).  The multi-hot matrix has zero columns up to va, so the product is taken over oa rounded up to 4 into
+        // scratch and the real rows are copied out (same tiles, same split, same summation order: same bits)
+        const int oa4 = (oa + 3) / 4 * 4;
+        float* atoms_out = oa4 == oa ? m.grad_atom_tables : ar.take((long)oa4 * F);
+        auto atom_tables = [&](void* ws, long wsb) -> int {
+            TRY(wgrad(oa4, F, N, hot, va, gh[c->gh_cur], F, atoms_out, F, ws, wsb, stream));
+            if (atoms_out != m.grad_atom_tables &&
+                hipMemcpyAsync(m.grad_atom_tables, atoms_out, (size_t)oa * F * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+                i3d::set_error("i3d_pna_model_bwd: copy of the atom-table gradient failed");
+                return I3D_ERR_LAUNCH;
+            }
+            return I3D_OK;
+        };
+        if (own_ws) TRY(atom_tables(tail_ws, tail_bytes - 256));
         if (!per_layer_join) TRY(i3d_wgrad_stream_join(stream));
-        if (!own_ws) TRY(wgrad(oa, F, N, hot, va, gh[c->gh_cur], F, m.grad_atom_tables, F, gemm_workspace, gemm_workspace_bytes, stream));
+        if (!own_ws) TRY(atom_tables(gemm_workspace, gemm_workspace_bytes));
         TRY(wgrad(ob, F, b.n_comb, hotb, vb, grad_table, F, m.grad_bond_tables, F, gemm_workspace, gemm_workspace_bytes, stream));
     }
     return I3D_OK;
