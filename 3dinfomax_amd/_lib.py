@@ -60,7 +60,7 @@ class PnaLayerArgs(ctypes.Structure):
                 ('avg_d_log', c_float), ('msg', _P), ('grad_msg', _P), ('post', GroupedFcArgs), ('n_post_extra', c_int),
                 ('postx', FcArgs * 3), ('residual', c_int), ('grad_out', _P), ('agg_event_start', _P), ('agg_event_stop', _P),
                 ('fused_bn', c_int), ('defer_join', c_int), ('stats_ws', _P), ('aff', _P * 4), ('weights_ready', c_int),
-                ('wgrad_split', c_int), ('eval_mode', c_int)]
+                ('merge_h', c_int), ('Wcat', _P), ('bcat', _P), ('PL', _P), ('DL', _P), ('wgrad_split', c_int), ('eval_mode', c_int)]
 
 
 class Net3dEdgeArgs(ctypes.Structure):
@@ -130,6 +130,10 @@ _SIGNATURES = {
     'i3d_rccl_init': (c_int, [ctypes.c_char_p, c_int, c_int, POINTER(c_void_p)]),
     'i3d_rccl_destroy': (c_int, [_P]),
     'i3d_set_collectives_rccl': (c_int, [_P, c_int, _P, c_long]),
+    'i3d_gemm_f32_fused_src': (c_int, [c_int, c_int, c_int, _P, c_int, c_long, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int,
+                                       _P, _P, _P, c_long, _P]),
+    'i3d_pna_pack_h_weights': (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, _P, _P, _P]),
+    'i3d_bn_bwd_strided': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     'i3d_wgrad_multi_supported': (c_int, [POINTER(WgradProblem), c_int, POINTER(WgradOutput), c_int]),
     'i3d_wgrad_multi_workspace_bytes': (c_long, [c_int]),
     'i3d_wgrad_multi_min_workspace_bytes': (c_long, [POINTER(WgradProblem), c_int]),

@@ -488,6 +488,7 @@ struct BwdApplyArgs {
     const float* sum_dy;      // [feat]  (train only)
     const float* sum_dy_xhat; // [feat]
     float* grad_pre;
+    int ld_out;               // row pitch of grad_pre in floats (>= feat): the result may be a column block of a wider matrix
     float* zero_out;          // [feat] or null: filled with zeros by the first row block (see i3d_bn_bwd: exact-zero bias gradient)
     const float* inv_n_ptr;   // device 1/N (synchronised BN) or null -> inv_n
     long items;
@@ -554,8 +555,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BwdApplyArgs g, RowTi
             if (g.act != I3D_ACT_NONE) gx *= act_grad(g.pre ? p[u][i] : x[u][i], g.act);   // relu'(pre) == relu'(x)
             dy[u][i] = gx;
         }
-        if (V == 4) *reinterpret_cast<float4*>(g.grad_pre + off) = make_float4(dy[u][0], dy[u][1 % V], dy[u][2 % V], dy[u][3 % V]);
-        else g.grad_pre[off] = dy[u][0];
+        const long oo = (long)row * g.ld_out + c0;
+        if (V == 4) *reinterpret_cast<float4*>(g.grad_pre + oo) = make_float4(dy[u][0], dy[u][1 % V], dy[u][2 % V], dy[u][3 % V]);
+        else g.grad_pre[oo] = dy[u][0];
     }
 }
 
@@ -624,8 +626,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_colsum_kernel(BwdApplyArgs g
                     dy[u][i] = gx;
                     a1[i] += gx;
                 }
-                if (V == 4) *reinterpret_cast<float4*>(g.grad_pre + off) = make_float4(dy[u][0], dy[u][1 % V], dy[u][2 % V], dy[u][3 % V]);
-                else g.grad_pre[off] = dy[u][0];
+                const long oo = (long)row * g.ld_out + c0;
+                if (V == 4) *reinterpret_cast<float4*>(g.grad_pre + oo) = make_float4(dy[u][0], dy[u][1 % V], dy[u][2 % V], dy[u][3 % V]);
+                else g.grad_pre[oo] = dy[u][0];
             }
         }
     }
@@ -857,11 +860,11 @@ extern "C" int i3d_bn_bias_finalize(const float* bias_partial, int rows, int fea
 // bias_partial != null (and grad_bias != null): the data-gradient pass stores the row-chunk partials of the bias gradient
 // there and does NOT finalise them - the in-launch finalisation is a ~10 us serial tail on the backward chain for a value
 // only the optimizer needs; the caller runs i3d_bn_bias_finalize later (the layer composite: on its side stream).
-extern "C" int i3d_bn_bwd_deferred_bias(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
-                                        int post_act, const float* mean, const float* invstd, const float* gamma,
-                                        const float* beta, float* grad_gamma, float* grad_beta, float* grad_pre,
-                                        float* grad_bias, double* sums_out, const double* sums_in, long total_rows,
-                                        void* workspace, float* bias_partial, void* stream) {
+static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
+                       int post_act, const float* mean, const float* invstd, const float* gamma,
+                       const float* beta, float* grad_gamma, float* grad_beta, float* grad_pre,
+                       float* grad_bias, double* sums_out, const double* sums_in, long total_rows,
+                       void* workspace, float* bias_partial, int ld_out, void* stream) {
     I3D_CHECK_ARG(rows > 0 && feat > 0, "rows > 0 and feat > 0 required");
     I3D_CHECK_ARG(workspace != nullptr, "workspace required");
     I3D_CHECK_ARG(act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU || pre != nullptr, "pre required for this activation");
@@ -872,15 +875,15 @@ extern "C" int i3d_bn_bwd_deferred_bias(const float* grad_y, const float* x, con
         // gradient all-reduce adds the ranks up)
         I3D_CHECK_ARG(coll->scratch_bytes >= (long)(2 * feat + 1) * 8, "collective scratch too small");
         double* s64 = (double*)coll->scratch;
-        int rc = i3d_bn_bwd_deferred_bias(grad_y, x, pre, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta,
-                                          nullptr, nullptr, s64, nullptr, rows, workspace, nullptr, stream);
+        int rc = bn_bwd_impl(grad_y, x, pre, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta,
+                             nullptr, nullptr, s64, nullptr, rows, workspace, nullptr, ld_out, stream);
         if (rc != I3D_OK) return rc;
         hipLaunchKernelGGL(set_double_kernel, dim3(1), dim3(1), 0, s, s64 + 2 * feat, (double)rows);
         I3D_CHECK_LAUNCH();
         rc = coll->all_reduce_f64(coll->user, s64, 2 * feat + 1, stream);
         if (rc != I3D_OK) return rc;
-        return i3d_bn_bwd_deferred_bias(grad_y, x, pre, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta,
-                                        grad_pre, grad_bias, nullptr, s64, 0, workspace, bias_partial, stream);
+        return bn_bwd_impl(grad_y, x, pre, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta,
+                           grad_pre, grad_bias, nullptr, s64, 0, workspace, bias_partial, ld_out, stream);
     }
     Chunking ch = make_chunking(rows, feat);
     float* partial = partial_of(workspace);
@@ -906,7 +909,7 @@ extern "C" int i3d_bn_bwd_deferred_bias(const float* grad_y, const float* x, con
     b.inv_n_ptr = sums_in != nullptr ? (partial + (long)MAX_PARTIAL_BLOCKS * 2 * feat + 2 * feat) : nullptr;
     b.grad_y = grad_y; b.x = x; b.pre = (act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU) ? nullptr : pre;
     b.mean = mean; b.invstd = invstd; b.gamma = gamma; b.beta = beta;
-    b.sum_dy = sum_dy; b.sum_dy_xhat = sum_dy_xhat; b.grad_pre = grad_pre; b.feat = feat; b.act = act;
+    b.sum_dy = sum_dy; b.sum_dy_xhat = sum_dy_xhat; b.grad_pre = grad_pre; b.ld_out = ld_out; b.feat = feat; b.act = act;
     b.post_act = post_act; b.eval_mode = 0; b.inv_n = 1.f / (float)total_rows; b.eps = 0.f;
     b.zero_out = nullptr;
     if (grad_bias != nullptr && act == I3D_ACT_NONE && sums_in == nullptr && exact_zero_bias_grad()) {
@@ -945,6 +948,25 @@ extern "C" int i3d_bn_bwd_deferred_bias(const float* grad_y, const float* x, con
     return I3D_OK;
 }
 
+extern "C" int i3d_bn_bwd_deferred_bias(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
+                                        int post_act, const float* mean, const float* invstd, const float* gamma,
+                                        const float* beta, float* grad_gamma, float* grad_beta, float* grad_pre,
+                                        float* grad_bias, double* sums_out, const double* sums_in, long total_rows,
+                                        void* workspace, float* bias_partial, void* stream) {
+    return bn_bwd_impl(grad_y, x, pre, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta, grad_pre,
+                       grad_bias, sums_out, sums_in, total_rows, workspace, bias_partial, feat, stream);
+}
+
+// the same with grad_pre as a column block of a wider matrix (row pitch ld_out floats)
+extern "C" int i3d_bn_bwd_strided(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
+                                  int post_act, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                  float* grad_gamma, float* grad_beta, float* grad_pre, int ld_out, float* grad_bias,
+                                  void* workspace, float* bias_partial, void* stream) {
+    I3D_CHECK_ARG(ld_out >= feat && (feat % 4 != 0 || (ld_out % 4 == 0 && (((uintptr_t)grad_pre) & 15) == 0)), "bad output pitch");
+    return bn_bwd_impl(grad_y, x, pre, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta, grad_pre,
+                       grad_bias, nullptr, nullptr, rows, workspace, bias_partial, ld_out, stream);
+}
+
 extern "C" int i3d_bn_eval_bwd(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
                                int post_act, const float* running_mean, const float* running_var, float eps,
                                const float* gamma, const float* beta, float* grad_gamma, float* grad_beta,
@@ -966,7 +988,7 @@ extern "C" int i3d_bn_eval_bwd(const float* grad_y, const float* x, const float*
     BwdApplyArgs b;
     b.grad_y = grad_y; b.x = x; b.pre = (act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU) ? nullptr : pre;
     b.mean = running_mean; b.invstd = running_var; b.gamma = gamma; b.beta = beta; b.sum_dy = nullptr;
-    b.sum_dy_xhat = nullptr; b.grad_pre = grad_pre; b.feat = feat; b.act = act; b.post_act = post_act;
+    b.sum_dy_xhat = nullptr; b.grad_pre = grad_pre; b.ld_out = feat; b.feat = feat; b.act = act; b.post_act = post_act;
     b.inv_n_ptr = nullptr; b.eval_mode = 1; b.inv_n = 0.f; b.eps = eps; b.zero_out = nullptr;
     launch_bwd_apply(b, rows, feat, s);
     I3D_CHECK_LAUNCH();

@@ -278,6 +278,12 @@ extern "C" int i3d_grouped_fc_bn_bwd(const I3dGroupedFcArgs* a, void* stream) {
     return grouped_fc_bn_bwd_wgrad(a, stream);
 }
 
+// the h-products of a layer merged into one GEMM per direction (I3dPnaLayerArgs.merge_h): fused form, one posttrans block
+static bool merge_h_ok(const I3dPnaLayerArgs* a) {
+    return a->merge_h && a->fused_bn && a->n_post_extra == 0 && a->Wcat != nullptr && a->bcat != nullptr && a->PL != nullptr &&
+           a->post.f_h == a->edge.f_h && a->post.pre_keep == nullptr;
+}
+
 // ---- all weight gradients of a PNA layer behind ONE fork, from ONE launch + one reduction (wgrad.hip) ---------------
 // posttrans h-block | per-degree posttrans blocks folded into the scaler blocks | later pretrans blocks (BatchNorm fix-up in
 // the fused form) | [W_s | W_d] of the edge block | dQ of the bond table; then the two [V, .] products behind dQ.  Returns
@@ -289,6 +295,12 @@ static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_r
     const I3dGroupedFcArgs* g = &a->post;
     if (!on || a->n_post_extra != 0 || e->q == nullptr || e->q_rows <= 0 || i3d_get_matmul_precision() != 0) return 0;
     const int Fh = e->f_h, Fo = e->f_out, N = e->num_nodes, E = e->num_edges, A = g->agg_width;
+    const bool merged = merge_h_ok(a) && a->DL != nullptr;
+    const int WL = 2 * Fo + g->f_out;
+    const float* dlin = merged ? a->DL + 2 * Fo : g->grad_pre;      // [N, f_out(post)]
+    const int ld_dlin = merged ? WL : g->f_out;
+    const float* dP = merged ? a->DL : e->grad_P;                    // [N, 2 Fo]
+    const int ld_dP = merged ? WL : 2 * Fo;
     I3dWgradProblem pr[40];
     I3dWgradOutput out[8];
     float coef[128];
@@ -308,7 +320,7 @@ static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_r
     if (do_post) {
         out[no].kind = I3D_WGRAD_PLAIN; out[no].n_groups = 1; out[no].first_problem = np; out[no].C = g->grad_W; out[no].ldc = g->ldw;
         ++no;
-        problem(g->grad_pre, g->f_out, g->f_out, g->h, Fh, Fh, N, nullptr, 0, N);
+        problem(dlin, ld_dlin, g->f_out, g->h, Fh, Fh, N, nullptr, 0, N);
     }
     // posttrans: dW_s = sum_D c_s(D) dlin_D^T a_D over the in-degree groups with a non-zero coefficient
     if (do_post) {
@@ -324,7 +336,7 @@ static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_r
                 continue;
             }
             for (int s = 0; s < g->n_scalers; ++s) coef[ng * g->n_scalers + s] = g->coef[k * g->n_scalers + s];
-            problem(g->grad_pre, g->f_out, g->f_out, g->agg, A, A, N, g->deg_rows, g->group_start[k], g->group_count[k]);
+            problem(dlin, ld_dlin, g->f_out, g->agg, A, A, N, g->deg_rows, g->group_start[k], g->group_count[k]);
             ++ng;
         }
         if (ng == 0) return 0;
@@ -345,7 +357,7 @@ static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_r
         I3dWgradOutput& o = out[no++];
         o.kind = I3D_WGRAD_PLAIN; o.n_groups = 1; o.first_problem = np; o.C = e->grad_W; o.ldc = e->ldw;
         o.c_split = Fo; o.c_delta = (long)Fh - (long)Fo * e->ldw;
-        problem(e->grad_P, 2 * Fo, 2 * Fo, e->h, Fh, Fh, N, nullptr, 0, N);
+        problem(dP, ld_dP, 2 * Fo, e->h, Fh, Fh, N, nullptr, 0, N);
     }
     // bond table: dQ = onehot^T dpre
     if (do_pre) {
@@ -395,13 +407,26 @@ static int pna_layer_fwd_fused(const I3dPnaLayerArgs* a, void* stream) {
     I3D_CHECK_ARG(a->stats_ws != nullptr && a->n_post_extra == 0 && e->pre_keep == nullptr && simple_act(e->tail.act) &&
                       e->tail.post_act == I3D_ACT_NONE && a->aff[0] != nullptr, "fused BatchNorm: unsupported block shape");
     // edge block: P and Q as before, then gather-combine + activation + statistics in one pass
-    const long wdelta = (long)Fh - (long)Fo * e->ldw, wview = (long)(Fo - 1) * e->ldw + 2 * Fh;
-    TRY(i3d_gemm_f32_blocks(0, 1, N, 2 * Fo, Fh, e->h, Fh, e->W, e->ldw, Fo, wdelta, wview, e->P, 2 * Fo, 0, 0, 0, nullptr, 0,
-                            stream));
+    const I3dGroupedFcArgs* pg = &a->post;
+    const bool merged = merge_h_ok(a);
+    const int WL = 2 * Fo + pg->f_out;        // merged: PL = h [W_s ; W_d ; W_h]^T + [0 | 0 | b_post], P = its first 2 Fo columns
+    const float* P = e->P;
+    int ldp = 2 * Fo;
+    if (merged) {
+        if (!a->weights_ready)
+            TRY(i3d_pna_pack_h_weights(e->W, e->ldw, Fo, pg->W, pg->ldw, pg->f_out, pg->bias, Fh, a->Wcat, a->bcat, stream));
+        TRY(i3d_gemm_f32(0, 1, N, WL, Fh, e->h, Fh, a->Wcat, Fh, a->PL, WL, a->bcat, 0, stream));
+        P = a->PL;
+        ldp = WL;
+    } else {
+        const long wdelta = (long)Fh - (long)Fo * e->ldw, wview = (long)(Fo - 1) * e->ldw + 2 * Fh;
+        TRY(i3d_gemm_f32_blocks(0, 1, N, 2 * Fo, Fh, e->h, Fh, e->W, e->ldw, Fo, wdelta, wview, e->P, 2 * Fo, 0, 0, 0, nullptr, 0,
+                                stream));
+    }
     if (e->q != nullptr && !a->weights_ready)
         TRY(i3d_gemm_f32(0, 1, e->q_rows > 0 ? e->q_rows : E, Fo, e->f_q, e->q, e->f_q, e->W + 2 * Fh, e->ldw, e->Q, Fo,
                          nullptr, 0, stream));
-    TRY(i3d_edge_combine_act_stats(e->P, 2 * Fo, e->q ? e->Q : nullptr, e->q_rows > 0 ? e->q_code : nullptr, e->bias, e->src_s,
+    TRY(i3d_edge_combine_act_stats(P, ldp, e->q ? e->Q : nullptr, e->q_rows > 0 ? e->q_code : nullptr, e->bias, e->src_s,
                                    e->dst_s, E, Fo, e->tail.act, e->xact, a->stats_ws, stream));
     TRY(finalize_stats(&e->tail, a->stats_ws, cdiv(E, i3d_edge_stats_rows_per_tile(Fo)), Fo, a->aff[0], stream, a->eval_mode));
     const float* x = e->xact;
@@ -428,11 +453,12 @@ static int pna_layer_fwd_fused(const I3dPnaLayerArgs* a, void* stream) {
     const I3dGroupedFcArgs* p = &a->post;
     I3D_CHECK_ARG(p->pre_keep == nullptr && simple_act(p->tail.act), "fused BatchNorm: unsupported block shape");
     const int A = p->agg_width, Fp = p->f_out;
-    TRY(i3d_gemm_f32(0, 1, N, Fp, p->f_h, p->h, p->f_h, p->W, p->ldw, p->xact, Fp, p->bias, 0, stream));
+    if (!merged) TRY(i3d_gemm_f32(0, 1, N, Fp, p->f_h, p->h, p->f_h, p->W, p->ldw, p->xact, Fp, p->bias, 0, stream));
     if (!a->weights_ready)
         TRY(i3d_pna_combine_weights_fwd(p->W, p->ldw, p->f_h, Fp, A, p->n_groups, p->n_scalers, p->coef, p->WD, stream));
-    TRY(i3d_gemm_f32_fused(p->m_padded, Fp, A, p->agg, A, N, p->WD, A, p->xact, Fp, nullptr, 1, nullptr, p->tail.act,
-                           a->stats_ws, p->deg_rows, p->deg_tile_group, (long)Fp * A, stream));
+    // merged: the h-product is the last Fp columns of PL - the grouped GEMM takes its addend from there
+    TRY(i3d_gemm_f32_fused_src(p->m_padded, Fp, A, p->agg, A, N, p->WD, A, p->xact, Fp, merged ? a->PL + 2 * Fo : nullptr, WL,
+                               nullptr, 1, nullptr, p->tail.act, a->stats_ws, p->deg_rows, p->deg_tile_group, (long)Fp * A, stream));
     if (a->eval_mode)
         return i3d_bn_eval_fwd(p->xact, N, Fp, p->tail.running_mean, p->tail.running_var, p->tail.eps, p->tail.gamma, p->tail.beta,
                                p->tail.post_act, p->residual, p->y, stream);
@@ -448,6 +474,8 @@ extern "C" int i3d_pna_layer_weights_fwd(const I3dPnaLayerArgs* a, void* stream)
     if (e->q != nullptr)
         TRY(i3d_gemm_f32(0, 1, e->q_rows > 0 ? e->q_rows : e->num_edges, e->f_out, e->f_q, e->q, e->f_q, e->W + 2 * e->f_h, e->ldw,
                          e->Q, e->f_out, nullptr, 0, stream));
+    if (merge_h_ok(a))
+        TRY(i3d_pna_pack_h_weights(e->W, e->ldw, e->f_out, p->W, p->ldw, p->f_out, p->bias, e->f_h, a->Wcat, a->bcat, stream));
     return i3d_pna_combine_weights_fwd(p->W, p->ldw, p->f_h, p->f_out, p->agg_width, p->n_groups, p->n_scalers, p->coef, p->WD,
                                        stream);
 }
@@ -504,13 +532,28 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     // blocks (then post.grad_y IS grad_out and its last reader, the BatchNorm backward, runs before that GEMM).
     const bool inplace = a->residual && a->post.grad_h == a->grad_out && a->n_post_extra == 0;
     I3D_CHECK_ARG(a->post.grad_h != a->grad_out || inplace, "grad_h may alias grad_out only for a residual layer without extra blocks");
-    TRY(grouped_fc_bn_bwd_chain(&a->post, stream, inplace ? 1 : 0));
-    const long n = (long)a->edge.num_nodes * a->edge.f_h;
-    // separate buffers: the residual's term right here, so that both forms add in the same order (dh_out + dlin W_h) + ...
-    if (a->residual && !inplace) TRY(i3d_add_inplace(a->post.grad_h, a->grad_out, n, stream));
     // round 3: every weight gradient of the layer from one launch behind ONE fork (after dP exists) when the layer's shape
     // allows it; otherwise the per-block launches behind two / three forks
     const bool multi = wgrad_multi_layer_ok(a);
+    // merged h-products (I3dPnaLayerArgs.merge_h): dlin goes into the last columns of DL = [dP | dlin], the posttrans block's
+    // own dL/dh GEMM is dropped and ONE GEMM  dL/dh (+)= DL [W_s ; W_d ; W_h]  closes the layer (needs the one-launch weight
+    // gradients: they take dlin / dP with DL's row pitch)
+    const bool merged = multi && merge_h_ok(a) && a->DL != nullptr;
+    const long n = (long)a->edge.num_nodes * a->edge.f_h;
+    if (merged) {
+        const I3dGroupedFcArgs* g = &a->post;
+        const int WLb = 2 * a->edge.f_out + g->f_out;
+        float* dlin = a->DL + 2 * a->edge.f_out;
+        TRY(i3d_bn_bwd_strided(g->grad_y, g->xact, g->pre_keep, g->num_nodes, g->f_out, g->tail.act, g->tail.post_act, g->tail.mean,
+                               g->tail.invstd, g->tail.gamma, g->tail.beta, g->grad_gamma, g->grad_beta, dlin, WLb, g->grad_bias,
+                               g->tail.workspace, g->tail.bias_partial, stream));
+        TRY(i3d_gemm_f32_grouped(0, g->m_padded, g->agg_width, g->f_out, dlin, WLb, g->num_nodes, g->deg_rows, g->deg_tile_group, g->WD,
+                                 g->agg_width, (long)g->f_out * g->agg_width, g->grad_agg, g->agg_width, 0, stream));
+    } else {
+        TRY(grouped_fc_bn_bwd_chain(&a->post, stream, inplace ? 1 : 0));
+        // separate buffers: the residual's term right here, so that both forms add in the same order (dh_out + dlin W_h) + ...
+        if (a->residual && !inplace) TRY(i3d_add_inplace(a->post.grad_h, a->grad_out, n, stream));
+    }
     void* wst = stream;
     if (multi && a->wgrad_split) {
         wst = fork_wgrad(x, stream);
@@ -533,7 +576,14 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_chain(&a->pre[i], stream));
     TRY(edge_fc_bn_bwd_tail(&a->edge, stream));
     if (multi) {
-        TRY(edge_fc_bn_bwd_sums(&a->edge, stream));
+        if (merged) {       // dP[src] | dP[dst] straight into the first 2 Fo columns of DL
+            const I3dEdgeFcArgs* e = &a->edge;
+            const int WLb = 2 * e->f_out + a->post.f_out;
+            TRY(i3d_segment_sum(e->grad_pre, e->f_out, e->out_ptr, e->out_epos, e->num_nodes, e->f_out, 0, a->DL, WLb, stream));
+            TRY(i3d_segment_sum(e->grad_pre, e->f_out, e->in_ptr, nullptr, e->num_nodes, e->f_out, 0, a->DL + e->f_out, WLb, stream));
+        } else {
+            TRY(edge_fc_bn_bwd_sums(&a->edge, stream));
+        }
         wst = fork_wgrad(x, stream);
         const int took = pna_layer_wgrad_multi(a, wst, false, a->wgrad_split ? 2 : 0);
         if (took < 0) return took;
@@ -551,7 +601,14 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
         for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_wgrad(&a->pre[i], wst, a->fused_bn ? a->aff[i] : nullptr));
         TRY(edge_fc_bn_bwd_wgrad(&a->edge, wst));
     }
-    TRY(edge_fc_bn_bwd_dgrad(&a->edge, stream, a->post.grad_h));       // post.grad_h += edge block's dh
+    if (merged) {
+        const int WLb = 2 * a->edge.f_out + a->post.f_out;
+        TRY(i3d_gemm_f32(0, 0, a->edge.num_nodes, a->edge.f_h, WLb, a->DL, WLb, a->Wcat, a->edge.f_h, a->post.grad_h, a->edge.f_h,
+                         nullptr, inplace ? 1 : 0, stream));
+        if (a->residual && !inplace) TRY(i3d_add_inplace(a->post.grad_h, a->grad_out, n, stream));
+    } else {
+        TRY(edge_fc_bn_bwd_dgrad(&a->edge, stream, a->post.grad_h));       // post.grad_h += edge block's dh
+    }
     if (a->defer_join) return I3D_OK;
     return join_wgrad(x, stream);
 }

@@ -65,6 +65,8 @@ struct GemmArgs {
                             // values this launch stores (after bias / accumulate / epi_act): the BatchNorm statistics of
                             // THIS block without a pass over its output (bn_finalize_partials_kernel combines the tiles)
     int epi_act;            // activation applied to the stored value (I3D_ACT_*)
+    const float* Cin;       // FUSE & 2 with accumulate: the addend is read from Cin (row pitch ldcin) instead of C - the addend may
+    int ldcin;              // be a column block of a wider matrix (the merged [P | lin_h] product of a PNA layer); null: C itself
 };
 
 __device__ __forceinline__ int swz(int k, int idx) { return idx ^ ((((k) ^ (k >> 2)) & 1) << 4); }
@@ -492,9 +494,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
                 if constexpr ((FUSE & 2) != 0) {
                     // C (+)= ... then the activation; the stored values also go to the LDS tile for the column statistics
                     if (g.accumulate) {
+                        const float* ci = g.Cin != nullptr ? g.Cin + (long)row * g.ldcin + n : c;
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (n + q < g.N) r[q] += c[q];
+                            if (n + q < g.N) r[q] += ci[q];
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) r[q] = apply_act(r[q], g.epi_act);
@@ -937,7 +940,7 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     g.accumulate = accumulate ? 1 : 0;
     g.m_rows = ex.m_rows; g.k_rows = nullptr; g.tile_group = ex.tile_group; g.b_group_stride = ex.b_group_stride;
     g.slab = nullptr;
-    g.a_aff = nullptr; g.stats = nullptr; g.epi_act = I3D_ACT_NONE;
+    g.a_aff = nullptr; g.stats = nullptr; g.epi_act = I3D_ACT_NONE; g.Cin = nullptr; g.ldcin = 0;
     g.b_split = ex.b_split; g.b_delta = ex.b_delta; g.c_split = ex.c_split; g.c_delta = ex.c_delta;
     int rc = fill_views(g, trans_a, trans_b, M, N, K, lda, ldb, ex);
     if (rc != I3D_OK) return rc;
@@ -1094,7 +1097,7 @@ static int rowseg_impl(int M, int N, const float* A, int lda, const float* B, in
     g.accumulate = 1; g.atomic_out = 1; g.k_per_split = 0;
     g.m_rows = nullptr; g.k_rows = ex.k_rows; g.tile_group = nullptr; g.b_group_stride = 0;
     g.slab = nullptr;
-    g.a_aff = nullptr; g.stats = nullptr; g.epi_act = I3D_ACT_NONE;
+    g.a_aff = nullptr; g.stats = nullptr; g.epi_act = I3D_ACT_NONE; g.Cin = nullptr; g.ldcin = 0;
     g.b_split = g.c_split = 0x7fffffff; g.b_delta = g.c_delta = 0;
     int rc = fill_views(g, 1, 0, M, N, k_hi, lda, ldb, ex);
     if (rc != I3D_OK) return rc;
@@ -1274,6 +1277,17 @@ extern "C" int i3d_gemm_f32_fused(int M, int N, int K, const float* A, int lda, 
                                   float* C, int ldc, const float* bias, int accumulate, const float* a_aff, int epi_act,
                                   float* stats, const int* m_rows, const int* tile_group, long b_group_stride,
                                   void* stream) {
+    return i3d_gemm_f32_fused_src(M, N, K, A, lda, a_rows_total, W, ldb, C, ldc, nullptr, 0, bias, accumulate, a_aff, epi_act, stats,
+                                  m_rows, tile_group, b_group_stride, stream);
+}
+
+// i3d_gemm_f32_fused with the addend of `accumulate` read from c_in (row pitch ldcin) instead of C
+extern "C" int i3d_gemm_f32_fused_src(int M, int N, int K, const float* A, int lda, long a_rows_total, const float* W, int ldb,
+                                      float* C, int ldc, const float* c_in, int ldcin, const float* bias, int accumulate,
+                                      const float* a_aff, int epi_act, float* stats, const int* m_rows, const int* tile_group,
+                                      long b_group_stride, void* stream) {
+    I3D_CHECK_ARG(c_in == nullptr || (stats != nullptr && accumulate && ldcin >= N && ldcin % 4 == 0 && (((uintptr_t)c_in) & 15) == 0),
+                  "c_in needs the statistics variant with accumulate, a pitch >= N that is a multiple of 4, 16-byte alignment");
     I3D_CHECK_ARG(M > 0 && N > 0 && K > 0, "empty GEMM");
     I3D_CHECK_ARG(a_aff != nullptr || stats != nullptr, "nothing to fuse: use i3d_gemm_f32");
     I3D_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "leading dimension too small");
@@ -1294,7 +1308,7 @@ extern "C" int i3d_gemm_f32_fused(int M, int N, int K, const float* A, int lda, 
     g.m_rows = m_rows; g.k_rows = nullptr; g.tile_group = tile_group; g.b_group_stride = b_group_stride;
     g.b_split = g.c_split = 0x7fffffff; g.b_delta = g.c_delta = 0;
     g.slab = nullptr;
-    g.a_aff = a_aff; g.stats = stats; g.epi_act = epi_act;
+    g.a_aff = a_aff; g.stats = stats; g.epi_act = epi_act; g.Cin = c_in; g.ldcin = ldcin;
     Extra ex;
     ex.m_rows = m_rows; ex.a_rows_total = a_rows_total;
     int rc = fill_views(g, 0, 1, M, N, K, lda, ldb, ex);

@@ -65,6 +65,23 @@ combine_weights_bwd_kernel(const float4* __restrict__ dWD, int ldw4, int f_in4, 
     for (int s = 0; s < S; ++s) dW[(long)n * ldw4 + f_in4 + (long)s * A4 + k] = acc[s];
 }
 
+// Wcat [2 Fo + Fp, Fh] = [W_s ; W_d ; W_h] (row blocks), bcat = [0 | 0 | b_post]: the three products of a PNA layer that read
+// the node features h - P = h [W_s | W_d]^T of the edge block and lin_h = h W_h^T + b of the posttrans block - as ONE GEMM
+__global__ void __launch_bounds__(256)
+pack_h_weights_kernel(const float4* __restrict__ We, int ldwe4, int Fo, const float4* __restrict__ Wp, int ldwp4, int Fp,
+                      const float* __restrict__ bias_p, int Fh4, float4* __restrict__ Wcat, float* __restrict__ bcat) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int rows = 2 * Fo + Fp;
+    if (t < rows) bcat[t] = t < 2 * Fo ? 0.f : (bias_p != nullptr ? bias_p[t - 2 * Fo] : 0.f);
+    if (t >= (long)rows * Fh4) return;
+    const int r = (int)(t / Fh4), k = (int)(t - (long)r * Fh4);
+    float4 v;
+    if (r < Fo) v = We[(long)r * ldwe4 + k];
+    else if (r < 2 * Fo) v = We[(long)(r - Fo) * ldwe4 + Fh4 + k];
+    else v = Wp[(long)(r - 2 * Fo) * ldwp4 + k];
+    Wcat[t] = v;
+}
+
 #define I3D_COMBINE_LAUNCH(KERNEL, ...)                                                                         \
     switch (n_scalers) {                                                                                        \
         case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
@@ -106,6 +123,20 @@ extern "C" int i3d_pna_combine_weights_bwd(const float* dWD, int ldw, int f_in, 
     long items = (long)f_out * (agg_width / 4);
     I3D_COMBINE_LAUNCH(combine_weights_bwd_kernel, (const float4*)dWD, ldw / 4, f_in / 4, f_out, agg_width / 4, n_groups, c,
                        (float4*)dW);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_pna_pack_h_weights(const float* W_edge, int ldw_edge, int f_out_edge, const float* W_post, int ldw_post,
+                                      int f_out_post, const float* bias_post, int f_h, float* Wcat, float* bcat, void* stream) {
+    I3D_CHECK_ARG(W_edge != nullptr && W_post != nullptr && Wcat != nullptr && bcat != nullptr, "null");
+    I3D_CHECK_ARG(f_h % 4 == 0 && ldw_edge % 4 == 0 && ldw_post % 4 == 0 && ldw_edge >= 2 * f_h && ldw_post >= f_h,
+                  "dimensions must be multiples of 4");
+    I3D_CHECK_ARG((((uintptr_t)W_edge | (uintptr_t)W_post | (uintptr_t)Wcat) & 15) == 0, "16-byte aligned pointers required");
+    const long items = (long)(2 * f_out_edge + f_out_post) * (f_h / 4);
+    hipLaunchKernelGGL(pack_h_weights_kernel, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)W_edge,
+                       ldw_edge / 4, f_out_edge, (const float4*)W_post, ldw_post / 4, f_out_post, bias_post, f_h / 4, (float4*)Wcat,
+                       bcat);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }

@@ -116,6 +116,13 @@ bool split_last_wgrad() {
     return on;
 }
 
+// I3D_MERGE_H=0: the products that read the node features (edge block's P, posttrans block's h-term, and their data gradients)
+// as separate GEMMs (round 2) instead of one per direction
+bool merge_h() {
+    static const bool on = [] { const char* e = getenv("I3D_MERGE_H"); return e == nullptr || e[0] != '0'; }();
+    return on;
+}
+
 bool simple_act(int act) { return act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU; }
 
 void fill_tail(I3dBnTail& t, const I3dFcParams& p, float* mean, float* invstd) {
@@ -165,6 +172,7 @@ long side_floats(const I3dPnaModel& m, const I3dPnaBatch& b, int l) {
     long t = al4(N * F) + al4((long)b.n_groups * F * A) + al4(i3d_bn_bias_partial_floats((int)F));
     for (int i = 1; i < m.n_pre; ++i) t += al4(E * (long)m.pre[l][i].f_out) + al4(i3d_bn_bias_partial_floats(m.pre[l][i].f_out));
     t += al4(E * Fo0) + al4(N * 2 * Fo0) + al4((long)b.v_pad * Fo0) + al4(i3d_bn_bias_partial_floats((int)Fo0));
+    t += al4(N * (2 * Fo0 + F));        // DL (merged h-products)
     return t;
 }
 
@@ -229,6 +237,12 @@ long plan_forward(PnaCtx& c, float* saved, float* node_emb, float* out) {
         e.src_s = b.src_s; e.dst_s = b.dst_s; e.in_ptr = b.in_ptr; e.out_ptr = b.out_ptr; e.out_epos = b.out_epos;
         e.Q = ar.take((long)b.n_comb * Fo0);
         e.P = ar.take((long)N * 2 * Fo0);
+        if (merge_h()) {
+            a.merge_h = 1;
+            a.Wcat = ar.take((long)(2 * Fo0 + F) * F);
+            a.bcat = ar.take(2 * Fo0 + F);
+            a.PL = ar.take((long)N * (2 * Fo0 + F));
+        }
         e.xact = ar.take((long)E * Fo0);
         a.aff[0] = ar.take(3L * Fo0);
         const float* x = e.xact;
@@ -331,6 +345,7 @@ extern "C" long i3d_pna_model_scratch_floats(const I3dPnaModel* m, const I3dPnaB
         for (int i = 1; i < m->n_pre; ++i)
             t += al4(E * (long)m->pre[l][i].f_out) + al4(E * (long)m->pre[l][i].f_in) + al4(i3d_bn_bias_partial_floats(m->pre[l][i].f_out));
         t += al4(E * Fo0) + al4(N * 2 * Fo0) + al4(N * F) + al4((long)b->v_pad * Fo0) + al4(i3d_bn_bias_partial_floats(Fo0));
+        t += al4(N * (2 * Fo0 + F));
         layer = std::max(layer, t);
     }
     long oa = 0, ob = 0;
@@ -542,6 +557,7 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
         e.grad_y = gy;
         e.grad_pre = sd.take((long)E * e.f_out);
         e.grad_P = sd.take((long)N * 2 * e.f_out);
+        a.DL = a.merge_h ? sd.take((long)N * (2 * e.f_out + F)) : nullptr;
         e.grad_h = ar.take((long)N * F);
         e.grad_Q = sd.take((long)b.v_pad * e.f_out);
         e.tail.bias_partial = defer_bias() ? sd.take(i3d_bn_bias_partial_floats(e.f_out)) : nullptr;

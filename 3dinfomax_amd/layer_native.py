@@ -22,6 +22,8 @@ NATIVE_LAYER = os.environ.get('I3D_NATIVE_LAYER', '1') != '0'
 # I3D_FUSED_BN=0: round-1 form of the layer (statistics pass + apply pass per block); default: BatchNorm statistics in the
 # producers' epilogues, BatchNorm-apply in the consumers' loads (csrc/fused_bn.hip).  Same arithmetic up to summation order.
 FUSED_BN = os.environ.get('I3D_FUSED_BN', '1') != '0'
+# I3D_MERGE_H=0: the products that read the node features as separate GEMMs (csrc/model.hip reads the same switch)
+MERGE_H = os.environ.get('I3D_MERGE_H', '1') != '0'
 _SIMPLE_ACTS = (None, 'relu', 'leakyrelu')
 KEEP_LAST_ARGS = None
 
@@ -124,6 +126,10 @@ def forward(ctx, h, q, index, qmap, plan, params):
         n_stats = int(L.i3d_pna_layer_stats_floats(N, E, rows_d.shape[0], f_max))
         total += _al(n_stats)
     total += _al(N * A) + _al(nG * Fp0 * A)
+    merged = fused and n_post == 1 and MERGE_H and Fp0 % 4 == 0          # csrc/composite.hip: merge_h_ok
+    WL = 2 * Fo0 + Fp0
+    if merged:
+        total += _al(WL * Fh) + _al(WL) + _al(N * WL)
     for i, spec in enumerate(plan.post_specs):
         Fo = post_p[i][0].shape[0]
         total += _al(N * Fo) * (2 + (1 if _keeps_pre(spec) else 0)) + 2 * _al(Fo)
@@ -150,6 +156,9 @@ def forward(ctx, h, q, index, qmap, plan, params):
     e.src_s, e.dst_s, e.in_ptr = index.src_s.data_ptr(), index.dst_s.data_ptr(), index.in_ptr.data_ptr()
     e.out_ptr, e.out_epos = index.out_ptr.data_ptr(), index.out_epos.data_ptr()
     e.P = ar.take(N * 2 * Fo0)
+    if merged:          # the products that read h as one GEMM per direction (include/infomax3d_hip.h: I3dPnaLayerArgs.merge_h)
+        a.merge_h = 1
+        a.Wcat, a.bcat, a.PL = ar.take(WL * Fh), ar.take(WL), ar.take(N * WL)
     e.xact = ar.take(E * Fo0)
     if _keeps_pre(spec):
         e.pre_keep = ar.take(E * Fo0)
@@ -260,6 +269,8 @@ def backward(ctx, grad):
     for (Fo, Fi) in dims_pre[1:]:
         total += _al(E * Fo) + _al(E * Fi)
     total += _al(E * Fo0) + _al(N * 2 * Fo0) + _al(N * Fh) + (_al(qmap.v_pad * Fo0) if (qmap is not None and q is not None) else 0)
+    if a.merge_h:
+        total += _al(N * (2 * Fo0 + Fp0))
     ar = _Arena(total, dev)
     grads = []          # (gW, gbias, ggamma, gbeta) per block, forward order
 
@@ -310,6 +321,8 @@ def backward(ctx, grad):
     set_param_grads(e, g4)
     gq = torch.empty_like(q) if need_q else None
     e.grad_y, e.grad_pre, e.grad_P, e.grad_h = gy, ar.take(E * Fo0), ar.take(N * 2 * Fo0), ar.take(N * Fh)
+    if a.merge_h:
+        a.DL = ar.take(N * (2 * Fo0 + Fp0))
     e.grad_q = gq.data_ptr() if gq is not None else None
     if qmap is not None and q is not None:
         e.grad_Q = ar.take(qmap.v_pad * Fo0)

@@ -319,6 +319,20 @@ int i3d_edge_combine_act_stats(const float* P, int ldp, const float* Q, const in
 int i3d_gemm_f32_fused(int M, int N, int K, const float* A, int lda, long a_rows_total, const float* W, int ldb, float* C,
                        int ldc, const float* bias, int accumulate, const float* a_aff, int epi_act, float* stats,
                        const int* m_rows, const int* tile_group, long b_group_stride, void* stream);
+/* i3d_gemm_f32_fused whose `accumulate` addend is read from c_in (row pitch ldcin) instead of C */
+int i3d_gemm_f32_fused_src(int M, int N, int K, const float* A, int lda, long a_rows_total, const float* W, int ldb, float* C,
+                           int ldc, const float* c_in, int ldcin, const float* bias, int accumulate, const float* a_aff,
+                           int epi_act, float* stats, const int* m_rows, const int* tile_group, long b_group_stride,
+                           void* stream);
+/* Wcat [2 f_out_edge + f_out_post, f_h] = [W_s ; W_d ; W_h], bcat = [0 | 0 | bias_post] (I3dPnaLayerArgs.merge_h) */
+int i3d_pna_pack_h_weights(const float* W_edge, int ldw_edge, int f_out_edge, const float* W_post, int ldw_post, int f_out_post,
+                           const float* bias_post, int f_h, float* Wcat, float* bcat, void* stream);
+/* i3d_bn_bwd_deferred_bias (local statistics or the process-wide collectives) with grad_pre as a column block of a wider
+ * matrix: row pitch ld_out floats */
+int i3d_bn_bwd_strided(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act, int post_act,
+                       const float* mean, const float* invstd, const float* gamma, const float* beta, float* grad_gamma,
+                       float* grad_beta, float* grad_pre, int ld_out, float* grad_bias, void* workspace, float* bias_partial,
+                       void* stream);
 /* dW[f_out,f_in] = dY^T y for y = (x - mean) * scale + shift (aff over f_in) computed from the raw x; grad_bias[f_out] =
  * column sums of dY (already computed) */
 int i3d_gemm_f32_wgrad_bn(int f_out, int f_in, int rows, const float* dY, int ldy, const float* x, int ldx, float* dW,
@@ -545,6 +559,17 @@ typedef struct { /* one PNA layer, reference models/pna.py:199-216: pretrans edg
     float* aff[I3D_MAX_EXTRA_FC + 1];  /* [3 f_out] mean | gamma invstd | beta of the edge block and of pre[i] (saved) */
     int weights_ready; /* forward (fused_bn): edge.Q and post.WD - products of parameters and the bond table only - are already
                         * there (i3d_pna_layer_weights_fwd, e.g. on the side stream while the layers before this one run) */
+    /* round 3: the products that read the node features h as ONE GEMM per direction.  Forward: PL [N, 2 f_out(edge) + f_out(post)]
+     * = h Wcat^T + bcat (Wcat = [W_s ; W_d ; W_h] packed by i3d_pna_pack_h_weights) - its first 2 f_out columns are the edge
+     * block's P, the rest the posttrans block's h-product, which the grouped GEMM takes as its addend.  Backward: DL (same
+     * shape) = [dP | dlin], dL/dh (+)= DL Wcat in one GEMM at the end of the layer.  merge_h = 1 needs fused_bn,
+     * n_post_extra == 0 and the four buffers (Wcat, bcat, PL saved by the forward pass; DL backward scratch that the
+     * weight-gradient stream reads). */
+    int merge_h;
+    float* Wcat;
+    float* bcat;
+    float* PL;
+    float* DL;
     int wgrad_split;   /* backward: issue the posttrans weight gradients as soon as the posttrans chain is done and the rest at the
                         * end, as two launches (the last layer of a backward pass: nothing runs next to its weight gradients
                         * once the chain has ended); 0: one launch at the end of the layer */
