@@ -229,6 +229,7 @@ _SIGNATURES = {
     'i3d_edge_combine_fwd': (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     'i3d_multihot': (c_int, [_P, _P, c_int, c_int, POINTER(c_int), c_int, _P, _P]),
     'i3d_edge_codes': (c_int, [_P, _P, c_int, c_int, POINTER(c_int), c_int, _P, _P, _P]),
+    'i3d_segment_sum_pair': (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'i3d_segment_sum': (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     'i3d_segment_bcast': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P]),
     'i3d_gather_rows': (c_int, [_P, _P, c_int, c_int, _P, _P]),

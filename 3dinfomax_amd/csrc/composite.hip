@@ -176,8 +176,8 @@ static int edge_fc_bn_bwd_tail(const I3dEdgeFcArgs* a, void* stream) {
 // d P[src] (out-edges through the source index), d P[dst] (in-edges are contiguous): segmented sums, no atomics
 static int edge_fc_bn_bwd_sums(const I3dEdgeFcArgs* a, void* stream) {
     const int Fo = a->f_out, N = a->num_nodes;
-    TRY(i3d_segment_sum(a->grad_pre, Fo, a->out_ptr, a->out_epos, N, Fo, 0, a->grad_P, 2 * Fo, stream));
-    return i3d_segment_sum(a->grad_pre, Fo, a->in_ptr, nullptr, N, Fo, 0, a->grad_P + Fo, 2 * Fo, stream);
+    return i3d_segment_sum_pair(a->grad_pre, Fo, a->out_ptr, a->out_epos, a->grad_P, a->in_ptr, nullptr, a->grad_P + Fo, N, Fo, 2 * Fo,
+                                stream);
 }
 
 static int edge_fc_bn_bwd_chain(const I3dEdgeFcArgs* a, void* stream) {
@@ -579,8 +579,8 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
         if (merged) {       // dP[src] | dP[dst] straight into the first 2 Fo columns of DL
             const I3dEdgeFcArgs* e = &a->edge;
             const int WLb = 2 * e->f_out + a->post.f_out;
-            TRY(i3d_segment_sum(e->grad_pre, e->f_out, e->out_ptr, e->out_epos, e->num_nodes, e->f_out, 0, a->DL, WLb, stream));
-            TRY(i3d_segment_sum(e->grad_pre, e->f_out, e->in_ptr, nullptr, e->num_nodes, e->f_out, 0, a->DL + e->f_out, WLb, stream));
+            TRY(i3d_segment_sum_pair(e->grad_pre, e->f_out, e->out_ptr, e->out_epos, a->DL, e->in_ptr, nullptr, a->DL + e->f_out,
+                                     e->num_nodes, e->f_out, WLb, stream));
         } else {
             TRY(edge_fc_bn_bwd_sums(&a->edge, stream));
         }

@@ -80,13 +80,19 @@ multihot_kernel(const long* __restrict__ idx, const int* __restrict__ row_perm, 
 }
 
 // out[v, :] = scale * sum_{j in [ptr[v], ptr[v+1])} x[idx ? idx[j] : j, :]
-template <int V>
+// PAIR: two segmentations of the same rows in one launch (the edge block's dP[src] over the out-edges and dP[dst] over the
+// in-edges): items [0, nseg FV) take (ptr, idx, out), the next nseg FV take (ptr1, idx1, out1)
+template <int V, bool PAIR = false>
 __global__ void __launch_bounds__(256)
 segment_sum_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ ptr, const int* __restrict__ idx,
-                   int nseg, int feat, int scale_mode, float* __restrict__ out, int ldo) {
+                   int nseg, int feat, int scale_mode, float* __restrict__ out, int ldo,
+                   const int* __restrict__ ptr1 = nullptr, const int* __restrict__ idx1 = nullptr, float* __restrict__ out1 = nullptr) {
     const int FV = feat / V;
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long)nseg * FV) return;
+    if (PAIR) {
+        if (t >= 2L * nseg * FV) return;
+        if (t >= (long)nseg * FV) { t -= (long)nseg * FV; ptr = ptr1; idx = idx1; out = out1; }
+    } else if (t >= (long)nseg * FV) return;
     int v = (int)(t / FV), c = (int)(t - (long)v * FV) * V;
     int beg = ptr[v], end = ptr[v + 1];
     float acc[V];
@@ -309,6 +315,23 @@ extern "C" int i3d_segment_sum(const float* x, int ldx, const int* ptr, const in
         long items = (long)num_segments * feat;
         hipLaunchKernelGGL(segment_sum_kernel<1>, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, ptr,
                            idx, num_segments, feat, scale_mode, out, ldo);
+    }
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_segment_sum_pair(const float* x, int ldx, const int* ptr0, const int* idx0, float* out0, const int* ptr1,
+                                    const int* idx1, float* out1, int num_segments, int feat, int ldo, void* stream) {
+    I3D_CHECK_ARG(num_segments >= 0 && feat > 0 && ldx >= feat && ldo >= feat, "bad shape");
+    if (num_segments == 0) return I3D_OK;
+    if (feat % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && (((uintptr_t)x | (uintptr_t)out0 | (uintptr_t)out1) & 15) == 0) {
+        long items = 2L * num_segments * (feat / 4);
+        hipLaunchKernelGGL((segment_sum_kernel<4, true>), dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, ptr0,
+                           idx0, num_segments, feat, 0, out0, ldo, ptr1, idx1, out1);
+    } else {
+        long items = 2L * num_segments * feat;
+        hipLaunchKernelGGL((segment_sum_kernel<1, true>), dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, ptr0,
+                           idx0, num_segments, feat, 0, out0, ldo, ptr1, idx1, out1);
     }
     I3D_CHECK_LAUNCH();
     return I3D_OK;

@@ -250,6 +250,9 @@ int i3d_edge_codes(const int64_t* idx, const int* row_perm, int rows, int n_cols
                    int* codes, float* onehot, void* stream);
 int i3d_segment_sum(const float* x, int ldx, const int* ptr, const int* idx, int num_segments, int feat,
                     int scale_mode, float* out, int ldo, void* stream);
+/* two segmentations of the same rows in one launch (sums, no scaling): out0 over (ptr0, idx0), out1 over (ptr1, idx1) */
+int i3d_segment_sum_pair(const float* x, int ldx, const int* ptr0, const int* idx0, float* out0, const int* ptr1,
+                         const int* idx1, float* out1, int num_segments, int feat, int ldo, void* stream);
 int i3d_segment_bcast(const float* g, const int* ptr, const int* seg_of_row, int rows, int feat, int scale_mode,
                       float* out, void* stream);
 /* rows gather: out[j,:] = x[idx[j],:]  (edge permutation edge-id -> epos order) */

@@ -426,7 +426,13 @@ def test_pretraining_config_hidden_200_vs_oracle_with_routed_extrema(amd, batch,
     assert rel_err(z2.cpu(), r2.detach()) < TOL and rel_err(z3.cpu(), r3.detach()) < TOL
     flips, total = routing_flips(route, cap, depth)
     assert flips <= 2e-3 * total, (flips, total)
-    grads_close(param_grads(pna), {k: P2[k].grad for k in O.trainable(P2)}, routed_tol(depth), 'pna ')
+    ref2 = {k: P2[k].grad for k in O.trainable(P2)}
+    # depth 7: which side of 0 an activation lands on moves with the GEMM's summation order (the tile configuration): one
+    # flipped gate measured 9.5e-4 absolute = 4e-3 of the largest gradient on layer 5's first pretrans weight (max 1.4e-2,
+    # the other tensors at 1.5e-4); max-norm with that much room, and the tensors as a whole to 1e-2 relative L2
+    grads_close(param_grads(pna), ref2, routed_tol(depth), 'pna ', gate_floor=0.0 if depth <= 4 else 1e-2)
+    if depth > 4:
+        grads_close_l2(param_grads(pna), ref2, 1e-2, 'pna ', floor=5e-5)      # floor: the biases in front of a BatchNorm (noise)
     grads_close_l2(param_grads(net), {k: P3[k].grad for k in O.trainable(P3)}, 5e-2, 'net3d ')
 
 
@@ -776,7 +782,10 @@ def test_process_level_switches_give_the_same_bits():
         "torch.save([p.detach().cpu() for p in params], sys.argv[1])\n") % (root, os.path.join(root, 'tests'))
     res = {}
     variants = {'default': {}, 'no_wgrad_stream': {'I3D_WGRAD_STREAM': '0'}, 'three_forks': {'I3D_WGRAD_FORKS': '3'},
-                'join_per_layer': {'I3D_WGRAD_JOIN': 'layer'}, 'python_sequenced_loss': {'I3D_LOSS_COMPOSITE': '0'},
+                'join_per_layer': {'I3D_WGRAD_JOIN': 'layer'},
+                # the loss sequenced from Python runs the first version's kernels (two norm launches, row_axpy after the
+                # GEMMs): the same bits as the C sequencer with I3D_LOSS_FUSED=0
+                'python_sequenced_loss': {'I3D_LOSS_COMPOSITE': '0'}, 'unfused_loss': {'I3D_LOSS_FUSED': '0'},
                 'torch_adam_kernel': None,
                 'fresh_grads': {'I3D_PERSISTENT_GRADS': '0'}, 'separate_final': {'I3D_FUSED_FINAL': '0'},
                 # the whole PNA pass from one C call per direction (csrc/model.hip) vs. sequenced layer by layer from Python
@@ -790,7 +799,10 @@ def test_process_level_switches_give_the_same_bits():
         res[name] = torch.load(path)
     assert len(res['default']) > 50
     for name in variants:
-        for a, b in zip(res['default'], res[name]):
+        base = 'unfused_loss' if name == 'python_sequenced_loss' else 'default'
+        if name == 'unfused_loss':
+            continue      # another summation order (both against the oracle to 2e-5: test_gpu_ops.test_ntxent_fwd_bwd_vs_oracle)
+        for a, b in zip(res[base], res[name]):
             assert torch.equal(a, b), name
 
 
