@@ -37,6 +37,7 @@ __device__ __forceinline__ void adam_update(float& param, float grad, float& exp
 __global__ void __launch_bounds__(256)
 adam_kernel(const AdamChunk* __restrict__ table, int n_chunks, float* steps, int n_steps, double lr, double beta1, double beta2,
             double weight_decay, double eps, float bc1, float bc2_sqrt) {
+    I3D_CHAIN_PRIO();
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < n_steps; i += 256) steps[i] += 1.f;
     const AdamChunk c = table[blockIdx.x];

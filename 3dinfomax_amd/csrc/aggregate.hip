@@ -59,6 +59,7 @@ template <int MODE>
 __global__ void __launch_bounds__(256)
 pna_aggregate_fwd_kernel(const float4* __restrict__ e, const int* __restrict__ in_ptr, int N, int FV,
                          AggCfg cfg, float4* __restrict__ out, const float4* __restrict__ aff) {
+    I3D_CHAIN_PRIO();
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)N * FV) return;
     int v = (int)(t / FV), c = (int)(t - (long)v * FV);
@@ -156,6 +157,7 @@ pna_aggregate_fwd_kernel(const float4* __restrict__ e, const int* __restrict__ i
 __global__ void __launch_bounds__(256)
 pna_aggregate_fwd_scalar_kernel(const float* __restrict__ e, const int* __restrict__ in_ptr, int N, int F,
                                 AggCfg cfg, float* __restrict__ out) {
+    I3D_CHAIN_PRIO();
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)N * F) return;
     int v = (int)(t / F), c = (int)(t - (long)v * F);
@@ -212,6 +214,7 @@ __global__ void __launch_bounds__(256)
 pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ e,
                          const int* __restrict__ in_ptr, int N, int F, AggCfg cfg, float* __restrict__ ge,
                          const float* __restrict__ aff) {
+    I3D_CHAIN_PRIO();
     const int FV = F / V;
     // mean | scale | shift of the messages' BatchNorm is ONE [3F] vector for the whole launch: staged in LDS once per
     // workgroup (round 2 loaded it per (node, chunk) item: three more 16-byte global loads per lane, 12.3 -> 16.8 us)
@@ -571,6 +574,7 @@ extern "C" int i3d_pna_aggregate_bwd_aff(const float* grad_out, const float* e, 
 // expression (and the same -ffp-contract=off build) - a test derives the kernels' arg-max / arg-min choices from them
 __global__ void __launch_bounds__(256) pna_messages_kernel(const float* __restrict__ e, const float* __restrict__ aff, long rows,
                                                            int F, float* __restrict__ out) {
+    I3D_CHAIN_PRIO();
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= rows * F) return;
     const int c = (int)(t % F);

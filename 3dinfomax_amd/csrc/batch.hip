@@ -28,6 +28,7 @@ complete_graph_kernel(const float* __restrict__ coords, const int* __restrict__ 
                       int* __restrict__ in_ptr, int* __restrict__ src_s, int* __restrict__ dst_s,
                       int* __restrict__ perm, int* __restrict__ inv_perm, int* __restrict__ out_epos,
                       int64_t* __restrict__ src_id, int64_t* __restrict__ dst_id, float* __restrict__ d_id) {
+    I3D_CHAIN_PRIO();
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t <= num_nodes) {     // node-level: CSR row pointer (identical by destination and by source)
         if (t == num_nodes) {

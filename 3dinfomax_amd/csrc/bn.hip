@@ -192,6 +192,7 @@ struct ReduceArgs {
 
 template <int MODE, int V>
 __global__ void __launch_bounds__(256) colreduce_partial_kernel(ReduceArgs g, Chunking ch, Final fin) {
+    I3D_CHAIN_PRIO();
     __shared__ float sm[2][256 * 4];
     const int t = threadIdx.x;
     const int cl = t % ch.tpr, rlane = t / ch.tpr;
@@ -325,6 +326,7 @@ __global__ void stats_final_kernel(const float* __restrict__ partial, int nblk, 
                                    int act, int rows, int feat, float eps, float momentum, float* mean, float* invstd,
                                    float* running_mean, float* running_var, double* sums_out,
                                    long long* batches_tracked) {
+    I3D_CHAIN_PRIO();
     int c;
     double s1, s2;
     if (!reduce_partials(partial, nblk, feat, c, s1, s2)) return;
@@ -352,6 +354,7 @@ __global__ void stats_final_kernel(const float* __restrict__ partial, int nblk, 
 __global__ void stats_from_sums_kernel(const double* __restrict__ sums, int feat, float eps, float momentum, float* mean,
                                        float* invstd, float* running_mean, float* running_var,
                                        long long* batches_tracked = nullptr) {
+    I3D_CHAIN_PRIO();
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= feat) return;
     if (c == 0 && batches_tracked != nullptr) *batches_tracked += 1;
@@ -371,6 +374,7 @@ __global__ void stats_from_sums_kernel(const double* __restrict__ sums, int feat
 // sums of the two partial columns -> out1[feat], out2[feat] (fp32) or fp64 sums_out[2*feat]
 __global__ void pair_final_kernel(const float* __restrict__ partial, int nblk, int feat, float* out1, float* out2,
                                   double* sums_out) {
+    I3D_CHAIN_PRIO();
     int c;
     double s1, s2;
     if (!reduce_partials(partial, nblk, feat, c, s1, s2)) return;
@@ -383,12 +387,14 @@ __global__ void pair_final_kernel(const float* __restrict__ partial, int nblk, i
 }
 
 __global__ void invstd_from_var_kernel(const float* __restrict__ rv, int feat, float eps, float* __restrict__ o) {
+    I3D_CHAIN_PRIO();
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < feat) o[c] = 1.f / sqrtf(rv[c] + eps);
 }
 
 // fp64 all-reduced sums {sum dy, sum dy*xhat, count} -> fp32 scratch {.., .., 1/count}
 __global__ void sums_to_float_kernel(const double* __restrict__ sums, int feat, float* out1, float* out2) {
+    I3D_CHAIN_PRIO();
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= feat) return;
     out1[c] = (float)sums[c];
@@ -428,6 +434,7 @@ static RowTiling make_row_tiling(int feat, int V) {
 
 template <int V>
 __global__ void __launch_bounds__(256) bn_apply_kernel(ApplyArgs g, RowTiling rt, int rows) {
+    I3D_CHAIN_PRIO();
     const int cl = threadIdx.x % rt.tpr, rlane = threadIdx.x / rt.tpr;
     const int cvi = blockIdx.y * rt.tpr + cl;
     if (rlane >= rt.rl || cvi >= rt.cv) return;
@@ -498,6 +505,7 @@ struct BwdApplyArgs {
 
 template <int V>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BwdApplyArgs g, RowTiling rt, int rows) {
+    I3D_CHAIN_PRIO();
     const int cl = threadIdx.x % rt.tpr, rlane = threadIdx.x / rt.tpr;
     const int cvi = blockIdx.y * rt.tpr + cl;
     if (rlane >= rt.rl || cvi >= rt.cv) return;
@@ -566,6 +574,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BwdApplyArgs g, RowTi
 template <int V>
 __global__ void __launch_bounds__(256) bn_bwd_apply_colsum_kernel(BwdApplyArgs g, Chunking ch, int rows, float* partial,
                                                                   Final fin) {
+    I3D_CHAIN_PRIO();
     __shared__ float sm[256 * 4];
     const int t = threadIdx.x;
     const int cl = t % ch.tpr, rlane = t / ch.tpr;
@@ -652,27 +661,32 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_colsum_kernel(BwdApplyArgs g
 }
 
 __global__ void __launch_bounds__(256) act_fwd_kernel(const float* __restrict__ x, long n, int act, float* __restrict__ y) {
+    I3D_CHAIN_PRIO();
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
         y[t] = apply_act(x[t], act);
 }
 
 __global__ void __launch_bounds__(256)
 act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, long n, int act, float* __restrict__ gx) {
+    I3D_CHAIN_PRIO();
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
         gx[t] = gy[t] * act_grad(x[t], act);
 }
 
 __global__ void __launch_bounds__(256) add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, long n) {
+    I3D_CHAIN_PRIO();
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) dst[t] += src[t];
 }
 
 __global__ void __launch_bounds__(256) add_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
                                                   float* __restrict__ out) {
+    I3D_CHAIN_PRIO();
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) out[t] = a[t] + b[t];
 }
 
 __global__ void __launch_bounds__(256) broadcast_row_kernel(const float* __restrict__ row, long rows, int feat,
                                                             float* __restrict__ out) {
+    I3D_CHAIN_PRIO();
     const long n = rows * feat;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) out[t] = row[t % feat];
 }

@@ -37,6 +37,16 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 constexpr int WAVE = 64;
 
+// First statement of every kernel of the step's dependent chain (everything but the weight-gradient family of wgrad.hip and
+// the 3D network's edge kernels, which run beside it on streams of their own): wave priority 3.  The weight-gradient panels
+// are a hundred microseconds of back-to-back MFMA on every CU; at equal priority the SIMD's arbiter serves those (older)
+// waves first and the small latency-bound kernels of the chain take 2-5 x as long next to them as alone (the BatchNorm
+// backward reduction: 13 us alone, 74 us beside a panel kernel, 25-30 us with this; step 2.246 -> 2.176 ms).
+#ifndef I3D_CHAIN_PRIO_LEVEL
+#define I3D_CHAIN_PRIO_LEVEL 3
+#endif
+#define I3D_CHAIN_PRIO() __builtin_amdgcn_s_setprio(I3D_CHAIN_PRIO_LEVEL)
+
 __device__ __forceinline__ float apply_act(float x, int act) {
     switch (act) {
         case I3D_ACT_RELU: return x > 0.f ? x : 0.f;

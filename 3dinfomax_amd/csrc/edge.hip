@@ -13,6 +13,7 @@ __global__ void __launch_bounds__(256)
 edge_combine_fwd_kernel(const float* __restrict__ P, int ldp, const float* __restrict__ Q, const int* __restrict__ q_code,
                         const float* __restrict__ bias, const int* __restrict__ src, const int* __restrict__ dst,
                         int E, int feat, float* __restrict__ pre) {
+    I3D_CHAIN_PRIO();
     const int FV = feat / V;
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)E * FV) return;
@@ -45,6 +46,7 @@ struct CodeStrides { int s[8]; };
 __global__ void __launch_bounds__(256)
 edge_codes_kernel(const long* __restrict__ idx, const int* __restrict__ row_perm, int rows, int n_cols, CodeStrides st,
                   int v_pad, int* __restrict__ codes, float* __restrict__ onehot) {
+    I3D_CHAIN_PRIO();
     const int VQ = v_pad / 4;
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)rows * VQ) return;
@@ -65,6 +67,7 @@ struct ColOffsets { int o[16]; };
 __global__ void __launch_bounds__(256)
 multihot_kernel(const long* __restrict__ idx, const int* __restrict__ row_perm, int rows, int n_cols, ColOffsets off, int v_pad,
                 float* __restrict__ out) {
+    I3D_CHAIN_PRIO();
     const int VQ = v_pad / 4;
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)rows * VQ) return;
@@ -87,6 +90,7 @@ __global__ void __launch_bounds__(256)
 segment_sum_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ ptr, const int* __restrict__ idx,
                    int nseg, int feat, int scale_mode, float* __restrict__ out, int ldo,
                    const int* __restrict__ ptr1 = nullptr, const int* __restrict__ idx1 = nullptr, float* __restrict__ out1 = nullptr) {
+    I3D_CHAIN_PRIO();
     const int FV = feat / V;
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (PAIR) {
@@ -140,6 +144,7 @@ template <int V>
 __global__ void __launch_bounds__(256)
 segment_bcast_kernel(const float* __restrict__ g, const int* __restrict__ ptr, const int* __restrict__ seg_of_row,
                      int rows, int feat, int scale_mode, float* __restrict__ out) {
+    I3D_CHAIN_PRIO();
     const int FV = feat / V;
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)rows * FV) return;
@@ -161,6 +166,7 @@ template <int V>
 __global__ void __launch_bounds__(256)
 gather_rows_kernel(const float* __restrict__ x, const int* __restrict__ idx, int rows, int feat,
                    float* __restrict__ out) {
+    I3D_CHAIN_PRIO();
     const int FV = feat / V;
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)rows * FV) return;
@@ -174,6 +180,7 @@ gather_rows_kernel(const float* __restrict__ x, const int* __restrict__ idx, int
 // reference commons/utils.py:103-110: [sin(d/2^k)]_k | [cos(d/2^k)]_k | d
 __global__ void __launch_bounds__(256)
 fourier_encode_kernel(const float* __restrict__ d, int E, int n_enc, float* __restrict__ out) {
+    I3D_CHAIN_PRIO();
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= E) return;
     float x = d[j];
@@ -192,6 +199,7 @@ fourier_encode_kernel(const float* __restrict__ d, int E, int n_enc, float* __re
 __global__ void __launch_bounds__(256)
 soft_edge_fwd_kernel(const float* __restrict__ m, const float* __restrict__ ws, const float* __restrict__ bs, int E,
                      int feat, float* __restrict__ msg, float* __restrict__ w) {
+    I3D_CHAIN_PRIO();
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= E) return;
     const float* p = m + (long)j * feat;
@@ -207,6 +215,7 @@ __global__ void __launch_bounds__(256)
 soft_edge_bwd_kernel(const float* __restrict__ gmsg, const float* __restrict__ m, const float* __restrict__ w,
                      const float* __restrict__ ws, int E, int feat, float* __restrict__ gm,
                      float* __restrict__ ggate) {
+    I3D_CHAIN_PRIO();
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= E) return;
     const float* p = m + (long)j * feat;
@@ -225,6 +234,7 @@ soft_edge_bwd_kernel(const float* __restrict__ gmsg, const float* __restrict__ m
 __global__ void __launch_bounds__(256)
 soft_edge_fwd_v8_kernel(const float* __restrict__ m, const float* __restrict__ ws, const float* __restrict__ bs, int E,
                         int feat, float* __restrict__ msg, float* __restrict__ w) {
+    I3D_CHAIN_PRIO();
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long j = t >> 3;
     const int q = (int)(t & 7);
@@ -247,6 +257,7 @@ soft_edge_fwd_v8_kernel(const float* __restrict__ m, const float* __restrict__ w
 __global__ void __launch_bounds__(256)
 soft_edge_bwd_v8_kernel(const float* __restrict__ gmsg, const float* __restrict__ m, const float* __restrict__ w,
                         const float* __restrict__ ws, int E, int feat, float* __restrict__ gm, float* __restrict__ ggate) {
+    I3D_CHAIN_PRIO();
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long j = t >> 3;
     const int q = (int)(t & 7);

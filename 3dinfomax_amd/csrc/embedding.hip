@@ -32,6 +32,7 @@ template <int V>
 __global__ void __launch_bounds__(256)
 embedding_sum_fwd_kernel(const int64_t* __restrict__ idx, const int* __restrict__ row_perm, int rows, int n_cols,
                          Tables tabs, int feat, float* __restrict__ out) {
+    I3D_CHAIN_PRIO();
     const int FV = feat / V;
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)rows * FV) return;
@@ -75,6 +76,7 @@ embedding_sum_fwd_kernel(const int64_t* __restrict__ idx, const int* __restrict_
 __global__ void __launch_bounds__(256)
 embedding_sum_bwd_kernel(const int64_t* __restrict__ idx, const int* __restrict__ row_perm, int rows, int n_cols,
                          const float* __restrict__ gout, int feat, GradTables tabs) {
+    I3D_CHAIN_PRIO();
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)rows * feat) return;
     int r = (int)(t / feat), c = (int)(t - (long)r * feat);
@@ -95,6 +97,7 @@ constexpr int LDS_TAB_ROWS = 192, LDS_FW = 64;
 __global__ void __launch_bounds__(256)
 embedding_sum_bwd_lds_kernel(const int64_t* __restrict__ idx, const int* __restrict__ row_perm, int rows, int n_cols,
                              const float* __restrict__ gout, int feat, GradTables tabs, int rows_per_block) {
+    I3D_CHAIN_PRIO();
     __shared__ float acc[LDS_TAB_ROWS * LDS_FW];
     __shared__ int off[MAX_TABLES + 1];
     const int t = threadIdx.x;

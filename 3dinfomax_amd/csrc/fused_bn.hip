@@ -32,6 +32,7 @@ bn_finalize_partials_kernel(const float* __restrict__ partial, int n_tiles, int 
                             const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean,
                             float* __restrict__ invstd, float* running_mean, float* running_var,
                             long long* batches_tracked, float* __restrict__ aff, float* __restrict__ triple_out = nullptr) {
+    I3D_CHAIN_PRIO();
     __shared__ double sm[2][FIN_LANES][FIN_COLS];
     const int cx = threadIdx.x & (FIN_COLS - 1), ly = threadIdx.x / FIN_COLS;
     const int c = blockIdx.x * FIN_COLS + cx;
@@ -155,6 +156,7 @@ __global__ void __launch_bounds__(256)
 edge_combine_act_stats_kernel(const float* __restrict__ P, int ldp, const float* __restrict__ Q, const int* __restrict__ q_code,
                               const float* __restrict__ bias, const int* __restrict__ src, const int* __restrict__ dst, int E,
                               int feat, int act, EcsTiling tl, float* __restrict__ x_out, float* __restrict__ partial) {
+    I3D_CHAIN_PRIO();
     __shared__ float sm[256 * 4];
     __shared__ float smean[256 * 4];
     const int t = threadIdx.x;
@@ -272,6 +274,7 @@ struct EvalAffTable {
 };
 
 __global__ void __launch_bounds__(256) bn_eval_aff_kernel(const EvalAffTable t) {
+    I3D_CHAIN_PRIO();
     const I3dBnEvalAff& e = t.e[blockIdx.y];
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= e.feat) return;

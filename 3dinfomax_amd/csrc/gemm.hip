@@ -575,6 +575,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 template <class S, bool VEC, bool A_KC, bool B_KC, bool BF16 = false>
 __global__ void __launch_bounds__(256)
 gemm_f32_kernel(GemmArgs g) {
+    I3D_CHAIN_PRIO();
     int bx, by, bz;
     xcd_tile(bx, by, bz);
     const int k_begin = bz * g.k_per_split;
@@ -594,6 +595,7 @@ gemm_f32_kernel(GemmArgs g) {
 template <class S, bool VEC, bool BF16 = false>
 __global__ void __launch_bounds__(256)
 gemm_f32_rowseg_kernel(GemmArgs g, SegTable segs) {
+    I3D_CHAIN_PRIO();
     __shared__ int kidx[SEG_MAX_K];
     int bx, by, bz;
     xcd_tile(bx, by, bz);
@@ -629,6 +631,7 @@ struct SlabReduce {
 
 template <int V>
 __global__ void __launch_bounds__(256) slab_reduce_kernel(SlabReduce a) {
+    I3D_CHAIN_PRIO();
     const int NV = a.N / V;
     const long per_group = (long)a.M * NV;
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -680,6 +683,7 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(SlabReduce a) {
 // the same fix-up as a kernel of its own (the product did not go through the slab)
 __global__ void __launch_bounds__(256)
 wgrad_bn_fixup_kernel(float* __restrict__ C, int M, int N, int ldc, const float* __restrict__ aff, const float* __restrict__ row) {
+    I3D_CHAIN_PRIO();
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)M * N) return;
     const int m = (int)(t / N), n = (int)(t - (long)m * N);
@@ -692,6 +696,7 @@ wgrad_bn_fixup_kernel(float* __restrict__ C, int M, int N, int ldc, const float*
 constexpr int ZL = 16;
 template <int V>
 __global__ void __launch_bounds__(256) slab_reduce_small_kernel(SlabReduce a) {
+    I3D_CHAIN_PRIO();
     __shared__ float sm[256 / ZL][ZL][V];
     const int NV = a.N / V;
     const long per_group = (long)a.M * NV;
@@ -862,6 +867,7 @@ static int bf16_bk() {
 template <bool VEC>
 __global__ void __launch_bounds__(256)
 gemm_f32_tt_kernel(GemmArgs g) {
+    I3D_CHAIN_PRIO();
     gemm_body<Cfg6, VEC, false, true, false>(g, blockIdx.x, blockIdx.y, 0, g.K, g.C, nullptr, true);
 }
 
@@ -869,6 +875,7 @@ gemm_f32_tt_kernel(GemmArgs g) {
 template <class S, int FUSE, bool BF16 = false>
 __global__ void __launch_bounds__(256)
 gemm_f32_fused_kernel(GemmArgs g) {
+    I3D_CHAIN_PRIO();
     int bx, by, bz;
     xcd_tile(bx, by, bz);
     gemm_body<S, true, true, true, false, FUSE, BF16>(g, bx, by, 0, g.K, g.C, nullptr, true);

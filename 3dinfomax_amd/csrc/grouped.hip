@@ -23,6 +23,7 @@ template <int S>
 __global__ void __launch_bounds__(256)
 combine_weights_fwd_kernel(const float4* __restrict__ W, int ldw4, int f_in4, int f_out, int A4, int n_groups, Coef coef,
                            float4* __restrict__ WD) {
+    I3D_CHAIN_PRIO();
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long per = (long)f_out * A4;
     if (t >= per) return;
@@ -46,6 +47,7 @@ template <int S>
 __global__ void __launch_bounds__(256)
 combine_weights_bwd_kernel(const float4* __restrict__ dWD, int ldw4, int f_in4, int f_out, int A4, int n_groups, Coef coef,
                            float4* __restrict__ dW) {
+    I3D_CHAIN_PRIO();
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long per = (long)f_out * A4;
     if (t >= per) return;
@@ -70,6 +72,7 @@ combine_weights_bwd_kernel(const float4* __restrict__ dWD, int ldw4, int f_in4, 
 __global__ void __launch_bounds__(256)
 pack_h_weights_kernel(const float4* __restrict__ We, int ldwe4, int Fo, const float4* __restrict__ Wp, int ldwp4, int Fp,
                       const float* __restrict__ bias_p, int Fh4, float4* __restrict__ Wcat, float* __restrict__ bcat) {
+    I3D_CHAIN_PRIO();
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int rows = 2 * Fo + Fp;
     if (t < rows) bcat[t] = t < 2 * Fo ? 0.f : (bias_p != nullptr ? bias_p[t - 2 * Fo] : 0.f);

@@ -31,6 +31,7 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
 __global__ void __launch_bounds__(256)
 contrastive_rowstats_kernel(const float* __restrict__ S, const float* __restrict__ G1, const float* __restrict__ G2, int B1,
                             int B2, float thr, float t, float alpha, float* __restrict__ out) {
+    I3D_CHAIN_PRIO();
     __shared__ float sm[256];
     const int i = blockIdx.x;
     float s_cos = 0.f, s_tn = 0.f, s_u1 = 0.f, s_u2 = 0.f;
@@ -71,6 +72,7 @@ contrastive_rowstats_kernel(const float* __restrict__ S, const float* __restrict
 //   out[a][1] = C_aa                                                 (sum of squares of column a)
 __global__ void __launch_bounds__(256)
 cov_rowstats_kernel(const float* __restrict__ C, const float* __restrict__ colsum, int n, int D, float* __restrict__ out) {
+    I3D_CHAIN_PRIO();
     __shared__ float sm[256];
     const int a = blockIdx.x;
     const float sa = colsum[a], inv_n = 1.f / (float)n, inv_n1 = 1.f / (float)(n > 1 ? n - 1 : 1);

@@ -23,6 +23,7 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
 
 __global__ void __launch_bounds__(256)
 row_norms_kernel(const float* __restrict__ z, int rows, int dim, float* __restrict__ norms) {
+    I3D_CHAIN_PRIO();
     __shared__ float sm[4];
     int r = blockIdx.x;
     float acc = 0.f;
@@ -38,6 +39,7 @@ __global__ void __launch_bounds__(256)
 ntxent_fwd_kernel(const float* __restrict__ sim, const float* __restrict__ n1, const float* __restrict__ n2, int b1,
                   int ncol, int conf, int pos_offset, float inv_tau, float eps, float* __restrict__ row_sum,
                   float* __restrict__ row_pos) {
+    I3D_CHAIN_PRIO();
     __shared__ float sm[4];
     int i = blockIdx.x;
     float a = n1[i];
@@ -60,6 +62,7 @@ ntxent_fwd_kernel(const float* __restrict__ sim, const float* __restrict__ n1, c
 __global__ void __launch_bounds__(256)
 ntxent_loss_kernel(const float* __restrict__ row_sum, const float* __restrict__ row_pos, int b1, float scale,
                    float* __restrict__ loss_sum) {
+    I3D_CHAIN_PRIO();
     __shared__ float sm[4];
     float acc = 0.f;
     for (int i = threadIdx.x; i < b1; i += 256) acc += -logf(row_pos[i] / (row_sum[i] - row_pos[i]));
@@ -73,6 +76,7 @@ ntxent_bwd_row_kernel(const float* __restrict__ sim, const float* __restrict__ n
                       const float* __restrict__ row_sum, const float* __restrict__ row_pos, int b1, int ncol, int conf,
                       int pos_offset, float inv_tau, float eps, float gs, const float* __restrict__ gs_dev,
                       float* __restrict__ dsim, float* __restrict__ ca) {
+    I3D_CHAIN_PRIO();
     __shared__ float sm[4];
     int i = blockIdx.x;
     if (gs_dev != nullptr) gs *= gs_dev[0];      // the upstream scalar gradient stays on the device
@@ -101,6 +105,7 @@ constexpr int COL_W = 16, COL_L = 16;
 __global__ void __launch_bounds__(256)
 ntxent_bwd_col_kernel(const float* __restrict__ sim, const float* __restrict__ dsim, const float* __restrict__ n1,
                       const float* __restrict__ n2, int b1, int ncol, float eps, float* __restrict__ cb) {
+    I3D_CHAIN_PRIO();
     __shared__ float sm[COL_L][COL_W];
     int cx = threadIdx.x % COL_W, ry = threadIdx.x / COL_W;
     int j = blockIdx.x * COL_W + cx;
@@ -127,6 +132,7 @@ ntxent_bwd_col_kernel(const float* __restrict__ sim, const float* __restrict__ d
 template <int V>
 __global__ void __launch_bounds__(256)
 row_axpy_kernel(const float* __restrict__ z, const float* __restrict__ coef, int rows, int dim, float* __restrict__ out) {
+    I3D_CHAIN_PRIO();
     const int DV = dim / V;
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)rows * DV) return;
@@ -146,6 +152,7 @@ row_axpy_kernel(const float* __restrict__ z, const float* __restrict__ coef, int
 template <int V>
 __global__ void __launch_bounds__(256)
 row_scale_kernel(const float* __restrict__ z, const float* __restrict__ coef, int rows, int dim, float* __restrict__ out) {
+    I3D_CHAIN_PRIO();
     const int DV = dim / V;
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)rows * DV) return;
@@ -165,6 +172,7 @@ row_scale_kernel(const float* __restrict__ z, const float* __restrict__ coef, in
 __global__ void __launch_bounds__(256)
 row_norms_pair_kernel(const float* __restrict__ z1, int rows1, const float* __restrict__ z2, int rows2, int dim,
                       float* __restrict__ n1, float* __restrict__ n2) {
+    I3D_CHAIN_PRIO();
     const int lane = threadIdx.x & 63;
     int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows1 + rows2) return;
@@ -198,6 +206,7 @@ ntxent_bwd_fused_kernel(const float* __restrict__ sim, const float* __restrict__
                         const float* __restrict__ z2, int b1, int ncol, int conf, int dim, int pos_offset, float inv_tau,
                         float eps, float gs, const float* __restrict__ gs_dev, float* __restrict__ dsim,
                         float* __restrict__ dz1, float* __restrict__ dz2) {
+    I3D_CHAIN_PRIO();
     __shared__ float sm[FC_L][FC_W];
     __shared__ float coef[FC_W];
     if (gs_dev != nullptr) gs *= gs_dev[0];      // the upstream scalar gradient stays on the device
