@@ -163,6 +163,8 @@ _SIGNATURES = {
     'i3d_pna_layer_bwd': (c_int, [POINTER(PnaLayerArgs), _P]),
     'i3d_fc_bn_fwd': (c_int, [POINTER(FcArgs), _P]),
     'i3d_fc_bn_bwd': (c_int, [POINTER(FcArgs), _P]),
+    'i3d_fc_bn_bwd_chain': (c_int, [POINTER(FcArgs), _P]),
+    'i3d_fc_bn_bwd_wgrad': (c_int, [POINTER(FcArgs), _P]),
     'i3d_edge_fc_bn_fwd': (c_int, [POINTER(EdgeFcArgs), _P]),
     'i3d_edge_fc_bn_bwd': (c_int, [POINTER(EdgeFcArgs), _P]),
     'i3d_grouped_fc_bn_fwd': (c_int, [POINTER(GroupedFcArgs), _P]),

@@ -150,6 +150,18 @@ extern "C" int i3d_fc_bn_bwd(const I3dFcArgs* a, void* stream) {
     return fc_bn_bwd_wgrad(a, stream);
 }
 
+// the two halves on their own (the whole-model sequencer runs the head's chain on its stream and the head's weight gradients
+// behind one fork of the weight-gradient stream: they are leaves, nothing of the chain waits for them)
+extern "C" int i3d_fc_bn_bwd_chain(const I3dFcArgs* a, void* stream) {
+    I3D_CHECK_ARG(a != nullptr && a->rows > 0, "bad arguments");
+    return fc_bn_bwd_chain(a, stream);
+}
+
+extern "C" int i3d_fc_bn_bwd_wgrad(const I3dFcArgs* a, void* stream) {
+    I3D_CHECK_ARG(a != nullptr && a->rows > 0, "bad arguments");
+    return fc_bn_bwd_wgrad(a, stream);
+}
+
 // ---- edge FC: [h_src | h_dst | q] -> Linear as node-level P + gather-combine -------------------------
 extern "C" int i3d_edge_fc_bn_fwd(const I3dEdgeFcArgs* a, void* stream) {
     I3D_CHECK_ARG(a != nullptr && a->num_edges > 0 && a->num_nodes > 0, "bad arguments");

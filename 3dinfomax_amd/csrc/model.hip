@@ -111,9 +111,9 @@ bool join_per_layer() {
 // I3D_WGRAD_SPLIT_LAST=1: the first layer's weight gradients (the last ones of a backward pass) as two launches, the
 // posttrans products early.  Off: measured 2.289 ms split against 2.253 ms in one launch (tools/ab.sh, 3 interleaved runs) -
 // the early launch takes CUs from the chain it was meant to hide behind.
-bool split_last_wgrad() {
-    static const bool on = [] { const char* e = getenv("I3D_WGRAD_SPLIT_LAST"); return e != nullptr && e[0] == '1'; }();
-    return on;
+int split_wgrad() {     // 0: no layer, 1: the first layer (last of the backward pass), 2: every layer
+    static const int v = [] { const char* e = getenv("I3D_WGRAD_SPLIT_LAST"); return e == nullptr ? 0 : (e[0] == '1' ? 1 : (e[0] == 'a' ? 2 : 0)); }();
+    return v;
 }
 
 // I3D_MERGE_H=0: the products that read the node features (edge block's P, posttrans block's h-term, and their data gradients)
@@ -163,6 +163,19 @@ int wgrad(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
           void* stream) {
     if (K >= 1024) return i3d_gemm_f32_ws(1, 0, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, ws, ws_bytes, stream);
     return i3d_gemm_f32(1, 0, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, stream);
+}
+
+// the head's backward buffers (read by its weight gradients on the side stream: kept apart from the layers' shared region),
+// and a column-reduction scratch of that stream's own
+long head_floats(const I3dPnaModel& m, long B) {
+    long t = 0;
+    for (int i = 0; i < m.n_head; ++i) t += al4(B * (long)m.head[i].f_in) + 2 * al4(B * (long)m.head[i].f_out);
+    return t;
+}
+long head_colsum_floats(const I3dPnaModel& m, long B) {
+    long t = 0;
+    for (int i = 0; i < m.n_head; ++i) t = std::max(t, (i3d_colreduce_workspace_bytes((int)B, m.head[i].f_out) + 3) / 4);
+    return al4(t);
 }
 
 // floats of the buffers of layer l's backward pass that the weight-gradient stream reads or writes
@@ -336,8 +349,7 @@ extern "C" long i3d_pna_model_scratch_floats(const I3dPnaModel* m, const I3dPnaB
     // mirrors the takes of i3d_pna_model_bwd
     const long N = b->num_nodes, E = b->num_edges, B = b->num_graphs, F = m->hidden;
     const long top = 2 * al4(N * F) + al4((long)b->n_comb * F);
-    long head = 0;
-    for (int i = 0; i < m->n_head; ++i) head += al4(B * (long)m->head[i].f_in) + al4(B * (long)m->head[i].f_out);
+    const long head = head_floats(*m, B) + head_colsum_floats(*m, B);
     long layer = 0;
     for (int l = 0; l < m->n_layers; ++l) {
         const long f_msg = m->pre[l][m->n_pre - 1].f_out, A = m->n_aggregators * f_msg, Fo0 = m->pre[l][0].f_out;
@@ -354,7 +366,7 @@ extern "C" long i3d_pna_model_scratch_floats(const I3dPnaModel* m, const I3dPnaB
     const long emb = al4(N * ((oa + 31) / 32 * 32)) + al4((long)b->n_comb * ((ob + 31) / 32 * 32)) + al4(((oa + 3) / 4 * 4) * F);
     long side = 0;          // generous: the per-layer sets are taken in addition to the shared region
     for (int l = 0; l < m->n_layers; ++l) side += side_floats(*m, *b, l);
-    return top + side + std::max(std::max(head, layer), emb);
+    return top + side + head + std::max(layer, emb);
 }
 
 extern "C" int i3d_pna_model_fwd(const I3dPnaModel* m, const I3dPnaBatch* b, float* saved, float* node_emb, float* edge_emb,
@@ -481,20 +493,26 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
     std::vector<float*> side(L, nullptr);
     if (!per_layer_join)
         for (int l = 0; l < L; ++l) side[l] = top.take(side_floats(m, b, l));
+    float* const head_buf = top.take(head_floats(m, B));
+    float* const head_colsum_ws = top.take(head_colsum_floats(m, B));
     float* const rest = scratch + top.used;
-    // ---- head, last block first
+    // ---- head, last block first: the chain (BatchNorm backward, data gradients) on the caller's stream, then ONE fork and the
+    // head's weight and bias gradients - leaves - on the weight-gradient stream, next to the readout's and the last layer's
+    // chain (round 2 ran them in line: three launches of latency on the critical path).  Their inputs live in `head_buf`,
+    // outside the region the layers reuse.
     if (part != 2) {
-        Bump ar(rest);
+        Bump ar(head_buf);
         const float* gy = grad_out;
+        const float* gpre_of[I3D_MAX_HEAD_FC] = {};
         for (int i = m.n_head - 1; i >= 0; --i) {
             I3dFcArgs& fc = c->head_args[i];
             const I3dFcParams& p = m.head[i];
             float* gx = ar.take((long)B * p.f_in);
             if (p.gamma != nullptr) {
-                set_ws(fc.tail, bn_workspace, gemm_workspace, gemm_workspace_bytes);
+                set_ws(fc.tail, bn_workspace, gemm_workspace, side_ws_bytes);
                 fc.grad_y = gy; fc.grad_pre = ar.take((long)B * p.f_out); fc.grad_x = gx;
                 fc.grad_W = p.grad_W; fc.grad_bias = p.grad_bias; fc.grad_gamma = p.grad_gamma; fc.grad_beta = p.grad_beta;
-                TRY(i3d_fc_bn_bwd(&fc, stream));
+                TRY(i3d_fc_bn_bwd_chain(&fc, stream));
             } else {
                 const float* gpre = gy;
                 if (p.act != I3D_ACT_NONE) {
@@ -503,11 +521,30 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
                     gpre = t;
                 }
                 TRY(i3d_gemm_f32(0, 0, B, p.f_in, p.f_out, gpre, p.f_out, p.W, p.f_in, gx, p.f_in, nullptr, 0, stream));
-                TRY(wgrad(p.f_out, p.f_in, B, gpre, p.f_out, fc.x, p.f_in, p.grad_W, p.f_in, gemm_workspace,
-                          gemm_workspace_bytes, stream));
-                TRY(i3d_colsum(gpre, nullptr, B, p.f_out, p.grad_bias, bn_workspace, stream));
+                gpre_of[i] = gpre;
             }
             gy = gx;
+        }
+        void* wst = stream;
+        static const bool leaves_aside = [] { const char* e = getenv("I3D_HEAD_LEAVES"); return e == nullptr || e[0] != '0'; }();
+        if (!per_layer_join && leaves_aside) TRY(i3d_wgrad_stream_fork(stream, &wst));
+        for (int i = m.n_head - 1; i >= 0; --i) {
+            I3dFcArgs& fc = c->head_args[i];
+            const I3dFcParams& p = m.head[i];
+            if (p.gamma != nullptr) {
+                TRY(i3d_fc_bn_bwd_wgrad(&fc, wst));
+            } else {
+                TRY(wgrad(p.f_out, p.f_in, B, gpre_of[i], p.f_out, fc.x, p.f_in, p.grad_W, p.f_in, gemm_workspace, side_ws_bytes, wst));
+                void* cws = bn_workspace;
+                if (wst != stream) {      // a reduction scratch of the side stream's own; its arrival counters (the first bytes) start at 0
+                    cws = head_colsum_ws;
+                    if (hipMemsetAsync(cws, 0, 256, (hipStream_t)wst) != hipSuccess) {
+                        i3d::set_error("i3d_pna_model_bwd: clearing the head's reduction scratch failed");
+                        return I3D_ERR_LAUNCH;
+                    }
+                }
+                TRY(i3d_colsum(gpre_of[i], nullptr, B, p.f_out, p.grad_bias, cws, wst));
+            }
         }
         // readout backward -> dL/dh_L
         TRY(i3d_segment_readout_bwd(gy, c->h[L], b.graph_ptr, B, F, m.readout_ops, m.n_readout, gh[L & 1], stream));
@@ -520,7 +557,7 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
         Bump own(side[l]);
         Bump& sd = per_layer_join ? ar : own;       // where the side stream's buffers of this layer live
         a.defer_join = per_layer_join ? 0 : 1;
-        a.wgrad_split = (l == 0 && !per_layer_join && split_last_wgrad()) ? 1 : 0;
+        a.wgrad_split = (!per_layer_join && (split_wgrad() == 2 || (l == 0 && split_wgrad() == 1))) ? 1 : 0;
         // a residual layer accumulates dL/dh_in on top of the incoming gradient IN PLACE (dh_in = dh_out + ...: the separate
         // add pass over [N, F] is gone, composite.hip: i3d_pna_layer_bwd); others ping-pong between the two buffers
         const int cur = c->gh_cur, nxt = a.residual ? cur : cur ^ 1;

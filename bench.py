@@ -66,6 +66,8 @@ def parse():
                     help='N > 1: BatchNorm statistics over the global batch (exact single-process equivalence) instead of '
                          'per-rank statistics (DistributedDataParallel semantics, the default)')
     ap.add_argument('--no-sync-bn', action='store_true', help=argparse.SUPPRESS)   # former name of the default
+    ap.add_argument('--host-profile', action='store_true',
+                    help='cProfile of the host side of the timed steps (top entries by own time, to stderr)')
     ap.add_argument('--lead-probe', action='store_true',
                     help='diagnostic: report how many steps the host runs ahead of the GPU (config.host_lead_steps)')
     ap.add_argument('--no-prewarm', action='store_true', help='skip dist.warm_up before init_process_group (A/B)')
@@ -297,6 +299,11 @@ def main():
     lead, lead_hist = [], []
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # per-step device times (median)
     marks[0].record()
+    prof = None
+    if args.host_profile:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
@@ -313,6 +320,10 @@ def main():
                     pending += 1
                 lead_hist.append(pending)
     t_enqueue = time.perf_counter() - t0      # host time to enqueue the steps (== dt when host-bound)
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats('tottime').print_stats(30)
     barrier()
     dt = time.perf_counter() - t0
     timers, ops.KERNEL_TIMERS = ops.KERNEL_TIMERS, None

@@ -664,6 +664,10 @@ int i3d_pna_layer_fwd(const I3dPnaLayerArgs* args, void* stream);
 int i3d_pna_layer_bwd(const I3dPnaLayerArgs* args, void* stream);
 int i3d_fc_bn_fwd(const I3dFcArgs* args, void* stream);
 int i3d_fc_bn_bwd(const I3dFcArgs* args, void* stream);
+/* the two halves of i3d_fc_bn_bwd: BatchNorm backward + data gradient (what the block in front waits for), and the weight
+ * gradients (leaves: they may run on another stream that is ordered after the chain half, e.g. i3d_wgrad_stream_fork) */
+int i3d_fc_bn_bwd_chain(const I3dFcArgs* args, void* stream);
+int i3d_fc_bn_bwd_wgrad(const I3dFcArgs* args, void* stream);
 int i3d_edge_fc_bn_fwd(const I3dEdgeFcArgs* args, void* stream);
 int i3d_edge_fc_bn_bwd(const I3dEdgeFcArgs* args, void* stream);
 int i3d_grouped_fc_bn_fwd(const I3dGroupedFcArgs* args, void* stream);
