@@ -396,6 +396,10 @@ extern "C" int i3d_pna_model_fwd(const I3dPnaModel* m, const I3dPnaBatch* b, flo
         TRY(i3d_wgrad_stream_fork(stream, &side));
         if (side != stream) {
             for (int l = 1; l < L; ++l) TRY(i3d_pna_layer_weights_fwd(&c->layers[l], side));
+            // reference side effect (models/pna.py:163): edata['feat'] becomes the float bond embedding, edge-id order - nothing
+            // in the step reads it: a leaf, off the chain (it was one more launch in front of the readout)
+            if (edge_emb != nullptr)
+                TRY(i3d_embedding_sum_fwd(b->bond_feat, nullptr, E, m->n_bond_tables, m->bond_tables, F, edge_emb, side));
             TRY(encoder_multihot(*c, c->hot_atoms, c->hot_bonds, side));      // needed by the backward pass only
             c->hot_ready = true;
             hoisted = true;
@@ -426,8 +430,7 @@ extern "C" int i3d_pna_model_fwd(const I3dPnaModel* m, const I3dPnaBatch* b, flo
         TRY(i3d_pna_layer_fwd(&a, stream));
         a.agg_event_start = a.agg_event_stop = nullptr;
     }
-    // reference side effect (models/pna.py:163): edata['feat'] becomes the float bond embedding, edge-id order
-    if (edge_emb != nullptr)
+    if (edge_emb != nullptr && !hoisted)
         TRY(i3d_embedding_sum_fwd(b->bond_feat, nullptr, E, m->n_bond_tables, m->bond_tables, F, edge_emb, stream));
     // ---- readout + head (models/pna.py:133-134, 127-129)
     TRY(i3d_segment_readout_fwd(c->h[L], b->graph_ptr, B, F, m->readout_ops, m->n_readout, c->readout, stream));
