@@ -997,7 +997,8 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     if (cfg == 9 && !trans_a && narrow_pays(N, tiles64)) cfg = 11;
     // Launches of at most ~4 32x32 tiles per CU (the projection head and the loss at batch 512: [512,600]x[200,600]^T is 80
     // 64x64 tiles on 256 CUs) are bound by ONE workgroup's serial chain, not by throughput: 32x32 tiles of four 16x16 waves
-    // have a quarter of the MFMA cycles per k and wave (tools/scratch sweep, r03: K = 600 18.9 -> 9.6 us, K = 200 9.0 -> 5.3 us,
+    // have a quarter of the MFMA cycles per k and wave (tools/small_gemm_sweep.py, profiles/r03_small_gemm_sweep.txt: K = 600 18.9 -> 9.6 us,
+    // K = 200 9.0 -> 5.3 us,
     // break-even at ~1000 tiles); weight-gradient layouts only while K is short (long K: slices through the scratch, above)
     const long tiles32 = (long)cdiv(M, 32) * cdiv(N, 32);
     static const bool small_tiles = [] { const char* e = getenv("I3D_SMALL_TILES"); return e == nullptr || e[0] != '0'; }();

@@ -528,7 +528,7 @@ def main():
                          ms_at_mfma_peak=round(flops / (fb.MFMA_BF16_PEAK_TF if args.dtype == 'bf16' else fb.MFMA_F32_PEAK_TF) / 1e9, 3),
                          algorithmic_bytes_per_step=int(byts), ms_at_hbm_peak=round(byts / HBM_PEAK_GBS / 1e6, 3),
                          note='PNA layers only (heads, encoders, Net3D, NT-Xent are < 2 % of the flops); the step is neither '
-                              'MFMA- nor HBM-bound: it is ~225 dependent launches of 5-50 us on three streams')
+                              'MFMA- nor HBM-bound: it is ~175 launches of 5-140 us on three streams, ~115 of them a dependent chain')
         roof['families'] = families
         roof['step'] = step_line
     if rank == 0:

@@ -61,15 +61,19 @@ def measure(amd, ops, g2, dev, F=200, big_batch=8192):
     dY_e, dY_n, dP = rnd(E, F) * 0.1, rnd(N, F) * 0.1, rnd(N, 2 * F) * 0.1
     Wsd = torch.cat([W1[:, :F], W1[:, F:2 * F]], 0).contiguous()                # [2F, F]
     lin3 = rnd(N, F)
+    Wcat = torch.cat([Wsd, W3[:, :F]], 0).contiguous()                          # [3F, F]
+    bias3 = torch.cat([torch.zeros(2 * F, device=dev), bias])
+    dPL = rnd(N, 3 * F) * 0.1
     gemms = {
-        'fwd P  [N,F]x[2F,F]^T': (lambda: ops.gemm(h, Wsd, trans_b=True), 2.0 * N * 2 * F * F),
+        # the three products that read the node features are ONE GEMM per direction since round 3 (I3dPnaLayerArgs.merge_h):
+        # PL = h [W_s ; W_d ; W_h]^T forward, dL/dh = [dP | dlin] [W_s ; W_d ; W_h] backward
+        'fwd PL [N,F]x[3F,F]^T (P | post h)': (lambda: ops.gemm(h, Wcat, trans_b=True, bias=bias3), 2.0 * N * 3 * F * F),
         'fwd FC2 [E,F]x[F,F]^T + BN prologue + statistics': (lambda: ops.gemm_fused(x1, W2, bias, aff, None), 2.0 * E * F * F),
-        'fwd post h [N,F]x[F,F]^T': (lambda: ops.gemm(h, W3[:, :F], trans_b=True, bias=bias), 2.0 * N * F * F),
         'fwd post agg grouped [N,4F]->F + statistics': (
             lambda: ops.gemm_fused(agg, WD, None, None, None, out=lin3, accumulate=True, m_rows=rows_d, tile_group=tiles_d),
             2.0 * m_pad * 4 * F * F),
         'dgrad FC2 [E,F]x[F,F]': (lambda: ops.gemm(dY_e, W2), 2.0 * E * F * F),
-        'dgrad P [N,2F]x[2F,F]': (lambda: ops.gemm(dP, Wsd), 2.0 * N * 2 * F * F),
+        'dgrad DL [N,3F]x[3F,F] (dP | dlin)': (lambda: ops.gemm(dPL, Wcat), 2.0 * N * 3 * F * F),
         'dgrad post agg grouped [N,F]->4F': (lambda: ops.gemm_grouped(dY_n, rows_d, tiles_d, WD, agg, trans_b=False, accumulate=False),
                                               2.0 * m_pad * 4 * F * F),
     }
