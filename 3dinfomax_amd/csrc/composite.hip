@@ -305,7 +305,9 @@ static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_r
     static const bool on = [] { const char* e = getenv("I3D_WGRAD_MULTI"); return e == nullptr || e[0] != '0'; }();
     const I3dEdgeFcArgs* e = &a->edge;
     const I3dGroupedFcArgs* g = &a->post;
-    if (!on || a->n_post_extra != 0 || e->q == nullptr || e->q_rows <= 0 || i3d_get_matmul_precision() != 0) return 0;
+    // (bf16 matmul mode: the panel kernel's bf16 form; I3D_WGRAD_MULTI_BF16=0: the per-product launches of round 2 there)
+    static const bool bf16_on = [] { const char* e = getenv("I3D_WGRAD_MULTI_BF16"); return e == nullptr || e[0] != '0'; }();
+    if (!on || a->n_post_extra != 0 || e->q == nullptr || e->q_rows <= 0 || (i3d_get_matmul_precision() != 0 && !bf16_on)) return 0;
     const int Fh = e->f_h, Fo = e->f_out, N = e->num_nodes, E = e->num_edges, A = g->agg_width;
     const bool merged = merge_h_ok(a) && a->DL != nullptr;
     const int WL = 2 * Fo + g->f_out;

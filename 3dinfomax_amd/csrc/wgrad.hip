@@ -42,6 +42,27 @@ namespace {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef int intx4 __attribute__((ext_vector_type(4)));
+typedef short shortx4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+
+// PREC of the panel kernel: how a product a * b of two fp32 operands is formed
+//   0: exact, on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32, 32 cycles per 16x16x4)
+//   1: bf16 matmul mode - both operands rounded to bf16 (RNE) when a lane has read its fragment, ONE v_mfma_f32_16x16x16_bf16
+//      per 16 rows of k (the rounding the other GEMMs of that mode apply), fp32 accumulation
+//   2: split operands a = a_h + a_l (a_h = bf16(a), a_l = bf16(a - a_h)): a_h b_h + a_h b_l + a_l b_h on the bf16 pipe, fp32
+//      accumulation - the a_l b_l term and the rounding of the low parts are dropped: |error| <= ~2^-15 |a b| per product
+//      against 2^-24 of the exact form (opt-in: I3D_WGRAD_SPLIT_BF16=1)
+constexpr int PREC_F32 = 0, PREC_BF16 = 1, PREC_BF16X3 = 2;
+
+__device__ __forceinline__ void split4(const float v[4], shortx4& hi, shortx4& lo, const bool want_lo) {
+    const bf16x4_t h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    hi = __builtin_bit_cast(shortx4, h);
+    if (want_lo) {
+        const bf16x4_t l = {(__bf16)(v[0] - (float)h[0]), (__bf16)(v[1] - (float)h[1]), (__bf16)(v[2] - (float)h[2]),
+                            (__bf16)(v[3] - (float)h[3])};
+        lo = __builtin_bit_cast(shortx4, l);
+    }
+}
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int WG_T = 13;                        // tiles per panel side
@@ -89,7 +110,7 @@ __device__ __forceinline__ int xcd_unit(int total) {
 
 // MT: tile rows the code is unrolled for (>= the panel's: surplus tiles are computed on whatever the LDS rows hold and
 // never stored - no per-MFMA branch); NFULL: the panel has all 13 tile columns (no branch at all in the K loop)
-template <int MT, bool NFULL>
+template <int MT, bool NFULL, int PREC>
 __device__ __forceinline__ void wgrad_unit(const WgProb& p, const int slice, const int mc, const int nc, float* __restrict__ out,
                                            float* __restrict__ smem, int* __restrict__ kidx, unsigned long long* stamps) {
     WG_STAMP(0);
@@ -164,6 +185,61 @@ __device__ __forceinline__ void wgrad_unit(const WgProb& p, const int slice, con
         read_rows(t + 1);                            // (clamped past the end; those rows load zeros)
         const float* as = As + cur * WG_BK * WG_LDP;
         const float* bs = Bs + cur * WG_BK * WG_LDP;
+        if constexpr (PREC != PREC_F32) {
+            // the SAME fragment reads as the fp32 form - row 4 kk + lk of the K-tile, kk = 0 .. 3 - but a lane's four values of a
+            // fragment become ONE packed bf16x4 operand: v_mfma_f32_16x16x16_bf16 takes 4 consecutive k per lane group, and any
+            // assignment of the tile's 16 rows to (lane group, element) is right as long as A and B use the same one
+            constexpr bool X3 = PREC == PREC_BF16X3;
+            auto frag = [&](const float* base, int off, shortx4& hi, shortx4& lo) {
+                float v[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) v[kk] = base[kk * 4 * WG_LDP + off];
+                split4(v, hi, lo, X3);
+            };
+            auto fma3 = [&](floatx4& c, const shortx4& bh, const shortx4& bl, const shortx4& ah, const shortx4& al) {
+                if constexpr (X3) {      // small terms first
+                    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bl, ah, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh, al, c, 0, 0, 0);
+                }
+                c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh, ah, c, 0, 0, 0);
+            };
+            shortx4 bh[3], bl[3], bxh, bxl;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) frag(bs, own_off + (wave + 4 * j) * 16, bh[j], bl[j]);
+            frag(bs, even_off + 12 * 16, bxh, bxl);
+            // tile rows in two halves (the packed fragments of all 13 next to 172 accumulator registers do not fit 256)
+            constexpr int H0 = (MT + 1) / 2;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int i0 = half ? H0 : 0, cnt = half ? MT - H0 : H0;
+                shortx4 ah[H0], al[H0];
+#pragma unroll
+                for (int i = 0; i < H0; ++i)
+                    if (i < cnt) frag(as, (((i0 + i) & 1) ? odd_off : even_off) + (i0 + i) * 16, ah[i], al[i]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (NFULL || wave + 4 * j < min(ntl, 12)) {
+#pragma unroll
+                        for (int i = 0; i < H0; ++i)
+                            if (i < cnt) fma3(acc[j][i0 + i], bh[j], bl[j], ah[i], al[i]);
+                    }
+                    if (j < 2) {     // the next tile's loads in four pieces between the MFMA groups
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_piece(t + 1, cur ^ 1, half * 2 + j);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if (NFULL || extra) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    shortx4 xh, xl;
+                    if (MT == WG_T && q == 3) frag(as, even_off + 12 * 16, xh, xl);
+                    else frag(as, own_off + (wave + 4 * q) * 16, xh, xl);
+                    fma3(accx[q], bxh, bxl, xh, xl);
+                }
+            }
+        } else
 #pragma unroll
         for (int kk = 0; kk < WG_BK / 4; ++kk) {
             const float* ae = as + kk * 4 * WG_LDP + even_off;
@@ -226,6 +302,7 @@ __device__ __forceinline__ void wgrad_unit(const WgProb& p, const int slice, con
     }
 }
 
+template <int PREC>
 __global__ void __launch_bounds__(256, 2) wgrad_multi_kernel(const WgArgs a) {
     __shared__ __attribute__((aligned(1024))) float smem[4 * WG_BK * WG_LDP];
     __shared__ int kidx[WG_MAX_SLICE];
@@ -247,8 +324,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_multi_kernel(const WgArgs a) {
 #endif
 #define WG_DISPATCH(MTV)                                                          \
     do {                                                                          \
-        if (nfull) wgrad_unit<MTV, true>(p, slice, mc, nc, out, smem, kidx, stamps);  \
-        else wgrad_unit<MTV, false>(p, slice, mc, nc, out, smem, kidx, stamps);       \
+        if (nfull) wgrad_unit<MTV, true, PREC>(p, slice, mc, nc, out, smem, kidx, stamps);  \
+        else wgrad_unit<MTV, false, PREC>(p, slice, mc, nc, out, smem, kidx, stamps);       \
     } while (0)
     if (mtl > 7) WG_DISPATCH(13);
     else if (mtl > 4) WG_DISPATCH(7);
@@ -498,7 +575,14 @@ extern "C" int i3d_wgrad_multi(const I3dWgradProblem* problems, int n_problems, 
     a.n_units = units;
     hipStream_t st = (hipStream_t)stream;
     if (units > 0) {
-        hipLaunchKernelGGL(wgrad_multi_kernel, dim3(units), dim3(256), 0, st, a);
+        // how the products are formed: the process-wide matmul precision (bf16 mode: bf16 operands), or - fp32 mode, opt-in -
+        // split bf16 operands (see PREC above)
+        const char* const sb = getenv("I3D_WGRAD_SPLIT_BF16");      // (read per call: a test switches it inside one process)
+        const bool split_bf16 = sb != nullptr && sb[0] == '1';
+        const int prec = i3d_get_matmul_precision() != 0 ? PREC_BF16 : (split_bf16 ? PREC_BF16X3 : PREC_F32);
+        if (prec == PREC_BF16) hipLaunchKernelGGL(wgrad_multi_kernel<PREC_BF16>, dim3(units), dim3(256), 0, st, a);
+        else if (prec == PREC_BF16X3) hipLaunchKernelGGL(wgrad_multi_kernel<PREC_BF16X3>, dim3(units), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(wgrad_multi_kernel<PREC_F32>, dim3(units), dim3(256), 0, st, a);
         I3D_CHECK_LAUNCH();
     }
     r.slab = a.slab;

@@ -142,6 +142,40 @@ def extra_workloads(amd, ops, dev, depth):
         return amd.Adam([{'params': [p for k, p in named if 'batch_norm' in k], 'weight_decay': 0},
                          {'params': [p for k, p in named if 'batch_norm' not in k]}], lr=8e-5, fused=True)
 
+    # ---- the headline workload (configs[1] shape) in the two other ways its products can be formed: the weight gradients of
+    # the PNA layers as three bf16 products of split operands (fp32 everywhere else; csrc/wgrad.hip PREC 2, error bound and
+    # parity in DESIGN.md section 6), and the bf16 matmul mode
+    B1 = 512
+    mols = amd.synth.make_dataset(B1, seed=1000)
+    g2 = amd.batch([amd.bond_graph(m) for m in mols]).to(dev)
+    g3 = amd.batch([amd.complete_graph(m) for m in mols]).to(dev)
+    for name, dtype, env in (('qm9_shape_fp32_split_bf16_weight_gradients', 'fp32', {'I3D_WGRAD_SPLIT_BF16': '1'}),
+                             ('qm9_shape_bf16', 'bf16', {})):
+        prev = ops.set_matmul_precision(dtype)
+        saved_env = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        torch.manual_seed(123)
+        pna = amd.PNA(avg_d=1.0, device=dev, **dict(PNA_KW, propagation_depth=depth)).to(dev).train()
+        net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_KW).to(dev).train()
+        loss_fn = amd.NTXent(tau=0.1)
+        optim = adam(list(pna.named_parameters()) + list(net.named_parameters()))
+
+        def step(i):
+            a, b = g2.local_copy(), g3.local_copy()
+            loss_fn(pna(a), net(b)).backward()
+            optim.step()
+            optim.zero_grad()
+        ms, host = window(step, 10, 40)
+        out[name] = dict(ms_per_step=round(ms, 3), molecules_per_s=round(B1 / ms * 1e3, 1), host_enqueue_ms=round(host, 3), batch=B1,
+                         depth=depth, matmul=dtype, weight_gradients='split bf16 x3' if env else ('bf16' if dtype == 'bf16' else 'fp32'))
+        ops.set_matmul_precision(prev)
+        for k, v in saved_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        del pna, net, optim
+    del g2, g3
     # ---- configs[3] shape
     B3 = 500
     mols = amd.synth.make_dataset(B3, seed=3000, kind='qmugs')

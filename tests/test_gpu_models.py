@@ -145,9 +145,13 @@ def _det_load(module, tag):
     module.load_state_dict(new)
 
 
-@pytest.mark.parametrize('L', [7, 4])
-def test_full_yml_config_vs_reference_fixture(amd, L):
-    """pre-train_QM9.yml dimensions (F=200, target 256; L=7 as in the yml, L=4 as in BASELINE.json)."""
+@pytest.mark.parametrize('L,wgrad', [(7, 'exact'), (4, 'exact'), (4, 'split_bf16')])
+def test_full_yml_config_vs_reference_fixture(amd, L, wgrad, monkeypatch):
+    """pre-train_QM9.yml dimensions (F=200, target 256; L=7 as in the yml, L=4 as in BASELINE.json).  split_bf16: the weight
+    gradients of the PNA layers as three bf16 products of split operands (I3D_WGRAD_SPLIT_BF16=1, csrc/wgrad.hip) - the same
+    bounds as the exact fp32 products."""
+    if wgrad == 'split_bf16':
+        monkeypatch.setenv('I3D_WGRAD_SPLIT_BF16', '1')
     z = load('full_config.npz')
     mols = mols_from_npz(z)
     pna = amd.PNA(avg_d=1.0, device='cuda:0', **dict(PNA_YML, propagation_depth=L))
@@ -172,9 +176,12 @@ def test_full_yml_config_vs_reference_fixture(amd, L):
     grads_close(param_grads(net), ref, 2e-3, 'net3d ')
 
 
-def test_batch64_vs_oracle_fwd_bwd(amd):
+@pytest.mark.parametrize('wgrad', ['exact', 'split_bf16'])
+def test_batch64_vs_oracle_fwd_bwd(amd, wgrad, monkeypatch):
     """A bigger seeded batch (64 QM9-shaped molecules, F=200, L=2): forward, loss, and every parameter gradient
-    against the oracle."""
+    against the oracle - with the exact fp32 weight gradients and with the split-bf16 ones, same bounds."""
+    if wgrad == 'split_bf16':
+        monkeypatch.setenv('I3D_WGRAD_SPLIT_BF16', '1')
     mols = synth.make_dataset(64, seed=5)
     kw2 = dict(PNA_YML, propagation_depth=2)
     pna = amd.PNA(avg_d=1.0, device='cuda:0', **kw2)

@@ -517,6 +517,44 @@ def _padded_groups(counts, n_rows, seed):
     return torch.tensor(rows, dtype=torch.int32), starts
 
 
+@pytest.mark.parametrize('F,N,E', [(200, 3001, 6007), (40, 500, 1100)])
+@pytest.mark.parametrize('mode', ['split_bf16', 'bf16'])
+def test_wgrad_multi_on_the_bf16_pipe(F, N, E, mode, monkeypatch):
+    """the one-launch weight gradients with split bf16 operands (a_h b_h + a_h b_l + a_l b_h, opt-in in fp32 mode: <= ~2^-15 per
+    product, measured 2e-6 of the largest entry on these sums) and in the bf16 matmul mode (operands rounded once: against
+    the fp64 product of the ROUNDED operands to 1e-4, like the other GEMMs of that mode, tests/test_gpu_bf16.py)"""
+    dpost, h, agg = rnd(N, F, seed=1, scale=0.1), rnd(N, F, seed=2), rnd(N, 4 * F, seed=3)
+    dpre2, x1 = rnd(E, F, seed=4, scale=0.1), rnd(E, F, seed=5)
+    aff, row = rnd(3 * F, seed=10), rnd(F, seed=11)
+    gW_h, gW2 = torch.empty(F, F), torch.empty(F, F)
+    d = dict(dpost=g(dpost), h=g(h), dpre2=g(dpre2), x1=g(x1), aff=g(aff), row=g(row), gW_h=g(gW_h), gW2=g(gW2))
+    problems = [dict(A=d['dpost'], B=d['h']), dict(A=d['dpre2'], B=d['x1'])]
+    outputs = [dict(first_problem=0, C=d['gW_h']), dict(kind=ops.WGRAD_BN, first_problem=1, C=d['gW2'], aff=d['aff'], row=d['row'])]
+    prev = ops.get_matmul_precision()
+    try:
+        if mode == 'bf16':
+            ops.set_matmul_precision('bf16')
+        else:
+            monkeypatch.setenv('I3D_WGRAD_SPLIT_BF16', '1')
+        ops.wgrad_multi(problems, outputs)
+        torch.cuda.synchronize()
+        first = [d['gW_h'].clone(), d['gW2'].clone()]
+        ops.wgrad_multi(problems, outputs)
+        torch.cuda.synchronize()
+        assert torch.equal(first[0], d['gW_h']) and torch.equal(first[1], d['gW2'])       # fixed summation order
+    finally:
+        ops.set_matmul_precision(prev)
+    R = (lambda t: t.bfloat16().double()) if mode == 'bf16' else (lambda t: t.double())
+    tol = 1e-4 if mode == 'bf16' else 1e-5
+    D = lambda t: t.double()
+    assert rel_err(d['gW_h'].cpu(), R(dpost).T @ R(h)) < tol
+    mean, scale, shift = D(aff[:F]), D(aff[F:2 * F]), D(aff[2 * F:])
+    ref2 = (R(dpre2).T @ R(x1) - D(row)[:, None] * mean[None]) * scale[None] + D(row)[:, None] * shift[None]
+    assert rel_err(d['gW2'].cpu(), ref2) < tol * (10 if mode == 'bf16' else 1)      # (bf16: `row` is not the column sum of the rounded dpre2)
+    if mode == 'split_bf16':      # and it is NOT the plain bf16 product: that one is off by ~2e-3
+        assert rel_err(d['gW_h'].cpu(), dpost.bfloat16().double().T @ h.bfloat16().double()) > 1e-4
+
+
 @pytest.mark.parametrize('F,N,E', [(200, 3001, 6007), (40, 500, 1100), (16, 130, 70), (208, 2100, 900)])
 def test_wgrad_multi_matches_fp64(F, N, E):
     """the five products of a PNA layer's backward (posttrans h-block, per-degree blocks folded into the scaler blocks,

@@ -82,7 +82,7 @@ def measure(amd, ops, g2, dev, F=200, big_batch=8192):
     onehot = torch.zeros(E, 64, device=dev)
     onehot[torch.arange(E, device=dev), torch.randint(0, 60, (E,), device=dev)] = 1.0
     gW3, gW2, gW1, gQ = torch.empty(F, 13 * F, device=dev), torch.empty(F, F, device=dev), torch.empty(F, 3 * F, device=dev), torch.empty(64, F, device=dev)
-    if ops.get_matmul_precision() == 'fp32':
+    if ops.get_matmul_precision() == 'fp32' or os.environ.get('I3D_WGRAD_MULTI_BF16', '1') != '0':
         coef = [c for D, _, _ in groups for c in ((1.0, float(np.log(D + 1)), 1.0 / float(np.log(D + 1))) if D > 0 else (0.0, 0.0, 0.0))]
         live = [(s0, cnt, coef[3 * k:3 * k + 3]) for k, (D, s0, cnt) in enumerate(groups) if D > 0 and cnt > 0]
         problems = [dict(A=dY_n, B=h)] + [dict(A=dY_n, B=agg, rows=rows_d, k_begin=s0, k_count=cnt) for s0, cnt, _ in live]
