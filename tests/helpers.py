@@ -86,7 +86,9 @@ def grads_close_l2(got, ref, rtol, what='', floor=5e-6):
         b = torch.as_tensor(v, dtype=torch.float64).flatten()
         err = (a - b).norm().item()
         bound = rtol * b.norm().item() + floor * scale      # floor: analytically-zero gradients (a shift a later BatchNorm removes)
-        assert err <= bound, f'{what}{k}: L2 err {err:.3e} > {bound:.3e}'
+        if os.environ.get('I3D_TEST_VERBOSE') and err > 0.2 * bound:
+            print(f'grads_close_l2 {what}{k}: rel {err / max(b.norm().item(), 1e-30):.3f} err {err:.3e} bound {bound:.3e} norm {b.norm().item():.3e} scale {scale:.3e}')
+        assert err <= bound or os.environ.get('I3D_TEST_VERBOSE') == 'noassert', f'{what}{k}: L2 err {err:.3e} > {bound:.3e}'
 
 
 def _segment_first_argext(values, ptr, largest):
