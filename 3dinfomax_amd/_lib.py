@@ -158,6 +158,7 @@ _SIGNATURES = {
     'i3d_net3d_edge_fwd': (c_int, [POINTER(Net3dEdgeArgs), _P]),
     'i3d_net3d_edge_bwd': (c_int, [POINTER(Net3dEdgeArgs), _P]),
     'i3d_wgrad_stream_fork': (c_int, [_P, POINTER(_P)]),
+    'i3d_wgrad_stream_peek': (c_int, [_P, POINTER(_P)]),
     'i3d_pna_layer_weights_fwd': (c_int, [POINTER(PnaLayerArgs), _P]),
     'i3d_pna_layer_fwd': (c_int, [POINTER(PnaLayerArgs), _P]),
     'i3d_pna_layer_bwd': (c_int, [POINTER(PnaLayerArgs), _P]),

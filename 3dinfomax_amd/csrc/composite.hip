@@ -500,6 +500,15 @@ extern "C" int i3d_wgrad_stream_fork(void* stream, void** side) {
     return I3D_OK;
 }
 
+// the weight-gradient stream of `stream` as it stands (no new fork: work enqueued there runs behind whatever the last fork
+// ordered it after); `stream` itself when there is none
+extern "C" int i3d_wgrad_stream_peek(void* stream, void** side) {
+    I3D_CHECK_ARG(side != nullptr, "null");
+    Aux* x = aux_for((hipStream_t)stream);
+    *side = x != nullptr ? (void*)x->s : stream;
+    return I3D_OK;
+}
+
 extern "C" long i3d_pna_layer_stats_floats(int num_nodes, int num_edges, int m_padded, int f) {
     (void)num_nodes;
     const int rpt = i3d_edge_stats_rows_per_tile(f);

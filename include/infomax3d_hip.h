@@ -658,6 +658,7 @@ int i3d_event_elapsed_ms(void* start, void* stop, float* ms);   /* both events m
 int i3d_wgrad_stream_join(void* stream);
 /* the side stream of `stream`, ordered behind everything `stream` holds now (*side == stream when there is none) */
 int i3d_wgrad_stream_fork(void* stream, void** side);
+int i3d_wgrad_stream_peek(void* stream, void** side);      /* that stream without a new fork (`stream` itself if there is none) */
 /* the parameter-only products of a fused_bn layer's forward: edge.Q = q W_q^T and post.WD = sum_s coef W_s */
 int i3d_pna_layer_weights_fwd(const I3dPnaLayerArgs* args, void* stream);
 int i3d_pna_layer_fwd(const I3dPnaLayerArgs* args, void* stream);
