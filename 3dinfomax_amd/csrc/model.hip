@@ -658,9 +658,17 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
             return I3D_OK;
         };
         if (own_ws) TRY(atom_tables(tail_ws, tail_bytes - 256));
+        // the bond tables' product reads the sum the weight-gradient stream has just finished: on THAT stream, in front of the
+        // join (behind it, it was one more cross-stream hop - ~10 us - between the last panel reduction and Adam)
+        void* bst = stream;
+        static const bool bond_aside = [] { const char* e = getenv("I3D_BOND_TABLE_ASIDE"); return e == nullptr || e[0] != '0'; }();
+        if (bond_aside && !per_layer_join && own_ws && c->hot_ready) TRY(i3d_wgrad_stream_peek(stream, &bst));
+        if (bst != stream)
+            TRY(wgrad(ob, F, b.n_comb, hotb, vb, grad_table, F, m.grad_bond_tables, F, gemm_workspace, side_ws_bytes, bst));
         if (!per_layer_join) TRY(i3d_wgrad_stream_join(stream));
         if (!own_ws) TRY(atom_tables(gemm_workspace, gemm_workspace_bytes));
-        TRY(wgrad(ob, F, b.n_comb, hotb, vb, grad_table, F, m.grad_bond_tables, F, gemm_workspace, gemm_workspace_bytes, stream));
+        if (bst == stream)
+            TRY(wgrad(ob, F, b.n_comb, hotb, vb, grad_table, F, m.grad_bond_tables, F, gemm_workspace, gemm_workspace_bytes, stream));
     }
     return I3D_OK;
 }
