@@ -56,6 +56,7 @@ struct EdgeK {                       // kernel argument (by value)
     int E, N, reduce_mean, rows_per_block;
     int ld_w_in, ld_w_msg;
     float inv_rows;                  // 1 / E
+    const float* inv_rows_dev;       // synchronised BatchNorm: 1 / (edges of ALL ranks), on the device; null: inv_rows
     const float* d_raw;
     const int* perm;
     const int* dst_s;
@@ -462,6 +463,7 @@ __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_msg_kernel(EdgeK p) {
     __shared__ float tiles[tile_floats<H, NB>()];      // also the accumulator exchange (4 * 1024 floats) at the end
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     load_weights(w, p, tid);
+    const float inv_rows = p.inv_rows_dev != nullptr ? p.inv_rows_dev[0] : p.inv_rows;
     __syncthreads();
     float* tile_a = tiles + wv * 64 * (odd(H) + odd(NB));
     float* tile_b = tile_a + 64 * odd(H);
@@ -488,7 +490,7 @@ __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_msg_kernel(EdgeK p) {
 #pragma unroll
             for (int c = 0; c < H; ++c) {
                 const float xh = (xm[c] - w.aff_msg[c]) * w.istd_msg[c];
-                const float gx = w.aff_msg[H + c] * (gm[c] - w.gs_msg[c] * p.inv_rows - xh * (w.gs_msg[H + c] * p.inv_rows));
+                const float gx = w.aff_msg[H + c] * (gm[c] - w.gs_msg[c] * inv_rows - xh * (w.gs_msg[H + c] * inv_rows));
                 glin[c] = gx * act_grad(lin[c], ACT);
             }
             store_row<H>(p.grad_lin + j * H, glin);
@@ -548,6 +550,7 @@ __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_in_kernel(EdgeK p) {
     __shared__ float tiles[tile_floats<H, NB>()];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     load_weights(w, p, tid);
+    const float inv_rows = p.inv_rows_dev != nullptr ? p.inv_rows_dev[0] : p.inv_rows;
     __syncthreads();
     float* tile_a = tiles + wv * 64 * (odd(H) + odd(NB));
     float* tile_b = tile_a + 64 * odd(H);
@@ -574,7 +577,7 @@ __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_in_kernel(EdgeK p) {
 #pragma unroll
             for (int c = 0; c < H; ++c) {
                 const float xh = (xa[c] - w.aff_in[c]) * w.istd_in[c];
-                const float gx = w.aff_in[H + c] * (gya[c] - w.gs_in[c] * p.inv_rows - xh * (w.gs_in[H + c] * p.inv_rows));
+                const float gx = w.aff_in[H + c] * (gya[c] - w.gs_in[c] * inv_rows - xh * (w.gs_in[H + c] * inv_rows));
                 ga[c] = gx * act_grad(a[c], ACT);
             }
         }
@@ -737,6 +740,35 @@ int check_common(const I3dNet3dEdgeArgs* a) {
     return I3D_OK;
 }
 
+// synchronised BatchNorm (comm.hip): the backward sums of a BatchNorm of this stage - [sum dy | sum dy xhat] over THIS rank's
+// edges, as the R kernels leave them - become the sums over all ranks (fp64 all-reduce on the caller's stream), and the row
+// count the data gradient divides by becomes the edges of all ranks; grad_gamma / grad_beta keep this rank's share (the
+// gradient all-reduce adds the ranks up)
+__global__ void n3_sums_to_f64_kernel(const float* __restrict__ gsum, int n, double rows, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)gsum[i];
+    if (i == n) out[n] = rows;
+}
+__global__ void n3_sums_from_f64_kernel(const double* __restrict__ in, int n, float* __restrict__ gsum, float* __restrict__ inv_rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) gsum[i] = (float)in[i];
+    if (i == n) inv_rows[0] = (float)(1.0 / in[n]);
+}
+
+int sync_backward_sums(float* gsum, int n, long local_rows, float* inv_rows_dev, void* stream) {
+    const I3dCollectives* coll = collectives();
+    if (coll == nullptr) return I3D_OK;
+    I3D_CHECK_ARG(coll->scratch_bytes >= (long)(n + 1) * 8, "collective scratch too small");
+    double* s64 = (double*)coll->scratch;
+    hipLaunchKernelGGL(n3_sums_to_f64_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, gsum, n, (double)local_rows, s64);
+    I3D_CHECK_LAUNCH();
+    const int rc = coll->all_reduce_f64(coll->user, s64, n + 1, stream);
+    if (rc != I3D_OK) return rc;
+    hipLaunchKernelGGL(n3_sums_from_f64_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, s64, n, gsum, inv_rows_dev);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
 #define N3_DISPATCH(KERNEL, grid, block, stream, ...)                                                                  \
     do {                                                                                                               \
         if (a->hidden == 20 && a->n_enc == 4) hipLaunchKernelGGL((KERNEL<20, 4>), grid, block, 0, stream, __VA_ARGS__); \
@@ -761,7 +793,7 @@ extern "C" long i3d_net3d_edge_bwd_floats(int num_edges, int hidden, int n_enc) 
     const int din = n_enc > 0 ? 2 * n_enc + 1 : 1;
     const long per = (long)hidden * (hidden + 1) + 2 * hidden;          // the widest pass (B2); B1: 3H+1, B3: H (DIN+1)
     const long per3 = (long)hidden * (din + 1);
-    return (long)plan_for(num_edges).bwd_blocks * (per > per3 ? per : per3) + 4 * hidden;
+    return (long)plan_for(num_edges).bwd_blocks * (per > per3 ? per : per3) + 4 * hidden + 4;      // ... | gsum [4H] | 1 / rows of all ranks
 }
 
 extern "C" int i3d_net3d_edge_fwd(const I3dNet3dEdgeArgs* a, void* stream_) {
@@ -815,6 +847,13 @@ extern "C" int i3d_net3d_edge_bwd(const I3dNet3dEdgeArgs* a, void* stream_) {
     q.gsum = gsum; q.grad_gamma = a->grad_gamma_msg; q.grad_beta = a->grad_beta_msg;
     hipLaunchKernelGGL(n3_reduce_sums_kernel, dim3(1), dim3(1024), 0, stream, q);
     I3D_CHECK_LAUNCH();
+    const bool synced = collectives() != nullptr;
+    float* inv_rows_dev = gsum + 4 * H;
+    I3D_CHECK_ARG(!synced || 2 * H < 128, "hidden too wide for the sum exchange");
+    if (synced) {
+        if (int rc = sync_backward_sums(gsum, 2 * H, a->num_edges, inv_rows_dev, stream_)) return rc;
+        p.inv_rows_dev = inv_rows_dev;
+    }
     p.gsum_msg = gsum;
     N3_DISPATCH(n3_bwd_msg_kernel, dim3(pl.bwd_blocks), dim3(TB), stream, p);
     I3D_CHECK_LAUNCH();
@@ -823,6 +862,9 @@ extern "C" int i3d_net3d_edge_bwd(const I3dNet3dEdgeArgs* a, void* stream_) {
     q.gsum = gsum + 2 * H; q.grad_gamma = a->grad_gamma_in; q.grad_beta = a->grad_beta_in;
     hipLaunchKernelGGL(n3_reduce_msg_kernel, dim3(1), dim3(1024), 0, stream, q);
     I3D_CHECK_LAUNCH();
+    if (synced) {
+        if (int rc = sync_backward_sums(gsum + 2 * H, 2 * H, a->num_edges, inv_rows_dev, stream_)) return rc;
+    }
     p.gsum_in = gsum + 2 * H;
     N3_DISPATCH(n3_bwd_in_kernel, dim3(pl.bwd_blocks), dim3(TB), stream, p);
     I3D_CHECK_LAUNCH();

@@ -200,11 +200,11 @@ def enable_native_sync(group, device):
         _lib.check(L.i3d_set_collectives(ctypes.byref(c)), 'i3d_set_collectives')
         _native_sync = (group, (scratch, cb_g, cb_r, c))
     # ONE stream issues the collectives of a communicator, in the same order on every rank: the 3D network joins the
-    # 2D network's stream, and its fused edge stage (whose backward reduces its BatchNorm sums in kernels of its own)
-    # gives way to the block path
-    from . import net3d_native, streams
+    # 2D network's stream.  Its fused edge stage stays: the forward statistics go through i3d_bn_finalize_partials like
+    # everyone's, the backward sums of its two BatchNorms are exchanged between its own kernels (csrc/net3d_edge.hip:
+    # sync_backward_sums)
+    from . import streams
     streams.NET3D_STREAM = False
-    net3d_native.FUSED_EDGE = False
     return True
 
 
