@@ -70,7 +70,7 @@ class Net3dEdgeArgs(ctypes.Structure):
                 ('w_gate', _P), ('b_gate', _P), ('stats', _P), ('aff_in', _P), ('aff_msg', _P), ('x_msg', _P), ('d_out', _P),
                 ('msg', _P), ('m_sum', _P), ('grad_m_sum', _P), ('grad_ya', _P), ('grad_lin', _P), ('partial', _P), ('grad_W_in', _P),
                 ('grad_b_in', _P), ('grad_gamma_in', _P), ('grad_beta_in', _P), ('grad_W_msg', _P), ('grad_b_msg', _P),
-                ('grad_gamma_msg', _P), ('grad_beta_msg', _P), ('grad_w_gate', _P), ('grad_b_gate', _P), ('grad_emb', _P)]
+                ('grad_gamma_msg', _P), ('grad_beta_msg', _P), ('grad_w_gate', _P), ('grad_b_gate', _P), ('grad_emb', _P), ('store_bf16', c_int), ('x_center', _P)]
 
 
 class FcParams(ctypes.Structure):
@@ -232,6 +232,7 @@ _SIGNATURES = {
     'i3d_edge_combine_fwd': (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     'i3d_multihot': (c_int, [_P, _P, c_int, c_int, POINTER(c_int), c_int, _P, _P]),
     'i3d_edge_codes': (c_int, [_P, _P, c_int, c_int, POINTER(c_int), c_int, _P, _P, _P]),
+    'i3d_segment_sum_bf16': (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     'i3d_segment_sum_pair': (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'i3d_segment_sum': (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     'i3d_segment_bcast': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P]),

@@ -85,7 +85,7 @@ multihot_kernel(const long* __restrict__ idx, const int* __restrict__ row_perm, 
 // out[v, :] = scale * sum_{j in [ptr[v], ptr[v+1])} x[idx ? idx[j] : j, :]
 // PAIR: two segmentations of the same rows in one launch (the edge block's dP[src] over the out-edges and dP[dst] over the
 // in-edges): items [0, nseg FV) take (ptr, idx, out), the next nseg FV take (ptr1, idx1, out1)
-template <int V, bool PAIR = false>
+template <int V, bool PAIR = false, bool XB16 = false>
 __global__ void __launch_bounds__(256)
 segment_sum_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ ptr, const int* __restrict__ idx,
                    int nseg, int feat, int scale_mode, float* __restrict__ out, int ldo,
@@ -115,7 +115,11 @@ segment_sum_kernel(const float* __restrict__ x, int ldx, const int* __restrict__
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float* p = x + rows[k] * ldx + c;
-            if (V == 4) {
+            if constexpr (XB16) {      // rows of bf16 (V == 4): 4 values = 8 bytes
+                const uint2 t2 = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x) + rows[k] * ldx + c);
+                a[k][0] = __uint_as_float(t2.x << 16); a[k][1 % V] = __uint_as_float(t2.x & 0xffff0000u);
+                a[k][2 % V] = __uint_as_float(t2.y << 16); a[k][3 % V] = __uint_as_float(t2.y & 0xffff0000u);
+            } else if (V == 4) {
                 const float4 t4 = *reinterpret_cast<const float4*>(p);
                 a[k][0] = t4.x; a[k][1 % V] = t4.y; a[k][2 % V] = t4.z; a[k][3 % V] = t4.w;
             } else {
@@ -327,6 +331,18 @@ extern "C" int i3d_segment_sum(const float* x, int ldx, const int* ptr, const in
         hipLaunchKernelGGL(segment_sum_kernel<1>, dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, ptr,
                            idx, num_segments, feat, scale_mode, out, ldo);
     }
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_segment_sum_bf16(const void* x, int ldx, const int* ptr, const int* idx, int num_segments, int feat,
+                                    int scale_mode, float* out, int ldo, void* stream) {
+    I3D_CHECK_ARG(num_segments >= 0 && feat > 0 && ldx >= feat && ldo >= feat, "bad shape");
+    I3D_CHECK_ARG(feat % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && (((uintptr_t)x & 7) | ((uintptr_t)out & 15)) == 0, "bf16 rows: multiples of 4, aligned");
+    if (num_segments == 0) return I3D_OK;
+    long items = (long)num_segments * (feat / 4);
+    hipLaunchKernelGGL((segment_sum_kernel<4, false, true>), dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       ldx, ptr, idx, num_segments, feat, scale_mode, out, ldo);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }

@@ -75,6 +75,7 @@ struct EdgeK {                       // kernel argument (by value)
     const float* gsum_in;            // grad_beta | grad_gamma of the input BatchNorm (after R2)   [2H]
     const float* gsum_msg;           // grad_beta | grad_gamma of the message BatchNorm (after R1) [2H]
     float* x_msg;
+    float* x_center;                 // [H] bf16 storage: x_msg holds bf16(x - x_center) (written by n3_center_kernel, read by everyone)
     float* d_out;
     float* msg;
     const float* grad_m_sum;
@@ -97,6 +98,7 @@ struct Wts {                         // LDS copy of the parameters of the stage
     float w_g[H];
     float gs_in[2 * H];
     float gs_msg[2 * H];
+    float ctr[H];
     float b_g;
 };
 
@@ -121,6 +123,7 @@ __device__ __forceinline__ void load_weights(Wts<H, DIN>& w, const EdgeK& p, int
         w.istd_in[tid] = p.invstd_in[tid];
         w.istd_msg[tid] = p.invstd_msg[tid];
         w.w_g[tid] = p.w_gate[tid];
+        w.ctr[tid] = p.x_center != nullptr ? p.x_center[tid] : 0.f;
         // c = (W_s + W_d) emb + b_msg: every node carries the same embedding (reference net3d.py:61)
         float acc = p.b_msg[tid];
         const float* row = p.W_msg + (long)tid * p.ld_w_msg;
@@ -202,6 +205,49 @@ __device__ __forceinline__ void store_row(float* p, const float* v) {
     for (int c = 0; c < H; c += 4) *reinterpret_cast<float4*>(p + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
 }
 
+// The [E, H] ACTIVATIONS that only this stage reads and writes - x_msg (saved) and msg - in the storage type of
+// the launch: fp32, or (bf16 matmul mode, EdgeK.store16) bf16 - half the bytes of the passes that are bound by them (at the
+// QMugs shape an [E3, 20] fp32 tensor is 313 MB and the stage moves eleven of them per step).  Row `row` of a buffer that was
+// sized for fp32; values are rounded (RNE) once, where they are stored; statistics are taken before the rounding.
+template <int H, bool B16>
+__device__ __forceinline__ void load_srow(const float* base, long row, float* v, const float* ctr = nullptr) {
+    if constexpr (!B16) {
+        load_row<H>(base + row * H, v);
+    } else {
+        const uint2* q = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + row * H);
+#pragma unroll
+        for (int c = 0; c < H; c += 4) {
+            const uint2 t = q[c / 4];
+            v[c] = __uint_as_float(t.x << 16); v[c + 1] = __uint_as_float(t.x & 0xffff0000u);
+            v[c + 2] = __uint_as_float(t.y << 16); v[c + 3] = __uint_as_float(t.y & 0xffff0000u);
+        }
+        if (ctr != nullptr) {
+#pragma unroll
+            for (int c = 0; c < H; ++c) v[c] += ctr[c];
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned bf16_rne(float x) {      // bits of bf16(x), round to nearest even (finite inputs)
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+template <int H, bool B16>
+__device__ __forceinline__ void store_srow(float* base, long row, const float* v, const float* ctr = nullptr) {
+    if constexpr (!B16) {
+        store_row<H>(base + row * H, v);
+    } else {
+        uint2* q = reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + row * H);
+        float d[H];
+#pragma unroll
+        for (int c = 0; c < H; ++c) d[c] = ctr != nullptr ? v[c] - ctr[c] : v[c];
+#pragma unroll
+        for (int c = 0; c < H; c += 4)
+            q[c / 4] = make_uint2(bf16_rne(d[c]) | (bf16_rne(d[c + 1]) << 16), bf16_rne(d[c + 2]) | (bf16_rne(d[c + 3]) << 16));
+    }
+}
+
 // column sums over the block: on return red[w * NC + c] holds wave w's sum of column c (4 waves)
 template <int NC>
 __device__ __forceinline__ void block_sum_cols(float* v, float* red, int tid) {
@@ -234,7 +280,7 @@ __device__ __forceinline__ void write_tile_partial(float* partial, int tile, con
 }
 
 // F1: statistics of xa = act(W_in f + b_in)
-template <int H, int NENC>
+template <int H, int NENC, bool B16>
 __global__ void __launch_bounds__(TB) N3_OCC n3_stats_in_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
     __shared__ Wts<H, DIN> w;
@@ -278,7 +324,40 @@ __global__ void __launch_bounds__(TB) N3_OCC n3_stats_in_kernel(EdgeK p) {
 }
 
 // F2: e0 -> d_out (edge-id order), x_msg = act(c + W_e e0) (stored, destination-sorted) and its statistics
-template <int H, int NENC>
+// bf16 storage: the centre x_msg is stored about - the column means of the message block's activation over the first TB edges.
+// A pre-BatchNorm activation must not be rounded as it is: its columns can be nearly constant over the batch (every edge
+// feature is a function of ONE scalar distance), the BatchNorm behind then divides a 2^-9 |x| rounding error by a standard
+// deviation that is smaller than that (measured with raw storage: 10-96 % error on the stage's parameter gradients at 32
+// molecules).  About a centre inside the distribution the rounding error is 2^-9 of the DEVIATION - what the BatchNorm scales.
+template <int H, int NENC, bool B16>
+__global__ void __launch_bounds__(TB) N3_OCC n3_center_kernel(EdgeK p) {
+    constexpr int DIN = Dims<H, NENC>::DIN;
+    __shared__ Wts<H, DIN> w;
+    __shared__ float red[4 * H];
+    const int tid = threadIdx.x;
+    load_weights(w, p, tid);
+    __syncthreads();
+    float f[DIN], a[H], xa[H], e0[H], xm[H];
+    const int n = p.E < TB ? p.E : TB;
+    if (tid < n) {
+        N3_NO_HOIST();
+        fourier<NENC>(p.d_raw[p.perm[tid]], f);
+        lin_in<H, DIN>(w, f, ACT, a, xa);
+        bn_apply<H>(w.aff_in, xa, e0);
+#pragma unroll
+        for (int c = 0; c < H; ++c) e0[c] = apply_act(e0[c], ACT);
+        lin_msg<H, DIN>(w, e0, xm);
+#pragma unroll
+        for (int c = 0; c < H; ++c) xm[c] = apply_act(xm[c], ACT);
+    } else {
+#pragma unroll
+        for (int c = 0; c < H; ++c) xm[c] = 0.f;
+    }
+    block_sum_cols<H>(xm, red, tid);
+    if (tid < H) p.x_center[tid] = (((red[tid] + red[H + tid]) + red[2 * H + tid]) + red[3 * H + tid]) / (float)n;
+}
+
+template <int H, int NENC, bool B16>
 __global__ void __launch_bounds__(TB) N3_OCC n3_msg_pre_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
     __shared__ Wts<H, DIN> w;
@@ -304,7 +383,7 @@ __global__ void __launch_bounds__(TB) N3_OCC n3_msg_pre_kernel(EdgeK p) {
         lin_msg<H, DIN>(w, e0, xm);
 #pragma unroll
         for (int c = 0; c < H; ++c) xm[c] = apply_act(xm[c], ACT);
-        store_row<H>(p.x_msg + jj * H, xm);
+        store_srow<H, B16>(p.x_msg, jj, xm, w.ctr);
     };
     long j = j0 + tid;
     const bool first = j < jend;
@@ -340,7 +419,7 @@ __device__ __forceinline__ float gate_of(const Wts<H, DIN>& w, const float* m) {
 }
 
 // F3: msg = m * gate, m = BN_msg(x_msg)
-template <int H, int NENC>
+template <int H, int NENC, bool B16>
 __global__ void __launch_bounds__(TB) N3_OCC n3_gate_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
     __shared__ Wts<H, DIN> w;
@@ -350,12 +429,12 @@ __global__ void __launch_bounds__(TB) N3_OCC n3_gate_kernel(EdgeK p) {
     const long j = (long)blockIdx.x * TB + tid;
     if (j >= p.E) return;
     float xm[H], m[H];
-    load_row<H>(p.x_msg + j * H, xm);
+    load_srow<H, B16>(p.x_msg, j, xm, w.ctr);
     bn_apply<H>(w.aff_msg, xm, m);
     const float g = gate_of<H, DIN>(w, m);
 #pragma unroll
     for (int c = 0; c < H; ++c) m[c] *= g;
-    store_row<H>(p.msg + j * H, m);
+    store_srow<H, B16>(p.msg, j, m);
 }
 
 // gradient reaching m of edge j:  gm = gmsg * g + gg * w_g,  gg = (gmsg . m) g (1 - g),  gmsg = grad_m_sum[dst] (/ deg)
@@ -376,7 +455,7 @@ __device__ __forceinline__ void grad_m(const Wts<H, DIN>& w, const EdgeK& p, lon
 }
 
 // B1: partial[block] = sum gm | sum gm xhat_m | sum gg m | sum gg
-template <int H, int NENC>
+template <int H, int NENC, bool B16>
 __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_sums_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
     constexpr int NC = 3 * H + 1;
@@ -393,7 +472,7 @@ __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_sums_kernel(EdgeK p) {
     for (long j = j0 + tid; j < jend; j += TB) {
         N3_NO_HOIST();
         float xm[H], m[H], gm[H], gg;
-        load_row<H>(p.x_msg + j * H, xm);
+        load_srow<H, B16>(p.x_msg, j, xm, w.ctr);
         bn_apply<H>(w.aff_msg, xm, m);
         grad_m<H, DIN>(w, p, j, m, gm, gg);
 #pragma unroll
@@ -455,7 +534,7 @@ __device__ __forceinline__ void write_outer(const f32x16& acc, float* scratch, f
 }
 
 // B2a: gradient through the message block: glin (stored), partial[block] = [H][H + 1] (dW_e | dc)
-template <int H, int NENC>
+template <int H, int NENC, bool B16>
 __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_msg_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
     constexpr int NB = H + 1, NP = H * NB + 2 * H;
@@ -482,7 +561,7 @@ __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_msg_kernel(EdgeK p) {
         e0x[H] = 1.f;
         if (valid) {
             float xm[H], m[H], gm[H], gg, lin[H];
-            load_row<H>(p.x_msg + j * H, xm);
+            load_srow<H, B16>(p.x_msg, j, xm, w.ctr);
             load_row<H>(p.d_out + (long)p.perm[j] * H, e0x);
             bn_apply<H>(w.aff_msg, xm, m);
             grad_m<H, DIN>(w, p, j, m, gm, gg);
@@ -502,7 +581,7 @@ __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_msg_kernel(EdgeK p) {
 
 // B2b: grad of e0 = W_e^T glin, through the post activation (needs ya = BN_in(xa), recomputed from the distance): gya
 // (stored), partial[block][H (H + 1) ...] = sum gya [H] | sum gya xhat_a [H]
-template <int H, int NENC>
+template <int H, int NENC, bool B16>
 __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_post_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
     constexpr int NB = H + 1, NP = H * NB + 2 * H;
@@ -542,7 +621,7 @@ __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_post_kernel(EdgeK p) {
 }
 
 // B3: gradient through the edge-input block: partial[block] = [H][DIN + 1] (dW_in | db_in)
-template <int H, int NENC>
+template <int H, int NENC, bool B16>
 __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_in_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
     constexpr int NB = DIN + 1, NP = H * NB;
@@ -722,6 +801,7 @@ EdgeK kernel_args(const I3dNet3dEdgeArgs* a) {
     p.W_in = a->W_in; p.b_in = a->b_in; p.W_msg = a->W_msg; p.b_msg = a->b_msg; p.w_gate = a->w_gate; p.b_gate = a->b_gate;
     p.aff_in = a->aff_in; p.aff_msg = a->aff_msg; p.invstd_in = a->tail_in.invstd; p.invstd_msg = a->tail_msg.invstd;
     p.x_msg = a->x_msg; p.d_out = a->d_out; p.msg = a->msg;
+    p.x_center = a->store_bf16 ? a->x_center : nullptr;
     p.grad_m_sum = a->grad_m_sum; p.grad_ya = a->grad_ya; p.grad_lin = a->grad_lin;
     return p;
 }
@@ -769,11 +849,16 @@ int sync_backward_sums(float* gsum, int n, long local_rows, float* inv_rows_dev,
     return I3D_OK;
 }
 
+#define N3_DISPATCH_T(KERNEL, B16V, grid, block, stream, ...)                                                           \
+    do {                                                                                                               \
+        if (a->hidden == 20 && a->n_enc == 4) hipLaunchKernelGGL((KERNEL<20, 4, B16V>), grid, block, 0, stream, __VA_ARGS__); \
+        else if (a->hidden == 20 && a->n_enc == 0) hipLaunchKernelGGL((KERNEL<20, 0, B16V>), grid, block, 0, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<16, 2, B16V>), grid, block, 0, stream, __VA_ARGS__);                            \
+    } while (0)
 #define N3_DISPATCH(KERNEL, grid, block, stream, ...)                                                                  \
     do {                                                                                                               \
-        if (a->hidden == 20 && a->n_enc == 4) hipLaunchKernelGGL((KERNEL<20, 4>), grid, block, 0, stream, __VA_ARGS__); \
-        else if (a->hidden == 20 && a->n_enc == 0) hipLaunchKernelGGL((KERNEL<20, 0>), grid, block, 0, stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL((KERNEL<16, 2>), grid, block, 0, stream, __VA_ARGS__);                                 \
+        if (a->store_bf16) N3_DISPATCH_T(KERNEL, true, grid, block, stream, __VA_ARGS__);                              \
+        else N3_DISPATCH_T(KERNEL, false, grid, block, stream, __VA_ARGS__);                                           \
     } while (0)
 
 }  // namespace
@@ -811,6 +896,11 @@ extern "C" int i3d_net3d_edge_fwd(const I3dNet3dEdgeArgs* a, void* stream_) {
     if (int rc = i3d_bn_finalize_partials(a->stats, pl.fwd_tiles, H, t1.eps, t1.momentum, t1.gamma, t1.beta, t1.mean, t1.invstd,
                                           t1.running_mean, t1.running_var, t1.num_batches_tracked, a->aff_in, stream_))
         return rc;
+    if (a->store_bf16) {
+        I3D_CHECK_ARG(a->x_center != nullptr, "bf16 storage needs x_center");
+        N3_DISPATCH(n3_center_kernel, dim3(1), dim3(TB), stream, p);
+        I3D_CHECK_LAUNCH();
+    }
     N3_DISPATCH(n3_msg_pre_kernel, dim3(pl.fwd_tiles), dim3(TB), stream, p);
     I3D_CHECK_LAUNCH();
     const I3dBnTail& t2 = a->tail_msg;
@@ -819,6 +909,7 @@ extern "C" int i3d_net3d_edge_fwd(const I3dNet3dEdgeArgs* a, void* stream_) {
         return rc;
     N3_DISPATCH(n3_gate_kernel, dim3(cdiv(a->num_edges, TB)), dim3(TB), stream, p);
     I3D_CHECK_LAUNCH();
+    if (a->store_bf16) return i3d_segment_sum_bf16(a->msg, H, a->in_ptr, nullptr, a->num_nodes, H, a->reduce_mean, a->m_sum, H, stream_);
     return i3d_segment_sum(a->msg, H, a->in_ptr, nullptr, a->num_nodes, H, a->reduce_mean, a->m_sum, H, stream_);
 }
 

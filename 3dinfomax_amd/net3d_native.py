@@ -21,6 +21,11 @@ from .layer_native import _Arena, _al, _tail
 from .layers import _composite_ok, _keeps_pre, _set_workspaces
 
 NATIVE_NET3D = os.environ.get('I3D_NATIVE_NET3D', '1') != '0'
+# bf16 matmul mode: the edge stage's own [E3, H] activations (x_msg, msg) stored as bf16 once they are large enough to be bound
+# by their bytes (QMugs shape, 3.9 M edges: 313 MB per tensor, step 6.71 -> 6.49 ms; at the QM9 shape's 140 k edges they sit in
+# the Infinity Cache and the extra conversion work costs 1 %).  I3D_NET3D_BF16_STORE=0: never; =force: at every size
+BF16_STORE = os.environ.get('I3D_NET3D_BF16_STORE', '1') != '0'
+BF16_STORE_MIN_EDGES = 0 if os.environ.get('I3D_NET3D_BF16_STORE') == 'force' else (1 << 20)
 FUSED_EDGE = os.environ.get('I3D_NET3D_FUSED_EDGE', '1') != '0'      # the edge stage in one lane per edge (csrc/net3d_edge.hip)
 _F32 = torch.float32
 
@@ -100,6 +105,9 @@ def _edge_stage_fwd(L, stream, ar, dev, model, g, idx, d_raw, edge_in, msg_fc, s
     a.x_msg, a.msg, a.m_sum = ar.take(E * H), ar.take(E * H), ar.take(N * H)
     d_out = torch.empty(E, H, dtype=_F32, device=dev)
     a.d_out = d_out.data_ptr()
+    # the storage form of a pass is fixed here (the backward call gets the same struct)
+    a.store_bf16 = int(BF16_STORE and E >= BF16_STORE_MIN_EDGES and L.i3d_get_matmul_precision() != 0)
+    a.x_center = ar.take(H)
     _chk(L.i3d_net3d_edge_fwd(ctypes.byref(a), stream), 'i3d_net3d_edge_fwd')
     return a, a.m_sum, d_out, (W_in, b_in, g_in, be_in, W_m, b_m, g_m, be_m, se.weight, se.bias)
 
@@ -152,7 +160,7 @@ def forward(ctx, model, g, params):
     # ---- scratch size
     total = _al(N * H)
     if fused:
-        total += 4 * _al(H) + 2 * _al(3 * H) + _al(int(L.i3d_net3d_edge_stats_floats(E, H))) + 2 * _al(E * H) + 2 * _al(N * H)
+        total += 5 * _al(H) + 2 * _al(3 * H) + _al(int(L.i3d_net3d_edge_stats_floats(E, H))) + 2 * _al(E * H) + 2 * _al(N * H)
     else:
         total += _al(E) + (_al(E * enc_dim) if n_enc > 0 else 0) + _fc_floats(E, H, edge_in.hot('silu')[4])
     for msg, se, upd, _ in layers:

@@ -251,6 +251,9 @@ int i3d_edge_codes(const int64_t* idx, const int* row_perm, int rows, int n_cols
 int i3d_segment_sum(const float* x, int ldx, const int* ptr, const int* idx, int num_segments, int feat,
                     int scale_mode, float* out, int ldo, void* stream);
 /* two segmentations of the same rows in one launch (sums, no scaling): out0 over (ptr0, idx0), out1 over (ptr1, idx1) */
+/* i3d_segment_sum over rows of bf16 values (x: row r at (bf16*)x + r * ldx; feat, ldx multiples of 4, 8-byte aligned), fp32 sums */
+int i3d_segment_sum_bf16(const void* x, int ldx, const int* ptr, const int* idx, int num_segments, int feat, int scale_mode,
+                         float* out, int ldo, void* stream);
 int i3d_segment_sum_pair(const float* x, int ldx, const int* ptr0, const int* idx0, float* out0, const int* ptr1,
                          const int* idx1, float* out1, int num_segments, int feat, int ldo, void* stream);
 int i3d_segment_bcast(const float* g, const int* ptr, const int* seg_of_row, int rows, int feat, int scale_mode,
@@ -641,6 +644,11 @@ typedef struct {
     float* grad_w_gate;
     float* grad_b_gate;
     float* grad_emb;     /* += */
+    int store_bf16;      /* x_msg and msg - the [E, hidden] activations only this stage reads and writes - hold bf16 (the buffers
+                          * keep their fp32 size): the bf16 matmul mode's storage form of the stage.  x_msg is stored about
+                          * x_center (its columns can be nearly constant over a batch: see n3_center_kernel).  The same value in
+                          * the forward and the backward call of a pass. */
+    float* x_center;     /* [hidden] saved (store_bf16 only) */
 } I3dNet3dEdgeArgs;
 int i3d_net3d_edge_supported(int hidden, int n_enc);   /* 1 when the kernels are built for this combination */
 long i3d_net3d_edge_stats_floats(int num_edges, int hidden);

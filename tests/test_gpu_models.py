@@ -323,7 +323,7 @@ def test_qmugs_conformers_multiple_positives_vs_oracle(amd, variant, n_mols, hid
 
 @pytest.mark.parametrize('variant,n_mols,hidden,depth', [('smooth', 64, 64, 2), ('as_configured', 64, 64, 2),
                                                          ('as_configured', 32, 200, 7)])
-def test_qmugs_conformers_bf16_matmul_vs_oracle(amd, variant, n_mols, hidden, depth):
+def test_qmugs_conformers_bf16_matmul_vs_oracle(amd, variant, n_mols, hidden, depth, monkeypatch):
     """configs[3] shape with the bf16 matmul precision (bf16-rounded operands on the bf16 matrix pipe, fp32 accumulation,
     fp32 tensors / BatchNorm statistics) against the fp32 CPU oracle, molecules x 3 conformers: loss within 5e-3 relative,
     embeddings within 3e-2 of their scale, every parameter gradient within 0.15 relative L2 + 2e-3 of the largest gradient
@@ -333,6 +333,8 @@ def test_qmugs_conformers_bf16_matmul_vs_oracle(amd, variant, n_mols, hidden, de
     this test is about); also at the yml's hidden 200 / depth 7, where seven layers of rounded products add up: measured and
     stated bounds in _qmugs_vs_oracle."""
     ops = importlib.import_module('3dinfomax_amd.ops')
+    # the bf16 STORAGE form of the 3D network's edge stage at these (small) sizes too: it switches on by size
+    monkeypatch.setattr(importlib.import_module('3dinfomax_amd.net3d_native'), 'BF16_STORE_MIN_EDGES', 0)
     prev = ops.set_matmul_precision('bf16')
     try:
         _qmugs_vs_oracle(amd, variant, n_mols, 'bf16', hidden=hidden, depth=depth)
@@ -418,7 +420,10 @@ def _qmugs_vs_oracle(amd, variant, n_mols, precision, hidden=64, depth=2):
         # measured relative L2 per tensor: smooth <= 0.07; as_configured median 0.14 at both sizes, the first head block (fed
         # by the max / min readouts) 0.26-0.37 (weight) / 0.31-0.50 (bias), posttrans BatchNorm biases up to 0.33
         grads_close_l2(param_grads(pna), {k: P2[k].grad for k in O.trainable(P2)}, 0.15 if variant == 'smooth' else 0.6, 'pna ', floor=2e-3)
-        grads_close_l2(param_grads(net), {k: P3[k].grad for k in O.trainable(P3)}, 0.15, 'net3d ', floor=2e-3)
+        # the 3D network with its edge-stage activations STORED as bf16 (net3d_native.BF16_STORE; x_msg about a centre:
+        # csrc/net3d_edge.hip n3_center_kernel): measured 0.04-0.18 per tensor (raw, un-centred storage: 0.14-0.96 on the
+        # 32-molecule case - the BatchNorm behind a nearly constant column divides the rounding error by its tiny deviation)
+        grads_close_l2(param_grads(net), {k: P3[k].grad for k in O.trainable(P3)}, 0.25, 'net3d ', floor=2e-3)
         return
     loss = amd.NTXentMultiplePositives(tau=0.1)(z2, z3)
     loss.backward()
