@@ -69,6 +69,10 @@ constexpr int WG_T = 13;                        // tiles per panel side
 constexpr int WG_LD = 208;                      // widest panel (columns)
 constexpr int WG_LDP = 256;                     // LDS pitch of an operand row (floats): one 1 KiB DMA per wave
 constexpr int WG_BK = 16;                       // rows per K-tile
+// K-tiles of both operands resident in LDS: one computed on, the others in flight.  Two for the exact fp32 form (its 5500 MFMA
+// cycles per tile cover one tile's load; a third stage measured 88.8 -> 93.9 us per layer), three for the bf16 forms, whose
+// K loop is bound by the loads (bf16 60.6 -> 53.0 us, split 68.9 -> 67.5)
+constexpr int wg_nst(int prec) { return prec == 0 ? 2 : 3; }
 constexpr int WG_UNIT_FLOATS = WG_T * WG_T * 256;   // slab floats of one unit (tile-major)
 constexpr int WG_MAX_PROBLEMS = 40;
 constexpr int WG_MAX_SLICE = 1024;              // rows of one K-slice (their row indices are staged in LDS)
@@ -134,8 +138,9 @@ __device__ __forceinline__ void wgrad_unit(const WgProb& p, const int slice, con
     const bool a_ok = s4 * 4 < mvalid, b_ok = s4 * 4 < nvalid;
     const unsigned lda4 = (unsigned)p.lda * 4u, ldb4 = (unsigned)p.ldb * 4u, col = (unsigned)s4 * 16u;
 
-    float* const As = smem;                          // [2][BK][LDP]
-    float* const Bs = smem + 2 * WG_BK * WG_LDP;     // [2][BK][LDP]
+    float* const As = smem;                          // [NST][BK][LDP]
+    constexpr int NST = wg_nst(PREC);
+    float* const Bs = smem + NST * WG_BK * WG_LDP;     // [NST][BK][LDP]
     const unsigned as_base = (unsigned)(unsigned long long)(lds_ptr_t)As, bs_base = (unsigned)(unsigned long long)(lds_ptr_t)Bs;
     __syncthreads();                                 // kidx visible
 
@@ -169,10 +174,16 @@ __device__ __forceinline__ void wgrad_unit(const WgProb& p, const int slice, con
     for (int q = 0; q < NQ; ++q) accx[q] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     const int nkt = (klen + WG_BK - 1) / WG_BK;
-    read_rows(0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_piece(0, 0, i);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows have landed
+    for (int t0 = 0; t0 < NST - 1; ++t0) {
+        read_rows(t0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_piece(t0, t0, i);
+    }
+    // a tile is 8 loads per wave (4 pieces x 2 operands, issued whether its rows exist or not): tile 0 has landed when at most
+    // the later tiles' loads are still in flight
+    if constexpr (NST == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __syncthreads();
     WG_STAMP(1);
     const bool extra = ntl == WG_T;                  // the 13th tile column is shared by the waves (tile rows wave + 4 q)
@@ -181,8 +192,8 @@ __device__ __forceinline__ void wgrad_unit(const WgProb& p, const int slice, con
     const int even_off = lk * WG_LDP + l15 + 16 * b, odd_off = lk * WG_LDP + l15 - 16 * b;
     const int own_off = pw ? odd_off : even_off;     // tiles wave + 4 j have the wave's parity
     for (int t = 0; t < nkt; ++t) {
-        const int cur = t & 1;
-        read_rows(t + 1);                            // (clamped past the end; those rows load zeros)
+        const int cur = t % NST, nxt = (t + NST - 1) % NST;      // nxt was last read in tile t - 1, behind that tile's barrier
+        read_rows(t + NST - 1);                      // (clamped past the end; those rows load zeros)
         const float* as = As + cur * WG_BK * WG_LDP;
         const float* bs = Bs + cur * WG_BK * WG_LDP;
         if constexpr (PREC != PREC_F32) {
@@ -225,7 +236,7 @@ __device__ __forceinline__ void wgrad_unit(const WgProb& p, const int slice, con
                     }
                     if (j < 2) {     // the next tile's loads in four pieces between the MFMA groups
                         __builtin_amdgcn_sched_barrier(0);
-                        issue_piece(t + 1, cur ^ 1, half * 2 + j);
+                        issue_piece(t + NST - 1, nxt, half * 2 + j);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -266,7 +277,7 @@ __device__ __forceinline__ void wgrad_unit(const WgProb& p, const int slice, con
                     // one piece of the next tile's loads behind the first MFMA group of every k-step: buffer cur ^ 1 was
                     // last read before the barrier that ended the previous trip
                     __builtin_amdgcn_sched_barrier(0);
-                    issue_piece(t + 1, cur ^ 1, kk);
+                    issue_piece(t + NST - 1, nxt, kk);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -275,9 +286,11 @@ __device__ __forceinline__ void wgrad_unit(const WgProb& p, const int slice, con
                 for (int q = 0; q < NQ; ++q) accx[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(bx, ax[q], accx[q], 0, 0, 0);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (NST == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // tile t + 1 has landed (tile t + 2's loads may still fly)
         __syncthreads();
     }
+    if constexpr (NST > 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the (zero) over-fetch past the last tile
 
     // epilogue: tile (mt, nt) -> out[(mt * 13 + nt) * 256 + lane * 4 ..]: one coalesced 1 KiB store per tile
     WG_STAMP(2);
@@ -304,7 +317,7 @@ __device__ __forceinline__ void wgrad_unit(const WgProb& p, const int slice, con
 
 template <int PREC>
 __global__ void __launch_bounds__(256, 2) wgrad_multi_kernel(const WgArgs a) {
-    __shared__ __attribute__((aligned(1024))) float smem[4 * WG_BK * WG_LDP];
+    __shared__ __attribute__((aligned(1024))) float smem[2 * wg_nst(PREC) * WG_BK * WG_LDP];
     __shared__ int kidx[WG_MAX_SLICE];
     const int u = xcd_unit(a.n_units);
     int pi = 0;
