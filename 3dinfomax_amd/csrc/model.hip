@@ -110,11 +110,14 @@ bool join_per_layer() {
     return on;
 }
 
-// I3D_WGRAD_SPLIT_LAST=1: the first layer's weight gradients (the last ones of a backward pass) as two launches, the
-// posttrans products early.  Off: measured 2.289 ms split against 2.253 ms in one launch (tools/ab.sh, 3 interleaved runs) -
-// the early launch takes CUs from the chain it was meant to hide behind.
+// The first layer's weight gradients (the last ones of a backward pass, and what the step waits for at its very end) as two
+// launches, the posttrans products early, next to that layer's chain: only the pretrans / bond-table products are left when the
+// chain ends.  Before the chain's kernels had wave priority this lost (2.289 against 2.253 ms: the early launch took the CUs from
+// the chain it was meant to hide behind); with it: 2.141 against 2.152 ms (tools/ab.sh, 5 interleaved runs).  Every layer split
+// the same way (I3D_WGRAD_SPLIT_LAST=all) loses 40 us: one more launch + reduction per layer for work that was hidden anyway.
+// I3D_WGRAD_SPLIT_LAST=0: one launch per layer everywhere.
 int split_wgrad() {     // 0: no layer, 1: the first layer (last of the backward pass), 2: every layer
-    static const int v = [] { const char* e = getenv("I3D_WGRAD_SPLIT_LAST"); return e == nullptr ? 0 : (e[0] == '1' ? 1 : (e[0] == 'a' ? 2 : 0)); }();
+    static const int v = [] { const char* e = getenv("I3D_WGRAD_SPLIT_LAST"); return e == nullptr ? 1 : (e[0] == '1' ? 1 : (e[0] == 'a' ? 2 : 0)); }();
     return v;
 }
 
@@ -569,7 +572,7 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
         Bump own(side[l]);
         Bump& sd = per_layer_join ? ar : own;       // where the side stream's buffers of this layer live
         a.defer_join = per_layer_join ? 0 : 1;
-        a.wgrad_split = (!per_layer_join && (split_wgrad() == 2 || (l == 0 && split_wgrad() == 1))) ? 1 : 0;
+        a.wgrad_split = (split_wgrad() == 2 || (l == 0 && split_wgrad() == 1)) ? 1 : 0;
         // a residual layer accumulates dL/dh_in on top of the incoming gradient IN PLACE (dh_in = dh_out + ...: the separate
         // add pass over [N, F] is gone, composite.hip: i3d_pna_layer_bwd); others ping-pong between the two buffers
         const int cur = c->gh_cur, nxt = a.residual ? cur : cur ^ 1;
