@@ -60,7 +60,7 @@ class PnaLayerArgs(ctypes.Structure):
                 ('avg_d_log', c_float), ('msg', _P), ('grad_msg', _P), ('post', GroupedFcArgs), ('n_post_extra', c_int),
                 ('postx', FcArgs * 3), ('residual', c_int), ('grad_out', _P), ('agg_event_start', _P), ('agg_event_stop', _P),
                 ('fused_bn', c_int), ('defer_join', c_int), ('stats_ws', _P), ('aff', _P * 4), ('weights_ready', c_int),
-                ('merge_h', c_int), ('Wcat', _P), ('bcat', _P), ('PL', _P), ('DL', _P), ('wgrad_split', c_int), ('eval_mode', c_int)]
+                ('merge_h', c_int), ('Wcat', _P), ('bcat', _P), ('PL', _P), ('DL', _P), ('wgrad_split', c_int), ('eval_mode', c_int), ('msg_bf16', c_int)]
 
 
 class Net3dEdgeArgs(ctypes.Structure):
@@ -145,6 +145,7 @@ _SIGNATURES = {
     'i3d_pna_model_bwd_part': (c_int, [_P, POINTER(PnaModel), _P, _P, _P, _P, c_long, c_int, c_int, _P]),
     'i3d_pna_model_ctx_free': (c_int, [_P]),
     'i3d_pna_messages_normalized': (c_int, [_P, _P, c_long, c_int, _P, _P]),
+    'i3d_pna_messages_normalized_ex': (c_int, [_P, c_int, _P, c_long, c_int, _P, _P]),
     'i3d_pna_model_debug_messages': (c_int, [_P, c_int, _P, _P]),
     'i3d_event_create': (c_int, [POINTER(c_void_p)]),
     'i3d_event_destroy': (c_int, [_P]),
@@ -179,6 +180,10 @@ _SIGNATURES = {
     'i3d_gemm_f32_wgrad_bn': (c_int, [c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P, c_long, _P]),
     'i3d_pna_aggregate_fwd_aff': (c_int, [_P, _P, _P, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_int, c_float,
                                           _P, _P]),
+    'i3d_pna_aggregate_fwd_ex': (c_int, [_P, c_int, _P, _P, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_int, c_float, _P, _P]),
+    'i3d_pna_aggregate_bwd_ex': (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_int, c_float, _P, _P]),
+    'i3d_gemm_f32_fused_bf16out': (c_int, [c_int, c_int, c_int, _P, c_int, c_long, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P]),
+    'i3d_bn_bwd_x_bf16': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'i3d_pna_aggregate_bwd_aff': (c_int, [_P, _P, _P, _P, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_int,
                                           c_float, _P, _P]),
     'i3d_bn_bias_partial_floats': (c_long, [c_int]),

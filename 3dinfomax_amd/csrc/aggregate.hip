@@ -55,7 +55,7 @@ __device__ __forceinline__ float4 aff4(const float4 x, const float4 mu, const fl
                        (x.w - mu.w) * sc.w + sh.w);
 }
 
-template <int MODE>
+template <int MODE, bool MB16 = false>      // MB16: the messages are stored as bf16 (rows of F bf16 values; bf16 matmul mode)
 __global__ void __launch_bounds__(256)
 pna_aggregate_fwd_kernel(const float4* __restrict__ e, const int* __restrict__ in_ptr, int N, int FV,
                          AggCfg cfg, float4* __restrict__ out, const float4* __restrict__ aff) {
@@ -72,11 +72,21 @@ pna_aggregate_fwd_kernel(const float4* __restrict__ e, const int* __restrict__ i
         return;
     }
     const float4* p = e + (long)beg * FV + c;
+    const uint2* p16 = reinterpret_cast<const uint2*>(e) + (long)beg * FV + c;      // (MB16: a chunk of 4 values is 8 bytes)
+    auto msg = [&](long j) -> float4 {
+        if constexpr (MB16) {
+            const uint2 t = p16[j * FV];
+            return make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
+                               __uint_as_float(t.y & 0xffff0000u));
+        } else {
+            return p[j * FV];
+        }
+    };
     // molecules: D <= 4 almost always.  The first four message rows are loaded unconditionally (clamped index, the
     // duplicates hit L1) so four loads are in flight instead of a dependent load-accumulate chain; the accumulation
     // order stays j = 0 .. D-1.
-    float4 x = p[0];
-    float4 x1 = p[(long)min(1, D - 1) * FV], x2 = p[(long)min(2, D - 1) * FV], x3 = p[(long)min(3, D - 1) * FV];
+    float4 x = msg(0);
+    float4 x1 = msg(min(1, D - 1)), x2 = msg(min(2, D - 1)), x3 = msg(min(3, D - 1));
     float4 a_mu, a_sc, a_sh;
     if (aff != nullptr) {
         a_mu = aff[c]; a_sc = aff[FV + c]; a_sh = aff[2 * FV + c];
@@ -96,8 +106,7 @@ pna_aggregate_fwd_kernel(const float4* __restrict__ e, const int* __restrict__ i
     if (D > 3) I3D_AGG_ACC(x3);
     // longer segments (per-graph readouts: ~18 atoms; hub atoms): four more rows in flight per trip, same order
     for (int j = 4; j < D; j += 4) {
-        float4 y0 = p[(long)j * FV], y1 = p[(long)min(j + 1, D - 1) * FV], y2 = p[(long)min(j + 2, D - 1) * FV],
-               y3 = p[(long)min(j + 3, D - 1) * FV];
+        float4 y0 = msg(j), y1 = msg(min(j + 1, D - 1)), y2 = msg(min(j + 2, D - 1)), y3 = msg(min(j + 3, D - 1));
         if (aff != nullptr) {
             y0 = aff4(y0, a_mu, a_sc, a_sh); y1 = aff4(y1, a_mu, a_sc, a_sh); y2 = aff4(y2, a_mu, a_sc, a_sh); y3 = aff4(y3, a_mu, a_sc, a_sh);
         }
@@ -209,7 +218,7 @@ __device__ __forceinline__ float& comp(T& a, int i) {
 }
 
 // MODE as in the forward kernel (0: any list, 1: standard 12 blocks, 2: standard 4 blocks); MODE 1/2 need V = 4
-template <int V, int MODE = 0>  // V = 4 (float4 items) or 1
+template <int V, int MODE = 0, bool MB16 = false>  // V = 4 (float4 items) or 1; MB16 (V = 4): messages stored as bf16
 __global__ void __launch_bounds__(256)
 pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ e,
                          const int* __restrict__ in_ptr, int N, int F, AggCfg cfg, float* __restrict__ ge,
@@ -235,6 +244,18 @@ pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict
     const float* go = gout + (long)v * nblk * F + (long)c * V;
     const float* p = e + (long)beg * F + (long)c * V;
     float* q = ge + (long)beg * F + (long)c * V;
+    auto load_msg = [&](long row, float* dst) {
+        if constexpr (MB16 && V == 4) {
+            const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(e) + ((long)beg + row) * F + (long)c * 4);
+            dst[0] = __uint_as_float(t.x << 16); dst[1 % V] = __uint_as_float(t.x & 0xffff0000u);
+            dst[2 % V] = __uint_as_float(t.y << 16); dst[3 % V] = __uint_as_float(t.y & 0xffff0000u);
+        } else if (V == 4) {
+            const float4 xx = *reinterpret_cast<const float4*>(p + row * F);
+            dst[0] = xx.x; dst[1 % V] = xx.y; dst[2 % V] = xx.z; dst[3 % V] = xx.w;
+        } else {
+            dst[0] = p[row * F];
+        }
+    };
     float amp, att;
     scaler_values(cfg, D, amp, att);
 
@@ -302,13 +323,7 @@ pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict
     float xr[4][V];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-        const long row = min(jj, D - 1);
-        if (V == 4) {
-            float4 xx = *reinterpret_cast<const float4*>(p + row * F);
-            xr[jj][0] = xx.x; xr[jj][1 % V] = xx.y; xr[jj][2 % V] = xx.z; xr[jj][3 % V] = xx.w;
-        } else {
-            xr[jj][0] = p[row * F];
-        }
+        load_msg(min(jj, D - 1), xr[jj]);
     }
     // messages as the forward saw them: (e - mean) * scale + shift (see pna_aggregate_fwd_kernel); the result is the
     // gradient with respect to THAT value, the BatchNorm backward in front follows in its own kernel
@@ -357,13 +372,7 @@ pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict
         float xs[4][V];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const long row = min(j0 + k, D - 1);
-            if (V == 4) {
-                float4 xx = *reinterpret_cast<const float4*>(p + row * F);
-                xs[k][0] = xx.x; xs[k][1 % V] = xx.y; xs[k][2 % V] = xx.z; xs[k][3 % V] = xx.w;
-            } else {
-                xs[k][0] = p[row * F];
-            }
+            load_msg(min(j0 + k, D - 1), xs[k]);
             if (aff != nullptr) {
 #pragma unroll
                 for (int i = 0; i < V; ++i) xs[k][i] = (xs[k][i] - a_mu[i]) * a_sc[i] + a_sh[i];
@@ -415,13 +424,7 @@ pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict
         float xs[4][V];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const long row = min(j0 + k, D - 1);
-            if (V == 4) {
-                float4 xx = *reinterpret_cast<const float4*>(p + row * F);
-                xs[k][0] = xx.x; xs[k][1 % V] = xx.y; xs[k][2 % V] = xx.z; xs[k][3 % V] = xx.w;
-            } else {
-                xs[k][0] = p[row * F];
-            }
+            load_msg(min(j0 + k, D - 1), xs[k]);
             if (aff != nullptr) {
 #pragma unroll
                 for (int i = 0; i < V; ++i) xs[k][i] = (xs[k][i] - a_mu[i]) * a_sc[i] + a_sh[i];
@@ -503,6 +506,15 @@ extern "C" int i3d_pna_aggregate_fwd(const float* e, const int* in_ptr, int num_
 extern "C" int i3d_pna_aggregate_fwd_aff(const float* e, const float* aff, const int* in_ptr, int num_nodes, int feat,
                                          const int* aggregators, int n_aggregators, const int* scalers,
                                          int n_scalers, int force_scalers, float avg_d_log, float* out, void* stream) {
+    return i3d_pna_aggregate_fwd_ex(e, 0, aff, in_ptr, num_nodes, feat, aggregators, n_aggregators, scalers, n_scalers, force_scalers,
+                                    avg_d_log, out, stream);
+}
+
+extern "C" int i3d_pna_aggregate_fwd_ex(const void* e_, int e_bf16, const float* aff, const int* in_ptr, int num_nodes, int feat,
+                                        const int* aggregators, int n_aggregators, const int* scalers,
+                                        int n_scalers, int force_scalers, float avg_d_log, float* out, void* stream) {
+    const float* e = (const float*)e_;
+    I3D_CHECK_ARG(!e_bf16 || (feat % 4 == 0 && (((uintptr_t)e_) & 7) == 0), "bf16 messages need feat % 4 == 0 and 8-byte alignment");
     I3D_CHECK_ARG(aff == nullptr || (feat % 4 == 0 && (((uintptr_t)aff) & 15) == 0), "aff needs feat % 4 == 0 and 16-byte alignment");
     I3D_CHECK_ARG(num_nodes >= 0 && feat > 0, "num_nodes >= 0 and feat > 0 required");
     AggCfg cfg;
@@ -514,7 +526,17 @@ extern "C" int i3d_pna_aggregate_fwd_aff(const float* e, const float* aff, const
         int FV = feat / 4;
         long items = (long)num_nodes * FV;
         dim3 grid(cdiv(items, 256));
-        if (is_std_cfg(cfg))
+        if (e_bf16) {
+            if (is_std_cfg(cfg))
+                hipLaunchKernelGGL((pna_aggregate_fwd_kernel<1, true>), grid, dim3(256), 0, s, (const float4*)e, in_ptr, num_nodes, FV, cfg,
+                                   (float4*)out, (const float4*)aff);
+            else if (is_ident_cfg(cfg))
+                hipLaunchKernelGGL((pna_aggregate_fwd_kernel<2, true>), grid, dim3(256), 0, s, (const float4*)e, in_ptr, num_nodes, FV, cfg,
+                                   (float4*)out, (const float4*)aff);
+            else
+                hipLaunchKernelGGL((pna_aggregate_fwd_kernel<0, true>), grid, dim3(256), 0, s, (const float4*)e, in_ptr, num_nodes, FV, cfg,
+                                   (float4*)out, (const float4*)aff);
+        } else if (is_std_cfg(cfg))
             hipLaunchKernelGGL(pna_aggregate_fwd_kernel<1>, grid, dim3(256), 0, s, (const float4*)e, in_ptr,
                                num_nodes, FV, cfg, (float4*)out, (const float4*)aff);
         else if (is_ident_cfg(cfg))      // (tried, not better back to back at batch 512: two items per lane 9.4 us vs 8.7 us;
@@ -544,6 +566,16 @@ extern "C" int i3d_pna_aggregate_bwd_aff(const float* grad_out, const float* e, 
                                          int num_nodes, int feat, const int* aggregators, int n_aggregators,
                                          const int* scalers, int n_scalers, int force_scalers, float avg_d_log,
                                          float* grad_e, void* stream) {
+    return i3d_pna_aggregate_bwd_ex(grad_out, e, 0, aff, in_ptr, num_nodes, feat, aggregators, n_aggregators, scalers, n_scalers,
+                                    force_scalers, avg_d_log, grad_e, stream);
+}
+
+extern "C" int i3d_pna_aggregate_bwd_ex(const float* grad_out, const void* e_, int e_bf16, const float* aff, const int* in_ptr,
+                                        int num_nodes, int feat, const int* aggregators, int n_aggregators,
+                                        const int* scalers, int n_scalers, int force_scalers, float avg_d_log,
+                                        float* grad_e, void* stream) {
+    const float* e = (const float*)e_;
+    I3D_CHECK_ARG(!e_bf16 || (feat % 4 == 0 && (((uintptr_t)e_) & 7) == 0), "bf16 messages need feat % 4 == 0 and 8-byte alignment");
     I3D_CHECK_ARG(num_nodes >= 0 && feat > 0, "num_nodes >= 0 and feat > 0 required");
     AggCfg cfg;
     I3D_CHECK_ARG(make_cfg(aggregators, n_aggregators, scalers, n_scalers, force_scalers, avg_d_log, cfg) == 0,
@@ -552,7 +584,17 @@ extern "C" int i3d_pna_aggregate_bwd_aff(const float* grad_out, const float* e, 
     hipStream_t s = (hipStream_t)stream;
     if (feat % 4 == 0) {
         long items = (long)num_nodes * (feat / 4);
-        if (is_std_cfg(cfg))
+        if (e_bf16) {
+            if (is_std_cfg(cfg))
+                hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 1, true>), dim3(cdiv(items, 256)), dim3(256), 0, s, grad_out, e, in_ptr,
+                                   num_nodes, feat, cfg, grad_e, aff);
+            else if (is_ident_cfg(cfg))
+                hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 2, true>), dim3(cdiv(items, 256)), dim3(256), 0, s, grad_out, e, in_ptr,
+                                   num_nodes, feat, cfg, grad_e, aff);
+            else
+                hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 0, true>), dim3(cdiv(items, 256)), dim3(256), 0, s, grad_out, e, in_ptr,
+                                   num_nodes, feat, cfg, grad_e, aff);
+        } else if (is_std_cfg(cfg))
             hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 1>), dim3(cdiv(items, 256)), dim3(256), 0, s, grad_out, e, in_ptr,
                                num_nodes, feat, cfg, grad_e, aff);
         else if (is_ident_cfg(cfg))
@@ -573,20 +615,26 @@ extern "C" int i3d_pna_aggregate_bwd_aff(const float* grad_out, const float* e, 
 // debug / test entry: the messages exactly as the aggregation kernels see them, (e - mean) * scale + shift with the same
 // expression (and the same -ffp-contract=off build) - a test derives the kernels' arg-max / arg-min choices from them
 __global__ void __launch_bounds__(256) pna_messages_kernel(const float* __restrict__ e, const float* __restrict__ aff, long rows,
-                                                           int F, float* __restrict__ out) {
+                                                           int F, float* __restrict__ out, int e_bf16) {
     I3D_CHAIN_PRIO();
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= rows * F) return;
     const int c = (int)(t % F);
     float a_mu = 0.f, a_sc = 1.f, a_sh = 0.f;
     if (aff != nullptr) { a_mu = aff[c]; a_sc = aff[F + c]; a_sh = aff[2 * F + c]; }
-    out[t] = aff != nullptr ? (e[t] - a_mu) * a_sc + a_sh : e[t];
+    const float v = e_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(e)[t] << 16) : e[t];
+    out[t] = aff != nullptr ? (v - a_mu) * a_sc + a_sh : v;
 }
 
 extern "C" int i3d_pna_messages_normalized(const float* e, const float* aff, long rows, int feat, float* out, void* stream) {
+    return i3d_pna_messages_normalized_ex(e, 0, aff, rows, feat, out, stream);
+}
+
+extern "C" int i3d_pna_messages_normalized_ex(const void* e, int e_bf16, const float* aff, long rows, int feat, float* out, void* stream) {
     I3D_CHECK_ARG(e != nullptr && out != nullptr && rows >= 0 && feat > 0, "bad arguments");
     if (rows == 0) return I3D_OK;
-    hipLaunchKernelGGL(pna_messages_kernel, dim3(cdiv(rows * feat, 256)), dim3(256), 0, (hipStream_t)stream, e, aff, rows, feat, out);
+    hipLaunchKernelGGL(pna_messages_kernel, dim3(cdiv(rows * feat, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)e, aff, rows, feat, out,
+                       e_bf16);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }

@@ -188,7 +188,18 @@ struct ReduceArgs {
     const float* beta;     // BN_BWD with post_act
     int rows, feat, act, post_act;
     float* partial;        // [nblk][2][feat]
+    int b_bf16;            // MODE_BN_BWD: b (the BatchNorm input x) is stored as bf16 (V = 4)
 };
+
+// 4 consecutive values of a row operand that is stored as fp32 or (x_bf16: the bf16 mode's message storage) as bf16
+__device__ __forceinline__ float4 load4_maybe_bf16(const float* base, long off, int is_bf16) {
+    if (is_bf16) {
+        const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
+        return make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
+                           __uint_as_float(t.y & 0xffff0000u));
+    }
+    return *reinterpret_cast<const float4*>(base + off);
+}
 
 template <int MODE, int V>
 __global__ void __launch_bounds__(256) colreduce_partial_kernel(ReduceArgs g, Chunking ch, Final fin) {
@@ -234,7 +245,7 @@ __global__ void __launch_bounds__(256) colreduce_partial_kernel(ReduceArgs g, Ch
                 }
                 if (MODE == MODE_BN_BWD) {
                     if (V == 4) {
-                        float4 yy = *reinterpret_cast<const float4*>(g.b + off);
+                        float4 yy = load4_maybe_bf16(g.b, off, g.b_bf16);
                         ys[u][0] = yy.x; ys[u][1 % V] = yy.y; ys[u][2 % V] = yy.z; ys[u][3 % V] = yy.w;
                     } else {
                         ys[u][0] = g.b[off];
@@ -501,6 +512,7 @@ struct BwdApplyArgs {
     long items;
     int feat, act, post_act, eval_mode;
     float inv_n, eps;
+    int x_bf16;               // x is stored as bf16 (feat % 4 == 0)
 };
 
 template <int V>
@@ -534,7 +546,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BwdApplyArgs g, RowTi
         const long off = (long)row * F + c0;
         if (V == 4) {
             float4 a = *reinterpret_cast<const float4*>(g.grad_y + off);
-            float4 b = *reinterpret_cast<const float4*>(g.x + off);
+            float4 b = load4_maybe_bf16(g.x, off, g.x_bf16);
             dy[u][0] = a.x; dy[u][1 % V] = a.y; dy[u][2 % V] = a.z; dy[u][3 % V] = a.w;
             x[u][0] = b.x; x[u][1 % V] = b.y; x[u][2 % V] = b.z; x[u][3 % V] = b.w;
             if (g.pre) {
@@ -607,7 +619,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_colsum_kernel(BwdApplyArgs g
                 const long off = (long)row * F + c0;
                 if (V == 4) {
                     float4 a = *reinterpret_cast<const float4*>(g.grad_y + off);
-                    float4 b = *reinterpret_cast<const float4*>(g.x + off);
+                    float4 b = load4_maybe_bf16(g.x, off, g.x_bf16);
                     dy[u][0] = a.x; dy[u][1 % V] = a.y; dy[u][2 % V] = a.z; dy[u][3 % V] = a.w;
                     x[u][0] = b.x; x[u][1 % V] = b.y; x[u][2 % V] = b.z; x[u][3 % V] = b.w;
                     if (g.pre) {
@@ -874,6 +886,9 @@ extern "C" int i3d_bn_bias_finalize(const float* bias_partial, int rows, int fea
 // bias_partial != null (and grad_bias != null): the data-gradient pass stores the row-chunk partials of the bias gradient
 // there and does NOT finalise them - the in-launch finalisation is a ~10 us serial tail on the backward chain for a value
 // only the optimizer needs; the caller runs i3d_bn_bias_finalize later (the layer composite: on its side stream).
+// the BatchNorm input x of the next bn_bwd_impl calls of this thread is stored as bf16 (i3d_bn_bwd_x_bf16)
+static thread_local int g_x_bf16 = 0;
+
 static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
                        int post_act, const float* mean, const float* invstd, const float* gamma,
                        const float* beta, float* grad_gamma, float* grad_beta, float* grad_pre,
@@ -905,6 +920,7 @@ static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, in
         ReduceArgs g = {};
         g.a = grad_y; g.b = x; g.mean = mean; g.invstd = invstd; g.gamma = gamma; g.beta = beta;
         g.rows = rows; g.feat = feat; g.act = act; g.post_act = post_act; g.partial = partial;
+        g.b_bf16 = g_x_bf16;
         launch_reduction<MODE_BN_BWD>(g, ch, pair_final_desc(workspace, feat, grad_beta, grad_gamma, sums_out), s);
         I3D_CHECK_LAUNCH();
         if (sums_out != nullptr) return I3D_OK;   // caller all-reduces, then calls again with sums_in
@@ -925,7 +941,7 @@ static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, in
     b.mean = mean; b.invstd = invstd; b.gamma = gamma; b.beta = beta;
     b.sum_dy = sum_dy; b.sum_dy_xhat = sum_dy_xhat; b.grad_pre = grad_pre; b.ld_out = ld_out; b.feat = feat; b.act = act;
     b.post_act = post_act; b.eval_mode = 0; b.inv_n = 1.f / (float)total_rows; b.eps = 0.f;
-    b.zero_out = nullptr;
+    b.zero_out = nullptr; b.x_bf16 = g_x_bf16;
     if (grad_bias != nullptr && act == I3D_ACT_NONE && sums_in == nullptr && exact_zero_bias_grad()) {
         // No activation between the Linear and the BatchNorm: the bias gradient is the column sum of the BatchNorm input
         // gradient  s (dy - mean(dy) - xhat mean(dy xhat))  over the rows the statistics were taken over, which is
@@ -971,6 +987,20 @@ extern "C" int i3d_bn_bwd_deferred_bias(const float* grad_y, const float* x, con
                        grad_bias, sums_out, sums_in, total_rows, workspace, bias_partial, feat, stream);
 }
 
+// i3d_bn_bwd_deferred_bias with the BatchNorm input x stored as bf16 (row r at (bf16*)x + r * feat; feat % 4 == 0; activations
+// none / ReLU / LeakyReLU: act' is taken from x): the bf16 mode's storage form of a PNA layer's messages
+extern "C" int i3d_bn_bwd_x_bf16(const float* grad_y, const void* x, int rows, int feat, int act, int post_act, const float* mean,
+                                 const float* invstd, const float* gamma, const float* beta, float* grad_gamma, float* grad_beta,
+                                 float* grad_pre, float* grad_bias, void* workspace, float* bias_partial, void* stream) {
+    I3D_CHECK_ARG(feat % 4 == 0 && (((uintptr_t)x) & 7) == 0, "bf16 x: feat % 4 == 0, 8-byte aligned");
+    I3D_CHECK_ARG(act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU, "bf16 x: act' must not need the Linear output");
+    g_x_bf16 = 1;
+    const int rc = bn_bwd_impl(grad_y, (const float*)x, nullptr, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta,
+                               grad_pre, grad_bias, nullptr, nullptr, rows, workspace, bias_partial, feat, stream);
+    g_x_bf16 = 0;
+    return rc;
+}
+
 // the same with grad_pre as a column block of a wider matrix (row pitch ld_out floats)
 extern "C" int i3d_bn_bwd_strided(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
                                   int post_act, const float* mean, const float* invstd, const float* gamma, const float* beta,
@@ -1000,6 +1030,7 @@ extern "C" int i3d_bn_eval_bwd(const float* grad_y, const float* x, const float*
     launch_reduction<MODE_BN_BWD>(g, ch, pair_final_desc(workspace, feat, grad_beta, grad_gamma, nullptr), s);
     I3D_CHECK_LAUNCH();
     BwdApplyArgs b;
+    b.x_bf16 = 0;
     b.grad_y = grad_y; b.x = x; b.pre = (act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU) ? nullptr : pre;
     b.mean = running_mean; b.invstd = running_var; b.gamma = gamma; b.beta = beta; b.sum_dy = nullptr;
     b.sum_dy_xhat = nullptr; b.grad_pre = grad_pre; b.ld_out = feat; b.feat = feat; b.act = act; b.post_act = post_act;

@@ -124,9 +124,14 @@ extern "C" int i3d_fc_bn_fwd(const I3dFcArgs* a, void* stream) {
 // waits for) on `stream`, and the weight gradients, which only need the block's grad_pre, on `wst` - the same stream for
 // the stand-alone entry points, the side stream for a PNA layer (which issues the weight gradients of several blocks behind
 // ONE fork: a fork or join costs the host ~7 us, tools/probes/forkjoin_probe.hip).
-static int fc_bn_bwd_chain(const I3dFcArgs* a, void* stream) {
-    TRY(tail_bwd(&a->tail, a->rows, a->f_out, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre,
-                 a->grad_bias, stream));
+static int fc_bn_bwd_chain(const I3dFcArgs* a, void* stream, int xact_bf16 = 0) {
+    if (xact_bf16)      // the block's activation (a PNA layer's messages) is stored as bf16
+        TRY(i3d_bn_bwd_x_bf16(a->grad_y, a->xact, a->rows, a->f_out, a->tail.act, a->tail.post_act, a->tail.mean, a->tail.invstd,
+                              a->tail.gamma, a->tail.beta, a->grad_gamma, a->grad_beta, a->grad_pre, a->grad_bias, a->tail.workspace,
+                              a->tail.bias_partial, stream));
+    else
+        TRY(tail_bwd(&a->tail, a->rows, a->f_out, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre,
+                     a->grad_bias, stream));
     if (a->grad_x != nullptr)
         TRY(i3d_gemm_f32(0, 0, a->rows, a->f_in, a->f_out, a->grad_pre, a->f_out, a->W, a->ldw, a->grad_x, a->f_in, nullptr,
                          0, stream));
@@ -451,16 +456,20 @@ static int pna_layer_fwd_fused(const I3dPnaLayerArgs* a, void* stream) {
         I3D_CHECK_ARG(c->pre_keep == nullptr && simple_act(c->tail.act) && c->tail.post_act == I3D_ACT_NONE &&
                           a->aff[i + 1] != nullptr && c->rows == E && c->f_in == f_in, "fused BatchNorm: unsupported block shape");
         // lin = BN_prev(x) W^T + b with the BatchNorm applied while x is staged; activation + statistics in the epilogue
-        TRY(i3d_gemm_f32_fused(E, c->f_out, f_in, x, f_in, E, c->W, c->ldw, c->xact, c->f_out, c->bias, 0, aff, c->tail.act,
-                               a->stats_ws, nullptr, nullptr, 0, stream));
+        if (a->msg_bf16 && i == a->n_pre_extra - 1)      // the messages: stored as bf16 (K4 and this block's BatchNorm backward read them)
+            TRY(i3d_gemm_f32_fused_bf16out(E, c->f_out, f_in, x, f_in, E, c->W, c->ldw, c->xact, c->f_out, c->bias, aff, c->tail.act,
+                                           a->stats_ws, stream));
+        else
+            TRY(i3d_gemm_f32_fused(E, c->f_out, f_in, x, f_in, E, c->W, c->ldw, c->xact, c->f_out, c->bias, 0, aff, c->tail.act,
+                                   a->stats_ws, nullptr, nullptr, 0, stream));
         TRY(finalize_stats(&c->tail, a->stats_ws, cdiv(E, 64), c->f_out, a->aff[i + 1], stream, a->eval_mode));
         x = c->xact;
         aff = a->aff[i + 1];
         f_in = c->f_out;
     }
     if (a->agg_event_start != nullptr) hipEventRecord((hipEvent_t)a->agg_event_start, (hipStream_t)stream);
-    TRY(i3d_pna_aggregate_fwd_aff(x, aff, e->in_ptr, N, f_in, a->aggregators, a->n_aggregators, a->scalers, a->n_scalers,
-                                  a->force_scalers, a->avg_d_log, const_cast<float*>(a->post.agg), stream));
+    TRY(i3d_pna_aggregate_fwd_ex(x, a->msg_bf16 && a->n_pre_extra > 0, aff, e->in_ptr, N, f_in, a->aggregators, a->n_aggregators, a->scalers,
+                                 a->n_scalers, a->force_scalers, a->avg_d_log, const_cast<float*>(a->post.agg), stream));
     if (a->agg_event_stop != nullptr) hipEventRecord((hipEvent_t)a->agg_event_stop, (hipStream_t)stream);
     // posttrans: lin = h W_h^T + b, += agg W_D^T per in-degree group with the statistics in that launch's epilogue (the
     // degree groups cover every node - in-degree 0 included, with zero coefficients), then apply + residual
@@ -593,10 +602,10 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     // pre[i].x / the aggregation read raw activations, so the weight gradients of pre[i] are corrected with aff[i]
     const float* msg_aff = a->fused_bn ? a->aff[a->n_pre_extra] : nullptr;
     const int f_msg = a->n_pre_extra > 0 ? a->pre[a->n_pre_extra - 1].f_out : a->edge.f_out;
-    TRY(i3d_pna_aggregate_bwd_aff(a->post.grad_agg, a->msg, msg_aff, a->edge.in_ptr, a->edge.num_nodes, f_msg, a->aggregators,
-                                  a->n_aggregators, a->scalers, a->n_scalers, a->force_scalers, a->avg_d_log, a->grad_msg,
-                                  stream));
-    for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_chain(&a->pre[i], stream));
+    const int msg16 = a->fused_bn && a->msg_bf16 && a->n_pre_extra > 0;
+    TRY(i3d_pna_aggregate_bwd_ex(a->post.grad_agg, a->msg, msg16, msg_aff, a->edge.in_ptr, a->edge.num_nodes, f_msg, a->aggregators,
+                                 a->n_aggregators, a->scalers, a->n_scalers, a->force_scalers, a->avg_d_log, a->grad_msg, stream));
+    for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_chain(&a->pre[i], stream, msg16 && i == a->n_pre_extra - 1));
     TRY(edge_fc_bn_bwd_tail(&a->edge, stream));
     if (multi) {
         if (merged) {       // dP[src] | dP[dst] straight into the first 2 Fo columns of DL

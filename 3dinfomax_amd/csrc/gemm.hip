@@ -67,6 +67,8 @@ struct GemmArgs {
     int epi_act;            // activation applied to the stored value (I3D_ACT_*)
     const float* Cin;       // FUSE & 2 with accumulate: the addend is read from Cin (row pitch ldcin) instead of C - the addend may
     int ldcin;              // be a column block of a wider matrix (the merged [P | lin_h] product of a PNA layer); null: C itself
+    int c_bf16;             // FUSE & 2: C is stored as bf16 (row r at (bf16*)C + r * ldc; rounded RNE where it is stored, the
+                            // statistics are taken from the fp32 values): the bf16 mode's storage form of the messages
 };
 
 __device__ __forceinline__ int swz(int k, int idx) { return idx ^ ((((k) ^ (k >> 2)) & 1) << 4); }
@@ -501,7 +503,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) r[q] = apply_act(r[q], g.epi_act);
-                    if (full && g.c_vec) {
+                    if (g.c_bf16) {      // (N % 4 == 0 checked by the host: a group of 4 is whole)
+                        auto rne = [](float x) { const unsigned u = __float_as_uint(x); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
+                        unsigned short* c16 = reinterpret_cast<unsigned short*>(Cout) + (long)row * g.ldc + n;
+                        *reinterpret_cast<uint2*>(c16) = make_uint2(rne(r[0]) | (rne(r[1]) << 16), rne(r[2]) | (rne(r[3]) << 16));
+                    } else if (full && g.c_vec) {
                         *reinterpret_cast<float4*>(c) = make_float4(r[0], r[1], r[2], r[3]);
                     } else {
 #pragma unroll
@@ -947,7 +953,7 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     g.accumulate = accumulate ? 1 : 0;
     g.m_rows = ex.m_rows; g.k_rows = nullptr; g.tile_group = ex.tile_group; g.b_group_stride = ex.b_group_stride;
     g.slab = nullptr;
-    g.a_aff = nullptr; g.stats = nullptr; g.epi_act = I3D_ACT_NONE; g.Cin = nullptr; g.ldcin = 0;
+    g.a_aff = nullptr; g.stats = nullptr; g.epi_act = I3D_ACT_NONE; g.Cin = nullptr; g.ldcin = 0; g.c_bf16 = 0;
     g.b_split = ex.b_split; g.b_delta = ex.b_delta; g.c_split = ex.c_split; g.c_delta = ex.c_delta;
     int rc = fill_views(g, trans_a, trans_b, M, N, K, lda, ldb, ex);
     if (rc != I3D_OK) return rc;
@@ -1112,7 +1118,7 @@ static int rowseg_impl(int M, int N, const float* A, int lda, const float* B, in
     g.accumulate = 1; g.atomic_out = 1; g.k_per_split = 0;
     g.m_rows = nullptr; g.k_rows = ex.k_rows; g.tile_group = nullptr; g.b_group_stride = 0;
     g.slab = nullptr;
-    g.a_aff = nullptr; g.stats = nullptr; g.epi_act = I3D_ACT_NONE; g.Cin = nullptr; g.ldcin = 0;
+    g.a_aff = nullptr; g.stats = nullptr; g.epi_act = I3D_ACT_NONE; g.Cin = nullptr; g.ldcin = 0; g.c_bf16 = 0;
     g.b_split = g.c_split = 0x7fffffff; g.b_delta = g.c_delta = 0;
     int rc = fill_views(g, 1, 0, M, N, k_hi, lda, ldb, ex);
     if (rc != I3D_OK) return rc;
@@ -1296,6 +1302,19 @@ extern "C" int i3d_gemm_f32_fused(int M, int N, int K, const float* A, int lda, 
                                   m_rows, tile_group, b_group_stride, stream);
 }
 
+// i3d_gemm_f32_fused (statistics variant, no accumulate) with C stored as bf16: row r at (bf16*)C + r * ldc
+static thread_local int g_fused_c_bf16 = 0;
+extern "C" int i3d_gemm_f32_fused_bf16out(int M, int N, int K, const float* A, int lda, long a_rows_total, const float* W, int ldb,
+                                          void* C, int ldc, const float* bias, const float* a_aff, int epi_act, float* stats,
+                                          void* stream) {
+    I3D_CHECK_ARG(stats != nullptr && N % 4 == 0 && ldc % 4 == 0 && (((uintptr_t)C) & 15) == 0, "bf16 output: statistics variant, N and ldc multiples of 4");
+    g_fused_c_bf16 = 1;
+    const int rc = i3d_gemm_f32_fused_src(M, N, K, A, lda, a_rows_total, W, ldb, (float*)C, ldc, nullptr, 0, bias, 0, a_aff, epi_act, stats,
+                                          nullptr, nullptr, 0, stream);
+    g_fused_c_bf16 = 0;
+    return rc;
+}
+
 // i3d_gemm_f32_fused with the addend of `accumulate` read from c_in (row pitch ldcin) instead of C
 extern "C" int i3d_gemm_f32_fused_src(int M, int N, int K, const float* A, int lda, long a_rows_total, const float* W, int ldb,
                                       float* C, int ldc, const float* c_in, int ldcin, const float* bias, int accumulate,
@@ -1323,7 +1342,7 @@ extern "C" int i3d_gemm_f32_fused_src(int M, int N, int K, const float* A, int l
     g.m_rows = m_rows; g.k_rows = nullptr; g.tile_group = tile_group; g.b_group_stride = b_group_stride;
     g.b_split = g.c_split = 0x7fffffff; g.b_delta = g.c_delta = 0;
     g.slab = nullptr;
-    g.a_aff = a_aff; g.stats = stats; g.epi_act = epi_act; g.Cin = c_in; g.ldcin = ldcin;
+    g.a_aff = a_aff; g.stats = stats; g.epi_act = epi_act; g.Cin = c_in; g.ldcin = ldcin; g.c_bf16 = g_fused_c_bf16;
     Extra ex;
     ex.m_rows = m_rows; ex.a_rows_total = a_rows_total;
     int rc = fill_views(g, 0, 1, M, N, K, lda, ldb, ex);

@@ -121,6 +121,16 @@ int split_wgrad() {     // 0: no layer, 1: the first layer (last of the backward
     return v;
 }
 
+// bf16 matmul mode: a layer's messages ([E, F], the last pretrans block's activation) stored as bf16 once they are large enough to
+// be bound by their bytes (I3D_MSG_BF16=0: never, =force: at every size; default: E * F * 4 >= 32 MB - the QMugs shape, not the QM9 one)
+bool msg_bf16_storage(const I3dPnaModel& m, long E) {
+    if (i3d_get_matmul_precision() == 0 || m.n_pre < 2) return false;
+    const char* e = getenv("I3D_MSG_BF16");
+    if (e != nullptr && e[0] == '0') return false;
+    if (e != nullptr && e[0] == 'f') return true;
+    return E * (long)m.hidden * 4 >= (32L << 20);
+}
+
 // I3D_MERGE_H=0: the products that read the node features (edge block's P, posttrans block's h-term, and their data gradients)
 // as separate GEMMs (round 2) instead of one per direction
 bool merge_h() {
@@ -425,6 +435,7 @@ extern "C" int i3d_pna_model_fwd(const I3dPnaModel* m, const I3dPnaBatch* b, flo
     for (int l = 0; l < L; ++l) {
         I3dPnaLayerArgs& a = c->layers[l];
         a.eval_mode = eval_mode;
+        a.msg_bf16 = msg_bf16_storage(*m, E) ? 1 : 0;
         a.weights_ready = (hoisted && l >= 1) ? 1 : 0;
         if (hoisted && l == 1) TRY(i3d_wgrad_stream_join(stream));
         set_ws(a.edge.tail, bn_workspace, nullptr, 0);
@@ -684,7 +695,7 @@ extern "C" int i3d_pna_model_debug_messages(void* ctx, int layer, float* out, vo
     I3D_CHECK_ARG(layer >= 0 && layer < c->m.n_layers, "layer out of range");
     const I3dPnaLayerArgs& a = c->layers[layer];
     const int f_msg = a.n_pre_extra > 0 ? a.pre[a.n_pre_extra - 1].f_out : a.edge.f_out;
-    return i3d_pna_messages_normalized(a.msg, a.aff[a.n_pre_extra], a.edge.num_edges, f_msg, out, stream);
+    return i3d_pna_messages_normalized_ex(a.msg, a.fused_bn && a.msg_bf16 && a.n_pre_extra > 0, a.aff[a.n_pre_extra], a.edge.num_edges, f_msg, out, stream);
 }
 
 extern "C" int i3d_pna_model_ctx_free(void* ctx) {

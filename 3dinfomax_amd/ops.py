@@ -622,6 +622,13 @@ def gemm_wgrad_bn(dY, x, grad_bias, aff):
 
 
 def pna_aggregate_fwd_aff(e, aff, in_ptr, num_nodes, aggregators, scalers, avg_d_log, force_scalers=False):
+    if e.dtype == torch.bfloat16:      # messages stored as bf16 (the bf16 mode's storage form): i3d_pna_aggregate_fwd_ex
+        n_s = len(scalers) if (len(scalers) > 1 or force_scalers) else 1
+        out = torch.empty(num_nodes, n_s * len(aggregators) * e.shape[1], dtype=torch.float32, device=e.device)
+        check(_lib.load().i3d_pna_aggregate_fwd_ex(e.data_ptr(), 1, _p(aff), _p(in_ptr), num_nodes, e.shape[1], int_array(aggregators),
+                                                   len(aggregators), int_array(scalers), len(scalers), int(force_scalers),
+                                                   float(avg_d_log), _p(out), _stream()), 'i3d_pna_aggregate_fwd_ex')
+        return out
     _chk(e)
     n_s = len(scalers) if (len(scalers) > 1 or force_scalers) else 1
     out = torch.empty(num_nodes, n_s * len(aggregators) * e.shape[1], dtype=torch.float32, device=e.device)
@@ -632,6 +639,13 @@ def pna_aggregate_fwd_aff(e, aff, in_ptr, num_nodes, aggregators, scalers, avg_d
 
 
 def pna_aggregate_bwd_aff(grad_out, e, aff, in_ptr, num_nodes, aggregators, scalers, avg_d_log, force_scalers=False):
+    if e.dtype == torch.bfloat16:
+        _chk(grad_out)
+        ge = torch.zeros(e.shape, dtype=torch.float32, device=e.device)
+        check(_lib.load().i3d_pna_aggregate_bwd_ex(_p(grad_out), e.data_ptr(), 1, _p(aff), _p(in_ptr), num_nodes, e.shape[1],
+                                                   int_array(aggregators), len(aggregators), int_array(scalers), len(scalers),
+                                                   int(force_scalers), float(avg_d_log), _p(ge), _stream()), 'i3d_pna_aggregate_bwd_ex')
+        return ge
     _chk(grad_out), _chk(e)
     ge = torch.zeros_like(e)
     check(_lib.load().i3d_pna_aggregate_bwd_aff(_p(grad_out), _p(e), _p(aff), _p(in_ptr), num_nodes, e.shape[1],

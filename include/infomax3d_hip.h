@@ -330,6 +330,10 @@ int i3d_gemm_f32_fused_src(int M, int N, int K, const float* A, int lda, long a_
                            int ldc, const float* c_in, int ldcin, const float* bias, int accumulate, const float* a_aff,
                            int epi_act, float* stats, const int* m_rows, const int* tile_group, long b_group_stride,
                            void* stream);
+/* i3d_gemm_f32_fused (statistics variant) with the output stored as bf16 - row r at (bf16*)C + r * ldc, rounded where it is
+ * stored, statistics from the fp32 values (the bf16 matmul mode's storage form of a PNA layer's messages) */
+int i3d_gemm_f32_fused_bf16out(int M, int N, int K, const float* A, int lda, long a_rows_total, const float* W, int ldb, void* C, int ldc,
+                               const float* bias, const float* a_aff, int epi_act, float* stats, void* stream);
 /* Wcat [2 f_out_edge + f_out_post, f_h] = [W_s ; W_d ; W_h], bcat = [0 | 0 | bias_post] (I3dPnaLayerArgs.merge_h) */
 int i3d_pna_pack_h_weights(const float* W_edge, int ldw_edge, int f_out_edge, const float* W_post, int ldw_post, int f_out_post,
                            const float* bias_post, int f_h, float* Wcat, float* bcat, void* stream);
@@ -339,6 +343,10 @@ int i3d_bn_bwd_strided(const float* grad_y, const float* x, const float* pre, in
                        const float* mean, const float* invstd, const float* gamma, const float* beta, float* grad_gamma,
                        float* grad_beta, float* grad_pre, int ld_out, float* grad_bias, void* workspace, float* bias_partial,
                        void* stream);
+/* i3d_bn_bwd with the BatchNorm input x stored as bf16 (row r at (bf16*)x + r * feat) */
+int i3d_bn_bwd_x_bf16(const float* grad_y, const void* x, int rows, int feat, int act, int post_act, const float* mean,
+                      const float* invstd, const float* gamma, const float* beta, float* grad_gamma, float* grad_beta, float* grad_pre,
+                      float* grad_bias, void* workspace, float* bias_partial, void* stream);
 /* dW[f_out,f_in] = dY^T y for y = (x - mean) * scale + shift (aff over f_in) computed from the raw x; grad_bias[f_out] =
  * column sums of dY (already computed) */
 int i3d_gemm_f32_wgrad_bn(int f_out, int f_in, int rows, const float* dY, int ldy, const float* x, int ldx, float* dW,
@@ -418,6 +426,15 @@ int i3d_pna_aggregate_fwd_aff(const float* e, const float* aff, const int* in_pt
 int i3d_pna_aggregate_bwd_aff(const float* grad_out, const float* e, const float* aff, const int* in_ptr, int num_nodes,
                               int feat, const int* aggregators, int n_aggregators, const int* scalers, int n_scalers,
                               int force_scalers, float avg_d_log, float* grad_e, void* stream);
+/* the same two with the messages stored as bf16 (e_bf16 != 0: row r of the [E, feat] message matrix at (bf16*)e + r * feat, feat a
+ * multiple of 4, 8-byte aligned; the bf16 matmul mode's storage form of the last pretrans block's activation): K4 reads half the
+ * message bytes; outputs and gradients stay fp32 */
+int i3d_pna_aggregate_fwd_ex(const void* e, int e_bf16, const float* aff, const int* in_ptr, int num_nodes, int feat,
+                             const int* aggregators, int n_aggregators, const int* scalers, int n_scalers, int force_scalers,
+                             float avg_d_log, float* out, void* stream);
+int i3d_pna_aggregate_bwd_ex(const float* grad_out, const void* e, int e_bf16, const float* aff, const int* in_ptr, int num_nodes,
+                             int feat, const int* aggregators, int n_aggregators, const int* scalers, int n_scalers,
+                             int force_scalers, float avg_d_log, float* grad_e, void* stream);
 
 /* i3d_bn_bwd with the finalisation of grad_bias deferred (bias_partial != NULL): see I3dBnTail.bias_partial */
 long i3d_bn_bias_partial_floats(int feat);
@@ -582,6 +599,9 @@ typedef struct { /* one PNA layer, reference models/pna.py:199-216: pretrans edg
     int eval_mode;     /* forward (fused_bn) in eval(): BatchNorm with the running statistics (reference: nn.BatchNorm1d in eval
                         * mode, trainer/trainer.py:75 model.eval()) - aff[i] already hold mean | gamma / sqrt(var + eps) | beta
                         * (i3d_bn_eval_aff_multi), no statistics are finalised, no running statistic is touched */
+    int msg_bf16;      /* fused_bn with at least one later pretrans block, bf16 matmul mode: `msg` (= the last pretrans block's xact,
+                        * [E, f_msg]) holds bf16 - written by that block's GEMM epilogue, read by the aggregation kernels and by the
+                        * block's BatchNorm backward; the buffer keeps its fp32 size.  Same value forward and backward. */
 } I3dPnaLayerArgs;
 
 /* eval-mode affine vector of one BatchNorm: aff [3 feat] = running_mean | gamma / sqrt(running_var + eps) | beta */
@@ -764,6 +784,7 @@ int i3d_pna_model_ctx_free(void* ctx);
  * (aff = mean | scale | shift, NULL: a copy); the messages of one layer of a forward pass from its context, [E, f_msg] in
  * destination-sorted order - the tests derive the kernels' arg-max / arg-min routing from them */
 int i3d_pna_messages_normalized(const float* e, const float* aff, long rows, int feat, float* out, void* stream);
+int i3d_pna_messages_normalized_ex(const void* e, int e_bf16, const float* aff, long rows, int feat, float* out, void* stream);
 int i3d_pna_model_debug_messages(void* ctx, int layer, float* out, void* stream);
 
 /* ---- Adam step of all parameter tensors in one launch (csrc/adam.hip; reference: torch.optim.Adam built by name,

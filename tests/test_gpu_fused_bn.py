@@ -157,3 +157,29 @@ def test_aggregation_with_batchnorm_applied_on_load(F, scalers):
     ge = ops.pna_aggregate_bwd_aff(gout, g(e), g(aff), ptr_d, n, aggs, sc, 1.0)
     ge_ref = ops.pna_aggregate_bwd_aff(gout, g(m), None, ptr_d, n, aggs, sc, 1.0)
     assert torch.equal(ge, ge_ref)                      # gradient w.r.t. the normalised message, as documented
+
+
+@pytest.mark.parametrize('scalers', [['identity'], ['identity', 'amplification', 'attenuation']])
+def test_aggregation_reads_messages_stored_as_bf16(scalers):
+    """the bf16 matmul mode's storage form of the messages (i3d_pna_aggregate_fwd_ex / _bwd_ex, e_bf16 = 1): the same bits as the
+    fp32 kernels on the same (bf16-representable) values, with and without the BatchNorm applied on load"""
+    n, F = 700, 200
+    rng = np.random.default_rng(5)
+    deg = rng.integers(0, 7, size=n)
+    ptr = np.zeros(n + 1, dtype=np.int32)
+    ptr[1:] = np.cumsum(deg)
+    E = int(ptr[-1])
+    e16 = (rnd(E, F, seed=2) * 3 + 1).bfloat16()
+    aff = torch.stack([rnd(F, seed=4) + 1.0, 1 + 0.3 * rnd(F, seed=5), 0.3 * rnd(F, seed=6)])
+    aggs = ops.agg_codes(['mean', 'max', 'min', 'std'])
+    sc = ops.scaler_codes(scalers)
+    ptr_d = g(torch.from_numpy(ptr))
+    for a in (None, g(aff)):
+        out = ops.pna_aggregate_fwd_aff(e16.cuda(), a, ptr_d, n, aggs, sc, 1.0)
+        ref = ops.pna_aggregate_fwd_aff(g(e16.float()), a, ptr_d, n, aggs, sc, 1.0)
+        assert torch.equal(out, ref)
+        gout = g(rnd(*out.shape, seed=9))
+        ge = ops.pna_aggregate_bwd_aff(gout, e16.cuda(), a, ptr_d, n, aggs, sc, 1.0)
+        ge_ref = ops.pna_aggregate_bwd_aff(gout, g(e16.float()), a, ptr_d, n, aggs, sc, 1.0)
+        assert torch.equal(ge, ge_ref)
+

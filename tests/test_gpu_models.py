@@ -335,6 +335,7 @@ def test_qmugs_conformers_bf16_matmul_vs_oracle(amd, variant, n_mols, hidden, de
     ops = importlib.import_module('3dinfomax_amd.ops')
     # the bf16 STORAGE form of the 3D network's edge stage at these (small) sizes too: it switches on by size
     monkeypatch.setattr(importlib.import_module('3dinfomax_amd.net3d_native'), 'BF16_STORE_MIN_EDGES', 0)
+    monkeypatch.setenv('I3D_MSG_BF16', 'force')      # and of the 2D network's messages (csrc/model.hip: msg_bf16_storage)
     prev = ops.set_matmul_precision('bf16')
     try:
         _qmugs_vs_oracle(amd, variant, n_mols, 'bf16', hidden=hidden, depth=depth)
