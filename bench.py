@@ -39,6 +39,18 @@ NET3D_KW = dict(target_dim=256, hidden_dim=20, hidden_edge_dim=20, node_wise_out
                 readout_layers=1, readout_aggregators=['min', 'max', 'mean'])
 
 
+def latest_pmc_summary():
+    """profiles/rNN_step_k4_pmc.json of the latest round that has one (tools/pmc_summary.py output of the PMC passes over this command)."""
+    import glob
+    import re
+    found = []
+    for p in glob.glob(os.path.join(ROOT, 'profiles', 'r*_step_k4_pmc.json')):
+        m = re.match(r'r(\d+)_step_k4_pmc\.json$', os.path.basename(p))
+        if m:
+            found.append((int(m.group(1)), p))
+    return max(found)[1] if found else None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -512,22 +524,24 @@ def main():
         # HBM traffic per launch from this round's PMC passes over THIS command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE around
         # bench.py, FETCH_SIZE x2 gfx950 correction, tools/pmc_summary.py -> profiles/r03_step_k4_pmc.json): the kernel variant
         # the step launches (messages normalised on load), the same synthetic batches (same seeds -> same N, E)
-        traffic = traffic_bwd = None
-        pmc = os.path.join(ROOT, 'profiles', 'r03_step_k4_pmc.json')
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                pj = json.load(f)
-            want = f'pna_aggregate_fwd_kernel<{2 if blocks == 4 else 1}>'
-            rows = [r for k, v in pj.items() if k.startswith(want) for r in v]
-            if rows:
-                traffic = int(1e6 * sum(r['traffic_MB'] * r['dispatches'] for r in rows) / sum(r['dispatches'] for r in rows))
-            rows = [r for k, v in pj.items() if k.startswith('pna_aggregate_bwd_kernel<4,2>') or k.startswith('pna_aggregate_bwd_kernel<4, 2>')
-                    for r in v]
-            if rows:
-                traffic_bwd = int(1e6 * sum(r['traffic_MB'] * r['dispatches'] for r in rows) / sum(r['dispatches'] for r in rows))
+        traffic = traffic_bwd = traffic_error = None
+        pmc = latest_pmc_summary()
+        if pmc is not None:
+            lk = importlib.import_module('tools.pmc_lookup')
+            pj = lk.load(pmc)
+            # only rows launched on THIS workload's batches: a K4 launch has one lane per (node, 4 features)
+            grids = {lk.k4_grid(int(N), int(Fk)) for _, _, N, _, Fk, _ in ev}
+            try:
+                traffic = lk.traffic_bytes(pj, 'pna_aggregate_fwd_kernel', (2 if blocks == 4 else 1,), grids)
+                traffic_bwd = lk.traffic_bytes(pj, 'pna_aggregate_bwd_kernel', (4, 2 if blocks == 4 else 1), grids)
+            except lk.PmcLookupError as exc:
+                traffic_error = f'{os.path.relpath(pmc, ROOT)}: {exc}'
+                print('bench.py: roofline.traffic lookup failed - ' + traffic_error, file=sys.stderr)
         roof = dict(bound='hbm', kernel=f'pna_aggregate_fwd_kernel ({blocks} output blocks [N,{blocks}F], as launched by the step)',
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                     unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_backward_kernel=traffic_bwd,
+                    **({'traffic_error': traffic_error} if traffic_error else {}),
+                    traffic_source=os.path.relpath(pmc, ROOT) if pmc else None,
                     launches=len(ev), avg_us=round(float(ms.mean() * 1e3), 2),
                     algorithmic_bytes_per_launch=int(byts.mean()),
                     # the contract figure is the reference-defined op ([N,12F] written); the fused form the
@@ -546,7 +560,7 @@ def main():
                          'event_pair_null_kernel_us (dispatch + completion signalling: the part of avg_us that is not the '
                          'kernel; rocprofv3 kernel time in profiles/); *_back_to_back: '
                          '20 launches per event pair after the timed region; reference_shaped_12F: the [N,12F] kernel of '
-                         'SURVEY.md 8(d) (I3D_GROUPED_POSTTRANS=0 path); traffic: rocprofv3 PMC bytes per launch of the step\'s own kernels (profiles/r03_step_k4_pmc.txt), traffic_backward_kernel: the same for pna_aggregate_bwd_kernel<4,2>')
+                         'SURVEY.md 8(d) (I3D_GROUPED_POSTTRANS=0 path); traffic: rocprofv3 PMC bytes per launch of the step\'s own kernels (traffic_source; rows matched by kernel base name + leading template arguments and by this workload\'s launch grids, tools/pmc_lookup.py), traffic_backward_kernel: the same for pna_aggregate_bwd_kernel<4,2,...>')
 
     # per-collective times of the data-parallel step (20 back-to-back calls per event pair, after the timed region)
     collectives = None
