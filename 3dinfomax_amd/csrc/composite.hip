@@ -320,9 +320,15 @@ static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_r
     const int ld_dlin = merged ? WL : g->f_out;
     const float* dP = merged ? a->DL : e->grad_P;                    // [N, 2 Fo]
     const int ld_dP = merged ? WL : 2 * Fo;
-    I3dWgradProblem pr[40];
-    I3dWgradOutput out[8];
-    float coef[128];
+    constexpr int MAX_PROBLEMS = 40, MAX_OUTPUTS = 8, MAX_GROUPS = 32, MAX_SCALERS = 4;     // the tables of wgrad.hip
+    I3dWgradProblem pr[MAX_PROBLEMS];
+    I3dWgradOutput out[MAX_OUTPUTS];
+    float coef[MAX_GROUPS * MAX_SCALERS];
+    // everything that is not a per-degree group: dW_h, the later pretrans blocks, [W_s | W_d], dQ; the group loop below
+    // stops short of what they need, so neither table can be overrun whatever degree distribution the caller hands in
+    const int fixed_problems = 3 + (a->n_pre_extra > 0 ? a->n_pre_extra : 0);
+    if (g->n_scalers > MAX_SCALERS || g->n_scalers < 0 || fixed_problems >= MAX_PROBLEMS || 4 + a->n_pre_extra > MAX_OUTPUTS) return 0;
+    const int max_group_problems = MAX_PROBLEMS - fixed_problems < MAX_GROUPS ? MAX_PROBLEMS - fixed_problems : MAX_GROUPS;
     std::memset(pr, 0, sizeof(pr));
     std::memset(out, 0, sizeof(out));
     int np = 0, no = 0;
@@ -350,10 +356,8 @@ static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_r
         for (int k = 0; k < g->n_groups; ++k) {
             bool any = false;
             for (int s = 0; s < g->n_scalers; ++s) any = any || g->coef[k * g->n_scalers + s] != 0.f;
-            if (!any || g->group_count[k] == 0 || np >= 36) {
-                if (any && g->group_count[k] != 0) return 0;       // more groups than the problem table holds
-                continue;
-            }
+            if (!any || g->group_count[k] == 0) continue;
+            if (ng >= max_group_problems) return 0;                // more groups than the tables hold: per-block launches
             for (int s = 0; s < g->n_scalers; ++s) coef[ng * g->n_scalers + s] = g->coef[k * g->n_scalers + s];
             problem(dlin, ld_dlin, g->f_out, g->agg, A, A, N, g->deg_rows, g->group_start[k], g->group_count[k]);
             ++ng;

@@ -13,7 +13,6 @@
 // (models/pna.py:131-135, 161-166, 199-213, 127-129) and its autograd backward.
 #include "common.h"
 
-#include <functional>
 
 #include <algorithm>
 #include <cmath>
@@ -515,7 +514,30 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
     float* const head_buf = top.take(head_floats(m, B));
     float* const head_colsum_ws = top.take(head_colsum_floats(m, B));
     float* const rest = scratch + top.used;
-    std::function<int(void*)> head_leaves;
+    // the head's weight / bias gradients (leaves); only invoked inside this call: a plain lambda over the locals (a
+    // std::function with by-value captures copied the whole model description and heap-allocated per backward call)
+    const float* gpre_of[I3D_MAX_HEAD_FC] = {};
+    auto head_leaves = [&](void* wst) -> int {
+        for (int i = m.n_head - 1; i >= 0; --i) {
+            I3dFcArgs& fc = c->head_args[i];
+            const I3dFcParams& p = m.head[i];
+            if (p.gamma != nullptr) {
+                TRY(i3d_fc_bn_bwd_wgrad(&fc, wst));
+            } else {
+                TRY(wgrad(p.f_out, p.f_in, B, gpre_of[i], p.f_out, fc.x, p.f_in, p.grad_W, p.f_in, gemm_workspace, side_ws_bytes, wst));
+                void* cws = bn_workspace;
+                if (wst != stream) {      // a reduction scratch of the side stream's own; its arrival counters (the first bytes) start at 0
+                    cws = head_colsum_ws;
+                    if (hipMemsetAsync(cws, 0, 256, (hipStream_t)wst) != hipSuccess) {
+                        i3d::set_error("i3d_pna_model_bwd: clearing the head's reduction scratch failed");
+                        return I3D_ERR_LAUNCH;
+                    }
+                }
+                TRY(i3d_colsum(gpre_of[i], nullptr, B, p.f_out, p.grad_bias, cws, wst));
+            }
+        }
+        return I3D_OK;
+    };
     bool leaves_pending = false;
     // ---- head, last block first: the chain (BatchNorm backward, data gradients) on the caller's stream, then ONE fork and the
     // head's weight and bias gradients - leaves - on the weight-gradient stream, next to the readout's and the last layer's
@@ -524,7 +546,6 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
     if (part != 2) {
         Bump ar(head_buf);
         const float* gy = grad_out;
-        const float* gpre_of[I3D_MAX_HEAD_FC] = {};
         for (int i = m.n_head - 1; i >= 0; --i) {
             I3dFcArgs& fc = c->head_args[i];
             const I3dFcParams& p = m.head[i];
@@ -547,27 +568,6 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
             gy = gx;
         }
         static const bool leaves_aside = [] { const char* e = getenv("I3D_HEAD_LEAVES"); return e == nullptr || e[0] != '0'; }();
-        head_leaves = [=](void* wst) -> int {
-            for (int i = m.n_head - 1; i >= 0; --i) {
-                I3dFcArgs& fc = c->head_args[i];
-                const I3dFcParams& p = m.head[i];
-                if (p.gamma != nullptr) {
-                    TRY(i3d_fc_bn_bwd_wgrad(&fc, wst));
-                } else {
-                    TRY(wgrad(p.f_out, p.f_in, B, gpre_of[i], p.f_out, fc.x, p.f_in, p.grad_W, p.f_in, gemm_workspace, side_ws_bytes, wst));
-                    void* cws = bn_workspace;
-                    if (wst != stream) {      // a reduction scratch of the side stream's own; its arrival counters (the first bytes) start at 0
-                        cws = head_colsum_ws;
-                        if (hipMemsetAsync(cws, 0, 256, (hipStream_t)wst) != hipSuccess) {
-                            i3d::set_error("i3d_pna_model_bwd: clearing the head's reduction scratch failed");
-                            return I3D_ERR_LAUNCH;
-                        }
-                    }
-                    TRY(i3d_colsum(gpre_of[i], nullptr, B, p.f_out, p.grad_bias, cws, wst));
-                }
-            }
-            return I3D_OK;
-        };
         // the leaves go to the weight-gradient stream behind the fork the LAST layer's backward makes anyway (a fork of their own
         // was one more event on the chain's stream: ~7 us); without a side stream for them: here, in line
         leaves_pending = !per_layer_join && leaves_aside && l_hi == L && l_hi > l_lo;

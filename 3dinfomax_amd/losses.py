@@ -143,7 +143,9 @@ class _NTXentBase(_Loss):
         self.uniformity_reg, self.variance_reg, self.covariance_reg = uniformity_reg, variance_reg, covariance_reg
         self.group = None
         self.shard_counts = None
-        self._equal_checked = {}       # local row count -> True once every rank has been seen to hold the same
+        self._equal_checked = {}       # local row count -> True once this rank has READ a check of that count (see _check_equal_shards)
+        self._pending = None           # (result of the last equal-shard all-reduce, event of its pinned copy, local rows)
+        self._pinned = None
 
     def attach_group(self, group):
         """Enable the data-parallel form (all-gathered negatives) on a torch.distributed process group."""
@@ -154,6 +156,46 @@ class _NTXentBase(_Loss):
         """molecules per rank of the current global batch when they differ (dist.shard_counts / shard_plan); None: equal"""
         self.shard_counts = list(counts) if counts is not None else None
         return self
+
+    def _check_equal_shards(self, z1, dist):
+        """Equal shards are ASSUMED when no counts were given (all_gather_into_tensor / reduce_scatter_tensor with different row
+        counts per rank hang or corrupt silently) - e.g. the last partial batch of an epoch sharded with the remainder kept.
+        EVERY call issues the same 2-element MAX all-reduce on every rank (whether a collective runs must never depend on
+        rank-local state: a rank that has seen this row count before and one that has not would otherwise issue different
+        collectives).  What IS rank-local is only when the result is read: at once for a row count this rank has not verified
+        yet and on host-side backends (gloo: the result is already there), otherwise - the steady state, no host
+        synchronisation in the step - through a pinned copy examined at the start of the next call.  A rank whose count is new
+        raises before its gather; a rank whose count it knew raises one call later."""
+        self._raise_if_unequal(block=True)          # the previous call's result: long finished, costs no wait
+        rows = z1.shape[0]
+        host_side = dist.get_backend(self.group) == 'gloo'
+        n = torch.tensor([rows, -rows], dtype=torch.float64, device='cpu' if host_side else z1.device)
+        dist.all_reduce(n, op=dist.ReduceOp.MAX, group=self.group)
+        if host_side:
+            self._pending = (n, None, rows)
+        else:
+            if self._pinned is None:
+                self._pinned = torch.empty(2, dtype=torch.float64).pin_memory()
+            self._pinned.copy_(n, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending = (self._pinned, ev, rows)
+        if host_side or rows not in self._equal_checked:
+            self._raise_if_unequal(block=True)
+            self._equal_checked[rows] = True
+
+    def _raise_if_unequal(self, block):
+        if self._pending is None:
+            return
+        n, ev, rows = self._pending
+        if ev is not None:
+            if not block and not ev.query():
+                return
+            ev.synchronize()
+        self._pending = None
+        if float(n[0]) != -float(n[1]):
+            raise ValueError(f'ranks hold different numbers of molecules ({rows} here, {int(-float(n[1]))}..'
+                             f'{int(float(n[0]))} over the group): pass them with loss.set_shard_counts(dist.shard_counts(...))')
 
     def _contrastive(self, z1, z2, conf):
         pos_offset, global_batch = 0, z1.shape[0]
@@ -168,17 +210,8 @@ class _NTXentBase(_Loss):
                     z2 = _AllGatherRowsFn.apply(z2, self.group, [c * conf for c in counts])
                     pos_offset, global_batch = sum(counts[:rank]), sum(counts)
                 else:
-                    if counts is None and z1.shape[0] not in self._equal_checked:
-                        # equal shards are ASSUMED when no counts were given (all_gather_into_tensor / reduce_scatter_tensor
-                        # with different row counts per rank hang or corrupt silently): checked once per local batch size -
-                        # e.g. the last partial batch of an epoch sharded with the remainder kept
-                        n = torch.tensor([z1.shape[0], -z1.shape[0]], dtype=torch.float64,
-                                         device='cpu' if dist.get_backend(self.group) == 'gloo' else z1.device)
-                        dist.all_reduce(n, op=dist.ReduceOp.MAX, group=self.group)
-                        if float(n[0]) != -float(n[1]):
-                            raise ValueError(f'ranks hold different numbers of molecules ({z1.shape[0]} here, {int(-n[1])}..'
-                                             f'{int(n[0])} over the group): pass them with loss.set_shard_counts(dist.shard_counts(...))')
-                        self._equal_checked[z1.shape[0]] = True
+                    if counts is None:
+                        self._check_equal_shards(z1, dist)
                     z2 = _AllGatherRowsFn.apply(z2, self.group)
                     pos_offset, global_batch = rank * z1.shape[0], world * z1.shape[0]
         return NTXentFn.apply(z1, z2, float(self.tau), float(self._eps), conf, pos_offset, global_batch, bool(self.norm))

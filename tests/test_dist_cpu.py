@@ -189,3 +189,41 @@ def test_early_all_reduce_with_gradient_accumulation():
     out = mgr.dict()
     mp.spawn(_accum_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def _equal_check_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    losses = importlib.import_module('3dinfomax_amd.losses')
+    loss = losses.NTXent(tau=0.1).attach_group(dist.group.WORLD)
+    issued = []
+    real = dist.all_reduce
+
+    def counting(t, *a, **k):
+        issued.append(tuple(t.shape))
+        return real(t, *a, **k)
+    dist.all_reduce = counting
+    ok = True
+    for _ in range(3):                      # the steady state: every call issues the collective on every rank
+        loss._check_equal_shards(torch.zeros(6, 4), dist)
+    ok = ok and len(issued) == 3 and 6 in loss._equal_checked
+    # the last partial batch: rank 0 still holds a row count it has verified, rank 1 a new one - BOTH must issue the same
+    # collective (no hang, no mismatched collectives) and both must get the ValueError
+    try:
+        loss._check_equal_shards(torch.zeros(6 if rank == 0 else 5, 4), dist)
+        ok = False
+    except ValueError as exc:
+        ok = ok and 'different numbers of molecules' in str(exc)
+    ok = ok and len(issued) == 4
+    dist.all_reduce = real
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_equal_shard_check_issues_the_same_collective_on_every_rank():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_equal_check_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
+    assert dict(out) == {0: True, 1: True}
