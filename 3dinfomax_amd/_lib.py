@@ -130,6 +130,15 @@ _SIGNATURES = {
     'i3d_rccl_init': (c_int, [ctypes.c_char_p, c_int, c_int, POINTER(c_void_p)]),
     'i3d_rccl_destroy': (c_int, [_P]),
     'i3d_set_collectives_rccl': (c_int, [_P, c_int, _P, c_long]),
+    'i3d_peer_mailbox_bytes': (c_long, []),
+    'i3d_peer_handle_bytes': (c_int, []),
+    'i3d_peer_alloc': (c_int, [POINTER(c_void_p), ctypes.c_char_p]),
+    'i3d_peer_open': (c_int, [_P, ctypes.c_char_p, c_int, c_int, c_double, POINTER(c_void_p)]),
+    'i3d_set_collectives_peer': (c_int, [_P, _P, c_long]),
+    'i3d_peer_bind_stream': (c_int, [_P, _P, _P, c_long]),
+    'i3d_peer_status': (c_int, [_P]),
+    'i3d_peer_sequence': (ctypes.c_longlong, [_P]),
+    'i3d_peer_close': (c_int, [_P]),
     'i3d_gemm_f32_fused_src': (c_int, [c_int, c_int, c_int, _P, c_int, c_long, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int,
                                        _P, _P, _P, c_long, _P]),
     'i3d_pna_pack_h_weights': (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, _P, _P, _P]),

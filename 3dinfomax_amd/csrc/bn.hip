@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "peer.h"
 
 namespace i3d {
 
@@ -788,12 +789,14 @@ extern "C" int i3d_act_stats_fwd_counted(const float* pre, int rows, int feat, i
     if (const I3dCollectives* coll = sums_out == nullptr ? collectives() : nullptr) {
         // synchronised BatchNorm (comm.hip): un-shifted fp64 [sum, sum of squares, count] of this rank -> all-reduce on this
         // stream -> mean / invstd / running statistics over all ranks
-        I3D_CHECK_ARG(coll->scratch_bytes >= (long)(2 * feat + 1) * 8, "collective scratch too small");
-        double* s64 = (double*)coll->scratch;
+        PeerCtx* pc = peer_active(stream);      // (a context and a scratch per stream that issues collectives)
+        I3D_CHECK_ARG((pc ? peer_scratch_bytes(pc) : coll->scratch_bytes) >= (long)(2 * feat + 1) * 8, "collective scratch too small");
+        double* s64 = (double*)(pc ? peer_scratch(pc) : coll->scratch);
         int rc = i3d_act_stats_fwd_counted(pre, rows, feat, act, x, eps, momentum, mean, invstd, nullptr, nullptr, s64, nullptr,
                                            workspace, stream);
         if (rc != I3D_OK) return rc;
-        rc = coll->all_reduce_f64(coll->user, s64, 2 * feat + 1, stream);
+        if (pc != nullptr) rc = peer_sum_f64(pc, s64, 2 * feat + 1, 0, 0.0, s64, nullptr, nullptr, stream);
+        else rc = coll->all_reduce_f64(coll->user, s64, 2 * feat + 1, stream);
         if (rc != I3D_OK) return rc;
         hipLaunchKernelGGL(stats_from_sums_kernel, dim3(cdiv(feat, 128)), dim3(128), 0, s, s64, feat, eps, momentum, mean, invstd,
                            running_mean, running_var, num_batches_tracked);
@@ -888,6 +891,8 @@ extern "C" int i3d_bn_bias_finalize(const float* bias_partial, int rows, int fea
 // only the optimizer needs; the caller runs i3d_bn_bias_finalize later (the layer composite: on its side stream).
 // the BatchNorm input x of the next bn_bwd_impl calls of this thread is stored as bf16 (i3d_bn_bwd_x_bf16)
 static thread_local int g_x_bf16 = 0;
+// phase 2 of the synchronised backward finds its fp32 sum vectors + 1 / rows already in the workspace (peer exchange)
+static thread_local int g_sums_ready = 0;
 
 static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
                        int post_act, const float* mean, const float* invstd, const float* gamma,
@@ -902,11 +907,24 @@ static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, in
         // synchronised BatchNorm (comm.hip): this rank's fp64 [sum dy, sum dy xhat] and row count -> all-reduce on this
         // stream -> the data gradient from the sums over all ranks; grad_gamma / grad_beta keep this rank's share (the
         // gradient all-reduce adds the ranks up)
-        I3D_CHECK_ARG(coll->scratch_bytes >= (long)(2 * feat + 1) * 8, "collective scratch too small");
-        double* s64 = (double*)coll->scratch;
+        PeerCtx* pc = peer_active(stream);
+        I3D_CHECK_ARG((pc ? peer_scratch_bytes(pc) : coll->scratch_bytes) >= (long)(2 * feat + 1) * 8, "collective scratch too small");
+        double* s64 = (double*)(pc ? peer_scratch(pc) : coll->scratch);
         int rc = bn_bwd_impl(grad_y, x, pre, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta,
                              nullptr, nullptr, s64, nullptr, rows, workspace, nullptr, ld_out, stream);
         if (rc != I3D_OK) return rc;
+        if (pc != nullptr) {
+            // peer-write exchange (peer.h): row count appended, sums over the ranks, conversion to the fp32 vectors + 1 / rows
+            // the data-gradient pass reads - ONE launch instead of set_double -> all-reduce -> sums_to_float
+            float* tmp = partial_of(workspace) + (long)MAX_PARTIAL_BLOCKS * 2 * feat;
+            rc = peer_sum_f64(pc, s64, 2 * feat, 1, (double)rows, nullptr, tmp, tmp + 2 * feat, stream);
+            if (rc != I3D_OK) return rc;
+            g_sums_ready = 1;
+            rc = bn_bwd_impl(grad_y, x, pre, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta,
+                             grad_pre, grad_bias, nullptr, s64, 0, workspace, bias_partial, ld_out, stream);
+            g_sums_ready = 0;
+            return rc;
+        }
         hipLaunchKernelGGL(set_double_kernel, dim3(1), dim3(1), 0, s, s64 + 2 * feat, (double)rows);
         I3D_CHECK_LAUNCH();
         rc = coll->all_reduce_f64(coll->user, s64, 2 * feat + 1, stream);
@@ -930,8 +948,10 @@ static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, in
     const float* sum_dy_xhat = grad_gamma;
     if (sums_in != nullptr) {   // phase 2 of synchronised BN: global sums drive the data gradient
         float* tmp = partial + (long)MAX_PARTIAL_BLOCKS * 2 * feat;
-        hipLaunchKernelGGL(sums_to_float_kernel, dim3(cdiv(feat, 128)), dim3(128), 0, s, sums_in, feat, tmp, tmp + feat);
-        I3D_CHECK_LAUNCH();
+        if (!g_sums_ready) {       // (the peer exchange has written them already)
+            hipLaunchKernelGGL(sums_to_float_kernel, dim3(cdiv(feat, 128)), dim3(128), 0, s, sums_in, feat, tmp, tmp + feat);
+            I3D_CHECK_LAUNCH();
+        }
         sum_dy = tmp;
         sum_dy_xhat = tmp + feat;
     }

@@ -11,7 +11,8 @@
 // trip, no event) and finalise over the ranks.  Every sequencer above them - block composites, PNA layer, whole model,
 // the 3D network - becomes synchronised without knowing it.
 //
-// Two providers:
+// Three providers (the third, peer.h / peer.hip, is the one meant for production: a one-shot peer-write exchange over IPC-
+// mapped mailboxes, inside the BatchNorm kernels themselves where it can be):
 //   * RCCL, bound at run time (dlopen: the library has no link-time dependency on it) through a communicator of the
 //     library's own, created from an id the caller distributes (i3d_rccl_unique_id on rank 0 -> every rank
 //     i3d_rccl_init): ncclAllGather / ncclAllReduce enqueued on the caller's stream;
@@ -19,6 +20,7 @@
 // One training per process, one stream issuing collectives (the 3D network's side stream is switched off by dist.setup
 // when this is on): RCCL needs every rank to issue the collectives of a communicator in the same order.
 #include "common.h"
+#include "peer.h"
 
 #include <dlfcn.h>
 
@@ -98,6 +100,7 @@ const I3dCollectives* collectives() { return g_coll.world > 0 && g_coll.all_gath
 using namespace i3d;
 
 extern "C" int i3d_set_collectives(const I3dCollectives* c) {
+    peer_deactivate();      // the fused peer-exchange paths belong to i3d_set_collectives_peer, which re-arms them after this call
     if (c == nullptr) {
         g_coll = I3dCollectives{0, nullptr, nullptr, nullptr, nullptr, 0};
         return I3D_OK;

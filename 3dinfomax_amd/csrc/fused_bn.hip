@@ -14,6 +14,7 @@
 //     never materialised.
 // Deterministic: fixed tile -> lane -> tree order everywhere, no atomics.
 #include "common.h"
+#include "peer.h"
 #include <algorithm>
 
 namespace i3d {
@@ -27,23 +28,21 @@ constexpr int FIN_COLS = 8, FIN_LANES = 32;
 constexpr int FIN_KEEP = 16;      // tiles per lane kept in registers between the passes (more: re-read, L2-resident)
 constexpr int FIN_TAIL = 8;       // tiles per lane and trip of the re-read loops
 
-__global__ void __launch_bounds__(256)
-bn_finalize_partials_kernel(const float* __restrict__ partial, int n_tiles, int feat, float eps, float momentum,
-                            const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean,
-                            float* __restrict__ invstd, float* running_mean, float* running_var,
-                            long long* batches_tracked, float* __restrict__ aff, float* __restrict__ triple_out = nullptr) {
-    I3D_CHAIN_PRIO();
-    __shared__ double sm[2][FIN_LANES][FIN_COLS];
-    const int cx = threadIdx.x & (FIN_COLS - 1), ly = threadIdx.x / FIN_COLS;
-    const int c = blockIdx.x * FIN_COLS + cx;
-    const bool live = c < feat;
+struct MergedTiles {
+    double tot, m2, n, mu;      // m2 is valid in the threads with ly == 0 only
+};
+
+// the exact merge of `n_tiles` {sum, M2, count} tiles (tile b at partial + b * tile_stride) of column c; every thread of the
+// workgroup calls it (two barriers inside; a barrier must separate two calls: `sm` is reused)
+__device__ __forceinline__ MergedTiles merge_tiles(const float* __restrict__ partial, long tile_stride, int n_tiles, int feat, int c,
+                                                   bool live, int cx, int ly, double (&sm)[2][FIN_LANES][FIN_COLS]) {
     float ks[FIN_KEEP], km[FIN_KEEP], kn[FIN_KEEP];
     double n_l = 0.0, s_l = 0.0;
 #pragma unroll
     for (int k = 0; k < FIN_KEEP; ++k) {
         const int b = ly + k * FIN_LANES;
         const bool ok = live && b < n_tiles;
-        const float* p = partial + (long)(ok ? b : 0) * 3 * feat + (live ? c : 0);
+        const float* p = partial + (long)(ok ? b : 0) * tile_stride + (live ? c : 0);
         ks[k] = p[0]; km[k] = p[feat]; kn[k] = ok ? p[2 * feat] : 0.f;
     }
 #pragma unroll
@@ -59,7 +58,7 @@ bn_finalize_partials_kernel(const float* __restrict__ partial, int n_tiles, int 
             for (int u = 0; u < FIN_TAIL; ++u) {
                 const int b = b0 + u * FIN_LANES;
                 const bool ok = b < n_tiles;
-                const float* p = partial + (long)(ok ? b : 0) * 3 * feat + c;
+                const float* p = partial + (long)(ok ? b : 0) * tile_stride + c;
                 ts[u] = p[0]; tn[u] = ok ? p[2 * feat] : 0.f;
             }
 #pragma unroll
@@ -69,10 +68,12 @@ bn_finalize_partials_kernel(const float* __restrict__ partial, int n_tiles, int 
     }
     sm[0][ly][cx] = n_l; sm[1][ly][cx] = s_l;
     __syncthreads();
-    double n = 0.0, tot = 0.0;
+    MergedTiles r;
+    r.n = 0.0; r.tot = 0.0; r.m2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < FIN_LANES; ++k) { n += sm[0][k][cx]; tot += sm[1][k][cx]; }
-    const double mu = n > 0.0 ? tot / n : 0.0;
+    for (int k = 0; k < FIN_LANES; ++k) { r.n += sm[0][k][cx]; r.tot += sm[1][k][cx]; }
+    const double mu = r.n > 0.0 ? r.tot / r.n : 0.0;
+    r.mu = mu;
     __syncthreads();
     double m2_l = 0.0;
 #pragma unroll
@@ -89,7 +90,7 @@ bn_finalize_partials_kernel(const float* __restrict__ partial, int n_tiles, int 
             for (int u = 0; u < FIN_TAIL; ++u) {
                 const int b = b0 + u * FIN_LANES;
                 const bool ok = b < n_tiles;
-                const float* p = partial + (long)(ok ? b : 0) * 3 * feat + c;
+                const float* p = partial + (long)(ok ? b : 0) * tile_stride + c;
                 ts[u] = p[0]; tm[u] = p[feat]; tn[u] = ok ? p[2 * feat] : 0.f;
             }
 #pragma unroll
@@ -103,11 +104,45 @@ bn_finalize_partials_kernel(const float* __restrict__ partial, int n_tiles, int 
     }
     sm[0][ly][cx] = m2_l;
     __syncthreads();
-    if (ly != 0 || !live) return;
-    double m2 = 0.0;
+    if (ly == 0) {
 #pragma unroll
-    for (int k = 0; k < FIN_LANES; ++k) m2 += sm[0][k][cx];
-    if (triple_out != nullptr) {        // synchronised BatchNorm: this rank's tiles merged into ONE {sum, M2, count} "tile"
+        for (int k = 0; k < FIN_LANES; ++k) r.m2 += sm[0][k][cx];
+    }
+    return r;
+}
+
+// PEER (synchronised BatchNorm through the peer-write exchange, peer.h): the workgroup merges this rank's tiles of its 8
+// columns into one {sum, M2, count} triple, writes it into every rank's mailbox, waits for every rank's triple of the same
+// columns and merges those `world` triples with the same code - the exchange sits INSIDE the finalisation, no launch
+// and no communicator on the chain.  The result has the bits of the two-launch form (local merge -> all-gather -> merge
+// over `world` tiles of pitch 3 feat), which the other providers run.
+template <bool PEER>
+__global__ void __launch_bounds__(256)
+bn_finalize_partials_kernel(const float* __restrict__ partial, int n_tiles, int feat, float eps, float momentum,
+                            const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean,
+                            float* __restrict__ invstd, float* running_mean, float* running_var,
+                            long long* batches_tracked, float* __restrict__ aff, float* __restrict__ triple_out, const PeerDev peer) {
+    I3D_CHAIN_PRIO();
+    __shared__ double sm[2][FIN_LANES][FIN_COLS];
+    const int cx = threadIdx.x & (FIN_COLS - 1), ly = threadIdx.x / FIN_COLS;
+    const int c = blockIdx.x * FIN_COLS + cx;
+    const bool live = c < feat;
+    MergedTiles r = merge_tiles(partial, 3L * feat, n_tiles, feat, c, live, cx, ly, sm);
+    if (PEER) {
+        if (ly == 0 && live) {
+            const float tot = (float)r.tot, m2 = (float)r.m2, n = (float)r.n;
+            for (int p = 0; p < peer.world; ++p) {
+                peer_put_f32(peer, p, c, tot);
+                peer_put_f32(peer, p, feat + c, m2);
+                peer_put_f32(peer, p, 2 * feat + c, n);
+            }
+        }
+        peer_signal_and_wait(peer, blockIdx.x);          // (its barriers also separate the two uses of `sm`)
+        r = merge_tiles((const float*)peer_recv_slot(peer, 0), PEER_PAYLOAD_BYTES / 4, peer.world, feat, c, live, cx, ly, sm);
+    }
+    if (ly != 0 || !live) return;
+    const double tot = r.tot, m2 = r.m2, n = r.n, mu = r.mu;
+    if (!PEER && triple_out != nullptr) {        // synchronised BatchNorm: this rank's tiles merged into ONE {sum, M2, count} "tile"
         triple_out[c] = (float)tot;
         triple_out[feat + c] = (float)m2;
         triple_out[2 * feat + c] = (float)n;
@@ -309,24 +344,36 @@ extern "C" int i3d_bn_finalize_partials(const float* partial, int n_tiles, int f
                                         float* aff, void* stream) {
     I3D_CHECK_ARG(partial != nullptr && n_tiles > 0 && feat > 0 && mean != nullptr && invstd != nullptr, "bad arguments");
     I3D_CHECK_ARG(aff == nullptr || (gamma != nullptr && beta != nullptr), "aff needs gamma and beta");
+    const PeerDev no_peer = {};
+    if (PeerCtx* pc = peer_active(stream)) {
+        // synchronised BatchNorm through the peer-write exchange (peer.h): ONE launch, the exchange inside it
+        I3D_CHECK_ARG(3L * feat * 4 <= PEER_PAYLOAD_BYTES && cdiv(feat, FIN_COLS) <= PEER_MAX_WG, "BatchNorm too wide for the peer mailbox");
+        PeerDev d;
+        if (int rc = peer_next(pc, &d)) return rc;
+        hipLaunchKernelGGL(bn_finalize_partials_kernel<true>, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial,
+                           n_tiles, feat, eps, momentum, gamma, beta, mean, invstd, running_mean, running_var,
+                           num_batches_tracked, aff, (float*)nullptr, d);
+        I3D_CHECK_LAUNCH();
+        return I3D_OK;
+    }
     if (const I3dCollectives* coll = collectives()) {
         // synchronised BatchNorm (comm.hip): local tiles -> one {sum, M2, count} triple -> all-gather on this stream -> the
         // same exact merge over the ranks' triples (the parallel-axis theorem does not care whose tiles they are)
         I3D_CHECK_ARG(coll->scratch_bytes >= (long)(1 + coll->world) * 3 * feat * 4, "collective scratch too small");
         float* send = (float*)coll->scratch;
         float* recv = send + 3L * feat;
-        hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial,
+        hipLaunchKernelGGL(bn_finalize_partials_kernel<false>, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial,
                            n_tiles, feat, eps, momentum, gamma, beta, mean, invstd, (float*)nullptr, (float*)nullptr,
-                           (long long*)nullptr, (float*)nullptr, send);
+                           (long long*)nullptr, (float*)nullptr, send, no_peer);
         I3D_CHECK_LAUNCH();
         const int rc = coll->all_gather_f32(coll->user, send, recv, 3L * feat, stream);
         if (rc != I3D_OK) return rc;
         partial = recv;
         n_tiles = coll->world;
     }
-    hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial,
+    hipLaunchKernelGGL(bn_finalize_partials_kernel<false>, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial,
                        n_tiles, feat, eps, momentum, gamma, beta, mean, invstd, running_mean, running_var,
-                       num_batches_tracked, aff, (float*)nullptr);
+                       num_batches_tracked, aff, (float*)nullptr, no_peer);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }

@@ -25,6 +25,7 @@
 // Every pass recomputes the cheap part of the chain (Fourier features, the [H, 2 n_enc + 1] product) from the distance.
 // Deterministic: per-lane -> wave tree -> wave order -> block order sums, no atomics.
 #include "common.h"
+#include "peer.h"
 
 namespace i3d {
 namespace {
@@ -838,6 +839,8 @@ __global__ void n3_sums_from_f64_kernel(const double* __restrict__ in, int n, fl
 int sync_backward_sums(float* gsum, int n, long local_rows, float* inv_rows_dev, void* stream) {
     const I3dCollectives* coll = collectives();
     if (coll == nullptr) return I3D_OK;
+    if (PeerCtx* pc = peer_active(stream))       // peer-write exchange (peer.h): fp32 in, fp64 sums over the ranks, fp32 + 1 / rows out: one launch
+        return peer_sum_f32(pc, gsum, n, 1, (double)local_rows, nullptr, gsum, inv_rows_dev, stream);
     I3D_CHECK_ARG(coll->scratch_bytes >= (long)(n + 1) * 8, "collective scratch too small");
     double* s64 = (double*)coll->scratch;
     hipLaunchKernelGGL(n3_sums_to_f64_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, gsum, n, (double)local_rows, s64);

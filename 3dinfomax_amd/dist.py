@@ -129,27 +129,85 @@ def warm_up(device, steps=2):
 
 # I3D_NATIVE_SYNC_BN=0: synchronised BatchNorm only on the per-block Python path (round-2 behaviour)
 NATIVE_SYNC_BN = os.environ.get('I3D_NATIVE_SYNC_BN', '1') != '0'
-_native_sync = None      # (group, keep-alive objects) while the library's process-wide collectives are set
+# provider of the library's process-wide collectives (csrc/comm.hip): "peer" (one-shot peer-write exchange over IPC-mapped
+# mailboxes, csrc/peer.hip: the default), "rccl" (a communicator of the library's own), "callbacks" (host-staged through the
+# torch group: functional check)
+SYNC_PROVIDER = os.environ.get('I3D_SYNC_PROVIDER', 'peer')
+_native_sync = None      # dict(group, provider, keep-alive objects, handles to release) while the collectives are set
 
 
 def native_sync_active():
     return _native_sync is not None
 
 
-def enable_native_sync(group, device):
-    """Synchronised BatchNorm from INSIDE the C sequencers (csrc/comm.hip): the library's BatchNorm entry points run their
-    collectives themselves, on the stream they are called on, while a process-wide collective table is set.  RCCL
-    ("nccl" backend): a communicator of the library's own, its id distributed through `group`; "gloo" (tests: ranks
-    sharing a GPU): host-staged callbacks.  Returns False when it cannot be set up (the per-block path then synchronises)."""
-    global _native_sync
+def native_sync_provider():
+    return _native_sync['provider'] if _native_sync is not None else None
+
+
+def _peer_context(L, group, device, timeout_s):
+    """One mailbox of this rank, exported, every rank's handle gathered through `group`, the peers' mailboxes mapped."""
+    import ctypes
     from . import _lib
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    hb = L.i3d_peer_handle_bytes()
+    box, handle = ctypes.c_void_p(), ctypes.create_string_buffer(hb)
+    with torch.cuda.device(device):
+        _lib.check(L.i3d_peer_alloc(ctypes.byref(box), handle), 'i3d_peer_alloc')
+        handles = [None] * world
+        dist.all_gather_object(handles, bytes(handle.raw), group=group)
+        ctx = ctypes.c_void_p()
+        _lib.check(L.i3d_peer_open(box, b''.join(handles), rank, world, float(timeout_s), ctypes.byref(ctx)), 'i3d_peer_open')
+    return ctx
+
+
+def enable_native_sync(group, device, provider=None, timeout_s=0.0):
+    """Synchronised BatchNorm from INSIDE the C sequencers (csrc/comm.hip): the library's BatchNorm entry points run their
+    collectives themselves, on the stream they are called on, while a process-wide collective table is set.
+
+    provider "peer" (default): csrc/peer.hip - every rank maps every other rank's mailbox (hipIpc handles gathered through
+    `group`, any backend), the BatchNorm kernels write their small vectors straight into the peers' mailboxes and wait for
+    the peers' flags; the statistics finalisation does it inside its one launch.  The 3D network's side stream gets a context
+    of its own and keeps running beside the 2D network.  "rccl": a communicator of the library's own, its id distributed
+    through `group` ("nccl" backend only); "callbacks": host-staged through `group` (functional check; the default for a gloo
+    group is still "peer": IPC works between processes that share a GPU).  With "rccl" / "callbacks" ONE stream issues the
+    collectives (the 3D network joins the 2D network's stream) and the early gradient all-reduce is off (two communicators
+    must not be in flight at once, GradReducer.overlap).  Idempotent for the same group and provider; returns False when it
+    cannot be set up (the per-block path then synchronises)."""
+    global _native_sync
+    import ctypes
+    from . import _lib, streams
+    provider = provider or SYNC_PROVIDER
+    if provider not in ('peer', 'rccl', 'callbacks'):
+        raise ValueError(f'I3D_SYNC_PROVIDER={provider!r}: peer, rccl or callbacks')
+    if provider == 'rccl' and _is_gloo(group):
+        provider = 'callbacks'
+    if _native_sync is not None:
+        if _native_sync['group'] is group and _native_sync['provider'] == provider:
+            return True
+        disable_native_sync()
     L = _lib.load()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    device = torch.device(device)
     scratch = torch.zeros(1 << 20, dtype=torch.uint8, device=device)
-    if not _is_gloo(group):
+    state = dict(group=group, provider=provider, device=device, net3d_stream=streams.NET3D_STREAM, keep=[scratch], comm=None, peers=[])
+    if provider == 'peer':
+        torch.cuda.synchronize(device)
+        main = _peer_context(L, group, device, timeout_s)
+        state['peers'].append(main)
+        _lib.check(L.i3d_set_collectives_peer(main, scratch.data_ptr(), scratch.numel()), 'i3d_set_collectives_peer')
+        if streams.NET3D_STREAM:
+            # the 3D network's stream: own mailbox, own sequence, own scratch (every rank creates both, in this order)
+            side_scratch = torch.zeros(1 << 20, dtype=torch.uint8, device=device)
+            side = _peer_context(L, group, device, timeout_s)
+            state['peers'].append(side)
+            state['keep'].append(side_scratch)
+            _lib.check(L.i3d_peer_bind_stream(side, ctypes.c_void_p(streams.side_stream(device).cuda_stream), side_scratch.data_ptr(),
+                                              side_scratch.numel()), 'i3d_peer_bind_stream')
+        _native_sync = state
+        return True
+    if provider == 'rccl':
         if not L.i3d_rccl_available():
             return False
-        import ctypes
         buf = ctypes.create_string_buffer(128)
         if rank == 0:
             _lib.check(L.i3d_rccl_unique_id(buf), 'i3d_rccl_unique_id')
@@ -159,7 +217,7 @@ def enable_native_sync(group, device):
         torch.cuda.synchronize(device)
         _lib.check(L.i3d_rccl_init(box[0], rank, world, ctypes.byref(comm)), 'i3d_rccl_init')
         _lib.check(L.i3d_set_collectives_rccl(comm, world, scratch.data_ptr(), scratch.numel()), 'i3d_set_collectives_rccl')
-        _native_sync = (group, (scratch, comm))
+        state['comm'] = comm
     else:
         base = scratch.data_ptr()
 
@@ -196,24 +254,39 @@ def enable_native_sync(group, device):
                 return -2
         cb_g, cb_r = _lib.ALL_GATHER_F32(all_gather), _lib.ALL_REDUCE_F64(all_reduce)
         c = _lib.Collectives(world, cb_g, cb_r, None, scratch.data_ptr(), scratch.numel())
-        import ctypes
         _lib.check(L.i3d_set_collectives(ctypes.byref(c)), 'i3d_set_collectives')
-        _native_sync = (group, (scratch, cb_g, cb_r, c))
+        state['keep'] += [cb_g, cb_r, c]
     # ONE stream issues the collectives of a communicator, in the same order on every rank: the 3D network joins the
     # 2D network's stream.  Its fused edge stage stays: the forward statistics go through i3d_bn_finalize_partials like
     # everyone's, the backward sums of its two BatchNorms are exchanged between its own kernels (csrc/net3d_edge.hip:
     # sync_backward_sums)
-    from . import streams
     streams.NET3D_STREAM = False
+    _native_sync = state
     return True
 
 
 def disable_native_sync():
+    """Switch the library's collectives off and release what enable_native_sync created (communicator / mailboxes); restores
+    the 3D network's side stream.  Collective when a peer or RCCL provider was set: every rank calls it."""
     global _native_sync
-    if _native_sync is not None:
-        from . import _lib
-        _lib.load().i3d_set_collectives(None)
-        _native_sync = None
+    if _native_sync is None:
+        return
+    from . import _lib, streams
+    st, _native_sync = _native_sync, None
+    L = _lib.load()
+    if st['device'].type == 'cuda':
+        torch.cuda.synchronize(st['device'])
+    L.i3d_set_collectives(None)
+    if st['peers'] or st['comm'] is not None:
+        try:        # nobody unmaps a mailbox a peer's kernel may still write to
+            dist.barrier(group=st['group'])
+        except Exception:      # noqa: BLE001 - the group may be gone already (interpreter shutdown)
+            pass
+    for ctx in st['peers']:
+        L.i3d_peer_close(ctx)
+    if st['comm'] is not None:
+        L.i3d_rccl_destroy(st['comm'])
+    streams.NET3D_STREAM = st['net3d_stream']
 
 
 def setup(modules, loss=None, group=None, sync_bn=False, broadcast=True):
@@ -228,7 +301,7 @@ def setup(modules, loss=None, group=None, sync_bn=False, broadcast=True):
     if sync_bn and NATIVE_SYNC_BN:
         dev = next((p.device for m in modules for p in m.parameters() if p.is_cuda), None)
         native = dev is not None and enable_native_sync(group, dev)
-    elif not sync_bn:
+    if not native:
         disable_native_sync()
     for m in modules:
         for sub in m.modules():
@@ -321,6 +394,12 @@ class GradReducer:
         caller - only the module the plan was made for may start it (another module's backward pass says nothing about
         whether THOSE gradients are final); None: reduce() itself."""
         if self._launched or not self._agreed:       # (no early collective before the ranks have agreed on the plan)
+            return
+        if native_sync_provider() == 'rccl':
+            # The library's own RCCL communicator issues the BatchNorm collectives of the rest of the backward pass on the
+            # compute stream; an asynchronous all-reduce of torch's communicator next to them would be two communicators in
+            # flight without a common order across ranks (documented as unsafe unless both kernels are always co-resident).
+            # The peer provider has no communicator: the early all-reduce stays on with it.
             return
         if module is not None and id(module) != self.early_module:
             return

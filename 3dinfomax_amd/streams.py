@@ -32,6 +32,11 @@ def _side(device):
     return s
 
 
+def side_stream(device):
+    """this thread's side stream on `device` (created on first use): the stream the 3D network runs on beside the 2D network"""
+    return _side(torch.device(device))
+
+
 class fork:
     """with fork(t1, t2, ...) as f:  kernels launched inside run on the side stream; `f.join()` (or leaving the
     `with` and calling join later in the same node) makes the main stream wait for them."""

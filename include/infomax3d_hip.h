@@ -360,6 +360,7 @@ int i3d_gemm_f32_wgrad_bn(int f_out, int f_in, int rows, const float* dY, int ld
  * this rank's share: the gradient all-reduce sums them).  world 1 runs the same sequence (self-test).
  *   all_gather_f32: recv[world][count] <- every rank's send[count];  all_reduce_f64: buf[count] summed in place
  *   scratch: device memory of the table's own (>= (4 + 3 world) * widest BatchNorm * 8 bytes; 1 MiB is plenty)
+ * Providers: callbacks (i3d_set_collectives), RCCL (below), peer-write exchange (further below: the production one).
  * RCCL provider: rank 0 i3d_rccl_unique_id -> (caller broadcasts the 128 bytes) -> every rank i3d_rccl_init ->
  * i3d_set_collectives_rccl.  i3d_set_collectives(NULL): off.  One training per process. */
 typedef struct {
@@ -377,6 +378,33 @@ int i3d_rccl_unique_id(char* out128 /* host */);
 int i3d_rccl_init(const char* id128 /* host */, int rank, int world, void** comm);
 int i3d_rccl_destroy(void* comm);
 int i3d_set_collectives_rccl(void* comm, int world, void* scratch, long scratch_bytes);
+/* ---- provider 3: one-shot peer-write exchange over IPC-mapped mailboxes (csrc/peer.h, peer.hip) -----------------------
+ * What the reference's whole-batch BatchNorm (models/base_layers.py:87, 100-111: nn.BatchNorm1d over every row the model is
+ * given) costs once the batch is sharded over ranks: ~50 vectors of <= [3F] floats per step, each needed by every rank, on
+ * the step's dependent chain.  Every rank allocates a mailbox (i3d_peer_alloc: uncached device memory + its IPC handle),
+ * the caller distributes the handles (torch.distributed all_gather_object), every rank maps the others' mailboxes
+ * (i3d_peer_open) and installs the provider (i3d_set_collectives_peer).  While it is installed
+ *   - i3d_bn_finalize_partials exchanges its {sum, M2, count} triples INSIDE the finalisation kernel (one launch, as
+ *     without synchronisation);
+ *   - i3d_bn_bwd*, i3d_act_stats_fwd* and the 3D network's edge stage exchange their fp64 sums in one launch
+ *     (append row count -> sum over ranks in rank order -> fp32 vectors + 1 / rows);
+ *   - the table's generic all_gather_f32 / all_reduce_f64 are one-launch kernels of the same protocol.
+ * A kernel writes payload + sequence flag into every rank's mailbox and waits (bounded: timeout_s, default 30 s,
+ * I3D_PEER_TIMEOUT_S) for the `world` flags in its own; a wait that times out is reported by the NEXT call (error return,
+ * i3d_peer_status) - no hung GPU.  One stream issues the collectives, in the same order on every rank.  Results are
+ * bit-identical on all ranks (sums in rank order).  world <= 16, BatchNorm width <= 4095. */
+long i3d_peer_mailbox_bytes(void);
+int i3d_peer_handle_bytes(void); /* sizeof(hipIpcMemHandle_t) = 64 */
+int i3d_peer_alloc(void** mailbox /* out: device */, char* handle_out /* host, i3d_peer_handle_bytes() */);
+int i3d_peer_open(void* mailbox, const char* handles /* host [world][handle bytes], rank order */, int rank, int world,
+                  double timeout_s /* <= 0: default */, void** ctx /* out */);
+int i3d_set_collectives_peer(void* ctx, void* scratch, long scratch_bytes);
+/* a second context (own mailbox, sequence and scratch) for the collectives issued on `stream`: the 3D network's side stream keeps
+ * running beside the 2D network under synchronised BatchNorm; every rank binds the same streams in the same roles */
+int i3d_peer_bind_stream(void* ctx, void* stream, void* scratch, long scratch_bytes);
+int i3d_peer_status(void* ctx); /* 0: healthy, else the sequence number of the collective whose wait timed out */
+long long i3d_peer_sequence(void* ctx); /* collectives issued so far */
+int i3d_peer_close(void* ctx); /* unmaps the peers, frees the mailbox; every rank must have stopped issuing collectives */
 
 /* ---- all weight gradients of a layer in ONE launch + one fixed-order reduction (csrc/wgrad.hip) ----------------------
  * Replaces autograd's dW = dY^T X of every nn.Linear of a PNA layer (reference models/base_layers.py:101; the Linears of

@@ -46,7 +46,8 @@ def _batch(amd, mols):
 
 
 def _worker(rank, port, path, native_sync):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), I3D_NATIVE_SYNC_BN='1' if native_sync else '0')
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), I3D_NATIVE_SYNC_BN='1' if native_sync else '0',
+                      I3D_SYNC_PROVIDER=native_sync or 'peer', I3D_PEER_TIMEOUT_S='20')
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     dist.init_process_group('gloo', rank=rank, world_size=WORLD)
@@ -60,7 +61,7 @@ def _worker(rank, port, path, native_sync):
     pna, net = _models(amd)
     loss_fn = amd.NTXent(tau=0.1)
     adist.setup([pna, net], loss_fn, sync_bn=True)      # global-batch BN statistics: equals the single-process step
-    assert adist.native_sync_active() == native_sync
+    assert adist.native_sync_active() == bool(native_sync) and adist.native_sync_provider() == (native_sync or None)
     g2, g3 = _batch(amd, adist.shard_molecules(mols, rank, WORLD))
     params = list(pna.parameters()) + list(net.parameters())
     if rank == 0:    # one rank delivers its gradients straight into the all-reduce buffer, the other through the copy path
@@ -79,13 +80,23 @@ def _worker(rank, port, path, native_sync):
             for k, b in m.named_buffers():
                 out[f'b/{tag}/{k}'] = b.cpu().numpy()
         np.savez(path, **out)
+    if native_sync == 'peer':
+        L = importlib.import_module('3dinfomax_amd._lib').load()
+        st = adist._native_sync
+        # both contexts (the 2D network's stream and the 3D network's side stream) have exchanged, nothing timed out
+        assert len(st['peers']) == 2 and all(L.i3d_peer_sequence(c) > 0 and L.i3d_peer_status(c) == 0 for c in st['peers'])
+    adist.disable_native_sync()
+    assert not adist.native_sync_active() and importlib.import_module('3dinfomax_amd.streams').NET3D_STREAM
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('native_sync', [True, False])
+@pytest.mark.parametrize('native_sync', ['peer', 'callbacks', False])
 def test_two_rank_sharded_step_equals_full_batch(tmp_path, native_sync):
-    """native_sync: BatchNorm synchronised inside the C sequencers (csrc/comm.hip, here with host-staged callbacks: RCCL
-    refuses two ranks on one device) - the whole-model sequencer runs; False: the per-block Python path of round 2."""
+    """BatchNorm synchronised inside the C sequencers (csrc/comm.hip) - the whole-model sequencer runs - through 'peer': the
+    one-shot peer-write exchange (csrc/peer.hip: each process maps the other's mailbox through hipIpc - which works between
+    processes that share a GPU - and the BatchNorm kernels exchange their vectors themselves; the 3D network keeps its side
+    stream with a context of its own) or 'callbacks': host-staged through gloo; False: the per-block Python path of round 2.
+    (RCCL refuses two ranks on one device: its provider has a world-1 test below.)"""
     assert torch.cuda.is_available()
     amd = importlib.import_module('3dinfomax_amd')
     from helpers import close, grads_close
@@ -237,8 +248,8 @@ def test_two_rank_uneven_shards_local_bn_and_early_allreduce(tmp_path):
         grads_close({k: z[f'g/{tag}/{k}'] for k in ref}, ref, 2e-4, tag + ' ')
 
 
-def _rccl_worker(rank, port, path):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+def _rccl_worker(rank, port, path, provider='rccl'):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), I3D_SYNC_PROVIDER=provider)
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     torch.cuda.set_device(0)
@@ -253,7 +264,8 @@ def _rccl_worker(rank, port, path):
     pna, net = _models(amd)
     loss_fn = amd.NTXent(tau=0.1)
     adist.setup([pna, net], loss_fn, sync_bn=True)
-    ok = adist.native_sync_active() and importlib.import_module('3dinfomax_amd._lib').load().i3d_collectives_world() == 1
+    ok = (adist.native_sync_active() and adist.native_sync_provider() == provider
+          and importlib.import_module('3dinfomax_amd._lib').load().i3d_collectives_world() == 1)
     g2, g3 = _batch(amd, mols)
     params = list(pna.parameters()) + list(net.parameters())
     adist.grad_reducer(params, modules=[pna, net])
@@ -272,14 +284,16 @@ def _rccl_worker(rank, port, path):
     dist.destroy_process_group()
 
 
-def test_rccl_provider_of_the_native_collectives_on_one_rank(tmp_path):
+@pytest.mark.parametrize('provider', ['rccl', 'peer'])
+def test_rccl_and_peer_providers_of_the_native_collectives_on_one_rank(tmp_path, provider):
     """The RCCL side of csrc/comm.hip (run-time binding, communicator of the library's own from a broadcast id,
-    ncclAllGather / ncclAllReduce enqueued on the sequencer's stream) on the one GPU a test box has: a world of one rank
-    runs every collective of the synchronised step and must reproduce the plain step."""
+    ncclAllGather / ncclAllReduce enqueued on the sequencer's stream) and the peer-write exchange (csrc/peer.hip) under an
+    "nccl" process group, on the one GPU a test box has: a world of one rank runs every collective of the synchronised
+    step and must reproduce the plain step."""
     amd = importlib.import_module('3dinfomax_amd')
     from helpers import close, grads_close
     path = str(tmp_path / 'rccl1.npz')
-    mp.spawn(_rccl_worker, args=(_free_port(), path), nprocs=1, join=True)
+    mp.spawn(_rccl_worker, args=(_free_port(), path, provider), nprocs=1, join=True)
     z = np.load(path)
     assert bool(z['ok'])
     mols = amd.synth.make_dataset(16, seed=21)
@@ -293,3 +307,47 @@ def test_rccl_provider_of_the_native_collectives_on_one_rank(tmp_path):
         grads_close({k: z[f'g/{tag}/{k}'] for k in ref}, ref, 2e-4, tag + ' ')
         for k, b in m.named_buffers():
             assert close(z[f'b/{tag}/{k}'], b.cpu(), 1e-5, 1e-6), k
+
+
+def _lost_rank_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), I3D_SYNC_PROVIDER='peer', I3D_PEER_TIMEOUT_S='1.5')
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    amd = importlib.import_module('3dinfomax_amd')
+    adist = importlib.import_module('3dinfomax_amd.dist')
+    L = importlib.import_module('3dinfomax_amd._lib').load()
+    ops = importlib.import_module('3dinfomax_amd.ops')
+    assert adist.enable_native_sync(dist.group.WORLD, torch.device('cuda:0'))
+    x = torch.randn(64, 24, device='cuda:0') + rank
+    dist.barrier()
+    res = None
+    if rank == 0:       # rank 1 never issues its BatchNorm: rank 0's kernel gives up after the timeout, the NEXT call reports it
+        import time
+        t0 = time.perf_counter()
+        ops.act_stats_fwd(x, 'relu', 1e-5, 0.1)
+        torch.cuda.synchronize()
+        waited = time.perf_counter() - t0
+        status = L.i3d_peer_status(adist._native_sync['peers'][0])
+        try:
+            ops.act_stats_fwd(x, 'relu', 1e-5, 0.1)
+            raised = False
+        except Exception as exc:      # noqa: BLE001
+            raised = 'timed out' in str(exc)
+        res = (1.0 < waited < 10.0) and status != 0 and raised
+    dist.barrier()
+    if rank == 0:
+        out[0] = bool(res)
+    else:
+        out[1] = True
+    # (no disable_native_sync: a rank is marked dead; the mailboxes go with the process)
+    dist.destroy_process_group()
+
+
+def test_peer_exchange_with_a_lost_rank_times_out_and_reports():
+    """A rank that never issues its collective must cost the others a bounded wait and a clean error from the next call - not
+    a hung GPU (csrc/peer.h: bounded spin, host-visible status word)."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_lost_rank_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
+    assert dict(out) == {0: True, 1: True}
