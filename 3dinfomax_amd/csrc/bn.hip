@@ -79,6 +79,15 @@ struct Final {
     double* sums_out;      // fp64 results for the synchronised-BN all-reduce (may be null)
     long long* batches_tracked;   // BatchNorm1d.num_batches_tracked (int64), incremented with the running statistics; may be null
     unsigned* counters;    // null: stage 2 is a separate launch (I3D_FUSED_FINAL=0)
+    // synchronised BatchNorm through the peer-write exchange (peer.h), inside the in-launch finalisation: the reducer of a
+    // column block writes its fp64 {s1, s2, rows} into every rank's mailbox, waits for every rank's and finishes from the
+    // sums over the ranks (rank order) - statistics: mean / invstd / running statistics of the global batch; pair: out1 /
+    // out2 keep this rank's share, g1 / g2 / ginv receive the global sums as fp32 and 1 / global rows
+    int peer_on;
+    float* g1;
+    float* g2;
+    float* ginv;
+    PeerDev peer;
 };
 
 __device__ __forceinline__ float ld_agent(const float* p) {
@@ -116,6 +125,46 @@ __device__ __forceinline__ void finalize_column(const Final& f, int c, double s1
         }
         if (f.out1 != nullptr) f.out1[c] = (float)s1;
         if (f.out2 != nullptr) f.out2[c] = (float)s2;
+    }
+}
+
+// the part of finalize_column that follows the exchange: T1, T2, N = sums over the ranks of what finalize_column_local put
+__device__ __forceinline__ void finalize_column_global(const Final& f, int c, double T1, double T2, double N) {
+    if (f.kind == 0) {          // == stats_from_sums_kernel
+        const double m = T1 / N;
+        double var = T2 / N - m * m;
+        if (var < 0.0) var = 0.0;
+        f.mean[c] = (float)m;
+        f.invstd[c] = (float)(1.0 / sqrt(var + (double)f.eps));
+        if (f.running_mean != nullptr) {
+            const double unbiased = N > 1.0 ? var * N / (N - 1.0) : var;
+            f.running_mean[c] = (float)((1.0 - f.momentum) * (double)f.running_mean[c] + f.momentum * m);
+            f.running_var[c] = (float)((1.0 - f.momentum) * (double)f.running_var[c] + f.momentum * unbiased);
+        }
+        if (c == 0 && f.batches_tracked != nullptr) *f.batches_tracked += 1;
+    } else {                    // == sums_to_float_kernel
+        f.g1[c] = (float)T1;
+        f.g2[c] = (float)T2;
+        if (c == 0) f.ginv[0] = (float)(1.0 / N);
+    }
+}
+
+// this rank's contribution to the exchange (un-shifted sums for the statistics); the pair's local results are stored here
+__device__ __forceinline__ void finalize_column_local(const Final& f, int c, double s1, double s2) {
+    const double n = (double)f.rows;
+    double a = s1, b = s2;
+    if (f.kind == 0) {
+        const double shift = (double)apply_act(f.pre_row0[c], f.act);
+        a = s1 + n * shift;
+        b = s2 + 2.0 * shift * s1 + n * shift * shift;
+    } else {
+        if (f.out1 != nullptr) f.out1[c] = (float)s1;
+        if (f.out2 != nullptr) f.out2[c] = (float)s2;
+    }
+    for (int p = 0; p < f.peer.world; ++p) {
+        peer_put_f64(f.peer, p, c, a);
+        peer_put_f64(f.peer, p, f.feat + c, b);
+        peer_put_f64(f.peer, p, 2 * f.feat + c, n);
     }
 }
 
@@ -166,7 +215,20 @@ __device__ __forceinline__ void arrive_and_finalize(const Final& f, const float*
             double s1 = 0.0, s2 = 0.0;
 #pragma unroll
             for (int k = 0; k < FIN_LANES; ++k) { s1 += s_red[0][k][cx]; s2 += s_red[1][k][cx]; }
-            finalize_column(f, c, s1, s2);
+            if (f.peer_on) finalize_column_local(f, c, s1, s2);
+            else finalize_column(f, c, s1, s2);
+        }
+        if (f.peer_on) {        // (uniform) the column block's exchange: flag index = column block, the same partition on every rank
+            peer_signal_and_wait(f.peer, (int)cb);
+            if (ly == 0 && c < f.feat) {
+                double T1 = 0.0, T2 = 0.0, N = 0.0;
+                for (int q = 0; q < f.peer.world; ++q) {
+                    T1 += peer_get_f64(f.peer, q, c);
+                    T2 += peer_get_f64(f.peer, q, f.feat + c);
+                    N += peer_get_f64(f.peer, q, 2 * f.feat + c);
+                }
+                finalize_column_global(f, c, T1, T2, N);
+            }
         }
         __syncthreads();
     }
@@ -728,6 +790,9 @@ static bool exact_zero_bias_grad() {
 
 static float* partial_of(void* workspace) { return (float*)((char*)workspace + WS_HEADER); }
 
+// [3 feat] doubles per rank in a mailbox slot, one flag per column block
+static bool peer_fits(int feat) { return 3L * feat * 8 <= PEER_PAYLOAD_BYTES && cdiv(feat, FIN_COLS) <= PEER_MAX_WG; }
+
 static Final stats_final_desc(void* workspace, const float* pre, int act, int rows, int feat, float eps, float momentum,
                               float* mean, float* invstd, float* running_mean, float* running_var, double* sums_out,
                               long long* batches_tracked = nullptr) {
@@ -790,6 +855,20 @@ extern "C" int i3d_act_stats_fwd_counted(const float* pre, int rows, int feat, i
         // synchronised BatchNorm (comm.hip): un-shifted fp64 [sum, sum of squares, count] of this rank -> all-reduce on this
         // stream -> mean / invstd / running statistics over all ranks
         PeerCtx* pc = peer_active(stream);      // (a context and a scratch per stream that issues collectives)
+        if (pc != nullptr && fused_final() && peer_fits(feat)) {
+            // peer-write exchange inside the reduction's in-launch finalisation: ONE launch, as without synchronisation
+            Chunking ch = make_chunking(rows, feat);
+            ReduceArgs g = {};
+            g.a = pre; g.out = x; g.rows = rows; g.feat = feat; g.act = act; g.post_act = I3D_ACT_NONE;
+            g.partial = partial_of(workspace);
+            Final f = stats_final_desc(workspace, pre, act, rows, feat, eps, momentum, mean, invstd, running_mean, running_var, nullptr,
+                                       num_batches_tracked);
+            f.peer_on = 1;
+            if (int rc = peer_next(pc, &f.peer)) return rc;
+            launch_reduction<MODE_STATS>(g, ch, f, s);
+            I3D_CHECK_LAUNCH();
+            return I3D_OK;
+        }
         I3D_CHECK_ARG((pc ? peer_scratch_bytes(pc) : coll->scratch_bytes) >= (long)(2 * feat + 1) * 8, "collective scratch too small");
         double* s64 = (double*)(pc ? peer_scratch(pc) : coll->scratch);
         int rc = i3d_act_stats_fwd_counted(pre, rows, feat, act, x, eps, momentum, mean, invstd, nullptr, nullptr, s64, nullptr,
@@ -908,6 +987,28 @@ static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, in
         // stream -> the data gradient from the sums over all ranks; grad_gamma / grad_beta keep this rank's share (the
         // gradient all-reduce adds the ranks up)
         PeerCtx* pc = peer_active(stream);
+        if (pc != nullptr && fused_final() && peer_fits(feat)) {
+            // peer-write exchange inside the reduction's in-launch finalisation: grad_gamma / grad_beta get this rank's share,
+            // the workspace the global sums as fp32 + 1 / global rows - then the data-gradient pass; no extra launch
+            Chunking ch = make_chunking(rows, feat);
+            float* partial = partial_of(workspace);
+            float* tmp = partial + (long)MAX_PARTIAL_BLOCKS * 2 * feat;
+            ReduceArgs g = {};
+            g.a = grad_y; g.b = x; g.mean = mean; g.invstd = invstd; g.gamma = gamma; g.beta = beta;
+            g.rows = rows; g.feat = feat; g.act = act; g.post_act = post_act; g.partial = partial;
+            g.b_bf16 = g_x_bf16;
+            Final f = pair_final_desc(workspace, feat, grad_beta, grad_gamma, nullptr);
+            f.rows = rows; f.peer_on = 1; f.g1 = tmp; f.g2 = tmp + feat; f.ginv = tmp + 2 * feat;
+            if (int rc = peer_next(pc, &f.peer)) return rc;
+            launch_reduction<MODE_BN_BWD>(g, ch, f, s);
+            I3D_CHECK_LAUNCH();
+            g_sums_ready = 1;
+            const int rc = bn_bwd_impl(grad_y, x, pre, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta,
+                                       grad_pre, grad_bias, nullptr, (const double*)tmp /* non-null: phase 2 */, 0, workspace,
+                                       bias_partial, ld_out, stream);
+            g_sums_ready = 0;
+            return rc;
+        }
         I3D_CHECK_ARG((pc ? peer_scratch_bytes(pc) : coll->scratch_bytes) >= (long)(2 * feat + 1) * 8, "collective scratch too small");
         double* s64 = (double*)(pc ? peer_scratch(pc) : coll->scratch);
         int rc = bn_bwd_impl(grad_y, x, pre, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta,
@@ -962,12 +1063,14 @@ static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, in
     b.sum_dy = sum_dy; b.sum_dy_xhat = sum_dy_xhat; b.grad_pre = grad_pre; b.ld_out = ld_out; b.feat = feat; b.act = act;
     b.post_act = post_act; b.eval_mode = 0; b.inv_n = 1.f / (float)total_rows; b.eps = 0.f;
     b.zero_out = nullptr; b.x_bf16 = g_x_bf16;
-    if (grad_bias != nullptr && act == I3D_ACT_NONE && sums_in == nullptr && exact_zero_bias_grad()) {
+    if (grad_bias != nullptr && act == I3D_ACT_NONE && exact_zero_bias_grad()) {
         // No activation between the Linear and the BatchNorm: the bias gradient is the column sum of the BatchNorm input
         // gradient  s (dy - mean(dy) - xhat mean(dy xhat))  over the rows the statistics were taken over, which is
         // IDENTICALLY zero (sum xhat = 0).  The reference sums it up in fp32 and gets rounding noise (~1e-9 of the scale,
         // which its Adam turns into +-lr steps on a bias the BatchNorm removes anyway); here it is the exact value, and the
-        // data-gradient pass loses its reduction and the ~10 us finalisation tail.
+        // data-gradient pass loses its reduction and the ~10 us finalisation tail.  (Synchronised BatchNorm: the sum over the
+        // rows of ALL ranks is zero, a rank's share is not - but the gradient all-reduce adds the shares up, so every rank
+        // writing the exact total, zero, gives the same all-reduced value.)
         b.zero_out = grad_bias;
         launch_bwd_apply(b, rows, feat, s);
         I3D_CHECK_LAUNCH();

@@ -34,6 +34,13 @@ struct MergedTiles {
 
 // the exact merge of `n_tiles` {sum, M2, count} tiles (tile b at partial + b * tile_stride) of column c; every thread of the
 // workgroup calls it (two barriers inside; a barrier must separate two calls: `sm` is reused)
+template <bool SYS>      // SYS: the tiles live in a peer mailbox - system-scope loads (peer.h)
+__device__ __forceinline__ float ld_tile(const float* p) {
+    if (SYS) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return *p;
+}
+
+template <bool SYS>
 __device__ __forceinline__ MergedTiles merge_tiles(const float* __restrict__ partial, long tile_stride, int n_tiles, int feat, int c,
                                                    bool live, int cx, int ly, double (&sm)[2][FIN_LANES][FIN_COLS]) {
     float ks[FIN_KEEP], km[FIN_KEEP], kn[FIN_KEEP];
@@ -43,7 +50,7 @@ __device__ __forceinline__ MergedTiles merge_tiles(const float* __restrict__ par
         const int b = ly + k * FIN_LANES;
         const bool ok = live && b < n_tiles;
         const float* p = partial + (long)(ok ? b : 0) * tile_stride + (live ? c : 0);
-        ks[k] = p[0]; km[k] = p[feat]; kn[k] = ok ? p[2 * feat] : 0.f;
+        ks[k] = ld_tile<SYS>(p); km[k] = ld_tile<SYS>(p + feat); kn[k] = ok ? ld_tile<SYS>(p + 2 * feat) : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < FIN_KEEP; ++k) {
@@ -59,7 +66,7 @@ __device__ __forceinline__ MergedTiles merge_tiles(const float* __restrict__ par
                 const int b = b0 + u * FIN_LANES;
                 const bool ok = b < n_tiles;
                 const float* p = partial + (long)(ok ? b : 0) * tile_stride + c;
-                ts[u] = p[0]; tn[u] = ok ? p[2 * feat] : 0.f;
+                ts[u] = ld_tile<SYS>(p); tn[u] = ok ? ld_tile<SYS>(p + 2 * feat) : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < FIN_TAIL; ++u)
@@ -91,7 +98,7 @@ __device__ __forceinline__ MergedTiles merge_tiles(const float* __restrict__ par
                 const int b = b0 + u * FIN_LANES;
                 const bool ok = b < n_tiles;
                 const float* p = partial + (long)(ok ? b : 0) * tile_stride + c;
-                ts[u] = p[0]; tm[u] = p[feat]; tn[u] = ok ? p[2 * feat] : 0.f;
+                ts[u] = ld_tile<SYS>(p); tm[u] = ld_tile<SYS>(p + feat); tn[u] = ok ? ld_tile<SYS>(p + 2 * feat) : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < FIN_TAIL; ++u) {
@@ -127,7 +134,7 @@ bn_finalize_partials_kernel(const float* __restrict__ partial, int n_tiles, int 
     const int cx = threadIdx.x & (FIN_COLS - 1), ly = threadIdx.x / FIN_COLS;
     const int c = blockIdx.x * FIN_COLS + cx;
     const bool live = c < feat;
-    MergedTiles r = merge_tiles(partial, 3L * feat, n_tiles, feat, c, live, cx, ly, sm);
+    MergedTiles r = merge_tiles<false>(partial, 3L * feat, n_tiles, feat, c, live, cx, ly, sm);
     if (PEER) {
         if (ly == 0 && live) {
             const float tot = (float)r.tot, m2 = (float)r.m2, n = (float)r.n;
@@ -138,7 +145,7 @@ bn_finalize_partials_kernel(const float* __restrict__ partial, int n_tiles, int 
             }
         }
         peer_signal_and_wait(peer, blockIdx.x);          // (its barriers also separate the two uses of `sm`)
-        r = merge_tiles((const float*)peer_recv_slot(peer, 0), PEER_PAYLOAD_BYTES / 4, peer.world, feat, c, live, cx, ly, sm);
+        r = merge_tiles<true>((const float*)peer_recv_slot(peer, 0), PEER_PAYLOAD_BYTES / 4, peer.world, feat, c, live, cx, ly, sm);
     }
     if (ly != 0 || !live) return;
     const double tot = r.tot, m2 = r.m2, n = r.n, mu = r.mu;

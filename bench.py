@@ -8,7 +8,9 @@ One step = reference trainer/self_supervised_trainer.py:24-29 + trainer/trainer.
 forward, NT-Xent, backward, Adam step, zero_grad - on a batch of synthetic QM9-shaped molecules already resident
 in HBM.  Workload = BASELINE.json configs[1]: PNA hidden 200, depth 4 (--depth 7 = the yml),
 batch 512 per GPU, fp32.  N>1: molecules sharded by rank (weak scaling, 512 per GPU), all-gathered negatives,
-synchronised BatchNorm, gradient all-reduce (3dinfomax_amd/dist.py).
+gradient all-reduce, and - the headline `value` - BatchNorm statistics over the GLOBAL batch (the reference normalises over
+every row it is given: only this mode reproduces its loss; csrc/peer.hip exchanges the statistics between the ranks' kernels);
+the step with per-rank statistics is measured right after it and reported as config.local_bn (3dinfomax_amd/dist.py).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     - the PNA aggregation kernel (K4): algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
@@ -74,10 +76,13 @@ def parse():
     ap.add_argument('--loader-workers', type=int, default=4,
                     help='DataLoader worker processes of the with-batch-assembly figure (0: assemble in the training thread)')
     ap.add_argument('--cpu-steps', type=int, default=3)
-    ap.add_argument('--sync-bn', action='store_true',
-                    help='N > 1: BatchNorm statistics over the global batch (exact single-process equivalence) instead of '
-                         'per-rank statistics (DistributedDataParallel semantics, the default)')
-    ap.add_argument('--no-sync-bn', action='store_true', help=argparse.SUPPRESS)   # former name of the default
+    ap.add_argument('--local-bn', action='store_true',
+                    help='N > 1: make per-rank BatchNorm statistics (DistributedDataParallel semantics; a DIFFERENT loss than the '
+                         'reference computes on the global batch) the headline `value`.  Default at N > 1: synchronised '
+                         'BatchNorm - statistics over the global batch, the mode whose loss matches the reference - is the '
+                         'headline and the local-BatchNorm rate is reported next to it (config.local_bn)')
+    ap.add_argument('--sync-bn', action='store_true', help=argparse.SUPPRESS)      # the default at N > 1 (kept for old command lines)
+    ap.add_argument('--no-sync-bn', action='store_true', help=argparse.SUPPRESS)   # former name of --local-bn
     ap.add_argument('--host-profile', action='store_true',
                     help='cProfile of the host side of the timed steps (top entries by own time, to stderr)')
     ap.add_argument('--lead-probe', action='store_true',
@@ -341,8 +346,12 @@ def main():
     adam_cls = torch.optim.Adam if args.torch_adam else amd.Adam
     optim = adam_cls([{'params': [p for k, p in named if 'batch_norm' in k], 'weight_decay': 0},
                       {'params': [p for k, p in named if 'batch_norm' not in k]}], lr=8e-5, fused=True)
+    # N > 1: the headline is the mode whose loss matches the reference on the global batch (synchronised BatchNorm: the
+    # reference normalises over every row it is given, models/base_layers.py:87, 100-111); the per-rank-statistics step is
+    # measured next to it (config.local_bn).  --local-bn swaps the two.
+    headline_sync = use_dist and not (args.local_bn or args.no_sync_bn)
     if use_dist:
-        adist.setup([pna, net], loss_fn, sync_bn=args.sync_bn)
+        adist.setup([pna, net], loss_fn, sync_bn=headline_sync)
         adist.grad_reducer(params, modules=[pna, net])        # backward passes write into the all-reduce buffer
 
     def step(i):
@@ -361,49 +370,67 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    if use_dist:       # RCCL prints its version banner through C stdio at communicator creation: push it out now, so that
-        import ctypes  # the JSON line is the last line of stdout
-        ctypes.CDLL(None).fflush(None)
-    ops.KERNEL_TIMERS = {}
     lead, lead_hist = [], []
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # per-step device times (median)
-    marks[0].record()
-    prof = None
-    if args.host_profile:
-        import cProfile
-        prof = cProfile.Profile()
-        prof.enable()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-        marks[i + 1].record()
-        if args.lead_probe:       # how many steps is the host ahead of the GPU? (0 = the GPU waits for the host)
-            ev = torch.cuda.Event()
-            ev.record()
-            lead.append(ev)
-            if i % 10 == 9:
-                pending = 0
-                for e in reversed(lead):
-                    if e.query():
-                        break
-                    pending += 1
-                lead_hist.append(pending)
-    t_enqueue = time.perf_counter() - t0      # host time to enqueue the steps (== dt when host-bound)
-    if prof is not None:
-        import pstats
-        prof.disable()
-        pstats.Stats(prof, stream=sys.stderr).sort_stats('tottime').print_stats(30)
-    barrier()
-    dt = time.perf_counter() - t0
+
+    def timed_region(n_warm, n_steps, profile=False):
+        """n_warm untimed steps, then EXACTLY n_steps steps between barrier + synchronize on both sides; max over ranks"""
+        for i in range(n_warm):
+            step(i)
+        barrier()
+        if use_dist:       # RCCL prints its version banner through C stdio at communicator creation: push it out now, so that
+            import ctypes  # the JSON line is the last line of stdout
+            ctypes.CDLL(None).fflush(None)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]      # per-step device times (median)
+        marks[0].record()
+        prof = None
+        if profile:
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            loss = step(n_warm + i)
+            marks[i + 1].record()
+            if args.lead_probe:       # how many steps is the host ahead of the GPU? (0 = the GPU waits for the host)
+                ev = torch.cuda.Event()
+                ev.record()
+                lead.append(ev)
+                if i % 10 == 9:
+                    pending = 0
+                    for e in reversed(lead):
+                        if e.query():
+                            break
+                        pending += 1
+                    lead_hist.append(pending)
+        t_enq = time.perf_counter() - t0      # host time to enqueue the steps (== dt when host-bound)
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof, stream=sys.stderr).sort_stats('tottime').print_stats(30)
+        barrier()
+        dt_ = time.perf_counter() - t0
+        ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n_steps))
+        if use_dist:
+            t = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = t.item()
+        return dt_, t_enq, ms, loss
+
+    ops.KERNEL_TIMERS = {}
+    dt, t_enqueue, step_ms, loss = timed_region(args.warmup, args.steps, profile=args.host_profile)
     timers, ops.KERNEL_TIMERS = ops.KERNEL_TIMERS, None
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    other_bn = None
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        # the other BatchNorm mode on the same models and batches (same number of steps; the weights keep training)
+        adist.setup([pna, net], loss_fn, sync_bn=not headline_sync, broadcast=False)
+        o_dt, o_enq, o_ms, o_loss = timed_region(min(args.warmup, 10), args.steps)
+        other_bn = dict(sync_bn=not headline_sync, value=round(args.steps * args.batch * world / o_dt, 1), unit='molecules/s',
+                        ms_per_step=round(o_dt / args.steps * 1e3, 3), ms_per_step_median=round(o_ms[len(o_ms) // 2], 3),
+                        host_enqueue_ms_per_step=round(o_enq / args.steps * 1e3, 3), final_loss=round(float(o_loss.item()), 5),
+                        note=('per-rank BatchNorm statistics (DistributedDataParallel semantics): NOT the reference\'s loss on the '
+                              'global batch' if headline_sync else
+                              'BatchNorm statistics over the global batch: the mode whose loss matches the reference'))
+        adist.setup([pna, net], loss_fn, sync_bn=headline_sync, broadcast=False)
 
     # secondary figure (SURVEY.md 8d "also report with H2D/collate included", row f1): every step first assembles a
     # fresh batch from the flat dataset on the host (vectorised numpy), copies it and builds the 3D graphs on device
@@ -624,7 +651,9 @@ def main():
                                complete_graph_edges_per_batch=int(batches[0][1].number_of_edges()),
                                optimizer='torch.optim.Adam(fused=True)' if args.torch_adam else 'infomax3d_amd.Adam (torch.optim.Adam subclass: same state and update expressions, one launch of csrc/adam.hip for all parameter tensors)',
                                global_batch=B * world, parallelism=f'dp{world}' if world > 1 else 'single',
-                               sync_bn=(use_dist and args.sync_bn), final_loss=round(float(loss.item()), 5),
+                               sync_bn=headline_sync, sync_bn_provider=(adist.native_sync_provider() if use_dist else None),
+                               **({('local_bn' if headline_sync else 'synchronised_bn'): other_bn} if other_bn else {}),
+                               final_loss=round(float(loss.item()), 5),
                                **({'host_lead_steps_median': sorted(lead_hist)[len(lead_hist) // 2],
                                    'host_lead_steps_min': min(lead_hist)} if lead_hist else {}),
                                host_enqueue_ms_per_step=round(t_enqueue / args.steps * 1e3, 3),
