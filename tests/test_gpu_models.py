@@ -343,6 +343,27 @@ def test_qmugs_conformers_bf16_matmul_vs_oracle(amd, variant, n_mols, hidden, de
         ops.set_matmul_precision(prev)
 
 
+# relative L2 bounds (2D network, 3D network) of the end-to-end bf16 check at 256 molecules x 3 conformers
+E2E_BF16_TOL = {'smooth': (0.13, 0.1), 'as_configured': (0.1, 0.1)}      # measured: smooth <= 0.115 (sum / var aggregators), as configured <= 0.096
+
+
+@pytest.mark.parametrize('variant', ['smooth', 'as_configured'])
+def test_qmugs_conformers_bf16_matmul_end_to_end_at_256_molecules(amd, variant, monkeypatch):
+    """The bf16 matmul mode END TO END: configs[3] shape at 256 molecules x 3 conformers - where
+    the projection head's BatchNorm backward is well-conditioned, unlike the 32-row case of the test above - with the
+    loss's own gradient flowing into both networks: every parameter gradient within 0.1 relative L2 of the fp32 CPU oracle
+    (2e-3 of the largest gradient norm as the floor for the analytically-zero ones), loss 5e-3, embeddings 3e-2.  The size
+    gates of the bf16 storage forms are forced on as in the test above."""
+    ops = importlib.import_module('3dinfomax_amd.ops')
+    monkeypatch.setattr(importlib.import_module('3dinfomax_amd.net3d_native'), 'BF16_STORE_MIN_EDGES', 0)
+    monkeypatch.setenv('I3D_MSG_BF16', 'force')
+    prev = ops.set_matmul_precision('bf16')
+    try:
+        _qmugs_vs_oracle(amd, variant, 256, 'bf16_e2e', hidden=64, depth=2)
+    finally:
+        ops.set_matmul_precision(prev)
+
+
 def _qmugs_vs_oracle(amd, variant, n_mols, precision, hidden=64, depth=2):
     """Gradient check at scale, two variants: `as_configured` keeps the max/min aggregators and readouts - fp32
     rounding may flip the arg-max of a near-tie between two atoms, so the gradients are held to a relative L2 bound;
@@ -386,6 +407,17 @@ def _qmugs_vs_oracle(amd, variant, n_mols, precision, hidden=64, depth=2):
     r2, _ = O.pna_forward(og2, P2, O.pna_config(**kw2), True, capture=cap, route=route)
     r3, _ = O.net3d_forward(og3, P3, O.net3d_config(**kw3), True)
     rloss = O.ntxent_multiple_positives(r2, r3, 0.1)
+    if precision == 'bf16_e2e':
+        # END TO END at a batch where the head's BatchNorm backward is well-conditioned (>= 256 molecules): the loss's OWN
+        # gradient as the upstream of both networks, every parameter gradient against the fp32 oracle in relative L2
+        rloss.backward()
+        loss = amd.NTXentMultiplePositives(tau=0.1)(z2, z3)
+        loss.backward()
+        assert abs(loss.item() - rloss.item()) < 5e-3 * abs(rloss.item())
+        assert rel_err(z2.cpu(), r2.detach()) < 3e-2 and rel_err(z3.cpu(), r3.detach()) < 3e-2
+        grads_close_l2(param_grads(pna), {k: P2[k].grad for k in O.trainable(P2)}, E2E_BF16_TOL[variant][0], 'pna ', floor=2e-3)
+        grads_close_l2(param_grads(net), {k: P3[k].grad for k in O.trainable(P3)}, E2E_BF16_TOL[variant][1], 'net3d ', floor=2e-3)
+        return
     if precision == 'bf16':      # (b) below: a fixed, well-conditioned upstream gradient instead of the loss's
         gen = torch.Generator().manual_seed(17)
         u2, u3 = torch.randn(r2.shape, generator=gen) * 0.01, torch.randn(r3.shape, generator=gen) * 0.01
@@ -966,3 +998,92 @@ def test_full_size_batch_properties(amd):
         assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
     assert abs(loss - lossp) <= 1e-5 * abs(loss)
     assert ((grads - gradsp).norm() / grads.norm()).item() <= 2e-3
+
+
+def _full_size_properties(amd, step, n, tol_z, tol_loss, tol_grad, dup=(7, None)):
+    """shared body of the full-size property tests: `step(order)` -> (z2, z3 or None, conformers per molecule, loss, grads)"""
+    last = n - 1
+    perm = np.random.default_rng(5).permutation(n)
+    z2, z3, conf, loss, grads = step(list(range(n)))
+    assert z2.shape[0] == n and math.isfinite(loss) and bool(torch.isfinite(grads).all())
+    assert torch.equal(z2[dup[0]], z2[last])                       # the duplicated molecule: bit-identical rows
+    if z3 is not None:
+        assert z3.shape[0] == n * conf
+        assert torch.equal(z3[dup[0] * conf:(dup[0] + 1) * conf], z3[last * conf:(last + 1) * conf])
+    z2p, z3p, _, lossp, gradsp = step(list(perm))
+    idx = torch.from_numpy(perm).cuda()
+    pairs = [(z2[idx], z2p)]
+    if z3 is not None:
+        idx3 = (idx[:, None] * conf + torch.arange(conf, device='cuda')[None, :]).flatten()
+        pairs.append((z3[idx3], z3p))
+    errs = [((a - b).abs().max() / b.abs().max()).item() for a, b in pairs]
+    gerr = ((grads - gradsp).norm() / grads.norm()).item()
+    if os.environ.get('I3D_TEST_VERBOSE'):
+        print(f'full-size properties: embeddings {errs}, loss {abs(loss - lossp) / abs(loss):.2e}, gradients {gerr:.2e}')
+    assert all(e <= tol_z for e in errs), errs
+    assert abs(loss - lossp) <= tol_loss * abs(loss)
+    assert gerr <= tol_grad, gerr
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_full_size_qmugs_batch_properties(amd, precision):
+    """configs[3] at its FULL size (pre-train_QMugs.yml: 500 molecules x 3 conformers, un-filtered atom counts, hidden 200,
+    depth 7, NTXentMultiplePositives; ~24 k atoms, ~3.9 M complete-graph edges), fp32 and the bf16 matmul mode with its size
+    gates NATURALLY on (bf16 storage of the 3D edge stage from 2^20 edges, of the messages from 32 MB; split-K slice counts
+    for K in the 100 k) - through the properties of test_full_size_batch_properties: the duplicated molecule gets
+    bit-identical rows in both embeddings (all three conformers), reordering the molecules reorders the rows and leaves
+    loss and gradients unchanged up to summation order (bf16: up to operands that round the other way, 2^-9 each)."""
+    ops = importlib.import_module('3dinfomax_amd.ops')
+    n = 500
+    mols = synth.make_dataset(n - 1, seed=61, kind='qmugs')
+    mols = mols + [mols[7]]
+    rng = np.random.default_rng(62)
+    confs = [synth.conformers(m, rng, 3) for m in mols[:-1]]
+    confs.append(confs[7])
+
+    def step(order):
+        torch.manual_seed(9)
+        pna = amd.PNA(avg_d=1.0, device='cuda:0', **dict(PNA_YML, propagation_depth=7)).cuda().train()
+        net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_YML).cuda().train()
+        g2 = amd.batch([amd.bond_graph(mols[i]) for i in order]).to('cuda:0')
+        g3 = amd.batch([amd.complete_graph(mols[i], c) for i in order for c in confs[i]]).to('cuda:0')
+        if precision == 'bf16':      # the gates are on by size, not forced
+            assert g3.number_of_edges() >= importlib.import_module('3dinfomax_amd.net3d_native').BF16_STORE_MIN_EDGES
+            assert g2.number_of_edges() * 200 * 4 >= 32 << 20
+        z2, z3 = pna(g2), net(g3)
+        loss = amd.NTXentMultiplePositives(tau=0.1)(z2, z3)
+        loss.backward()
+        grads = torch.cat([p.grad.flatten() for p in list(pna.parameters()) + list(net.parameters())])
+        return z2.detach(), z3.detach(), 3, loss.item(), grads
+
+    prev = ops.set_matmul_precision(precision)
+    try:
+        # measured: fp32 embeddings 9e-7, loss 0, gradients 3.5e-5; bf16 4.3e-3 / 1.4e-5 / 3.7e-2
+        tz, tl, tg = (1e-5, 1e-5, 1e-3) if precision == 'fp32' else (1e-2, 1e-3, 8e-2)
+        _full_size_properties(amd, step, n, tz, tl, tg)
+    finally:
+        ops.set_matmul_precision(prev)
+
+
+def test_full_size_finetune_batch_properties(amd):
+    """configs[4] at its FULL size (tune_QM9_homo.yml: PNA only, batch 1024, depth 7, readout min / max / mean / sum, L1 loss
+    on one target): duplicate-molecule bit equality, batch-order equivariance of the predictions, loss and gradients."""
+    n = 1024
+    mols = synth.make_dataset(n - 1, seed=71)
+    mols = mols + [mols[7]]
+    targets = torch.randn(n, 1, generator=torch.Generator().manual_seed(72))
+    targets[n - 1] = targets[7]
+    kw = dict(PNA_YML, target_dim=1, batch_norm_momentum=0.1, propagation_depth=7, readout_aggregators=['min', 'max', 'mean', 'sum'])
+
+    def step(order):
+        torch.manual_seed(9)
+        pna = amd.PNA(avg_d=1.0, device='cuda:0', **kw).cuda().train()
+        g2 = amd.batch([amd.bond_graph(mols[i]) for i in order]).to('cuda:0')
+        z = pna(g2)
+        loss = torch.nn.L1Loss()(z, targets[torch.as_tensor(order)].cuda())
+        loss.backward()
+        grads = torch.cat([p.grad.flatten() for p in pna.parameters()])
+        return z.detach(), None, 1, loss.item(), grads
+
+    # (the sign() of an L1 residual within rounding of 0 may flip with the summation order: one row's gradient either way)
+    _full_size_properties(amd, step, n, 1e-5, 1e-5, 2e-3)      # measured 6e-7 / 0 / 1e-4
