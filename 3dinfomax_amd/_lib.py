@@ -101,6 +101,10 @@ class BnEvalAff(ctypes.Structure):
                 ('eps', c_float)]
 
 
+class CopyBlock(ctypes.Structure):
+    _fields_ = [('src', _P), ('dst', _P), ('rows', c_int), ('cols', c_int), ('ld_src', c_long), ('ld_dst', c_long)]
+
+
 ALL_GATHER_F32 = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p)
 ALL_REDUCE_F64 = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_long, c_void_p)
 
@@ -130,6 +134,7 @@ _SIGNATURES = {
     'i3d_rccl_init': (c_int, [ctypes.c_char_p, c_int, c_int, POINTER(c_void_p)]),
     'i3d_rccl_destroy': (c_int, [_P]),
     'i3d_set_collectives_rccl': (c_int, [_P, c_int, _P, c_long]),
+    'i3d_block_copy': (c_int, [_P, c_int, c_int, _P]),
     'i3d_peer_mailbox_bytes': (c_long, []),
     'i3d_peer_handle_bytes': (c_int, []),
     'i3d_peer_alloc': (c_int, [POINTER(c_void_p), ctypes.c_char_p]),

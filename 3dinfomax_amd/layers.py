@@ -245,8 +245,8 @@ class FCFn(torch.autograd.Function):
             _call('i3d_fc_bn_bwd', a)
             return gx, gW, gbias, gg, gb, grad_res, None
         grad_pre, gg, gb = _Tail.backward(ctx.saved, grad_y, gamma, beta, ctx.spec)
-        gW = torch.empty_like(W) if ctx.needs_input_grad[1] else None
-        gbias = torch.empty(W.shape[0], dtype=W.dtype, device=W.device) if ctx.needs_input_grad[2] else None
+        gW = tape.grad_like(W) if ctx.needs_input_grad[1] else None
+        gbias = tape.grad_for_bias_of(W, W.shape[0]) if ctx.needs_input_grad[2] else None
         with fork(grad_pre, x) as f:            # weight/bias gradients next to the data gradient (streams.py)
             if gW is not None:
                 ops.gemm(grad_pre, x, trans_a=True, out=gW)
@@ -278,8 +278,8 @@ class Concat2FCFn(torch.autograd.Function):
         grad_y = grad_y.contiguous()
         grad_res = grad_y if ctx.has_res else None
         grad_pre, gg, gb = _Tail.backward(ctx.saved, grad_y, gamma, beta, ctx.spec)
-        gW = torch.empty_like(W)
-        gbias = torch.empty(W.shape[0], dtype=W.dtype, device=W.device)
+        gW = tape.grad_like(W)
+        gbias = tape.grad_for_bias_of(W, W.shape[0])
         with fork(grad_pre, a, c) as f:
             ops.gemm(grad_pre, c, trans_a=True, out=gW[:, Fa:])
             ops.gemm(grad_pre, a, trans_a=True, out=gW[:, :Fa])
@@ -450,11 +450,11 @@ class EdgeFCFn(torch.autograd.Function):
             _call('i3d_edge_fc_bn_bwd', a)
             return gh, gq, gW, gbias, gg, gb, None, None, None
         grad_pre, gg, gb = _Tail.backward(ctx.saved, grad_y.contiguous(), gamma, beta, ctx.spec)
-        gW = torch.empty_like(W)
+        gW = tape.grad_like(W)
         gP = torch.empty(N, 2 * Fo, dtype=torch.float32, device=h.device)
         ops.segment_sum(grad_pre, idx.out_ptr, idx.out_epos, N, out=gP[:, :Fo])     # d P[src]
         ops.segment_sum(grad_pre, idx.in_ptr, None, N, out=gP[:, Fo:])              # d P[dst]
-        gbias = torch.empty(Fo, dtype=W.dtype, device=W.device)
+        gbias = tape.grad_for_bias_of(W, Fo)
         qmap = ctx.qmap if ctx.has_q else None
         gQ = None
         if qmap is not None:      # dQ[v] = sum of dpre over the edges of category v

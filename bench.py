@@ -256,30 +256,32 @@ def extra_workloads(amd, ops, dev, depth):
                                   batch=B5, depth=depth)
     del pna
     # ---- the tower variant (reference configs/pna_original.yml:37-72, models/pna_original.py): hidden 90 in
-    # 5 towers, edge features 70, graph norm, L1 loss, batch 128 - sequenced per block from Python, the same HIP kernels (the
-    # towers are tiny GEMMs: a functional figure, not a tuned one)
-    B6 = 128
-    mols = amd.synth.make_dataset(B6, seed=6000)
-    g2 = amd.batch([amd.bond_graph(m) for m in mols]).to(dev)
-    snorm = torch.cat([torch.full((m.n_atoms, 1), float(m.n_atoms) ** -0.5) for m in mols]).to(dev)
-    targets = torch.randn(B6, 1, device=dev)
-    torch.manual_seed(123)
-    orig = amd.PNAOriginal(target_dim=1, hidden_dim=90, last_layer_dim=90, mid_batch_norm=True, last_batch_norm=True, graph_norm=True,
-                           readout_batchnorm=True, edge_hidden_dim=70, readout_hidden_dim=70, readout_layers=2, dropout=0.0,
-                           in_feat_dropout=0.0, propagation_depth=4, towers=5, divide_input_first=False, divide_input_last=True,
-                           aggregators=['mean', 'max', 'min', 'std'], scalers=['identity', 'amplification', 'attenuation'],
-                           readout_aggregators=['mean', 'max', 'min', 'sum'], pretrans_layers=1, posttrans_layers=1, residual=True,
-                           gru=False, avg_d=1.0, device=dev).to(dev).train()
-    optim = amd.Adam(list(orig.parameters()), lr=1e-4, fused=True)
-    l1 = torch.nn.L1Loss()
+    # 5 towers, edge features 70, graph norm, L1 loss, batch 128 and 512 - the towers of a layer stacked into one wide layer
+    # (3dinfomax_amd/pna_original.py: _TowerStacks), blocks sequenced from Python under one autograd node, the same HIP kernels
+    for B6 in (128, 512):
+        mols = amd.synth.make_dataset(B6, seed=6000)
+        g2 = amd.batch([amd.bond_graph(m) for m in mols]).to(dev)
+        snorm = torch.cat([torch.full((m.n_atoms, 1), float(m.n_atoms) ** -0.5) for m in mols]).to(dev)
+        targets = torch.randn(B6, 1, device=dev)
+        torch.manual_seed(123)
+        orig = amd.PNAOriginal(target_dim=1, hidden_dim=90, last_layer_dim=90, mid_batch_norm=True, last_batch_norm=True, graph_norm=True,
+                               readout_batchnorm=True, edge_hidden_dim=70, readout_hidden_dim=70, readout_layers=2, dropout=0.0,
+                               in_feat_dropout=0.0, propagation_depth=4, towers=5, divide_input_first=False, divide_input_last=True,
+                               aggregators=['mean', 'max', 'min', 'std'], scalers=['identity', 'amplification', 'attenuation'],
+                               readout_aggregators=['mean', 'max', 'min', 'sum'], pretrans_layers=1, posttrans_layers=1, residual=True,
+                               gru=False, avg_d=1.0, device=dev).to(dev).train()
+        optim = amd.Adam(list(orig.parameters()), lr=1e-4, fused=True)
+        l1 = torch.nn.L1Loss()
 
-    def orig_step(i):
-        l1(orig(g2.local_copy(), snorm), targets).backward()
-        optim.step()
-        optim.zero_grad()
-    ms, host = window(orig_step, 5, 20)
-    out['pna_original_towers'] = dict(ms_per_step=round(ms, 3), molecules_per_s=round(B6 / ms * 1e3, 1), host_enqueue_ms=round(host, 3),
-                                      batch=B6, depth=4, towers=5, hidden=90, loss='L1Loss')
+        def orig_step(i):
+            l1(orig(g2.local_copy(), snorm), targets).backward()
+            optim.step()
+            optim.zero_grad()
+        ms, host = window(orig_step, 5, 20)
+        out['pna_original_towers' if B6 == 128 else f'pna_original_towers_batch{B6}'] = dict(
+            ms_per_step=round(ms, 3), molecules_per_s=round(B6 / ms * 1e3, 1), host_enqueue_ms=round(host, 3), batch=B6, depth=4,
+            towers=5, hidden=90, loss='L1Loss', form='the towers of a layer stacked into one wide layer, the model as one autograd node')
+        del orig, optim
     return out
 
 

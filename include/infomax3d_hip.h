@@ -303,6 +303,16 @@ int i3d_ntxent_loss_bwd(const float* z1, const float* z2, int b1, int b2, int co
 int i3d_row_axpy(const float* z, const float* coef, int rows, int dim, float* out, void* stream);
 /* out[r,:] = coef[r] * z[r,:]   (graph-size normalisation h * snorm_n, reference models/pna_original.py:258-259) */
 int i3d_row_scale(const float* z, const float* coef, int rows, int dim, float* out, void* stream);
+/* ---- the tower variant's stacked parameters (csrc/pack.hip; reference models/pna_original.py:264-319: `towers` PNATowers per
+ * layer, outputs concatenated) - n_blocks 2-D copies src[rows, cols] (pitch ld_src) -> dst (pitch ld_dst) in ONE launch, the
+ * table in device memory; reverse != 0: dst -> src (stacked gradients / running statistics back to the towers' tensors) */
+typedef struct {
+    const float* src;
+    float* dst;
+    int rows, cols;
+    long ld_src, ld_dst;
+} I3dCopyBlock;
+int i3d_block_copy(const I3dCopyBlock* table /* device */, int n_blocks, int reverse, void* stream);
 
 /* ---- BatchNorm out of the memory path (csrc/fused_bn.hip, csrc/gemm.hip; reference models/base_layers.py:100-111) ----
  * Column statistics as per-row-tile partials  partial[tile][3][feat] = {sum, M2 about the tile mean, row count},

@@ -54,10 +54,17 @@ def test_oracle_matches_reference_fixture(tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('tag', ['orig', 'simple'])
-def test_hip_modules_match_reference_fixture(tag):
+@pytest.mark.parametrize('tag', ['orig', 'simple', 'orig_per_tower'])
+def test_hip_modules_match_reference_fixture(tag, monkeypatch):
+    """orig: the towers of a layer stacked into one wide layer (3dinfomax_amd/pna_original.py: _TowerStacks - the default);
+    orig_per_tower: one tower after the other (I3D_TOWER_STACK=0)."""
     assert torch.cuda.is_available()
     amd = importlib.import_module('3dinfomax_amd')
+    po = importlib.import_module('3dinfomax_amd.pna_original')
+    stacked = tag == 'orig'
+    if tag == 'orig_per_tower':
+        monkeypatch.setattr(po, 'TOWER_STACK', False)
+        tag = 'orig' 
     z = load('pna_original.npz')
     mols = mols_from_npz(z)
     model = amd.PNAOriginal(**PNA_ORIG_KW) if tag == 'orig' else amd.PNAOriginalSimple(**PNA_SIMPLE_KW)
@@ -78,6 +85,69 @@ def test_hip_modules_match_reference_fixture(tag):
     for k, v in sd_from_npz(z, f'{tag}/sd_after').items():
         if 'running' in k:
             assert close(sd[k], v, 1e-4, 1e-6), k
+    if tag == 'orig':
+        assert isinstance(model.__dict__.get('_i3d_stacks'), po._TowerStacks) == stacked
+        for k, v in sd.items():
+            if k.endswith('num_batches_tracked') and 'towers' in k:
+                assert int(v) == 1, k
+
+
+PNA_ORIG_YML = dict(target_dim=1, hidden_dim=90, last_layer_dim=90, mid_batch_norm=True, last_batch_norm=True, graph_norm=True,
+                    readout_batchnorm=True, edge_hidden_dim=70, readout_hidden_dim=70, readout_layers=2, dropout=0.0,
+                    in_feat_dropout=0.0, propagation_depth=4, towers=5, divide_input_first=False, divide_input_last=True,
+                    aggregators=['mean', 'max', 'min', 'std'], scalers=['identity', 'amplification', 'attenuation'],
+                    readout_aggregators=['mean', 'max', 'min', 'sum'], pretrans_layers=1, posttrans_layers=1, residual=True,
+                    gru=False, avg_d=1.0, device='cpu')
+
+
+@pytest.mark.gpu
+def test_stacked_towers_equal_the_per_tower_path_on_the_yml_configuration(monkeypatch):
+    """reference configs/pna_original.yml:37-72 (hidden 90, 5 towers, edge features 70, depth 4): three optimisation steps with
+    the stacked layers against the same steps one tower after the other - same arithmetic up to the order of the GEMMs'
+    sums (zeros in the stacked weights add nothing): outputs, every parameter and buffer after the steps; then the
+    eval-mode forward of both."""
+    amd = importlib.import_module('3dinfomax_amd')
+    po = importlib.import_module('3dinfomax_amd.pna_original')
+    synth = importlib.import_module('3dinfomax_amd.synth')
+    mols = synth.make_dataset(48, seed=77)
+    snorm = O.snorm_n([m.n_atoms for m in mols]).cuda()
+    targets = torch.randn(48, 1, generator=torch.Generator().manual_seed(3)).cuda()
+    res = {}
+    for stacked in (True, False):
+        monkeypatch.setattr(po, 'TOWER_STACK', stacked)
+        torch.manual_seed(5)
+        model = amd.PNAOriginal(**PNA_ORIG_YML)
+        with torch.no_grad():       # O(1) activations in front of the BatchNorms
+            for n, p in model.named_parameters():
+                if n.endswith('linear.weight'):
+                    p.mul_(p.shape[1] * 0.5)
+        model.cuda().train()
+        optim = amd.Adam(list(model.parameters()), lr=1e-3)
+        g2 = amd.batch([amd.bond_graph(m) for m in mols]).to('cuda:0')
+        outs, first_grads = [], None
+        for _ in range(3):
+            out = model(g2.local_copy(), snorm)
+            torch.nn.L1Loss()(out, targets).backward()
+            if first_grads is None:
+                first_grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+            optim.step()
+            optim.zero_grad()
+            outs.append(out.detach().clone())
+        model.eval()
+        with torch.no_grad():
+            outs.append(model(g2.local_copy(), snorm).clone())
+        torch.cuda.synchronize()
+        res[stacked] = (outs, {k: v.detach().clone().float() for k, v in model.state_dict().items() if 'running' in k or 'tracked' in k},
+                        first_grads)
+        assert isinstance(model.__dict__.get('_i3d_stacks'), po._TowerStacks) == stacked
+    for a, b in zip(res[True][0], res[False][0]):
+        assert rel_err(a.cpu(), b.cpu()) < 2e-4
+    # (the weights after three Adam steps are not compared: Adam turns a gradient element that is rounding noise into a
+    # +-lr step, on both sides; the outputs of the steps above and the gradients of the first step are)
+    assert set(res[True][2]) == set(res[False][2])
+    grads_close({k: v.cpu() for k, v in res[True][2].items()}, {k: v.cpu() for k, v in res[False][2].items()}, 1e-3)
+    for k, v in res[False][1].items():      # (running statistics after three steps of slightly different weights)
+        assert close(res[True][1][k], v, 2e-2, 1e-3), k
 
 
 def test_state_dict_surface_of_original_variants():
