@@ -887,6 +887,20 @@ gemm_f32_fused_kernel(GemmArgs g) {
     gemm_body<S, true, true, true, false, FUSE, BF16>(g, bx, by, 0, g.K, g.C, nullptr, true);
 }
 
+// The same with five waves per SIMD asked of the register allocator, for the four-wave 64x64 shape in fp32 (82 + 16 registers
+// -> 88, no spill; the two-wave 64x32 shape would spill).  [E, 200] x [200, 200] is 1040 tiles: at four workgroups per CU the
+// chip holds 1024 and the last 16 run as a second round - the statistics variant of that GEMM 35.4 -> 30.7 us, the fused
+// (prologue + statistics) one 40.2 -> 34.0 us back to back (tools/fused_gemm_bench.py), step 2.163 -> 2.144 ms.
+// I3D_FUSED_OCC5=0: off.
+template <class S, int FUSE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5)))
+gemm_f32_fused_o5_kernel(GemmArgs g) {
+    I3D_CHAIN_PRIO();
+    int bx, by, bz;
+    xcd_tile(bx, by, bz);
+    gemm_body<S, true, true, true, false, FUSE, false>(g, bx, by, 0, g.K, g.C, nullptr, true);
+}
+
 template <class S>
 static void launch_fused(const GemmArgs& g, int fuse, hipStream_t s) {
     dim3 grid(cdiv(g.M, S::BM), cdiv(g.N, S::BN), 1), block(S::NT);
@@ -897,6 +911,17 @@ static void launch_fused(const GemmArgs& g, int fuse, hipStream_t s) {
             default: hipLaunchKernelGGL((gemm_f32_fused_kernel<S, 3, true>), grid, block, 0, s, g); break;
         }
         return;
+    }
+    static const bool occ5 = [] { const char* e = getenv("I3D_FUSED_OCC5"); return e == nullptr || e[0] != '0'; }();
+    if constexpr (S::WAVES_N == 2 && S::BK == 16) {
+        if (occ5) {
+            switch (fuse) {
+                case 1: hipLaunchKernelGGL((gemm_f32_fused_o5_kernel<S, 1>), grid, block, 0, s, g); break;
+                case 2: hipLaunchKernelGGL((gemm_f32_fused_o5_kernel<S, 2>), grid, block, 0, s, g); break;
+                default: hipLaunchKernelGGL((gemm_f32_fused_o5_kernel<S, 3>), grid, block, 0, s, g); break;
+            }
+            return;
+        }
     }
     switch (fuse) {
         case 1: hipLaunchKernelGGL((gemm_f32_fused_kernel<S, 1>), grid, block, 0, s, g); break;
