@@ -70,8 +70,9 @@ def parse():
                     help='qm9: BASELINE.json configs[1] (the metric); qmugs: configs[3] shape - QMugs-shaped molecules (~55 atoms), '
                          '3 conformers per molecule, NTXentMultiplePositives, batch 500, PNA depth 7 (pre-train_QMugs.yml), fp32')
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
-                    help='matmul precision: fp32 (configs[1], default) or bf16 operands on the bf16 matrix pipe with fp32 '
-                         'accumulation, fp32 tensors / BatchNorm statistics / master weights (configs[3])')
+                    help='matmul precision: fp32 (configs[1], default) or the bf16 MATMUL mode - bf16-rounded operands on the bf16 '
+                         'matrix pipe with fp32 accumulation; tensors, BatchNorm statistics, master weights stay fp32 (configs[3]: '
+                         'a matmul mode, not bf16 storage)')
     ap.add_argument('--no-families', action='store_true', help='skip the per-family roofline block (tools/family_bench.py)')
     ap.add_argument('--loader-workers', type=int, default=4,
                     help='DataLoader worker processes of the with-batch-assembly figure (0: assemble in the training thread)')
@@ -184,7 +185,7 @@ def extra_workloads(amd, ops, dev, depth):
             optim.zero_grad()
         ms, host = window(step, 10, 40)
         out[name] = dict(ms_per_step=round(ms, 3), molecules_per_s=round(B1 / ms * 1e3, 1), host_enqueue_ms=round(host, 3), batch=B1,
-                         depth=depth, matmul=dtype, weight_gradients='split bf16 x3' if env else ('bf16' if dtype == 'bf16' else 'fp32'))
+                         depth=depth, matmul=dtype + (' matmul mode (fp32 storage)' if dtype == 'bf16' else ''), weight_gradients='split bf16 x3' if env else ('bf16' if dtype == 'bf16' else 'fp32'))
         ops.set_matmul_precision(prev)
         for k, v in saved_env.items():
             if v is None:
@@ -215,7 +216,8 @@ def extra_workloads(amd, ops, dev, depth):
         ms, host = window(step, 5, 15)
         out[f'qmugs_shape_{dtype}'] = dict(ms_per_step=round(ms, 3), molecules_per_s=round(B3 / ms * 1e3, 1), host_enqueue_ms=round(host, 3),
                                            batch=B3, conformers=3, depth=7, atoms=int(g2.number_of_nodes()),
-                                           complete_graph_edges=int(g3.number_of_edges()), matmul=dtype)
+                                           complete_graph_edges=int(g3.number_of_edges()),
+                                           matmul=dtype + (' matmul mode (fp32 storage but the 3D edge stage and the messages, by size)' if dtype == 'bf16' else ''))
         ops.set_matmul_precision(prev)
         del pna, net, optim
     del g2, g3
@@ -641,9 +643,12 @@ def main():
                    ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
                    vs_baseline=None, dtype='f32' if args.dtype == 'fp32' else 'bf16', data='synthetic',
                    config=dict(precision=('fp32 (exact fp32 products on the fp32 matrix pipe)' if args.dtype == 'fp32' else
-                                          'bf16 matmul operands (rounded when a lane reads its MFMA fragments) on '
-                                          'v_mfma_f32_*_bf16, fp32 accumulation; tensors in HBM, BatchNorm statistics, '
-                                          'master weights, Adam in fp32; the hidden-20 products of the 3D network stay fp32'),
+                                          'bf16 MATMUL mode - not bf16 storage: every GEMM multiplies bf16-rounded operands on '
+                                          'v_mfma_f32_*_bf16 with fp32 accumulation; all tensors in HBM (activations, gradients, '
+                                          'master weights, Adam state) and the BatchNorm statistics stay fp32, except - by size - '
+                                          'the [E3,20] edge activations of the 3D network and the [E,F] messages, which are '
+                                          'stored as bf16 once they no longer fit the Infinity Cache (>= 2^20 edges / >= 32 MB); '
+                                          'the hidden-20 products of the 3D network stay fp32'),
                                workload=(f'configs[3] shape: PNA hidden=200 depth={args.depth} + Net3D hidden=20 + '
                                          f'NTXentMultiplePositives tau=0.1, QMugs-shaped synthetic molecules, 3 conformers, batch {B}/GPU, Adam'
                                          if qmugs else
