@@ -105,6 +105,18 @@ class CopyBlock(ctypes.Structure):
     _fields_ = [('src', _P), ('dst', _P), ('rows', c_int), ('cols', c_int), ('ld_src', c_long), ('ld_dst', c_long)]
 
 
+class TowerLayerArgs(ctypes.Structure):
+    _fields_ = ([(n, c_int) for n in ('num_nodes', 'num_edges', 'f_in', 'f_edge', 'f_msg', 'f_out', 'f_mix', 'ldp', 'ldq', 'ldgp',
+                                      'ldgq', 'n_aggregators', 'n_scalers', 'residual', 'training', 'grad_e_accumulate')]
+                + [('aggregators', c_int * 8), ('scalers', c_int * 4), ('avg_d_log', c_float), ('eps', c_float), ('momentum', c_float)]
+                + [(n, _P) for n in ('h', 'e', 'snorm', 'Wp', 'bp', 'Wq', 'bq', 'gamma', 'beta', 'running_mean', 'running_var', 'Wm',
+                                     'bm', 'src_s', 'dst_s', 'in_ptr', 'out_ptr', 'out_epos', 'saved', 'scratch', 'workspace',
+                                     'gemm_workspace')]
+                + [('gemm_workspace_bytes', c_long)]
+                + [(n, _P) for n in ('out', 'grad_out', 'grad_h', 'grad_e', 'grad_Wp', 'grad_bp', 'grad_Wq', 'grad_bq', 'grad_gamma',
+                                     'grad_beta', 'grad_Wm', 'grad_bm')])
+
+
 ALL_GATHER_F32 = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p)
 ALL_REDUCE_F64 = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_long, c_void_p)
 
@@ -135,6 +147,10 @@ _SIGNATURES = {
     'i3d_rccl_destroy': (c_int, [_P]),
     'i3d_set_collectives_rccl': (c_int, [_P, c_int, _P, c_long]),
     'i3d_block_copy': (c_int, [_P, c_int, c_int, _P]),
+    'i3d_tower_layer_saved_floats': (c_long, [POINTER(TowerLayerArgs)]),
+    'i3d_tower_layer_scratch_floats': (c_long, [POINTER(TowerLayerArgs)]),
+    'i3d_tower_layer_fwd': (c_int, [POINTER(TowerLayerArgs), _P]),
+    'i3d_tower_layer_bwd': (c_int, [POINTER(TowerLayerArgs), _P]),
     'i3d_peer_mailbox_bytes': (c_long, []),
     'i3d_peer_handle_bytes': (c_int, []),
     'i3d_peer_alloc': (c_int, [POINTER(c_void_p), ctypes.c_char_p]),

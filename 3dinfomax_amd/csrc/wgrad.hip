@@ -394,12 +394,13 @@ __device__ __forceinline__ void wgrad_reduce_item(const WgReduceArgs& a, const W
         const long stride = (long)o.m_chunks * o.n_chunks * WG_UNIT_FLOATS;
         const float* p = a.slab + ((long)a.unit_begin[pi] + (long)mc * o.n_chunks + nc) * WG_UNIT_FLOATS + tile * 256 + lane * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int z0 = 0; z0 < zn; z0 += 4) {         // four slices in flight per trip, summed in slice order
-            float4 x[4];
+        constexpr int FL = 8;      // slices in flight per trip (round 3: 4 - a panel has ~12 slices: three dependent round trips), summed in slice order
+        for (int z0 = 0; z0 < zn; z0 += FL) {
+            float4 x[FL];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) x[k] = *reinterpret_cast<const float4*>(p + (long)min(z0 + k, zn - 1) * stride);
+            for (int k = 0; k < FL; ++k) x[k] = *reinterpret_cast<const float4*>(p + (long)min(z0 + k, zn - 1) * stride);
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < FL; ++k)
                 if (z0 + k < zn) { v.x += x[k].x; v.y += x[k].y; v.z += x[k].z; v.w += x[k].w; }
         }
         if (o.kind == I3D_WGRAD_COMBINE) {

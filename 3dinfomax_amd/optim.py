@@ -63,6 +63,7 @@ class Adam(torch.optim.Adam):
         self._native = None          # (_NativeTable, host step count)
         self._host_step = None
         self._steps_unequal = False
+        self._gradless = []
 
     @staticmethod
     def _all_cuda(params):
@@ -79,18 +80,20 @@ class Adam(torch.optim.Adam):
     def _build_lists(self):
         self._steps_unequal = False
         lists = []
+        self._gradless = []          # parameters torch has never seen a gradient for (no state): skipped, as torch.optim.Adam does -
+        #                              e.g. the reference's PNAGNNOriginal.MLP_layer, built but not used by forward
         for group in self.param_groups:
-            ps = group['params']
+            ps = [p for p in group['params'] if p in self.state and len(self.state[p]) > 0]
+            self._gradless += [p for p in group['params'] if not (p in self.state and len(self.state[p]) > 0)]
             if not ps:
                 lists.append(None)
                 continue
-            if not self._plain(group) or any((not p.is_cuda) or p.dtype != torch.float32 or p.device != ps[0].device
-                                             or p not in self.state or len(self.state[p]) == 0 for p in ps):
+            if not self._plain(group) or any((not p.is_cuda) or p.dtype != torch.float32 or p.device != ps[0].device for p in ps):
                 return None
             st = [self.state[p] for p in ps]
             if any((not torch.is_tensor(s['step'])) or (not s['step'].is_cuda) for s in st):
                 return None
-            lists.append((list(ps), [s['exp_avg'] for s in st], [s['exp_avg_sq'] for s in st], [s['step'] for s in st]))
+            lists.append((list(ps), [s['exp_avg'] for s in st], [s['exp_avg_sq'] for s in st], [s['step'] for s in st], len(group['params'])))
         # the step counters of all parameters become views of ONE tensor: a single add per step() instead of a
         # multi-tensor add per group (same values, same dtype; state_dict() keeps working, load_state_dict() rebuilds)
         every = [s for lst in lists if lst is not None for s in lst[3]]
@@ -113,6 +116,9 @@ class Adam(torch.optim.Adam):
         """steady state of the one-launch kernel: same gradient tensor objects as last step, same hyper-parameters ->
         straight to the launch (no tensor lists, no torch.no_grad context: nothing here touches autograd)"""
         nat = self._native
+        for p in self._gradless:
+            if p.grad is not None:       # a parameter that had no gradient so far has one now: torch creates its state
+                return False
         for p, g, ptr in zip(nat.params, nat.grads, nat.param_ptrs):
             # same gradient objects AND the parameter's storage is the one the chunk table points into (a swap of
             # `p.data` - .to(), a checkpoint surgery - keeps p and p.grad alive but moves the memory)
@@ -150,14 +156,17 @@ class Adam(torch.optim.Adam):
             self._host_step = None
             return out
         work = []
+        if any(p.grad is not None for p in self._gradless):
+            self._lists = None
+            return super().step()
         for group, lst in zip(self.param_groups, self._lists):
             if lst is None:
-                if group['params']:
+                if any(p.grad is not None for p in group['params']):
                     self._lists = None
                     return super().step()
                 continue
             ps = lst[0]
-            if len(ps) != len(group['params']) or not self._plain(group):
+            if lst[4] != len(group['params']) or not self._plain(group):
                 self._lists = None
                 return super().step()
             grads = [p.grad for p in ps]
@@ -184,7 +193,7 @@ class Adam(torch.optim.Adam):
                                    beta1=key[1][0], beta2=key[1][1], weight_decay=key[2], eps=key[3], maximize=False,
                                    grad_scale=None, found_inf=None)
                 return None
-        for group, (ps, exp_avgs, exp_avg_sqs, steps), grads in work:
+        for group, (ps, exp_avgs, exp_avg_sqs, steps, _n), grads in work:
             beta1, beta2 = group['betas']
             if self._steps_flat is None:
                 torch._foreach_add_(steps, 1)

@@ -139,8 +139,21 @@ class PNAOriginal(nn.Module):
         h = gnn.embedding_h(g.ndata['feat'])
         e_sorted = gnn.embedding_e(g.edata['feat'], perm=idx.perm) if gnn.edge_feat else None     # destination-sorted
         snorm = snorm_n.to(h.device)
+        snorm_flat = None
         for layer, st in zip(gnn.layers, stacks.layers):
             tw = layer.towers[0]
+            # (an eval-mode layer under a tape may still be differentiated: that backward is sequenced by the block path only)
+            native = TOWER_NATIVE and (layer.training or tape.active() is None) and ops.GEMM_WORKSPACE_BYTES > 0
+            if native:
+                if tw.graph_norm and snorm_flat is None:
+                    snorm_flat = snorm.reshape(-1).contiguous().float()
+                h = tape.apply(_TowerLayerFn, h, e_sorted if tw.edge_features else None, snorm_flat if tw.graph_norm else None,
+                               st.Wp, st.bp, st.Wq, st.bq, st.gamma, st.beta, layer.mixing_network.weight, layer.mixing_network.bias,
+                               idx, st, layer, layer.training)
+                if layer.training:
+                    for c in st.counters:
+                        _layers._bump(c)
+                continue
             msg = tape.apply(EdgeFCFn, h, e_sorted if tw.edge_features else None, st.Wp, st.bp, None, None, idx, st.pre_spec, None)
             agg = tape.apply(AggregateFn, msg, idx, tw.aggregators, tw.scalers, float(tw.avg_d), True)
             x = tape.apply(Concat2FCFn, h, agg, st.Wq, st.bq, st.gamma, st.beta, None, st.post_spec(layer.training))
@@ -282,6 +295,7 @@ class _TowerStacks:
         self.t_stats = table([entry(b, st, lambda t: t, False) for st in self.layers for b in st.stat_blocks])
         self.t_grads = table([entry(b, st, lambda t: self.pgrad[id(t)], True) for st in self.layers for b in st.param_blocks])
         self._pool = None
+        self.other_grad = {}         # id(parameter outside the towers) -> its persistent gradient buffer
 
     def _copy(self, tab, reverse):
         dev, n = tab
@@ -298,14 +312,19 @@ class _TowerStacks:
     def unpack_grads(self):
         self._copy(self.t_grads, True)
 
-    def grad_pool(self):
+    def grad_pool(self, others=()):
         """what tape.grad_like / grad_for_bias_of consult during the backward pass: the stacked leaves' gradients are written
-        straight into the stacked gradient buffer"""
+        straight into the stacked gradient buffer, the other parameters' (`others`: encoders, mixing networks, head) into
+        persistent buffers of their own - the optimizer's one-launch kernel keeps its pointer table from step to step"""
         pool = self._pool
-        if pool is None:
+        if pool is None or any(id(p) not in self.other_grad for p in others):
+            for p in others:
+                if id(p) not in self.other_grad:
+                    self.other_grad[id(p)] = torch.zeros_like(p)
             pool = self._pool = tape._GradPool.__new__(tape._GradPool)
             pool.key = ()
             pool.view_of = {id(v): g for v, g in zip(self.leaves, self.leaf_grads)}
+            pool.view_of.update(self.other_grad)
             pool.bias_of = {k: b for st in self.layers for k, b in st.bias_of.items()}
             pool.used = set()
         pool.used.clear()
@@ -358,6 +377,80 @@ def _stacks_for(model):
     return st
 
 
+# I3D_TOWER_NATIVE=0: the stacked layer as five block Functions sequenced from Python instead of one C call per direction
+TOWER_NATIVE = os.environ.get('I3D_TOWER_NATIVE', '1') != '0'
+
+
+class _TowerLayerFn(torch.autograd.Function):
+    """A stacked PNALayer from ONE C call per direction (csrc/tower.hip: i3d_tower_layer_fwd / _bwd) - the kernels and the
+    operands of the five blocks _forward_stacked sequences from Python (edge block, aggregation, concat block with BatchNorm,
+    row scale, mixing block), with the layout of saved activations and scratch computed in C."""
+
+    @staticmethod
+    def forward(ctx, h, e, snorm, Wp, bp, Wq, bq, gamma, beta, Wm, bm, idx, st, layer, training):
+        h = h.contiguous()
+        dev = h.device
+        tw = layer.towers[0]
+        a = _lib.TowerLayerArgs()
+        a.num_nodes, a.num_edges, a.f_in = h.shape[0], idx.num_edges, h.shape[1]
+        a.f_edge = e.shape[1] if e is not None else 0
+        a.f_msg, a.f_out, a.f_mix = Wp.shape[0], Wq.shape[0], Wm.shape[0]
+        a.ldp, a.ldq = Wp.stride(0), Wq.stride(0)
+        a.n_aggregators, a.n_scalers = len(tw.aggregators), len(tw.scalers)
+        for i, v in enumerate(tw.aggregators):
+            a.aggregators[i] = v
+        for i, v in enumerate(tw.scalers):
+            a.scalers[i] = v
+        a.avg_d_log = float(tw.avg_d)
+        a.residual, a.training = int(layer.residual), int(training)
+        a.h, a.e = h.data_ptr(), (e.data_ptr() if e is not None else None)
+        a.snorm = snorm.data_ptr() if snorm is not None else None
+        a.Wp, a.bp, a.Wq, a.bq = Wp.data_ptr(), bp.data_ptr(), Wq.data_ptr(), bq.data_ptr()
+        if gamma is not None:
+            a.gamma, a.beta = gamma.data_ptr(), beta.data_ptr()
+            a.running_mean, a.running_var = st.rmean.data_ptr(), st.rvar.data_ptr()
+            a.momentum, a.eps = st._bn
+        a.Wm, a.bm = Wm.data_ptr(), bm.data_ptr()
+        a.src_s, a.dst_s, a.in_ptr = idx.src_s.data_ptr(), idx.dst_s.data_ptr(), idx.in_ptr.data_ptr()
+        a.out_ptr, a.out_epos = idx.out_ptr.data_ptr(), idx.out_epos.data_ptr()
+        L = _lib.load()
+        saved = torch.empty(L.i3d_tower_layer_saved_floats(ctypes.byref(a)), dtype=torch.float32, device=dev)
+        scratch = torch.empty(L.i3d_tower_layer_scratch_floats(ctypes.byref(a)), dtype=torch.float32, device=dev)
+        out = torch.empty(h.shape[0], Wm.shape[0], dtype=torch.float32, device=dev)
+        a.saved, a.scratch, a.out = saved.data_ptr(), scratch.data_ptr(), out.data_ptr()
+        a.workspace = ops._workspace(max(a.f_msg, a.f_out), dev).data_ptr()
+        _lib.check(L.i3d_tower_layer_fwd(ctypes.byref(a), ops._stream()), 'i3d_tower_layer_fwd')
+        ctx.args, ctx.keep = a, (h, e, snorm, Wp, bp, Wq, bq, gamma, beta, Wm, bm, saved)
+        ctx.has_e_grad = e is not None and ctx.needs_input_grad[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        a = ctx.args
+        h, e, snorm, Wp, bp, Wq, bq, gamma, beta, Wm, bm, saved = ctx.keep
+        dev = h.device
+        grad_out = grad_out.contiguous()
+        L = _lib.load()
+        scratch = torch.empty(L.i3d_tower_layer_scratch_floats(ctypes.byref(a)), dtype=torch.float32, device=dev)
+        gh = torch.empty_like(h)
+        ge = torch.empty_like(e) if ctx.has_e_grad else None
+        gWp, gbp, gWq, gbq = tape.grad_like(Wp), tape.grad_like(bp), tape.grad_like(Wq), tape.grad_like(bq)
+        gg = tape.grad_like(gamma) if gamma is not None else None
+        gb = tape.grad_like(beta) if beta is not None else None
+        gWm, gbm = tape.grad_like(Wm), tape.grad_like(bm)
+        a.scratch, a.grad_out, a.grad_h = scratch.data_ptr(), grad_out.data_ptr(), gh.data_ptr()
+        a.grad_e, a.grad_e_accumulate = (ge.data_ptr() if ge is not None else None), 0
+        a.grad_Wp, a.grad_bp, a.grad_Wq, a.grad_bq = gWp.data_ptr(), gbp.data_ptr(), gWq.data_ptr(), gbq.data_ptr()
+        a.ldgp, a.ldgq = gWp.stride(0), gWq.stride(0)
+        a.grad_gamma = gg.data_ptr() if gg is not None else None
+        a.grad_beta = gb.data_ptr() if gb is not None else None
+        a.grad_Wm, a.grad_bm = gWm.data_ptr(), gbm.data_ptr()
+        a.workspace = ops._workspace(max(a.f_msg, a.f_out), dev).data_ptr()        # per thread and stream (autograd's thread here)
+        a.gemm_workspace, a.gemm_workspace_bytes = ops._gemm_workspace(dev).data_ptr(), ops.GEMM_WORKSPACE_BYTES
+        _lib.check(L.i3d_tower_layer_bwd(ctypes.byref(a), ops._stream()), 'i3d_tower_layer_bwd')
+        return gh, ge, None, gWp, gbp, gWq, gbq, gg, gb, gWm, gbm, None, None, None, None
+
+
 class _StackedModelFn(torch.autograd.Function):
     """PNAOriginal with stacked towers as ONE autograd node (tape.ModelFn with the stacked views as additional leaves): pack the
     towers' parameters, run the blocks under a tape; backward: walk the tape (weight gradients land in the stacked gradient
@@ -384,7 +477,8 @@ class _StackedModelFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         stacks = ctx.stacks
-        tape._tls.pool = stacks.grad_pool()
+        others = [p for p in ctx.params if id(p) not in stacks.param_ids]
+        tape._tls.pool = stacks.grad_pool(others)
         try:
             grads = ctx.tape.backward(ctx.out_id, grad.contiguous())
         finally:
@@ -396,13 +490,22 @@ class _StackedModelFn(torch.autograd.Function):
             elif ent[0].data_ptr() != gv.data_ptr():
                 gv.copy_(ent[0])
         stacks.unpack_grads()
-        out = []
+        out, dsts, srcs = [], [], []
         for p in ctx.params:
             if id(p) in stacks.param_ids:
                 out.append(stacks.pgrad[id(p)])
             else:
                 ent = grads.get(id(p))
-                out.append(ent[0] if ent is not None else None)
+                if ent is None:
+                    out.append(None)
+                    continue
+                keep = stacks.other_grad[id(p)]
+                if ent[0].data_ptr() != keep.data_ptr():       # a gradient that was not written through tape.grad_like (the encoders' tables)
+                    dsts.append(keep)
+                    srcs.append(ent[0])
+                out.append(keep)
+        if dsts:
+            torch._foreach_copy_(dsts, srcs)
         if tape.DIRECT_PARAM_GRADS and tape._plain_leaves(ctx.params):
             for p, g in zip(ctx.params, out):
                 if g is not None:

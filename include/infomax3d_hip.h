@@ -314,6 +314,63 @@ typedef struct {
 } I3dCopyBlock;
 int i3d_block_copy(const I3dCopyBlock* table /* device */, int n_blocks, int reverse, void* stream);
 
+/* ---- one PNALayer of the tower variant from ONE call per direction (csrc/tower.hip) --------------------------------------
+ * Replaces PNALayer.forward of reference models/pna_original.py:296-319 (all `towers` PNATower.forward, :239-261, the
+ * concatenation, the mixing network, LeakyReLU and the residual) and its autograd backward, on the STACKED form of the
+ * towers: Wp [f_msg, 2 f_in + f_edge] (pitch ldp) = every tower's pretrans Linear, Wq [f_out, f_in + B f_msg] (pitch ldq) =
+ * every tower's posttrans Linear (B = n_aggregators * n_scalers column blocks of f_msg), bq / gamma / beta / running
+ * statistics [f_out] side by side, Wm [f_mix, f_out] / bm the mixing network.  h [N, f_in], e [E, f_edge] (destination-
+ * sorted, or NULL), snorm [N] or NULL (graph norm), out [N, f_mix]; residual needs f_mix == f_in.  gamma NULL: no BatchNorm.
+ * saved / scratch: i3d_tower_layer_saved_floats / _scratch_floats floats (the forward's `saved` is the backward's).
+ * workspace: i3d_colreduce_workspace_bytes, zero-initialised; gemm_workspace: the split-K scratch of the weight gradients.
+ * Backward: grad_out [N, f_mix] -> grad_h [N, f_in] (written), grad_e [E, f_edge] (written, or added to when
+ * grad_e_accumulate; NULL: not wanted), parameter gradients (grad_Wp / grad_Wq with pitches ldgp / ldgq). */
+typedef struct {
+    int num_nodes, num_edges, f_in, f_edge, f_msg, f_out, f_mix, ldp, ldq, ldgp, ldgq;
+    int n_aggregators, n_scalers, residual, training, grad_e_accumulate;
+    int aggregators[8], scalers[4];
+    float avg_d_log, eps, momentum;
+    const float* h;
+    const float* e;
+    const float* snorm;
+    const float* Wp;
+    const float* bp;
+    const float* Wq;
+    const float* bq;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    const float* Wm;
+    const float* bm;
+    const int* src_s;
+    const int* dst_s;
+    const int* in_ptr;
+    const int* out_ptr;
+    const int* out_epos;
+    float* saved;
+    float* scratch;
+    void* workspace;
+    void* gemm_workspace;
+    long gemm_workspace_bytes;
+    float* out;
+    const float* grad_out;
+    float* grad_h;
+    float* grad_e;
+    float* grad_Wp;
+    float* grad_bp;
+    float* grad_Wq;
+    float* grad_bq;
+    float* grad_gamma;
+    float* grad_beta;
+    float* grad_Wm;
+    float* grad_bm;
+} I3dTowerLayerArgs;
+long i3d_tower_layer_saved_floats(const I3dTowerLayerArgs* a);
+long i3d_tower_layer_scratch_floats(const I3dTowerLayerArgs* a);
+int i3d_tower_layer_fwd(const I3dTowerLayerArgs* a, void* stream);
+int i3d_tower_layer_bwd(const I3dTowerLayerArgs* a, void* stream);
+
 /* ---- BatchNorm out of the memory path (csrc/fused_bn.hip, csrc/gemm.hip; reference models/base_layers.py:100-111) ----
  * Column statistics as per-row-tile partials  partial[tile][3][feat] = {sum, M2 about the tile mean, row count},
  * produced by the kernel that writes the activation; i3d_bn_finalize_partials merges them (fp64, fixed order) into

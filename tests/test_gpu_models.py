@@ -667,6 +667,36 @@ def test_adam_fast_path_is_torch_adam(amd, second_group_wd, native, monkeypatch)
     oa.step()
 
 
+def test_native_adam_skips_parameters_that_never_get_a_gradient(amd):
+    """Parameters the forward never uses (the reference builds some: PNAGNNOriginal.MLP_layer, models/pna_original.py:179) have no
+    gradient and no optimizer state - torch.optim.Adam skips them.  They must not keep the one-launch kernel off: same values
+    as torch over several steps with the native path taken, and a late first gradient for such a parameter is honoured."""
+    torch.manual_seed(2)
+    shapes = [(64, 40), (40,), (9, 5), (12,)]
+    pa = [torch.randn(s, device='cuda:0').requires_grad_() for s in shapes]
+    pb = [p.detach().clone().requires_grad_() for p in pa]
+    oa, ob = amd.Adam(pa, lr=1e-3), torch.optim.Adam(pb, lr=1e-3, fused=True)
+
+    def step(with_last):
+        gs = [torch.randn(s, device='cuda:0') for s in shapes]
+        for i, (p, q, g_) in enumerate(zip(pa, pb, gs)):
+            none = (not with_last) and i == len(shapes) - 1
+            p.grad, q.grad = (None, None) if none else (g_.clone(), g_.clone())
+        oa.step()
+        ob.step()
+
+    def close():
+        return all((p - q).abs().max().item() <= 4e-7 * max(q.abs().max().item(), 1e-30) for p, q in zip(pa, pb))
+    for _ in range(4):
+        step(False)
+    assert close() and oa._native is not None and oa._host_step == 4 and len(oa._gradless) == 1
+    assert torch.equal(pa[-1], pb[-1]) and pa[-1] not in oa.state or len(oa.state[pa[-1]]) == 0
+    for _ in range(3):
+        step(True)                  # the parameter gets its first gradient: torch creates its state, step counts differ
+    assert close()
+    assert [float(oa.state[p]['step']) for p in pa] == [7.0, 7.0, 7.0, 3.0] == [float(ob.state[q]['step']) for q in pb]
+
+
 def test_native_adam_with_unequal_step_counts_a_moved_parameter_and_an_lr_schedule(amd):
     """The one-launch Adam takes ONE step count for its bias corrections: parameters whose `step` differs (a parameter
     that had no gradient for some steps, add_param_group on a trained optimizer, unfreezing) must get torch's

@@ -54,16 +54,20 @@ def test_oracle_matches_reference_fixture(tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('tag', ['orig', 'simple', 'orig_per_tower'])
+@pytest.mark.parametrize('tag', ['orig', 'simple', 'orig_per_tower', 'orig_stacked_blocks'])
 def test_hip_modules_match_reference_fixture(tag, monkeypatch):
-    """orig: the towers of a layer stacked into one wide layer (3dinfomax_amd/pna_original.py: _TowerStacks - the default);
-    orig_per_tower: one tower after the other (I3D_TOWER_STACK=0)."""
+    """orig: the towers of a layer stacked into one wide layer, one C call per layer and direction (3dinfomax_amd/pna_original.py:
+    _TowerStacks, csrc/tower.hip - the default); orig_stacked_blocks: the stacked layer as five block Functions sequenced from
+    Python (I3D_TOWER_NATIVE=0); orig_per_tower: one tower after the other (I3D_TOWER_STACK=0)."""
     assert torch.cuda.is_available()
     amd = importlib.import_module('3dinfomax_amd')
     po = importlib.import_module('3dinfomax_amd.pna_original')
-    stacked = tag == 'orig'
+    stacked = tag in ('orig', 'orig_stacked_blocks')
     if tag == 'orig_per_tower':
         monkeypatch.setattr(po, 'TOWER_STACK', False)
+    if tag == 'orig_stacked_blocks':
+        monkeypatch.setattr(po, 'TOWER_NATIVE', False)
+    if tag.startswith('orig'):
         tag = 'orig' 
     z = load('pna_original.npz')
     mols = mols_from_npz(z)
