@@ -144,19 +144,37 @@ def native_sync_provider():
     return _native_sync['provider'] if _native_sync is not None else None
 
 
+def _all_ok(ok, group):
+    """every rank's `ok` ANDed: a set-up step either holds on every rank or on none (the ranks then take the same fallback)"""
+    flags = [None] * dist.get_world_size(group)
+    dist.all_gather_object(flags, bool(ok), group=group)
+    return all(flags)
+
+
 def _peer_context(L, group, device, timeout_s):
-    """One mailbox of this rank, exported, every rank's handle gathered through `group`, the peers' mailboxes mapped."""
+    """One mailbox of this rank, exported, every rank's handle gathered through `group`, the peers' mailboxes mapped.  Returns the
+    context or None - None on EVERY rank when any rank failed at any step (nothing stays allocated or mapped then)."""
     import ctypes
-    from . import _lib
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     hb = L.i3d_peer_handle_bytes()
     box, handle = ctypes.c_void_p(), ctypes.create_string_buffer(hb)
     with torch.cuda.device(device):
-        _lib.check(L.i3d_peer_alloc(ctypes.byref(box), handle), 'i3d_peer_alloc')
-        handles = [None] * world
-        dist.all_gather_object(handles, bytes(handle.raw), group=group)
+        ok = L.i3d_peer_alloc(ctypes.byref(box), handle) == 0
+        if os.environ.get('I3D_TEST_PEER_FAIL') == str(rank):      # test hook: this rank "cannot" set the exchange up
+            ok = False
+        msgs = [None] * world
+        dist.all_gather_object(msgs, (bool(ok), bytes(handle.raw)), group=group)       # (every rank takes part, failed or not)
         ctx = ctypes.c_void_p()
-        _lib.check(L.i3d_peer_open(box, b''.join(handles), rank, world, float(timeout_s), ctypes.byref(ctx)), 'i3d_peer_open')
+        if all(m[0] for m in msgs):
+            ok = L.i3d_peer_open(box, b''.join(m[1] for m in msgs), rank, world, float(timeout_s), ctypes.byref(ctx)) == 0
+            if not ok:
+                ctx = ctypes.c_void_p()
+        else:
+            ok = False
+        if not _all_ok(ok, group):
+            if ctx:
+                L.i3d_peer_close(ctx)              # (frees the mailbox too)
+            return None
     return ctx
 
 
@@ -193,20 +211,37 @@ def enable_native_sync(group, device, provider=None, timeout_s=0.0):
     if provider == 'peer':
         torch.cuda.synchronize(device)
         main = _peer_context(L, group, device, timeout_s)
-        state['peers'].append(main)
-        _lib.check(L.i3d_set_collectives_peer(main, scratch.data_ptr(), scratch.numel()), 'i3d_set_collectives_peer')
-        if streams.NET3D_STREAM:
+        ok = main is not None
+        if ok:
+            state['peers'].append(main)
+            ok = L.i3d_set_collectives_peer(main, scratch.data_ptr(), scratch.numel()) == 0
+        side = None
+        if _all_ok(ok, group) and streams.NET3D_STREAM:
             # the 3D network's stream: own mailbox, own sequence, own scratch (every rank creates both, in this order)
             side_scratch = torch.zeros(1 << 20, dtype=torch.uint8, device=device)
             side = _peer_context(L, group, device, timeout_s)
-            state['peers'].append(side)
-            state['keep'].append(side_scratch)
-            _lib.check(L.i3d_peer_bind_stream(side, ctypes.c_void_p(streams.side_stream(device).cuda_stream), side_scratch.data_ptr(),
-                                              side_scratch.numel()), 'i3d_peer_bind_stream')
-        _native_sync = state
-        return True
+            ok = side is not None
+            if ok:
+                state['peers'].append(side)
+                state['keep'].append(side_scratch)
+                ok = L.i3d_peer_bind_stream(side, ctypes.c_void_p(streams.side_stream(device).cuda_stream), side_scratch.data_ptr(),
+                                            side_scratch.numel()) == 0
+        if _all_ok(ok, group):
+            _native_sync = state
+            return True
+        # some rank could not set the exchange up (no IPC between these devices, no uncached memory...): every rank tears it
+        # down and takes the next provider - the decision is collective, the ranks never run different providers
+        L.i3d_set_collectives(None)
+        for ctx in state['peers']:
+            L.i3d_peer_close(ctx)
+        state['peers'], state['keep'] = [], [scratch]
+        import warnings
+        warnings.warn('3dinfomax_amd.dist: the peer-write exchange could not be set up on every rank '
+                      f'({L.i3d_last_error().decode() if L.i3d_last_error() else "no message"}); falling back to '
+                      + ('host-staged callbacks' if _is_gloo(group) else 'the RCCL provider'))
+        provider = state['provider'] = 'callbacks' if _is_gloo(group) else 'rccl'
     if provider == 'rccl':
-        if not L.i3d_rccl_available():
+        if not _all_ok(L.i3d_rccl_available(), group):
             return False
         buf = ctypes.create_string_buffer(128)
         if rank == 0:
