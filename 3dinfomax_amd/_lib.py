@@ -154,6 +154,7 @@ _SIGNATURES = {
     'i3d_peer_mailbox_bytes': (c_long, []),
     'i3d_peer_handle_bytes': (c_int, []),
     'i3d_peer_alloc': (c_int, [POINTER(c_void_p), ctypes.c_char_p]),
+    'i3d_peer_free': (c_int, [_P]),
     'i3d_peer_open': (c_int, [_P, ctypes.c_char_p, c_int, c_int, c_double, POINTER(c_void_p)]),
     'i3d_set_collectives_peer': (c_int, [_P, _P, c_long]),
     'i3d_peer_bind_stream': (c_int, [_P, _P, _P, c_long]),

@@ -173,6 +173,12 @@ extern "C" int i3d_peer_alloc(void** mailbox, char* handle_out) {
     return I3D_OK;
 }
 
+// a mailbox that never made it into a context (set-up abandoned because another rank failed)
+extern "C" int i3d_peer_free(void* mailbox) {
+    if (mailbox != nullptr) (void)hipFree(mailbox);
+    return I3D_OK;
+}
+
 // Open every peer's mailbox (handles[world][i3d_peer_handle_bytes()], rank order; this rank's own entry is not opened).
 extern "C" int i3d_peer_open(void* mailbox, const char* handles, int rank, int world, double timeout_s, void** ctx_out) {
     I3D_CHECK_ARG(mailbox != nullptr && ctx_out != nullptr && world >= 1 && world <= PEER_MAX_WORLD && rank >= 0 && rank < world,
@@ -202,16 +208,26 @@ extern "C" int i3d_peer_open(void* mailbox, const char* handles, int rank, int w
         ctx->opened[q] = p;
         ctx->dev.box[q] = (PeerBox*)p;
     }
+    auto undo = [&]() {        // nothing stays mapped or allocated behind a failed open (the mailbox stays the caller's)
+        for (int k = 0; k < world; ++k)
+            if (ctx->opened[k] != nullptr) (void)hipIpcCloseMemHandle(ctx->opened[k]);
+        if (ctx->status_host != nullptr) (void)hipHostFree(ctx->status_host);
+        delete ctx;
+    };
     void* st = nullptr;
     hipError_t e = hipHostMalloc(&st, 64, hipHostMallocMapped);
     if (e != hipSuccess) {
-        delete ctx;
+        undo();
         HIP_TRY(e, "hipHostMalloc");
     }
     std::memset(st, 0, 64);
     ctx->status_host = (int*)st;
     void* st_dev = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(&st_dev, st, 0), "hipHostGetDevicePointer");
+    e = hipHostGetDevicePointer(&st_dev, st, 0);
+    if (e != hipSuccess) {
+        undo();
+        HIP_TRY(e, "hipHostGetDevicePointer");
+    }
     ctx->dev.status = (int*)st_dev;
     *ctx_out = ctx;
     return I3D_OK;

@@ -174,6 +174,8 @@ def _peer_context(L, group, device, timeout_s):
         if not _all_ok(ok, group):
             if ctx:
                 L.i3d_peer_close(ctx)              # (frees the mailbox too)
+            elif box:
+                L.i3d_peer_free(box)
             return None
     return ctx
 

@@ -264,6 +264,9 @@ class _TowerStacks:
     """The stacked layers of one PNAOriginal and the three copy tables (device memory, built once): parameters -> stacked
     values, running statistics <-> stacked statistics, stacked gradients -> per-parameter gradient buffers."""
 
+    def __reduce__(self):          # copy.deepcopy(model) / pickling: the copy starts without stacks (_stacks_for rebuilds them
+        return (type(None), ())    # from ITS parameters: the copy tables hold device pointers)
+
     def __init__(self, model, device):
         self.layers = [_LayerStack(layer, device) for layer in model.node_gnn.layers]
         self.params = [p for st in self.layers for p in st.params]

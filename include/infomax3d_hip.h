@@ -463,6 +463,7 @@ int i3d_set_collectives_rccl(void* comm, int world, void* scratch, long scratch_
 long i3d_peer_mailbox_bytes(void);
 int i3d_peer_handle_bytes(void); /* sizeof(hipIpcMemHandle_t) = 64 */
 int i3d_peer_alloc(void** mailbox /* out: device */, char* handle_out /* host, i3d_peer_handle_bytes() */);
+int i3d_peer_free(void* mailbox); /* a mailbox that did not end up in a context (i3d_peer_close frees the one it owns) */
 int i3d_peer_open(void* mailbox, const char* handles /* host [world][handle bytes], rank order */, int rank, int world,
                   double timeout_s /* <= 0: default */, void** ctx /* out */);
 int i3d_set_collectives_peer(void* ctx, void* scratch, long scratch_bytes);
