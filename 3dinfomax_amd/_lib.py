@@ -264,6 +264,7 @@ _SIGNATURES = {
     'i3d_act_bwd': (c_int, [_P, _P, c_long, c_int, _P, _P]),
     'i3d_add_inplace': (c_int, [_P, _P, c_long, _P]),
     'i3d_add': (c_int, [_P, _P, c_long, _P, _P]),
+    'i3d_mul': (c_int, [_P, _P, c_long, _P, _P]),
     'i3d_broadcast_row': (c_int, [_P, c_long, c_int, _P, _P]),
     'i3d_edge_combine_fwd': (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     'i3d_multihot': (c_int, [_P, _P, c_int, c_int, POINTER(c_int), c_int, _P, _P]),

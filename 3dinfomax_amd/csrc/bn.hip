@@ -759,6 +759,12 @@ __global__ void __launch_bounds__(256) add_kernel(const float* __restrict__ a, c
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) out[t] = a[t] + b[t];
 }
 
+// out = a * b (dropout: b is the mask already scaled by 1 / (1 - p), reference models/base_layers.py:104-105; out may alias a)
+__global__ void __launch_bounds__(256) mul_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, float* out) {
+    I3D_CHAIN_PRIO();
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) out[t] = a[t] * b[t];
+}
+
 __global__ void __launch_bounds__(256) broadcast_row_kernel(const float* __restrict__ row, long rows, int feat,
                                                             float* __restrict__ out) {
     I3D_CHAIN_PRIO();
@@ -1200,6 +1206,13 @@ extern "C" int i3d_add_inplace(float* dst, const float* src, long n, void* strea
 extern "C" int i3d_add(const float* a, const float* b, long n, float* out, void* stream) {
     if (n <= 0) return I3D_OK;
     hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, out);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_mul(const float* a, const float* b, long n, float* out, void* stream) {
+    if (n <= 0) return I3D_OK;
+    hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, out);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }

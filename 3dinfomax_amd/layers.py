@@ -50,6 +50,8 @@ class FCSpec:
     act: Optional[str]               # activation between Linear and BatchNorm
     bn: Optional[BNSpec]
     post_act: Optional[str] = None   # activation after the BatchNorm (Net3D edge_input: silu(BN(silu(.))))
+    dropout: float = 0.0             # nn.Dropout between the activation and the BatchNorm (reference models/base_layers.py:104-105);
+    #                                  0.0 in eval mode.  > 0: the per-kernel path (the composites and native sequencers stand aside)
 
 
 # num_batches_tracked of every BatchNorm touched in a model forward is bumped by ONE multi-tensor op at the end of that
@@ -97,6 +99,8 @@ class _Tail:
     @staticmethod
     def forward(pre, gamma, beta, spec: FCSpec, residual=None):
         bn = spec.bn
+        if spec.dropout > 0.0:
+            return _Tail._forward_dropout(pre, gamma, beta, spec, residual)
         if bn is None:
             acts = [a for a in (spec.act, spec.post_act) if a is not None]
             inputs, y = [], pre
@@ -127,8 +131,62 @@ class _Tail:
         return y, (x, pre if keep_pre else None, bn.running_mean.clone(), bn.running_var.clone())
 
     @staticmethod
+    def _forward_dropout(pre, gamma, beta, spec: FCSpec, residual):
+        """Linear -> activation -> DROPOUT -> BatchNorm (reference models/base_layers.py:100-111): the activation as a pass of its
+        own, the mask torch's dropout kernel draws for this shape (ops.dropout_mask: the reference module's mask for the same
+        seed on this device), BatchNorm statistics of the dropped values.  Training mode only (spec.dropout is 0 in eval)."""
+        bn = spec.bn
+        a = ops.act_fwd(pre, spec.act) if spec.act is not None else pre
+        m = ops.dropout_mask(a, spec.dropout)
+        x = ops.mul(a, m)
+        if bn is None:
+            y = ops.act_fwd(x, spec.post_act) if spec.post_act is not None else x
+            if residual is not None:
+                y = ops.add_inplace(y.clone() if y is x else y, residual)
+            return y, ('dropout', pre, a, x, m, None, None)
+        if bn.sync_group is not None:
+            from . import dist as adist
+            sums = torch.empty(2 * x.shape[1] + 1, dtype=torch.float64, device=x.device)
+            ops.act_stats_fwd(x, None, bn.eps, bn.momentum, sums_out=sums)
+            adist.all_reduce_sum(sums, bn.sync_group)
+            mean, invstd = ops.bn_finalize_stats(sums, x.shape[1], bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+        else:
+            _, mean, invstd = ops.act_stats_fwd(x, None, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+        _bump(bn.num_batches_tracked)
+        y = ops.bn_apply_fwd(x, mean, invstd, gamma, beta, spec.post_act, residual)
+        return y, ('dropout', pre, a, x, m, mean, invstd)
+
+    @staticmethod
+    def _backward_dropout(saved, grad_y, gamma, beta, spec: FCSpec):
+        _, pre, a, x, m, mean, invstd = saved
+        bn = spec.bn
+        gg = gb = None
+        if bn is None:
+            g = ops.act_bwd(grad_y, x, spec.post_act) if spec.post_act is not None else grad_y
+        elif bn.sync_group is not None:
+            from . import dist as adist
+            feat = x.shape[1]
+            sums = torch.empty(2 * feat + 1, dtype=torch.float64, device=x.device)
+            gg = torch.empty(feat, dtype=torch.float32, device=x.device)
+            gb = torch.empty(feat, dtype=torch.float32, device=x.device)
+            ops.bn_bwd(grad_y, x, None, None, spec.post_act, mean, invstd, gamma, beta, sums_out=sums, grad_gamma=gg, grad_beta=gb,
+                       out=grad_y)
+            sums[2 * feat:].fill_(x.shape[0])
+            adist.all_reduce_sum(sums, bn.sync_group)
+            g, _, _ = ops.bn_bwd(grad_y, x, None, None, spec.post_act, mean, invstd, gamma, beta, sums_in=sums, grad_gamma=gg,
+                                 grad_beta=gb)
+        else:
+            g, gg, gb = ops.bn_bwd(grad_y, x, None, None, spec.post_act, mean, invstd, gamma, beta)     # d / d(dropped value)
+        g = ops.mul(g, m)                                                                        # d / d(activation)
+        if spec.act is not None:
+            g = ops.act_bwd(g, pre, spec.act)                                                    # d / d(pre-activation)
+        return g, gg, gb
+
+    @staticmethod
     def backward(saved, grad_y, gamma, beta, spec: FCSpec):
         bn = spec.bn
+        if len(saved) == 7 and isinstance(saved[0], str) and saved[0] == 'dropout':
+            return _Tail._backward_dropout(saved, grad_y, gamma, beta, spec)
         if bn is None:
             inputs, acts = saved
             grad_pre = grad_y
@@ -162,7 +220,7 @@ COMPOSITE = os.environ.get('I3D_COMPOSITE', '1') != '0'
 
 
 def _composite_ok(spec: FCSpec, *tensors):
-    return (COMPOSITE and spec.bn is not None and spec.bn.training and spec.bn.sync_group is None
+    return (COMPOSITE and spec.bn is not None and spec.bn.training and spec.bn.sync_group is None and spec.dropout == 0.0
             and all(t is None or t.is_cuda for t in tensors))
 
 
@@ -481,13 +539,11 @@ class FCLayer(nn.Module):
     def __init__(self, in_dim, out_dim, activation='relu', dropout=0., batch_norm=False, batch_norm_momentum=0.1,
                  bias=True, init_fn=None, device='cpu'):
         super().__init__()
-        if dropout:
-            raise NotImplementedError('dropout > 0 is not on the accelerated path (all BASELINE configs use 0.0)')
         if not bias:
             raise NotImplementedError('bias=False is not on the accelerated path')
         self.in_dim, self.out_dim, self.bias = in_dim, out_dim, bias
         self.linear = nn.Linear(in_dim, out_dim, bias=bias).to(device)
-        self.dropout = None
+        self.dropout = nn.Dropout(p=dropout) if dropout else None      # (the reference's attribute; applied in _Tail, training mode only)
         self.batch_norm = nn.BatchNorm1d(out_dim, momentum=batch_norm_momentum).to(device) if batch_norm else None
         self.activation = act_name(activation)
         self.init_fn = nn.init.xavier_uniform_
@@ -528,7 +584,8 @@ class FCLayer(nn.Module):
                         self.sync_group if self.training else None)
             gamma, beta, bp = m.weight, m.bias, m._parameters
         lin = self.linear
-        h = cache[post_act] = (lin.weight, lin.bias, gamma, beta, FCSpec(self.activation, bn, post_act), lin._parameters, bp)
+        drop = float(self.dropout.p) if (self.dropout is not None and self.training) else 0.0
+        h = cache[post_act] = (lin.weight, lin.bias, gamma, beta, FCSpec(self.activation, bn, post_act, drop), lin._parameters, bp)
         return h
 
     def _drop_hot(self):
@@ -543,7 +600,7 @@ class FCLayer(nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     def __setattr__(self, name, value):
-        if name in ('sync_group', 'batch_norm', 'linear', 'activation'):
+        if name in ('sync_group', 'batch_norm', 'linear', 'activation', 'dropout'):
             self.__dict__.pop('_i3d_hot', None)
         super().__setattr__(name, value)
 
@@ -681,3 +738,27 @@ class ReadoutFn(torch.autograd.Function):
         (h,) = ctx.saved_tensors
         index, op_codes = ctx.cfg
         return ops.segment_readout_bwd(grad_out.contiguous(), h, index.graph_ptr, index.num_graphs, op_codes), None, None
+
+
+class DropoutFn(torch.autograd.Function):
+    """y = nn.Dropout(p)(x) in training mode, as a step of the tape: the mask is torch's own (ops.dropout_mask), the products are
+    HIP kernels.  reference models/pna_original.py:260 (PNATower), :428 (PNASimpleLayer), :188, :375 (in_feat_dropout)."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        x = x.contiguous()
+        m = ops.dropout_mask(x, p)
+        ctx.save_for_backward(m)
+        return ops.mul(x, m)
+
+    @staticmethod
+    def backward(ctx, g):
+        (m,) = ctx.saved_tensors
+        return ops.mul(g.contiguous(), m), None
+
+
+def dropout(x, p, training):
+    """nn.Dropout(p) on the tape; identity when p == 0 or in eval mode"""
+    if not training or not p:
+        return x
+    return tape.apply(DropoutFn, x, float(p))

@@ -358,6 +358,24 @@ def add_inplace(dst, src):
     return dst
 
 
+def mul(a, b, out=None):
+    """out = a * b elementwise (same shape; out may be a)"""
+    _chk(a)
+    _chk(b)
+    assert a.numel() == b.numel()
+    if out is None:
+        out = torch.empty_like(a)
+    check(_lib.load().i3d_mul(_p(a), _p(b), a.numel(), _p(out), _stream()), 'i3d_mul')
+    return out
+
+
+def dropout_mask(like, p):
+    """the scaled keep-mask nn.Dropout(p) would apply to a tensor shaped like `like` at this point of torch's generator
+    stream: torch's own dropout kernel on a tensor of ones (same shape -> same Philox offsets -> the SAME mask the reference's
+    module draws on this device with this seed), values 0 or 1 / (1 - p)"""
+    return torch.nn.functional.dropout(torch.ones_like(like), float(p), True)
+
+
 # ---- edge kernels ----------------------------------------------------------------------------------------
 def edge_combine_fwd(P, Q, bias, src_s, dst_s, q_code=None):
     _chk(P)

@@ -29,6 +29,8 @@ class _Desc:
 
 
 def _fc_ok(fc, need_bn):
+    if fc.dropout is not None:          # dropout > 0: the per-kernel path (layers._Tail)
+        return False
     if fc.batch_norm is None:
         return not need_bn and fc.activation in _SIMPLE
     return (fc.activation in _SIMPLE and fc.sync_group is None and fc.batch_norm.affine

@@ -5,8 +5,9 @@ state_dict keys.  They reuse the hot path's kernels: the segmented aggregation (
 always-applied scalers (reference :231-236 - no single-scaler quirk here), the edge gather-combine for the tower
 pretrans, the two-segment posttrans GEMMs, `h * snorm_n` as a row-scale kernel, LeakyReLU mixing.
 
-Not on the accelerated path (raise NotImplementedError; configs/pna_original.yml uses none of them):
-gru_enable, use_3d, dropout > 0, moment aggregators.
+dropout / in_feat_dropout > 0 (configs/pna_original_simple.yml: 0.3) draw torch's own mask (layers.DropoutFn) and keep the
+towers on the per-tower path.  Not on the accelerated path (raise NotImplementedError; no yml of these models uses them):
+gru_enable, use_3d, moment aggregators.
 """
 import ctypes
 import os
@@ -16,7 +17,7 @@ import torch.nn as nn
 
 from . import _lib, layers as _layers, ops, tape
 from .graph import as_batched_graph
-from .layers import MLP, AggregateFn, BNSpec, Concat2FCFn, EdgeFCFn, FCFn, FCSpec, ReadoutFn
+from .layers import MLP, AggregateFn, BNSpec, Concat2FCFn, EdgeFCFn, FCFn, FCSpec, ReadoutFn, dropout as _dropout
 from .mol_encoder import AtomEncoder, BondEncoder
 from .pna import _codes, _GatherRowsFn
 
@@ -83,8 +84,6 @@ class MLPReadout(nn.Module):
 
 
 def _check_unsupported(dropout=0.0, in_feat_dropout=0.0, gru_enable=False, use_3d=False):
-    if dropout or in_feat_dropout:
-        raise NotImplementedError('dropout > 0 is not on the accelerated path')
     if gru_enable:
         raise NotImplementedError('gru_enable=True is not on the accelerated path')
     if use_3d:
@@ -137,6 +136,7 @@ class PNAOriginal(nn.Module):
         gnn = self.node_gnn
         idx = g.index()
         h = gnn.embedding_h(g.ndata['feat'])
+        h = _dropout(h, gnn.in_feat_dropout.p, gnn.training)
         e_sorted = gnn.embedding_e(g.edata['feat'], perm=idx.perm) if gnn.edge_feat else None     # destination-sorted
         snorm = snorm_n.to(h.device)
         snorm_flat = None
@@ -338,6 +338,8 @@ def _stackable(model):
     gnn = model.node_gnn
     if getattr(gnn, 'gru_enable', False):
         return False
+    if any(tw.dropout.p > 0 for layer in gnn.layers for tw in layer.towers):
+        return False          # (a mask per tower, drawn in the towers' order: the per-tower path keeps the reference's random stream)
     for layer in gnn.layers:
         tws = list(layer.towers)
         for tw in tws:
@@ -528,6 +530,7 @@ class PNAGNNOriginal(nn.Module):
         _check_unsupported(dropout, in_feat_dropout, gru_enable, use_3d)
         self.gru_enable = gru_enable
         self.edge_feat = edge_feat
+        self.in_feat_dropout = nn.Dropout(in_feat_dropout)
         self.embedding_h = AtomEncoder(hidden_dim)
         if self.edge_feat:
             self.embedding_e = BondEncoder(edge_hidden_dim)
@@ -545,6 +548,7 @@ class PNAGNNOriginal(nn.Module):
         g = as_batched_graph(g)
         idx = g.index()
         h = self.embedding_h(h)
+        h = _dropout(h, self.in_feat_dropout.p, self.training)                        # :187
         e_sorted = self.embedding_e(e, perm=idx.perm) if self.edge_feat else None     # destination-sorted
         snorm = snorm_n.to(h.device)
         for conv in self.layers:
@@ -560,6 +564,7 @@ class PNATower(nn.Module):
                  avg_d, use_3d, pretrans_layers, posttrans_layers, edge_features, edge_hidden_dim):
         super().__init__()
         _check_unsupported(dropout, 0.0, False, use_3d)
+        self.dropout = nn.Dropout(dropout)
         self.graph_norm = graph_norm
         self.edge_features = edge_features
         self.aggregators = _codes(aggregators, ops.AGG, 'aggregator')
@@ -578,7 +583,7 @@ class PNATower(nn.Module):
         h = self.posttrans.forward_concat2(h, agg)                                                # :250-253
         if self.graph_norm:
             h = _RowScaleFn.apply(h, snorm_n)                                                     # :256-258
-        return h
+        return _dropout(h, self.dropout.p, self.training)                                         # :260
 
 
 class PNALayer(nn.Module):
@@ -659,7 +664,7 @@ class PNAGNNSimple(nn.Module):
     def __init__(self, hidden_dim, last_layer_dim, in_feat_dropout, dropout, residual, aggregators, scalers, avg_d,
                  last_batch_norm, mid_batch_norm, propagation_depth, posttrans_layers):
         super().__init__()
-        _check_unsupported(dropout, in_feat_dropout)
+        self.in_feat_dropout = nn.Dropout(in_feat_dropout)
         self.embedding_h = AtomEncoder(emb_dim=hidden_dim)
         common = dict(dropout=dropout, last_batch_norm=last_batch_norm, mid_batch_norm=mid_batch_norm,
                       residual=residual, aggregators=aggregators, scalers=scalers, avg_d=avg_d,
@@ -672,6 +677,7 @@ class PNAGNNSimple(nn.Module):
     def forward(self, g, h):
         g = as_batched_graph(g)
         h = self.embedding_h(h)
+        h = _dropout(h, self.in_feat_dropout.p, self.training)                        # :375
         for conv in self.layers:
             h = conv(g, h)
         g.ndata['feat'] = h
@@ -685,7 +691,7 @@ class PNASimpleLayer(nn.Module):
     def __init__(self, in_dim, out_dim, aggregators, scalers, avg_d, dropout, last_batch_norm, mid_batch_norm, residual,
                  posttrans_layers=1):
         super().__init__()
-        _check_unsupported(dropout)
+        self.dropout = nn.Dropout(p=dropout)
         self.aggregators = _codes(aggregators, ops.AGG, 'aggregator')
         self.scalers = _codes(scalers, ops.SCALER, 'scaler')
         self.in_dim, self.out_dim = in_dim, out_dim
@@ -701,7 +707,7 @@ class PNASimpleLayer(nn.Module):
         agg = AggregateFn.apply(m, idx, self.aggregators, self.scalers, float(self.avg_d), True)
         # posttrans -> ReLU -> (+ h_in): the ReLU rides on the last BatchNorm, the residual is added after it
         res = h if self.residual else None       # NB the reference adds the residual even when in_dim != out_dim would fail
-        return self.posttrans(agg, residual=res, post_act='relu')
+        return _dropout(self.posttrans(agg, residual=res, post_act='relu'), self.dropout.p, self.training)       # :428
 
     def __repr__(self):
         return '{}(in_channels={}, out_channels={})'.format(self.__class__.__name__, self.in_dim, self.out_dim)

@@ -357,6 +357,9 @@ def main():
     if use_dist:
         adist.setup([pna, net], loss_fn, sync_bn=headline_sync)
         adist.grad_reducer(params, modules=[pna, net])        # backward passes write into the all-reduce buffer
+        # the shard sizes are known here (B molecules on every rank): the loss then skips its per-step equal-shard check
+        # (a 2-element all-reduce on the compute stream: losses._check_equal_shards)
+        loss_fn.set_shard_counts([B] * world)
 
     def step(i):
         g2, g3, _ = batches[i % pool]

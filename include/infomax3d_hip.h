@@ -221,6 +221,9 @@ int i3d_act_bwd(const float* grad_y, const float* x, long n, int act, float* gra
 /* dst += src;  out = a + b;  out[r, :] = row for r < rows (Net3D's broadcast node embedding, models/net3d.py:61) */
 int i3d_add_inplace(float* dst, const float* src, long n, void* stream);
 int i3d_add(const float* a, const float* b, long n, float* out, void* stream);
+/* out = a * b elementwise (out may alias a): nn.Dropout of FCLayer / the tower variants with the scaled mask as b (reference
+ * models/base_layers.py:84-85, 104-105; models/pna_original.py:260, 428) */
+int i3d_mul(const float* a, const float* b, long n, float* out, void* stream);
 int i3d_broadcast_row(const float* row, long rows, int feat, float* out, void* stream);
 
 /* ---- edge kernels ----------------------------------------------------------------------------------

@@ -1117,3 +1117,40 @@ def test_full_size_finetune_batch_properties(amd):
 
     # (the sign() of an L1 residual within rounding of 0 may flip with the summation order: one row's gradient either way)
     _full_size_properties(amd, step, n, 1e-5, 1e-5, 2e-3)      # measured 6e-7 / 0 / 1e-4
+
+
+def test_pna_and_net3d_with_dropout(amd):
+    """dropout > 0 (reference models/base_layers.py:84-85, 104-105: nn.Dropout between activation and BatchNorm in every FCLayer of
+    the MLPs; no BASELINE config sets it) takes the per-kernel path: the models train (finite loss, every parameter gets a
+    gradient), two runs from the same seed are bit-identical, and in eval mode the outputs equal the dropout-free models'."""
+    mols = synth.make_dataset(48, seed=13)
+    kw2 = dict(PNA_YML, propagation_depth=2, hidden_dim=40, readout_hidden_dim=40, target_dim=16)
+    kw3 = dict(NET3D_YML, target_dim=16)
+
+    def build(p):
+        torch.manual_seed(4)
+        pna = amd.PNA(avg_d=1.0, device='cuda:0', **dict(kw2, dropout=p)).cuda().train()
+        net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **dict(kw3, dropout=p)).cuda().train()
+        return pna, net
+
+    def run():
+        pna, net = build(0.2)
+        g2, g3 = make_batch(amd, mols)
+        torch.manual_seed(11)
+        loss = amd.NTXent(tau=0.1)(pna(g2), net(g3))
+        loss.backward()
+        return loss.item(), [p.grad.clone() for p in list(pna.parameters()) + list(net.parameters())], pna, net
+    l1, g1, pna, net = run()
+    l2, g2_, _, _ = run()
+    assert math.isfinite(l1) and l1 == l2
+    for a, b in zip(g1, g2_):
+        assert a is not None and torch.equal(a, b)
+    p0, n0 = build(0.0)
+    p0.load_state_dict(pna.state_dict()), n0.load_state_dict(net.state_dict())
+    for m in (pna, net, p0, n0):
+        m.eval()
+    ga, gb = make_batch(amd, mols)
+    a1, a2, b1, b2 = ga.local_copy(), ga.local_copy(), gb.local_copy(), gb.local_copy()      # (a forward overwrites the graph's features)
+    with torch.no_grad():
+        assert rel_err(pna(a1).cpu(), p0(a2).cpu()) < 1e-5
+        assert rel_err(net(b1).cpu(), n0(b2).cpu()) < 1e-5

@@ -620,3 +620,59 @@ def test_wgrad_multi_matches_fp64(F, N, E):
     torch.cuda.synchronize()
     for a, k in zip(first, ('gW_post', 'gW2', 'gW1', 'gQ')):
         assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(d[k]))
+
+
+# ---- dropout (reference models/base_layers.py:84-85, 104-105; models/pna_original.py:260, 428) -------------------------------
+@pytest.mark.parametrize('act,bn', [('relu', True), ('none', True), ('silu', True), ('relu', False)])
+def test_fclayer_with_dropout_matches_torch_on_the_same_random_stream(act, bn):
+    """FCLayer(dropout=p): Linear -> activation -> nn.Dropout -> BatchNorm1d, forward and backward against the same sequence of
+    torch modules on the GPU with the same seed (the mask is torch's own: ops.dropout_mask draws it with torch's dropout kernel
+    on a tensor of the same shape), and the eval-mode forward (no dropout)."""
+    layers = importlib.import_module('3dinfomax_amd.layers')
+    torch.manual_seed(0)
+    fc = layers.FCLayer(24, 40, activation=act, dropout=0.3, batch_norm=bn, batch_norm_momentum=0.1).cuda().train()
+    with torch.no_grad():
+        fc.linear.weight.mul_(24 * 0.7)
+        fc.linear.bias.normal_()
+    x = torch.randn(300, 24, device='cuda:0')
+    w = torch.randn(300, 40, device='cuda:0')
+    ref_lin = torch.nn.Linear(24, 40).cuda()
+    ref_lin.load_state_dict(fc.linear.state_dict())
+    ref_bn = torch.nn.BatchNorm1d(40, momentum=0.1).cuda().train() if bn else None
+    ref_act = {'relu': torch.relu, 'silu': torch.nn.functional.silu, 'none': lambda t: t}[act]
+
+    def ref(xx, training):
+        h = ref_act(ref_lin(xx))
+        h = torch.nn.functional.dropout(h, 0.3, training)
+        return ref_bn(h) if ref_bn is not None else h
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    torch.manual_seed(7)
+    ya = fc(xa)
+    torch.manual_seed(7)
+    yb = ref(xb, True)
+    assert rel_err(ya.cpu(), yb.detach().cpu()) < 2e-5
+    (ya * w).sum().backward()
+    (yb * w).sum().backward()
+    assert rel_err(xa.grad.cpu(), xb.grad.cpu()) < 2e-4
+    assert rel_err(fc.linear.weight.grad.cpu(), ref_lin.weight.grad.cpu()) < 2e-4
+    if bn:
+        assert rel_err(fc.batch_norm.weight.grad.cpu(), ref_bn.weight.grad.cpu()) < 2e-4
+        assert rel_err(fc.batch_norm.running_var.cpu(), ref_bn.running_var.cpu()) < 1e-5
+    fc.eval()
+    if ref_bn is not None:
+        ref_bn.eval()
+    with torch.no_grad():
+        assert rel_err(fc(x).cpu(), ref(x, False).cpu()) < 2e-5
+
+
+def test_dropout_function_is_torch_dropout():
+    layers = importlib.import_module('3dinfomax_amd.layers')
+    x = torch.randn(513, 70, device='cuda:0').requires_grad_()
+    torch.manual_seed(3)
+    y = layers.dropout(x, 0.3, True)
+    torch.manual_seed(3)
+    y_ref = torch.nn.functional.dropout(x.detach(), 0.3, True)
+    assert torch.equal(y.detach(), y_ref)
+    y.sum().backward()
+    assert torch.equal(x.grad, (y_ref != 0).float() / 0.7) or rel_err(x.grad.cpu(), ((y_ref != 0).float() / 0.7).cpu()) < 1e-6
+    assert layers.dropout(x, 0.3, False) is x and layers.dropout(x, 0.0, True) is x

@@ -162,3 +162,50 @@ def test_state_dict_surface_of_original_variants():
         assert list(model.state_dict().keys()) == list(ref.keys()), tag
         for k, v in model.state_dict().items():
             assert tuple(v.shape) == tuple(ref[k].shape), k
+
+
+@pytest.mark.gpu
+def test_simple_variant_with_the_dropout_of_its_yml():
+    """reference configs/pna_original_simple.yml:37-60 sets dropout 0.3 (nn.Dropout at the end of every PNASimpleLayer,
+    models/pna_original.py:428): a layer's training-mode output is the dropout-free output times torch's mask for the same
+    seed, gradients follow; the whole model trains, and in eval mode equals the dropout-free model."""
+    amd = importlib.import_module('3dinfomax_amd')
+    po = importlib.import_module('3dinfomax_amd.pna_original')
+    synth = importlib.import_module('3dinfomax_amd.synth')
+    mols = synth.make_dataset(24, seed=9)
+    g2 = amd.batch([amd.bond_graph(m) for m in mols]).to('cuda:0')
+    torch.manual_seed(1)
+    layer = po.PNASimpleLayer(in_dim=24, out_dim=24, aggregators=['mean', 'max', 'min', 'std'],
+                              scalers=['identity', 'amplification', 'attenuation'], avg_d=1.4, dropout=0.3, last_batch_norm=True,
+                              mid_batch_norm=True, residual=True).cuda().train()
+    h = torch.randn(g2.number_of_nodes(), 24, device='cuda:0')
+    ha, hb = h.clone().requires_grad_(), h.clone().requires_grad_()
+    torch.manual_seed(5)
+    ya = layer(g2, ha)
+    layer.dropout.p = 0.0
+    yb = layer(g2, hb)
+    layer.dropout.p = 0.3
+    torch.manual_seed(5)
+    mask = torch.nn.functional.dropout(torch.ones_like(yb), 0.3, True)
+    assert torch.equal(ya.detach(), (yb * mask).detach())
+    w = torch.randn_like(ya)
+    (ya * w).sum().backward()
+    (yb * mask * w).sum().backward()
+    assert rel_err(ha.grad.cpu(), hb.grad.cpu()) < 1e-5
+    # the yml's model
+    kw = dict(PNA_SIMPLE_KW, dropout=0.3)
+    torch.manual_seed(2)
+    model = amd.PNAOriginalSimple(**kw).cuda().train()
+    plain = amd.PNAOriginalSimple(**PNA_SIMPLE_KW).cuda()
+    plain.load_state_dict(model.state_dict(), strict=True)       # dropout adds no parameters
+    optim = amd.Adam(list(model.parameters()), lr=1e-3)
+    for _ in range(2):
+        out = model(g2.local_copy())
+        assert bool(torch.isfinite(out).all())
+        out.abs().mean().backward()
+        optim.step()
+        optim.zero_grad()
+    plain.load_state_dict(model.state_dict(), strict=True)
+    model.eval(), plain.eval()
+    with torch.no_grad():
+        assert torch.equal(model(g2.local_copy()), plain(g2.local_copy()))
