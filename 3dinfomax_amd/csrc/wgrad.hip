@@ -315,8 +315,10 @@ __device__ __forceinline__ void wgrad_unit(const WgProb& p, const int slice, con
     }
 }
 
+// two workgroups per CU for the exact form (203 registers, 68 KB of LDS); the bf16 forms stage three K-tiles (100 KB of LDS): one
+// workgroup per CU whatever the registers do - asking for two there only made the compiler report a missed target
 template <int PREC>
-__global__ void __launch_bounds__(256, 2) wgrad_multi_kernel(const WgArgs a) {
+__global__ void __launch_bounds__(256, PREC == 0 ? 2 : 1) wgrad_multi_kernel(const WgArgs a) {
     __shared__ __attribute__((aligned(1024))) float smem[2 * wg_nst(PREC) * WG_BK * WG_LDP];
     __shared__ int kidx[WG_MAX_SLICE];
     const int u = xcd_unit(a.n_units);
