@@ -576,7 +576,7 @@ def main():
         # HBM traffic per launch from this round's PMC passes over THIS command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE around
         # bench.py, FETCH_SIZE x2 gfx950 correction, tools/pmc_summary.py -> profiles/r03_step_k4_pmc.json): the kernel variant
         # the step launches (messages normalised on load), the same synthetic batches (same seeds -> same N, E)
-        traffic = traffic_bwd = traffic_error = None
+        traffic = traffic_bwd = traffic_error = traffic_note = None
         pmc = latest_pmc_summary()
         if pmc is not None:
             lk = importlib.import_module('tools.pmc_lookup')
@@ -586,6 +586,8 @@ def main():
             try:
                 traffic = lk.traffic_bytes(pj, 'pna_aggregate_fwd_kernel', (2 if blocks == 4 else 1,), grids)
                 traffic_bwd = lk.traffic_bytes(pj, 'pna_aggregate_bwd_kernel', (4, 2 if blocks == 4 else 1), grids)
+            except lk.PmcNotCovered as exc:       # another workload than the one the PMC passes ran over: nothing to attach
+                traffic_note = str(exc)
             except lk.PmcLookupError as exc:
                 traffic_error = f'{os.path.relpath(pmc, ROOT)}: {exc}'
                 print('bench.py: roofline.traffic lookup failed - ' + traffic_error, file=sys.stderr)
@@ -593,6 +595,7 @@ def main():
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                     unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_backward_kernel=traffic_bwd,
                     **({'traffic_error': traffic_error} if traffic_error else {}),
+                    **({'traffic_note': traffic_note} if traffic_note else {}),
                     traffic_source=os.path.relpath(pmc, ROOT) if pmc else None,
                     launches=len(ev), avg_us=round(float(ms.mean() * 1e3), 2),
                     algorithmic_bytes_per_launch=int(byts.mean()),

@@ -32,8 +32,10 @@ def test_kernel_names_match_on_base_name_and_leading_template_arguments():
     assert lk.traffic_bytes(summary, 'k', (2, 'false')) == 2_000_000
     with pytest.raises(lk.PmcLookupError):
         lk.traffic_bytes(summary, 'k', (3,))
-    with pytest.raises(lk.PmcLookupError):
+    with pytest.raises(lk.PmcNotCovered):           # the kernel is there, this workload's grid is not: another workload's pass
         lk.traffic_bytes(summary, 'k', (2,), grids={1024})
+    with pytest.raises(lk.PmcLookupError):          # a kernel the file does not hold at all
+        lk.traffic_bytes(summary, 'renamed_kernel', (2,), grids={512})
 
 
 def test_committed_pmc_summary_has_rows_for_the_default_bench_workload():

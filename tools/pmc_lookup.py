@@ -51,9 +51,19 @@ def rows_for(summary, base, leading_args=(), grids=None):
     return out
 
 
+class PmcNotCovered(LookupError):
+    """the summary holds the kernel, but no launch with this workload's grids: the PMC pass was over another workload"""
+
+
 def traffic_bytes(summary, base, leading_args=(), grids=None):
-    """Dispatch-weighted mean HBM bytes per launch, or raise PmcLookupError naming what was looked for and what the file holds."""
+    """Dispatch-weighted mean HBM bytes per launch.  PmcNotCovered: the kernel is in the file but was never launched with one of
+    `grids` (another workload's pass: no number to attach, not an error); PmcLookupError: the kernel is not in the file at all (a
+    renamed / re-templated kernel: the caller has to show it) - both name what was looked for and what the file holds."""
     rows = rows_for(summary, base, leading_args, grids)
+    if not rows and grids is not None and rows_for(summary, base, leading_args, None):
+        have = sorted({r['grid'] for r in rows_for(summary, base, leading_args, None)})
+        raise PmcNotCovered(f'{base}<{", ".join(map(str, leading_args))}...> is in the summary with grids {have[:4]}'
+                            f'{"..." if len(have) > 4 else ""}, none of {sorted(grids)}: the PMC pass was over another workload')
     if not rows:
         names = sorted(k for k in summary if not k.startswith('_'))
         have = sorted({r['grid'] for k in names if split_kernel_name(k)[0] == base for r in summary[k]})

@@ -31,7 +31,7 @@ def main(fetch_db, write_db, pattern, json_out=None):
     f = per_kernel(fetch_db, 'FETCH_SIZE', pattern)
     w = per_kernel(write_db, 'WRITE_SIZE', pattern)
     res = {}
-    print('# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python tools/family_bench.py   (one pass per counter)')
+    print('# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- <command>   (one pass per counter; the command: profiles/README.md)')
     print('# KiB per dispatch averaged over the dispatches of (kernel, grid); fetch x2 (gfx950 wide-read correction), MB = 1e6 bytes')
     print(f'{"kernel":72s} {"grid":>9s} {"n":>4s} {"fetch_MB":>9s} {"write_MB":>9s} {"total_MB":>9s}')
     for key in sorted(set(f) | set(w)):
