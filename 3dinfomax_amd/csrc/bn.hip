@@ -172,6 +172,7 @@ __device__ __forceinline__ void finalize_column_local(const Final& f, int c, dou
 __device__ __forceinline__ void arrive_and_finalize(const Final& f, const float* partial, int nblk) {
     __shared__ unsigned s_ticket;
     __shared__ double s_red[2][FIN_LANES][FIN_COLS];
+    __shared__ double s_peer[3][PEER_MAX_WORLD][FIN_COLS];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's partial stores have left (agent-scope, write-through)
     __syncthreads();
     const unsigned total = gridDim.x * gridDim.y;
@@ -218,14 +219,19 @@ __device__ __forceinline__ void arrive_and_finalize(const Final& f, const float*
             if (f.peer_on) finalize_column_local(f, c, s1, s2);
             else finalize_column(f, c, s1, s2);
         }
-        if (f.peer_on) {        // (uniform) the column block's exchange: flag index = column block, the same partition on every rank
-            peer_signal_and_wait(f.peer, (int)cb);
+        if (f.peer_on) {        // (uniform) the column block's exchange: lane `ly` < world fetches rank ly's triple of its column
+            if (ly < f.peer.world && c < f.feat) {
+                double t[3];
+                peer_get3_f64(f.peer, ly, c, f.feat + c, 2 * f.feat + c, t);
+                s_peer[0][ly][cx] = t[0]; s_peer[1][ly][cx] = t[1]; s_peer[2][ly][cx] = t[2];
+            }
+            __syncthreads();
             if (ly == 0 && c < f.feat) {
                 double T1 = 0.0, T2 = 0.0, N = 0.0;
-                for (int q = 0; q < f.peer.world; ++q) {
-                    T1 += peer_get_f64(f.peer, q, c);
-                    T2 += peer_get_f64(f.peer, q, f.feat + c);
-                    N += peer_get_f64(f.peer, q, 2 * f.feat + c);
+                for (int q = 0; q < f.peer.world; ++q) {      // rank order: the same bits on every rank
+                    T1 += s_peer[0][q][cx];
+                    T2 += s_peer[1][q][cx];
+                    N += s_peer[2][q][cx];
                 }
                 finalize_column_global(f, c, T1, T2, N);
             }
@@ -797,7 +803,7 @@ static bool exact_zero_bias_grad() {
 static float* partial_of(void* workspace) { return (float*)((char*)workspace + WS_HEADER); }
 
 // [3 feat] doubles per rank in a mailbox slot, one flag per column block
-static bool peer_fits(int feat) { return 3L * feat * 8 <= PEER_PAYLOAD_BYTES && cdiv(feat, FIN_COLS) <= PEER_MAX_WG; }
+static bool peer_fits(int feat) { return 6L * feat <= PEER_PAYLOAD_WORDS; }
 
 static Final stats_final_desc(void* workspace, const float* pre, int act, int rows, int feat, float eps, float momentum,
                               float* mean, float* invstd, float* running_mean, float* running_var, double* sums_out,

@@ -34,13 +34,6 @@ struct MergedTiles {
 
 // the exact merge of `n_tiles` {sum, M2, count} tiles (tile b at partial + b * tile_stride) of column c; every thread of the
 // workgroup calls it (two barriers inside; a barrier must separate two calls: `sm` is reused)
-template <bool SYS>      // SYS: the tiles live in a peer mailbox - system-scope loads (peer.h)
-__device__ __forceinline__ float ld_tile(const float* p) {
-    if (SYS) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return *p;
-}
-
-template <bool SYS>
 __device__ __forceinline__ MergedTiles merge_tiles(const float* __restrict__ partial, long tile_stride, int n_tiles, int feat, int c,
                                                    bool live, int cx, int ly, double (&sm)[2][FIN_LANES][FIN_COLS]) {
     float ks[FIN_KEEP], km[FIN_KEEP], kn[FIN_KEEP];
@@ -50,7 +43,7 @@ __device__ __forceinline__ MergedTiles merge_tiles(const float* __restrict__ par
         const int b = ly + k * FIN_LANES;
         const bool ok = live && b < n_tiles;
         const float* p = partial + (long)(ok ? b : 0) * tile_stride + (live ? c : 0);
-        ks[k] = ld_tile<SYS>(p); km[k] = ld_tile<SYS>(p + feat); kn[k] = ok ? ld_tile<SYS>(p + 2 * feat) : 0.f;
+        ks[k] = *p; km[k] = p[feat]; kn[k] = ok ? p[2 * feat] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < FIN_KEEP; ++k) {
@@ -66,7 +59,7 @@ __device__ __forceinline__ MergedTiles merge_tiles(const float* __restrict__ par
                 const int b = b0 + u * FIN_LANES;
                 const bool ok = b < n_tiles;
                 const float* p = partial + (long)(ok ? b : 0) * tile_stride + c;
-                ts[u] = ld_tile<SYS>(p); tn[u] = ok ? ld_tile<SYS>(p + 2 * feat) : 0.f;
+                ts[u] = *p; tn[u] = ok ? p[2 * feat] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < FIN_TAIL; ++u)
@@ -98,7 +91,7 @@ __device__ __forceinline__ MergedTiles merge_tiles(const float* __restrict__ par
                 const int b = b0 + u * FIN_LANES;
                 const bool ok = b < n_tiles;
                 const float* p = partial + (long)(ok ? b : 0) * tile_stride + c;
-                ts[u] = ld_tile<SYS>(p); tm[u] = ld_tile<SYS>(p + feat); tn[u] = ok ? ld_tile<SYS>(p + 2 * feat) : 0.f;
+                ts[u] = *p; tm[u] = p[feat]; tn[u] = ok ? p[2 * feat] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < FIN_TAIL; ++u) {
@@ -131,10 +124,11 @@ bn_finalize_partials_kernel(const float* __restrict__ partial, int n_tiles, int 
                             long long* batches_tracked, float* __restrict__ aff, float* __restrict__ triple_out, const PeerDev peer) {
     I3D_CHAIN_PRIO();
     __shared__ double sm[2][FIN_LANES][FIN_COLS];
+    __shared__ float gathered[PEER ? PEER_MAX_WORLD : 1][3][FIN_COLS];
     const int cx = threadIdx.x & (FIN_COLS - 1), ly = threadIdx.x / FIN_COLS;
     const int c = blockIdx.x * FIN_COLS + cx;
     const bool live = c < feat;
-    MergedTiles r = merge_tiles<false>(partial, 3L * feat, n_tiles, feat, c, live, cx, ly, sm);
+    MergedTiles r = merge_tiles(partial, 3L * feat, n_tiles, feat, c, live, cx, ly, sm);
     if (PEER) {
         if (ly == 0 && live) {
             const float tot = (float)r.tot, m2 = (float)r.m2, n = (float)r.n;
@@ -144,8 +138,16 @@ bn_finalize_partials_kernel(const float* __restrict__ partial, int n_tiles, int 
                 peer_put_f32(peer, p, 2 * feat + c, n);
             }
         }
-        peer_signal_and_wait(peer, blockIdx.x);          // (its barriers also separate the two uses of `sm`)
-        r = merge_tiles<true>((const float*)peer_recv_slot(peer, 0), PEER_PAYLOAD_BYTES / 4, peer.world, feat, c, live, cx, ly, sm);
+        // lane `ly` < world fetches rank ly's triple of its column (the words say when they are there) into LDS: the `world`
+        // triples are then merged as tiles of pitch 3 FIN_COLS by the same code as the rank's own tiles
+        __syncthreads();                                 // (separates the two uses of `sm`)
+        if (ly < peer.world && live) {
+            float t[3];
+            peer_get3_f32(peer, ly, c, feat + c, 2 * feat + c, t);
+            gathered[ly][0][cx] = t[0]; gathered[ly][1][cx] = t[1]; gathered[ly][2][cx] = t[2];
+        }
+        __syncthreads();
+        r = merge_tiles(&gathered[0][0][0], 3L * FIN_COLS, peer.world, FIN_COLS, cx, live, cx, ly, sm);
     }
     if (ly != 0 || !live) return;
     const double tot = r.tot, m2 = r.m2, n = r.n, mu = r.mu;
@@ -354,7 +356,7 @@ extern "C" int i3d_bn_finalize_partials(const float* partial, int n_tiles, int f
     const PeerDev no_peer = {};
     if (PeerCtx* pc = peer_active(stream)) {
         // synchronised BatchNorm through the peer-write exchange (peer.h): ONE launch, the exchange inside it
-        I3D_CHECK_ARG(3L * feat * 4 <= PEER_PAYLOAD_BYTES && cdiv(feat, FIN_COLS) <= PEER_MAX_WG, "BatchNorm too wide for the peer mailbox");
+        I3D_CHECK_ARG(3L * feat <= PEER_PAYLOAD_WORDS, "BatchNorm too wide for the peer mailbox");
         PeerDev d;
         if (int rc = peer_next(pc, &d)) return rc;
         hipLaunchKernelGGL(bn_finalize_partials_kernel<true>, dim3(cdiv(feat, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial,

@@ -28,36 +28,47 @@ constexpr int MAX_BOUND = 4;
 PeerCtx* g_active = nullptr;            // default context (any stream without one of its own)
 PeerCtx* g_bound[MAX_BOUND] = {};      // contexts bound to a stream
 
-// generic all-gather: recv[world][count] <- every rank's send[count]; workgroup b moves elements [b * 1024, (b + 1) * 1024)
+// generic all-gather: recv[world][count] <- every rank's send[count]; a thread moves one element to every rank and fetches
+// the `world` elements of its index that arrive here
 __global__ void __launch_bounds__(256) peer_all_gather_f32_kernel(const PeerDev d, const float* __restrict__ send,
                                                                   float* __restrict__ recv, int count) {
     I3D_CHAIN_PRIO();
-    const int lo = blockIdx.x * 1024, hi = min(lo + 1024, count);
-    for (int p = 0; p < d.world; ++p)
-        for (int i = lo + threadIdx.x; i < hi; i += 256) peer_put_f32(d, p, i, send[i]);
-    peer_signal_and_wait(d, blockIdx.x);
-    for (int q = 0; q < d.world; ++q)
-        for (int i = lo + threadIdx.x; i < hi; i += 256) recv[(long)q * count + i] = peer_get_f32(d, q, i);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const float v = send[i];
+    for (int p = 0; p < d.world; ++p) peer_put_f32(d, p, i, v);
+    // four ranks per round: their words in flight together (a rank after the other is one memory latency per rank)
+    for (int q0 = 0; q0 < d.world; q0 += 4) {
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = peer_get_f32(d, min(q0 + k, d.world - 1), i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (q0 + k < d.world) recv[(long)(q0 + k) * count + i] = r[k];
+    }
 }
 
-// sum over the ranks in rank order (fp64), workgroup b owns elements [b * 256, (b + 1) * 256); element n = `rows` when
-// append_rows.  Outputs: out64[n_total] and / or outf[n] (the appended element is not written to outf), inv_last = 1 / sum of
-// the last element.
+// sum over the ranks in rank order (fp64): 16 threads per element - thread (e, q) fetches rank q's value of element e, the
+// element's first thread adds them in rank order; element n = `rows` when append_rows.  Outputs: out64[n_total] and / or
+// outf[n] (the appended element is not written to outf), inv_last = 1 / sum of the last element.
 template <typename In>
-__global__ void __launch_bounds__(256) peer_sum_kernel(const PeerDev d, const In* __restrict__ in, int n, int append_rows,
-                                                       double rows, double* __restrict__ out64, float* __restrict__ outf,
-                                                       float* __restrict__ inv_last) {
+__global__ void __launch_bounds__(256) peer_sum_kernel(const PeerDev d, const In* in, int n, int append_rows,
+                                                       double rows, double* out64, float* __restrict__ outf,
+                                                       float* __restrict__ inv_last) {      // (in == out64: in place)
     I3D_CHAIN_PRIO();
+    __shared__ double sv[256 / PEER_MAX_WORLD][PEER_MAX_WORLD];
     const int total = n + (append_rows ? 1 : 0);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < total) {
+    const int el = threadIdx.x / PEER_MAX_WORLD, q = threadIdx.x % PEER_MAX_WORLD;
+    const int i = blockIdx.x * (256 / PEER_MAX_WORLD) + el;
+    if (i < total && q < d.world) {
         const double v = i < n ? (double)in[i] : rows;
-        for (int p = 0; p < d.world; ++p) peer_put_f64(d, p, i, v);
+        peer_put_f64(d, q, i, v);              // (thread q of the element writes to rank q)
+        sv[el][q] = peer_get_f64(d, q, i);
     }
-    peer_signal_and_wait(d, blockIdx.x);
-    if (i >= total) return;
+    __syncthreads();
+    if (i >= total || q != 0) return;
     double s = 0.0;
-    for (int q = 0; q < d.world; ++q) s += peer_get_f64(d, q, i);
+    for (int r = 0; r < d.world; ++r) s += sv[el][r];
     if (out64 != nullptr) out64[i] = s;
     if (outf != nullptr && i < n) outf[i] = (float)s;
     if (inv_last != nullptr && i == total - 1) inv_last[0] = (float)(1.0 / s);
@@ -67,10 +78,10 @@ int table_all_gather_f32(void* user, const float* send, float* recv, long count,
     (void)user;
     PeerCtx* ctx = peer_active(stream);
     I3D_CHECK_ARG(ctx != nullptr, "peer provider not installed");
-    I3D_CHECK_ARG(count > 0 && count * 4 <= PEER_PAYLOAD_BYTES && cdiv(count, 1024) <= PEER_MAX_WG, "payload too large for the mailbox");
+    I3D_CHECK_ARG(count > 0 && count <= PEER_PAYLOAD_WORDS, "payload too large for the mailbox");
     PeerDev d;
     if (int rc = peer_next(ctx, &d)) return rc;
-    hipLaunchKernelGGL(peer_all_gather_f32_kernel, dim3(cdiv(count, 1024)), dim3(256), 0, (hipStream_t)stream, d, send, recv, (int)count);
+    hipLaunchKernelGGL(peer_all_gather_f32_kernel, dim3(cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream, d, send, recv, (int)count);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }
@@ -84,11 +95,11 @@ template <typename In>
 int peer_sum_impl(PeerCtx* ctx, const In* in, int n, int append_rows, double rows, double* out64, float* outf, float* inv_last,
                   void* stream) {
     const int total = n + (append_rows ? 1 : 0);
-    I3D_CHECK_ARG(ctx != nullptr && in != nullptr && n > 0 && (long)total * 8 <= PEER_PAYLOAD_BYTES && cdiv(total, 256) <= PEER_MAX_WG,
+    I3D_CHECK_ARG(ctx != nullptr && in != nullptr && n > 0 && 2L * total <= PEER_PAYLOAD_WORDS,
                   "bad arguments / payload too large for the mailbox");
     PeerDev d;
     if (int rc = peer_next(ctx, &d)) return rc;
-    hipLaunchKernelGGL(peer_sum_kernel<In>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, d, in, n, append_rows, rows,
+    hipLaunchKernelGGL(peer_sum_kernel<In>, dim3(cdiv(total, 256 / PEER_MAX_WORLD)), dim3(256), 0, (hipStream_t)stream, d, in, n, append_rows, rows,
                        out64, outf, inv_last);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
