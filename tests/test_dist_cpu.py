@@ -1,4 +1,5 @@
-"""world_size-2 `gloo` tests (CPU, no GPU needed) of the data-parallel plumbing in 3dinfomax_amd/dist.py and
+"""world_size-2 (and, for the sharded loss, world_size-4: chunk / offset arithmetic that a pair of ranks cannot get wrong)
+`gloo` tests (CPU, no GPU needed) of the data-parallel plumbing in 3dinfomax_amd/dist.py and
 losses._AllGatherRowsFn: the molecule-sharded formulation - every rank scores its local 2D rows against the
 ALL-GATHERED 3D rows, backward reduce-scatters dz2, gradients are summed - must reproduce the single-process loss
 and gradients of the reference formula (oracle/pna3d_oracle.ntxent).  The compute inside each rank is done with
@@ -33,7 +34,7 @@ def _share(z1_local, z2_full, pos_offset, global_batch, tau=0.1):
     return (-torch.log(pos / (sim.sum(1) - pos))).sum() / global_batch
 
 
-def _worker(rank, port, out):
+def _worker(rank, port, out, WORLD=WORLD):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=WORLD)
     import sys
@@ -65,9 +66,10 @@ def _worker(rank, port, out):
     # ---- helpers
     x = torch.full((3, 2), float(rank + 1))
     gathered = adist.all_gather_rows(x)
-    ok = ok and gathered.shape == (6, 2) and gathered[:3].eq(1).all() and gathered[3:].eq(2).all()
+    ok = ok and gathered.shape == (3 * WORLD, 2) and all(gathered[3 * r:3 * r + 3].eq(r + 1).all() for r in range(WORLD))
     rs = adist.reduce_scatter_rows(torch.arange(8.).view(4, 2) * (rank + 1))
-    ok = ok and torch.equal(rs, (torch.arange(8.).view(4, 2) * 3)[rank * 2:(rank + 1) * 2])
+    per_rs = 4 // WORLD
+    ok = ok and torch.equal(rs, (torch.arange(8.).view(4, 2) * (WORLD * (WORLD + 1) // 2))[rank * per_rs:(rank + 1) * per_rs])
     # sync-BN statistic algebra: fp64 [sum, sumsq, count] all-reduce == full-batch mean / biased var
     rows = torch.randn(10 + 7 * rank, 5, generator=torch.Generator().manual_seed(10 + rank)).double() + 3
     sums = torch.cat([rows.sum(0), (rows * rows).sum(0), torch.tensor([float(rows.shape[0])], dtype=torch.float64)])
@@ -78,16 +80,18 @@ def _worker(rank, port, out):
     mean, var = sums[:5] / n, sums[5:10] / n - (sums[:5] / n) ** 2
     ok = ok and torch.allclose(mean, allrows.mean(0)) and torch.allclose(var, allrows.var(0, unbiased=False))
     mols = list(range(10))
-    ok = ok and adist.shard_molecules(mols, rank, WORLD) == mols[rank * 5:(rank + 1) * 5]
+    cnt = adist.shard_counts(10, WORLD)
+    ok = ok and adist.shard_molecules(mols, rank, WORLD) == mols[sum(cnt[:rank]):sum(cnt[:rank + 1])]
     out[rank] = bool(ok)
     dist.destroy_process_group()
 
 
-def test_sharded_ntxent_and_collectives_match_single_process():
+@pytest.mark.parametrize('world', [2, 4])
+def test_sharded_ntxent_and_collectives_match_single_process(world):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
-    assert dict(out) == {0: True, 1: True}
+    mp.spawn(_worker, args=(_free_port(), out, world), nprocs=world, join=True)
+    assert dict(out) == {r: True for r in range(world)}
 
 
 def test_shard_plan_balances_atoms_and_drops_nothing():
@@ -106,7 +110,9 @@ def test_shard_plan_balances_atoms_and_drops_nothing():
     assert [adist.shard_molecules(mols, r, 3) for r in range(3)] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10]]
 
 
-def _var_worker(rank, port, out):
+def _var_worker(rank, port, out, counts=(7, 4)):
+    WORLD = len(counts)
+    counts = list(counts)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=WORLD)
     import sys
@@ -114,7 +120,7 @@ def _var_worker(rank, port, out):
     adist = importlib.import_module('3dinfomax_amd.dist')
     losses = importlib.import_module('3dinfomax_amd.losses')
     from oracle import pna3d_oracle as O
-    counts, dim = [7, 4], 8
+    dim = 8
     B = sum(counts)
     g = torch.Generator().manual_seed(1)
     z1, z2, W = torch.randn(B, dim, generator=g), torch.randn(B, dim, generator=g), torch.randn(dim, dim, generator=g)
@@ -135,11 +141,12 @@ def _var_worker(rank, port, out):
     dist.destroy_process_group()
 
 
-def test_sharded_ntxent_with_uneven_shards():
+@pytest.mark.parametrize('counts', [(7, 4), (5, 3, 6, 2)])
+def test_sharded_ntxent_with_uneven_shards(counts):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_var_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
-    assert dict(out) == {0: True, 1: True}
+    mp.spawn(_var_worker, args=(_free_port(), out, counts), nprocs=len(counts), join=True)
+    assert dict(out) == {r: True for r in range(len(counts))}
 
 
 def _accum_worker(rank, port, out):

@@ -45,7 +45,7 @@ def _batch(amd, mols):
             amd.batch([amd.complete_graph(m) for m in mols]).to('cuda:0'))
 
 
-def _worker(rank, port, path, native_sync):
+def _worker(rank, port, path, native_sync, WORLD=WORLD):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), I3D_NATIVE_SYNC_BN='1' if native_sync else '0',
                       I3D_SYNC_PROVIDER=native_sync or 'peer', I3D_PEER_TIMEOUT_S='20')
     if native_sync == 'peer_fails_on_rank_1':       # the exchange cannot be set up on ONE rank: every rank must take the fallback
@@ -95,19 +95,20 @@ def _worker(rank, port, path, native_sync):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('native_sync', ['peer', 'callbacks', 'peer_fails_on_rank_1', False])
-def test_two_rank_sharded_step_equals_full_batch(tmp_path, native_sync):
+@pytest.mark.parametrize('native_sync,world', [('peer', 2), ('peer', 4), ('callbacks', 2), ('peer_fails_on_rank_1', 2), (False, 2)])
+def test_two_rank_sharded_step_equals_full_batch(tmp_path, native_sync, world):
     """BatchNorm synchronised inside the C sequencers (csrc/comm.hip) - the whole-model sequencer runs - through 'peer': the
     one-shot peer-write exchange (csrc/peer.hip: each process maps the other's mailbox through hipIpc - which works between
     processes that share a GPU - and the BatchNorm kernels exchange their vectors themselves; the 3D network keeps its side
     stream with a context of its own) or 'callbacks': host-staged through gloo; False: the per-block Python path of round 2.
     (RCCL refuses two ranks on one device: its provider has a world-1 test below.)  'peer_fails_on_rank_1': one rank cannot set
-    the exchange up - the decision to fall back is collective, both ranks end on the same provider."""
+    the exchange up - the decision to fall back is collective, both ranks end on the same provider.  ('peer', 4): four ranks
+    on the one GPU - rank indexing of the exchange (a lane per rank on the reading side) beyond a pair."""
     assert torch.cuda.is_available()
     amd = importlib.import_module('3dinfomax_amd')
     from helpers import close, grads_close
     path = str(tmp_path / 'dp.npz')
-    mp.spawn(_worker, args=(_free_port(), path, native_sync), nprocs=WORLD, join=True)
+    mp.spawn(_worker, args=(_free_port(), path, native_sync, world), nprocs=world, join=True)
     z = np.load(path)
     mols = amd.synth.make_dataset(16, seed=21)
     pna, net = _models(amd)
