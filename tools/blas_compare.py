@@ -9,7 +9,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ops = importlib.import_module('3dinfomax_amd.ops')
 dev = torch.device('cuda:0')
-SHAPES = [('fwd   [N,F]x[F,F]^T', 0, 1, 8320, 200, 200), ('fwd   [E,F]x[F,F]^T', 0, 1, 16640, 200, 200),
+# (round 4: + the merged h-product [N,F]x[3F,F]^T, the grouped posttrans K = 5F, the merged data gradient [N,3F]x[3F,F])
+SHAPES = [('fwd   [N,F]x[3F,F]^T (PL)', 0, 1, 9216, 600, 200), ('fwd   [N,5F]x[F,5F]^T', 0, 1, 9216, 200, 1000),
+          ('dgrad [N,3F]x[3F,F]', 0, 0, 9216, 200, 600), ('fwd   [E,F]x[F,F]^T b512', 0, 1, 19100, 200, 200),
+          ('fwd   [N,F]x[F,F]^T', 0, 1, 8320, 200, 200), ('fwd   [E,F]x[F,F]^T', 0, 1, 16640, 200, 200),
           ('fwd   [N,F]x[2F,F]^T (P)', 0, 1, 8320, 400, 200), ('fwd   [N,4F]x[F,4F]^T', 0, 1, 8320, 200, 800),
           ('dgrad [E,F]x[F,F]', 0, 0, 16640, 200, 200), ('dgrad [N,F]x[F,4F]', 0, 0, 8320, 800, 200),
           ('wgrad [F,F] K=N', 1, 0, 200, 200, 8320), ('wgrad [F,F] K=E', 1, 0, 200, 200, 16640),
