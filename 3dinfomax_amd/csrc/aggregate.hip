@@ -219,34 +219,45 @@ __device__ __forceinline__ float& comp(T& a, int i) {
 
 // MODE as in the forward kernel (0: any list, 1: standard 12 blocks, 2: standard 4 blocks); MODE 1/2 need V = 4
 template <int V, int MODE = 0, bool MB16 = false>  // V = 4 (float4 items) or 1; MB16 (V = 4): messages stored as bf16
-__global__ void __launch_bounds__(256)
+// (the [N, 4F] form of the step sits one register above five waves per SIMD when left to the allocator: asked for)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V == 4 && MODE == 2 ? 5 : 1)))
 pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ e,
                          const int* __restrict__ in_ptr, int N, int F, AggCfg cfg, float* __restrict__ ge,
                          const float* __restrict__ aff) {
     I3D_CHAIN_PRIO();
     const int FV = F / V;
     // mean | scale | shift of the messages' BatchNorm is ONE [3F] vector for the whole launch: staged in LDS once per
-    // workgroup (round 2 loaded it per (node, chunk) item: three more 16-byte global loads per lane, 12.3 -> 16.8 us)
-    constexpr int AFF_MAX_F = 1024;
+    // workgroup (round 2 loaded it per (node, chunk) item: three more 16-byte global loads per lane, 12.3 -> 16.8 us).
+    // Its global loads are issued FIRST and parked in registers; the LDS stores and the barrier come after the lane has
+    // issued its index, gradient and message loads - in front of them the staging was one more dependent memory round
+    // trip per workgroup (round 4: 170 -> 14x us at batch 8192, where the plain kernel needs 144)
+    // (one 16-byte item per thread: F <= 340; wider layers take the per-lane global loads - two more staging registers per lane
+    // cost the kernel a wave of occupancy)
+    constexpr int AFF_MAX_F = 340;
     __shared__ __attribute__((aligned(16))) float affs[V == 4 ? 3 * AFF_MAX_F : 4];
     const bool aff_lds = V == 4 && aff != nullptr && F <= AFF_MAX_F;
-    if (aff_lds) {
-        for (int i = threadIdx.x; i < 3 * FV; i += blockDim.x)
-            reinterpret_cast<float4*>(affs)[i] = reinterpret_cast<const float4*>(aff)[i];
-        __syncthreads();
-    }
+    static_assert(3 * (AFF_MAX_F / 4) <= 256, "one staged 16-byte item per thread");
+    const int si0 = threadIdx.x;
+    float4 st0;      // (clamped index, unconditional load: a select between a global and a private address is a flat load)
+    if (aff_lds) st0 = reinterpret_cast<const float4*>(aff)[min(si0, 3 * FV - 1)];
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long)N * FV) return;
-    int v = (int)(t / FV), c = (int)(t - (long)v * FV);
+    const bool in_range = t < (long)N * FV;
+    int v = in_range ? (int)(t / FV) : 0, c = in_range ? (int)(t - (long)v * FV) : 0;
     int beg = in_ptr[v], D = in_ptr[v + 1] - beg;
-    if (D <= 0) return;
+    // lanes without work still take part in the barrier: they issue the same loads at addresses that exist (node 0's or
+    // their own node's gradient rows) and leave after it
+    const bool live = in_range && D > 0;
+    if (!live) { beg = 0; D = 1; }
     const int nblk = cfg.n_agg * cfg.n_scaler;
     const float* go = gout + (long)v * nblk * F + (long)c * V;
-    const float* p = e + (long)beg * F + (long)c * V;
+    // (a lane without work reads its gradient row instead of a message row: a graph without edges has no message row at all)
+    const float* p = live ? e + (long)beg * F + (long)c * V : go;
+    const unsigned short* p16 = live ? reinterpret_cast<const unsigned short*>(e) + (long)beg * F + (long)c * 4
+                                     : reinterpret_cast<const unsigned short*>(go);
     float* q = ge + (long)beg * F + (long)c * V;
     auto load_msg = [&](long row, float* dst) {
         if constexpr (MB16 && V == 4) {
-            const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(e) + ((long)beg + row) * F + (long)c * 4);
+            const uint2 t = *reinterpret_cast<const uint2*>(p16 + row * F);
             dst[0] = __uint_as_float(t.x << 16); dst[1 % V] = __uint_as_float(t.x & 0xffff0000u);
             dst[2 % V] = __uint_as_float(t.y << 16); dst[3 % V] = __uint_as_float(t.y & 0xffff0000u);
         } else if (V == 4) {
@@ -325,6 +336,11 @@ pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict
     for (int jj = 0; jj < 4; ++jj) {
         load_msg(min(jj, D - 1), xr[jj]);
     }
+    if (aff_lds) {           // every thread of the workgroup; the loads above are in flight: the barrier's wait covers them all at once
+        if (si0 < 3 * FV) reinterpret_cast<float4*>(affs)[si0] = st0;
+        __syncthreads();
+    }
+    if (!live) return;
     // messages as the forward saw them: (e - mean) * scale + shift (see pna_aggregate_fwd_kernel); the result is the
     // gradient with respect to THAT value, the BatchNorm backward in front follows in its own kernel
     float a_mu[V], a_sc[V], a_sh[V];

@@ -659,13 +659,13 @@ def pna_aggregate_fwd_aff(e, aff, in_ptr, num_nodes, aggregators, scalers, avg_d
 def pna_aggregate_bwd_aff(grad_out, e, aff, in_ptr, num_nodes, aggregators, scalers, avg_d_log, force_scalers=False):
     if e.dtype == torch.bfloat16:
         _chk(grad_out)
-        ge = torch.zeros(e.shape, dtype=torch.float32, device=e.device)
+        ge = torch.empty(e.shape, dtype=torch.float32, device=e.device)      # (every edge row has a destination: all rows are written)
         check(_lib.load().i3d_pna_aggregate_bwd_ex(_p(grad_out), e.data_ptr(), 1, _p(aff), _p(in_ptr), num_nodes, e.shape[1],
                                                    int_array(aggregators), len(aggregators), int_array(scalers), len(scalers),
                                                    int(force_scalers), float(avg_d_log), _p(ge), _stream()), 'i3d_pna_aggregate_bwd_ex')
         return ge
     _chk(grad_out), _chk(e)
-    ge = torch.zeros_like(e)
+    ge = torch.empty_like(e)
     check(_lib.load().i3d_pna_aggregate_bwd_aff(_p(grad_out), _p(e), _p(aff), _p(in_ptr), num_nodes, e.shape[1],
                                                 int_array(aggregators), len(aggregators), int_array(scalers), len(scalers),
                                                 int(force_scalers), float(avg_d_log), _p(ge), _stream()),
