@@ -141,6 +141,8 @@ _SIGNATURES = {
     'i3d_bn_eval_aff_multi': (c_int, [POINTER(BnEvalAff), c_int, _P]),
     'i3d_set_collectives': (c_int, [POINTER(Collectives)]),
     'i3d_collectives_world': (c_int, []),
+    'i3d_collectives_all_gather_f32': (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
+    'i3d_collectives_all_reduce_f64': (c_int, [c_void_p, c_long, c_void_p]),
     'i3d_rccl_available': (c_int, []),
     'i3d_rccl_unique_id': (c_int, [ctypes.c_char_p]),
     'i3d_rccl_init': (c_int, [ctypes.c_char_p, c_int, c_int, POINTER(c_void_p)]),

@@ -99,6 +99,15 @@ const I3dCollectives* collectives() { return g_coll.world > 0 && g_coll.all_gath
 
 using namespace i3d;
 
+#define I3D_CHECK_HIP(call)                                                                  \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            i3d::set_error("%s: %s failed: %s", __func__, #call, hipGetErrorString(e_));     \
+            return I3D_ERR_LAUNCH;                                                           \
+        }                                                                                    \
+    } while (0)
+
 extern "C" int i3d_set_collectives(const I3dCollectives* c) {
     peer_deactivate();      // the fused peer-exchange paths belong to i3d_set_collectives_peer, which re-arms them after this call
     if (c == nullptr) {
@@ -112,6 +121,39 @@ extern "C" int i3d_set_collectives(const I3dCollectives* c) {
 }
 
 extern "C" int i3d_collectives_world(void) { return collectives() != nullptr ? g_coll.world : 0; }
+
+// The installed provider's two collectives, callable by the host (a binding's self-test; tests/test_gpu_dist.py): exactly what the
+// BatchNorm entry points call when no fused exchange applies - the vectors staged in the table's scratch, as they stage theirs (a
+// host-staged provider may only know that buffer).  Every rank must make the same calls in the same order.
+extern "C" int i3d_collectives_all_gather_f32(const float* send, float* recv, long count, void* stream) {
+    const I3dCollectives* c = collectives();
+    I3D_CHECK_ARG(c != nullptr, "no collectives installed");
+    I3D_CHECK_ARG(send != nullptr && recv != nullptr && count > 0, "bad arguments");
+    const long cnt4 = (count + 3) & ~3L;
+    I3D_CHECK_ARG((cnt4 + (long)c->world * count) * 4 <= c->scratch_bytes, "vector too long for the provider's scratch");
+    float* s_send = (float*)c->scratch;
+    float* s_recv = s_send + cnt4;
+    hipStream_t st = (hipStream_t)stream;
+    I3D_CHECK_HIP(hipMemcpyAsync(s_send, send, (size_t)count * 4, hipMemcpyDeviceToDevice, st));
+    const int rc = c->all_gather_f32(c->user, s_send, s_recv, count, stream);
+    if (rc != I3D_OK) return rc;
+    I3D_CHECK_HIP(hipMemcpyAsync(recv, s_recv, (size_t)c->world * count * 4, hipMemcpyDeviceToDevice, st));
+    return I3D_OK;
+}
+
+extern "C" int i3d_collectives_all_reduce_f64(double* buf, long count, void* stream) {
+    const I3dCollectives* c = collectives();
+    I3D_CHECK_ARG(c != nullptr, "no collectives installed");
+    I3D_CHECK_ARG(buf != nullptr && count > 0, "bad arguments");
+    I3D_CHECK_ARG(count * 8 <= c->scratch_bytes, "vector too long for the provider's scratch");
+    double* s_buf = (double*)c->scratch;
+    hipStream_t st = (hipStream_t)stream;
+    I3D_CHECK_HIP(hipMemcpyAsync(s_buf, buf, (size_t)count * 8, hipMemcpyDeviceToDevice, st));
+    const int rc = c->all_reduce_f64(c->user, s_buf, count, stream);
+    if (rc != I3D_OK) return rc;
+    I3D_CHECK_HIP(hipMemcpyAsync(buf, s_buf, (size_t)count * 8, hipMemcpyDeviceToDevice, st));
+    return I3D_OK;
+}
 
 extern "C" int i3d_rccl_available(void) { return rccl() != nullptr ? 1 : 0; }
 

@@ -107,6 +107,39 @@ __device__ __forceinline__ void peer_get_words(const PeerDev& d, int q, const in
 #pragma unroll
     for (int k = 0; k < K; ++k) out[k] = (unsigned)v[k];
 }
+// word w of the payloads of ranks q0 .. q0 + Q - 1 (clamped to the last rank) of THIS collective: the Q loads in flight together
+template <int Q>
+__device__ __forceinline__ void peer_get_word_ranks(const PeerDev& d, int q0, int w, unsigned (&out)[Q]) {
+    const unsigned tag = (unsigned)d.seq;
+    const unsigned long long* a[Q];
+    unsigned long long v[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) a[k] = peer_recv_slot(d, min(q0 + k, d.world - 1)) + w;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) v[k] = __hip_atomic_load(a[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+    for (int k = 0; k < Q; ++k) ok = ok && (unsigned)(v[k] >> 32) == tag;
+    if (!ok && __hip_atomic_load(&d.box[d.rank]->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+        const long long t0 = wall_clock64();
+        for (;;) {
+            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int k = 0; k < Q; ++k) v[k] = __hip_atomic_load(a[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            ok = true;
+#pragma unroll
+            for (int k = 0; k < Q; ++k) ok = ok && (unsigned)(v[k] >> 32) == tag;
+            if (ok) break;
+            if (wall_clock64() - t0 > d.timeout) {
+                __hip_atomic_store(&d.box[d.rank]->dead, d.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(d.status, (int)d.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < Q; ++k) out[k] = (unsigned)v[k];
+}
 // element i of a float payload is word i, of a double payload words 2 i (low half) and 2 i + 1
 __device__ __forceinline__ void peer_put_f32(const PeerDev& d, int p, int i, float v) { peer_put_word(d, p, i, __float_as_uint(v)); }
 __device__ __forceinline__ void peer_put_f64(const PeerDev& d, int p, int i, double v) {

@@ -39,12 +39,11 @@ __global__ void __launch_bounds__(256) peer_all_gather_f32_kernel(const PeerDev 
     for (int p = 0; p < d.world; ++p) peer_put_f32(d, p, i, v);
     // four ranks per round: their words in flight together (a rank after the other is one memory latency per rank)
     for (int q0 = 0; q0 < d.world; q0 += 4) {
-        float r[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = peer_get_f32(d, min(q0 + k, d.world - 1), i);
+        unsigned r[4];
+        peer_get_word_ranks<4>(d, q0, i, r);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (q0 + k < d.world) recv[(long)(q0 + k) * count + i] = r[k];
+            if (q0 + k < d.world) recv[(long)(q0 + k) * count + i] = __uint_as_float(r[k]);
     }
 }
 

@@ -443,6 +443,13 @@ typedef struct {
 } I3dCollectives;
 int i3d_set_collectives(const I3dCollectives* c /* host; copied */);
 int i3d_collectives_world(void); /* 0: none set */
+/* The installed provider's collectives as the BatchNorm entry points call them when no fused exchange applies: recv[world][count]
+ * <- every rank's send[count]; buf[count] <- sum over the ranks (the peer provider: in rank order).  The vectors are staged through the
+ * table's scratch as the BatchNorm entry points stage theirs ((count + world count) floats / count doubles must fit).  For a binding's
+ * self-test (tests/test_gpu_dist.py); every rank makes the same calls in the same order on one stream.  (No reference counterpart:
+ * SURVEY.md C3.) */
+int i3d_collectives_all_gather_f32(const float* send, float* recv, long count, void* stream);
+int i3d_collectives_all_reduce_f64(double* buf, long count, void* stream);
 int i3d_rccl_available(void);
 int i3d_rccl_unique_id(char* out128 /* host */);
 int i3d_rccl_init(const char* id128 /* host */, int rank, int world, void** comm);

@@ -85,6 +85,25 @@ def _worker(rank, port, path, native_sync, WORLD=WORLD):
             for k, b in m.named_buffers():
                 out[f'b/{tag}/{k}'] = b.cpu().numpy()
         np.savez(path, **out)
+    if native_sync:      # the provider's own two collectives (what the BatchNorm entry points call when no fused exchange applies)
+        L = importlib.import_module('3dinfomax_amd._lib').load()
+        ops = importlib.import_module('3dinfomax_amd.ops')
+        stream = torch.cuda.current_stream().cuda_stream
+        for count in (1, 37, 1201):
+            send = torch.arange(count, device='cuda', dtype=torch.float32) * (rank + 1) + 0.25
+            recv = torch.empty(WORLD, count, device='cuda')
+            ops.check(L.i3d_collectives_all_gather_f32(send.data_ptr(), recv.data_ptr(), count, stream), 'all_gather')
+            want = torch.stack([torch.arange(count, dtype=torch.float32) * (r + 1) + 0.25 for r in range(WORLD)])
+            assert torch.equal(recv.cpu(), want), (count, recv, want)
+            buf = (torch.arange(count, dtype=torch.float64) / (rank + 3)).cuda()       # (inputs from the CPU: same bits as `tot` below)
+            ops.check(L.i3d_collectives_all_reduce_f64(buf.data_ptr(), count, stream), 'all_reduce')
+            tot = torch.zeros(count, dtype=torch.float64)
+            for r in range(WORLD):          # rank order: the same bits on every rank
+                tot = tot + torch.arange(count, dtype=torch.float64) / (r + 3)
+            if native_sync == 'peer':       # sums formed in rank order by every rank
+                assert torch.equal(buf.cpu(), tot), (count, buf.cpu() - tot)
+            else:                           # (the host-staged provider adds in gloo's order)
+                assert torch.allclose(buf.cpu(), tot, rtol=1e-14, atol=0), (count, buf.cpu() - tot)
     if native_sync == 'peer':
         L = importlib.import_module('3dinfomax_amd._lib').load()
         st = adist._native_sync
