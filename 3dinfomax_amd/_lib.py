@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('I3D_LIB_PATH') or os.path.join(HERE, 'lib', 'lib3dinf
 HEADER_PATH = os.path.join(os.path.dirname(HERE), 'include', 'infomax3d_hip.h')
 
 # constants of include/infomax3d_hip.h
-ACT = {'none': 0, None: 0, 'relu': 1, 'silu': 2, 'sigmoid': 3, 'leakyrelu': 4}
+ACT = {'none': 0, None: 0, 'relu': 1, 'silu': 2, 'sigmoid': 3, 'leakyrelu': 4, 'tanh': 5, 'elu': 6, 'selu': 7, 'softplus': 8}
 AGG = {'mean': 0, 'sum': 1, 'max': 2, 'min': 3, 'std': 4, 'var': 5}
 SCALER = {'identity': 0, 'amplification': 1, 'attenuation': 2}
 

@@ -55,6 +55,15 @@ static Chunking make_chunking(int rows, int feat) {
 
 enum { MODE_STATS = 0, MODE_BN_BWD = 1, MODE_COLSUM = 2 };
 
+// The pivot of the shifted sums of column c: a value near the column's data that EVERY workgroup and the finalisation derive from
+// row 0 alike - also when the activation is applied in place and row 0 may already hold act(pre) when a workgroup reads it.
+// ReLU / LeakyReLU (the in-place activations): max(v, 0) - the same number from pre and from act(pre) (act(act(v)) would not be,
+// for LeakyReLU: round 4, a wrong mean); identical to relu(v), the pivot used so far.  The others are never applied in place (their
+// derivative needs the pre-activation).
+__device__ __forceinline__ float stats_pivot(float v, int act) {
+    return (act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU) ? fmaxf(v, 0.f) : apply_act(v, act);
+}
+
 constexpr int FIN_COLS = 8, FIN_LANES = 32;    // stage 2: 8 columns x 32 partial-lanes per workgroup (25 of them at F=200)
 constexpr int WS_HEADER = 128;                 // bytes in front of the partial rows: the arrival / done counters
 
@@ -99,7 +108,7 @@ __device__ __forceinline__ void st_agent(float* p, float v) {
 
 __device__ __forceinline__ void finalize_column(const Final& f, int c, double s1, double s2) {
     if (f.kind == 0) {
-        const double shift = (double)apply_act(f.pre_row0[c], f.act);
+        const double shift = (double)stats_pivot(f.pre_row0[c], f.act);
         const double n = (double)f.rows;
         if (f.sums_out != nullptr) {   // synchronised BN: hand un-shifted fp64 sums to the all-reduce
             f.sums_out[c] = s1 + n * shift;
@@ -154,7 +163,7 @@ __device__ __forceinline__ void finalize_column_local(const Final& f, int c, dou
     const double n = (double)f.rows;
     double a = s1, b = s2;
     if (f.kind == 0) {
-        const double shift = (double)apply_act(f.pre_row0[c], f.act);
+        const double shift = (double)stats_pivot(f.pre_row0[c], f.act);
         a = s1 + n * shift;
         b = s2 + 2.0 * shift * s1 + n * shift * shift;
     } else {
@@ -286,7 +295,7 @@ __global__ void __launch_bounds__(256) colreduce_partial_kernel(ReduceArgs g, Ch
     if (active) {
         if (MODE == MODE_STATS) {
 #pragma unroll
-            for (int i = 0; i < V; ++i) shift[i] = apply_act(g.a[c0 + i], g.act);   // row 0
+            for (int i = 0; i < V; ++i) shift[i] = stats_pivot(g.a[c0 + i], g.act);   // row 0
         }
         if (MODE == MODE_BN_BWD) {
 #pragma unroll
@@ -410,7 +419,7 @@ __global__ void stats_final_kernel(const float* __restrict__ partial, int nblk, 
     int c;
     double s1, s2;
     if (!reduce_partials(partial, nblk, feat, c, s1, s2)) return;
-    double shift = (double)apply_act(pre_row0[c], act);
+    double shift = (double)stats_pivot(pre_row0[c], act);
     double n = (double)rows;
     if (sums_out != nullptr) {   // synchronised BN: hand un-shifted fp64 sums to the all-reduce
         sums_out[c] = s1 + n * shift;

@@ -53,6 +53,10 @@ __device__ __forceinline__ float apply_act(float x, int act) {
         case I3D_ACT_SILU: return x / (1.f + __expf(-x));
         case I3D_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
         case I3D_ACT_LEAKY_RELU: return x > 0.f ? x : 0.01f * x;
+        case I3D_ACT_TANH: return tanhf(x);
+        case I3D_ACT_ELU: return x > 0.f ? x : expm1f(x);
+        case I3D_ACT_SELU: return 1.0507009873554804934193349852946f * (x > 0.f ? x : 1.6732632423543772848170429916717f * expm1f(x));
+        case I3D_ACT_SOFTPLUS: return x > 20.f ? x : log1pf(expf(x));
         default: return x;
     }
 }
@@ -70,6 +74,13 @@ __device__ __forceinline__ float act_grad(float x, int act) {
             return s * (1.f - s);
         }
         case I3D_ACT_LEAKY_RELU: return x > 0.f ? 1.f : 0.01f;
+        case I3D_ACT_TANH: {
+            const float t = tanhf(x);
+            return 1.f - t * t;
+        }
+        case I3D_ACT_ELU: return x > 0.f ? 1.f : expf(x);
+        case I3D_ACT_SELU: return 1.0507009873554804934193349852946f * (x > 0.f ? 1.f : 1.6732632423543772848170429916717f * expf(x));
+        case I3D_ACT_SOFTPLUS: return x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
         default: return 1.f;
     }
 }

@@ -18,7 +18,7 @@ import torch.nn as nn
 from . import _lib, ops, tape
 from .streams import fork
 
-SUPPORTED_ACTIVATIONS = {'relu', 'silu', 'sigmoid', 'leakyrelu', 'none'}
+SUPPORTED_ACTIVATIONS = {'relu', 'silu', 'sigmoid', 'leakyrelu', 'tanh', 'elu', 'selu', 'softplus', 'none'}
 
 
 def act_name(activation):
@@ -29,7 +29,7 @@ def act_name(activation):
         activation = type(activation).__name__
     a = activation.lower()
     if a not in SUPPORTED_ACTIVATIONS:
-        raise NotImplementedError(f'activation {activation!r} has no HIP kernel yet (supported: ReLU, SiLU, Sigmoid, None)')
+        raise NotImplementedError(f'activation {activation!r} has no HIP kernel yet (supported: ReLU, SiLU, Sigmoid, LeakyReLU, Tanh, ELU, SELU, Softplus, None)')
     return None if a == 'none' else a
 
 

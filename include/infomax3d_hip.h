@@ -35,6 +35,12 @@ extern "C" {
 #define I3D_ACT_SILU 2
 #define I3D_ACT_SIGMOID 3
 #define I3D_ACT_LEAKY_RELU 4 /* negative slope 0.01 = nn.LeakyReLU() default, reference models/pna_original.py:291 */
+/* the rest of the reference's SUPPORTED_ACTIVATION_MAP (models/base_layers.py:5) with torch's default parameters; GLU (halves the
+ * feature dimension) is not an elementwise activation and is not offered */
+#define I3D_ACT_TANH 5
+#define I3D_ACT_ELU 6      /* alpha 1 */
+#define I3D_ACT_SELU 7
+#define I3D_ACT_SOFTPLUS 8 /* beta 1, threshold 20 */
 
 /* aggregators: reference models/pna.py:71-81 (PNA_AGGREGATORS); readout ops: dgl.readout_nodes */
 #define I3D_AGG_MEAN 0

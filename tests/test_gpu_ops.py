@@ -293,13 +293,18 @@ def test_padding_encoders_match_the_reference_module():
 
 # ---- BatchNorm -------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('rows,feat', [(5000, 200), (300, 20), (17, 7), (70000, 20)])
-@pytest.mark.parametrize('act,post', [('relu', None), (None, None), ('silu', 'silu')])
+@pytest.mark.parametrize('act,post', [('relu', None), (None, None), ('silu', 'silu'), ('leakyrelu', None), ('tanh', 'elu'),
+                                      ('selu', 'softplus'), ('softplus', 'tanh'), ('elu', 'selu')])
 def test_act_bn_fwd_bwd_vs_torch(rows, feat, act, post):
-    pre = rnd(rows, feat, seed=50) + 3.0            # large mean: exercises the shifted statistics
+    """activation -> BatchNorm1d (train) -> activation (+ residual) of FCLayer, reference models/base_layers.py:100-111, for every
+    elementwise entry of its SUPPORTED_ACTIVATION_MAP (:5) against the torch functions of the same names (default parameters)."""
+    # large mean: exercises the shifted statistics (the saturating activations get a small one: tanh(3 +- 1) is a constant)
+    pre = rnd(rows, feat, seed=50) + (3.0 if act in (None, 'relu', 'silu', 'leakyrelu') else 0.3)
     gamma, beta = rnd(feat, seed=51) * 0.2 + 1, rnd(feat, seed=52) * 0.2
     res = rnd(rows, feat, seed=53)
     rm, rv = torch.zeros(feat), torch.ones(feat)
-    acts = {'relu': F.relu, 'silu': F.silu, None: lambda t: t}
+    acts = {'relu': F.relu, 'silu': F.silu, None: lambda t: t, 'leakyrelu': F.leaky_relu, 'tanh': torch.tanh, 'elu': F.elu,
+            'selu': F.selu, 'softplus': F.softplus}
     pr = pre.clone().requires_grad_(True)
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     x = acts[act](pr)
@@ -308,7 +313,7 @@ def test_act_bn_fwd_bwd_vs_torch(rows, feat, act, post):
     (y * cot).sum().backward()
     rm_g, rv_g = torch.zeros(feat, device=DEV), torch.ones(feat, device=DEV)
     pre_g = g(pre)
-    keep = act not in (None, 'relu')
+    keep = act not in (None, 'relu', 'leakyrelu')
     xg, mean, invstd = ops.act_stats_fwd(pre_g.clone(), act, 1e-5, 0.93, rm_g, rv_g,
                                          out=torch.empty_like(pre_g) if keep else None)
     yg = ops.bn_apply_fwd(xg, mean, invstd, g(gamma), g(beta), post, g(res))
@@ -676,3 +681,51 @@ def test_dropout_function_is_torch_dropout():
     y.sum().backward()
     assert torch.equal(x.grad, (y_ref != 0).float() / 0.7) or rel_err(x.grad.cpu(), ((y_ref != 0).float() / 0.7).cpu()) < 1e-6
     assert layers.dropout(x, 0.3, False) is x and layers.dropout(x, 0.0, True) is x
+
+
+@pytest.mark.parametrize('bn', [True, False])
+@pytest.mark.parametrize('act', ['Tanh', 'ELU', 'SELU', 'Softplus', 'LeakyReLU', 'Sigmoid'])
+def test_fclayer_with_every_elementwise_activation_of_the_reference_map(act, bn):
+    """FCLayer(activation=<name>) for the entries of the reference's SUPPORTED_ACTIVATION_MAP (models/base_layers.py:5, resolved by
+    get_activation :9-20 to torch.nn.modules.activation.<name>() with default parameters) against Linear -> that torch module ->
+    BatchNorm1d, forward, backward and eval mode.  (GLU halves the feature dimension: not an elementwise activation, not offered.)"""
+    layers = importlib.import_module('3dinfomax_amd.layers')
+    torch.manual_seed(1)
+    fc = layers.FCLayer(24, 40, activation=act, batch_norm=bn, batch_norm_momentum=0.1).cuda().train()
+    with torch.no_grad():
+        fc.linear.weight.mul_(24 * 0.3)
+        fc.linear.bias.normal_()
+    ref_lin = torch.nn.Linear(24, 40).cuda()
+    ref_lin.load_state_dict(fc.linear.state_dict())
+    ref_bn = torch.nn.BatchNorm1d(40, momentum=0.1).cuda().train() if bn else None
+    ref_act = vars(torch.nn.modules.activation)[act]()
+    x = torch.randn(300, 24, device='cuda:0')
+    w = torch.randn(300, 40, device='cuda:0')
+
+    def ref(xx):
+        h = ref_act(ref_lin(xx))
+        return ref_bn(h) if ref_bn is not None else h
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya, yb = fc(xa), ref(xb)
+    assert rel_err(ya.cpu(), yb.detach().cpu()) < 2e-5
+    (ya * w).sum().backward()
+    (yb * w).sum().backward()
+    assert rel_err(xa.grad.cpu(), xb.grad.cpu()) < 2e-4
+    assert rel_err(fc.linear.weight.grad.cpu(), ref_lin.weight.grad.cpu()) < 2e-4
+    if bn:
+        assert rel_err(fc.batch_norm.weight.grad.cpu(), ref_bn.weight.grad.cpu()) < 2e-4
+        assert rel_err(fc.batch_norm.bias.grad.cpu(), ref_bn.bias.grad.cpu()) < 2e-4
+        assert rel_err(fc.batch_norm.running_var.cpu(), ref_bn.running_var.cpu()) < 1e-5
+    else:
+        assert rel_err(fc.linear.bias.grad.cpu(), ref_lin.bias.grad.cpu()) < 2e-4
+    fc.eval()
+    if ref_bn is not None:
+        ref_bn.eval()
+    with torch.no_grad():
+        assert rel_err(fc(x).cpu(), ref(x).cpu()) < 2e-5
+
+
+def test_glu_is_refused_by_name():
+    layers = importlib.import_module('3dinfomax_amd.layers')
+    with pytest.raises(NotImplementedError):
+        layers.FCLayer(8, 8, activation='GLU')
