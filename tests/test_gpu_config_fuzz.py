@@ -12,7 +12,7 @@ import torch
 
 from helpers import rel_err, synth
 from oracle import pna3d_oracle as O
-from test_gpu_models import _det_load, make_batch, param_grads
+from test_gpu_models import _det_load, _lonely, _star, make_batch, param_grads
 
 pytestmark = pytest.mark.gpu
 
@@ -85,6 +85,8 @@ def test_pna_option_combinations_vs_oracle(seed):
     rng = random.Random(1000 + seed)
     kw = _pna_cfg(rng)
     mols = synth.make_dataset(rng.choice([9, 24]), seed=200 + seed)
+    if seed % 3 == 0:       # ragged batches: an isolated atom (in-degree 0, a graph without edges), a hub, a two-atom molecule
+        mols = [_lonely(seed)] + mols[:4] + [_star(9 + seed % 7, seed), _star(1, seed + 1)] + mols[4:]
     pna = amd.PNA(avg_d=1.0, device='cuda:0', **kw)
     _det_load(pna, f'fuzz{seed}')
     sd = {k: v.clone() for k, v in pna.state_dict().items()}
@@ -151,6 +153,8 @@ def test_tower_variant_option_combinations_vs_oracle(seed, stack, monkeypatch):
     rng = random.Random(3000 + seed)
     kw = _orig_cfg(rng)
     mols = synth.make_dataset(rng.choice([8, 20]), seed=400 + seed)
+    if seed % 3 == 0:
+        mols = [_lonely(seed)] + mols[:4] + [_star(9 + seed % 7, seed), _star(1, seed + 1)] + mols[4:]
     model = amd.PNAOriginal(**kw)
     _det_load(model, f'fuzzo{seed}')
     sd = {k: v.clone() for k, v in model.state_dict().items()}
