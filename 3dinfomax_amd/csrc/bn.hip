@@ -60,8 +60,10 @@ enum { MODE_STATS = 0, MODE_BN_BWD = 1, MODE_COLSUM = 2 };
 // ReLU / LeakyReLU (the in-place activations): max(v, 0) - the same number from pre and from act(pre) (act(act(v)) would not be,
 // for LeakyReLU: round 4, a wrong mean); identical to relu(v), the pivot used so far.  The others are never applied in place (their
 // derivative needs the pre-activation).
+template <bool GA = true>      // (GA false: the kernel was launched for none / ReLU / LeakyReLU only, common.h)
 __device__ __forceinline__ float stats_pivot(float v, int act) {
-    return (act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU) ? fmaxf(v, 0.f) : apply_act(v, act);
+    if (act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU) return fmaxf(v, 0.f);
+    return GA ? apply_act(v, act) : v;
 }
 
 constexpr int FIN_COLS = 8, FIN_LANES = 32;    // stage 2: 8 columns x 32 partial-lanes per workgroup (25 of them at F=200)
@@ -106,9 +108,10 @@ __device__ __forceinline__ void st_agent(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <bool GA>
 __device__ __forceinline__ void finalize_column(const Final& f, int c, double s1, double s2) {
     if (f.kind == 0) {
-        const double shift = (double)stats_pivot(f.pre_row0[c], f.act);
+        const double shift = (double)stats_pivot<GA>(f.pre_row0[c], f.act);
         const double n = (double)f.rows;
         if (f.sums_out != nullptr) {   // synchronised BN: hand un-shifted fp64 sums to the all-reduce
             f.sums_out[c] = s1 + n * shift;
@@ -159,11 +162,12 @@ __device__ __forceinline__ void finalize_column_global(const Final& f, int c, do
 }
 
 // this rank's contribution to the exchange (un-shifted sums for the statistics); the pair's local results are stored here
+template <bool GA>
 __device__ __forceinline__ void finalize_column_local(const Final& f, int c, double s1, double s2) {
     const double n = (double)f.rows;
     double a = s1, b = s2;
     if (f.kind == 0) {
-        const double shift = (double)stats_pivot(f.pre_row0[c], f.act);
+        const double shift = (double)stats_pivot<GA>(f.pre_row0[c], f.act);
         a = s1 + n * shift;
         b = s2 + 2.0 * shift * s1 + n * shift * shift;
     } else {
@@ -178,6 +182,7 @@ __device__ __forceinline__ void finalize_column_local(const Final& f, int c, dou
 }
 
 // called by ALL threads of every workgroup after the partial row of the workgroup has been stored with st_agent
+template <bool GA>
 __device__ __forceinline__ void arrive_and_finalize(const Final& f, const float* partial, int nblk) {
     __shared__ unsigned s_ticket;
     __shared__ double s_red[2][FIN_LANES][FIN_COLS];
@@ -225,8 +230,8 @@ __device__ __forceinline__ void arrive_and_finalize(const Final& f, const float*
             double s1 = 0.0, s2 = 0.0;
 #pragma unroll
             for (int k = 0; k < FIN_LANES; ++k) { s1 += s_red[0][k][cx]; s2 += s_red[1][k][cx]; }
-            if (f.peer_on) finalize_column_local(f, c, s1, s2);
-            else finalize_column(f, c, s1, s2);
+            if (f.peer_on) finalize_column_local<GA>(f, c, s1, s2);
+            else finalize_column<GA>(f, c, s1, s2);
         }
         if (f.peer_on) {        // (uniform) the column block's exchange: lane `ly` < world fetches rank ly's triple of its column
             if (ly < f.peer.world && c < f.feat) {
@@ -279,7 +284,7 @@ __device__ __forceinline__ float4 load4_maybe_bf16(const float* base, long off, 
     return *reinterpret_cast<const float4*>(base + off);
 }
 
-template <int MODE, int V>
+template <int MODE, int V, bool GA>      // GA: see apply_act_c (common.h)
 __global__ void __launch_bounds__(256) colreduce_partial_kernel(ReduceArgs g, Chunking ch, Final fin) {
     I3D_CHAIN_PRIO();
     __shared__ float sm[2][256 * 4];
@@ -295,7 +300,7 @@ __global__ void __launch_bounds__(256) colreduce_partial_kernel(ReduceArgs g, Ch
     if (active) {
         if (MODE == MODE_STATS) {
 #pragma unroll
-            for (int i = 0; i < V; ++i) shift[i] = stats_pivot(g.a[c0 + i], g.act);   // row 0
+            for (int i = 0; i < V; ++i) shift[i] = stats_pivot<GA>(g.a[c0 + i], g.act);   // row 0
         }
         if (MODE == MODE_BN_BWD) {
 #pragma unroll
@@ -340,7 +345,7 @@ __global__ void __launch_bounds__(256) colreduce_partial_kernel(ReduceArgs g, Ch
                 if (MODE == MODE_STATS) {
 #pragma unroll
                     for (int i = 0; i < V; ++i) {
-                        x[i] = apply_act(x[i], g.act);
+                        x[i] = apply_act_c<GA>(x[i], g.act);
                         float d = x[i] - shift[i];
                         a1[i] += d;
                         a2[i] += d * d;
@@ -354,7 +359,7 @@ __global__ void __launch_bounds__(256) colreduce_partial_kernel(ReduceArgs g, Ch
                     for (int i = 0; i < V; ++i) {
                         float xh = (ys[u][i] - mu[i]) * is[i];
                         float dy = x[i];
-                        if (g.post_act != I3D_ACT_NONE) dy *= act_grad(xh * ga[i] + be[i], g.post_act);
+                        if (g.post_act != I3D_ACT_NONE) dy *= act_grad_c<GA>(xh * ga[i] + be[i], g.post_act);
                         a1[i] += dy;
                         a2[i] += dy * xh;
                     }
@@ -382,7 +387,7 @@ __global__ void __launch_bounds__(256) colreduce_partial_kernel(ReduceArgs g, Ch
 #pragma unroll
         for (int i = 0; i < V; ++i) { st_agent(p + i, s1[i]); st_agent(p + F + i, s2[i]); }
     }
-    if (fin.counters != nullptr) arrive_and_finalize(fin, g.partial, gridDim.x);
+    if (fin.counters != nullptr) arrive_and_finalize<GA>(fin, g.partial, gridDim.x);
 }
 
 // ---- stage 2 ----------------------------------------------------------------------------------------
@@ -521,7 +526,7 @@ static RowTiling make_row_tiling(int feat, int V) {
     return t;
 }
 
-template <int V>
+template <int V, bool GA>
 __global__ void __launch_bounds__(256) bn_apply_kernel(ApplyArgs g, RowTiling rt, int rows) {
     I3D_CHAIN_PRIO();
     const int cl = threadIdx.x % rt.tpr, rlane = threadIdx.x / rt.tpr;
@@ -564,7 +569,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(ApplyArgs g, RowTiling rt
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             float v = (x[u][i] - sh[i]) * sc[i] * ga[i] + be[i];
-            v = apply_act(v, g.post_act);
+            v = apply_act_c<GA>(v, g.post_act);
             if (g.residual) v += r[u][i];
             x[u][i] = v;
         }
@@ -593,7 +598,7 @@ struct BwdApplyArgs {
     int x_bf16;               // x is stored as bf16 (feat % 4 == 0)
 };
 
-template <int V>
+template <int V, bool GA>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BwdApplyArgs g, RowTiling rt, int rows) {
     I3D_CHAIN_PRIO();
     const int cl = threadIdx.x % rt.tpr, rlane = threadIdx.x / rt.tpr;
@@ -646,11 +651,11 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BwdApplyArgs g, RowTi
         for (int i = 0; i < V; ++i) {
             float xh = (x[u][i] - mu[i]) * is[i];
             float d = dy[u][i];
-            if (g.post_act != I3D_ACT_NONE) d *= act_grad(xh * ga[i] + be[i], g.post_act);
+            if (g.post_act != I3D_ACT_NONE) d *= act_grad_c<GA>(xh * ga[i] + be[i], g.post_act);
             float gx;
             if (g.eval_mode) gx = d * ga[i] * is[i];
             else gx = ga[i] * is[i] * (d - k1[i] - xh * k2[i]);
-            if (g.act != I3D_ACT_NONE) gx *= act_grad(g.pre ? p[u][i] : x[u][i], g.act);   // relu'(pre) == relu'(x)
+            if (g.act != I3D_ACT_NONE) gx *= act_grad_c<GA>(g.pre ? p[u][i] : x[u][i], g.act);   // relu'(pre) == relu'(x)
             dy[u][i] = gx;
         }
         const long oo = (long)row * g.ld_out + c0;
@@ -661,7 +666,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BwdApplyArgs g, RowTi
 
 // bn_bwd_apply + column sums of the result (the bias gradient of the Linear in front: dL/db = sum_rows grad_pre): the
 // row-chunk layout of the reduction kernels, one partial row per block, finalised by pair_final_kernel.
-template <int V>
+template <int V, bool GA>
 __global__ void __launch_bounds__(256) bn_bwd_apply_colsum_kernel(BwdApplyArgs g, Chunking ch, int rows, float* partial,
                                                                   Final fin) {
     I3D_CHAIN_PRIO();
@@ -719,9 +724,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_colsum_kernel(BwdApplyArgs g
                 for (int i = 0; i < V; ++i) {
                     float xh = (x[u][i] - mu[i]) * is[i];
                     float d = dy[u][i];
-                    if (g.post_act != I3D_ACT_NONE) d *= act_grad(xh * ga[i] + be[i], g.post_act);
+                    if (g.post_act != I3D_ACT_NONE) d *= act_grad_c<GA>(xh * ga[i] + be[i], g.post_act);
                     float gx = ga[i] * is[i] * (d - k1[i] - xh * k2[i]);
-                    if (g.act != I3D_ACT_NONE) gx *= act_grad(g.pre ? p[u][i] : x[u][i], g.act);
+                    if (g.act != I3D_ACT_NONE) gx *= act_grad_c<GA>(g.pre ? p[u][i] : x[u][i], g.act);
                     dy[u][i] = gx;
                     a1[i] += gx;
                 }
@@ -747,20 +752,20 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_colsum_kernel(BwdApplyArgs g
 #pragma unroll
         for (int i = 0; i < V; ++i) { st_agent(q + i, s1[i]); st_agent(q + F + i, 0.f); }
     }
-    if (fin.counters != nullptr) arrive_and_finalize(fin, partial, gridDim.x);
+    if (fin.counters != nullptr) arrive_and_finalize<GA>(fin, partial, gridDim.x);
 }
 
 __global__ void __launch_bounds__(256) act_fwd_kernel(const float* __restrict__ x, long n, int act, float* __restrict__ y) {
     I3D_CHAIN_PRIO();
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
-        y[t] = apply_act(x[t], act);
+        y[t] = apply_act_any(x[t], act);
 }
 
 __global__ void __launch_bounds__(256)
 act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, long n, int act, float* __restrict__ gx) {
     I3D_CHAIN_PRIO();
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
-        gx[t] = gy[t] * act_grad(x[t], act);
+        gx[t] = gy[t] * act_grad_any(x[t], act);
 }
 
 __global__ void __launch_bounds__(256) add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, long n) {
@@ -836,8 +841,14 @@ static Final pair_final_desc(void* workspace, int feat, float* out1, float* out2
 template <int MODE>
 static void launch_reduction(const ReduceArgs& g, const Chunking& ch, const Final& f, hipStream_t s) {
     dim3 grid(ch.nblk, ch.ncolblk);
-    if (ch.V == 4) hipLaunchKernelGGL((colreduce_partial_kernel<MODE, 4>), grid, dim3(256), 0, s, g, ch, f);
-    else hipLaunchKernelGGL((colreduce_partial_kernel<MODE, 1>), grid, dim3(256), 0, s, g, ch, f);
+    const bool ga = !(relu_class(g.act) && relu_class(g.post_act));
+    if (ch.V == 4) {
+        if (ga) hipLaunchKernelGGL((colreduce_partial_kernel<MODE, 4, true>), grid, dim3(256), 0, s, g, ch, f);
+        else hipLaunchKernelGGL((colreduce_partial_kernel<MODE, 4, false>), grid, dim3(256), 0, s, g, ch, f);
+    } else {
+        if (ga) hipLaunchKernelGGL((colreduce_partial_kernel<MODE, 1, true>), grid, dim3(256), 0, s, g, ch, f);
+        else hipLaunchKernelGGL((colreduce_partial_kernel<MODE, 1, false>), grid, dim3(256), 0, s, g, ch, f);
+    }
     if (f.counters != nullptr) return;
     if (f.kind == 0)
         hipLaunchKernelGGL(stats_final_kernel, dim3(cdiv(f.feat, FIN_COLS)), dim3(256), 0, s, g.partial, ch.nblk, f.pre_row0,
@@ -871,6 +882,7 @@ extern "C" int i3d_act_stats_fwd_counted(const float* pre, int rows, int feat, i
                                          double* sums_out, long long* num_batches_tracked, void* workspace, void* stream) {
     I3D_CHECK_ARG(rows > 0 && feat > 0, "rows > 0 and feat > 0 required");
     I3D_CHECK_ARG(workspace != nullptr, "workspace required");
+    I3D_CHECK_ARG(fused_act(act), "this activation exists as an elementwise pass only (i3d_act_fwd / i3d_act_bwd)");
     hipStream_t s = (hipStream_t)stream;
     if (const I3dCollectives* coll = sums_out == nullptr ? collectives() : nullptr) {
         // synchronised BatchNorm (comm.hip): un-shifted fp64 [sum, sum of squares, count] of this rank -> all-reduce on this
@@ -934,8 +946,14 @@ static int bn_apply_common(const float* x, int rows, int feat, const float* mean
     const int V = feat % 4 == 0 ? 4 : 1;
     const RowTiling rt = make_row_tiling(feat, V);
     dim3 grid(cdiv(rows, rt.rl * RU), rt.ncolblk);
-    if (V == 4) hipLaunchKernelGGL(bn_apply_kernel<4>, grid, dim3(256), 0, s, g, rt, rows);
-    else hipLaunchKernelGGL(bn_apply_kernel<1>, grid, dim3(256), 0, s, g, rt, rows);
+    const bool ga = !relu_class(post_act);
+    if (V == 4) {
+        if (ga) hipLaunchKernelGGL((bn_apply_kernel<4, true>), grid, dim3(256), 0, s, g, rt, rows);
+        else hipLaunchKernelGGL((bn_apply_kernel<4, false>), grid, dim3(256), 0, s, g, rt, rows);
+    } else {
+        if (ga) hipLaunchKernelGGL((bn_apply_kernel<1, true>), grid, dim3(256), 0, s, g, rt, rows);
+        else hipLaunchKernelGGL((bn_apply_kernel<1, false>), grid, dim3(256), 0, s, g, rt, rows);
+    }
     return I3D_OK;
 }
 
@@ -943,6 +961,7 @@ extern "C" int i3d_bn_apply_fwd(const float* x, int rows, int feat, const float*
                                 const float* gamma, const float* beta, int post_act, const float* residual, float* y,
                                 void* stream) {
     I3D_CHECK_ARG(rows >= 0 && feat > 0, "bad shape");
+    I3D_CHECK_ARG(fused_act(post_act), "this activation exists as an elementwise pass only (i3d_act_fwd / i3d_act_bwd)");
     bn_apply_common(x, rows, feat, mean, invstd, gamma, beta, post_act, residual, y, 0, 0.f, stream);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
@@ -952,6 +971,7 @@ extern "C" int i3d_bn_eval_fwd(const float* x, int rows, int feat, const float* 
                                const float* running_var, float eps, const float* gamma, const float* beta,
                                int post_act, const float* residual, float* y, void* stream) {
     I3D_CHECK_ARG(rows >= 0 && feat > 0, "bad shape");
+    I3D_CHECK_ARG(fused_act(post_act), "this activation exists as an elementwise pass only (i3d_act_fwd / i3d_act_bwd)");
     bn_apply_common(x, rows, feat, running_mean, running_var, gamma, beta, post_act, residual, y, 1, eps, stream);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
@@ -962,8 +982,14 @@ static void launch_bwd_apply(BwdApplyArgs& g, int rows, int feat, hipStream_t s)
     const int V = feat % 4 == 0 ? 4 : 1;
     const RowTiling rt = make_row_tiling(feat, V);
     dim3 grid(cdiv(rows, rt.rl * RU), rt.ncolblk);
-    if (V == 4) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, grid, dim3(256), 0, s, g, rt, rows);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, s, g, rt, rows);
+    const bool ga = !(relu_class(g.act) && relu_class(g.post_act));
+    if (V == 4) {
+        if (ga) hipLaunchKernelGGL((bn_bwd_apply_kernel<4, true>), grid, dim3(256), 0, s, g, rt, rows);
+        else hipLaunchKernelGGL((bn_bwd_apply_kernel<4, false>), grid, dim3(256), 0, s, g, rt, rows);
+    } else {
+        if (ga) hipLaunchKernelGGL((bn_bwd_apply_kernel<1, true>), grid, dim3(256), 0, s, g, rt, rows);
+        else hipLaunchKernelGGL((bn_bwd_apply_kernel<1, false>), grid, dim3(256), 0, s, g, rt, rows);
+    }
 }
 
 extern "C" int i3d_bn_bwd(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
@@ -1002,6 +1028,7 @@ static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, in
     I3D_CHECK_ARG(rows > 0 && feat > 0, "rows > 0 and feat > 0 required");
     I3D_CHECK_ARG(workspace != nullptr, "workspace required");
     I3D_CHECK_ARG(act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU || pre != nullptr, "pre required for this activation");
+    I3D_CHECK_ARG(fused_act(act) && fused_act(post_act), "this activation exists as an elementwise pass only (i3d_act_fwd / i3d_act_bwd)");
     hipStream_t s = (hipStream_t)stream;
     if (const I3dCollectives* coll = (sums_out == nullptr && sums_in == nullptr) ? collectives() : nullptr) {
         // synchronised BatchNorm (comm.hip): this rank's fp64 [sum dy, sum dy xhat] and row count -> all-reduce on this
@@ -1106,8 +1133,14 @@ static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, in
             f.counters = nullptr;
             bias_part = bias_partial;
         }
-        if (ch.V == 4) hipLaunchKernelGGL(bn_bwd_apply_colsum_kernel<4>, grid, dim3(256), 0, s, b, ch, rows, bias_part, f);
-        else hipLaunchKernelGGL(bn_bwd_apply_colsum_kernel<1>, grid, dim3(256), 0, s, b, ch, rows, bias_part, f);
+        const bool ga = !(relu_class(b.act) && relu_class(b.post_act));
+        if (ch.V == 4) {
+            if (ga) hipLaunchKernelGGL((bn_bwd_apply_colsum_kernel<4, true>), grid, dim3(256), 0, s, b, ch, rows, bias_part, f);
+            else hipLaunchKernelGGL((bn_bwd_apply_colsum_kernel<4, false>), grid, dim3(256), 0, s, b, ch, rows, bias_part, f);
+        } else {
+            if (ga) hipLaunchKernelGGL((bn_bwd_apply_colsum_kernel<1, true>), grid, dim3(256), 0, s, b, ch, rows, bias_part, f);
+            else hipLaunchKernelGGL((bn_bwd_apply_colsum_kernel<1, false>), grid, dim3(256), 0, s, b, ch, rows, bias_part, f);
+        }
         I3D_CHECK_LAUNCH();
         if (bias_partial != nullptr) return I3D_OK;
         if (f.counters == nullptr) {
@@ -1161,6 +1194,7 @@ extern "C" int i3d_bn_eval_bwd(const float* grad_y, const float* x, const float*
                                float* grad_pre, void* workspace, void* stream) {
     I3D_CHECK_ARG(rows > 0 && feat > 0, "rows > 0 and feat > 0 required");
     I3D_CHECK_ARG(workspace != nullptr, "workspace required");
+    I3D_CHECK_ARG(fused_act(act) && fused_act(post_act), "this activation exists as an elementwise pass only (i3d_act_fwd / i3d_act_bwd)");
     hipStream_t s = (hipStream_t)stream;
     // grad_gamma / grad_beta need xhat with invstd from running_var: materialise invstd in the workspace tail
     Chunking ch = make_chunking(rows, feat);

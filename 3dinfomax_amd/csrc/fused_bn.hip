@@ -253,7 +253,7 @@ edge_combine_act_stats_kernel(const float* __restrict__ P, int ldp, const float*
                 for (int i = 0; i < V; ++i) {
                     float r = a[u][i] + b[u][i] + (Q != nullptr ? d[u][i] : 0.f);       // summation order of edge_combine_fwd
                     if (bias != nullptr) r += bb[i];
-                    r = apply_act(r, act);
+                    r = apply_act_c<false>(r, act);      // (none / ReLU / LeakyReLU: checked by the host)
                     x[h + u][i] = live ? r : 0.f;
                     if (live) s1[i] += r;
                 }

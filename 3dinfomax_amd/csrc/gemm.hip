@@ -502,7 +502,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
                             if (n + q < g.N) r[q] += ci[q];
                     }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) r[q] = apply_act(r[q], g.epi_act);
+                    for (int q = 0; q < 4; ++q) r[q] = apply_act_c<false>(r[q], g.epi_act);      // (none / ReLU / LeakyReLU: checked by the host)
                     if (g.c_bf16) {      // (N % 4 == 0 checked by the host: a group of 4 is whole)
                         auto rne = [](float x) { const unsigned u = __float_as_uint(x); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
                         unsigned short* c16 = reinterpret_cast<unsigned short*>(Cout) + (long)row * g.ldc + n;
@@ -1353,8 +1353,7 @@ extern "C" int i3d_gemm_f32_fused_src(int M, int N, int K, const float* A, int l
     I3D_CHECK_ARG(a_aff == nullptr || K <= FUSE_MAX_K, "BatchNorm prologue: K <= 1024");
     I3D_CHECK_ARG((m_rows == nullptr) == (tile_group == nullptr), "grouped GEMM needs m_rows and tile_group");
     I3D_CHECK_ARG(m_rows == nullptr || M % 64 == 0, "grouped GEMM needs 64-padded m_rows");
-    I3D_CHECK_ARG(epi_act == I3D_ACT_NONE || epi_act == I3D_ACT_RELU || epi_act == I3D_ACT_LEAKY_RELU || stats != nullptr,
-                  "epilogue activation needs the statistics variant");
+    I3D_CHECK_ARG(relu_class(epi_act), "epilogue activation: none, ReLU or LeakyReLU (the others: a pass of their own)");
     const bool al = ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) == 0) && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 &&
                     K % 4 == 0 && b_group_stride % 4 == 0;
     I3D_CHECK_ARG(al, "fused GEMM needs 16-byte aligned operands and K, leading dimensions multiples of 4");

@@ -19,6 +19,9 @@ from . import _lib, ops, tape
 from .streams import fork
 
 SUPPORTED_ACTIVATIONS = {'relu', 'silu', 'sigmoid', 'leakyrelu', 'tanh', 'elu', 'selu', 'softplus', 'none'}
+# activations that exist as an elementwise pass only (csrc/common.h: apply_act_any): the fused kernels - GEMM epilogues, statistics /
+# BatchNorm passes - keep the four the reference's configurations use (their switch is inlined into every kernel of the step)
+ELEMENTWISE_ONLY = {'tanh', 'elu', 'selu', 'softplus'}
 
 
 def act_name(activation):
@@ -99,8 +102,8 @@ class _Tail:
     @staticmethod
     def forward(pre, gamma, beta, spec: FCSpec, residual=None):
         bn = spec.bn
-        if spec.dropout > 0.0:
-            return _Tail._forward_dropout(pre, gamma, beta, spec, residual)
+        if spec.dropout > 0.0 or spec.act in ELEMENTWISE_ONLY or spec.post_act in ELEMENTWISE_ONLY:
+            return _Tail._forward_split(pre, gamma, beta, spec, residual)
         if bn is None:
             acts = [a for a in (spec.act, spec.post_act) if a is not None]
             inputs, y = [], pre
@@ -131,62 +134,87 @@ class _Tail:
         return y, (x, pre if keep_pre else None, bn.running_mean.clone(), bn.running_var.clone())
 
     @staticmethod
-    def _forward_dropout(pre, gamma, beta, spec: FCSpec, residual):
-        """Linear -> activation -> DROPOUT -> BatchNorm (reference models/base_layers.py:100-111): the activation as a pass of its
-        own, the mask torch's dropout kernel draws for this shape (ops.dropout_mask: the reference module's mask for the same
-        seed on this device), BatchNorm statistics of the dropped values.  Training mode only (spec.dropout is 0 in eval)."""
+    def _forward_split(pre, gamma, beta, spec: FCSpec, residual):
+        """Linear -> activation -> DROPOUT -> BatchNorm -> post-activation (reference models/base_layers.py:100-111) with the
+        activation as a pass of its own: the form for dropout > 0 (the mask is the one torch's dropout kernel draws for this shape
+        - ops.dropout_mask: the reference module's mask for the same seed on this device - and the BatchNorm statistics are those
+        of the dropped values; training mode only, spec.dropout is 0 in eval) and for the activations the fused kernels do not
+        carry (ELEMENTWISE_ONLY)."""
         bn = spec.bn
         a = ops.act_fwd(pre, spec.act) if spec.act is not None else pre
-        m = ops.dropout_mask(a, spec.dropout)
-        x = ops.mul(a, m)
+        m = ops.dropout_mask(a, spec.dropout) if spec.dropout > 0.0 else None
+        x = ops.mul(a, m) if m is not None else a
+        post = spec.post_act
+        fused_post = post if post not in ELEMENTWISE_ONLY else None       # (applied by the BatchNorm apply kernel, with the residual)
         if bn is None:
-            y = ops.act_fwd(x, spec.post_act) if spec.post_act is not None else x
+            mean = stat2 = None
+            y0 = x
+            y = ops.act_fwd(x, post) if post is not None else x
             if residual is not None:
-                y = ops.add_inplace(y.clone() if y is x else y, residual)
-            return y, ('dropout', pre, a, x, m, None, None)
-        if bn.sync_group is not None:
-            from . import dist as adist
-            sums = torch.empty(2 * x.shape[1] + 1, dtype=torch.float64, device=x.device)
-            ops.act_stats_fwd(x, None, bn.eps, bn.momentum, sums_out=sums)
-            adist.all_reduce_sum(sums, bn.sync_group)
-            mean, invstd = ops.bn_finalize_stats(sums, x.shape[1], bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+                y = ops.add_inplace(y.clone() if (y is x and (x is pre or x is a)) else y, residual)
+            return y, ('split', pre, a, x, m, None, None, y0)
+        if bn.training:
+            if bn.sync_group is not None:
+                from . import dist as adist
+                sums = torch.empty(2 * x.shape[1] + 1, dtype=torch.float64, device=x.device)
+                ops.act_stats_fwd(x, None, bn.eps, bn.momentum, sums_out=sums)
+                adist.all_reduce_sum(sums, bn.sync_group)
+                mean, stat2 = ops.bn_finalize_stats(sums, x.shape[1], bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+            else:
+                _, mean, stat2 = ops.act_stats_fwd(x, None, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+            _bump(bn.num_batches_tracked)
+            y0 = ops.bn_apply_fwd(x, mean, stat2, gamma, beta, fused_post, residual if fused_post is post else None)
         else:
-            _, mean, invstd = ops.act_stats_fwd(x, None, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
-        _bump(bn.num_batches_tracked)
-        y = ops.bn_apply_fwd(x, mean, invstd, gamma, beta, spec.post_act, residual)
-        return y, ('dropout', pre, a, x, m, mean, invstd)
+            mean, stat2 = bn.running_mean.clone(), bn.running_var.clone()
+            y0 = ops.bn_eval_fwd(x, bn.running_mean, bn.running_var, bn.eps, gamma, beta, fused_post,
+                                 residual if fused_post is post else None)
+        if fused_post is post:
+            return y0, ('split', pre, a, x, m, mean, stat2, None)
+        y = ops.act_fwd(y0, post)                       # elementwise-only post-activation: y0 = the BatchNorm's output, kept
+        if residual is not None:
+            y = ops.add_inplace(y, residual)
+        return y, ('split', pre, a, x, m, mean, stat2, y0)
 
     @staticmethod
-    def _backward_dropout(saved, grad_y, gamma, beta, spec: FCSpec):
-        _, pre, a, x, m, mean, invstd = saved
+    def _backward_split(saved, grad_y, gamma, beta, spec: FCSpec):
+        _, pre, a, x, m, mean, stat2, y0 = saved
         bn = spec.bn
+        post = spec.post_act
+        fused_post = post if post not in ELEMENTWISE_ONLY else None
         gg = gb = None
+        g = grad_y
         if bn is None:
-            g = ops.act_bwd(grad_y, x, spec.post_act) if spec.post_act is not None else grad_y
-        elif bn.sync_group is not None:
-            from . import dist as adist
-            feat = x.shape[1]
-            sums = torch.empty(2 * feat + 1, dtype=torch.float64, device=x.device)
-            gg = torch.empty(feat, dtype=torch.float32, device=x.device)
-            gb = torch.empty(feat, dtype=torch.float32, device=x.device)
-            ops.bn_bwd(grad_y, x, None, None, spec.post_act, mean, invstd, gamma, beta, sums_out=sums, grad_gamma=gg, grad_beta=gb,
-                       out=grad_y)
-            sums[2 * feat:].fill_(x.shape[0])
-            adist.all_reduce_sum(sums, bn.sync_group)
-            g, _, _ = ops.bn_bwd(grad_y, x, None, None, spec.post_act, mean, invstd, gamma, beta, sums_in=sums, grad_gamma=gg,
-                                 grad_beta=gb)
+            if post is not None:
+                g = ops.act_bwd(g, x, post)
         else:
-            g, gg, gb = ops.bn_bwd(grad_y, x, None, None, spec.post_act, mean, invstd, gamma, beta)     # d / d(dropped value)
-        g = ops.mul(g, m)                                                                        # d / d(activation)
+            if fused_post is not post:
+                g = ops.act_bwd(g, y0, post)            # d / d(BatchNorm output)
+            if not bn.training:
+                g, gg, gb = ops.bn_eval_bwd(g, x, None, None, fused_post, mean, stat2, bn.eps, gamma, beta)
+            elif bn.sync_group is not None:
+                from . import dist as adist
+                feat = x.shape[1]
+                sums = torch.empty(2 * feat + 1, dtype=torch.float64, device=x.device)
+                gg = torch.empty(feat, dtype=torch.float32, device=x.device)
+                gb = torch.empty(feat, dtype=torch.float32, device=x.device)
+                g = g if g is not grad_y else grad_y
+                ops.bn_bwd(g, x, None, None, fused_post, mean, stat2, gamma, beta, sums_out=sums, grad_gamma=gg, grad_beta=gb, out=g)
+                sums[2 * feat:].fill_(x.shape[0])
+                adist.all_reduce_sum(sums, bn.sync_group)
+                g, _, _ = ops.bn_bwd(g, x, None, None, fused_post, mean, stat2, gamma, beta, sums_in=sums, grad_gamma=gg, grad_beta=gb)
+            else:
+                g, gg, gb = ops.bn_bwd(g, x, None, None, fused_post, mean, stat2, gamma, beta)      # d / d(dropped value)
+        if m is not None:
+            g = ops.mul(g, m)                                                                   # d / d(activation)
         if spec.act is not None:
-            g = ops.act_bwd(g, pre, spec.act)                                                    # d / d(pre-activation)
+            g = ops.act_bwd(g, pre, spec.act)                                                   # d / d(pre-activation)
         return g, gg, gb
 
     @staticmethod
     def backward(saved, grad_y, gamma, beta, spec: FCSpec):
         bn = spec.bn
-        if len(saved) == 7 and isinstance(saved[0], str) and saved[0] == 'dropout':
-            return _Tail._backward_dropout(saved, grad_y, gamma, beta, spec)
+        if len(saved) == 8 and isinstance(saved[0], str) and saved[0] == 'split':
+            return _Tail._backward_split(saved, grad_y, gamma, beta, spec)
         if bn is None:
             inputs, acts = saved
             grad_pre = grad_y
@@ -221,6 +249,7 @@ COMPOSITE = os.environ.get('I3D_COMPOSITE', '1') != '0'
 
 def _composite_ok(spec: FCSpec, *tensors):
     return (COMPOSITE and spec.bn is not None and spec.bn.training and spec.bn.sync_group is None and spec.dropout == 0.0
+            and spec.act not in ELEMENTWISE_ONLY and spec.post_act not in ELEMENTWISE_ONLY
             and all(t is None or t.is_cuda for t in tensors))
 
 

@@ -397,7 +397,8 @@ int i3d_edge_combine_act_stats(const float* P, int ldp, const float* Q, const in
 /* C[M,N] = epi_act(A' W^T + bias (+ C)),  A' = (A - mean) * scale + shift per column k when a_aff ([3K]) is given (the
  * BatchNorm of the block in front applied while A is staged), W [N,K] row-major; stats ([ceil(M/64)][3][N]) receives the
  * partials of the stored values per 64-row tile.  Grouped form as i3d_gemm_f32_grouped (m_rows padded to 64 per group with
- * -1, M = padded count, a_rows_total = physical rows of A / C).  Needs 16-byte aligned operands, K % 4 == 0. */
+ * -1, M = padded count, a_rows_total = physical rows of A / C).  Needs 16-byte aligned operands, K % 4 == 0.  epi_act: none, ReLU
+ * or LeakyReLU (the activations of the blocks this product sits in; any other runs as a pass of its own behind a plain product). */
 int i3d_gemm_f32_fused(int M, int N, int K, const float* A, int lda, long a_rows_total, const float* W, int ldb, float* C,
                        int ldc, const float* bias, int accumulate, const float* a_aff, int epi_act, float* stats,
                        const int* m_rows, const int* tile_group, long b_group_stride, void* stream);

@@ -293,18 +293,15 @@ def test_padding_encoders_match_the_reference_module():
 
 # ---- BatchNorm -------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('rows,feat', [(5000, 200), (300, 20), (17, 7), (70000, 20)])
-@pytest.mark.parametrize('act,post', [('relu', None), (None, None), ('silu', 'silu'), ('leakyrelu', None), ('tanh', 'elu'),
-                                      ('selu', 'softplus'), ('softplus', 'tanh'), ('elu', 'selu')])
+@pytest.mark.parametrize('act,post', [('relu', None), (None, None), ('silu', 'silu'), ('leakyrelu', None), ('sigmoid', 'leakyrelu')])
 def test_act_bn_fwd_bwd_vs_torch(rows, feat, act, post):
-    """activation -> BatchNorm1d (train) -> activation (+ residual) of FCLayer, reference models/base_layers.py:100-111, for every
-    elementwise entry of its SUPPORTED_ACTIVATION_MAP (:5) against the torch functions of the same names (default parameters)."""
-    # large mean: exercises the shifted statistics (the saturating activations get a small one: tanh(3 +- 1) is a constant)
-    pre = rnd(rows, feat, seed=50) + (3.0 if act in (None, 'relu', 'silu', 'leakyrelu') else 0.3)
+    """activation -> BatchNorm1d (train) -> activation (+ residual) of FCLayer, reference models/base_layers.py:100-111, through the
+    fused kernels (the activations they carry: csrc/common.h) against the torch functions of the same names."""
+    pre = rnd(rows, feat, seed=50) + 3.0            # large mean: exercises the shifted statistics
     gamma, beta = rnd(feat, seed=51) * 0.2 + 1, rnd(feat, seed=52) * 0.2
     res = rnd(rows, feat, seed=53)
     rm, rv = torch.zeros(feat), torch.ones(feat)
-    acts = {'relu': F.relu, 'silu': F.silu, None: lambda t: t, 'leakyrelu': F.leaky_relu, 'tanh': torch.tanh, 'elu': F.elu,
-            'selu': F.selu, 'softplus': F.softplus}
+    acts = {'relu': F.relu, 'silu': F.silu, None: lambda t: t, 'leakyrelu': F.leaky_relu, 'sigmoid': torch.sigmoid}
     pr = pre.clone().requires_grad_(True)
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     x = acts[act](pr)
@@ -729,3 +726,41 @@ def test_glu_is_refused_by_name():
     layers = importlib.import_module('3dinfomax_amd.layers')
     with pytest.raises(NotImplementedError):
         layers.FCLayer(8, 8, activation='GLU')
+
+
+@pytest.mark.parametrize('training', [True, False])
+@pytest.mark.parametrize('bn', [True, False])
+@pytest.mark.parametrize('act,post', [('tanh', 'elu'), ('selu', 'softplus'), ('softplus', 'tanh'), ('elu', None), (None, 'selu'),
+                                      ('relu', 'tanh'), ('tanh', 'silu')])
+def test_tail_with_elementwise_only_activations_vs_torch(act, post, bn, training):
+    """The activations the fused kernels do not carry (Tanh, ELU, SELU, Softplus: layers.ELEMENTWISE_ONLY) in front of and behind
+    the BatchNorm: layers._Tail runs them as passes of their own around the fused BatchNorm kernels - forward, backward, running
+    statistics and the residual against the torch functions; the fused entry points refuse their codes."""
+    layers = importlib.import_module('3dinfomax_amd.layers')
+    rows, feat = 700, 36
+    acts = {'relu': F.relu, 'silu': F.silu, None: lambda t: t, 'tanh': torch.tanh, 'elu': F.elu, 'selu': F.selu, 'softplus': F.softplus}
+    pre = rnd(rows, feat, seed=60) + 0.3
+    gamma, beta, res, cot = rnd(feat, seed=61) * 0.2 + 1, rnd(feat, seed=62) * 0.2, rnd(rows, feat, seed=63), rnd(rows, feat, seed=64)
+    rm, rv = rnd(feat, seed=65) * 0.1, rnd(feat, seed=66).abs() * 0.5 + 0.5
+    pr, gr, br = pre.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    h = acts[act](pr)
+    if bn:
+        h = F.batch_norm(h, rm_ref, rv_ref, gr, br, training, 0.2, 1e-5)
+    y = acts[post](h) + res
+    (y * cot).sum().backward()
+    spec_bn = layers.BNSpec(g(rm), g(rv), None, 0.2, 1e-5, training) if bn else None
+    spec = layers.FCSpec(act, spec_bn, post)
+    pre_g = g(pre)
+    yg, saved = layers._Tail.forward(pre_g, g(gamma) if bn else None, g(beta) if bn else None, spec, g(res))
+    assert rel_err(yg.cpu(), y.detach()) < 2e-5
+    assert torch.equal(pre_g.cpu(), pre)                      # the pre-activation is kept (its derivative needs it)
+    gp, gg, gb = layers._Tail.backward(saved, g(cot), g(gamma) if bn else None, g(beta) if bn else None, spec)
+    assert rel_err(gp.cpu(), pr.grad) < 5e-5
+    if bn:
+        assert rel_err(gg.cpu(), gr.grad) < 5e-5 and rel_err(gb.cpu(), br.grad) < 5e-5
+        assert rel_err(spec_bn.running_mean.cpu(), rm_ref) < 1e-5 and rel_err(spec_bn.running_var.cpu(), rv_ref) < 1e-5
+    ops_ = importlib.import_module('3dinfomax_amd.ops')
+    lib = importlib.import_module('3dinfomax_amd._lib')
+    with pytest.raises(lib.HipLibraryError):
+        ops_.act_stats_fwd(pre_g.clone(), 'tanh', 1e-5, 0.1, torch.zeros(feat, device=DEV), torch.ones(feat, device=DEV))
