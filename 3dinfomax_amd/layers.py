@@ -197,7 +197,6 @@ class _Tail:
                 sums = torch.empty(2 * feat + 1, dtype=torch.float64, device=x.device)
                 gg = torch.empty(feat, dtype=torch.float32, device=x.device)
                 gb = torch.empty(feat, dtype=torch.float32, device=x.device)
-                g = g if g is not grad_y else grad_y
                 ops.bn_bwd(g, x, None, None, fused_post, mean, stat2, gamma, beta, sums_out=sums, grad_gamma=gg, grad_beta=gb, out=g)
                 sums[2 * feat:].fill_(x.shape[0])
                 adist.all_reduce_sum(sums, bn.sync_group)
