@@ -123,4 +123,7 @@ __device__ __forceinline__ float act_grad_any(float x, int act) {
 // the fused kernels' activation codes (see above)
 inline bool fused_act(int act) { return act >= I3D_ACT_NONE && act <= I3D_ACT_LEAKY_RELU; }
 
+// aggregate.hip: the next K4 forward launch of this thread carries these timing events (bench.py's in-step roofline figure)
+void k4_time_next_launch(void* start, void* stop);
+
 }  // namespace i3d

@@ -471,10 +471,9 @@ static int pna_layer_fwd_fused(const I3dPnaLayerArgs* a, void* stream) {
         aff = a->aff[i + 1];
         f_in = c->f_out;
     }
-    if (a->agg_event_start != nullptr) (void)hipEventRecord((hipEvent_t)a->agg_event_start, (hipStream_t)stream);
+    if (a->agg_event_start != nullptr && a->agg_event_stop != nullptr) k4_time_next_launch(a->agg_event_start, a->agg_event_stop);
     TRY(i3d_pna_aggregate_fwd_ex(x, a->msg_bf16 && a->n_pre_extra > 0, aff, e->in_ptr, N, f_in, a->aggregators, a->n_aggregators, a->scalers,
                                  a->n_scalers, a->force_scalers, a->avg_d_log, const_cast<float*>(a->post.agg), stream));
-    if (a->agg_event_stop != nullptr) (void)hipEventRecord((hipEvent_t)a->agg_event_stop, (hipStream_t)stream);
     // posttrans: lin = h W_h^T + b, += agg W_D^T per in-degree group with the statistics in that launch's epilogue (the
     // degree groups cover every node - in-degree 0 included, with zero coefficients), then apply + residual
     const I3dGroupedFcArgs* p = &a->post;
@@ -537,10 +536,9 @@ extern "C" int i3d_pna_layer_fwd(const I3dPnaLayerArgs* a, void* stream) {
     if (a->fused_bn) return pna_layer_fwd_fused(a, stream);
     TRY(i3d_edge_fc_bn_fwd(&a->edge, stream));
     for (int i = 0; i < a->n_pre_extra; ++i) TRY(i3d_fc_bn_fwd(&a->pre[i], stream));
-    if (a->agg_event_start != nullptr) (void)hipEventRecord((hipEvent_t)a->agg_event_start, (hipStream_t)stream);
+    if (a->agg_event_start != nullptr && a->agg_event_stop != nullptr) k4_time_next_launch(a->agg_event_start, a->agg_event_stop);
     TRY(i3d_pna_aggregate_fwd(a->msg, a->edge.in_ptr, a->edge.num_nodes, a->edge.f_out, a->aggregators, a->n_aggregators,
                               a->scalers, a->n_scalers, a->force_scalers, a->avg_d_log, const_cast<float*>(a->post.agg), stream));
-    if (a->agg_event_stop != nullptr) (void)hipEventRecord((hipEvent_t)a->agg_event_stop, (hipStream_t)stream);
     TRY(i3d_grouped_fc_bn_fwd(&a->post, stream));
     for (int i = 0; i < a->n_post_extra; ++i) TRY(i3d_fc_bn_fwd(&a->postx[i], stream));
     return I3D_OK;

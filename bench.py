@@ -608,12 +608,12 @@ def main():
                     avg_us_back_to_back=round(b2b_us, 2),
                     reference_shaped_12F=dict(achieved_back_to_back=round(b2b12, 1), frac_back_to_back=round(b2b12 / HBM_PEAK_GBS, 4),
                                               avg_us_back_to_back=round(b2b12_us, 2)),
-                    note='achieved/frac: one HIP-event pair (timing-only events: hipEventDisableSystemFence) around every K4 launch of the '
-                         'timed steps, recorded by the layer '
-                         'composite right before/after the launch; Net3D kernels run concurrently on a side stream. The '
-                         'same event pair around a one-workgroup kernel on a busy device measures '
-                         'event_pair_null_kernel_us (dispatch + completion signalling: the part of avg_us that is not the '
-                         'kernel; rocprofv3 kernel time in profiles/); *_back_to_back: '
+                    note='achieved/frac: every K4 forward launch of the timed steps carries a start and a stop HIP event ON its own '
+                         'dispatch (hipExtLaunchKernelGGL from the layer composite: the begin / end timestamps of that dispatch, what '
+                         'rocprofv3\'s kernel trace reports - profiles/ - not two event records around it); Net3D kernels run '
+                         'concurrently on a side stream. event_pair_null_kernel_us: what a record / record pair around a one-workgroup '
+                         'kernel measures on a busy device (dispatch + completion signalling: 4.8 us that rounds 1-3 of this file '
+                         'counted into avg_us); *_back_to_back: '
                          '20 launches per event pair after the timed region; reference_shaped_12F: the [N,12F] kernel of '
                          'SURVEY.md 8(d) (I3D_GROUPED_POSTTRANS=0 path); traffic: rocprofv3 PMC bytes per launch of the step\'s own kernels (traffic_source; rows matched by kernel base name + leading template arguments and by this workload\'s launch grids, tools/pmc_lookup.py), traffic_backward_kernel: the same for pna_aggregate_bwd_kernel<4,2,...>')
 
