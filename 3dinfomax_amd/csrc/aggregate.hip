@@ -531,11 +531,10 @@ void k4_time_next_launch(void* start, void* stop) { g_time_start = (hipEvent_t)s
 }
 #define K4_FWD_LAUNCH(KERNEL, GRID, ...)                                                                              \
     do {                                                                                                              \
-        if (g_time_start != nullptr && g_time_stop != nullptr)                                                        \
-            hipExtLaunchKernelGGL(KERNEL, GRID, dim3(256), 0, s, g_time_start, g_time_stop, 0, __VA_ARGS__);          \
+        if (t_start != nullptr && t_stop != nullptr)                                                                  \
+            hipExtLaunchKernelGGL(KERNEL, GRID, dim3(256), 0, s, t_start, t_stop, 0, __VA_ARGS__);                    \
         else                                                                                                          \
             hipLaunchKernelGGL(KERNEL, GRID, dim3(256), 0, s, __VA_ARGS__);                                           \
-        g_time_start = g_time_stop = nullptr;                                                                         \
     } while (0)
 
 extern "C" int i3d_pna_aggregate_fwd_aff(const float* e, const float* aff, const int* in_ptr, int num_nodes, int feat,
@@ -549,6 +548,8 @@ extern "C" int i3d_pna_aggregate_fwd_ex(const void* e_, int e_bf16, const float*
                                         const int* aggregators, int n_aggregators, const int* scalers,
                                         int n_scalers, int force_scalers, float avg_d_log, float* out, void* stream) {
     const float* e = (const float*)e_;
+    const hipEvent_t t_start = g_time_start, t_stop = g_time_stop;      // (consumed by THIS call whatever it returns)
+    g_time_start = g_time_stop = nullptr;
     I3D_CHECK_ARG(!e_bf16 || (feat % 4 == 0 && (((uintptr_t)e_) & 7) == 0), "bf16 messages need feat % 4 == 0 and 8-byte alignment");
     I3D_CHECK_ARG(aff == nullptr || (feat % 4 == 0 && (((uintptr_t)aff) & 15) == 0), "aff needs feat % 4 == 0 and 16-byte alignment");
     I3D_CHECK_ARG(num_nodes >= 0 && feat > 0, "num_nodes >= 0 and feat > 0 required");
