@@ -60,7 +60,8 @@ class PnaLayerArgs(ctypes.Structure):
                 ('avg_d_log', c_float), ('msg', _P), ('grad_msg', _P), ('post', GroupedFcArgs), ('n_post_extra', c_int),
                 ('postx', FcArgs * 3), ('residual', c_int), ('grad_out', _P), ('agg_event_start', _P), ('agg_event_stop', _P),
                 ('fused_bn', c_int), ('defer_join', c_int), ('stats_ws', _P), ('aff', _P * 4), ('weights_ready', c_int),
-                ('merge_h', c_int), ('Wcat', _P), ('bcat', _P), ('PL', _P), ('DL', _P), ('wgrad_split', c_int), ('eval_mode', c_int), ('msg_bf16', c_int)]
+                ('merge_h', c_int), ('Wcat', _P), ('bcat', _P), ('PL', _P), ('DL', _P), ('wgrad_split', c_int), ('eval_mode', c_int), ('msg_bf16', c_int),
+                ('edge_bias_partial', _P)]
 
 
 class Net3dEdgeArgs(ctypes.Structure):
@@ -223,6 +224,8 @@ _SIGNATURES = {
     'i3d_bn_bwd_deferred_bias': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_long,
                                          _P, _P, _P]),
     'i3d_bn_bias_finalize': (c_int, [_P, c_int, c_int, _P, _P]),
+    'i3d_bn_bwd_edge_sums': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, _P, _P]),
+    'i3d_colsum_strided': (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     'i3d_wgrad_stream_join': (c_int, [_P]),
     'i3d_adam_chunk_elems': (c_int, []),
     'i3d_adam_chunk_bytes': (c_int, []),

@@ -272,6 +272,7 @@ struct ReduceArgs {
     int rows, feat, act, post_act;
     float* partial;        // [nblk][2][feat]
     int b_bf16;            // MODE_BN_BWD: b (the BatchNorm input x) is stored as bf16 (V = 4)
+    int lda;               // MODE_COLSUM: row pitch of a in floats (0: feat) - a column block of a wider matrix
 };
 
 // 4 consecutive values of a row operand that is stored as fp32 or (x_bf16: the bf16 mode's message storage) as bf16
@@ -320,11 +321,12 @@ __global__ void __launch_bounds__(256) colreduce_partial_kernel(ReduceArgs g, Ch
             for (int u = 0; u < RU; ++u) {
                 const int r = min(r0 + u * ch.rl, r_end - 1);
                 const long off = (long)r * F + c0;
+                const long off_a = (MODE == MODE_COLSUM && g.lda > 0) ? (long)r * g.lda + c0 : off;
                 if (V == 4) {
-                    float4 xx = *reinterpret_cast<const float4*>(g.a + off);
+                    float4 xx = *reinterpret_cast<const float4*>(g.a + off_a);
                     xs[u][0] = xx.x; xs[u][1 % V] = xx.y; xs[u][2 % V] = xx.z; xs[u][3 % V] = xx.w;
                 } else {
-                    xs[u][0] = g.a[off];
+                    xs[u][0] = g.a[off_a];
                 }
                 if (MODE == MODE_BN_BWD) {
                     if (V == 4) {
@@ -755,6 +757,93 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_colsum_kernel(BwdApplyArgs g
     if (fin.counters != nullptr) arrive_and_finalize<GA>(fin, partial, gridDim.x);
 }
 
+// BatchNorm backward of the edge block fused with what follows it on the chain (round 4): the data gradient
+//     g_e = gamma invstd (dy_e - mean(dy) - xhat_e mean(dy xhat)) act'(x_e)
+// of every edge row (bn_bwd_apply_kernel's expression) is formed ON THE FLY by the two segmented sums that consume it -
+//     dP[src][v] = sum over the out-edges of v,  dP[dst][v] = sum over the in-edges of v          (edge.hip: segment_sum_kernel<4, true>)
+// - one lane per (node, 4 features, direction), rows in the order the segmented-sum kernel adds them: the same bits as the two
+// launches it replaces (apply + column sums of the result: 21-24 us, pair of segmented sums: 8.5 us at batch 512).  The lanes of
+// the in-edge direction also store g (the weight gradients of the block read it); the bias gradient - the column sum of g - is the
+// column sum of dP[dst] and is taken on the weight-gradient stream (i3d_colsum_strided), off the chain.
+struct EdgeSums {
+    const int* in_ptr;      // [N + 1] rows of the in-edges of node v: [in_ptr[v], in_ptr[v + 1]) (destination-sorted edge order)
+    const int* out_ptr;     // [N + 1] / out_epos: row of every out-edge, grouped by source node
+    const int* out_epos;
+    int num_nodes;
+    float* out_src;         // dP[src] [N, feat], row pitch ldo
+    float* out_dst;         // dP[dst]
+    int ldo;
+};
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_edge_sums_kernel(BwdApplyArgs g, EdgeSums e) {
+    I3D_CHAIN_PRIO();
+    constexpr int MAX_F = 512;
+    __shared__ __attribute__((aligned(16))) float col[5 * MAX_F];      // mean | invstd | gamma invstd | k1 | k2
+    const int F = g.feat, FV = F / 4;
+    {
+        const float inv_n = g.inv_n_ptr ? g.inv_n_ptr[0] : g.inv_n;
+        for (int c = threadIdx.x; c < F; c += blockDim.x) {
+            const float is = g.invstd[c];
+            col[c] = g.mean[c];
+            col[F + c] = is;
+            col[2 * F + c] = g.gamma[c] * is;
+            col[3 * F + c] = g.sum_dy[c] * inv_n;
+            col[4 * F + c] = g.sum_dy_xhat[c] * inv_n;
+        }
+    }
+    __syncthreads();
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long half = (long)e.num_nodes * FV;
+    if (t >= 2 * half) return;
+    const bool in_dir = t >= half;          // second half of the grid: in-edges (contiguous rows), stores g
+    if (in_dir) t -= half;
+    const int v = (int)(t / FV), c = (int)(t - (long)v * FV) * 4;
+    const int* ptr = in_dir ? e.in_ptr : e.out_ptr;
+    const int beg = ptr[v], end = ptr[v + 1];
+    const float4 mu = *reinterpret_cast<const float4*>(col + c), is = *reinterpret_cast<const float4*>(col + F + c),
+                 gi = *reinterpret_cast<const float4*>(col + 2 * F + c), k1 = *reinterpret_cast<const float4*>(col + 3 * F + c),
+                 k2 = *reinterpret_cast<const float4*>(col + 4 * F + c);
+    const int act = g.act;
+    auto grad_of = [&](const float4 dy, const float4 x) -> float4 {
+        float4 r;
+        {   const float xh = (x.x - mu.x) * is.x; r.x = gi.x * (dy.x - k1.x - xh * k2.x); }
+        {   const float xh = (x.y - mu.y) * is.y; r.y = gi.y * (dy.y - k1.y - xh * k2.y); }
+        {   const float xh = (x.z - mu.z) * is.z; r.z = gi.z * (dy.z - k1.z - xh * k2.z); }
+        {   const float xh = (x.w - mu.w) * is.w; r.w = gi.w * (dy.w - k1.w - xh * k2.w); }
+        if (act != I3D_ACT_NONE) {
+            r.x *= act_grad_c<false>(x.x, act); r.y *= act_grad_c<false>(x.y, act);
+            r.z *= act_grad_c<false>(x.z, act); r.w *= act_grad_c<false>(x.w, act);
+        }
+        return r;
+    };
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // four rows per trip, loaded unconditionally (clamped index), the additions in the order j = beg .. end - 1: segment_sum_kernel
+    for (int j = beg; j < end; j += 4) {
+        long rows[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int jj = min(j + k, end - 1);
+            rows[k] = in_dir ? jj : e.out_epos[jj];
+        }
+        float4 dy[4], xx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dy[k] = *reinterpret_cast<const float4*>(g.grad_y + rows[k] * F + c);
+            xx[k] = *reinterpret_cast<const float4*>(g.x + rows[k] * F + c);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (j + k < end) {
+                const float4 r = grad_of(dy[k], xx[k]);
+                if (in_dir) *reinterpret_cast<float4*>(g.grad_pre + rows[k] * g.ld_out + c) = r;
+                acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+            }
+        }
+    }
+    float* o = (in_dir ? e.out_dst : e.out_src) + (long)v * e.ldo + c;
+    *reinterpret_cast<float4*>(o) = acc;
+}
+
 __global__ void __launch_bounds__(256) act_fwd_kernel(const float* __restrict__ x, long n, int act, float* __restrict__ y) {
     I3D_CHAIN_PRIO();
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
@@ -1017,6 +1106,8 @@ extern "C" int i3d_bn_bias_finalize(const float* bias_partial, int rows, int fea
 // only the optimizer needs; the caller runs i3d_bn_bias_finalize later (the layer composite: on its side stream).
 // the BatchNorm input x of the next bn_bwd_impl calls of this thread is stored as bf16 (i3d_bn_bwd_x_bf16)
 static thread_local int g_x_bf16 = 0;
+// the data-gradient pass of the next bn_bwd_impl call of this thread is bn_bwd_apply_edge_sums_kernel (i3d_bn_bwd_edge_sums)
+static thread_local const EdgeSums* g_edge_sums = nullptr;
 // phase 2 of the synchronised backward finds its fp32 sum vectors + 1 / rows already in the workspace (peer exchange)
 static thread_local int g_sums_ready = 0;
 
@@ -1111,6 +1202,13 @@ static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, in
     b.sum_dy = sum_dy; b.sum_dy_xhat = sum_dy_xhat; b.grad_pre = grad_pre; b.ld_out = ld_out; b.feat = feat; b.act = act;
     b.post_act = post_act; b.eval_mode = 0; b.inv_n = 1.f / (float)total_rows; b.eps = 0.f;
     b.zero_out = nullptr; b.x_bf16 = g_x_bf16;
+    if (g_edge_sums != nullptr) {      // i3d_bn_bwd_edge_sums: the data gradient formed inside the segmented sums that consume it
+        const EdgeSums es = *g_edge_sums;
+        const long lanes = 2L * es.num_nodes * (feat / 4);
+        hipLaunchKernelGGL(bn_bwd_apply_edge_sums_kernel, dim3(cdiv(lanes, 256)), dim3(256), 0, s, b, es);
+        I3D_CHECK_LAUNCH();
+        return I3D_OK;
+    }
     if (grad_bias != nullptr && act == I3D_ACT_NONE && exact_zero_bias_grad()) {
         // No activation between the Linear and the BatchNorm: the bias gradient is the column sum of the BatchNorm input
         // gradient  s (dy - mean(dy) - xhat mean(dy xhat))  over the rows the statistics were taken over, which is
@@ -1162,6 +1260,41 @@ extern "C" int i3d_bn_bwd_deferred_bias(const float* grad_y, const float* x, con
                                         void* workspace, float* bias_partial, void* stream) {
     return bn_bwd_impl(grad_y, x, pre, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta, grad_pre,
                        grad_bias, sums_out, sums_in, total_rows, workspace, bias_partial, feat, stream);
+}
+
+extern "C" int i3d_bn_bwd_edge_sums(const float* grad_y, const float* x, int rows, int feat, int act, const float* mean,
+                                    const float* invstd, const float* gamma, const float* beta, float* grad_gamma, float* grad_beta,
+                                    float* grad_pre, const int* in_ptr, const int* out_ptr, const int* out_epos, int num_nodes,
+                                    float* out_src, float* out_dst, int ldo, void* workspace, void* stream) {
+    I3D_CHECK_ARG(feat % 4 == 0 && feat <= 512 && ldo % 4 == 0 && ldo >= feat, "feat % 4 == 0, feat <= 512, 16-byte rows");
+    I3D_CHECK_ARG(relu_class(act), "activation: none, ReLU or LeakyReLU (act' from the stored activation)");
+    I3D_CHECK_ARG(in_ptr != nullptr && out_ptr != nullptr && out_epos != nullptr && num_nodes > 0 && out_src != nullptr && out_dst != nullptr &&
+                      grad_pre != nullptr, "null argument");
+    I3D_CHECK_ARG(((((uintptr_t)grad_y) | ((uintptr_t)x) | ((uintptr_t)grad_pre) | ((uintptr_t)out_src) | ((uintptr_t)out_dst)) & 15) == 0,
+                  "16-byte aligned tensors");
+    const EdgeSums es{in_ptr, out_ptr, out_epos, num_nodes, out_src, out_dst, ldo};
+    g_edge_sums = &es;
+    const int rc = bn_bwd_impl(grad_y, x, nullptr, rows, feat, act, I3D_ACT_NONE, mean, invstd, gamma, beta, grad_gamma, grad_beta, grad_pre,
+                               nullptr, nullptr, nullptr, rows, workspace, nullptr, feat, stream);
+    g_edge_sums = nullptr;
+    return rc;
+}
+
+// out[c] = sum over the rows of x[r * ldx + c]: the two-stage deterministic column reduction of this file on a column block of a
+// wider matrix, partials through the caller's buffer (i3d_bn_bias_partial_floats(feat) floats - a stream of its own next to the
+// BatchNorm passes must not share their workspace), finalised by a second launch
+extern "C" int i3d_colsum_strided(const float* x, int ldx, int rows, int feat, float* out, float* partial, void* stream) {
+    I3D_CHECK_ARG(x != nullptr && out != nullptr && partial != nullptr && rows > 0 && feat > 0 && ldx >= feat, "bad arguments");
+    I3D_CHECK_ARG(feat % 4 != 0 || (ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0), "16-byte rows for feat % 4 == 0");
+    hipStream_t s = (hipStream_t)stream;
+    const Chunking ch = make_chunking(rows, feat);
+    ReduceArgs g = {};
+    g.a = x; g.lda = ldx; g.rows = rows; g.feat = feat; g.partial = partial;
+    Final f = {};        // counters == nullptr: no in-launch finalisation, launch_reduction adds the pair finalisation launch
+    f.kind = 1; f.feat = feat; f.out1 = out;
+    launch_reduction<MODE_COLSUM>(g, ch, f, s);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
 }
 
 // i3d_bn_bwd_deferred_bias with the BatchNorm input x stored as bf16 (row r at (bf16*)x + r * feat; feat % 4 == 0; activations

@@ -306,6 +306,17 @@ static bool merge_h_ok(const I3dPnaLayerArgs* a) {
            a->post.f_h == a->edge.f_h && a->post.pre_keep == nullptr;
 }
 
+// the edge block's BatchNorm backward fused with the segmented sums behind it (bn.hip: i3d_bn_bwd_edge_sums): merged h-products
+// (dP lands in the first two column blocks of DL), an activation whose derivative follows from the stored activation, 16-byte rows.
+// I3D_EDGE_BWD_FUSED=0: BatchNorm backward + i3d_segment_sum_pair (the same bits).
+static bool edge_bwd_fused_ok(const I3dPnaLayerArgs* a) {
+    static const bool on = [] { const char* v = getenv("I3D_EDGE_BWD_FUSED"); return v == nullptr || v[0] != '0'; }();
+    const I3dEdgeFcArgs* e = &a->edge;
+    return on && merge_h_ok(a) && a->DL != nullptr && e->pre_keep == nullptr && relu_class(e->tail.act) && e->tail.post_act == I3D_ACT_NONE &&
+           e->f_out % 4 == 0 && e->f_out <= 512 && a->post.f_out % 4 == 0 && e->out_ptr != nullptr && e->out_epos != nullptr &&
+           a->edge_bias_partial != nullptr && e->grad_bias != nullptr;
+}
+
 // ---- all weight gradients of a PNA layer behind ONE fork, from ONE launch + one reduction (wgrad.hip) ---------------
 // posttrans h-block | per-degree posttrans blocks folded into the scaler blocks | later pretrans blocks (BatchNorm fix-up in
 // the fused form) | [W_s | W_d] of the edge block | dQ of the bond table; then the two [V, .] products behind dQ.  Returns
@@ -400,7 +411,12 @@ static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_r
     if (do_post) TRY(bias_final(&g->tail, N, g->f_out, g->grad_bias, wst));
     for (int i = a->n_pre_extra - 1; i >= 0 && do_pre; --i)
         TRY(bias_final(&a->pre[i].tail, a->pre[i].rows, a->pre[i].f_out, a->pre[i].grad_bias, wst));
-    if (do_pre) TRY(bias_final(&e->tail, E, Fo, e->grad_bias, wst));
+    if (do_pre) {
+        if (edge_bwd_fused_ok(a))      // the bias gradient = column sum of dP[dst] (the layer's backward took i3d_bn_bwd_edge_sums)
+            TRY(i3d_colsum_strided(a->DL + Fo, 2 * Fo + a->post.f_out, N, Fo, e->grad_bias, a->edge_bias_partial, wst));
+        else
+            TRY(bias_final(&e->tail, E, Fo, e->grad_bias, wst));
+    }
     TRY(i3d_wgrad_multi(pr, np, out, no, ws, wsb, wst));
     if (!do_pre) return 1;
     const int V = e->q_rows;
@@ -613,9 +629,19 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     TRY(i3d_pna_aggregate_bwd_ex(a->post.grad_agg, a->msg, msg16, msg_aff, a->edge.in_ptr, a->edge.num_nodes, f_msg, a->aggregators,
                                  a->n_aggregators, a->scalers, a->n_scalers, a->force_scalers, a->avg_d_log, a->grad_msg, stream));
     for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_chain(&a->pre[i], stream, msg16 && i == a->n_pre_extra - 1));
-    TRY(edge_fc_bn_bwd_tail(&a->edge, stream));
+    const bool edge_fused = multi && merged && edge_bwd_fused_ok(a);
+    if (edge_fused) {       // BatchNorm backward of the edge block with the data gradient formed inside the two segmented sums
+        const I3dEdgeFcArgs* e = &a->edge;
+        const int WLb = 2 * e->f_out + a->post.f_out;
+        TRY(i3d_bn_bwd_edge_sums(e->grad_y, e->xact, e->num_edges, e->f_out, e->tail.act, e->tail.mean, e->tail.invstd, e->tail.gamma,
+                                 e->tail.beta, e->grad_gamma, e->grad_beta, e->grad_pre, e->in_ptr, e->out_ptr, e->out_epos, e->num_nodes,
+                                 a->DL, a->DL + e->f_out, WLb, e->tail.workspace, stream));
+    } else {
+        TRY(edge_fc_bn_bwd_tail(&a->edge, stream));
+    }
     if (multi) {
-        if (merged) {       // dP[src] | dP[dst] straight into the first 2 Fo columns of DL
+        if (edge_fused) {
+        } else if (merged) {       // dP[src] | dP[dst] straight into the first 2 Fo columns of DL
             const I3dEdgeFcArgs* e = &a->edge;
             const int WLb = 2 * e->f_out + a->post.f_out;
             TRY(i3d_segment_sum_pair(e->grad_pre, e->f_out, e->out_ptr, e->out_epos, a->DL, e->in_ptr, nullptr, a->DL + e->f_out,

@@ -624,6 +624,8 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
         e.grad_h = ar.take((long)N * F);
         e.grad_Q = sd.take((long)b.v_pad * e.f_out);
         e.tail.bias_partial = defer_bias() ? sd.take(i3d_bn_bias_partial_floats(e.f_out)) : nullptr;
+        // (the buffer side_floats() counts for the edge block's bias partials: taken by exactly one of the two)
+        a.edge_bias_partial = (a.merge_h && !defer_bias()) ? sd.take(i3d_bn_bias_partial_floats(e.f_out)) : nullptr;
         e.grad_q = grad_table;
         e.grad_q_accumulate = (l == L - 1) ? 0 : 1;        // the bond table feeds every layer: its gradient is their sum
         TRY(i3d_pna_layer_bwd(&a, stream));

@@ -270,7 +270,7 @@ def backward(ctx, grad):
         total += _al(E * Fo) + _al(E * Fi)
     total += _al(E * Fo0) + _al(N * 2 * Fo0) + _al(N * Fh) + (_al(qmap.v_pad * Fo0) if (qmap is not None and q is not None) else 0)
     if a.merge_h:
-        total += _al(N * (2 * Fo0 + Fp0))
+        total += _al(N * (2 * Fo0 + Fp0)) + _al(_lib.load().i3d_bn_bias_partial_floats(Fo0))
     ar = _Arena(total, dev)
     grads = []          # (gW, gbias, ggamma, gbeta) per block, forward order
 
@@ -323,6 +323,9 @@ def backward(ctx, grad):
     e.grad_y, e.grad_pre, e.grad_P, e.grad_h = gy, ar.take(E * Fo0), ar.take(N * 2 * Fo0), ar.take(N * Fh)
     if a.merge_h:
         a.DL = ar.take(N * (2 * Fo0 + Fp0))
+        # the edge block's BatchNorm backward fused with its segmented sums (csrc/bn.hip: i3d_bn_bwd_edge_sums): partials of the
+        # bias gradient's column sum on the weight-gradient stream
+        a.edge_bias_partial = ar.take(_lib.load().i3d_bn_bias_partial_floats(Fo0))
     e.grad_q = gq.data_ptr() if gq is not None else None
     if qmap is not None and q is not None:
         e.grad_Q = ar.take(qmap.v_pad * Fo0)

@@ -556,6 +556,20 @@ int i3d_bn_bwd_deferred_bias(const float* grad_y, const float* x, const float* p
                              float* grad_gamma, float* grad_beta, float* grad_pre, float* grad_bias, double* sums_out,
                              const double* sums_in, long total_rows, void* workspace, float* bias_partial, void* stream);
 int i3d_bn_bias_finalize(const float* bias_partial, int rows, int feat, float* grad_bias, void* stream);
+/* The BatchNorm backward of a PNA layer's edge block (the FCLayer inside pretrans_edges, reference models/pna.py:237-252 with
+ * models/base_layers.py:100-111) fused with the two segmented sums behind it: column sums of dy and dy xhat as i3d_bn_bwd (one
+ * launch; grad_gamma / grad_beta), then ONE launch that forms the data gradient g of every edge row inside the sums that consume
+ * it - out_src[v] = sum of g over the out-edges of v (rows out_epos[out_ptr[v] .. out_ptr[v+1])), out_dst[v] = sum over its
+ * in-edges (rows in_ptr[v] .. in_ptr[v+1]) - and stores g to grad_pre [rows, feat].  The same bits as i3d_bn_bwd followed by
+ * i3d_segment_sum_pair.  act: none / ReLU / LeakyReLU; feat % 4 == 0, feat <= 512; synchronised statistics as i3d_bn_bwd.
+ * The bias gradient of the Linear in front is the column sum of out_dst: i3d_colsum_strided (any stream). */
+int i3d_bn_bwd_edge_sums(const float* grad_y, const float* x, int rows, int feat, int act, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, float* grad_gamma, float* grad_beta, float* grad_pre,
+                         const int* in_ptr, const int* out_ptr, const int* out_epos, int num_nodes, float* out_src, float* out_dst,
+                         int ldo, void* workspace, void* stream);
+/* out[c] = sum over rows of x[r * ldx + c] (two launches, fixed order: deterministic); partial: i3d_bn_bias_partial_floats(feat) floats
+ * of the caller's (the reduction's row-chunk partials - not the BatchNorm workspace, which another stream may be using) */
+int i3d_colsum_strided(const float* x, int ldx, int rows, int feat, float* out, float* partial, void* stream);
 
 /* ---- composites: one call enqueues a whole FCLayer-shaped block (forward or backward) ------------------------
  * "input operator -> Linear -> activation -> BatchNorm1d (training, local statistics) -> post-activation (+ residual)",
@@ -715,6 +729,10 @@ typedef struct { /* one PNA layer, reference models/pna.py:199-216: pretrans edg
     int msg_bf16;      /* fused_bn with at least one later pretrans block, bf16 matmul mode: `msg` (= the last pretrans block's xact,
                         * [E, f_msg]) holds bf16 - written by that block's GEMM epilogue, read by the aggregation kernels and by the
                         * block's BatchNorm backward; the buffer keeps its fp32 size.  Same value forward and backward. */
+    float* edge_bias_partial; /* backward, optional (i3d_bn_bias_partial_floats(edge.f_out) floats): with it (and merge_h, an
+                        * activation of the none / ReLU / LeakyReLU class, 16-byte rows) the edge block's BatchNorm backward runs
+                        * as i3d_bn_bwd_edge_sums - the data gradient formed inside the two segmented sums behind it - and its
+                        * bias gradient is taken from dP[dst] on the weight-gradient stream through this buffer */
 } I3dPnaLayerArgs;
 
 /* eval-mode affine vector of one BatchNorm: aff [3 feat] = running_mean | gamma / sqrt(running_var + eps) | beta */

@@ -764,3 +764,54 @@ def test_tail_with_elementwise_only_activations_vs_torch(act, post, bn, training
     lib = importlib.import_module('3dinfomax_amd._lib')
     with pytest.raises(lib.HipLibraryError):
         ops_.act_stats_fwd(pre_g.clone(), 'tanh', 1e-5, 0.1, torch.zeros(feat, device=DEV), torch.ones(feat, device=DEV))
+
+
+@pytest.mark.parametrize('feat,act', [(200, 'relu'), (20, 'relu'), (64, None), (36, 'leakyrelu')])
+def test_edge_block_bn_backward_fused_with_its_segmented_sums(feat, act):
+    """i3d_bn_bwd_edge_sums (the BatchNorm backward of a PNA layer's edge block with the data gradient formed inside the two segmented
+    sums that consume it) against the launches it replaces - i3d_bn_bwd, then the sums over the in-edges (contiguous rows) and over
+    the out-edges (through the index list) - bit for bit: grad_pre, dP[src], dP[dst] (written into column blocks of a wider matrix),
+    grad_gamma / grad_beta; and the bias gradient as the column sum of dP[dst] (i3d_colsum_strided) against the fp64 sum."""
+    import ctypes
+    L = importlib.import_module('3dinfomax_amd._lib')
+    lib = L.load()
+    n = 900
+    dst, ptr = _random_csr(n, 5, seed=170, zero_frac=0.05)
+    E = dst.shape[0]
+    gen = torch.Generator().manual_seed(17)
+    src = torch.randint(0, n, (E,), generator=gen)
+    order = torch.sort(src, stable=True)[1].int()
+    optr = torch.zeros(n + 1, dtype=torch.int32)
+    optr[1:] = torch.cumsum(torch.bincount(src, minlength=n), 0)
+    pre = rnd(E, feat, seed=171) + 0.5
+    acts = {'relu': F.relu, None: lambda t: t, 'leakyrelu': F.leaky_relu}
+    x = acts[act](pre).contiguous()
+    dy = rnd(E, feat, seed=172)
+    gamma, beta = rnd(feat, seed=173) * 0.2 + 1, rnd(feat, seed=174) * 0.2
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-5)
+    xg, dyg, mg, ig, gg_, bg = g(x), g(dy), g(mean), g(invstd), g(gamma), g(beta)
+    # the launches it replaces
+    gp_ref, ggam_ref, gbet_ref = ops.bn_bwd(dyg, xg, None, act, None, mg, ig, gg_, bg)
+    W = 2 * feat + 8
+    DL_ref = torch.zeros(n, W, device=DEV)
+    ops.segment_sum(gp_ref, g(optr), g(order), n, out=DL_ref[:, :feat])
+    ops.segment_sum(gp_ref, g(ptr), None, n, out=DL_ref[:, feat:2 * feat])
+    # the fused entry
+    gp = torch.empty_like(xg)
+    ggam, gbet = torch.empty(feat, device=DEV), torch.empty(feat, device=DEV)
+    DL = torch.zeros(n, W, device=DEV)
+    ws = ops._workspace(feat, xg.device)
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
+    ptr_g, optr_g, order_g = g(ptr), g(optr), g(order)          # (kept alive: only their addresses go through the C ABI)
+    ops.check(lib.i3d_bn_bwd_edge_sums(p(dyg), p(xg), E, feat, L.ACT[act], p(mg), p(ig), p(gg_), p(bg), p(ggam), p(gbet), p(gp), p(ptr_g),
+                                       p(optr_g), p(order_g), n, p(DL), ctypes.c_void_p(DL.data_ptr() + 4 * feat), W, p(ws), st),
+              'i3d_bn_bwd_edge_sums')
+    assert torch.equal(gp, gp_ref) and torch.equal(ggam, ggam_ref) and torch.equal(gbet, gbet_ref)
+    assert torch.equal(DL, DL_ref)
+    bias = torch.empty(feat, device=DEV)
+    part = torch.empty(lib.i3d_bn_bias_partial_floats(feat), device=DEV)
+    ops.check(lib.i3d_colsum_strided(ctypes.c_void_p(DL.data_ptr() + 4 * feat), W, n, feat, p(bias), p(part), st), 'i3d_colsum_strided')
+    ref_bias = gp_ref.double().sum(0).cpu()
+    assert float((bias.cpu().double() - ref_bias).abs().max()) < 2e-6 * max(1.0, float(gp_ref.abs().double().sum(0).max()))
