@@ -309,6 +309,15 @@ static bool merge_h_ok(const I3dPnaLayerArgs* a) {
 // the edge block's BatchNorm backward fused with the segmented sums behind it (bn.hip: i3d_bn_bwd_edge_sums): merged h-products
 // (dP lands in the first two column blocks of DL), an activation whose derivative follows from the stored activation, 16-byte rows.
 // I3D_EDGE_BWD_FUSED=0: BatchNorm backward + i3d_segment_sum_pair (the same bits).
+// The LAST layer of a backward pass (wgrad_split: nothing of the chain runs next to its weight gradients any more): the chain's
+// stream is idle behind its data gradient while the weight-gradient stream still has the layer's panels, their reduction and
+// the bond-table products in front of the join - the two small launches of the bias gradient go to the chain's stream there
+// (19 us off the tail of the step).  I3D_EDGE_BIAS_ON_CHAIN=0: on the weight-gradient stream like the other layers'.
+static bool edge_bias_on_chain(const I3dPnaLayerArgs* a) {
+    static const bool on = [] { const char* v = getenv("I3D_EDGE_BIAS_ON_CHAIN"); return v == nullptr || v[0] != '0'; }();
+    return on && a->wgrad_split != 0;
+}
+
 static bool edge_bwd_fused_ok(const I3dPnaLayerArgs* a) {
     static const bool on = [] { const char* v = getenv("I3D_EDGE_BWD_FUSED"); return v == nullptr || v[0] != '0'; }();
     const I3dEdgeFcArgs* e = &a->edge;
@@ -412,7 +421,9 @@ static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_r
     for (int i = a->n_pre_extra - 1; i >= 0 && do_pre; --i)
         TRY(bias_final(&a->pre[i].tail, a->pre[i].rows, a->pre[i].f_out, a->pre[i].grad_bias, wst));
     if (do_pre) {
-        if (edge_bwd_fused_ok(a))      // the bias gradient = column sum of dP[dst] (the layer's backward took i3d_bn_bwd_edge_sums)
+        if (edge_bwd_fused_ok(a) && edge_bias_on_chain(a)) {
+            // (taken on the caller's stream at the end of the layer's backward: see there)
+        } else if (edge_bwd_fused_ok(a))      // the bias gradient = column sum of dP[dst] (the layer's backward took i3d_bn_bwd_edge_sums)
             TRY(i3d_colsum_strided(a->DL + Fo, 2 * Fo + a->post.f_out, N, Fo, e->grad_bias, a->edge_bias_partial, wst));
         else
             TRY(bias_final(&e->tail, E, Fo, e->grad_bias, wst));
@@ -673,6 +684,10 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
         if (a->residual && !inplace) TRY(i3d_add_inplace(a->post.grad_h, a->grad_out, n, stream));
     } else {
         TRY(edge_fc_bn_bwd_dgrad(&a->edge, stream, a->post.grad_h));       // post.grad_h += edge block's dh
+    }
+    if (edge_fused && edge_bias_on_chain(a)) {
+        const int Fo = a->edge.f_out;
+        TRY(i3d_colsum_strided(a->DL + Fo, 2 * Fo + a->post.f_out, a->edge.num_nodes, Fo, a->edge.grad_bias, a->edge_bias_partial, stream));
     }
     if (a->defer_join) return I3D_OK;
     return join_wgrad(x, stream);
