@@ -23,7 +23,7 @@ def _sources():
 
 def _stamp():
     h = hashlib.sha256()
-    for p in _sources() + [os.path.join(CSRC, 'common.h'), HEADER, os.path.abspath(__file__)]:
+    for p in _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + [HEADER, os.path.abspath(__file__)]:
         with open(p, 'rb') as f:
             h.update(f.read())
     return h.hexdigest()
@@ -44,12 +44,22 @@ def build(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + '.o')
+        # per-object stamp: the source, every header it can include and the flags (an unchanged unit is not recompiled)
+        h = hashlib.sha256(' '.join(FLAGS).encode())
+        for p in [src, HEADER] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')):
+            with open(p, 'rb') as f:
+                h.update(f.read())
+        tag, tagfile = h.hexdigest(), obj + '.stamp'
+        if not force and os.path.exists(obj) and os.path.exists(tagfile) and open(tagfile).read().strip() == tag:
+            return obj
         cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
+        with open(tagfile, 'w') as f:
+            f.write(tag)
         return obj
 
     with ThreadPoolExecutor(max_workers=8) as ex:

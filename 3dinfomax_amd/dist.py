@@ -144,6 +144,13 @@ def native_sync_provider():
     return _native_sync['provider'] if _native_sync is not None else None
 
 
+_fallbacks = []      # every provider fallback taken in this process, in order (bench.py reports it next to the provider in use)
+
+
+def native_sync_fallbacks():
+    return list(_fallbacks)
+
+
 def _all_ok(ok, group):
     """every rank's `ok` ANDed: a set-up step either holds on every rank or on none (the ranks then take the same fallback)"""
     flags = [None] * dist.get_world_size(group)
@@ -242,8 +249,10 @@ def enable_native_sync(group, device, provider=None, timeout_s=0.0):
                       f'({L.i3d_last_error().decode() if L.i3d_last_error() else "no message"}); falling back to '
                       + ('host-staged callbacks' if _is_gloo(group) else 'the RCCL provider'))
         provider = state['provider'] = 'callbacks' if _is_gloo(group) else 'rccl'
+        _fallbacks.append(f'peer -> {provider}')
     if provider == 'rccl':
         if not _all_ok(L.i3d_rccl_available(), group):
+            _fallbacks.append('rccl -> per-block (librccl not loadable on some rank)')
             return False
         buf = ctypes.create_string_buffer(128)
         if rank == 0:

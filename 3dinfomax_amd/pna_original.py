@@ -114,7 +114,10 @@ class PNAOriginal(nn.Module):
 
     def forward(self, g, snorm_n):
         g = as_batched_graph(g)
-        stacks = _stacks_for(self) if (TOWER_STACK and g.ndata['feat'].is_cuda) else None
+        # (under an outer tape the stacked copies would not be leaves of THAT tape: the towers' parameters would silently get no
+        # gradient - the per-tower path runs on the parameters themselves)
+        stacks = _stacks_for(self) if (TOWER_STACK and g.ndata['feat'].is_cuda and
+                                       not (tape.active() is not None and torch.is_grad_enabled())) else None
         if stacks is None:          # per-tower path (any structure; also the cross-check of the stacked path in the tests)
             g, h = self.node_gnn(g, g.ndata['feat'], g.edata['feat'], snorm_n)
             readout = ReadoutFn.apply(h, g.index(), self._readout_codes)
@@ -143,7 +146,8 @@ class PNAOriginal(nn.Module):
         for layer, st in zip(gnn.layers, stacks.layers):
             tw = layer.towers[0]
             # (an eval-mode layer under a tape may still be differentiated: that backward is sequenced by the block path only)
-            native = TOWER_NATIVE and (layer.training or tape.active() is None) and ops.GEMM_WORKSPACE_BYTES > 0
+            native = (TOWER_NATIVE and (layer.training or tape.active() is None) and ops.GEMM_WORKSPACE_BYTES > 0
+                      and idx.num_edges > 0)       # (a batch without bonds: the block path handles E = 0)
             if native:
                 if tw.graph_norm and snorm_flat is None:
                     snorm_flat = snorm.reshape(-1).contiguous().float()
@@ -315,10 +319,19 @@ class _TowerStacks:
     def unpack_grads(self):
         self._copy(self.t_grads, True)
 
-    def grad_pool(self, others=()):
+    def grad_pool(self, others=(), persistent_others=True):
         """what tape.grad_like / grad_for_bias_of consult during the backward pass: the stacked leaves' gradients are written
         straight into the stacked gradient buffer, the other parameters' (`others`: encoders, mixing networks, head) into
-        persistent buffers of their own - the optimizer's one-launch kernel keeps its pointer table from step to step"""
+        persistent buffers of their own - the optimizer's one-launch kernel keeps its pointer table from step to step.
+        persistent_others=False (a `.grad` may still alias those buffers): only the stacked leaves are pooled, every other
+        gradient is a new tensor."""
+        if not persistent_others:
+            pool = tape._GradPool.__new__(tape._GradPool)
+            pool.key = ()
+            pool.view_of = {id(v): g for v, g in zip(self.leaves, self.leaf_grads)}
+            pool.bias_of = {k: b for st in self.layers for k, b in st.bias_of.items()}
+            pool.used = set()
+            return pool
         pool = self._pool
         if pool is None or any(id(p) not in self.other_grad for p in others):
             for p in others:
@@ -483,7 +496,12 @@ class _StackedModelFn(torch.autograd.Function):
     def backward(ctx, grad):
         stacks = ctx.stacks
         others = [p for p in ctx.params if id(p) not in stacks.param_ids]
-        tape._tls.pool = stacks.grad_pool(others)
+        # The persistent per-parameter buffers (stacks.pgrad, stacks.other_grad) may be handed out only when nothing can still be
+        # looking at them: every `.grad` empty, no hooks (tape.ModelFn's rule).  After such a step `p.grad` IS the buffer; with
+        # zero_grad(set_to_none=False), gradient accumulation or two forwards before one backward the next pass must not write
+        # into it - autograd would then add the new gradient to a buffer that already holds it (2 g_new instead of g_old + g_new).
+        direct = tape.DIRECT_PARAM_GRADS and tape._plain_leaves(ctx.params)
+        tape._tls.pool = stacks.grad_pool(others if direct else (), persistent_others=direct)
         try:
             grads = ctx.tape.backward(ctx.out_id, grad.contiguous())
         finally:
@@ -494,15 +512,29 @@ class _StackedModelFn(torch.autograd.Function):
                 gv.zero_()
             elif ent[0].data_ptr() != gv.data_ptr():
                 gv.copy_(ent[0])
-        stacks.unpack_grads()
+        if direct:
+            stacks.unpack_grads()
+            pgrad = stacks.pgrad
+        else:
+            # the copy table's destination is the persistent flat buffer, which a `.grad` may alias: scatter into it, take a copy,
+            # put back what it held
+            held = stacks.pgrad_flat.clone()
+            stacks.unpack_grads()
+            fresh = stacks.pgrad_flat.clone()
+            stacks.pgrad_flat.copy_(held)
+            sizes = [p.numel() for p in stacks.params]
+            pgrad = {id(p): v.view_as(p) for p, v in zip(stacks.params, fresh.split(sizes))}
         out, dsts, srcs = [], [], []
         for p in ctx.params:
             if id(p) in stacks.param_ids:
-                out.append(stacks.pgrad[id(p)])
+                out.append(pgrad[id(p)])
             else:
                 ent = grads.get(id(p))
                 if ent is None:
                     out.append(None)
+                    continue
+                if not direct:
+                    out.append(ent[0])
                     continue
                 keep = stacks.other_grad[id(p)]
                 if ent[0].data_ptr() != keep.data_ptr():       # a gradient that was not written through tape.grad_like (the encoders' tables)
@@ -511,7 +543,7 @@ class _StackedModelFn(torch.autograd.Function):
                 out.append(keep)
         if dsts:
             torch._foreach_copy_(dsts, srcs)
-        if tape.DIRECT_PARAM_GRADS and tape._plain_leaves(ctx.params):
+        if direct:
             for p, g in zip(ctx.params, out):
                 if g is not None:
                     p.grad = g

@@ -93,7 +93,58 @@ def parse():
                     help='initialise RCCL and run the data-parallel code path even with one rank (self-test)')
     ap.add_argument('--no-extra-workloads', action='store_true',
                     help='skip the short windows of the other BASELINE.json configs after the timed region (config.extra_workloads)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launch check only: start the ranks, form the process group, count the ranks the communicator sees '
+                         '(all-reduce of ones) and print the JSON line without running a model (no GPU needed with --backend gloo)')
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks ourselves - the same
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` the driver
+    uses, on a free port - and hand its exit code back.  Under a launcher (WORLD_SIZE set) this is never reached."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL / the peer exchange across processes need it here
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('bench.py: --gpus %d without a launcher: ' % args.gpus + ' '.join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def ranks_report(dist, world, rank, dev, backend):
+    """What the communicator itself saw: an all-reduce of ones (`ranks_seen`), every rank's device, the collective library."""
+    import torch.distributed  # noqa: F401
+    cpu = dev is None
+    ones = torch.ones(1, dtype=torch.float32, device='cpu' if cpu else dev)
+    dist.all_reduce(ones)
+    mine = dict(rank=rank, local_rank=int(os.environ.get('LOCAL_RANK', '0')), pid=os.getpid(),
+                device=None if cpu else int(dev.index),
+                device_name=None if cpu else torch.cuda.get_device_name(dev),
+                pci_bus_id=None)
+    if not cpu:
+        try:
+            mine['pci_bus_id'] = '%04x:%02x:%02x' % tuple(
+                getattr(torch.cuda.get_device_properties(dev), k, 0) for k in ('pci_domain_id', 'pci_bus_id', 'pci_device_id'))
+        except Exception:         # noqa: BLE001
+            pass
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    lib = None
+    if backend == 'nccl':
+        try:
+            lib = 'RCCL %s' % '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as exc:  # noqa: BLE001
+            lib = f'RCCL (version unavailable: {type(exc).__name__})'
+    else:
+        lib = 'gloo (host-staged; functional check only)'
+    return dict(ranks_seen=int(round(ones.item())), ranks=gathered, collective_library=lib, backend=backend,
+                distinct_devices=len({(r['device'], r['pci_bus_id']) for r in gathered}) if not cpu else 0)
 
 
 def cpu_baseline(mols, depth, steps):
@@ -287,12 +338,38 @@ def extra_workloads(amd, ops, dev, depth):
     return out
 
 
+def dry_run(args, world, rank):
+    """--dry-run: the launch path and the process group only (CPU tests; `--backend gloo` needs no GPU)."""
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29511')
+    dev = None
+    if args.backend == 'nccl':
+        assert torch.cuda.is_available(), '--dry-run --backend nccl needs GPUs (use --backend gloo on a CPU box)'
+        dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+        torch.cuda.set_device(dev)
+    if world > 1 or args.force_dist:
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **({'device_id': dev} if dev is not None else {}))
+        seen = ranks_report(dist, world, rank, dev, args.backend)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen = dict(ranks_seen=1, ranks=[dict(rank=0, local_rank=0, pid=os.getpid(), device=None)], backend=None)
+    if rank == 0:
+        print(json.dumps(dict(metric='molecules/sec pretraining step (PNA+Net3D, QM9-50k); PNA-agg HBM GB/s vs peak', value=None,
+                              unit='molecules/s', n_gpus=world, steps=0, warmup=0, dry_run=True, **seen)), flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
+    assert world == args.gpus, f'--gpus {args.gpus} but the launcher set WORLD_SIZE={world}'
+    if args.dry_run:
+        return dry_run(args, world, rank)
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
     if args.backend == 'gloo':      # functional check of the N > 1 code path on a box with fewer GPUs than ranks
         local_rank %= torch.cuda.device_count()
@@ -313,6 +390,8 @@ def main():
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        seen = ranks_report(dist, world, rank, dev, args.backend)      # did the communicator see N ranks, on which devices
+        assert seen['ranks_seen'] == world, f"the communicator counted {seen['ranks_seen']} ranks, launched {world}"
 
     # synthetic QM9-shaped data: `pool` global batches, each rank keeps its shard resident in HBM
     qmugs = args.workload == 'qmugs'
@@ -696,6 +775,16 @@ def main():
                    roofline=roof)
         if collectives is not None:
             out['collectives'] = collectives
+        if use_dist:
+            out['ranks_seen'] = seen['ranks_seen']
+            out['distributed'] = dict(seen, sync_bn_provider_in_use=adist.native_sync_provider(),
+                                      sync_bn_fallbacks=adist.native_sync_fallbacks() if hasattr(adist, 'native_sync_fallbacks') else None)
+            # which BatchNorm the headline `value` ran with: only statistics over the GLOBAL batch reproduce the reference's loss
+            # (models/base_layers.py:87, 100-111 normalises over every row it is given); a run that fell back to per-rank statistics
+            # is a throughput number, not the loss-matching one
+            out['parity'] = ('reference-equal: BatchNorm statistics over the global batch, all-gathered negatives' if headline_sync
+                             else 'NOT reference-equal: per-rank BatchNorm statistics'
+                                  + (' (fallback: the synchronised step failed at run time)' if sync_note else ' (--local-bn)'))
         if world == 1 and not use_dist and not qmugs and not args.no_extra_workloads and args.dtype == 'fp32':
             del batches[1:]
             out['config']['extra_workloads'] = extra_workloads(amd, ops, dev, args.depth)

@@ -57,3 +57,34 @@ def test_committed_pmc_summary_has_rows_for_the_default_bench_workload():
         alg_bwd = 4.0 * N * 4 * F + 2 * 4.0 * E * F + 4.0 * (N + 1)
         assert 0.95 < fwd / alg_fwd < 1.08, (seed, fwd, alg_fwd)
         assert 0.95 < bwd / alg_bwd < 1.08, (seed, bwd, alg_bwd)
+
+
+def test_bench_starts_its_own_ranks_from_a_plain_python_command():
+    """the driver's N = 1 command shape (`python bench.py --gpus N ...`) must also start at N > 1 - bench.py
+    re-executes itself under torch.distributed.run on a free port when no launcher set WORLD_SIZE - and the line must say how
+    many ranks the communicator saw.  --dry-run --backend gloo: launch path + process group only, no GPU."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--backend', 'gloo', '--dry-run'], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout          # ONE line, from rank 0
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['ranks_seen'] == 2 and out['dry_run'] is True
+    assert sorted(x['rank'] for x in out['ranks']) == [0, 1] and len({x['pid'] for x in out['ranks']}) == 2
+    assert 'torch.distributed.run' in r.stderr          # it says what it launched
+
+
+def test_bench_under_a_launcher_does_not_launch_again():
+    """The driver's own N > 1 command (torch.distributed.run around bench.py) keeps working: WORLD_SIZE set -> no re-exec."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', '29641', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo',
+                        '--dry-run'], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert out['ranks_seen'] == 2 and 'without a launcher' not in r.stderr

@@ -154,6 +154,50 @@ def test_stacked_towers_equal_the_per_tower_path_on_the_yml_configuration(monkey
         assert close(res[True][1][k], v, 2e-2, 1e-3), k
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['two_backwards', 'zero_grad_keeps_tensors', 'two_forwards_one_backward'])
+def test_stacked_towers_accumulate_gradients_like_the_per_tower_path(mode, monkeypatch):
+    """ADVICE round 4 (medium): after a step whose gradients were stored directly, `p.grad` IS the stacked path's persistent buffer;
+    a second backward without zero_grad, zero_grad(set_to_none=False), or two forwards before one backward must still end in
+    g_old + g_new (not 2 g_new).  Stacked path against I3D_TOWER_STACK=0 on the small configuration."""
+    amd = importlib.import_module('3dinfomax_amd')
+    po = importlib.import_module('3dinfomax_amd.pna_original')
+    synth = importlib.import_module('3dinfomax_amd.synth')
+    mols_a, mols_b = synth.make_dataset(12, seed=5), synth.make_dataset(12, seed=6)
+    res = {}
+    for stacked in (True, False):
+        monkeypatch.setattr(po, 'TOWER_STACK', stacked)
+        torch.manual_seed(11)
+        model = amd.PNAOriginal(**PNA_ORIG_KW)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n.endswith('linear.weight'):
+                    p.mul_(p.shape[1] * 0.5)
+        model.cuda().train()
+        ga = amd.batch([amd.bond_graph(m) for m in mols_a]).to('cuda:0')
+        gb = amd.batch([amd.bond_graph(m) for m in mols_b]).to('cuda:0')
+        sa = O.snorm_n([m.n_atoms for m in mols_a]).cuda()
+        sb = O.snorm_n([m.n_atoms for m in mols_b]).cuda()
+        if mode == 'two_backwards':
+            model(ga.local_copy(), sa).square().mean().backward()          # direct store: .grad is the persistent buffer
+            model(gb.local_copy(), sb).square().mean().backward()          # must ADD
+        elif mode == 'zero_grad_keeps_tensors':
+            model(ga.local_copy(), sa).square().mean().backward()
+            for p in model.parameters():                                   # zero_grad(set_to_none=False)
+                if p.grad is not None:
+                    p.grad.zero_()
+            model(gb.local_copy(), sb).square().mean().backward()
+            model(ga.local_copy(), sa).square().mean().backward()
+        else:
+            la = model(ga.local_copy(), sa).square().mean()
+            lb = model(gb.local_copy(), sb).square().mean()
+            (la + lb).backward()
+        torch.cuda.synchronize()
+        res[stacked] = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
+    assert set(res[True]) == set(res[False])
+    grads_close(res[True], res[False], 2e-3)
+
+
 def test_state_dict_surface_of_original_variants():
     amd = importlib.import_module('3dinfomax_amd')
     z = load('pna_original.npz')
