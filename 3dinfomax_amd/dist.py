@@ -441,11 +441,14 @@ class GradReducer:
         whether THOSE gradients are final); None: reduce() itself."""
         if self._launched or not self._agreed:       # (no early collective before the ranks have agreed on the plan)
             return
-        if native_sync_provider() == 'rccl':
+        if module is not None and native_sync_provider() == 'rccl':
             # The library's own RCCL communicator issues the BatchNorm collectives of the rest of the backward pass on the
             # compute stream; an asynchronous all-reduce of torch's communicator next to them would be two communicators in
             # flight without a common order across ranks (documented as unsafe unless both kernels are always co-resident).
-            # The peer provider has no communicator: the early all-reduce stays on with it.
+            # The peer provider has no communicator: the early all-reduce stays on with it.  Only the start from INSIDE a
+            # backward pass is switched off: reduce() (module None; the backward pass and its BatchNorm collectives are enqueued)
+            # still reduces these slices - it skips them in its complement (round 5: it used to return here too, which left
+            # the head's and the upper layers' gradients un-reduced whenever the RCCL provider was in use at world > 1).
             return
         if module is not None and id(module) != self.early_module:
             return
@@ -517,7 +520,9 @@ class GradReducer:
             dist.all_reduce(both, op=dist.ReduceOp.MAX, group=self.group)
             both = both.cpu()
             self._agreed = bool(self.overlap and self.early_spans and torch.equal(both[:3], -both[3:]))
-        if self._agreed and dist.get_world_size(self.group) > 1:
+        if self._agreed is None and os.environ.get('I3D_TEST_FORCE_EARLY_ALLREDUCE') == '1':
+            self._agreed = bool(self.overlap and self.early_spans)      # test hook: the split reduction at world 1 (one-GPU box)
+        if self._agreed:
             # the same collectives in the same order on every rank: the early slices (now, if the backward pass did not
             # start them), then the complement; then wait for the early ones
             self.launch_async()

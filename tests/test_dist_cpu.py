@@ -198,6 +198,41 @@ def test_early_all_reduce_with_gradient_accumulation():
     assert dict(out) == {0: True, 1: True}
 
 
+def _rccl_switch_worker(rank, port, out):
+    """The RCCL provider of the synchronised BatchNorm switches the EARLY start of the gradient all-reduce off (two communicators
+    must not be in flight at once) - the slices it would have started early must still be reduced by reduce()."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    adist = importlib.import_module('3dinfomax_amd.dist')
+    adist.native_sync_provider = lambda: 'rccl'          # (the provider itself needs one GPU per rank: its decision is what is tested)
+    g = torch.Generator().manual_seed(7)
+    params = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in ((4, 3), (5,), (2, 6), (7,))]
+    grads = [torch.randn(WORLD, *p.shape, generator=g) for p in params]
+    red = adist.GradReducer(params)
+    owner = torch.nn.Linear(1, 1)
+    red.early_spans = [[red.span_of[id(params[2])][0], red.span_of[id(params[3])][1]]]
+    red.early_module = id(owner)
+    red._agreed = True
+    for p, v in zip(params, red._sink(params, [gr[rank].clone() for gr in grads])):
+        p.grad = v
+    red.launch_async(owner)                                 # from inside the backward pass: switched off under RCCL
+    ok = red._launched == []
+    red.reduce()
+    for p, gr in zip(params, grads):                        # EVERY slice reduced, the early ones included
+        ok = ok and torch.allclose(p.grad, gr.sum(0), rtol=1e-5, atol=1e-6)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_rccl_provider_switches_the_early_start_off_but_every_gradient_is_reduced():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_switch_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
 def _equal_check_worker(rank, port, out):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=WORLD)

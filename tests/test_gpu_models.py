@@ -130,6 +130,48 @@ def test_three_adam_steps_vs_reference_fixture(amd, fixture):
                 assert close(p.detach(), z[f'{tag}/{k}'], 1e-4, 2e-5), k
 
 
+def test_three_adam_steps_in_the_bf16_matmul_mode_vs_reference_fixture(amd):
+    """The three optimisation steps of train3.npz (the reference's fp32 trajectory) in the bf16 MATMUL mode (configs[3]'s mode:
+    bf16-rounded operands on the bf16 matrix pipe, fp32 accumulation, fp32 tensors / statistics / master weights): what a
+    user of that mode gets instead of the fp32 losses - every loss of the trajectory within BF16_TRAJ_TOL of the reference's."""
+    ops = importlib.import_module('3dinfomax_amd.ops')
+    z = load('train3.npz')
+    mols = mols_from_npz(z)
+    prev = ops.set_matmul_precision('bf16')
+    try:
+        pna = amd.PNA(avg_d=1.0, device='cuda:0', **PNA_SMALL)
+        net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_SMALL)
+        pna.load_state_dict(sd_from_npz(z, 'pna_sd'))
+        net.load_state_dict(sd_from_npz(z, 'net3d_sd'))
+        pna.cuda().train(), net.cuda().train()
+        loss_fn = amd.NTXent(tau=0.1)
+        named = list(pna.named_parameters()) + list(net.named_parameters())
+        optim = amd.Adam([{'params': [p for k, p in named if 'batch_norm' in k], 'weight_decay': 0},
+                          {'params': [p for k, p in named if 'batch_norm' not in k]}], lr=8e-5)
+        g2, g3 = make_batch(amd, mols)
+        losses = []
+        for _ in range(3):
+            a, b = g2.local_copy(), g3.local_copy()
+            loss = loss_fn(pna(a), net(b), nodes_per_graph=a.batch_num_nodes())
+            loss.backward()
+            optim.step()
+            optim.zero_grad()
+            losses.append(loss.item())
+    finally:
+        ops.set_matmul_precision(prev)
+    ref = np.asarray(z['losses'], dtype=np.float64)
+    rel = np.abs(np.asarray(losses) - ref) / np.abs(ref)
+    print('bf16 matmul mode, three Adam steps: losses', losses, 'reference', list(ref), 'relative', list(rel))
+    assert float(rel.max()) < BF16_TRAJ_TOL, (losses, list(ref))
+    # and the trajectory moves the way the reference's does (same sign of every step-to-step change that is above the bound)
+    for i in range(2):
+        if abs(ref[i + 1] - ref[i]) > 2 * BF16_TRAJ_TOL * abs(ref[i]):
+            assert (losses[i + 1] - losses[i]) * (ref[i + 1] - ref[i]) > 0
+
+
+BF16_TRAJ_TOL = 1e-2      # relative, per loss of the trajectory
+
+
 def _det_load(module, tag):
     new = {}
     for k, v in module.state_dict().items():
@@ -477,12 +519,19 @@ def _qmugs_vs_oracle(amd, variant, n_mols, precision, hidden=64, depth=2):
         grads_close_l2(param_grads(net), {k: P3[k].grad for k in O.trainable(P3)}, 5e-2, 'net3d ')
 
 
-@pytest.mark.parametrize('batch,depth', [(256, 4), (128, 7)])
+# un-routed gradient bound (relative L2 per tensor of the 2D model; measured values in DESIGN.md section 6)
+UNROUTED_L2 = {4: 5e-2, 7: 1e-1}
+
+
+@pytest.mark.parametrize('batch,depth', [(512, 4), (256, 4), (128, 7)])
 def test_pretraining_config_hidden_200_vs_oracle_with_routed_extrema(amd, batch, depth):
-    """BASELINE.json configs[1] at hidden 200 / depth 4 on 256 molecules (and the yml's depth 7 on 128) against the CPU
-    oracle, aggregators and readouts AS CONFIGURED (mean / max / min / std, min / max / mean): loss and embeddings to 1e-4,
-    every parameter gradient of the 2D model to 2e-3 max-norm with the oracle's max / min gradients routed to the
-    positions the HIP kernels picked; flips (near-ties resolved differently by fp32 rounding) are counted."""
+    """BASELINE.json configs[1] at hidden 200 / depth 4 AT ITS OWN SIZE (512 molecules; also 256, and the yml's depth 7 on
+    128) against the CPU oracle, trained-like weights (_det_load), aggregators and readouts AS CONFIGURED (mean / max / min /
+    std, min / max / mean): loss, node embeddings and outputs to 1e-4, every parameter gradient of the 2D model to 2e-3
+    max-norm with the oracle's max / min gradients routed to the positions the HIP kernels picked; flips (near-ties resolved
+    differently by fp32 rounding) are counted.  Next to it the UN-routed statement: the same gradients against the oracle
+    with its own arg-max / arg-min choices, relative L2 per tensor, printed and bounded (the routed comparison is a
+    refinement of this one, not the only evidence)."""
     mols = synth.make_dataset(batch, seed=41)
     kw2 = dict(PNA_YML, propagation_depth=depth)
     kw3 = dict(NET3D_YML)
@@ -517,6 +566,28 @@ def test_pretraining_config_hidden_200_vs_oracle_with_routed_extrema(amd, batch,
     if depth > 4:
         grads_close_l2(param_grads(pna), ref2, 1e-2, 'pna ', floor=5e-5)      # floor: the biases in front of a BatchNorm (noise)
     grads_close_l2(param_grads(net), {k: P3[k].grad for k in O.trainable(P3)}, 5e-2, 'net3d ')
+    # ---- un-routed: the oracle alone decides where its max / min gradients go (reference semantics: first index of the
+    # extremum of ITS fp32 values).  A near-tie that the two sides' roundings resolve differently moves one gradient row.
+    U2 = O.require_grad({k: v.detach().clone() for k, v in P2.items()})
+    U3 = O.require_grad({k: v.detach().clone() for k, v in P3.items()})
+    u2, _ = O.pna_forward(og2, U2, O.pna_config(**kw2), True)
+    u3, _ = O.net3d_forward(og3, U3, O.net3d_config(**kw3), True)
+    O.ntxent(u2, u3, 0.1).backward()
+    mine = param_grads(pna)
+    worst, rows = 0.0, []
+    for k in O.trainable(U2):
+        if k not in mine or U2[k].grad is None:
+            continue
+        ref, got = U2[k].grad, mine[k].cpu()
+        if ref.norm().item() < 5e-5:          # biases in front of a BatchNorm: analytically zero, noise on both sides
+            continue
+        e = ((got - ref).norm() / ref.norm()).item()
+        rows.append((e, k))
+        worst = max(worst, e)
+    rows.sort(reverse=True)
+    print(f'un-routed 2D gradients vs the oracle (batch {batch}, depth {depth}): worst relative L2 {worst:.2e} ({rows[0][1]}), '
+          f'median {rows[len(rows) // 2][0]:.2e}')
+    assert worst < UNROUTED_L2[depth], rows[:5]
 
 
 @pytest.mark.parametrize('variant,depth', [('as_configured', 3), ('smooth', 3), ('as_configured', 7)])
@@ -997,6 +1068,10 @@ def test_missing_library_fails_loudly(amd, monkeypatch):
         L.load()
 
 
+# embeddings (max-norm) / loss / all gradients (relative L2) under a reordering of the batch, trained-like weights
+FULL_SIZE_TOL = (2e-5, 1e-5, 5e-3)
+
+
 def test_full_size_batch_properties(amd):
     """configs[1] at its full size (512 molecules, hidden 200, depth 4 + Net3D + NT-Xent), through properties that do not
     need the oracle at that size: (1) reordering the molecules of the batch reorders the rows of both embeddings and
@@ -1010,8 +1085,13 @@ def test_full_size_batch_properties(amd):
 
     def step(order):
         torch.manual_seed(9)
-        pna = amd.PNA(avg_d=1.0, device='cuda:0', **dict(PNA_YML, propagation_depth=4)).cuda().train()
-        net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_YML).cuda().train()
+        pna = amd.PNA(avg_d=1.0, device='cuda:0', **dict(PNA_YML, propagation_depth=4))
+        net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_YML)
+        # trained-like weights: with the reference init (gain 1 / in_dim) the pre-BatchNorm variance is far below eps and
+        # the embeddings barely depend on the input - the properties would be checked on near-constant rows
+        _det_load(pna, 'pnaR')
+        _det_load(net, 'net3dR')
+        pna.cuda().train(), net.cuda().train()
         g2, g3 = make_batch(amd, [mols[i] for i in order])
         z2, z3 = pna(g2), net(g3)
         loss = amd.NTXent(tau=0.1)(z2, z3)
@@ -1021,13 +1101,16 @@ def test_full_size_batch_properties(amd):
 
     z2, z3, loss, grads = step(range(512))
     assert z2.shape == (512, 256) and z3.shape == (512, 256) and math.isfinite(loss)
+    assert z2.std(0).mean().item() > 1e-2 and z3.std(0).mean().item() > 1e-2      # the rows DO depend on the molecule
     assert torch.equal(z2[7], z2[511]) and torch.equal(z3[7], z3[511])
     z2p, z3p, lossp, gradsp = step(perm)
     idx = torch.from_numpy(perm).cuda()
-    for a, b in ((z2[idx], z2p), (z3[idx], z3p)):
-        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
-    assert abs(loss - lossp) <= 1e-5 * abs(loss)
-    assert ((grads - gradsp).norm() / grads.norm()).item() <= 2e-3
+    errs = [((a - b).abs().max() / b.abs().max()).item() for a, b in ((z2[idx], z2p), (z3[idx], z3p))]
+    gerr = ((grads - gradsp).norm() / grads.norm()).item()
+    print(f'full-size properties (configs[1]): embeddings {errs}, loss {abs(loss - lossp) / abs(loss):.2e}, gradients {gerr:.2e}')
+    assert max(errs) <= FULL_SIZE_TOL[0]
+    assert abs(loss - lossp) <= FULL_SIZE_TOL[1] * abs(loss)
+    assert gerr <= FULL_SIZE_TOL[2]
 
 
 def _full_size_properties(amd, step, n, tol_z, tol_loss, tol_grad, dup=(7, None)):
@@ -1048,8 +1131,7 @@ def _full_size_properties(amd, step, n, tol_z, tol_loss, tol_grad, dup=(7, None)
         pairs.append((z3[idx3], z3p))
     errs = [((a - b).abs().max() / b.abs().max()).item() for a, b in pairs]
     gerr = ((grads - gradsp).norm() / grads.norm()).item()
-    if os.environ.get('I3D_TEST_VERBOSE'):
-        print(f'full-size properties: embeddings {errs}, loss {abs(loss - lossp) / abs(loss):.2e}, gradients {gerr:.2e}')
+    print(f'full-size properties: embeddings {errs}, loss {abs(loss - lossp) / abs(loss):.2e}, gradients {gerr:.2e}')
     assert all(e <= tol_z for e in errs), errs
     assert abs(loss - lossp) <= tol_loss * abs(loss)
     assert gerr <= tol_grad, gerr
@@ -1073,8 +1155,11 @@ def test_full_size_qmugs_batch_properties(amd, precision):
 
     def step(order):
         torch.manual_seed(9)
-        pna = amd.PNA(avg_d=1.0, device='cuda:0', **dict(PNA_YML, propagation_depth=7)).cuda().train()
-        net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_YML).cuda().train()
+        pna = amd.PNA(avg_d=1.0, device='cuda:0', **dict(PNA_YML, propagation_depth=7))
+        net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_YML)
+        _det_load(pna, 'pnaQ7')          # trained-like weights (see test_full_size_batch_properties)
+        _det_load(net, 'net3dQ7')
+        pna.cuda().train(), net.cuda().train()
         g2 = amd.batch([amd.bond_graph(mols[i]) for i in order]).to('cuda:0')
         g3 = amd.batch([amd.complete_graph(mols[i], c) for i in order for c in confs[i]]).to('cuda:0')
         if precision == 'bf16':      # the gates are on by size, not forced
@@ -1107,7 +1192,9 @@ def test_full_size_finetune_batch_properties(amd):
 
     def step(order):
         torch.manual_seed(9)
-        pna = amd.PNA(avg_d=1.0, device='cuda:0', **kw).cuda().train()
+        pna = amd.PNA(avg_d=1.0, device='cuda:0', **kw)
+        _det_load(pna, 'pnaF7')          # trained-like weights (see test_full_size_batch_properties)
+        pna.cuda().train()
         g2 = amd.batch([amd.bond_graph(mols[i]) for i in order]).to('cuda:0')
         z = pna(g2)
         loss = torch.nn.L1Loss()(z, targets[torch.as_tensor(order)].cuda())
