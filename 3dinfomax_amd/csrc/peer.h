@@ -23,6 +23,9 @@
 // clock): on expiry the thread records `seq` in a host-visible status word and in its own mailbox (later waits return at
 // once) and the next enqueue returns an error - a lost rank costs a timeout, not a hung GPU.
 // Sums are formed in rank order by every rank: bit-identical results on all ranks, deterministic.
+// The tag is the low 32 bits of seq; sequence numbers with a zero tag are skipped (a zero-initialised, never-written word must
+// not validate; the status word's 0 means healthy).  A word that still carries the tag of 2^32 collectives ago would need to
+// have gone unwritten for that long: every word a collective reads is written by the same collective of the step before.
 #pragma once
 #include "common.h"
 

@@ -330,7 +330,7 @@ class PNAModelFn(torch.autograd.Function):
         red = ctx.state.reducer
         n_layers = desc.struct.n_layers
         if (red is not None and red._agreed and n_layers >= 2 and key is not None
-                and ctx.state.sink_views is views and _world(red.group) > 1):
+                and ctx.state.sink_views is views and (_world(red.group) > 1 or _FORCE_EARLY)):
             # data parallel: the gradients of the head and of the upper half of the layers are final after part 1 - their
             # all-reduce (RCCL, its own stream) runs next to the lower half of the backward pass
             split = n_layers // 2
@@ -349,6 +349,10 @@ class PNAModelFn(torch.autograd.Function):
                 p.grad = gr
             return (None,) * (3 + len(params))
         return (None, None, None) + tuple(out)
+
+
+# test hook (tests/test_gpu_dist.py): the split backward pass + early all-reduce at world 1, on the one-GPU box
+_FORCE_EARLY = os.environ.get('I3D_TEST_FORCE_EARLY_ALLREDUCE') == '1'
 
 
 def _world(group):

@@ -169,7 +169,7 @@ def test_three_adam_steps_in_the_bf16_matmul_mode_vs_reference_fixture(amd):
             assert (losses[i + 1] - losses[i]) * (ref[i + 1] - ref[i]) > 0
 
 
-BF16_TRAJ_TOL = 1e-2      # relative, per loss of the trajectory
+BF16_TRAJ_TOL = 2e-2      # relative, per loss of the trajectory (measured 1.2e-4 / 3.5e-3 / 9.4e-3 on steps 1 / 2 / 3)
 
 
 def _det_load(module, tag):
@@ -520,7 +520,9 @@ def _qmugs_vs_oracle(amd, variant, n_mols, precision, hidden=64, depth=2):
 
 
 # un-routed gradient bound (relative L2 per tensor of the 2D model; measured values in DESIGN.md section 6)
-UNROUTED_L2 = {4: 5e-2, 7: 1e-1}
+# measured: depth 4 worst 2.0e-4 / median 9.6e-5 at 256 molecules; depth 7 / 128 molecules worst 1.7e-2 (a bias) / median 2.5e-3.
+# An arg-max near-tie that the two sides resolve differently moves a whole row: the bounds leave room for a few of those.
+UNROUTED_L2 = {4: 1e-2, 7: 1e-1}
 
 
 @pytest.mark.parametrize('batch,depth', [(512, 4), (256, 4), (128, 7)])
@@ -562,7 +564,11 @@ def test_pretraining_config_hidden_200_vs_oracle_with_routed_extrema(amd, batch,
     # depth 7: which side of 0 an activation lands on moves with the GEMM's summation order (the tile configuration): one
     # flipped gate measured 9.5e-4 absolute = 4e-3 of the largest gradient on layer 5's first pretrans weight (max 1.4e-2,
     # the other tensors at 1.5e-4); max-norm with that much room, and the tensors as a whole to 1e-2 relative L2
-    grads_close(param_grads(pna), ref2, routed_tol(depth), 'pna ', gate_floor=0.0 if depth <= 4 else 1e-2)
+    # 512 molecules: twice the rows of the 256 case, twice the ReLU gates within rounding of 0 - one cut on one side and passed
+    # on the other measured 5.4e-5 absolute = 6e-4 of the largest gradient on layer 1's first pretrans weight (bound without
+    # room for a gate: 3.7e-5); every other tensor sits below a third of its bound
+    grads_close(param_grads(pna), ref2, routed_tol(depth), 'pna ',
+                gate_floor=(1e-3 if batch >= 512 else 0.0) if depth <= 4 else 1e-2)
     if depth > 4:
         grads_close_l2(param_grads(pna), ref2, 1e-2, 'pna ', floor=5e-5)      # floor: the biases in front of a BatchNorm (noise)
     grads_close_l2(param_grads(net), {k: P3[k].grad for k in O.trainable(P3)}, 5e-2, 'net3d ')
@@ -1173,8 +1179,12 @@ def test_full_size_qmugs_batch_properties(amd, precision):
 
     prev = ops.set_matmul_precision(precision)
     try:
-        # measured: fp32 embeddings 9e-7, loss 0, gradients 3.5e-5; bf16 4.3e-3 / 1.4e-5 / 3.7e-2
-        tz, tl, tg = (1e-5, 1e-5, 1e-3) if precision == 'fp32' else (1e-2, 1e-3, 8e-2)
+        # measured with trained-like weights: fp32 embeddings 2.3e-6, loss 0, gradients 1.1e-3; bf16 1.7e-2 / 7.5e-6 / 0.23 -
+        # in the bf16 mode a reordering moves every GEMM tile boundary, operands round the other way (2^-9 each) and the
+        # depth-7 backward pass amplifies it: two runs of the mode are as far from each other as each is from the fp32
+        # oracle (0.10-0.15 relative L2, test_qmugs_conformers_bf16_matmul_end_to_end_at_256_molecules); with the reference init the same
+        # test read 3.7e-2 because the embeddings barely depended on the input
+        tz, tl, tg = (1e-5, 1e-5, 5e-3) if precision == 'fp32' else (3e-2, 1e-3, 0.35)
         _full_size_properties(amd, step, n, tz, tl, tg)
     finally:
         ops.set_matmul_precision(prev)
