@@ -1,4 +1,4 @@
-// The edge stage of the 3D network in one lane per edge (round 2).
+// The edge stage of the 3D network in one lane per edge (round 2; instruction diet + fused backward pass in round 5).
 //
 // reference models/net3d.py:57-81, 100-118 for the structure of the pre-training configs (propagation_depth 1, one
 // message block, node embedding broadcast from one parameter):
@@ -8,50 +8,75 @@
 //     msg  = m * sigmoid( w_g . m + b_g )                   soft edge gate (:117-118)
 //     m_sum[v] = mean / sum of msg over the in-edges of v   (:109)
 // With h the broadcast of ONE vector, W_s h_src + W_d h_dst + b_msg is one constant vector c: the whole stage is a
-// function of the scalar distance of the edge and of the two BatchNorm statistics.  The per-block path (net3d_native.py)
-// runs it as ~20 launches per direction over [E, 20] tensors (GEMM tiles 20 columns wide, a statistics pass and an apply
-// pass per BatchNorm).  Here a lane owns an edge and carries the 20-wide vectors in registers; the weights sit in LDS and
-// are read as broadcasts; what goes through memory is what has to exist as a tensor (the distance embedding the forward
-// leaves on the graph, edge-id order) plus ONE saved [E, H] activation and one transient per direction.
+// function of the scalar distance of the edge and of the two BatchNorm statistics.  A lane owns an edge and carries the
+// 20-wide vectors in registers; what goes through memory is what has to exist as a tensor (the distance embedding the
+// forward leaves on the graph, edge-id order) plus ONE saved [E, H] activation and one transient per direction.
 //
-//   forward   F1  statistics of act(W_in f + b)                      -> per-tile partials -> finalisation (fused_bn.hip)
+//   forward   P   parameters packed for scalar loads (below)
+//             F1  statistics of act(W_in f + b)                      -> per-tile partials -> finalisation (fused_bn.hip)
 //             F2  e0 (stored, edge-id order), x_msg (stored), its statistics -> finalisation
 //             F3  m, gate, msg (stored) -> i3d_segment_sum
-//   backward  B1  sums of the message BatchNorm + the gate's parameter gradients        -> R1
-//             B2a gradient through the message block (stored): dW_e and dc on the MFMA unit (a wave's 64 edges are the K
-//                 dimension of v_mfma_f32_32x32x2_f32, a ones column gives the column sum)
-//             B2b grad of e0 -> through the post activation (stored), sums of the input BatchNorm     -> R2
+//   backward  P
+//             B1  sums of the message BatchNorm + the gate's parameter gradients        -> R1
+//             B2  gradient through the message block (dW_e and dc on the MFMA unit: a wave's 64 edges are the K dimension of
+//                 v_mfma_f32_32x32x2_f32, a ones column gives the column sum), on through W_e^T and the post activation
+//                 (stored: the only [E, H] tensor the backward pass writes), sums of the input BatchNorm     -> R2
 //             B3  gradient through the edge-input block: dW_in | db_in on the MFMA unit  -> R3
-// Every pass recomputes the cheap part of the chain (Fourier features, the [H, 2 n_enc + 1] product) from the distance.
+// Every pass recomputes the cheap part of the chain (Fourier features, the [H, 2 n_enc + 1] product, e0) from the distance.
 // Deterministic: per-lane -> wave tree -> wave order -> block order sums, no atomics.
+//
+// Round 5: these kernels were instruction-bound, not memory-bound (profiles/r05_n3_*: the pass that reads NO [E, H] tensor took
+// 104 us at the QMugs shape; ~2700 instructions per 64 edges in F2, of which 880 LDS reads of weights, 1000 register moves
+// feeding packed operands from them and 480 instructions of IEEE division inside 60 SiLUs).  Now: the parameters are packed
+// once per direction into a small block in global memory and read through the CONSTANT address space - wave-uniform addresses
+// become s_load_dwordx16 and the weights arrive as SGPR pairs that v_pk_fma_f32 takes directly (op_sel splats the lane's
+// value over both halves): a 20 x 20 product is 200 packed FMAs and nothing else; no LDS, no moves, no hoisting hack.
+// sigmoid = v_rcp_f32(1 + v_exp_f32(-x log2 e)) (1 ulp each; the division was ten instructions).  B2 is the former B2a + B2b
+// in one pass: grad_lin never exists as a tensor and e0 is recomputed from the distance instead of gathered from the
+// edge-id-ordered d_out (three [E, H] passes less: 2.43 -> 1.3 GB of traffic per backward pass at the QMugs shape).
 #include "common.h"
 #include "peer.h"
+
+#include <cstdlib>
 
 namespace i3d {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+// wave-uniform reads through the constant address space: s_load_dwordx2..x16, the values arrive in SGPRs
+typedef const __attribute__((address_space(4))) float* cfp;
+typedef const __attribute__((address_space(4))) f2* cf2p;
 
 constexpr int TB = 256;
 // The three activations of the stage (edge-input block, the outer one of net3d.py:81, message block) are SiLU in the
-// reference's configs (`activation: SiLU` is the constructor default and :81 is hard-coded): compiled in.  A runtime code
-// per element turns the unrolled 20-wide loops into ~1000 branches and 500 live registers.
+// reference's configs (`activation: SiLU` is the constructor default and :81 is hard-coded): compiled in.
 constexpr int ACT = I3D_ACT_SILU;
 constexpr int odd(int n) { return n | 1; }   // row stride of an MFMA operand tile in LDS: odd -> the per-lane row writes hit
                                              // distinct banks
-// The weights are loop-invariant LDS reads: without this the compiler hoists all ~600 of them out of the per-edge loops
-// into registers and spills.  A compiler-level memory barrier at the top of an iteration keeps them as LDS broadcasts.
-#define N3_NO_HOIST() __asm__ volatile("" ::: "memory")
-// <= 168 registers per lane (3 waves per SIMD): the 3D network runs on a stream of its own next to the 2D network - a wave
-// that takes the whole register file of its SIMD (the unrolled 20-wide code schedules to 470 registers when allowed to)
-// shuts the other stream out of every CU for the length of the kernel
-#define N3_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
-constexpr int MAX_BWD_BLOCKS = 512;  // two blocks per CU; the R kernels add this many partial rows per column
+// >= 3 waves per SIMD (<= 168 registers per lane): the 3D network runs on a stream of its own next to the 2D network - a wave
+// that takes the whole register file of its SIMD shuts the other stream out of every CU for the length of the kernel
+#define N3_OCC __attribute__((amdgpu_waves_per_eu(3)))
+constexpr int MAX_BWD_BLOCKS = 1024; // four blocks per CU; the R kernels add this many partial rows per column
 
 template <int H, int NENC>
 struct Dims {
     static constexpr int DIN = NENC > 0 ? 2 * NENC + 1 : 1;
 };
+
+// Packed parameter block (floats; every offset even: read as pairs).  Written by n3_pack_kernel once per direction.
+template <int H, int DIN>
+struct Pk {
+    static constexpr int W_IN_T = 0;                 // [DIN][H]     k-major: the pairs of a packed FMA run over the outputs
+    static constexpr int B_IN = W_IN_T + DIN * H;    // [H]
+    static constexpr int W_E_T = B_IN + H;           // [H k][H o]   forward product lin = c + W_e e0
+    static constexpr int W_E = W_E_T + H * H;        // [H o][H k]   backward product W_e^T glin (pairs over k)
+    static constexpr int C = W_E + H * H;            // [H]          (W_s + W_d) emb + b_msg
+    static constexpr int W_G = C + H;                // [H]
+    static constexpr int B_G = W_G + H;              // [1] + pad
+    static constexpr int SIZE = B_G + 2;
+};
+constexpr int PACK_FLOATS = 1280;                    // >= Pk<20, 9>::SIZE = 1042
 
 struct EdgeK {                       // kernel argument (by value)
     int E, N, reduce_mean, rows_per_block;
@@ -75,69 +100,83 @@ struct EdgeK {                       // kernel argument (by value)
     const float* invstd_msg;
     const float* gsum_in;            // grad_beta | grad_gamma of the input BatchNorm (after R2)   [2H]
     const float* gsum_msg;           // grad_beta | grad_gamma of the message BatchNorm (after R1) [2H]
+    float* packed;                   // [PACK_FLOATS] the Pk block
     float* x_msg;
     float* x_center;                 // [H] bf16 storage: x_msg holds bf16(x - x_center) (written by n3_center_kernel, read by everyone)
     float* d_out;
     float* msg;
     const float* grad_m_sum;
     float* grad_ya;
-    float* grad_lin;
     float* partial;
 };
 
-template <int H, int DIN>
-struct Wts {                         // LDS copy of the parameters of the stage
-    float w_in[H * DIN];
-    float b_in[H];
-    float w_e[H * H];
-    float w_et[H * H];               // transposed: the backward product reads contiguous rows too
-    float c[H];
-    float aff_in[3 * H];
-    float aff_msg[3 * H];
-    float istd_in[H];
-    float istd_msg[H];
-    float w_g[H];
-    float gs_in[2 * H];
-    float gs_msg[2 * H];
-    float ctr[H];
-    float b_g;
-};
-
-template <int H, int DIN>
-__device__ __forceinline__ void load_weights(Wts<H, DIN>& w, const EdgeK& p, int tid) {
-    for (int i = tid; i < H * DIN; i += TB) w.w_in[i] = p.W_in[(i / DIN) * p.ld_w_in + (i % DIN)];
-    for (int i = tid; i < H * H; i += TB) {
-        const float v = p.W_msg[(i / H) * p.ld_w_msg + 2 * H + (i % H)];
-        w.w_e[i] = v;
-        w.w_et[(i % H) * H + (i / H)] = v;
-    }
-    for (int i = tid; i < 3 * H; i += TB) {
-        w.aff_in[i] = p.aff_in[i];
-        w.aff_msg[i] = p.aff_msg[i];
-    }
-    for (int i = tid; i < 2 * H; i += TB) {
-        w.gs_in[i] = p.gsum_in ? p.gsum_in[i] : 0.f;
-        w.gs_msg[i] = p.gsum_msg ? p.gsum_msg[i] : 0.f;
+// P: the weights in the layouts of Pk, c = (W_s + W_d) emb + b_msg (every node carries the same embedding, net3d.py:61)
+__global__ void __launch_bounds__(256) n3_pack_kernel(EdgeK p, int H, int DIN) {
+    float* out = p.packed;
+    const int tid = threadIdx.x;
+    const int o_bin = DIN * H, o_wet = o_bin + H, o_we = o_wet + H * H, o_c = o_we + H * H, o_wg = o_c + H, o_bg = o_wg + H;
+    for (int i = tid; i < DIN * H; i += 256) out[i] = p.W_in[(i % H) * p.ld_w_in + (i / H)];
+    for (int i = tid; i < H * H; i += 256) {
+        const int k = i / H, o = i - k * H;
+        const float v = p.W_msg[(long)o * p.ld_w_msg + 2 * H + k];
+        out[o_wet + i] = v;
+        out[o_we + o * H + k] = v;
     }
     if (tid < H) {
-        w.b_in[tid] = p.b_in[tid];
-        w.istd_in[tid] = p.invstd_in[tid];
-        w.istd_msg[tid] = p.invstd_msg[tid];
-        w.w_g[tid] = p.w_gate[tid];
-        w.ctr[tid] = p.x_center != nullptr ? p.x_center[tid] : 0.f;
-        // c = (W_s + W_d) emb + b_msg: every node carries the same embedding (reference net3d.py:61)
+        out[o_bin + tid] = p.b_in[tid];
+        out[o_wg + tid] = p.w_gate[tid];
         float acc = p.b_msg[tid];
         const float* row = p.W_msg + (long)tid * p.ld_w_msg;
         for (int k = 0; k < H; ++k) acc = fmaf(row[k] + row[H + k], p.emb[k], acc);
-        w.c[tid] = acc;
+        out[o_c + tid] = acc;
     }
-    if (tid == 0) w.b_g = p.b_gate[0];
+    if (tid == 0) { out[o_bg] = p.b_gate[0]; out[o_bg + 1] = 0.f; }
+}
+
+// The parameter loads are wave-uniform, loop-invariant reads of constant memory: left alone the compiler hoists ALL of them
+// (~1500 SGPRs' worth) out of the per-edge loop and spills them to VGPR lanes (v_writelane / v_readlane by the thousand).
+// Passing the base pointer through an empty volatile asm once per edge makes its loads belong to that iteration: they are issued
+// as s_load_dwordx16 bursts next to their use and the scalar cache serves them.
+template <typename T>
+__device__ __forceinline__ T per_edge(T ptr) {
+    __asm__ volatile("" : "+s"(ptr));
+    return ptr;
+}
+// ... and tied to a value of the lane: the loads through the returned pointer cannot be issued before `dep` exists, so the
+// scheduler cannot gather the parameter loads of ALL stages of an edge at its top either (the fused backward pass reads ~1600
+// parameter words per edge: gathered, they spill again)
+template <typename T>
+__device__ __forceinline__ T after(T ptr, float dep) {
+    __asm__ volatile("" : "+s"(ptr) : "v"(dep));
+    return ptr;
+}
+// ... tied to EVERY accumulator pair of a product (tied to one, the scheduler runs that accumulator's chain through all rows
+// first and parks each row's weights in VGPR lanes for the other nine)
+template <int NP, typename T>
+__device__ __forceinline__ T after_all(T ptr, const f2* a) {
+    static_assert(NP == 10 || NP == 8, "hidden 20 or 16");
+    if constexpr (NP == 10)
+        __asm__ volatile("" : "+s"(ptr) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]));
+    else
+        __asm__ volatile("" : "+s"(ptr) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
+    return ptr;
+}
+__device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float comp(const f2* v, int c) { return (c & 1) ? v[c >> 1].y : v[c >> 1].x; }
+// sigmoid with the hardware's reciprocal and exponential (1 ulp each; x / (1 + e) as an IEEE division is ten instructions,
+// and a pass has up to sixty of them per edge)
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ f2 sigm2(f2 x) { return f2{sigm(x.x), sigm(x.y)}; }
+__device__ __forceinline__ f2 silu2(f2 x) { return x * sigm2(x); }
+__device__ __forceinline__ f2 silu_grad2(f2 x) {          // d/dx x sigmoid(x) = s (1 + x (1 - s))
+    const f2 s = sigm2(x);
+    return s * (1.f + x * (1.f - s));
 }
 
 // reference commons/utils.py:103-110: [sin(d / 2^k)]_k | [cos(d / 2^k)]_k | d.  ONE accurate sincos of the smallest angle
 // d / 2^(n-1), the others by angle doubling (sin 2t = 2 sin t cos t, cos 2t = 1 - 2 sin^2 t): each doubling at most doubles
-// the absolute error, 2^(n-1) ulp = 5e-7 at n = 4 - the four passes that need the features recompute them from the
-// distance, and eight range-reduced sinf / cosf per edge and pass were a third of their instruction count
+// the absolute error, 2^(n-1) ulp = 5e-7 at n = 4 - the passes that need the features recompute them from the distance
 template <int NENC>
 __device__ __forceinline__ void fourier(float x, float* f) {
     if constexpr (NENC == 0) {
@@ -158,60 +197,86 @@ __device__ __forceinline__ void fourier(float x, float* f) {
     }
 }
 
-// a = W_in f + b_in, xa = act(a)
+// The products walk the weights row by row (H / 2 SGPR pairs per row).  Loads of constant memory carry no memory dependence:
+// instruction selection floats all 25 s_load_dwordx16 of a product (400 SGPRs) in front of its first FMA and the register
+// allocator spills them to VGPR lanes (a scheduling barrier does not hold them: they are placed before it exists).  So row k's
+// pointer is tied (`after_all`) to the accumulators as row k - 1 left them: a row of weights is loaded, used by its H / 2
+// packed FMAs and dead; the other waves of the SIMD cover the scalar cache's latency.
+
+// a = W_in f + b_in   (per output: b + sum over k in k order)
 template <int H, int DIN>
-__device__ __forceinline__ void lin_in(const Wts<H, DIN>& w, const float* f, int act, float* a, float* xa) {
+__device__ __forceinline__ void lin_in(cfp P, const float* f, f2* a) {
+    const cf2p b = (cf2p)(P + Pk<H, DIN>::B_IN);
 #pragma unroll
-    for (int o = 0; o < H; ++o) {
-        N3_NO_HOIST();
-        float acc = w.b_in[o];
+    for (int o = 0; o < H / 2; ++o) a[o] = b[o];
 #pragma unroll
-        for (int k = 0; k < DIN; ++k) acc = fmaf(w.w_in[o * DIN + k], f[k], acc);
-        a[o] = acc;
-        xa[o] = apply_act(acc, act);
+    for (int k = 0; k < DIN; ++k) {
+        const cf2p wt = (cf2p)(after_all<H / 2>(P, a) + Pk<H, DIN>::W_IN_T + k * H);
+        const f2 fk = splat(f[k]);
+#pragma unroll
+        for (int o = 0; o < H / 2; ++o) a[o] = fma2(wt[o], fk, a[o]);
     }
 }
 
+// y = (x - mean) * (gamma invstd) + beta,  aff = mean | gamma invstd | beta
 template <int H>
-__device__ __forceinline__ void bn_apply(const float* aff, const float* x, float* y) {
+__device__ __forceinline__ void bn_apply(cfp aff, const f2* x, f2* y) {
+    const cf2p mu = (cf2p)aff, sc = (cf2p)(aff + H), sh = (cf2p)(aff + 2 * H);
 #pragma unroll
-    for (int c = 0; c < H; ++c) y[c] = (x[c] - aff[c]) * aff[H + c] + aff[2 * H + c];
+    for (int o = 0; o < H / 2; ++o) y[o] = (x[o] - mu[o]) * sc[o] + sh[o];
 }
 
 // lin = c + W_e e0
 template <int H, int DIN>
-__device__ __forceinline__ void lin_msg(const Wts<H, DIN>& w, const float* e0, float* lin) {
+__device__ __forceinline__ void lin_msg(cfp P, const f2* e0, f2* lin) {
+    const cf2p c = (cf2p)(P + Pk<H, DIN>::C);
+#pragma unroll
+    for (int o = 0; o < H / 2; ++o) lin[o] = c[o];
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        const cf2p wt = (cf2p)(after_all<H / 2>(P, lin) + Pk<H, DIN>::W_E_T + k * H);
+        const f2 ek = splat(comp(e0, k));
+#pragma unroll
+        for (int o = 0; o < H / 2; ++o) lin[o] = fma2(wt[o], ek, lin[o]);
+    }
+}
+
+// ge = W_e^T glin
+template <int H, int DIN>
+__device__ __forceinline__ void lin_msg_t(cfp P, const f2* glin, f2* ge) {
+#pragma unroll
+    for (int k = 0; k < H / 2; ++k) ge[k] = splat(0.f);
 #pragma unroll
     for (int o = 0; o < H; ++o) {
-        N3_NO_HOIST();
-        float acc = w.c[o];
+        const cf2p w = (cf2p)(after_all<H / 2>(P, ge) + Pk<H, DIN>::W_E + o * H);
+        const f2 go = splat(comp(glin, o));
 #pragma unroll
-        for (int k = 0; k < H; ++k) acc = fmaf(w.w_e[o * H + k], e0[k], acc);
-        lin[o] = acc;
+        for (int k = 0; k < H / 2; ++k) ge[k] = fma2(w[k], go, ge[k]);
     }
 }
 
 template <int H>
-__device__ __forceinline__ void load_row(const float* p, float* v) {
+__device__ __forceinline__ void load_row(const float* p, f2* v) {
 #pragma unroll
     for (int c = 0; c < H; c += 4) {
         const float4 t = *reinterpret_cast<const float4*>(p + c);
-        v[c] = t.x; v[c + 1] = t.y; v[c + 2] = t.z; v[c + 3] = t.w;
+        v[c / 2] = f2{t.x, t.y};
+        v[c / 2 + 1] = f2{t.z, t.w};
     }
 }
 
 template <int H>
-__device__ __forceinline__ void store_row(float* p, const float* v) {
+__device__ __forceinline__ void store_row(float* p, const f2* v) {
 #pragma unroll
-    for (int c = 0; c < H; c += 4) *reinterpret_cast<float4*>(p + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+    for (int c = 0; c < H; c += 4) *reinterpret_cast<float4*>(p + c) = make_float4(v[c / 2].x, v[c / 2].y, v[c / 2 + 1].x, v[c / 2 + 1].y);
 }
 
 // The [E, H] ACTIVATIONS that only this stage reads and writes - x_msg (saved) and msg - in the storage type of
-// the launch: fp32, or (bf16 matmul mode, EdgeK.store16) bf16 - half the bytes of the passes that are bound by them (at the
-// QMugs shape an [E3, 20] fp32 tensor is 313 MB and the stage moves eleven of them per step).  Row `row` of a buffer that was
-// sized for fp32; values are rounded (RNE) once, where they are stored; statistics are taken before the rounding.
+// the launch: fp32, or (bf16 matmul mode, I3dNet3dEdgeArgs.store_bf16) bf16 - half the bytes of the passes that are bound by
+// them (at the QMugs shape an [E3, 20] fp32 tensor is 313 MB).  Row `row` of a buffer that was sized for fp32; values are
+// rounded (RNE) once, where they are stored; statistics are taken before the rounding.  ctr: the centre x_msg is stored about.
 template <int H, bool B16>
-__device__ __forceinline__ void load_srow(const float* base, long row, float* v, const float* ctr = nullptr) {
+__device__ __forceinline__ void load_srow(const float* base, long row, f2* v, cfp ctr = nullptr) {
     if constexpr (!B16) {
         load_row<H>(base + row * H, v);
     } else {
@@ -219,12 +284,13 @@ __device__ __forceinline__ void load_srow(const float* base, long row, float* v,
 #pragma unroll
         for (int c = 0; c < H; c += 4) {
             const uint2 t = q[c / 4];
-            v[c] = __uint_as_float(t.x << 16); v[c + 1] = __uint_as_float(t.x & 0xffff0000u);
-            v[c + 2] = __uint_as_float(t.y << 16); v[c + 3] = __uint_as_float(t.y & 0xffff0000u);
+            v[c / 2] = f2{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u)};
+            v[c / 2 + 1] = f2{__uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
         }
         if (ctr != nullptr) {
+            const cf2p c2 = (cf2p)ctr;
 #pragma unroll
-            for (int c = 0; c < H; ++c) v[c] += ctr[c];
+            for (int o = 0; o < H / 2; ++o) v[o] += c2[o];
         }
     }
 }
@@ -235,38 +301,40 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {      // bits of bf16(x),
 }
 
 template <int H, bool B16>
-__device__ __forceinline__ void store_srow(float* base, long row, const float* v, const float* ctr = nullptr) {
+__device__ __forceinline__ void store_srow(float* base, long row, const f2* v, cfp ctr = nullptr) {
     if constexpr (!B16) {
         store_row<H>(base + row * H, v);
     } else {
         uint2* q = reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + row * H);
-        float d[H];
+        f2 d[H / 2];
+        const cf2p c2 = (cf2p)ctr;
 #pragma unroll
-        for (int c = 0; c < H; ++c) d[c] = ctr != nullptr ? v[c] - ctr[c] : v[c];
+        for (int o = 0; o < H / 2; ++o) d[o] = ctr != nullptr ? v[o] - c2[o] : v[o];
 #pragma unroll
         for (int c = 0; c < H; c += 4)
-            q[c / 4] = make_uint2(bf16_rne(d[c]) | (bf16_rne(d[c + 1]) << 16), bf16_rne(d[c + 2]) | (bf16_rne(d[c + 3]) << 16));
+            q[c / 4] = make_uint2(bf16_rne(d[c / 2].x) | (bf16_rne(d[c / 2].y) << 16),
+                                  bf16_rne(d[c / 2 + 1].x) | (bf16_rne(d[c / 2 + 1].y) << 16));
     }
 }
 
-// column sums over the block: on return red[w * NC + c] holds wave w's sum of column c (4 waves)
-template <int NC>
-__device__ __forceinline__ void block_sum_cols(float* v, float* red, int tid) {
+// column sums over the block: on return red[w * 2 NP + c] holds wave w's sum of column c of `v` (NP pairs = 2 NP columns; 4 waves)
+template <int NP>
+__device__ __forceinline__ void block_sum_pairs(f2* v, float* red, int tid) {
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        float x = v[c];
+    for (int c = 0; c < NP; ++c) {
+        float x = v[c].x, y = v[c].y;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
-        v[c] = x;
+        for (int off = 32; off >= 1; off >>= 1) { x += __shfl_xor(x, off); y += __shfl_xor(y, off); }
+        v[c] = f2{x, y};
     }
     if ((tid & 63) == 0) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) red[(tid >> 6) * NC + c] = v[c];
+        for (int c = 0; c < NP; ++c) { red[(tid >> 6) * 2 * NP + 2 * c] = v[c].x; red[(tid >> 6) * 2 * NP + 2 * c + 1] = v[c].y; }
     }
-    __syncthreads();
 }
 
 // ---- statistics of a tile from sums about a pivot (a sample of the tile: no cancellation whatever mean / std of the column)
+// red: wave w's sums at red[w 2H + c] (shifted sum of column c) and red[w 2H + H + c] (shifted sum of squares)
 template <int H>
 __device__ __forceinline__ void write_tile_partial(float* partial, int tile, const float* red, const float* pivot, float n,
                                                    int tid) {
@@ -280,51 +348,82 @@ __device__ __forceinline__ void write_tile_partial(float* partial, int tile, con
     }
 }
 
+// shifted sums of one row: s[0..H/2) += x - pv,  s[H/2..H) += (x - pv)^2
+template <int H>
+__device__ __forceinline__ void stat_row(const f2* x, const f2* pv, f2* s) {
+#pragma unroll
+    for (int o = 0; o < H / 2; ++o) {
+        const f2 t = x[o] - pv[o];
+        s[o] += t;
+        s[H / 2 + o] = fma2(t, t, s[H / 2 + o]);
+    }
+}
+
+// the pivot of a tile: the row of the tile's first edge (thread 0), broadcast through LDS
+template <int H>
+__device__ __forceinline__ void share_pivot(float* pivot, const f2* row, f2* pv, int tid) {
+    if (tid == 0) {
+#pragma unroll
+        for (int o = 0; o < H / 2; ++o) { pivot[2 * o] = row[o].x; pivot[2 * o + 1] = row[o].y; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < H / 2; ++o) pv[o] = f2{pivot[2 * o], pivot[2 * o + 1]};
+}
+
 // F1: statistics of xa = act(W_in f + b_in)
 template <int H, int NENC, bool B16>
 __global__ void __launch_bounds__(TB) N3_OCC n3_stats_in_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
-    __shared__ Wts<H, DIN> w;
     __shared__ float pivot[H];
     __shared__ float red[4 * 2 * H];
+    const cfp P = (cfp)p.packed;
     const int tid = threadIdx.x;
-    load_weights(w, p, tid);
-    __syncthreads();
     const long j0 = (long)blockIdx.x * p.rows_per_block;
     const long jend = min(j0 + p.rows_per_block, (long)p.E);
-    float f[DIN], a[H], xa[H], s[2 * H];
+    f2 xa[H / 2], s[H], pv[H / 2];
 #pragma unroll
-    for (int c = 0; c < 2 * H; ++c) s[c] = 0.f;
+    for (int c = 0; c < H; ++c) s[c] = splat(0.f);
+#pragma unroll
+    for (int c = 0; c < H / 2; ++c) xa[c] = splat(0.f);
+    auto edge = [&](float d) {
+        float f[DIN];
+        f2 a[H / 2];
+        fourier<NENC>(d, f);
+        lin_in<H, DIN>(after(P, f[0]), f, a);
+#pragma unroll
+        for (int o = 0; o < H / 2; ++o) xa[o] = silu2(a[o]);
+    };
     long j = j0 + tid;
     const bool first = j < jend;
-    if (first) {
-        fourier<NENC>(p.d_raw[p.perm[j]], f);
-        lin_in<H, DIN>(w, f, ACT, a, xa);
-    }
-    if (tid == 0) {
-#pragma unroll
-        for (int c = 0; c < H; ++c) pivot[c] = xa[c];
-    }
-    __syncthreads();
-    float pv[H];
-#pragma unroll
-    for (int c = 0; c < H; ++c) pv[c] = pivot[c];
-    if (first) {
-#pragma unroll
-        for (int c = 0; c < H; ++c) { const float t = xa[c] - pv[c]; s[c] += t; s[H + c] = fmaf(t, t, s[H + c]); }
-    }
+    float dn = (j + TB < jend) ? p.d_raw[p.perm[j + TB]] : 0.f;       // the next edge's distance is in flight during this one's arithmetic
+    if (first) edge(p.d_raw[p.perm[j]]);
+    share_pivot<H>(pivot, xa, pv, tid);
+    if (first) stat_row<H>(xa, pv, s);
     for (j += TB; j < jend; j += TB) {
-        N3_NO_HOIST();
-        fourier<NENC>(p.d_raw[p.perm[j]], f);
-        lin_in<H, DIN>(w, f, ACT, a, xa);
-#pragma unroll
-        for (int c = 0; c < H; ++c) { const float t = xa[c] - pv[c]; s[c] += t; s[H + c] = fmaf(t, t, s[H + c]); }
+        const float d = dn;
+        dn = (j + TB < jend) ? p.d_raw[p.perm[j + TB]] : 0.f;
+        edge(d);
+        stat_row<H>(xa, pv, s);
     }
-    block_sum_cols<2 * H>(s, red, tid);
+    block_sum_pairs<H>(s, red, tid);
+    __syncthreads();
     write_tile_partial<H>(p.partial, blockIdx.x, red, pivot, (float)(jend - j0), tid);
 }
 
-// F2: e0 -> d_out (edge-id order), x_msg = act(c + W_e e0) (stored, destination-sorted) and its statistics
+// e0 = act( BN_in( act( W_in f + b_in ) ) ) of one distance; xa / ya (the BatchNorm's input / output) for the callers that differentiate
+template <int H, int NENC>
+__device__ __forceinline__ void edge_input(cfp P, cfp aff_in, float d, float* f, f2* a, f2* xa, f2* ya, f2* e0) {
+    constexpr int DIN = Dims<H, NENC>::DIN;
+    fourier<NENC>(d, f);
+    lin_in<H, DIN>(after(P, f[0]), f, a);
+#pragma unroll
+    for (int o = 0; o < H / 2; ++o) xa[o] = silu2(a[o]);
+    bn_apply<H>(after(aff_in, xa[0].x), xa, ya);
+#pragma unroll
+    for (int o = 0; o < H / 2; ++o) e0[o] = silu2(ya[o]);
+}
+
 // bf16 storage: the centre x_msg is stored about - the column means of the message block's activation over the first TB edges.
 // A pre-BatchNorm activation must not be rounded as it is: its columns can be nearly constant over the batch (every edge
 // feature is a function of ONE scalar distance), the BatchNorm behind then divides a 2^-9 |x| rounding error by a standard
@@ -333,171 +432,165 @@ __global__ void __launch_bounds__(TB) N3_OCC n3_stats_in_kernel(EdgeK p) {
 template <int H, int NENC, bool B16>
 __global__ void __launch_bounds__(TB) N3_OCC n3_center_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
-    __shared__ Wts<H, DIN> w;
     __shared__ float red[4 * H];
+    const cfp P = (cfp)p.packed;
     const int tid = threadIdx.x;
-    load_weights(w, p, tid);
-    __syncthreads();
-    float f[DIN], a[H], xa[H], e0[H], xm[H];
+    f2 xm[H / 2];
     const int n = p.E < TB ? p.E : TB;
     if (tid < n) {
-        N3_NO_HOIST();
-        fourier<NENC>(p.d_raw[p.perm[tid]], f);
-        lin_in<H, DIN>(w, f, ACT, a, xa);
-        bn_apply<H>(w.aff_in, xa, e0);
+        float f[DIN];
+        f2 a[H / 2], xa[H / 2], ya[H / 2], e0[H / 2], lin[H / 2];
+        edge_input<H, NENC>(P, (cfp)p.aff_in, p.d_raw[p.perm[tid]], f, a, xa, ya, e0);
+        lin_msg<H, DIN>(after(P, e0[0].x), e0, lin);
 #pragma unroll
-        for (int c = 0; c < H; ++c) e0[c] = apply_act(e0[c], ACT);
-        lin_msg<H, DIN>(w, e0, xm);
-#pragma unroll
-        for (int c = 0; c < H; ++c) xm[c] = apply_act(xm[c], ACT);
+        for (int o = 0; o < H / 2; ++o) xm[o] = silu2(lin[o]);
     } else {
 #pragma unroll
-        for (int c = 0; c < H; ++c) xm[c] = 0.f;
+        for (int o = 0; o < H / 2; ++o) xm[o] = splat(0.f);
     }
-    block_sum_cols<H>(xm, red, tid);
+    block_sum_pairs<H / 2>(xm, red, tid);
+    __syncthreads();
     if (tid < H) p.x_center[tid] = (((red[tid] + red[H + tid]) + red[2 * H + tid]) + red[3 * H + tid]) / (float)n;
 }
 
+// F2: e0 -> d_out (edge-id order), x_msg = act(c + W_e e0) (stored, destination-sorted) and its statistics
 template <int H, int NENC, bool B16>
 __global__ void __launch_bounds__(TB) N3_OCC n3_msg_pre_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
-    __shared__ Wts<H, DIN> w;
     __shared__ float pivot[H];
     __shared__ float red[4 * 2 * H];
+    const cfp P = (cfp)p.packed;
+    const cfp ctr = B16 ? (cfp)p.x_center : nullptr;
     const int tid = threadIdx.x;
-    load_weights(w, p, tid);
-    __syncthreads();
     const long j0 = (long)blockIdx.x * p.rows_per_block;
     const long jend = min(j0 + p.rows_per_block, (long)p.E);
-    float f[DIN], a[H], xa[H], e0[H], xm[H], s[2 * H];
+    f2 xm[H / 2], s[H], pv[H / 2];
 #pragma unroll
-    for (int c = 0; c < 2 * H; ++c) s[c] = 0.f;
-    auto edge = [&](long jj) {
-        N3_NO_HOIST();
-        const int eid = p.perm[jj];
-        fourier<NENC>(p.d_raw[eid], f);
-        lin_in<H, DIN>(w, f, ACT, a, xa);
-        bn_apply<H>(w.aff_in, xa, e0);
+    for (int c = 0; c < H; ++c) s[c] = splat(0.f);
 #pragma unroll
-        for (int c = 0; c < H; ++c) e0[c] = apply_act(e0[c], ACT);
+    for (int c = 0; c < H / 2; ++c) xm[c] = splat(0.f);
+    auto edge = [&](long jj, int eid, float d) {
+        float f[DIN];
+        f2 a[H / 2], xa[H / 2], ya[H / 2], e0[H / 2], lin[H / 2];
+        edge_input<H, NENC>(P, (cfp)p.aff_in, d, f, a, xa, ya, e0);
         store_row<H>(p.d_out + (long)eid * H, e0);
-        lin_msg<H, DIN>(w, e0, xm);
+        lin_msg<H, DIN>(after(P, e0[0].x), e0, lin);
 #pragma unroll
-        for (int c = 0; c < H; ++c) xm[c] = apply_act(xm[c], ACT);
-        store_srow<H, B16>(p.x_msg, jj, xm, w.ctr);
+        for (int o = 0; o < H / 2; ++o) xm[o] = silu2(lin[o]);
+        store_srow<H, B16>(p.x_msg, jj, xm, B16 ? after(ctr, xm[0].x) : nullptr);
     };
     long j = j0 + tid;
     const bool first = j < jend;
-    if (first) edge(j);
-    if (tid == 0) {
-#pragma unroll
-        for (int c = 0; c < H; ++c) pivot[c] = xm[c];
-    }
-    __syncthreads();
-    float pv[H];
-#pragma unroll
-    for (int c = 0; c < H; ++c) pv[c] = pivot[c];
+    int en = 0;
+    float dn = 0.f;
+    if (j + TB < jend) { en = p.perm[j + TB]; dn = p.d_raw[en]; }
     if (first) {
-#pragma unroll
-        for (int c = 0; c < H; ++c) { const float t = xm[c] - pv[c]; s[c] += t; s[H + c] = fmaf(t, t, s[H + c]); }
+        const int eid = p.perm[j];
+        edge(j, eid, p.d_raw[eid]);
     }
+    share_pivot<H>(pivot, xm, pv, tid);
+    if (first) stat_row<H>(xm, pv, s);
     for (j += TB; j < jend; j += TB) {
-        edge(j);
-#pragma unroll
-        for (int c = 0; c < H; ++c) { const float t = xm[c] - pv[c]; s[c] += t; s[H + c] = fmaf(t, t, s[H + c]); }
+        const int eid = en;
+        const float d = dn;
+        if (j + TB < jend) { en = p.perm[j + TB]; dn = p.d_raw[en]; }
+        edge(j, eid, d);
+        stat_row<H>(xm, pv, s);
     }
-    block_sum_cols<2 * H>(s, red, tid);
+    block_sum_pairs<H>(s, red, tid);
+    __syncthreads();
     write_tile_partial<H>(p.partial, blockIdx.x, red, pivot, (float)(jend - j0), tid);
 }
 
-// the gate: w = sigmoid(w_g . m + b_g) (same expression as edge.hip soft_edge_fwd_kernel)
+// the gate: w = sigmoid(w_g . m + b_g)
 template <int H, int DIN>
-__device__ __forceinline__ float gate_of(const Wts<H, DIN>& w, const float* m) {
-    float dot = w.b_g;
+__device__ __forceinline__ float gate_of(cfp P, const f2* m) {
+    const cf2p wg = (cf2p)(P + Pk<H, DIN>::W_G);
+    f2 acc = f2{P[Pk<H, DIN>::B_G], 0.f};
 #pragma unroll
-    for (int c = 0; c < H; ++c) dot += m[c] * w.w_g[c];
-    return 1.f / (1.f + expf(-dot));
+    for (int o = 0; o < H / 2; ++o) acc = fma2(m[o], wg[o], acc);
+    return sigm(acc.x + acc.y);
 }
 
 // F3: msg = m * gate, m = BN_msg(x_msg)
 template <int H, int NENC, bool B16>
 __global__ void __launch_bounds__(TB) N3_OCC n3_gate_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
-    __shared__ Wts<H, DIN> w;
-    const int tid = threadIdx.x;
-    load_weights(w, p, tid);
-    __syncthreads();
-    const long j = (long)blockIdx.x * TB + tid;
+    const cfp P = (cfp)p.packed;
+    const long j = (long)blockIdx.x * TB + threadIdx.x;
     if (j >= p.E) return;
-    float xm[H], m[H];
-    load_srow<H, B16>(p.x_msg, j, xm, w.ctr);
-    bn_apply<H>(w.aff_msg, xm, m);
-    const float g = gate_of<H, DIN>(w, m);
+    f2 xm[H / 2], m[H / 2];
+    load_srow<H, B16>(p.x_msg, j, xm, B16 ? (cfp)p.x_center : nullptr);
+    bn_apply<H>((cfp)p.aff_msg, xm, m);
+    const float g = gate_of<H, DIN>(P, m);
 #pragma unroll
-    for (int c = 0; c < H; ++c) m[c] *= g;
+    for (int o = 0; o < H / 2; ++o) m[o] *= g;
     store_srow<H, B16>(p.msg, j, m);
 }
 
 // gradient reaching m of edge j:  gm = gmsg * g + gg * w_g,  gg = (gmsg . m) g (1 - g),  gmsg = grad_m_sum[dst] (/ deg)
 template <int H, int DIN>
-__device__ __forceinline__ void grad_m(const Wts<H, DIN>& w, const EdgeK& p, long j, const float* m, float* gm, float& gg) {
+__device__ __forceinline__ void grad_m(cfp P, const EdgeK& p, long j, const f2* m, f2* gm, float& gg) {
     const int v = p.dst_s[j];
     float sc = 1.f;
     if (p.reduce_mean) sc = 1.f / (float)(p.in_ptr[v + 1] - p.in_ptr[v]);
-    float gmsg[H];
+    f2 gmsg[H / 2];
     load_row<H>(p.grad_m_sum + (long)v * H, gmsg);
-    const float g = gate_of<H, DIN>(w, m);
-    float dot = 0.f;
+    const float g = gate_of<H, DIN>(P, m);
+    f2 dot = splat(0.f);
 #pragma unroll
-    for (int c = 0; c < H; ++c) { gmsg[c] *= sc; dot += gmsg[c] * m[c]; }
-    gg = dot * g * (1.f - g);
+    for (int o = 0; o < H / 2; ++o) { gmsg[o] *= sc; dot = fma2(gmsg[o], m[o], dot); }
+    gg = (dot.x + dot.y) * g * (1.f - g);
+    const cf2p wg = (cf2p)(P + Pk<H, DIN>::W_G);
 #pragma unroll
-    for (int c = 0; c < H; ++c) gm[c] = gmsg[c] * g + gg * w.w_g[c];
+    for (int o = 0; o < H / 2; ++o) gm[o] = gmsg[o] * g + gg * wg[o];
 }
 
 // B1: partial[block] = sum gm | sum gm xhat_m | sum gg m | sum gg
 template <int H, int NENC, bool B16>
 __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_sums_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
-    constexpr int NC = 3 * H + 1;
-    __shared__ Wts<H, DIN> w;
-    __shared__ float red[4 * NC];
+    constexpr int NC = 3 * H + 1, NPR = 3 * H / 2 + 1;      // columns; pairs (the last pair: sum gg | 0)
+    __shared__ float red[4 * 2 * NPR];
+    const cfp P = (cfp)p.packed;
+    const cfp ctr = B16 ? (cfp)p.x_center : nullptr;
     const int tid = threadIdx.x;
-    load_weights(w, p, tid);
-    __syncthreads();
     const long j0 = (long)blockIdx.x * p.rows_per_block;
     const long jend = min(j0 + p.rows_per_block, (long)p.E);
-    float s[NC];
+    f2 s[NPR];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) s[c] = 0.f;
+    for (int c = 0; c < NPR; ++c) s[c] = splat(0.f);
     for (long j = j0 + tid; j < jend; j += TB) {
-        N3_NO_HOIST();
-        float xm[H], m[H], gm[H], gg;
-        load_srow<H, B16>(p.x_msg, j, xm, w.ctr);
-        bn_apply<H>(w.aff_msg, xm, m);
-        grad_m<H, DIN>(w, p, j, m, gm, gg);
+        f2 xm[H / 2], m[H / 2], gm[H / 2];
+        float gg;
+        load_srow<H, B16>(p.x_msg, j, xm, B16 ? per_edge(ctr) : nullptr);
+        const cfp aff = after((cfp)p.aff_msg, xm[0].x);
+        bn_apply<H>(aff, xm, m);
+        grad_m<H, DIN>(after(P, m[0].x), p, j, m, gm, gg);
+        const cf2p mu = (cf2p)after(aff, gm[0].x), istd = (cf2p)after((cfp)p.invstd_msg, gm[0].x);
 #pragma unroll
-        for (int c = 0; c < H; ++c) {
-            const float xh = (xm[c] - w.aff_msg[c]) * w.istd_msg[c];
-            s[c] += gm[c];
-            s[H + c] = fmaf(gm[c], xh, s[H + c]);
-            s[2 * H + c] = fmaf(gg, m[c], s[2 * H + c]);
+        for (int o = 0; o < H / 2; ++o) {
+            const f2 xh = (xm[o] - mu[o]) * istd[o];
+            s[o] += gm[o];
+            s[H / 2 + o] = fma2(gm[o], xh, s[H / 2 + o]);
+            s[H + o] = fma2(splat(gg), m[o], s[H + o]);
         }
-        s[3 * H] += gg;
+        s[3 * H / 2].x += gg;
     }
-    block_sum_cols<NC>(s, red, tid);
-    if (tid < NC) p.partial[(long)blockIdx.x * NC + tid] = red[tid] + red[NC + tid] + red[2 * NC + tid] + red[3 * NC + tid];
+    block_sum_pairs<NPR>(s, red, tid);
+    __syncthreads();
+    if (tid < NC) p.partial[(long)blockIdx.x * NC + tid] = red[tid] + red[2 * NPR + tid] + red[4 * NPR + tid] + red[6 * NPR + tid];
 }
 
 // D[i][j] += sum over the wave's 64 edges of A[edge][i] * B[edge][j]: v_mfma_f32_32x32x2_f32, the edge pair (2 s, 2 s + 1)
 // is the K dimension of step s.  tile_a / tile_b: this wave's [64][odd(NA)] / [64][odd(NB)] tiles; the lanes of the
-// padding columns (>= NA / NB) feed zeros.
+// padding columns (>= NA / NB) feed zeros.  a: NA values as pairs; b: NB values as floats.
 template <int NA, int NB>
-__device__ __forceinline__ void outer_accumulate(float* tile_a, float* tile_b, const float* a, const float* b, bool valid, int lane,
+__device__ __forceinline__ void outer_accumulate(float* tile_a, float* tile_b, const f2* a, const float* b, bool valid, int lane,
                                                  f32x16& acc) {
     constexpr int LDA = odd(NA), LDB = odd(NB);
 #pragma unroll
-    for (int c = 0; c < NA; ++c) tile_a[lane * LDA + c] = valid ? a[c] : 0.f;
+    for (int c = 0; c < NA; ++c) tile_a[lane * LDA + c] = valid ? comp(a, c) : 0.f;
 #pragma unroll
     for (int c = 0; c < NB; ++c) tile_b[lane * LDB + c] = valid ? b[c] : 0.f;
     __syncthreads();
@@ -534,17 +627,22 @@ __device__ __forceinline__ void write_outer(const f32x16& acc, float* scratch, f
     }
 }
 
-// B2a: gradient through the message block: glin (stored), partial[block] = [H][H + 1] (dW_e | dc)
-template <int H, int NENC, bool B16>
-__global__ void __launch_bounds__(TB) N3_OCC n3_bwd_msg_kernel(EdgeK p) {
+// B2: gradient through the message block and on through W_e^T and the post activation of the edge-input block:
+//     glin = BN_msg'(gm) act'(lin)            (registers only)
+//     partial[block][H][H + 1] = sum glin (x) [e0 | 1]         (dW_e | dc, MFMA)
+//     gya  = (W_e^T glin) act'(ya)            (stored)
+//     partial[block][H (H + 1) ...] = sum gya [H] | sum gya xhat_a [H]
+// e0, ya, xa are recomputed from the distance (a few hundred instructions against a gathered [E, H] read of d_out).
+template <int H, int NENC, bool B16, int OCC>
+__global__ void __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(OCC))) n3_bwd_msg_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
     constexpr int NB = H + 1, NP = H * NB + 2 * H;
-    __shared__ Wts<H, DIN> w;
     __shared__ float tiles[tile_floats<H, NB>()];      // also the accumulator exchange (4 * 1024 floats) at the end
+    __shared__ float red[4 * 2 * H];
+    const cfp P = (cfp)p.packed;
+    const cfp ctr = B16 ? (cfp)p.x_center : nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    load_weights(w, p, tid);
     const float inv_rows = p.inv_rows_dev != nullptr ? p.inv_rows_dev[0] : p.inv_rows;
-    __syncthreads();
     float* tile_a = tiles + wv * 64 * (odd(H) + odd(NB));
     float* tile_b = tile_a + 64 * odd(H);
     const long j0 = (long)blockIdx.x * p.rows_per_block;
@@ -552,71 +650,63 @@ __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_msg_kernel(EdgeK p) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    f2 s[H];
+#pragma unroll
+    for (int c = 0; c < H; ++c) s[c] = splat(0.f);
+    float dn = (j0 + tid < jend) ? p.d_raw[p.perm[j0 + tid]] : 0.f;
     for (long base = j0; base < jend; base += TB) {
-        N3_NO_HOIST();
         const long j = base + tid;
         const bool valid = j < jend;
-        float glin[H], e0x[NB];
+        const float d = dn;
+        dn = (j + TB < jend) ? p.d_raw[p.perm[j + TB]] : 0.f;
+        f2 glin[H / 2];
+        float e0x[NB];
 #pragma unroll
-        for (int c = 0; c < H; ++c) { glin[c] = 0.f; e0x[c] = 0.f; }
+        for (int c = 0; c < H / 2; ++c) glin[c] = splat(0.f);
+#pragma unroll
+        for (int c = 0; c < H; ++c) e0x[c] = 0.f;
         e0x[H] = 1.f;
         if (valid) {
-            float xm[H], m[H], gm[H], gg, lin[H];
-            load_srow<H, B16>(p.x_msg, j, xm, w.ctr);
-            load_row<H>(p.d_out + (long)p.perm[j] * H, e0x);
-            bn_apply<H>(w.aff_msg, xm, m);
-            grad_m<H, DIN>(w, p, j, m, gm, gg);
-            lin_msg<H, DIN>(w, e0x, lin);
+            float f[DIN];
+            f2 a[H / 2], xa[H / 2], ya[H / 2], e0[H / 2];
+            edge_input<H, NENC>(P, (cfp)p.aff_in, d, f, a, xa, ya, e0);
+            f2 lin[H / 2];
+            lin_msg<H, DIN>(after(P, e0[0].x), e0, lin);
 #pragma unroll
-            for (int c = 0; c < H; ++c) {
-                const float xh = (xm[c] - w.aff_msg[c]) * w.istd_msg[c];
-                const float gx = w.aff_msg[H + c] * (gm[c] - w.gs_msg[c] * inv_rows - xh * (w.gs_msg[H + c] * inv_rows));
-                glin[c] = gx * act_grad(lin[c], ACT);
+            for (int c = 0; c < H; ++c) e0x[c] = comp(e0, c);
+            {
+                f2 xm[H / 2], m[H / 2], gm[H / 2];
+                float gg;
+                load_srow<H, B16>(p.x_msg, j, xm, B16 ? after(ctr, lin[0].x) : nullptr);
+                const cfp aff_m = after((cfp)p.aff_msg, xm[0].x);
+                bn_apply<H>(aff_m, xm, m);
+                grad_m<H, DIN>(after(P, m[0].x), p, j, m, gm, gg);
+                const cfp aff_m2 = after(aff_m, gm[0].x), gsm = after((cfp)p.gsum_msg, gm[0].x);
+                const cf2p mu_m = (cf2p)aff_m2, sc_m = (cf2p)(aff_m2 + H), istd_m = (cf2p)after((cfp)p.invstd_msg, gm[0].x);
+                const cf2p gs_m = (cf2p)gsm, gs_m2 = (cf2p)(gsm + H);
+#pragma unroll
+                for (int o = 0; o < H / 2; ++o) {
+                    const f2 xh = (xm[o] - mu_m[o]) * istd_m[o];
+                    const f2 gx = sc_m[o] * (gm[o] - gs_m[o] * inv_rows - xh * (gs_m2[o] * inv_rows));
+                    glin[o] = gx * silu_grad2(lin[o]);
+                }
             }
-            store_row<H>(p.grad_lin + j * H, glin);
+            f2 gya[H / 2];
+            lin_msg_t<H, DIN>(after(P, glin[0].x), glin, gya);
+            const cf2p mu_a = (cf2p)after((cfp)p.aff_in, gya[0].x), istd_a = (cf2p)after((cfp)p.invstd_in, gya[0].x);
+#pragma unroll
+            for (int o = 0; o < H / 2; ++o) {
+                gya[o] *= silu_grad2(ya[o]);
+                const f2 xh = (xa[o] - mu_a[o]) * istd_a[o];
+                s[o] += gya[o];
+                s[H / 2 + o] = fma2(gya[o], xh, s[H / 2 + o]);
+            }
+            store_row<H>(p.grad_ya + j * H, gya);
         }
         outer_accumulate<H, NB>(tile_a, tile_b, glin, e0x, valid, lane, acc);
     }
-    write_outer<H, NB>(acc, tiles, p.partial + (long)blockIdx.x * NP, tid);
-}
-
-// B2b: grad of e0 = W_e^T glin, through the post activation (needs ya = BN_in(xa), recomputed from the distance): gya
-// (stored), partial[block][H (H + 1) ...] = sum gya [H] | sum gya xhat_a [H]
-template <int H, int NENC, bool B16>
-__global__ void __launch_bounds__(TB) N3_OCC n3_bwd_post_kernel(EdgeK p) {
-    constexpr int DIN = Dims<H, NENC>::DIN;
-    constexpr int NB = H + 1, NP = H * NB + 2 * H;
-    __shared__ Wts<H, DIN> w;
-    __shared__ float red[4 * 2 * H];
-    const int tid = threadIdx.x;
-    load_weights(w, p, tid);
-    __syncthreads();
-    const long j0 = (long)blockIdx.x * p.rows_per_block;
-    const long jend = min(j0 + p.rows_per_block, (long)p.E);
-    float s[2 * H];
-#pragma unroll
-    for (int c = 0; c < 2 * H; ++c) s[c] = 0.f;
-    for (long j = j0 + tid; j < jend; j += TB) {
-        N3_NO_HOIST();
-        float f[DIN], a[H], xa[H], ya[H], glin[H], gya[H];
-        fourier<NENC>(p.d_raw[p.perm[j]], f);
-        lin_in<H, DIN>(w, f, ACT, a, xa);
-        bn_apply<H>(w.aff_in, xa, ya);
-        load_row<H>(p.grad_lin + j * H, glin);
-#pragma unroll
-        for (int k = 0; k < H; ++k) {
-            N3_NO_HOIST();
-            float ge = 0.f;
-#pragma unroll
-            for (int o = 0; o < H; ++o) ge = fmaf(w.w_et[k * H + o], glin[o], ge);
-            gya[k] = ge * act_grad(ya[k], ACT);
-            const float xh = (xa[k] - w.aff_in[k]) * w.istd_in[k];
-            s[k] += gya[k];
-            s[H + k] = fmaf(gya[k], xh, s[H + k]);
-        }
-        store_row<H>(p.grad_ya + j * H, gya);
-    }
-    block_sum_cols<2 * H>(s, red, tid);
+    block_sum_pairs<H>(s, red, tid);
+    write_outer<H, NB>(acc, tiles, p.partial + (long)blockIdx.x * NP, tid);      // (its barrier also publishes `red`)
     if (tid < 2 * H)
         p.partial[(long)blockIdx.x * NP + H * NB + tid] = red[tid] + red[2 * H + tid] + red[4 * H + tid] + red[6 * H + tid];
 }
@@ -626,12 +716,10 @@ template <int H, int NENC, bool B16>
 __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_in_kernel(EdgeK p) {
     constexpr int DIN = Dims<H, NENC>::DIN;
     constexpr int NB = DIN + 1, NP = H * NB;
-    __shared__ Wts<H, DIN> w;
     __shared__ float tiles[tile_floats<H, NB>()];
+    const cfp P = (cfp)p.packed;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    load_weights(w, p, tid);
     const float inv_rows = p.inv_rows_dev != nullptr ? p.inv_rows_dev[0] : p.inv_rows;
-    __syncthreads();
     float* tile_a = tiles + wv * 64 * (odd(H) + odd(NB));
     float* tile_b = tile_a + 64 * odd(H);
     const long j0 = (long)blockIdx.x * p.rows_per_block;
@@ -639,26 +727,33 @@ __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_in_kernel(EdgeK p) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float dn = (j0 + tid < jend) ? p.d_raw[p.perm[j0 + tid]] : 0.f;
     for (long base = j0; base < jend; base += TB) {
-        N3_NO_HOIST();
         const long j = base + tid;
         const bool valid = j < jend;
-        float ga[H], fx[NB];
+        const float d = dn;
+        dn = (j + TB < jend) ? p.d_raw[p.perm[j + TB]] : 0.f;
+        f2 ga[H / 2];
+        float fx[NB];
 #pragma unroll
-        for (int c = 0; c < H; ++c) ga[c] = 0.f;
+        for (int c = 0; c < H / 2; ++c) ga[c] = splat(0.f);
 #pragma unroll
         for (int c = 0; c < DIN; ++c) fx[c] = 0.f;
         fx[DIN] = 1.f;
         if (valid) {
-            float a[H], xa[H], gya[H];
-            fourier<NENC>(p.d_raw[p.perm[j]], fx);
-            lin_in<H, DIN>(w, fx, ACT, a, xa);
+            f2 a[H / 2], gya[H / 2];
             load_row<H>(p.grad_ya + j * H, gya);
+            fourier<NENC>(d, fx);
+            lin_in<H, DIN>(after(P, fx[0]), fx, a);
+            const cfp aff_a = after((cfp)p.aff_in, a[0].x), gsa = after((cfp)p.gsum_in, a[0].x);
+            const cf2p mu_a = (cf2p)aff_a, sc_a = (cf2p)(aff_a + H), istd_a = (cf2p)after((cfp)p.invstd_in, a[0].x);
+            const cf2p gs_a = (cf2p)gsa, gs_a2 = (cf2p)(gsa + H);
 #pragma unroll
-            for (int c = 0; c < H; ++c) {
-                const float xh = (xa[c] - w.aff_in[c]) * w.istd_in[c];
-                const float gx = w.aff_in[H + c] * (gya[c] - w.gs_in[c] * inv_rows - xh * (w.gs_in[H + c] * inv_rows));
-                ga[c] = gx * act_grad(a[c], ACT);
+            for (int o = 0; o < H / 2; ++o) {
+                const f2 xa = silu2(a[o]);
+                const f2 xh = (xa - mu_a[o]) * istd_a[o];
+                const f2 gx = sc_a[o] * (gya[o] - gs_a[o] * inv_rows - xh * (gs_a2[o] * inv_rows));
+                ga[o] = gx * silu_grad2(a[o]);
             }
         }
         outer_accumulate<H, NB>(tile_a, tile_b, ga, fx, valid, lane, acc);
@@ -666,37 +761,11 @@ __global__ void __launch_bounds__(TB) N3_OCC n3_bwd_in_kernel(EdgeK p) {
     write_outer<H, NB>(acc, tiles, p.partial + (long)blockIdx.x * NP, tid);
 }
 
-// ---- R kernels: one block adds the partial rows of the pass (block order) and writes the parameter gradients
-// tot[c] = sum over the rows of partial[row][c] (fixed order).  The block's threads form `groups` row groups (a power of
-// two) x `cw` columns; group g adds rows g, g + groups, ...; the groups are added in group order.  scratch: nthreads floats.
-__device__ __forceinline__ void reduce_rows(const float* partial, int n_rows, int n_cols, float* tot, float* scratch, int tid,
-                                            int nthreads) {
-    int cw = 32;
-    while (cw < n_cols && cw < nthreads) cw <<= 1;
-    const int groups = nthreads / cw;
-    const int c0 = tid % cw, grp = tid / cw;
-    for (int cb = 0; cb < n_cols; cb += cw) {
-        const int c = cb + c0;
-        float a0 = 0.f, a1 = 0.f;
-        if (c < n_cols) {
-            int r = grp;
-            for (; r + groups < n_rows; r += 2 * groups) {
-                a0 += partial[(long)r * n_cols + c];
-                a1 += partial[(long)(r + groups) * n_cols + c];
-            }
-            if (r < n_rows) a0 += partial[(long)r * n_cols + c];
-        }
-        scratch[tid] = a0 + a1;
-        __syncthreads();
-        if (grp == 0 && c < n_cols) {
-            float t = 0.f;
-            for (int q = 0; q < groups; ++q) t += scratch[q * cw + c0];
-            tot[c] = t;
-        }
-        __syncthreads();
-    }
-}
-
+// ---- R kernels: the partial rows of a pass (block order) -> the parameter gradients.  One workgroup per 32 columns: its 1024
+// threads form 32 row groups x 32 columns, group g adds rows g, g + 32, ... (two alternating accumulators, eight loads in
+// flight), the groups are added in group order: a fixed order whatever the grid.  Every column's owner writes what the column
+// means; the few outputs that need SEVERAL columns (d emb from all of dc) are formed by workgroup 0, which adds those columns
+// once more (the same order: the same bits).  Round 4's one-workgroup form needed 67 us for 0.9 MB at the QMugs shape.
 struct ReduceK {
     int H, DIN, n_rows, ld_w_in, ld_w_msg;
     const float* partial;
@@ -714,63 +783,105 @@ struct ReduceK {
     float* grad_b_in;
 };
 
-__global__ void __launch_bounds__(1024) n3_reduce_sums_kernel(ReduceK q) {      // R1
-    __shared__ float tot[3 * 32 + 1];
-    __shared__ float scratch[1024];
-    const int H = q.H, tid = threadIdx.x;
-    reduce_rows(q.partial, q.n_rows, 3 * H + 1, tot, scratch, tid, 1024);
-    if (tid < H) {
-        q.grad_beta[tid] = tot[tid];
-        q.grad_gamma[tid] = tot[H + tid];
-        q.gsum[tid] = tot[tid];
-        q.gsum[H + tid] = tot[H + tid];
-        q.grad_w_gate[tid] = tot[2 * H + tid];
-    }
-    if (tid == 0) q.grad_b_gate[0] = tot[3 * H];
-}
-
-__global__ void __launch_bounds__(1024) n3_reduce_msg_kernel(ReduceK q) {       // R2
-    __shared__ float tot[32 * 33 + 64];
-    __shared__ float scratch[1024];
-    const int H = q.H, NB = H + 1, tid = threadIdx.x;
-    reduce_rows(q.partial, q.n_rows, H * NB + 2 * H, tot, scratch, tid, 1024);
-    // message weights [H, 3H] = [W_s | W_d | W_e]: dW_s = dW_d = dc (x) emb, dW_e from the MFMA accumulators, db = dc
-    for (int t = tid; t < H * H; t += 1024) {
-        const int o = t / H, k = t - o * H;
-        const float gc = tot[o * NB + H];
-        const float ge = gc * q.emb[k];
-        float* row = q.grad_W_msg + (long)o * q.ld_w_msg;
-        row[k] = ge;
-        row[H + k] = ge;
-        row[2 * H + k] = tot[o * NB + k];
-    }
-    if (tid < H) {
-        q.grad_b_msg[tid] = tot[tid * NB + H];
-        // d emb += (W_s + W_d)^T dc
-        float acc = 0.f;
-        for (int o = 0; o < H; ++o) {
-            const float* row = q.W_msg + (long)o * q.ld_w_msg;
-            acc = fmaf(row[tid] + row[H + tid], tot[o * NB + H], acc);
+// sum over the rows of column `col` (col < 0: nothing) for the thread's row group -> the column total in tot[c0] (c0 = tid & 31)
+__device__ __forceinline__ void reduce_col(const float* partial, int n_rows, int n_cols, int col, float* scratch, float* tot, int tid) {
+    const int c0 = tid & 31, grp = tid >> 5;
+    float a0 = 0.f, a1 = 0.f;
+    if (col >= 0) {
+        const float* q = partial + col;
+        int r = grp;
+        for (; r + 15 * 32 < n_rows; r += 16 * 32) {      // sixteen rows in flight (a row is a page apart from the next)
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = q[(long)(r + u * 32) * n_cols];
+#pragma unroll
+            for (int u = 0; u < 16; u += 2) { a0 += v[u]; a1 += v[u + 1]; }
         }
-        q.grad_emb[tid] += acc;
-        const float gb = tot[H * NB + tid], gg = tot[H * NB + H + tid];
-        q.grad_beta[tid] = gb;
-        q.grad_gamma[tid] = gg;
-        q.gsum[tid] = gb;
-        q.gsum[H + tid] = gg;
+        for (; r + 32 < n_rows; r += 2 * 32) {
+            a0 += q[(long)r * n_cols];
+            a1 += q[(long)(r + 32) * n_cols];
+        }
+        if (r < n_rows) a0 += q[(long)r * n_cols];
+    }
+    scratch[tid] = a0 + a1;
+    __syncthreads();
+    if (grp == 0) {
+        float t = 0.f;
+        for (int g = 0; g < 32; ++g) t += scratch[g * 32 + c0];
+        tot[c0] = t;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(1024) n3_reduce_sums_kernel(ReduceK q) {      // R1: 3H + 1 columns
+    __shared__ float tot[32];
+    __shared__ float scratch[1024];
+    const int H = q.H, tid = threadIdx.x, n_cols = 3 * H + 1;
+    const int col = blockIdx.x * 32 + (tid & 31);
+    reduce_col(q.partial, q.n_rows, n_cols, col < n_cols ? col : -1, scratch, tot, tid);
+    if (tid < 32 && col < n_cols) {
+        const float t = tot[tid];
+        if (col < H) { q.grad_beta[col] = t; q.gsum[col] = t; }
+        else if (col < 2 * H) { q.grad_gamma[col - H] = t; q.gsum[col] = t; }
+        else if (col < 3 * H) q.grad_w_gate[col - 2 * H] = t;
+        else q.grad_b_gate[0] = t;
     }
 }
 
-__global__ void __launch_bounds__(1024) n3_reduce_in_kernel(ReduceK q) {        // R3
-    __shared__ float tot[32 * 33];
+__global__ void __launch_bounds__(1024) n3_reduce_msg_kernel(ReduceK q) {       // R2: H (H + 1) + 2H columns
+    __shared__ float tot[32];
     __shared__ float scratch[1024];
-    const int H = q.H, NB = q.DIN + 1, tid = threadIdx.x;
-    reduce_rows(q.partial, q.n_rows, H * NB, tot, scratch, tid, 1024);
-    for (int t = tid; t < H * q.DIN; t += 1024) {
-        const int o = t / q.DIN, k = t - o * q.DIN;
-        q.grad_W_in[(long)o * q.ld_w_in + k] = tot[o * NB + k];
+    const int H = q.H, NB = H + 1, tid = threadIdx.x, n_cols = H * NB + 2 * H;
+    const int col = blockIdx.x * 32 + (tid & 31);
+    reduce_col(q.partial, q.n_rows, n_cols, col < n_cols ? col : -1, scratch, tot, tid);
+    // message weights [H, 3H] = [W_s | W_d | W_e]: dW_s = dW_d = dc (x) emb, dW_e from the MFMA accumulators, db = dc
+    if (tid < 32 && col < n_cols) {
+        const float t = tot[tid];
+        if (col < H * NB) {
+            const int o = col / NB, k = col - o * NB;
+            float* row = q.grad_W_msg + (long)o * q.ld_w_msg;
+            if (k < H) {
+                row[2 * H + k] = t;
+            } else {                          // dc[o]
+                q.grad_b_msg[o] = t;
+                for (int kk = 0; kk < H; ++kk) {
+                    const float ge = t * q.emb[kk];
+                    row[kk] = ge;
+                    row[H + kk] = ge;
+                }
+            }
+        } else {
+            const int c = col - H * NB;       // grad_beta [H] | grad_gamma [H] of the input BatchNorm
+            q.gsum[c] = t;
+            if (c < H) q.grad_beta[c] = t; else q.grad_gamma[c - H] = t;
+        }
     }
-    if (tid < H) q.grad_b_in[tid] = tot[tid * NB + q.DIN];
+    if (blockIdx.x == 0) {                    // d emb += (W_s + W_d)^T dc: every dc, added once more in the same order
+        __syncthreads();
+        const int c0 = tid & 31;
+        reduce_col(q.partial, q.n_rows, n_cols, c0 < H ? c0 * NB + H : -1, scratch, tot, tid);
+        if (tid < H) {
+            float acc = 0.f;
+            for (int o = 0; o < H; ++o) {
+                const float* row = q.W_msg + (long)o * q.ld_w_msg;
+                acc = fmaf(row[tid] + row[H + tid], tot[o], acc);
+            }
+            q.grad_emb[tid] += acc;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(1024) n3_reduce_in_kernel(ReduceK q) {        // R3: H (DIN + 1) columns
+    __shared__ float tot[32];
+    __shared__ float scratch[1024];
+    const int H = q.H, NB = q.DIN + 1, tid = threadIdx.x, n_cols = H * NB;
+    const int col = blockIdx.x * 32 + (tid & 31);
+    reduce_col(q.partial, q.n_rows, n_cols, col < n_cols ? col : -1, scratch, tot, tid);
+    if (tid < 32 && col < n_cols) {
+        const int o = col / NB, k = col - o * NB;
+        if (k < q.DIN) q.grad_W_in[(long)o * q.ld_w_in + k] = tot[tid];
+        else q.grad_b_in[o] = tot[tid];
+    }
 }
 
 // ---- host side
@@ -785,7 +896,8 @@ Plan plan_for(long E) {
     const long per = (chunks + 1023) / 1024;              // <= 1024 statistics tiles
     pl.fwd_rows_per_tile = (int)(per * TB);
     pl.fwd_tiles = (int)((E + pl.fwd_rows_per_tile - 1) / pl.fwd_rows_per_tile);
-    const long perb = (chunks + MAX_BWD_BLOCKS - 1) / MAX_BWD_BLOCKS;
+    long perb = (chunks + MAX_BWD_BLOCKS - 1) / MAX_BWD_BLOCKS;
+    if (perb < 2 && chunks >= 512) perb = 2;             // (a block's fixed cost - accumulator exchange, partial row - over >= 512 edges)
     pl.bwd_rows_per_block = (int)(perb * TB);
     pl.bwd_blocks = (int)((E + pl.bwd_rows_per_block - 1) / pl.bwd_rows_per_block);
     return pl;
@@ -803,7 +915,7 @@ EdgeK kernel_args(const I3dNet3dEdgeArgs* a) {
     p.aff_in = a->aff_in; p.aff_msg = a->aff_msg; p.invstd_in = a->tail_in.invstd; p.invstd_msg = a->tail_msg.invstd;
     p.x_msg = a->x_msg; p.d_out = a->d_out; p.msg = a->msg;
     p.x_center = a->store_bf16 ? a->x_center : nullptr;
-    p.grad_m_sum = a->grad_m_sum; p.grad_ya = a->grad_ya; p.grad_lin = a->grad_lin;
+    p.grad_m_sum = a->grad_m_sum; p.grad_ya = a->grad_ya;
     return p;
 }
 
@@ -858,6 +970,19 @@ int sync_backward_sums(float* gsum, int n, long local_rows, float* inv_rows_dev,
         else if (a->hidden == 20 && a->n_enc == 0) hipLaunchKernelGGL((KERNEL<20, 0, B16V>), grid, block, 0, stream, __VA_ARGS__); \
         else hipLaunchKernelGGL((KERNEL<16, 2, B16V>), grid, block, 0, stream, __VA_ARGS__);                            \
     } while (0)
+#define N3_DISPATCH_O(KERNEL, O, grid, block, stream, ...)                                                              \
+    do {                                                                                                               \
+        if (a->hidden == 20 && a->n_enc == 4) {                                                                        \
+            if (a->store_bf16) hipLaunchKernelGGL((KERNEL<20, 4, true, O>), grid, block, 0, stream, __VA_ARGS__);      \
+            else hipLaunchKernelGGL((KERNEL<20, 4, false, O>), grid, block, 0, stream, __VA_ARGS__);                   \
+        } else if (a->hidden == 20 && a->n_enc == 0) {                                                                 \
+            if (a->store_bf16) hipLaunchKernelGGL((KERNEL<20, 0, true, O>), grid, block, 0, stream, __VA_ARGS__);      \
+            else hipLaunchKernelGGL((KERNEL<20, 0, false, O>), grid, block, 0, stream, __VA_ARGS__);                   \
+        } else {                                                                                                       \
+            if (a->store_bf16) hipLaunchKernelGGL((KERNEL<16, 2, true, O>), grid, block, 0, stream, __VA_ARGS__);      \
+            else hipLaunchKernelGGL((KERNEL<16, 2, false, O>), grid, block, 0, stream, __VA_ARGS__);                   \
+        }                                                                                                              \
+    } while (0)
 #define N3_DISPATCH(KERNEL, grid, block, stream, ...)                                                                  \
     do {                                                                                                               \
         if (a->store_bf16) N3_DISPATCH_T(KERNEL, true, grid, block, stream, __VA_ARGS__);                              \
@@ -871,9 +996,12 @@ using namespace i3d;
 
 extern "C" int i3d_net3d_edge_supported(int hidden, int n_enc) { return supported(hidden, n_enc) ? 1 : 0; }
 
+// forward scratch: [tiles][3 hidden] statistics partials | the packed parameter block
+static long stats_partial_floats(int num_edges, int hidden) { return ((long)plan_for(num_edges).fwd_tiles * 3 * hidden + 3) & ~3L; }
+
 extern "C" long i3d_net3d_edge_stats_floats(int num_edges, int hidden) {
     if (num_edges <= 0 || hidden <= 0) return 0;
-    return (long)plan_for(num_edges).fwd_tiles * 3 * hidden;
+    return stats_partial_floats(num_edges, hidden) + PACK_FLOATS;
 }
 
 extern "C" long i3d_net3d_edge_bwd_floats(int num_edges, int hidden, int n_enc) {
@@ -881,7 +1009,7 @@ extern "C" long i3d_net3d_edge_bwd_floats(int num_edges, int hidden, int n_enc) 
     const int din = n_enc > 0 ? 2 * n_enc + 1 : 1;
     const long per = (long)hidden * (hidden + 1) + 2 * hidden;          // the widest pass (B2); B1: 3H+1, B3: H (DIN+1)
     const long per3 = (long)hidden * (din + 1);
-    return (long)plan_for(num_edges).bwd_blocks * (per > per3 ? per : per3) + 4 * hidden + 4;      // ... | gsum [4H] | 1 / rows of all ranks
+    return (long)plan_for(num_edges).bwd_blocks * (per > per3 ? per : per3) + 4 * hidden + 4 + PACK_FLOATS;      // ... | gsum [4H] | 1 / rows of all ranks | packed parameters
 }
 
 extern "C" int i3d_net3d_edge_fwd(const I3dNet3dEdgeArgs* a, void* stream_) {
@@ -892,7 +1020,10 @@ extern "C" int i3d_net3d_edge_fwd(const I3dNet3dEdgeArgs* a, void* stream_) {
     EdgeK p = kernel_args(a);
     p.rows_per_block = pl.fwd_rows_per_tile;
     p.partial = a->stats;
+    p.packed = a->stats + stats_partial_floats(a->num_edges, a->hidden);
     const int H = a->hidden;
+    hipLaunchKernelGGL(n3_pack_kernel, dim3(1), dim3(256), 0, stream, p, H, a->n_enc > 0 ? 2 * a->n_enc + 1 : 1);
+    I3D_CHECK_LAUNCH();
     N3_DISPATCH(n3_stats_in_kernel, dim3(pl.fwd_tiles), dim3(TB), stream, p);
     I3D_CHECK_LAUNCH();
     const I3dBnTail& t1 = a->tail_in;
@@ -918,7 +1049,7 @@ extern "C" int i3d_net3d_edge_fwd(const I3dNet3dEdgeArgs* a, void* stream_) {
 
 extern "C" int i3d_net3d_edge_bwd(const I3dNet3dEdgeArgs* a, void* stream_) {
     if (int rc = check_common(a)) return rc;
-    I3D_CHECK_ARG(a->grad_m_sum && a->grad_ya && a->grad_lin && a->partial, "null backward buffer");
+    I3D_CHECK_ARG(a->grad_m_sum && a->grad_ya && a->partial, "null backward buffer");      // (grad_lin: no longer used)
     I3D_CHECK_ARG(a->grad_W_in && a->grad_b_in && a->grad_gamma_in && a->grad_beta_in && a->grad_W_msg && a->grad_b_msg &&
                       a->grad_gamma_msg && a->grad_beta_msg && a->grad_w_gate && a->grad_b_gate && a->grad_emb,
                   "null gradient buffer");
@@ -930,6 +1061,9 @@ extern "C" int i3d_net3d_edge_bwd(const I3dNet3dEdgeArgs* a, void* stream_) {
     EdgeK p = kernel_args(a);
     p.rows_per_block = pl.bwd_rows_per_block;
     p.partial = a->partial;
+    p.packed = gsum + 4 * H + 4;
+    hipLaunchKernelGGL(n3_pack_kernel, dim3(1), dim3(256), 0, stream, p, H, DIN);
+    I3D_CHECK_LAUNCH();
     ReduceK q{};
     q.H = H; q.DIN = DIN; q.n_rows = pl.bwd_blocks; q.ld_w_in = a->ld_w_in; q.ld_w_msg = a->ld_w_msg;
     q.partial = a->partial; q.emb = a->emb; q.W_msg = a->W_msg;
@@ -939,7 +1073,7 @@ extern "C" int i3d_net3d_edge_bwd(const I3dNet3dEdgeArgs* a, void* stream_) {
     N3_DISPATCH(n3_bwd_sums_kernel, dim3(pl.bwd_blocks), dim3(TB), stream, p);
     I3D_CHECK_LAUNCH();
     q.gsum = gsum; q.grad_gamma = a->grad_gamma_msg; q.grad_beta = a->grad_beta_msg;
-    hipLaunchKernelGGL(n3_reduce_sums_kernel, dim3(1), dim3(1024), 0, stream, q);
+    hipLaunchKernelGGL(n3_reduce_sums_kernel, dim3(cdiv(3 * H + 1, 32)), dim3(1024), 0, stream, q);
     I3D_CHECK_LAUNCH();
     const bool synced = collectives() != nullptr;
     float* inv_rows_dev = gsum + 4 * H;
@@ -949,12 +1083,13 @@ extern "C" int i3d_net3d_edge_bwd(const I3dNet3dEdgeArgs* a, void* stream_) {
         p.inv_rows_dev = inv_rows_dev;
     }
     p.gsum_msg = gsum;
-    N3_DISPATCH(n3_bwd_msg_kernel, dim3(pl.bwd_blocks), dim3(TB), stream, p);
-    I3D_CHECK_LAUNCH();
-    N3_DISPATCH(n3_bwd_post_kernel, dim3(pl.bwd_blocks), dim3(TB), stream, p);
+    // two register budgets of the fused pass (I3D_N3_B2_WAVES=2 | 3 per SIMD: 256 registers without spills / 168 with ~40 spilled)
+    static const int b2_waves = [] { const char* e = getenv("I3D_N3_B2_WAVES"); return e != nullptr && atoi(e) == 3 ? 3 : 2; }();
+    if (b2_waves == 3) N3_DISPATCH_O(n3_bwd_msg_kernel, 3, dim3(pl.bwd_blocks), dim3(TB), stream, p);
+    else N3_DISPATCH_O(n3_bwd_msg_kernel, 2, dim3(pl.bwd_blocks), dim3(TB), stream, p);
     I3D_CHECK_LAUNCH();
     q.gsum = gsum + 2 * H; q.grad_gamma = a->grad_gamma_in; q.grad_beta = a->grad_beta_in;
-    hipLaunchKernelGGL(n3_reduce_msg_kernel, dim3(1), dim3(1024), 0, stream, q);
+    hipLaunchKernelGGL(n3_reduce_msg_kernel, dim3(cdiv((int)per, 32)), dim3(1024), 0, stream, q);
     I3D_CHECK_LAUNCH();
     if (synced) {
         if (int rc = sync_backward_sums(gsum + 2 * H, 2 * H, a->num_edges, inv_rows_dev, stream_)) return rc;
@@ -962,7 +1097,7 @@ extern "C" int i3d_net3d_edge_bwd(const I3dNet3dEdgeArgs* a, void* stream_) {
     p.gsum_in = gsum + 2 * H;
     N3_DISPATCH(n3_bwd_in_kernel, dim3(pl.bwd_blocks), dim3(TB), stream, p);
     I3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(n3_reduce_in_kernel, dim3(1), dim3(1024), 0, stream, q);
+    hipLaunchKernelGGL(n3_reduce_in_kernel, dim3(cdiv((int)per3, 32)), dim3(1024), 0, stream, q);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }

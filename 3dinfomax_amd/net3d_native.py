@@ -327,7 +327,7 @@ def _edge_stage_bwd(L, stream, ar, dev, a, gu, gh_l, emb, grads, ctx, N, E, H, w
     _chk(L.i3d_colsum(gh_l, None, N, H, gemb.data_ptr(), ws_h, stream), 'i3d_colsum')
     a.grad_emb = gemb.data_ptr()
     a.grad_m_sum = gu
-    a.grad_ya, a.grad_lin = ar.take(E * H), ar.take(E * H)
+    a.grad_ya, a.grad_lin = ar.take(E * H), None        # (grad_lin: the fused backward pass keeps it in registers)
     a.partial = ar.take(int(L.i3d_net3d_edge_bwd_floats(E, H, a.n_enc)))
     _chk(L.i3d_net3d_edge_bwd(ctypes.byref(a), stream), 'i3d_net3d_edge_bwd')
 
@@ -346,7 +346,7 @@ def _bwd_floats(tr, N, E, H, L):
         total += sum(fc(r) for r in lay['upd'] + lay['msg'])
         if 'fused' in lay:
             a = lay['fused']
-            total += _al(N * H) + 2 * _al(E * H) + _al(int(L.i3d_net3d_edge_bwd_floats(E, H, a.n_enc)))
+            total += _al(N * H) + _al(E * H) + _al(int(L.i3d_net3d_edge_bwd_floats(E, H, a.n_enc)))
             continue
         Fo = lay['edge'].fout
         total += 2 * _al(N * H) + 3 * _al(E * H) + _al(E) + _al(E * Fo) + _al(N * 2 * Fo)

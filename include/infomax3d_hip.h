@@ -782,7 +782,7 @@ typedef struct {
     float* m_sum;        /* [N, hidden] out */
     const float* grad_m_sum; /* [N, hidden] */
     float* grad_ya;      /* scratch [E, hidden] (backward) */
-    float* grad_lin;     /* scratch [E, hidden] (backward) */
+    float* grad_lin;     /* unused since round 5 (the gradient of the message block's pre-activation stays in registers); may be null */
     float* partial;      /* scratch, i3d_net3d_edge_bwd_floats(E, hidden, n_enc) floats (backward) */
     float* grad_W_in;
     float* grad_b_in;
