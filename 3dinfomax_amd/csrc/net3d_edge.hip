@@ -589,11 +589,16 @@ template <int NA, int NB>
 __device__ __forceinline__ void outer_accumulate(float* tile_a, float* tile_b, const f2* a, const float* b, bool valid, int lane,
                                                  f32x16& acc) {
     constexpr int LDA = odd(NA), LDB = odd(NB);
+    // The tiles are the WAVE's own: a wave's LDS operations execute in issue order, so its writes below are complete before its
+    // reads, and those before the next trip's writes - no workgroup barrier (round 2 had two per trip: four waves in lock step,
+    // nobody's VALU work under anybody's MFMAs).  The wave barriers only pin the order for the compiler.
 #pragma unroll
     for (int c = 0; c < NA; ++c) tile_a[lane * LDA + c] = valid ? comp(a, c) : 0.f;
 #pragma unroll
     for (int c = 0; c < NB; ++c) tile_b[lane * LDB + c] = valid ? b[c] : 0.f;
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int row = lane >> 5, col = lane & 31;
     const int ca = col < NA ? col : 0, cb = col < NB ? col : 0;
 #pragma unroll 8
@@ -604,7 +609,9 @@ __device__ __forceinline__ void outer_accumulate(float* tile_a, float* tile_b, c
         bv = col < NB ? bv : 0.f;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <int NA, int NB>
@@ -614,6 +621,7 @@ constexpr int tile_floats() { return 4 * 64 * (odd(NA) + odd(NB)) > 4096 ? 4 * 6
 template <int NA, int NB>
 __device__ __forceinline__ void write_outer(const f32x16& acc, float* scratch, float* out, int tid) {
     const int lane = tid & 63, wv = tid >> 6;
+    __syncthreads();          // every wave is done with its operand tiles (the scratch overlays them)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
