@@ -199,7 +199,14 @@ def enable_native_sync(group, device, provider=None, timeout_s=0.0):
     group is still "peer": IPC works between processes that share a GPU).  With "rccl" / "callbacks" ONE stream issues the
     collectives (the 3D network joins the 2D network's stream) and the early gradient all-reduce is off (two communicators
     must not be in flight at once, GradReducer.overlap).  Idempotent for the same group and provider; returns False when it
-    cannot be set up (the per-block path then synchronises)."""
+    cannot be set up (the per-block path then synchronises).
+
+    Threading constraint: the 3D network's context is bound to the side stream of THE THREAD THAT CALLS THIS FUNCTION
+    (streams.side_stream is per thread).  The training loop - forward passes included - must run on that thread: a forward
+    pass on another thread issues the 3D network's collectives on a stream without a context of its own, the default context
+    then serves two streams and its slot reuse (which relies on ONE stream's order) is no longer protected; the symptom is an
+    exchange time-out, not a silent wrong sum (the tags still have to match).  `multithreaded_seeds`-style runs (one training per
+    thread) are single-process, without data parallelism, and never come here."""
     global _native_sync
     import ctypes
     from . import _lib, streams
@@ -216,7 +223,9 @@ def enable_native_sync(group, device, provider=None, timeout_s=0.0):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     device = torch.device(device)
     scratch = torch.zeros(1 << 20, dtype=torch.uint8, device=device)
-    state = dict(group=group, provider=provider, device=device, net3d_stream=streams.NET3D_STREAM, keep=[scratch], comm=None, peers=[])
+    import threading
+    state = dict(group=group, provider=provider, device=device, net3d_stream=streams.NET3D_STREAM, keep=[scratch], comm=None, peers=[],
+                 thread=threading.get_ident())
     if provider == 'peer':
         torch.cuda.synchronize(device)
         main = _peer_context(L, group, device, timeout_s)
@@ -237,6 +246,7 @@ def enable_native_sync(group, device, provider=None, timeout_s=0.0):
                                             side_scratch.numel()) == 0
         if _all_ok(ok, group):
             _native_sync = state
+            streams.BOUND_THREAD = state['thread'] if side is not None else None
             return True
         # some rank could not set the exchange up (no IPC between these devices, no uncached memory...): every rank tears it
         # down and takes the next provider - the decision is collective, the ranks never run different providers
@@ -333,6 +343,7 @@ def disable_native_sync():
     if st['comm'] is not None:
         L.i3d_rccl_destroy(st['comm'])
     streams.NET3D_STREAM = st['net3d_stream']
+    streams.BOUND_THREAD = None
 
 
 def setup(modules, loss=None, group=None, sync_bn=False, broadcast=True):

@@ -604,7 +604,9 @@ class FCLayer(nn.Module):
         if h is not None:
             lp, bp = h[5], h[6]      # the sub-modules' parameter dicts: a re-assigned Parameter object invalidates the entry
             if lp['weight'] is h[0] and lp['bias'] is h[1] and (bp is None or (bp['weight'] is h[2] and bp['bias'] is h[3])):
-                return h
+                dm = h[7]            # the nn.Dropout module (or None): `layer.dropout.p = ...` in place must take effect too
+                if dm is None or (float(dm.p) if self.training else 0.0) == h[4].dropout:
+                    return h
         bn, gamma, beta, bp = None, None, None, None
         if self.batch_norm is not None:
             m = self.batch_norm
@@ -613,7 +615,8 @@ class FCLayer(nn.Module):
             gamma, beta, bp = m.weight, m.bias, m._parameters
         lin = self.linear
         drop = float(self.dropout.p) if (self.dropout is not None and self.training) else 0.0
-        h = cache[post_act] = (lin.weight, lin.bias, gamma, beta, FCSpec(self.activation, bn, post_act, drop), lin._parameters, bp)
+        h = cache[post_act] = (lin.weight, lin.bias, gamma, beta, FCSpec(self.activation, bn, post_act, drop), lin._parameters, bp,
+                               self.dropout)
         return h
 
     def _drop_hot(self):

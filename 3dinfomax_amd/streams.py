@@ -32,6 +32,10 @@ def _side(device):
     return s
 
 
+# thread the peer exchange's side-stream context belongs to (dist.enable_native_sync / disable_native_sync), or None
+BOUND_THREAD = None
+
+
 def side_stream(device):
     """this thread's side stream on `device` (created on first use): the stream the 3D network runs on beside the 2D network"""
     return _side(torch.device(device))
@@ -113,6 +117,11 @@ def side_stream_for(graph_event, device):
     """The side stream, already ordered after the step-start mark and the batch's own event - or None."""
     if not NET3D_STREAM or graph_event is None:
         return None
+    if BOUND_THREAD is not None and BOUND_THREAD != threading.get_ident():
+        # dist.enable_native_sync bound the peer exchange's second context to the side stream of ANOTHER thread: this thread's
+        # side stream has no context (its collectives would share the default one with the 2D network's stream)
+        raise RuntimeError('3dinfomax_amd: synchronised BatchNorm (peer exchange) was set up on another thread; run the '
+                           'training loop on the thread that called dist.setup / enable_native_sync')
     main = torch.cuda.current_stream(device)
     if getattr(_tls, 'step_valid', None) != (device.index, main.cuda_stream, _generation[0]):
         return None

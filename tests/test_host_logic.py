@@ -3,6 +3,8 @@ import copy
 import importlib
 import pickle
 
+import pytest
+
 import torch
 
 amd = importlib.import_module('3dinfomax_amd')
@@ -122,3 +124,17 @@ def test_metrics_cache_requires_the_very_tensor_objects():
     r2 = weakref.ref(y)
     del y
     assert not M._same_object(r2, x)
+
+
+def test_fclayer_hot_cache_follows_an_in_place_change_of_the_dropout_probability():
+    """the cached FCSpec bakes in dropout.p; `layer.dropout.p = q` (no attribute re-assignment) must invalidate it"""
+    import importlib
+    layers = importlib.import_module('3dinfomax_amd.layers')
+    fc = layers.FCLayer(8, 8, activation='relu', dropout=0.3, batch_norm=True).train()
+    assert fc.spec().dropout == pytest.approx(0.3)
+    fc.dropout.p = 0.5
+    assert fc.spec().dropout == pytest.approx(0.5)
+    fc.eval()
+    assert fc.spec().dropout == 0.0
+    plain = layers.FCLayer(8, 8).train()
+    assert plain.spec().dropout == 0.0 and plain.hot() is plain.hot()      # (no dropout module: the entry is reused)

@@ -59,6 +59,13 @@ def main():
     wrap(mods['net3d_native'], 'backward', 'bwd:   Net3D native backward')
     wrap(mods['tape'], '_model_backward', 'bwd: model backward (tape, both models)')
     wrap(mods['losses'].NTXentFn, 'backward', 'bwd: NTXentFn.backward')
+    pn = importlib.import_module('3dinfomax_amd.pna_native')
+    wrap(pn.PNAModelFn, 'backward', 'bwd: PNAModelFn.backward (whole-model C sequencer + Python around it)')
+    wrap(pn.PNAModelFn, 'forward', 'fwd:  PNAModelFn.forward')
+    L = importlib.import_module('3dinfomax_amd._lib').load()
+    for nm in ('i3d_pna_model_fwd', 'i3d_pna_model_bwd_part', 'i3d_net3d_edge_fwd', 'i3d_net3d_edge_bwd', 'i3d_ntxent_loss_fwd', 'i3d_ntxent_loss_bwd', 'i3d_adam_step'):
+        if hasattr(L, nm):
+            wrap(L, nm, 'C call: ' + nm)
     wrap(mods['pna'].PNAGNN, 'forward', 'fwd:  PNAGNN.forward (embeddings + layers)')
     wrap(mods['layers'].MLP, 'forward', 'fwd:  MLP.forward (heads)')
 
