@@ -158,6 +158,58 @@ def _all_ok(ok, group):
     return all(flags)
 
 
+# I3D_PEER_SELFTEST=0: skip the pattern exchange at set-up (world > 1 only; ~100 small launches)
+PEER_SELFTEST = os.environ.get('I3D_PEER_SELFTEST', '1') != '0'
+
+
+def _peer_selftest(L, state, device, with_side):
+    """Pattern exchange through the installed peer provider (default context on the current stream, the 3D network's context on
+    its side stream): all-gathers and fp64 rank-order sums of values every rank can predict, payload sizes from one word to the
+    BatchNorm vectors' [3 x 200] and beyond, enough rounds to reuse every slot many times.  -> bool (this rank saw only correct
+    values and no time-out); the caller combines the ranks' verdicts."""
+    from . import streams
+    group = state['group']
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    todo = [torch.cuda.current_stream(device)] + ([streams.side_stream(device)] if with_side else [])
+    wrong = 0
+    try:
+        for stream in todo:
+            stream.synchronize()
+            with torch.cuda.stream(stream):
+                ptr = stream.cuda_stream
+                bad = torch.zeros((), dtype=torch.int64, device=device)      # (a counter per stream: nothing crosses streams unordered)
+                for rnd in range(48):
+                    count = (1, 7, 64, 600, 601, 1201, 4097)[rnd % 7]
+                    base = torch.arange(count, dtype=torch.float32, device=device)
+                    send = base * (rank + 1) + (rnd + 0.25)
+                    recv = torch.empty(world, count, dtype=torch.float32, device=device)
+                    if L.i3d_collectives_all_gather_f32(send.data_ptr(), recv.data_ptr(), count, ptr) != 0:
+                        return False
+                    want = torch.stack([base * (r + 1) + (rnd + 0.25) for r in range(world)])
+                    bad += (recv != want).sum()
+                    b64 = torch.arange(count, dtype=torch.float64, device=device)
+                    buf = b64 / (rank + 3) + rnd
+                    if L.i3d_collectives_all_reduce_f64(buf.data_ptr(), count, ptr) != 0:
+                        return False
+                    tot = torch.zeros(count, dtype=torch.float64, device=device)
+                    for r in range(world):          # rank order: the order the exchange adds in
+                        tot = tot + (b64 / (r + 3) + rnd)
+                    bad += (buf != tot).sum()
+                wrong += int(bad.item())
+        torch.cuda.synchronize(device)
+        ok = wrong == 0 and all(L.i3d_peer_status(c) == 0 for c in state['peers'])
+        if not ok and os.environ.get('I3D_DEBUG_SELFTEST'):
+            print(f'[rank {rank}] peer self-test: {wrong} wrong values, status {[L.i3d_peer_status(c) for c in state["peers"]]}', flush=True)
+    except Exception:      # noqa: BLE001 - a failing exchange must end in the fallback, not in a crash of one rank
+        if os.environ.get('I3D_DEBUG_SELFTEST'):
+            import traceback
+            traceback.print_exc()
+        ok = False
+    if os.environ.get('I3D_TEST_PEER_SELFTEST_FAIL') == str(rank):      # test hook: this rank "saw a wrong value"
+        ok = False
+    return ok
+
+
 def _peer_context(L, group, device, timeout_s):
     """One mailbox of this rank, exported, every rank's handle gathered through `group`, the peers' mailboxes mapped.  Returns the
     context or None - None on EVERY rank when any rank failed at any step (nothing stays allocated or mapped then)."""
@@ -244,6 +296,12 @@ def enable_native_sync(group, device, provider=None, timeout_s=0.0):
                 state['keep'].append(side_scratch)
                 ok = L.i3d_peer_bind_stream(side, ctypes.c_void_p(streams.side_stream(device).cuda_stream), side_scratch.data_ptr(),
                                             side_scratch.numel()) == 0
+        if _all_ok(ok, group) and world > 1 and PEER_SELFTEST:
+            # Before any BatchNorm depends on it: exchange known patterns through BOTH contexts and compare bit for bit.  The
+            # protocol rests on properties of the fabric nobody could test without a multi-GPU node (an 8-byte system-scope
+            # store arrives whole at a peer's uncached memory; mapped mailboxes of another device are pollable): if they do
+            # not hold here, some rank sees a wrong value or a time-out NOW, and every rank takes the next provider.
+            ok = _peer_selftest(L, state, device, side is not None)
         if _all_ok(ok, group):
             _native_sync = state
             streams.BOUND_THREAD = state['thread'] if side is not None else None
@@ -255,7 +313,7 @@ def enable_native_sync(group, device, provider=None, timeout_s=0.0):
             L.i3d_peer_close(ctx)
         state['peers'], state['keep'] = [], [scratch]
         import warnings
-        warnings.warn('3dinfomax_amd.dist: the peer-write exchange could not be set up on every rank '
+        warnings.warn('3dinfomax_amd.dist: the peer-write exchange could not be set up (or failed its pattern exchange) on every rank '
                       f'({L.i3d_last_error().decode() if L.i3d_last_error() else "no message"}); falling back to '
                       + ('host-staged callbacks' if _is_gloo(group) else 'the RCCL provider'))
         provider = state['provider'] = 'callbacks' if _is_gloo(group) else 'rccl'

@@ -48,11 +48,16 @@ def _batch(amd, mols):
 def _worker(rank, port, path, native_sync, WORLD=WORLD):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), I3D_NATIVE_SYNC_BN='1' if native_sync else '0',
                       I3D_SYNC_PROVIDER=native_sync or 'peer', I3D_PEER_TIMEOUT_S='20')
+    if native_sync == 'peer_selftest_fails_on_rank_0':      # the exchange is set up but ONE rank reads a wrong value in the pattern exchange
+        os.environ.update(I3D_SYNC_PROVIDER='peer', I3D_TEST_PEER_SELFTEST_FAIL='0')
+        import warnings
+        warnings.simplefilter('ignore')
+        native_sync = 'callbacks'
     if native_sync == 'peer_fails_on_rank_1':       # the exchange cannot be set up on ONE rank: every rank must take the fallback
         os.environ.update(I3D_SYNC_PROVIDER='peer', I3D_TEST_PEER_FAIL='1')
         import warnings
         warnings.simplefilter('ignore')
-        native_sync = 'callbacks' 
+        native_sync = 'callbacks'
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     dist.init_process_group('gloo', rank=rank, world_size=WORLD)
@@ -114,14 +119,17 @@ def _worker(rank, port, path, native_sync, WORLD=WORLD):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('native_sync,world', [('peer', 2), ('peer', 4), ('callbacks', 2), ('peer_fails_on_rank_1', 2), (False, 2)])
+@pytest.mark.parametrize('native_sync,world', [('peer', 2), ('peer', 4), ('callbacks', 2), ('peer_fails_on_rank_1', 2),
+                                               ('peer_selftest_fails_on_rank_0', 2), (False, 2)])
 def test_two_rank_sharded_step_equals_full_batch(tmp_path, native_sync, world):
     """BatchNorm synchronised inside the C sequencers (csrc/comm.hip) - the whole-model sequencer runs - through 'peer': the
     one-shot peer-write exchange (csrc/peer.hip: each process maps the other's mailbox through hipIpc - which works between
     processes that share a GPU - and the BatchNorm kernels exchange their vectors themselves; the 3D network keeps its side
     stream with a context of its own) or 'callbacks': host-staged through gloo; False: the per-block Python path of round 2.
     (RCCL refuses two ranks on one device: its provider has a world-1 test below.)  'peer_fails_on_rank_1': one rank cannot set
-    the exchange up - the decision to fall back is collective, both ranks end on the same provider.  ('peer', 4): four ranks
+    the exchange up - the decision to fall back is collective, both ranks end on the same provider; 'peer_selftest_fails_on_rank_0':
+    the exchange is up but one rank's pattern exchange at set-up (dist._peer_selftest: what would catch a fabric that does not
+    deliver the 8-byte words whole) reports a wrong value - same collective fallback.  ('peer', 4): four ranks
     on the one GPU - rank indexing of the exchange (a lane per rank on the reading side) beyond a pair."""
     assert torch.cuda.is_available()
     amd = importlib.import_module('3dinfomax_amd')
@@ -536,7 +544,8 @@ def test_peer_exchange_soak_across_the_wrap_of_the_32_bit_tag(tmp_path):
     mp.spawn(_soak_worker, args=(_free_port(), path, world, steps, seq0), nprocs=world, join=True)
     z = np.load(path)
     assert list(z['status']) == [0, 0] and bool(z['same'])
-    assert (z['first_seq'] == seq0).all() and (z['last_seq'] > (1 << 32)).all(), (z['first_seq'], z['last_seq'])
+    # (the pattern exchange at set-up has already used the first ~100 sequence numbers of both contexts)
+    assert (z['first_seq'] >= seq0).all() and (z['first_seq'] < seq0 + 1000).all() and (z['last_seq'] > (1 << 32)).all(), (z['first_seq'], z['last_seq'])
     pna, net = _models(amd)
     for tag, m in (('pna', pna), ('net', net)):
         m.load_state_dict({k: torch.from_numpy(z[f'w/{tag}/{k}']) for k in m.state_dict()})

@@ -15,6 +15,7 @@ import bench  # noqa: E402
 ACC = collections.defaultdict(float)
 CNT = collections.defaultdict(int)
 ON = [False]
+SERIES = []
 
 
 def wrap(obj, name, label):
@@ -35,18 +36,26 @@ def wrap(obj, name, label):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--workload', default='qm9', choices=['qm9', 'qmugs'])
+    ap.add_argument('--series', action='store_true', help='print the per-step host times of the big pieces')
     a = ap.parse_args()
     amd = importlib.import_module('3dinfomax_amd')
     mods = {n: importlib.import_module('3dinfomax_amd.' + n) for n in
             ('pna', 'net3d', 'losses', 'tape', 'layer_native', 'net3d_native', 'optim', 'layers', 'ops', 'streams')}
     dev = torch.device('cuda:0')
-    mols = amd.synth.make_dataset(512, seed=1000)
+    qmugs = a.workload == 'qmugs'
+    mols = amd.synth.make_dataset(500 if qmugs else 512, seed=1000, kind='qmugs' if qmugs else 'qm9')
     g2 = amd.batch([amd.bond_graph(m) for m in mols]).to(dev)
-    g3 = amd.batch([amd.complete_graph(m) for m in mols]).to(dev)
+    if qmugs:
+        import numpy as np
+        rng = np.random.default_rng(2000)
+        g3 = amd.batch([amd.complete_graph(m, c) for m in mols for c in amd.synth.conformers(m, rng, 3)]).to(dev)
+    else:
+        g3 = amd.batch([amd.complete_graph(m) for m in mols]).to(dev)
     torch.manual_seed(123)
-    pna = amd.PNA(avg_d=1.0, device=dev, **bench.PNA_KW).to(dev).train()
+    pna = amd.PNA(avg_d=1.0, device=dev, **dict(bench.PNA_KW, propagation_depth=7 if qmugs else 4)).to(dev).train()
     net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **bench.NET3D_KW).to(dev).train()
-    loss_fn = amd.NTXent(tau=0.1)
+    loss_fn = amd.NTXentMultiplePositives(tau=0.1) if qmugs else amd.NTXent(tau=0.1)
     named = list(pna.named_parameters()) + list(net.named_parameters())
     optim = amd.Adam([{'params': [p for k, p in named if 'batch_norm' in k], 'weight_decay': 0},
                       {'params': [p for k, p in named if 'batch_norm' not in k]}], lr=8e-5, fused=True)
@@ -84,6 +93,7 @@ def main():
             for k, v in (('STEP fwd+loss', t1 - t0), ('STEP backward', t2 - t1), ('STEP adam', t3 - t2), ('STEP zero_grad', t4 - t3)):
                 ACC[k] += v
                 CNT[k] += 1
+            SERIES.append((t1 - t0, t2 - t1, t3 - t2))
 
     for _ in range(30):
         step()
@@ -98,6 +108,10 @@ def main():
     print(f'{a.steps} steps: host enqueue {1e3 * host / a.steps:.3f} ms/step, with GPU drain {1e3 * total / a.steps:.3f} ms/step')
     for k in sorted(ACC):
         print(f'  {k:58s} {1e3 * ACC[k] / a.steps:7.3f} ms/step  ({CNT[k] / a.steps:.1f} calls)')
+    if a.series:
+        print('per step (ms): fwd+loss | backward | adam')
+        for f, b, o in SERIES[:60]:
+            print(f'  {1e3 * f:7.3f} {1e3 * b:7.3f} {1e3 * o:7.3f}')
 
 
 if __name__ == '__main__':
