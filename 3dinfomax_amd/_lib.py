@@ -142,6 +142,9 @@ _SIGNATURES = {
     'i3d_bn_eval_aff_multi': (c_int, [POINTER(BnEvalAff), c_int, _P]),
     'i3d_set_collectives': (c_int, [POINTER(Collectives)]),
     'i3d_collectives_world': (c_int, []),
+    'i3d_bn_bwd_sums': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'i3d_gemm_f32_bnbwd_supported': (c_int, [c_int]),
+    'i3d_gemm_f32_bnbwd': (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, c_long, _P, _P, c_int, _P, _P, c_int, c_long, _P, c_int, c_int, _P, _P, _P]),
     'i3d_collectives_all_gather_f32': (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
     'i3d_collectives_all_reduce_f64': (c_int, [c_void_p, c_long, c_void_p]),
     'i3d_rccl_available': (c_int, []),

@@ -1110,6 +1110,9 @@ static thread_local int g_x_bf16 = 0;
 static thread_local const EdgeSums* g_edge_sums = nullptr;
 // phase 2 of the synchronised backward finds its fp32 sum vectors + 1 / rows already in the workspace (peer exchange)
 static thread_local int g_sums_ready = 0;
+// the next bn_bwd_impl call of this thread stops in front of its data-gradient pass and reports the vectors that pass would read
+// (i3d_bn_bwd_sums: the data gradient is then formed by the GEMM that consumes it, gemm.hip FUSE & 4)
+static thread_local I3dBnBwdVectors* g_sums_only = nullptr;
 
 static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
                        int post_act, const float* mean, const float* invstd, const float* gamma,
@@ -1202,6 +1205,12 @@ static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, in
     b.sum_dy = sum_dy; b.sum_dy_xhat = sum_dy_xhat; b.grad_pre = grad_pre; b.ld_out = ld_out; b.feat = feat; b.act = act;
     b.post_act = post_act; b.eval_mode = 0; b.inv_n = 1.f / (float)total_rows; b.eps = 0.f;
     b.zero_out = nullptr; b.x_bf16 = g_x_bf16;
+    if (g_sums_only != nullptr) {
+        I3dBnBwdVectors* o = g_sums_only;
+        o->mean = mean; o->invstd = invstd; o->gamma = gamma; o->sum_dy = sum_dy; o->sum_dy_xhat = sum_dy_xhat;
+        o->inv_n_ptr = b.inv_n_ptr; o->inv_n = b.inv_n; o->act = act;
+        return I3D_OK;
+    }
     if (g_edge_sums != nullptr) {      // i3d_bn_bwd_edge_sums: the data gradient formed inside the segmented sums that consume it
         const EdgeSums es = *g_edge_sums;
         const long lanes = 2L * es.num_nodes * (feat / 4);
@@ -1319,6 +1328,17 @@ extern "C" int i3d_bn_bwd_strided(const float* grad_y, const float* x, const flo
     I3D_CHECK_ARG(ld_out >= feat && (feat % 4 != 0 || (ld_out % 4 == 0 && (((uintptr_t)grad_pre) & 15) == 0)), "bad output pitch");
     return bn_bwd_impl(grad_y, x, pre, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta, grad_pre,
                        grad_bias, nullptr, nullptr, rows, workspace, bias_partial, ld_out, stream);
+}
+
+extern "C" int i3d_bn_bwd_sums(const float* grad_y, const float* x, int rows, int feat, int act, int post_act, const float* mean,
+                               const float* invstd, const float* gamma, const float* beta, float* grad_gamma, float* grad_beta,
+                               void* workspace, I3dBnBwdVectors* out, void* stream) {
+    I3D_CHECK_ARG(out != nullptr && post_act == I3D_ACT_NONE && relu_class(act), "vectors out; no activation behind the BatchNorm; none / ReLU / LeakyReLU in front");
+    g_sums_only = out;
+    const int rc = bn_bwd_impl(grad_y, x, nullptr, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta,
+                               nullptr, nullptr, nullptr, nullptr, rows, workspace, nullptr, feat, stream);
+    g_sums_only = nullptr;
+    return rc;
 }
 
 extern "C" int i3d_bn_eval_bwd(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,

@@ -420,6 +420,32 @@ int i3d_bn_bwd_strided(const float* grad_y, const float* x, const float* pre, in
                        const float* mean, const float* invstd, const float* gamma, const float* beta, float* grad_gamma,
                        float* grad_beta, float* grad_pre, int ld_out, float* grad_bias, void* workspace, float* bias_partial,
                        void* stream);
+/* ---- BatchNorm backward folded into the data-gradient GEMM (round 5) ------------------------------------------------------
+ * replaces the second half of autograd's native_batch_norm_backward for the BatchNorm1d of FCLayer (reference
+ * models/base_layers.py:106-108) - the elementwise pass  dz = gamma invstd (dy - mean(dy) - xhat mean(dy xhat)) act'(x)  - as a
+ * pass of its own: i3d_bn_bwd_sums runs the reduction half (sums, grad_gamma / grad_beta, synchronised over the ranks when a
+ * collective table is set) and hands out the vectors; i3d_gemm_f32_bnbwd forms dz while it stages the A tiles of the product
+ * that consumes it (C (+)= dz op(B): trans_b 0 = B stored [K, N], the data gradient of a Linear) and stores it to DZ for the
+ * weight gradients.  Same expression and operation order as the pass it replaces: the same bits.  zero_out ([K] or NULL): the
+ * bias gradient of a Linear directly in front of a BatchNorm (no activation) is exactly zero. */
+typedef struct {
+    const float* mean;
+    const float* invstd;
+    const float* gamma;
+    const float* sum_dy;      /* [feat] column sums of dy (over all ranks under synchronised BatchNorm) */
+    const float* sum_dy_xhat; /* [feat] */
+    const float* inv_n_ptr;   /* 1 / rows on the device, or NULL: inv_n */
+    float inv_n;
+    int act;                  /* activation in front of the BatchNorm (I3D_ACT_NONE / RELU / LEAKY_RELU) */
+} I3dBnBwdVectors;
+int i3d_bn_bwd_sums(const float* grad_y, const float* x, int rows, int feat, int act, int post_act, const float* mean,
+                    const float* invstd, const float* gamma, const float* beta, float* grad_gamma, float* grad_beta,
+                    void* workspace, I3dBnBwdVectors* out, void* stream);
+int i3d_gemm_f32_bnbwd_supported(int K);
+int i3d_gemm_f32_bnbwd(int trans_b, int M, int N, int K, const float* dY, const float* X, int ld, long a_rows_total,
+                       const I3dBnBwdVectors* v, float* DZ, int lddz, float* zero_out, const float* B, int ldb,
+                       long b_group_stride, float* C, int ldc, int accumulate, const int* m_rows, const int* tile_group,
+                       void* stream);
 /* i3d_bn_bwd with the BatchNorm input x stored as bf16 (row r at (bf16*)x + r * feat) */
 int i3d_bn_bwd_x_bf16(const float* grad_y, const void* x, int rows, int feat, int act, int post_act, const float* mean,
                       const float* invstd, const float* gamma, const float* beta, float* grad_gamma, float* grad_beta, float* grad_pre,

@@ -981,7 +981,10 @@ def test_process_level_switches_give_the_same_bits():
                 # the whole PNA pass from one C call per direction (csrc/model.hip) vs. sequenced layer by layer from Python
                 'python_sequenced_model': {'I3D_NATIVE_MODEL': '0'},
                 'python_sequenced_fresh_grads': {'I3D_NATIVE_MODEL': '0', 'I3D_PERSISTENT_GRADS': '0'},
-                'autograd_param_grads': {'I3D_DIRECT_PARAM_GRADS': '0'}}
+                'autograd_param_grads': {'I3D_DIRECT_PARAM_GRADS': '0'},
+                # round 5 (opt-in, measured slower): the BatchNorm backward's data-gradient pass formed inside the product that
+                # consumes it - the same data gradients; a bias gradient behind an activation is summed in another order
+                'bn_backward_in_the_gemm_prologue': {'I3D_BNBWD_PROLOGUE': '1'}}
     variants = {k: v for k, v in variants.items() if v is not None}
     for name, env in variants.items():
         path = f'/tmp/i3d_switch_{name}.pt'
@@ -993,7 +996,10 @@ def test_process_level_switches_give_the_same_bits():
         if name == 'unfused_loss':
             continue      # another summation order (both against the oracle to 2e-5: test_gpu_ops.test_ntxent_fwd_bwd_vs_oracle)
         for a, b in zip(res[base], res[name]):
-            assert torch.equal(a, b), name
+            if name == 'bn_backward_in_the_gemm_prologue':
+                assert torch.allclose(a, b, rtol=1e-4, atol=2e-5), name      # (three Adam steps at lr 1e-3 behind re-ordered bias sums)
+            else:
+                assert torch.equal(a, b), name
 
 
 @pytest.mark.parametrize('cfg', ['yml', 'deep'])
