@@ -49,6 +49,9 @@ typedef const __attribute__((address_space(4))) float* cfp;
 typedef const __attribute__((address_space(4))) f2* cf2p;
 
 constexpr int TB = 256;
+#ifndef N3_LOOKBACK
+#define N3_LOOKBACK 1      // rows of weights a product may have in flight ahead of its FMAs (see `after_all`)
+#endif
 // The three activations of the stage (edge-input block, the outer one of net3d.py:81, message block) are SiLU in the
 // reference's configs (`activation: SiLU` is the constructor default and :81 is hard-coded): compiled in.
 constexpr int ACT = I3D_ACT_SILU;
@@ -232,9 +235,16 @@ __device__ __forceinline__ void lin_msg(cfp P, const f2* e0, f2* lin) {
     const cf2p c = (cf2p)(P + Pk<H, DIN>::C);
 #pragma unroll
     for (int o = 0; o < H / 2; ++o) lin[o] = c[o];
+    f2 prev[H / 2];                          // the accumulators as the row before last left them (N3_LOOKBACK 2)
+#pragma unroll
+    for (int o = 0; o < H / 2; ++o) prev[o] = lin[o];
 #pragma unroll
     for (int k = 0; k < H; ++k) {
-        const cf2p wt = (cf2p)(after_all<H / 2>(P, lin) + Pk<H, DIN>::W_E_T + k * H);
+        const cf2p wt = (cf2p)(after_all<H / 2>(P, N3_LOOKBACK == 2 ? prev : lin) + Pk<H, DIN>::W_E_T + k * H);
+        if (N3_LOOKBACK == 2) {
+#pragma unroll
+            for (int o = 0; o < H / 2; ++o) prev[o] = lin[o];
+        }
         const f2 ek = splat(comp(e0, k));
 #pragma unroll
         for (int o = 0; o < H / 2; ++o) lin[o] = fma2(wt[o], ek, lin[o]);
@@ -246,9 +256,16 @@ template <int H, int DIN>
 __device__ __forceinline__ void lin_msg_t(cfp P, const f2* glin, f2* ge) {
 #pragma unroll
     for (int k = 0; k < H / 2; ++k) ge[k] = splat(0.f);
+    f2 prev[H / 2];
+#pragma unroll
+    for (int k = 0; k < H / 2; ++k) prev[k] = glin[k];
 #pragma unroll
     for (int o = 0; o < H; ++o) {
-        const cf2p w = (cf2p)(after_all<H / 2>(P, ge) + Pk<H, DIN>::W_E + o * H);
+        const cf2p w = (cf2p)(after_all<H / 2>(P, N3_LOOKBACK == 2 ? prev : (o == 0 ? glin : ge)) + Pk<H, DIN>::W_E + o * H);
+        if (N3_LOOKBACK == 2) {
+#pragma unroll
+            for (int k = 0; k < H / 2; ++k) prev[k] = o == 0 ? glin[k] : ge[k];
+        }
         const f2 go = splat(comp(glin, o));
 #pragma unroll
         for (int k = 0; k < H / 2; ++k) ge[k] = fma2(w[k], go, ge[k]);
