@@ -696,6 +696,38 @@ def main():
                          '20 launches per event pair after the timed region; reference_shaped_12F: the [N,12F] kernel of '
                          'SURVEY.md 8(d) (I3D_GROUPED_POSTTRANS=0 path); traffic: rocprofv3 PMC bytes per launch of the step\'s own kernels (traffic_source; rows matched by kernel base name + leading template arguments and by this workload\'s launch grids, tools/pmc_lookup.py), traffic_backward_kernel: the same for pna_aggregate_bwd_kernel<4,2,...>')
 
+    # configs[3] shape: the 3D network's edge stage is the part of that step whose tensors leave the Infinity Cache ([E3, 20] fp32 =
+    # 313 MB each).  Forward + backward of the 3D network ALONE, back to back (nothing else on the device), against the bytes its
+    # passes move by construction (csrc/net3d_edge.hip: F2 writes d_out and x_msg, F3 reads x_msg and writes msg, the segmented
+    # mean reads msg, B1 and B2 read x_msg, B2 writes grad_ya, B3 reads it: eight [E3, H] passes in the stage's storage type, d_out
+    # always fp32; + distances and indices); per-kernel times and PMC bytes: profiles/r05_n3_trace_*.txt, r05_net3d_edge_pmc_qmugs*.txt
+    if qmugs and rank == 0 and roof is not None and not use_dist:
+        g3 = batches[0][1]
+        E3, H3 = int(g3.number_of_edges()), NET3D_KW['hidden_dim']
+        cot = torch.randn(B * 3, NET3D_KW['target_dim'], device=dev) * 0.01
+
+        def n3_step():
+            net(g3.local_copy()).backward(cot)
+            for p in net.parameters():
+                p.grad = None
+        for _ in range(3):
+            n3_step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            n3_step()
+        e1.record()
+        torch.cuda.synchronize()
+        n3_ms = e0.elapsed_time(e1) / 10
+        store = 2 if args.dtype == 'bf16' else 4            # x_msg / msg in the bf16 mode (by size)
+        n3_bytes = E3 * H3 * (4 + 8 + store * 6) + E3 * 8 * 4      # d_out written (fp32), grad_ya written + read (fp32), six passes in the storage type; distances + indices of four passes
+        roof['net3d_edge_stage'] = dict(ms_forward_backward_alone=round(n3_ms, 3), complete_graph_edges=E3,
+                                        algorithmic_bytes=int(n3_bytes), achieved=round(n3_bytes / (n3_ms * 1e-3) / 1e9, 1),
+                                        frac=round(n3_bytes / (n3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), unit='GB/s',
+                                        note='whole 3D network (edge stage + node blocks + head), forward + backward, stand-alone; the edge '
+                                             'stage is instruction-bound in its fused backward pass (B2) and HBM-bound elsewhere: per-kernel '
+                                             'figures in DESIGN.md section 4')
     # per-collective times of the data-parallel step (20 back-to-back calls per event pair, after the timed region)
     collectives = None
     if use_dist:
