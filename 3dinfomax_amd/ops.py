@@ -611,7 +611,9 @@ def edge_combine_act_stats(P, Q, bias, src_s, dst_s, act=None, q_code=None):
 def gemm_fused(A, W, bias=None, a_aff=None, act=None, want_stats=True, out=None, accumulate=False, m_rows=None,
                tile_group=None):
     """out = act(A' W^T + bias (+ out)), A' = (A - mean) * scale + shift per column when a_aff [3, K] is given;
-    -> (out, partial [tiles, 3, N] or None, tiles).  W: [N, K], or [G, N, K] with m_rows / tile_group (grouped)."""
+    -> (out, partial [tiles, 3, N] or None, tiles).  W: [N, K], or [G, N, K] with m_rows / tile_group (grouped).
+    act: None, 'relu' or 'leakyrelu' only (since round 4 the fused epilogue carries the ReLU class; SiLU / Sigmoid / Tanh ... run as a
+    pass of their own behind a plain product - the C entry point refuses their codes)."""
     _chk(A)
     K = A.shape[1]
     if m_rows is not None:
