@@ -76,7 +76,7 @@ def parse():
     ap.add_argument('--no-families', action='store_true', help='skip the per-family roofline block (tools/family_bench.py)')
     ap.add_argument('--loader-workers', type=int, default=4,
                     help='DataLoader worker processes of the with-batch-assembly figure (0: assemble in the training thread)')
-    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--cpu-steps', type=int, default=10, help='timed oracle steps of the cpu_baseline leg (at ~1.1 s each)')
     ap.add_argument('--local-bn', action='store_true',
                     help='N > 1: make per-rank BatchNorm statistics (DistributedDataParallel semantics; a DIFFERENT loss than the '
                          'reference computes on the global batch) the headline `value`.  Default at N > 1: synchronised '
@@ -148,9 +148,11 @@ def ranks_report(dist, world, rank, dev, backend):
 
 
 def cpu_baseline(mols, depth, steps):
-    """Oracle (CPU restatement of the reference path, torch CPU eager) on the same workload, bounded sample: one timed step
-    per thread setting (8 / 16 / 32 / 64 / all cores: torch's CPU eager mode is oversubscribed with every core of a large
-    host), `steps` more at the best setting; the best rate is reported with its thread count."""
+    """Oracle (CPU restatement of the reference path, torch CPU eager) on the same workload, bounded sample (~20 s):
+    one warm-up step, one timed step per thread setting (8 / 16 / 32: torch's CPU eager mode is oversubscribed beyond that on a
+    large host - 64 threads 2.6 s, 128 threads 11 s per step, profiles/r02_*), then - BASELINE.md section 3: >= 3 warm-up,
+    >= 10 steps - two more warm-up steps and `steps` (default 10) timed ones at the best setting; reported: their median,
+    the thread count, and the 8-thread figure BASELINE.md asks for next to it."""
     from oracle import pna3d_oracle as O
     cfg2 = O.pna_config(**dict(PNA_KW, propagation_depth=depth))
     cfg3 = O.net3d_config(**NET3D_KW)
@@ -160,28 +162,31 @@ def cpu_baseline(mols, depth, steps):
                               {'params': [p for k, p in named if 'batch_norm' not in k]}], lr=8e-5)
     g2, g3 = O.graphs_from_molecules(mols)
     all_cores = torch.get_num_threads()
-    settings = sorted({t for t in (8, 16, 32, 64, all_cores) if t <= all_cores})
+    settings = sorted({t for t in (8, 16, 32) if t <= all_cores}) or [all_cores]
 
-    def timed(n):
+    def one():
         t0 = time.perf_counter()
-        for _ in range(n):
-            O.train_step(g2, g3, P2, cfg2, P3, cfg3, optim, 0.1)
-        return (time.perf_counter() - t0) / n
+        O.train_step(g2, g3, P2, cfg2, P3, cfg3, optim, 0.1)
+        return time.perf_counter() - t0
 
     torch.set_num_threads(settings[-1])
-    timed(1)                                                    # warm-up (allocator, thread pools)
+    one()                                                       # warm-up (allocator, thread pools)
     sweep = {}
     for t in settings:
         torch.set_num_threads(t)
-        sweep[t] = timed(1)
+        sweep[t] = one()
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
-    dt = min(sweep[best], timed(max(steps - 1, 1)))
+    one(), one()
+    times = sorted(one() for _ in range(max(steps, 1)))
+    dt = times[len(times) // 2]
     torch.set_num_threads(all_cores)
     return dict(value=len(mols) / dt, unit='molecules/s', cores=best, kind='port',
-                sample=f'batch {len(mols)} (depth {depth}, fp32, torch CPU eager): one step per thread setting, '
-                       f'{max(steps - 1, 1)} more at the best; best {best} threads {dt:.3f} s/step',
-                thread_sweep_s_per_step={str(t): round(v, 3) for t, v in sweep.items()}, host_cores=all_cores)
+                sample=f'batch {len(mols)} (depth {depth}, fp32, torch CPU eager): 1 warm-up, one step per thread setting {settings}, '
+                       f'2 more warm-up and {len(times)} timed steps at the best ({best} threads): median {dt:.3f} s/step, '
+                       f'min {times[0]:.3f}, max {times[-1]:.3f}',
+                thread_sweep_s_per_step={str(t): round(v, 3) for t, v in sweep.items()}, host_cores=all_cores,
+                molecules_per_s_8_threads=round(len(mols) / sweep[8], 1) if 8 in sweep else None)
 
 
 def extra_workloads(amd, ops, dev, depth):
