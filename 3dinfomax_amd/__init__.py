@@ -39,7 +39,7 @@ def __getattr__(name):
     if name == 'Adam':
         from . import optim
         return optim.Adam
-    if name in ('set_matmul_precision', 'get_matmul_precision'):
+    if name in ('set_matmul_precision', 'get_matmul_precision', 'set_fp32_products', 'get_fp32_products'):
         from . import ops
         return getattr(ops, name)
     if name in ('dataset', 'dist', 'tape', 'streams', 'ops'):

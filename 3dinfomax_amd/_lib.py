@@ -190,6 +190,8 @@ _SIGNATURES = {
     'i3d_event_elapsed_ms': (c_int, [_P, _P, POINTER(c_float)]),
     'i3d_set_matmul_precision': (c_int, [c_int]),
     'i3d_get_matmul_precision': (c_int, []),
+    'i3d_set_fp32_products': (c_int, [c_int]),
+    'i3d_get_fp32_products': (c_int, []),
     'i3d_net3d_edge_supported': (c_int, [c_int, c_int]),
     'i3d_net3d_edge_stats_floats': (c_long, [c_int, c_int]),
     'i3d_net3d_edge_bwd_floats': (c_long, [c_int, c_int, c_int]),

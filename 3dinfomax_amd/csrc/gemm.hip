@@ -101,12 +101,30 @@ __device__ __forceinline__ int swz(int k, int idx) { return idx ^ ((((k) ^ (k >>
 // fragment (8 consecutive k of one row) is ONE ds_read_b128: half the LDS bytes of the fp32 image, an eighth of its
 // fragment reads (round 2 kept the fp32 image and converted at every fragment read).  Row pitch BK + 8 halves = 12 / 20 /
 // 36 dwords: the 16 lanes of a b128 access group land on disjoint banks.
+// IH = 3 (split products, i3d_set_fp32_products(1)): THREE such images hi | mid | lo with x = hi + mid + lo exactly (each part
+// the bf16 rounding of what the parts in front of it leave), one behind the other at IMG_HALVES.
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-template <int R, int LD, int BK, bool KC, bool IM = false, int NT = 256, bool IH = false>       // NT: threads of the workgroup
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// (a, b) -> packed bf16 pairs hi | mid | lo with a = hi.a + mid.a + lo.a exactly (same for b): every part is the RNE bf16 of what
+// the parts in front of it leave (v_cvt_pk_bf16_f32 on the pair), the remainders are exact fp32 differences (v_pk_add_f32)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    auto pack = [](f32x2_t v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t)); };
+    auto widen = [](unsigned u) { f32x2_t r; r.x = __uint_as_float(u << 16); r.y = __uint_as_float(u & 0xffff0000u); return r; };
+    f32x2_t v;
+    v.x = a; v.y = b;
+    hi = pack(v);
+    const f32x2_t r1 = v - widen(hi);
+    mid = pack(r1);
+    const f32x2_t r2 = r1 - widen(mid);
+    lo = pack(r2);
+}
+template <int R, int LD, int BK, bool KC, bool IM = false, int NT = 256, int IH = 0>       // NT: threads of the workgroup
 struct TileStage {
     static constexpr int LDK = BK + 2;
     static constexpr int LDKH = BK + 8;                      // bf16 image: row pitch in halves
-    static constexpr int LDS_FLOATS = IH ? R * LDKH / 2 : (IM ? R * LDK : BK * LD);
+    static constexpr int IMG_HALVES = R * LDKH;              // one bf16 image
+    static constexpr int LDS_FLOATS = IH ? IH * R * LDKH / 2 : (IM ? R * LDK : BK * LD);
     static constexpr int SLOTS = R * BK / 4;                 // float4 slots in a tile
     static constexpr int KQ = BK / 4;                        // float4 slots along k of one row
     static constexpr int PER_THREAD = (SLOTS + NT - 1) / NT;
@@ -180,9 +198,19 @@ struct TileStage {
     // store for the fused BatchNorm-apply prologue (IM image of a k-contiguous operand): aff = LDS copy of [3][KP] mean |
     // scale | shift (zeros beyond K, so out-of-range k stay finite and meet the zeros of the other operand)
     __device__ __forceinline__ static void put_bf16x4(float* __restrict__ T, int idx, int k, float a, float b, float c, float d) {
-        bf16x4 h;
-        h[0] = (__bf16)a; h[1] = (__bf16)b; h[2] = (__bf16)c; h[3] = (__bf16)d;
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(T) + idx * LDKH + k) = h;
+        __bf16* const p = reinterpret_cast<__bf16*>(T) + idx * LDKH + k;
+        if constexpr (IH == 3) {
+            uint2 h, m, l;
+            split_pair(a, b, h.x, m.x, l.x);
+            split_pair(c, d, h.y, m.y, l.y);
+            *reinterpret_cast<uint2*>(p) = h;
+            *reinterpret_cast<uint2*>(p + IMG_HALVES) = m;
+            *reinterpret_cast<uint2*>(p + 2 * IMG_HALVES) = l;
+        } else {
+            bf16x4 h;
+            h[0] = (__bf16)a; h[1] = (__bf16)b; h[2] = (__bf16)c; h[3] = (__bf16)d;
+            *reinterpret_cast<bf16x4*>(p) = h;
+        }
     }
 
     __device__ __forceinline__ void store_aff(const Regs& r, float* __restrict__ T, const float* aff, int KP, int k0) const {
@@ -197,7 +225,7 @@ struct TileStage {
                 const float4 sc = *reinterpret_cast<const float4*>(aff + KP + kg);
                 const float4 sh = *reinterpret_cast<const float4*>(aff + 2 * KP + kg);
                 const float4 v = r.v[it];
-                if constexpr (IH) {
+                if constexpr (IH != 0) {
                     put_bf16x4(T, idx, k, (v.x - mu.x) * sc.x + sh.x, (v.y - mu.y) * sc.y + sh.y, (v.z - mu.z) * sc.z + sh.z,
                                (v.w - mu.w) * sc.w + sh.w);
                     continue;
@@ -237,7 +265,7 @@ struct TileStage {
                 }
                 if (write && ok[it] && k0 + k < K)       // (K % 4 == 0: a valid first element is a valid float4)
                     *reinterpret_cast<float4*>(dz + (long)rowi[it] * lddz + k0 + k) = r;
-                if constexpr (IH) {
+                if constexpr (IH != 0) {
                     put_bf16x4(T, idx, k, r.x, r.y, r.z, r.w);
                     continue;
                 }
@@ -329,17 +357,31 @@ __device__ __forceinline__ bf16x8 to_bf16x8(const float* f) {
     return r;
 }
 
-template <class S, bool VEC, bool A_KC, bool B_KC, bool ROWS, int FUSE = 0, bool BF16 = false>
+// f = hi + mid + lo exactly: hi = bf16(f), mid = bf16(f - hi), lo = f - hi - mid (<= 8 significant bits: a bf16); operands
+// whose LDS image is fp32 (idx-contiguous ones) are split when a lane has read its fragment
+__device__ __forceinline__ void split_bf16x8(const float* f, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    uint4 h, m, l;
+    split_pair(f[0], f[1], h.x, m.x, l.x);
+    split_pair(f[2], f[3], h.y, m.y, l.y);
+    split_pair(f[4], f[5], h.z, m.z, l.z);
+    split_pair(f[6], f[7], h.w, m.w, l.w);
+    hi = __builtin_bit_cast(bf16x8, h);
+    mid = __builtin_bit_cast(bf16x8, m);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+
+template <class S, bool VEC, bool A_KC, bool B_KC, bool ROWS, int FUSE = 0, int BF16 = 0>       // BF16: 0 fp32 MFMA, 1 bf16-rounded operands, 2 split products
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int k_begin, const int k_end,
                                           float* __restrict__ Cout, const int* kidx, const bool first_split) {
     constexpr int MT = S::MT, WAVES_N = S::WAVES_N, WM_T = S::WM_T, WN_T = S::WN_T, BK = S::BK, PF = S::PF;
     constexpr int BM = S::BM, BN = S::BN;
     constexpr int LDA = (BM + 31) / 32 * 32, LDB = (BN + 31) / 32 * 32;
     constexpr int KSTEP = (MT == 16) ? 4 : 2;         // k per MFMA
-    constexpr bool A_IH = BF16 && VEC && S::KP && A_KC && MT == 32, B_IH = BF16 && VEC && S::KP && B_KC && MT == 32;   // bf16 images
+    constexpr bool SPLIT = BF16 == 2;
+    constexpr bool A_IH = BF16 != 0 && VEC && S::KP && A_KC && MT == 32, B_IH = BF16 != 0 && VEC && S::KP && B_KC && MT == 32;   // bf16 images
     constexpr bool A_IM = S::KP && A_KC && MT == 32 && !A_IH, B_IM = S::KP && B_KC && MT == 32 && !B_IH;
-    typedef TileStage<BM, LDA, BK, A_KC, A_IM, S::NT, A_IH> StageA;
-    typedef TileStage<BN, LDB, BK, B_KC, B_IM, S::NT, B_IH> StageB;
+    typedef TileStage<BM, LDA, BK, A_KC, A_IM, S::NT, A_IH ? (SPLIT ? 3 : 1) : 0> StageA;
+    typedef TileStage<BN, LDB, BK, B_KC, B_IM, S::NT, B_IH ? (SPLIT ? 3 : 1) : 0> StageB;
     // one block of LDS: the operand double buffers, reused by the statistics epilogue as the [BM][BN + 1] output tile
     constexpr int OPER_FLOATS = 2 * StageA::LDS_FLOATS + 2 * StageB::LDS_FLOATS;
     constexpr int CT_PITCH = BN + 1;
@@ -426,19 +468,24 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
             if (t < nk) {
                 const float* as = As + cur * StageA::LDS_FLOATS;
                 const float* bs = Bs + cur * StageB::LDS_FLOATS;
-                if constexpr (BF16) {
+                if constexpr (BF16 != 0) {
                     static_assert(bf16_shape<S>(), "bf16 MFMA: the K-tile is a whole number of instructions");
+                    static_assert(!SPLIT || MT == 32, "split products: 32x32 tiles");
                     constexpr int KI = (MT == 32) ? 16 : 32;       // k per instruction
+                    constexpr int NI = SPLIT ? 3 : 1;              // images: the rounded operand, or hi | mid | lo
 #pragma unroll
                     for (int ks = 0; ks < BK / KI; ++ks) {
                         // lane (lt, lk) supplies k = ks KI + 8 lk .. + 7 of row lt of its tiles
                         const int k0 = ks * KI + 8 * lk;
-                        bf16x8 a8[WM_T], b8[WN_T];
+                        bf16x8 a8[NI][WM_T], b8[NI][WN_T];
 #pragma unroll
                         for (int i = 0; i < WM_T; ++i) {
                             const int idx = (wm * WM_T + i) * MT + lt;
                             if constexpr (A_IH) {
-                                a8[i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(as) + idx * StageA::LDKH + k0);
+#pragma unroll
+                                for (int p = 0; p < NI; ++p)
+                                    a8[p][i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(as) + p * StageA::IMG_HALVES +
+                                                                                idx * StageA::LDKH + k0);
                             } else {
                                 float f[8];
                                 if constexpr (A_IM) {
@@ -451,14 +498,18 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 #pragma unroll
                                     for (int q = 0; q < 8; ++q) f[q] = as[(k0 + q) * LDA + swz(k0 + q, idx)];
                                 }
-                                a8[i] = to_bf16x8(f);
+                                if constexpr (SPLIT) split_bf16x8(f, a8[0][i], a8[1][i], a8[2][i]);
+                                else a8[0][i] = to_bf16x8(f);
                             }
                         }
 #pragma unroll
                         for (int j = 0; j < WN_T; ++j) {
                             const int idx = (wn * WN_T + j) * MT + lt;
                             if constexpr (B_IH) {
-                                b8[j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(bs) + idx * StageB::LDKH + k0);
+#pragma unroll
+                                for (int p = 0; p < NI; ++p)
+                                    b8[p][j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(bs) + p * StageB::IMG_HALVES +
+                                                                                idx * StageB::LDKH + k0);
                             } else {
                                 float f[8];
                                 if constexpr (B_IM) {
@@ -471,15 +522,28 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 #pragma unroll
                                     for (int q = 0; q < 8; ++q) f[q] = bs[(k0 + q) * LDB + swz(k0 + q, idx)];
                                 }
-                                b8[j] = to_bf16x8(f);
+                                if constexpr (SPLIT) split_bf16x8(f, b8[0][j], b8[1][j], b8[2][j]);
+                                else b8[0][j] = to_bf16x8(f);
                             }
                         }
 #pragma unroll
                         for (int i = 0; i < WM_T; ++i)
 #pragma unroll
                             for (int j = 0; j < WN_T; ++j) {
-                                if constexpr (MT == 16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8[j], a8[i], acc[i][j], 0, 0, 0);
-                                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[j], a8[i], acc[i][j], 0, 0, 0);
+                                if constexpr (SPLIT) {
+                                    // a b = sum of the six part products of order <= 2 (each exact in fp32), small ones first; the three
+                                    // dropped ones are <= 2^-24 |a b| each: the rounding class of one fp32 product
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[2][j], a8[0][i], acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[0][j], a8[2][i], acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[1][j], a8[1][i], acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[1][j], a8[0][i], acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[0][j], a8[1][i], acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[0][j], a8[0][i], acc[i][j], 0, 0, 0);
+                                } else if constexpr (MT == 16) {
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8[0][j], a8[0][i], acc[i][j], 0, 0, 0);
+                                } else {
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[0][j], a8[0][i], acc[i][j], 0, 0, 0);
+                                }
                             }
                     }
                 } else if constexpr (S::KP && MT == 32) {
@@ -665,7 +729,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     }
 }
 
-template <class S, bool VEC, bool A_KC, bool B_KC, bool BF16 = false>
+template <class S, bool VEC, bool A_KC, bool B_KC, int BF16 = 0>
 __global__ void __launch_bounds__(256)
 gemm_f32_kernel(GemmArgs g) {
     I3D_CHAIN_PRIO();
@@ -685,7 +749,7 @@ gemm_f32_kernel(GemmArgs g) {
     gemm_body<S, VEC, A_KC, B_KC, false, 0, BF16>(g, bx, by, k_begin, k_end, g.C, nullptr, bz == 0);
 }
 
-template <class S, bool VEC, bool BF16 = false>
+template <class S, bool VEC, int BF16 = 0>
 __global__ void __launch_bounds__(256)
 gemm_f32_rowseg_kernel(GemmArgs g, SegTable segs) {
     I3D_CHAIN_PRIO();
@@ -880,10 +944,29 @@ static bool fuse_narrow_short_k() {
 
 // process-level: 0 = fp32 MFMA (exact fp32 products), 1 = bf16 MFMA on bf16-rounded operands (i3d_set_matmul_precision)
 static int g_matmul_bf16 = 0;
+// fp32 mode: how the 32x32-tile kernels with an idx-major LDS image (the forward and data-gradient GEMMs of the chain) form a product
+// of two fp32 operands (i3d_set_fp32_products; I3D_FP32_PRODUCTS=native|split at load):
+//   0 native: v_mfma_f32_32x32x2_f32, 64 cycles per 2 k (exact products, one rounding per accumulation)
+//   1 split : a = a_h + a_m + a_l, b likewise (three bf16 parts each, the decomposition is exact); a b ~ the six part products of
+//             order <= 2 on the bf16 pipe (6 x v_mfma_f32_32x32x16_bf16 = 192 cycles per 16 k against 512), fp32 accumulation.  Every
+//             part product is exact in fp32; the three dropped ones are <= 2^-24 |a b| each - what the rounding of ONE fp32
+//             accumulation costs.  Against an fp64 product the error is that of an fp32 GEMM in another summation order
+//             (tests/test_gpu_ops.py: test_split_products_are_fp32_products).
+static int g_fp32_split = [] { const char* e = getenv("I3D_FP32_PRODUCTS"); return (e != nullptr && e[0] == 'n') ? 0 : 1; }();
+template <class S> constexpr bool split_shape() {      // the 64x64 and 64x32 tilings of the chain (Cfg9, Cfg11)
+    return S::KP && S::MT == 32 && S::BK == 16 && S::WAVES_M == 2 && S::WM_T == 1 && S::WN_T == 1;
+}
 
 template <class S>
 static void launch(const GemmArgs& g, int layout, int splits, bool vec, hipStream_t s) {
     dim3 grid(cdiv(g.M, S::BM), cdiv(g.N, S::BN), splits), block(S::NT);
+    if constexpr (split_shape<S>()) {
+        if (!g_matmul_bf16 && g_fp32_split && vec && layout <= 1) {
+            if (layout == 0) hipLaunchKernelGGL((gemm_f32_kernel<S, true, true, true, 2>), grid, block, 0, s, g);
+            else hipLaunchKernelGGL((gemm_f32_kernel<S, true, true, false, 2>), grid, block, 0, s, g);
+            return;
+        }
+    }
     if constexpr (bf16_shape<S>()) {
         if (g_matmul_bf16 && vec) {      // (the unaligned variants are not on the training path: they stay fp32)
             switch (layout) {
@@ -965,7 +1048,7 @@ gemm_f32_tt_kernel(GemmArgs g) {
 }
 
 // forward layout (A and B k-contiguous, 16-byte loads) with the fused BatchNorm prologue / statistics epilogue
-template <class S, int FUSE, bool BF16 = false>
+template <class S, int FUSE, int BF16 = 0>
 __global__ void __launch_bounds__(256)
 gemm_f32_fused_kernel(GemmArgs g) {
     I3D_CHAIN_PRIO();
@@ -990,7 +1073,7 @@ gemm_f32_fused_o5_kernel(GemmArgs g) {
 
 // data-gradient layouts (A k-contiguous: the gradient at a BatchNorm output; B stored [K, N] or [N, K]) with the BatchNorm-backward
 // prologue (FUSE 4)
-template <class S, bool B_KC, bool BF16>
+template <class S, bool B_KC, int BF16>
 __global__ void __launch_bounds__(256)
 gemm_f32_bnbwd_kernel(GemmArgs g) {
     I3D_CHAIN_PRIO();
@@ -1006,6 +1089,13 @@ static void launch_bnbwd(const GemmArgs& g, bool b_kc, hipStream_t s) {
         if (b_kc) hipLaunchKernelGGL((gemm_f32_bnbwd_kernel<S, true, true>), grid, block, 0, s, g);
         else hipLaunchKernelGGL((gemm_f32_bnbwd_kernel<S, false, true>), grid, block, 0, s, g);
     } else {
+        if constexpr (split_shape<S>()) {
+            if (g_fp32_split) {
+                if (b_kc) hipLaunchKernelGGL((gemm_f32_bnbwd_kernel<S, true, 2>), grid, block, 0, s, g);
+                else hipLaunchKernelGGL((gemm_f32_bnbwd_kernel<S, false, 2>), grid, block, 0, s, g);
+                return;
+            }
+        }
         if (b_kc) hipLaunchKernelGGL((gemm_f32_bnbwd_kernel<S, true, false>), grid, block, 0, s, g);
         else hipLaunchKernelGGL((gemm_f32_bnbwd_kernel<S, false, false>), grid, block, 0, s, g);
     }
@@ -1021,6 +1111,16 @@ static void launch_fused(const GemmArgs& g, int fuse, hipStream_t s) {
             default: hipLaunchKernelGGL((gemm_f32_fused_kernel<S, 3, true>), grid, block, 0, s, g); break;
         }
         return;
+    }
+    if constexpr (split_shape<S>()) {
+        if (g_fp32_split) {
+            switch (fuse) {
+                case 1: hipLaunchKernelGGL((gemm_f32_fused_kernel<S, 1, 2>), grid, block, 0, s, g); break;
+                case 2: hipLaunchKernelGGL((gemm_f32_fused_kernel<S, 2, 2>), grid, block, 0, s, g); break;
+                default: hipLaunchKernelGGL((gemm_f32_fused_kernel<S, 3, 2>), grid, block, 0, s, g); break;
+            }
+            return;
+        }
     }
     static const bool occ5 = [] { const char* e = getenv("I3D_FUSED_OCC5"); return e == nullptr || e[0] != '0'; }();
     if constexpr (S::WAVES_N == 2 && S::BK == 16) {
@@ -1356,6 +1456,14 @@ extern "C" int i3d_set_matmul_precision(int bf16) {
 }
 
 extern "C" int i3d_get_matmul_precision(void) { return g_matmul_bf16; }
+
+extern "C" int i3d_set_fp32_products(int split) {
+    I3D_CHECK_ARG(split == 0 || split == 1, "0: fp32 MFMA, 1: three-part bf16 split of both operands, six part products");
+    g_fp32_split = split;
+    return I3D_OK;
+}
+
+extern "C" int i3d_get_fp32_products(void) { return g_fp32_split; }
 
 extern "C" int i3d_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
                             int ldb, float* C, int ldc, const float* bias, int accumulate, void* stream) {

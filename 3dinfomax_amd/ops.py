@@ -230,6 +230,21 @@ def get_matmul_precision():
     return 'bf16' if _lib.load().i3d_get_matmul_precision() else 'fp32'
 
 
+def set_fp32_products(mode):
+    """'native': v_mfma_f32_32x32x2_f32; 'split': three-part bf16 split of both operands, six part products on the bf16 pipe
+    (include/infomax3d_hip.h: i3d_set_fp32_products).  fp32 mode only.  Returns the previous setting."""
+    L = _lib.load()
+    prev = 'split' if L.i3d_get_fp32_products() else 'native'
+    if mode not in ('native', 'split'):
+        raise ValueError(f'fp32 products {mode!r}: native or split')
+    check(L.i3d_set_fp32_products(int(mode == 'split')), 'i3d_set_fp32_products')
+    return prev
+
+
+def get_fp32_products():
+    return 'split' if _lib.load().i3d_get_fp32_products() else 'native'
+
+
 def gemm(A, B, trans_a=False, trans_b=False, out=None, bias=None, accumulate=False):
     """out[M,N] = (accumulate ? out : 0) + op(A) op(B) + bias.  A, B, out: 2-D fp32, unit inner stride
     (row slices / column slices of a contiguous tensor are fine: the row stride is the leading dimension)."""

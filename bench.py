@@ -73,6 +73,9 @@ def parse():
                     help='matmul precision: fp32 (configs[1], default) or the bf16 MATMUL mode - bf16-rounded operands on the bf16 '
                          'matrix pipe with fp32 accumulation; tensors, BatchNorm statistics, master weights stay fp32 (configs[3]: '
                          'a matmul mode, not bf16 storage)')
+    ap.add_argument('--fp32-products', default=None, choices=['split', 'native'],
+                    help='fp32 mode: how the tiled GEMMs form a product (default: the library default, split - include/infomax3d_hip.h: '
+                         'i3d_set_fp32_products); native: v_mfma_f32_32x32x2_f32')
     ap.add_argument('--no-families', action='store_true', help='skip the per-family roofline block (tools/family_bench.py)')
     ap.add_argument('--loader-workers', type=int, default=4,
                     help='DataLoader worker processes of the with-batch-assembly figure (0: assemble in the training thread)')
@@ -189,6 +192,16 @@ def cpu_baseline(mols, depth, steps):
                 molecules_per_s_8_threads=round(len(mols) / sweep[8], 1) if 8 in sweep else None)
 
 
+FP32_PRODUCTS = {
+    'split': 'fp32: every tensor, accumulator and statistic fp32; the tiled GEMMs form a product of two fp32 operands from an EXACT '
+             'three-part bf16 split of both (x = hi + mid + lo) - the six part products of order <= 2 on v_mfma_f32_*_bf16, each exact '
+             'in the fp32 accumulator; dropped: <= 3 x 2^-24 |a b|.  Against fp64 the error is not larger than that of '
+             'v_mfma_f32_32x32x2_f32 on the same operands (tests/test_gpu_ops.py: test_split_products_are_fp32_products; measured 2.1e-7 '
+             'against 2.5e-7 rms at K = 200).  I3D_FP32_PRODUCTS=native / --fp32-products native: the fp32 matrix pipe '
+             '(config.extra_workloads.qm9_shape_fp32_native_mfma_products)',
+    'native': 'fp32 (exact fp32 products on the fp32 matrix pipe: v_mfma_f32_32x32x2_f32 / 16x16x4_f32)'}
+
+
 def extra_workloads(amd, ops, dev, depth):
     """Short windows of the OTHER BASELINE.json configurations after the main timed region (N = 1), so that the driver's
     default line carries a number for each: configs[3] shape (QMugs-shaped molecules, 3 conformers,
@@ -223,9 +236,11 @@ def extra_workloads(amd, ops, dev, depth):
     mols = amd.synth.make_dataset(B1, seed=1000)
     g2 = amd.batch([amd.bond_graph(m) for m in mols]).to(dev)
     g3 = amd.batch([amd.complete_graph(m) for m in mols]).to(dev)
-    for name, dtype, env in (('qm9_shape_fp32_split_bf16_weight_gradients', 'fp32', {'I3D_WGRAD_SPLIT_BF16': '1'}),
+    for name, dtype, env in (('qm9_shape_fp32_native_mfma_products', 'fp32', {}),
+                             ('qm9_shape_fp32_split_bf16_weight_gradients', 'fp32', {'I3D_WGRAD_SPLIT_BF16': '1'}),
                              ('qm9_shape_bf16', 'bf16', {})):
         prev = ops.set_matmul_precision(dtype)
+        prev_products = ops.set_fp32_products('native') if 'native' in name else ops.get_fp32_products()
         saved_env = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         torch.manual_seed(123)
@@ -241,8 +256,10 @@ def extra_workloads(amd, ops, dev, depth):
             optim.zero_grad()
         ms, host = window(step, 10, 40)
         out[name] = dict(ms_per_step=round(ms, 3), molecules_per_s=round(B1 / ms * 1e3, 1), host_enqueue_ms=round(host, 3), batch=B1,
-                         depth=depth, matmul=dtype + (' matmul mode (fp32 storage)' if dtype == 'bf16' else ''), weight_gradients='split bf16 x3' if env else ('bf16' if dtype == 'bf16' else 'fp32'))
+                         depth=depth, matmul=dtype + (' matmul mode (fp32 storage)' if dtype == 'bf16' else f' ({ops.get_fp32_products()} products)'),
+                         weight_gradients='two-part split, 3 products (2^-15 per product)' if env else ('bf16' if dtype == 'bf16' else ops.get_fp32_products()))
         ops.set_matmul_precision(prev)
+        ops.set_fp32_products(prev_products)
         for k, v in saved_env.items():
             if v is None:
                 os.environ.pop(k, None)
@@ -386,6 +403,8 @@ def main():
     ops = importlib.import_module('3dinfomax_amd.ops')
     adist = importlib.import_module('3dinfomax_amd.dist')
     ops.set_matmul_precision(args.dtype)
+    if args.fp32_products is not None:
+        ops.set_fp32_products(args.fp32_products)
     if use_dist:
         if not args.no_prewarm:
             adist.warm_up(dev)          # kernels, streams and autograd's thread before the communicator (dist.warm_up: 7 %)
@@ -782,7 +801,7 @@ def main():
                    value=round(mol_per_s, 1), unit='molecules/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
                    vs_baseline=None, dtype='f32' if args.dtype == 'fp32' else 'bf16', data='synthetic',
-                   config=dict(precision=('fp32 (exact fp32 products on the fp32 matrix pipe)' if args.dtype == 'fp32' else
+                   config=dict(precision=(FP32_PRODUCTS[ops.get_fp32_products()] if args.dtype == 'fp32' else
                                           'bf16 MATMUL mode - not bf16 storage: every GEMM multiplies bf16-rounded operands on '
                                           'v_mfma_f32_*_bf16 with fp32 accumulation; all tensors in HBM (activations, gradients, '
                                           'master weights, Adam state) and the BatchNorm statistics stay fp32, except - by size - '

@@ -121,6 +121,14 @@ int i3d_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, const float* 
  * epilogue / BatchNorm statistics / tensors in memory stay fp32 (the master weights are the fp32 parameters). */
 int i3d_set_matmul_precision(int bf16);
 int i3d_get_matmul_precision(void);
+/* fp32 mode only - how the tiled forward / data-gradient GEMMs (32x32 MFMA tiles, 16-byte aligned operands) form the product of
+ * two fp32 operands: 0 = v_mfma_f32_32x32x2_f32; 1 = both operands split exactly into three bf16 parts (x = hi + mid + lo) and
+ * the six part products of order <= 2 taken on the bf16 matrix pipe with fp32 accumulation (each part product is exact; what is
+ * dropped is <= 3 x 2^-24 |a b|, the size of one fp32 rounding) - the same nn.Linear arithmetic class as
+ * /root/reference/models/base_layers.py:101, 2.7x fewer matrix-pipe cycles.  Process-level; I3D_FP32_PRODUCTS=native|split
+ * sets it at load. */
+int i3d_set_fp32_products(int split);
+int i3d_get_fp32_products(void);
 
 /* i3d_gemm_f32 with scratch: when the reduction dimension is split over workgroups (weight gradients), the slices are
  * written to workspace[slices][M][N] and summed in a fixed order by a second kernel (deterministic, no zero-fill, no

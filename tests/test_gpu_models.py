@@ -188,13 +188,22 @@ def _det_load(module, tag):
     module.load_state_dict(new)
 
 
-@pytest.mark.parametrize('L,wgrad', [(7, 'exact'), (4, 'exact'), (4, 'split_bf16')])
-def test_full_yml_config_vs_reference_fixture(amd, L, wgrad, monkeypatch):
-    """pre-train_QM9.yml dimensions (F=200, target 256; L=7 as in the yml, L=4 as in BASELINE.json).  split_bf16: the weight
-    gradients of the PNA layers as three bf16 products of split operands (I3D_WGRAD_SPLIT_BF16=1, csrc/wgrad.hip) - the same
-    bounds as the exact fp32 products."""
+def _products(amd, request, wgrad, monkeypatch):
+    """'exact': the fp32 mode's default (three-part split of both operands, six part products: csrc/gemm.hip); 'native_mfma':
+    v_mfma_f32_32x32x2_f32 / 16x16x4_f32 everywhere; 'split_bf16': round 3's two-part split of the weight gradients (opt-in)"""
     if wgrad == 'split_bf16':
         monkeypatch.setenv('I3D_WGRAD_SPLIT_BF16', '1')
+    if wgrad == 'native_mfma':
+        prev = amd.set_fp32_products('native')
+        request.addfinalizer(lambda: amd.set_fp32_products(prev))
+    assert amd.get_fp32_products() == ('native' if wgrad == 'native_mfma' else 'split')
+
+
+@pytest.mark.parametrize('L,wgrad', [(7, 'exact'), (4, 'exact'), (4, 'split_bf16'), (4, 'native_mfma')])
+def test_full_yml_config_vs_reference_fixture(amd, L, wgrad, monkeypatch, request):
+    """pre-train_QM9.yml dimensions (F=200, target 256; L=7 as in the yml, L=4 as in BASELINE.json), with every way the fp32 mode
+    forms its products (_products) - the same bounds."""
+    _products(amd, request, wgrad, monkeypatch)
     z = load('full_config.npz')
     mols = mols_from_npz(z)
     pna = amd.PNA(avg_d=1.0, device='cuda:0', **dict(PNA_YML, propagation_depth=L))
@@ -219,12 +228,11 @@ def test_full_yml_config_vs_reference_fixture(amd, L, wgrad, monkeypatch):
     grads_close(param_grads(net), ref, 2e-3, 'net3d ')
 
 
-@pytest.mark.parametrize('wgrad', ['exact', 'split_bf16'])
-def test_batch64_vs_oracle_fwd_bwd(amd, wgrad, monkeypatch):
+@pytest.mark.parametrize('wgrad', ['exact', 'split_bf16', 'native_mfma'])
+def test_batch64_vs_oracle_fwd_bwd(amd, wgrad, monkeypatch, request):
     """A bigger seeded batch (64 QM9-shaped molecules, F=200, L=2): forward, loss, and every parameter gradient
-    against the oracle - with the exact fp32 weight gradients and with the split-bf16 ones, same bounds."""
-    if wgrad == 'split_bf16':
-        monkeypatch.setenv('I3D_WGRAD_SPLIT_BF16', '1')
+    against the oracle - with every way the fp32 mode forms its products (_products), same bounds."""
+    _products(amd, request, wgrad, monkeypatch)
     mols = synth.make_dataset(64, seed=5)
     kw2 = dict(PNA_YML, propagation_depth=2)
     pna = amd.PNA(avg_d=1.0, device='cuda:0', **kw2)

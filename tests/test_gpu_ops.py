@@ -50,6 +50,60 @@ def test_gemm_matches_fp64(M, N, K, ta, tb):
     assert rel_err(out.cpu(), ref) < max(tol, 1e-5)
 
 
+def _rms_rel(out, ref):
+    return ((out.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+
+
+@pytest.mark.parametrize('M,N,K,tb', [(9216, 400, 200, True), (9216, 200, 800, True), (9216, 800, 200, False), (19400, 200, 200, False)])
+def test_split_products_are_fp32_products(M, N, K, tb):
+    """fp32 mode, the default way the tiled GEMMs form a product (csrc/gemm.hip, i3d_set_fp32_products(1)): both operands split
+    exactly into three bf16 parts, the six part products of order <= 2 on the bf16 matrix pipe, fp32 accumulation.  Held to:
+    against the fp64 product its error is NOT larger than that of v_mfma_f32_32x32x2_f32 on the same operands (measured: 0.8x,
+    2.1e-7 against 2.5e-7 rms at K = 200) - an fp32 GEMM in another summation order, not a reduced-precision one; the bf16
+    matmul mode on the same operands is four orders of magnitude away.  Forward and data-gradient layouts, the fused
+    (BatchNorm prologue / statistics) variant; reference op: nn.Linear, models/base_layers.py:101"""
+    A, B = rnd(M, K, seed=1), rnd(*((N, K) if tb else (K, N)), seed=2) * K ** -0.5
+    ref = A.double() @ (B.double().T if tb else B.double())
+    res = {}
+    prev = ops.get_fp32_products()
+    try:
+        for mode in ('native', 'split'):
+            ops.set_fp32_products(mode)
+            res[mode] = ops.gemm(g(A), g(B), trans_b=tb).cpu()
+        ops.set_matmul_precision('bf16')
+        res['bf16'] = ops.gemm(g(A), g(B), trans_b=tb).cpu()
+    finally:
+        ops.set_matmul_precision('fp32')
+        ops.set_fp32_products(prev)
+    e = {k: _rms_rel(v, ref) for k, v in res.items()}
+    assert not torch.equal(res['native'], res['split'])              # (the switch does switch)
+    assert e['split'] <= 1.05 * e['native'] and e['split'] < 1e-6, e
+    assert rel_err(res['split'], ref) <= 1.25 * rel_err(res['native'], ref), (rel_err(res['split'], ref), rel_err(res['native'], ref))
+    assert e['bf16'] > 1000 * e['split'], e
+
+
+def test_split_products_in_the_fused_gemm():
+    """the same statement for the fused forward GEMM (BatchNorm prologue + statistics epilogue).  (The one-launch weight gradients
+    and the small-tile / unaligned kernels keep the fp32 matrix pipe: the six-product form of the panel kernel was measured slower,
+    87.7 -> 95.1 us per layer, profiles/r05_split_products.txt)"""
+    M, N, K = 6000, 200, 200
+    A, W, bias, aff = rnd(M, K, seed=1), rnd(N, K, seed=2) * K ** -0.5, rnd(N, seed=3), rnd(3, K, seed=4)
+    a = aff.double()
+    ref = ((A.double() - a[0]) * a[1] + a[2]) @ W.double().T + bias.double()
+    e, stats = {}, {}
+    prev = ops.get_fp32_products()
+    try:
+        for mode in ('native', 'split'):
+            ops.set_fp32_products(mode)
+            out, st = ops.gemm_fused(g(A), g(W), g(bias), g(aff), None, want_stats=True)[:2]
+            e[mode] = _rms_rel(out.cpu(), ref)
+            stats[mode] = st.cpu()
+    finally:
+        ops.set_fp32_products(prev)
+    assert e['split'] <= 1.05 * e['native'] and e['split'] < 1e-6, e
+    assert torch.allclose(stats['native'], stats['split'], rtol=1e-4, atol=1e-4)
+
+
 def test_gemm_weight_grad_split_k_and_strided_views():
     rows, Fo, Fi = 20000, 200, 2600
     dY, X = rnd(rows, Fo, seed=4, scale=0.1), rnd(rows, Fi, seed=5)
