@@ -792,7 +792,9 @@ def main():
                          ms_at_mfma_peak=round(flops / (fb.MFMA_BF16_PEAK_TF if args.dtype == 'bf16' else fb.MFMA_F32_PEAK_TF) / 1e9, 3),
                          algorithmic_bytes_per_step=int(byts), ms_at_hbm_peak=round(byts / HBM_PEAK_GBS / 1e6, 3),
                          note='PNA layers only (heads, encoders, Net3D, NT-Xent are < 2 % of the flops); the step is neither '
-                              'MFMA- nor HBM-bound: it is ~175 launches of 5-140 us on three streams, ~115 of them a dependent chain')
+                              'MFMA- nor HBM-bound: it is ~175 launches of 5-140 us on three streams, ~115 of them a dependent chain.  '
+                              'flops = 2MNK of the products (algorithmic); peak = the fp32 matrix pipe in the fp32 mode whichever way the '
+                              'products are formed (split form: 6 bf16-pipe instructions per 16 k = 0.375 of the fp32 pipe\'s cycles)')
         roof['families'] = families
         roof['step'] = step_line
     if rank == 0:
