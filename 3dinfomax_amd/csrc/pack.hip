@@ -7,6 +7,8 @@
 // built once per model (3dinfomax_amd/pna_original.py: _TowerStacks).
 #include "common.h"
 
+#include <algorithm>
+
 namespace i3d {
 
 namespace {
@@ -23,10 +25,47 @@ __global__ void __launch_bounds__(256) block_copy_kernel(const I3dCopyBlock* __r
     }
 }
 
+// dst[r, c] = c < cols_src ? src[r, c] : 0 for c < cols_dst: widens rows to a pitch the 16-byte kernels take (zeros in the new
+// columns) or crops them back; a thread moves one float4 of dst when cols_dst % 4 == 0
+__global__ void __launch_bounds__(256) copy_cols_kernel(const float* __restrict__ src, int rows, int cols_src, float* __restrict__ dst,
+                                                        int cols_dst, int vec) {
+    const long n = vec ? (long)rows * (cols_dst / 4) : (long)rows * cols_dst;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        if (vec) {
+            const int q = cols_dst / 4;
+            const long r = i / q;
+            const int c = (int)(i - r * q) * 4;
+            const float* s = src + r * cols_src + c;
+            float4 v;
+            v.x = c < cols_src ? s[0] : 0.f;
+            v.y = c + 1 < cols_src ? s[1] : 0.f;
+            v.z = c + 2 < cols_src ? s[2] : 0.f;
+            v.w = c + 3 < cols_src ? s[3] : 0.f;
+            *reinterpret_cast<float4*>(dst + r * cols_dst + c) = v;
+        } else {
+            const long r = i / cols_dst;
+            const int c = (int)(i - r * cols_dst);
+            dst[i] = c < cols_src ? src[r * cols_src + c] : 0.f;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace i3d
 
 using namespace i3d;
+
+extern "C" int i3d_copy_cols(const float* src, int rows, int cols_src, float* dst, int cols_dst, void* stream) {
+    I3D_CHECK_ARG(rows >= 0 && cols_src >= 0 && cols_dst >= 0 && (rows == 0 || cols_dst == 0 || (src != nullptr && dst != nullptr)),
+                  "bad arguments");
+    if (rows == 0 || cols_dst == 0) return I3D_OK;
+    const int vec = (cols_dst % 4 == 0) && (((uintptr_t)dst & 15) == 0);
+    const long n = vec ? (long)rows * (cols_dst / 4) : (long)rows * cols_dst;
+    const int grid = (int)std::min<long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, rows, cols_src, dst, cols_dst, vec);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
 
 // table: n_blocks entries in DEVICE memory; reverse != 0 copies dst -> src (the same table scatters results back)
 extern "C" int i3d_block_copy(const I3dCopyBlock* table, int n_blocks, int reverse, void* stream) {

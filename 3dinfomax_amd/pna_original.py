@@ -23,6 +23,9 @@ from .pna import _codes, _GatherRowsFn
 
 # I3D_TOWER_STACK=0: the towers of a layer one after the other (one autograd node per block and tower: the first version)
 TOWER_STACK = os.environ.get('I3D_TOWER_STACK', '1') != '0'
+# I3D_TOWER_PAD=0: the stacked layers at the model's own widths (hidden_dim 90 / edge_hidden_dim 70 of the yml: every kernel of the
+# layer in its unaligned form - 4.8 ms per step at batch 512 against the padded form's)
+PAD_WIDTHS = os.environ.get('I3D_TOWER_PAD', '1') != '0'
 
 
 class _RowScaleFn(torch.autograd.Function):
@@ -38,6 +41,27 @@ class _RowScaleFn(torch.autograd.Function):
     def backward(ctx, g):
         (s,) = ctx.saved_tensors
         return ops.row_scale(g.contiguous(), s), None
+
+
+class _CopyColsFn(torch.autograd.Function):
+    """x [rows, c] -> [rows, cols]: zeros in the new columns (cols > c) or the first cols columns (csrc/pack.hip: i3d_copy_cols);
+    the gradient goes the other way round"""
+
+    @staticmethod
+    def forward(ctx, x, cols):
+        x = x.contiguous()
+        ctx.cols_in = x.shape[1]
+        out = torch.empty(x.shape[0], cols, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().i3d_copy_cols(x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), cols, ops._stream()), 'i3d_copy_cols')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        out = torch.empty(g.shape[0], ctx.cols_in, dtype=torch.float32, device=g.device)
+        _lib.check(_lib.load().i3d_copy_cols(g.data_ptr(), g.shape[0], g.shape[1], out.data_ptr(), ctx.cols_in, ops._stream()),
+                   'i3d_copy_cols')
+        return out, None
 
 
 class _GatherSrcFn(torch.autograd.Function):
@@ -141,10 +165,17 @@ class PNAOriginal(nn.Module):
         h = gnn.embedding_h(g.ndata['feat'])
         h = _dropout(h, gnn.in_feat_dropout.p, gnn.training)
         e_sorted = gnn.embedding_e(g.edata['feat'], perm=idx.perm) if gnn.edge_feat else None     # destination-sorted
+        # widths rounded up to 4 floats (_LayerStack): zeros in the extra columns from here to the last layer's output
+        st0 = stacks.layers[0]
+        if h.shape[1] != st0.Dp:
+            h = tape.apply(_CopyColsFn, h, st0.Dp)
+        if e_sorted is not None and e_sorted.shape[1] != st0.Fep:
+            e_sorted = tape.apply(_CopyColsFn, e_sorted, st0.Fep)
         snorm = snorm_n.to(h.device)
         snorm_flat = None
         for layer, st in zip(gnn.layers, stacks.layers):
             tw = layer.towers[0]
+            assert h.shape[1] == st.Dp
             # (an eval-mode layer under a tape may still be differentiated: that backward is sequenced by the block path only)
             native = (TOWER_NATIVE and (layer.training or tape.active() is None) and ops.GEMM_WORKSPACE_BYTES > 0
                       and idx.num_edges > 0)       # (a batch without bonds: the block path handles E = 0)
@@ -152,8 +183,7 @@ class PNAOriginal(nn.Module):
                 if tw.graph_norm and snorm_flat is None:
                     snorm_flat = snorm.reshape(-1).contiguous().float()
                 h = tape.apply(_TowerLayerFn, h, e_sorted if tw.edge_features else None, snorm_flat if tw.graph_norm else None,
-                               st.Wp, st.bp, st.Wq, st.bq, st.gamma, st.beta, layer.mixing_network.weight, layer.mixing_network.bias,
-                               idx, st, layer, layer.training)
+                               st.Wp, st.bp, st.Wq, st.bq, st.gamma, st.beta, st.Wm, st.bm, idx, st, layer, layer.training)
                 if layer.training:
                     for c in st.counters:
                         _layers._bump(c)
@@ -166,8 +196,9 @@ class PNAOriginal(nn.Module):
                     _layers._bump(c)
             if tw.graph_norm:
                 x = tape.apply(_RowScaleFn, x, snorm)
-            h = tape.apply(FCFn, x, layer.mixing_network.weight, layer.mixing_network.bias, None, None,
-                           h if layer.residual else None, FCSpec('leakyrelu', None))
+            h = tape.apply(FCFn, x, st.Wm, st.bm, None, None, h if layer.residual else None, FCSpec('leakyrelu', None))
+        if h.shape[1] != stacks.layers[-1].Mix:
+            h = tape.apply(_CopyColsFn, h, stacks.layers[-1].Mix)
         g.ndata['feat'] = h
         readout = tape.apply(ReadoutFn, h, idx, self._readout_codes)
         return self.output(readout)
@@ -177,13 +208,19 @@ class PNAOriginal(nn.Module):
 class _LayerStack:
     """Stacked buffers of ONE PNALayer (reference models/pna_original.py:264-319) and the block list that fills them.
 
-    T towers, F_i inputs / F_o outputs per tower, D = the layer's input width, F_e edge features, B = aggregators x scalers:
-      Wp [T F_i, 2 D + F_e]   rows of tower t = its pretrans Linear; columns: [h_src | h_dst | e] - with divide_input a tower reads
-                              only columns t F_i .. of h (zeros elsewhere)
-      Wq [T F_o, D + B T F_i] rows of tower t = its posttrans Linear; the aggregation of the stacked messages is
-                              [block (scaler, aggregator)][tower][feature], a tower's B column blocks are scattered accordingly
-      bp, bq, gamma, beta, running_mean, running_var: the towers' vectors side by side.
-    `values` / `grads`: one flat buffer each, the tensors above are views (row pitches padded to 4 floats)."""
+    T towers, F_i inputs / F_o outputs per tower, D = the layer's input width, F_e edge features, B = aggregators x scalers.
+    Every width is rounded up to a multiple of 4 floats (the yml's hidden_dim 90, edge_hidden_dim 70, 18 columns per tower are
+    none) so that every kernel of the layer takes its 16-byte form: Dp = pad(D) (the activations between the layers carry
+    zeros in the extra columns), Fep = pad(F_e), Fip = pad(F_i), Fop = pad(F_o) PER TOWER (a tower's columns never share a
+    float4 with its neighbour's), Mixp = pad(out_dim).  Zeros in the extra rows / columns of every stacked tensor: the extra
+    message / output columns are exactly zero in both directions and nothing is read back from them.
+      Wp [T Fip, 2 Dp + Fep]   rows of tower t = its pretrans Linear; columns: [h_src | h_dst | e] - with divide_input a tower reads
+                               only columns t F_i .. of h (zeros elsewhere)
+      Wq [T Fop, Dp + B T Fip] rows of tower t = its posttrans Linear; the aggregation of the stacked messages is
+                               [block (scaler, aggregator)][tower][feature], a tower's B column blocks are scattered accordingly
+      Wm [Mixp, T Fop]         the mixing network (models/pna_original.py:291), its input columns at the towers' padded positions
+      bp, bq, gamma, beta, running_mean, running_var, bm: the vectors side by side.
+    `values` / `grads`: one flat buffer each, the tensors above are views."""
 
     def __init__(self, layer, device):
         towers = list(layer.towers)
@@ -193,16 +230,20 @@ class _LayerStack:
         B = len(towers[0].aggregators) * len(towers[0].scalers)
         assert fc_post.in_dim == (B + 1) * Fi and fc_pre.out_dim == Fi and fc_post.out_dim == Fo
         self.has_bn = fc_post.batch_norm is not None
-        Mp, Kp, Mq, Kq = T * Fi, 2 * D + Fe, T * Fo, D + B * T * Fi
-        pad = lambda n: (n + 3) & ~3                              # noqa: E731
-        ldp, ldq = pad(Kp), pad(Kq)
-        sizes = [Mp * ldp, pad(Mp), Mq * ldq, pad(Mq), pad(Mq), pad(Mq)]
+        pad = (lambda n: (n + 3) & ~3) if PAD_WIDTHS else (lambda n: n)          # noqa: E731
+        pad4 = lambda n: (n + 3) & ~3                                            # noqa: E731
+        Dp, Fep, Fip, Fop, Mix = pad(D), pad(Fe), pad(Fi), pad(Fo), layer.out_dim
+        Mixp = pad(Mix)
+        self.D, self.Dp, self.Fe, self.Fep, self.Mix, self.Mixp = D, Dp, Fe, Fep, Mix, Mixp
+        Mp, Kp, Mq, Kq = T * Fip, 2 * Dp + Fep, T * Fop, Dp + B * T * Fip
+        ldp, ldq, ldm = pad4(Kp), pad4(Kq), Mq        # (csrc/tower.hip takes the mixing weights contiguous)
+        sizes = [Mp * ldp, pad4(Mp), Mq * ldq, pad4(Mq), pad4(Mq), pad4(Mq), pad4(Mixp * ldm), pad4(Mixp)]
         offs = [0]
         for n in sizes:
             offs.append(offs[-1] + n)
         self.values = torch.zeros(offs[-1], dtype=torch.float32, device=device)
         self.grads = torch.zeros(offs[-1], dtype=torch.float32, device=device)
-        self.stats = torch.zeros(2 * pad(Mq), dtype=torch.float32, device=device)
+        self.stats = torch.zeros(2 * pad4(Mq), dtype=torch.float32, device=device)
 
         def views(buf):
             Wp = buf[offs[0]:offs[1]].view(Mp, ldp)[:, :Kp]
@@ -211,13 +252,15 @@ class _LayerStack:
             bq = buf[offs[3]:offs[3] + Mq]
             gamma = buf[offs[4]:offs[4] + Mq] if self.has_bn else None
             beta = buf[offs[5]:offs[5] + Mq] if self.has_bn else None
-            return Wp, bp, Wq, bq, gamma, beta
-        self.Wp, self.bp, self.Wq, self.bq, self.gamma, self.beta = views(self.values)
+            Wm = buf[offs[6]:offs[7]].view(Mixp, ldm)[:, :Mq]
+            bm = buf[offs[7]:offs[7] + Mixp]
+            return Wp, bp, Wq, bq, gamma, beta, Wm, bm
+        self.Wp, self.bp, self.Wq, self.bq, self.gamma, self.beta, self.Wm, self.bm = views(self.values)
         self.g_views = views(self.grads)
-        self.rmean, self.rvar = self.stats[:Mq], self.stats[pad(Mq):pad(Mq) + Mq]
-        self.leaves = [v for v in (self.Wp, self.bp, self.Wq, self.bq, self.gamma, self.beta) if v is not None]
+        self.rmean, self.rvar = self.stats[:Mq], self.stats[pad4(Mq):pad4(Mq) + Mq]
+        self.leaves = [v for v in (self.Wp, self.bp, self.Wq, self.bq, self.gamma, self.beta, self.Wm, self.bm) if v is not None]
         self.leaf_grads = [v for v in self.g_views if v is not None]
-        self.bias_of = {id(self.Wp): self.bp, id(self.Wq): self.bq}
+        self.bias_of = {id(self.Wp): self.bp, id(self.Wq): self.bq, id(self.Wm): self.bm}
         self.pre_spec = FCSpec(fc_pre.activation, None)
         self._post_act = fc_post.activation
         bn = fc_post.batch_norm
@@ -230,21 +273,28 @@ class _LayerStack:
             pre, post = tw.pretrans.fully_connected[0], tw.posttrans.fully_connected[0]
             W, b = pre.linear.weight, pre.linear.bias
             c0 = t * Fi if layer.divide_input else 0
-            self.param_blocks += [(W, 0, Fi, Fi, Kp_t(W), 'Wp', t * Fi, c0), (W, Fi, Fi, Fi, Kp_t(W), 'Wp', t * Fi, D + c0)]
+            self.param_blocks += [(W, 0, Fi, Fi, Kp_t(W), 'Wp', t * Fip, c0), (W, Fi, Fi, Fi, Kp_t(W), 'Wp', t * Fip, Dp + c0)]
             if Fe:
-                self.param_blocks.append((W, 2 * Fi, Fi, Fe, Kp_t(W), 'Wp', t * Fi, 2 * D))
-            self.param_blocks.append((b, 0, 1, Fi, Fi, 'bp', 0, t * Fi))
+                self.param_blocks.append((W, 2 * Fi, Fi, Fe, Kp_t(W), 'Wp', t * Fip, 2 * Dp))
+            self.param_blocks.append((b, 0, 1, Fi, Fi, 'bp', 0, t * Fip))
             W2, b2 = post.linear.weight, post.linear.bias
-            self.param_blocks.append((W2, 0, Fo, Fi, Kp_t(W2), 'Wq', t * Fo, c0))
+            self.param_blocks.append((W2, 0, Fo, Fi, Kp_t(W2), 'Wq', t * Fop, c0))
             for k in range(B):
-                self.param_blocks.append((W2, Fi + k * Fi, Fo, Fi, Kp_t(W2), 'Wq', t * Fo, D + k * T * Fi + t * Fi))
-            self.param_blocks.append((b2, 0, 1, Fo, Fo, 'bq', 0, t * Fo))
+                self.param_blocks.append((W2, Fi + k * Fi, Fo, Fi, Kp_t(W2), 'Wq', t * Fop, Dp + k * T * Fip + t * Fip))
+            self.param_blocks.append((b2, 0, 1, Fo, Fo, 'bq', 0, t * Fop))
             self.params += [W, b, W2, b2]
             if self.has_bn:
                 m = post.batch_norm
-                self.param_blocks += [(m.weight, 0, 1, Fo, Fo, 'gamma', 0, t * Fo), (m.bias, 0, 1, Fo, Fo, 'beta', 0, t * Fo)]
-                self.stat_blocks += [(m.running_mean, 0, 1, Fo, Fo, 'rmean', 0, t * Fo), (m.running_var, 0, 1, Fo, Fo, 'rvar', 0, t * Fo)]
+                self.param_blocks += [(m.weight, 0, 1, Fo, Fo, 'gamma', 0, t * Fop), (m.bias, 0, 1, Fo, Fo, 'beta', 0, t * Fop)]
+                self.stat_blocks += [(m.running_mean, 0, 1, Fo, Fo, 'rmean', 0, t * Fop), (m.running_var, 0, 1, Fo, Fo, 'rvar', 0, t * Fop)]
                 self.params += [m.weight, m.bias]
+        # the mixing network reads the towers' outputs at their padded positions
+        Wm, bm = layer.mixing_network.weight, layer.mixing_network.bias
+        assert tuple(Wm.shape) == (Mix, T * Fo)
+        for t in range(T):
+            self.param_blocks.append((Wm, t * Fo, Mix, Fo, Kp_t(Wm), 'Wm', 0, t * Fop))
+        self.param_blocks.append((bm, 0, 1, Mix, Mix, 'bm', 0, 0))
+        self.params += [Wm, bm]
 
     def post_spec(self, training):
         sp = self._specs.get(training)
@@ -256,8 +306,8 @@ class _LayerStack:
     def dest(self, name, grads=False):
         if name in ('rmean', 'rvar'):
             return getattr(self, name)
-        i = ('Wp', 'bp', 'Wq', 'bq', 'gamma', 'beta').index(name)
-        return (self.g_views if grads else (self.Wp, self.bp, self.Wq, self.bq, self.gamma, self.beta))[i]
+        i = ('Wp', 'bp', 'Wq', 'bq', 'gamma', 'beta', 'Wm', 'bm').index(name)
+        return (self.g_views if grads else (self.Wp, self.bp, self.Wq, self.bq, self.gamma, self.beta, self.Wm, self.bm))[i]
 
 
 def Kp_t(W):

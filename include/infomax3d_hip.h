@@ -330,6 +330,11 @@ typedef struct {
     long ld_src, ld_dst;
 } I3dCopyBlock;
 int i3d_block_copy(const I3dCopyBlock* table /* device */, int n_blocks, int reverse, void* stream);
+/* dst[rows, cols_dst] (contiguous) = the first cols_dst columns of src[rows, cols_src] (contiguous), zeros where cols_dst >
+ * cols_src: the stacked towers run on activations whose width is rounded up to 4 floats (hidden_dim 90 of the reference's
+ * configs/pna_original.yml -> 92: every kernel then takes its 16-byte form); the embedding's output is widened once, the
+ * last layer's output cropped once, their gradients the other way round */
+int i3d_copy_cols(const float* src, int rows, int cols_src, float* dst, int cols_dst, void* stream);
 
 /* ---- one PNALayer of the tower variant from ONE call per direction (csrc/tower.hip) --------------------------------------
  * Replaces PNALayer.forward of reference models/pna_original.py:296-319 (all `towers` PNATower.forward, :239-261, the
