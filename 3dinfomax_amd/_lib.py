@@ -115,7 +115,8 @@ class TowerLayerArgs(ctypes.Structure):
                                      'gemm_workspace')]
                 + [('gemm_workspace_bytes', c_long)]
                 + [(n, _P) for n in ('out', 'grad_out', 'grad_h', 'grad_e', 'grad_Wp', 'grad_bp', 'grad_Wq', 'grad_bq', 'grad_gamma',
-                                     'grad_beta', 'grad_Wm', 'grad_bm')])
+                                     'grad_beta', 'grad_Wm', 'grad_bm')]
+                + [('n_towers', c_int)])
 
 
 ALL_GATHER_F32 = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p)
@@ -243,6 +244,9 @@ _SIGNATURES = {
     'i3d_last_error': (c_char_p, []),
     'i3d_embedding_sum_fwd': (c_int, [_P, _P, c_int, c_int, POINTER(c_void_p), c_int, _P, _P]),
     'i3d_embedding_sum_bwd': (c_int, [_P, _P, c_int, c_int, _P, c_int, POINTER(c_void_p), POINTER(c_int), _P]),
+    'i3d_pna_aggregate_fwd_towers': (c_int, [_P, _P, c_int, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_int, c_float, _P, _P]),
+    'i3d_pna_aggregate_bwd_towers': (c_int, [_P, _P, _P, c_int, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_int, c_float,
+                                             _P, _P]),
     'i3d_pna_aggregate_fwd': (c_int, [_P, _P, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_int, c_float, _P,
                                       _P]),
     'i3d_pna_aggregate_bwd': (c_int, [_P, _P, _P, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_int, c_float,
@@ -255,6 +259,8 @@ _SIGNATURES = {
     'i3d_gemm_f32_blocks': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_long, c_long, _P, c_int,
                                     c_int, c_long, c_int, _P, c_long, _P]),
     'i3d_gemm_f32_ws': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_long, _P]),
+    'i3d_gemm_f32_batched': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, c_long, _P, c_int, c_long, _P, c_int, c_long, c_int,
+                                     c_int, _P, c_long, _P]),
     'i3d_pna_combine_weights_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), _P, _P]),
     'i3d_pna_combine_weights_bwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), _P, _P]),
     'i3d_gemm_f32_grouped': (c_int, [c_int, c_int, c_int, c_int, _P, c_int, c_long, _P, _P, _P, c_int, c_long, _P, c_int,

@@ -57,10 +57,13 @@ __device__ __forceinline__ float4 aff4(const float4 x, const float4 mu, const fl
                        (x.w - mu.w) * sc.w + sh.w);
 }
 
-template <int MODE, bool MB16 = false>      // MB16: the messages are stored as bf16 (rows of F bf16 values; bf16 matmul mode)
+// TM (tower-major output, the tower variant's stacked layers: csrc/tower.hip): the features are `towers` groups of FVT chunks and a
+// node's row is [tower][block][feature of the tower] instead of [block][feature] - tower t's nblk blocks are ONE contiguous
+// range of columns, the K range of its own posttrans product (i3d_gemm_f32_batched)
+template <int MODE, bool MB16 = false, bool TM = false>      // MB16: the messages are stored as bf16 (rows of F bf16 values; bf16 matmul mode)
 __global__ void __launch_bounds__(256)
 pna_aggregate_fwd_kernel(const float4* __restrict__ e, const int* __restrict__ in_ptr, int N, int FV,
-                         AggCfg cfg, float4* __restrict__ out, const float4* __restrict__ aff) {
+                         AggCfg cfg, float4* __restrict__ out, const float4* __restrict__ aff, int FVT) {
     I3D_CHAIN_PRIO();
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)N * FV) return;
@@ -69,8 +72,13 @@ pna_aggregate_fwd_kernel(const float4* __restrict__ e, const int* __restrict__ i
     int D = end - beg;
     const int nblk = cfg.n_agg * cfg.n_scaler;
     float4* o = out + (long)v * nblk * FV + c;
+    const int BS = TM ? FVT : FV;                 // distance of two blocks of one feature chunk
+    if constexpr (TM) {
+        const int tw = c / FVT;
+        o = out + (long)v * nblk * FV + (long)tw * nblk * FVT + (c - tw * FVT);
+    }
     if (D <= 0) {  // DGL leaves zero rows for isolated nodes
-        for (int b = 0; b < nblk; ++b) o[(long)b * FV] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = 0; b < nblk; ++b) o[(long)b * BS] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
     const float4* p = e + (long)beg * FV + c;
@@ -127,20 +135,20 @@ pna_aggregate_fwd_kernel(const float4* __restrict__ e, const int* __restrict__ i
     scaler_values(cfg, D, amp, att);
     if (MODE == 2) {
         o[0] = mean;
-        o[(long)FV] = mx;
-        o[(long)2 * FV] = mn;
-        o[(long)3 * FV] = make_float4(sqrtf(var.x + 1e-5f), sqrtf(var.y + 1e-5f), sqrtf(var.z + 1e-5f), sqrtf(var.w + 1e-5f));
+        o[(long)BS] = mx;
+        o[(long)2 * BS] = mn;
+        o[(long)3 * BS] = make_float4(sqrtf(var.x + 1e-5f), sqrtf(var.y + 1e-5f), sqrtf(var.z + 1e-5f), sqrtf(var.w + 1e-5f));
     } else if (MODE == 1) {  // fully unrolled
         float4 sd = make_float4(sqrtf(var.x + 1e-5f), sqrtf(var.y + 1e-5f), sqrtf(var.z + 1e-5f), sqrtf(var.w + 1e-5f));
         float4 a[4] = {mean, mx, mn, sd};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[(long)k * FV] = a[k];
+        for (int k = 0; k < 4; ++k) o[(long)k * BS] = a[k];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            o[(long)(4 + k) * FV] = make_float4(a[k].x * amp, a[k].y * amp, a[k].z * amp, a[k].w * amp);
+            o[(long)(4 + k) * BS] = make_float4(a[k].x * amp, a[k].y * amp, a[k].z * amp, a[k].w * amp);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            o[(long)(8 + k) * FV] = make_float4(a[k].x * att, a[k].y * att, a[k].z * att, a[k].w * att);
+            o[(long)(8 + k) * BS] = make_float4(a[k].x * att, a[k].y * att, a[k].z * att, a[k].w * att);
     } else {
         for (int s = 0; s < cfg.n_scaler; ++s) {
             float sc = cfg.scaler[s] == I3D_SCALE_AMPLIFICATION ? amp
@@ -158,7 +166,7 @@ pna_aggregate_fwd_kernel(const float4* __restrict__ e, const int* __restrict__ i
                                         sqrtf(var.w + 1e-5f));
                 }
                 if (cfg.scaler[s] != I3D_SCALE_IDENTITY) a = make_float4(a.x * sc, a.y * sc, a.z * sc, a.w * sc);
-                o[(long)(s * cfg.n_agg + k) * FV] = a;
+                o[(long)(s * cfg.n_agg + k) * BS] = a;
             }
         }
     }
@@ -220,14 +228,15 @@ __device__ __forceinline__ float& comp(T& a, int i) {
 }
 
 // MODE as in the forward kernel (0: any list, 1: standard 12 blocks, 2: standard 4 blocks); MODE 1/2 need V = 4
-template <int V, int MODE = 0, bool MB16 = false>  // V = 4 (float4 items) or 1; MB16 (V = 4): messages stored as bf16
+template <int V, int MODE = 0, bool MB16 = false, bool TM = false>  // V = 4 (float4 items) or 1; MB16 (V = 4): messages stored as bf16; TM: tower-major gout
 // (the [N, 4F] form of the step sits one register above five waves per SIMD when left to the allocator: asked for)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V == 4 && MODE == 2 ? 5 : 1)))
 pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ e,
                          const int* __restrict__ in_ptr, int N, int F, AggCfg cfg, float* __restrict__ ge,
-                         const float* __restrict__ aff) {
+                         const float* __restrict__ aff, int FT) {
     I3D_CHAIN_PRIO();
     const int FV = F / V;
+    const int BS = TM ? FT : F;       // distance (floats) of two blocks of one feature in a node's gradient row
     // mean | scale | shift of the messages' BatchNorm is ONE [3F] vector for the whole launch: staged in LDS once per
     // workgroup (round 2 loaded it per (node, chunk) item: three more 16-byte global loads per lane, 12.3 -> 16.8 us).
     // Its global loads are issued FIRST and parked in registers; the LDS stores and the barrier come after the lane has
@@ -252,6 +261,10 @@ pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict
     if (!live) { beg = 0; D = 1; }
     const int nblk = cfg.n_agg * cfg.n_scaler;
     const float* go = gout + (long)v * nblk * F + (long)c * V;
+    if constexpr (TM) {               // row = [tower][block][feature of the tower]
+        const int f = c * V, tw = f / FT;
+        go = gout + (long)v * nblk * F + (long)tw * nblk * FT + (f - tw * FT);
+    }
     // (a lane without work reads its gradient row instead of a message row: a graph without edges has no message row at all)
     const float* p = live ? e + (long)beg * F + (long)c * V : go;
     const unsigned short* p16 = live ? reinterpret_cast<const unsigned short*>(e) + (long)beg * F + (long)c * 4
@@ -285,7 +298,7 @@ pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) gb[s][k] = *reinterpret_cast<const float4*>(go + (long)(s * 4 + k) * F);
+            for (int k = 0; k < 4; ++k) gb[s][k] = *reinterpret_cast<const float4*>(go + (long)(s * 4 + k) * BS);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const float sc = s == 0 ? 1.f : (s == 1 ? amp : att);
@@ -307,10 +320,10 @@ pna_aggregate_bwd_kernel(const float* __restrict__ gout, const float* __restrict
         for (int k = 0; k < cfg.n_agg; ++k) {
             float g[V];
             if (V == 4) {
-                float4 gg = *reinterpret_cast<const float4*>(go + (long)(s * cfg.n_agg + k) * F);
+                float4 gg = *reinterpret_cast<const float4*>(go + (long)(s * cfg.n_agg + k) * BS);
                 g[0] = gg.x; g[1 % V] = gg.y; g[2 % V] = gg.z; g[3 % V] = gg.w;
             } else {
-                g[0] = go[(long)(s * cfg.n_agg + k) * F];
+                g[0] = go[(long)(s * cfg.n_agg + k) * BS];
             }
 #pragma unroll
             for (int i = 0; i < V; ++i) {
@@ -564,22 +577,64 @@ extern "C" int i3d_pna_aggregate_fwd_ex(const void* e_, int e_bf16, const float*
         dim3 grid(cdiv(items, 256));
         if (e_bf16) {
             if (is_std_cfg(cfg))
-                K4_FWD_LAUNCH((pna_aggregate_fwd_kernel<1, true>), grid, (const float4*)e, in_ptr, num_nodes, FV, cfg, (float4*)out, (const float4*)aff);
+                K4_FWD_LAUNCH((pna_aggregate_fwd_kernel<1, true>), grid, (const float4*)e, in_ptr, num_nodes, FV, cfg, (float4*)out, (const float4*)aff, 0);
             else if (is_ident_cfg(cfg))
-                K4_FWD_LAUNCH((pna_aggregate_fwd_kernel<2, true>), grid, (const float4*)e, in_ptr, num_nodes, FV, cfg, (float4*)out, (const float4*)aff);
+                K4_FWD_LAUNCH((pna_aggregate_fwd_kernel<2, true>), grid, (const float4*)e, in_ptr, num_nodes, FV, cfg, (float4*)out, (const float4*)aff, 0);
             else
-                K4_FWD_LAUNCH((pna_aggregate_fwd_kernel<0, true>), grid, (const float4*)e, in_ptr, num_nodes, FV, cfg, (float4*)out, (const float4*)aff);
+                K4_FWD_LAUNCH((pna_aggregate_fwd_kernel<0, true>), grid, (const float4*)e, in_ptr, num_nodes, FV, cfg, (float4*)out, (const float4*)aff, 0);
         } else if (is_std_cfg(cfg))
-            K4_FWD_LAUNCH(pna_aggregate_fwd_kernel<1>, grid, (const float4*)e, in_ptr, num_nodes, FV, cfg, (float4*)out, (const float4*)aff);
+            K4_FWD_LAUNCH(pna_aggregate_fwd_kernel<1>, grid, (const float4*)e, in_ptr, num_nodes, FV, cfg, (float4*)out, (const float4*)aff, 0);
         else if (is_ident_cfg(cfg))      // (tried, not better back to back at batch 512: two items per lane 9.4 us vs 8.7 us;
             //                              one wavefront per node with scalar row-pointer loads 8.8 us vs 8.8 us)
-            K4_FWD_LAUNCH(pna_aggregate_fwd_kernel<2>, grid, (const float4*)e, in_ptr, num_nodes, FV, cfg, (float4*)out, (const float4*)aff);
+            K4_FWD_LAUNCH(pna_aggregate_fwd_kernel<2>, grid, (const float4*)e, in_ptr, num_nodes, FV, cfg, (float4*)out, (const float4*)aff, 0);
         else
-            K4_FWD_LAUNCH(pna_aggregate_fwd_kernel<0>, grid, (const float4*)e, in_ptr, num_nodes, FV, cfg, (float4*)out, (const float4*)aff);
+            K4_FWD_LAUNCH(pna_aggregate_fwd_kernel<0>, grid, (const float4*)e, in_ptr, num_nodes, FV, cfg, (float4*)out, (const float4*)aff, 0);
     } else {
         long items = (long)num_nodes * feat;
         K4_FWD_LAUNCH(pna_aggregate_fwd_scalar_kernel, dim3(cdiv(items, 256)), e, in_ptr, num_nodes, feat, cfg, out);
     }
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+// tower-major forms (include/infomax3d_hip.h): fp32 messages, feat and tower_feat multiples of 4
+extern "C" int i3d_pna_aggregate_fwd_towers(const float* e, const int* in_ptr, int num_nodes, int feat, int tower_feat,
+                                            const int* aggregators, int n_aggregators, const int* scalers, int n_scalers,
+                                            int force_scalers, float avg_d_log, float* out, void* stream) {
+    I3D_CHECK_ARG(num_nodes >= 0 && feat > 0 && tower_feat > 0 && feat % 4 == 0 && tower_feat % 4 == 0 && feat % tower_feat == 0,
+                  "feat and tower_feat must be multiples of 4, tower_feat a divisor of feat");
+    AggCfg cfg;
+    I3D_CHECK_ARG(make_cfg(aggregators, n_aggregators, scalers, n_scalers, force_scalers, avg_d_log, cfg) == 0,
+                  "bad aggregator/scaler list");
+    if (num_nodes == 0) return I3D_OK;
+    const int FV = feat / 4;
+    dim3 grid(cdiv((long)num_nodes * FV, 256));
+    if (is_std_cfg(cfg))
+        hipLaunchKernelGGL((pna_aggregate_fwd_kernel<1, false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)e, in_ptr,
+                           num_nodes, FV, cfg, (float4*)out, (const float4*)nullptr, tower_feat / 4);
+    else
+        hipLaunchKernelGGL((pna_aggregate_fwd_kernel<0, false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)e, in_ptr,
+                           num_nodes, FV, cfg, (float4*)out, (const float4*)nullptr, tower_feat / 4);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_pna_aggregate_bwd_towers(const float* grad_out, const float* e, const int* in_ptr, int num_nodes, int feat,
+                                            int tower_feat, const int* aggregators, int n_aggregators, const int* scalers,
+                                            int n_scalers, int force_scalers, float avg_d_log, float* grad_e, void* stream) {
+    I3D_CHECK_ARG(num_nodes >= 0 && feat > 0 && tower_feat > 0 && feat % 4 == 0 && tower_feat % 4 == 0 && feat % tower_feat == 0,
+                  "feat and tower_feat must be multiples of 4, tower_feat a divisor of feat");
+    AggCfg cfg;
+    I3D_CHECK_ARG(make_cfg(aggregators, n_aggregators, scalers, n_scalers, force_scalers, avg_d_log, cfg) == 0,
+                  "bad aggregator/scaler list");
+    if (num_nodes == 0) return I3D_OK;
+    const long items = (long)num_nodes * (feat / 4);
+    if (is_std_cfg(cfg))
+        hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 1, false, true>), dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream,
+                           grad_out, e, in_ptr, num_nodes, feat, cfg, grad_e, (const float*)nullptr, tower_feat);
+    else
+        hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 0, false, true>), dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream,
+                           grad_out, e, in_ptr, num_nodes, feat, cfg, grad_e, (const float*)nullptr, tower_feat);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }
@@ -616,26 +671,26 @@ extern "C" int i3d_pna_aggregate_bwd_ex(const float* grad_out, const void* e_, i
         if (e_bf16) {
             if (is_std_cfg(cfg))
                 hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 1, true>), dim3(cdiv(items, 256)), dim3(256), 0, s, grad_out, e, in_ptr,
-                                   num_nodes, feat, cfg, grad_e, aff);
+                                   num_nodes, feat, cfg, grad_e, aff, 0);
             else if (is_ident_cfg(cfg))
                 hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 2, true>), dim3(cdiv(items, 256)), dim3(256), 0, s, grad_out, e, in_ptr,
-                                   num_nodes, feat, cfg, grad_e, aff);
+                                   num_nodes, feat, cfg, grad_e, aff, 0);
             else
                 hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 0, true>), dim3(cdiv(items, 256)), dim3(256), 0, s, grad_out, e, in_ptr,
-                                   num_nodes, feat, cfg, grad_e, aff);
+                                   num_nodes, feat, cfg, grad_e, aff, 0);
         } else if (is_std_cfg(cfg))
             hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 1>), dim3(cdiv(items, 256)), dim3(256), 0, s, grad_out, e, in_ptr,
-                               num_nodes, feat, cfg, grad_e, aff);
+                               num_nodes, feat, cfg, grad_e, aff, 0);
         else if (is_ident_cfg(cfg))
             hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 2>), dim3(cdiv(items, 256)), dim3(256), 0, s, grad_out, e, in_ptr,
-                               num_nodes, feat, cfg, grad_e, aff);
+                               num_nodes, feat, cfg, grad_e, aff, 0);
         else
             hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 0>), dim3(cdiv(items, 256)), dim3(256), 0, s, grad_out, e, in_ptr,
-                               num_nodes, feat, cfg, grad_e, aff);
+                               num_nodes, feat, cfg, grad_e, aff, 0);
     } else {
         long items = (long)num_nodes * feat;
         hipLaunchKernelGGL((pna_aggregate_bwd_kernel<1, 0>), dim3(cdiv(items, 256)), dim3(256), 0, s, grad_out, e, in_ptr,
-                           num_nodes, feat, cfg, grad_e, aff);
+                           num_nodes, feat, cfg, grad_e, aff, 0);
     }
     I3D_CHECK_LAUNCH();
     return I3D_OK;

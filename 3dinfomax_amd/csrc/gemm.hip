@@ -88,6 +88,10 @@ struct GemmArgs {
     float* DZ;              // [rows, K] out, row pitch lddz
     int lddz;
     float* bw_zero;         // [K] or null: zero-filled (the bias gradient in front of a BatchNorm without activation is exactly zero)
+    // batched products (gemm_f32_kernel only; i3d_gemm_f32_batched): blockIdx.z = batch * z_splits + K-slice, batch b works on
+    // A + b a_batch, B + b b_batch, C + b c_batch (floats) - the diagonal blocks of a block-diagonal product in ONE launch
+    int n_batch, z_splits;  // n_batch <= 1: plain product
+    long a_batch, b_batch, c_batch;
 };
 
 __device__ __forceinline__ int swz(int k, int idx) { return idx ^ ((((k) ^ (k >> 2)) & 1) << 4); }
@@ -735,13 +739,19 @@ gemm_f32_kernel(GemmArgs g) {
     I3D_CHAIN_PRIO();
     int bx, by, bz;
     xcd_tile(bx, by, bz);
+    const int slice = bz;              // (slab index: one per batch and K-slice)
+    if (g.n_batch > 1) {               // (uniform) batched product: this workgroup's batch, then its K-slice
+        const int bb = bz / g.z_splits;
+        bz -= bb * g.z_splits;
+        g.A += bb * g.a_batch; g.B += bb * g.b_batch; g.C += bb * g.c_batch;
+    }
     const int k_begin = bz * g.k_per_split;
     const int k_end = min(g.K, k_begin + g.k_per_split);
     if (g.slab != nullptr) {           // every slice writes (zeros for an empty one): the reduction reads them all
         GemmArgs gl = g;
         gl.ldc = g.N; gl.accumulate = 0; gl.atomic_out = 0; gl.c_vec = (g.N % 4 == 0); gl.bias = nullptr;
         gl.c_split = 0x7fffffff; gl.c_delta = 0;
-        gemm_body<S, VEC, A_KC, B_KC, false, 0, BF16>(gl, bx, by, min(k_begin, g.K), k_end, g.slab + (long)bz * g.M * g.N, nullptr,
+        gemm_body<S, VEC, A_KC, B_KC, false, 0, BF16>(gl, bx, by, min(k_begin, g.K), k_end, g.slab + (long)slice * g.M * g.N, nullptr,
                                                       false);
         return;
     }
@@ -959,7 +969,7 @@ template <class S> constexpr bool split_shape() {      // the 64x64 and 64x32 ti
 
 template <class S>
 static void launch(const GemmArgs& g, int layout, int splits, bool vec, hipStream_t s) {
-    dim3 grid(cdiv(g.M, S::BM), cdiv(g.N, S::BN), splits), block(S::NT);
+    dim3 grid(cdiv(g.M, S::BM), cdiv(g.N, S::BN), splits * (g.n_batch > 1 ? g.n_batch : 1)), block(S::NT);
     if constexpr (split_shape<S>()) {
         if (!g_matmul_bf16 && g_fp32_split && vec && layout <= 1) {
             if (layout == 0) hipLaunchKernelGGL((gemm_f32_kernel<S, true, true, true, 2>), grid, block, 0, s, g);
@@ -1160,6 +1170,8 @@ struct Extra {
     long b_delta = 0, c_delta = 0, b_view_floats = 0;
     const float* post_aff = nullptr;   // SlabReduce::post_aff / post_row
     const float* post_row = nullptr;
+    int n_batch = 1;                   // GemmArgs::n_batch ...
+    long a_batch = 0, b_batch = 0, c_batch = 0;
 };
 
 static int fill_views(GemmArgs& g, int trans_a, int trans_b, int M, int N, int K, int lda, int ldb, const Extra& ex) {
@@ -1200,10 +1212,17 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     g.c_vec = (((uintptr_t)C & 15) == 0) && (ldc % 4 == 0);
     // fast path: 16-byte loads need aligned pointers / leading dimensions and contiguous extents that are
     // multiples of 4 (K for k-contiguous operands, M or N for the others)
+    const int nb = ex.n_batch > 1 ? ex.n_batch : 1;
     const bool vec = a_al && b_al && ((trans_a ? M : K) % 4 == 0) && ((trans_b ? K : N) % 4 == 0) &&
-                     (ex.b_group_stride % 4 == 0) && (ex.b_delta % 4 == 0);
-    if (ex.c_delta % 4 != 0) g.c_vec = 0;
+                     (ex.b_group_stride % 4 == 0) && (ex.b_delta % 4 == 0) && (nb == 1 || (ex.a_batch % 4 == 0 && ex.b_batch % 4 == 0));
+    if (ex.c_delta % 4 != 0 || (nb > 1 && ex.c_batch % 4 != 0)) g.c_vec = 0;
     const int layout = trans_a ? (trans_b ? 3 : 2) : (trans_b ? 0 : 1);
+    if (nb > 1) {
+        I3D_CHECK_ARG(nb <= 32 && layout != 3 && ex.m_rows == nullptr && ex.tile_group == nullptr && ex.b_split == 0x7fffffff &&
+                          ex.c_split == 0x7fffffff && bias == nullptr && ex.post_aff == nullptr,
+                      "batched product: plain operands, at most 32 batches");
+        g.n_batch = nb; g.a_batch = ex.a_batch; g.b_batch = ex.b_batch; g.c_batch = ex.c_batch;
+    }
 
     if (layout == 3) {
         I3D_CHECK_ARG(ex.m_rows == nullptr && ex.tile_group == nullptr, "row indirection needs a k-contiguous A");
@@ -1220,11 +1239,11 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     // 133440 --all-cfgs --wide-sweep`, profiles/r02_gemm_sweep_B4096.log: the 128x128 tiling the first version switched
     // to at >= 4096 tiles is 20-30 % slower than 64x64 on every shape of the step).
     int cfg;
-    const long tiles64 = (long)cdiv(M, 64) * cdiv(N, 64);
+    const long tiles64 = (long)cdiv(M, 64) * cdiv(N, 64) * nb;
     const bool have_ws = ex.workspace != nullptr && (((uintptr_t)ex.workspace & 15) == 0) && ex.m_rows == nullptr;
     if (trans_a && M <= 32 && N <= 32) cfg = 8;
     else if (trans_a && have_ws && tiles64 <= 16) cfg = 8;   // small weight gradients: 32x32 tiles, slices through the scratch
-    else if (N <= 32) cfg = 1;
+    else if (N <= 32) cfg = (nb > 1 && !trans_a && trans_b) ? 11 : 1;   // (batched: many 64x32 tiles instead of few 256x32 ones)
     else if (trans_a && tiles64 < 512) cfg = 3;   // weight gradients: few output tiles, long K
     else cfg = 2;
     if (ex.tile_group != nullptr) cfg = 2;        // the group padding of m_rows is 64 rows
@@ -1241,7 +1260,7 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     // have a quarter of the MFMA cycles per k and wave (tools/small_gemm_sweep.py, profiles/r03_small_gemm_sweep.txt: K = 600 18.9 -> 9.6 us,
     // K = 200 9.0 -> 5.3 us,
     // break-even at ~1000 tiles); weight-gradient layouts only while K is short (long K: slices through the scratch, above)
-    const long tiles32 = (long)cdiv(M, 32) * cdiv(N, 32);
+    const long tiles32 = (long)cdiv(M, 32) * cdiv(N, 32) * nb;
     static const bool small_tiles = [] { const char* e = getenv("I3D_SMALL_TILES"); return e == nullptr || e[0] != '0'; }();
     if (small_tiles && ex.tile_group == nullptr && N > 32 && tiles32 <= 1024 && (!trans_a || K < 2048)) cfg = 8;
     if (g_matmul_bf16 && vec && (cfg == 9 || cfg == 11) && bf16_bk() != 16)      // bf16 LDS image: longer K-tiles
@@ -1252,7 +1271,7 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
         cfg = force_cfg;
     }
     const int bm = CFG_BM[cfg], bn = CFG_BN[cfg], BK = CFG_BK[cfg];
-    int tiles = cdiv(M, bm) * cdiv(N, bn);
+    int tiles = cdiv(M, bm) * cdiv(N, bn) * nb;
     int splits = 1;
     // split-K ONLY for the row-reduction GEMMs of the backward pass (trans_a: dW = dY^T X, K = number of rows).
     // Forward GEMMs stay single-pass and bit-deterministic, so that the arg-max/arg-min routing of the aggregators and
@@ -1279,8 +1298,10 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     splits = K > 0 ? cdiv(K, kps) : 1;
     g.k_per_split = kps;
     g.atomic_out = splits > 1;
-    const bool use_slab = splits > 1 && ex.workspace != nullptr && (long)splits * M * N * 4 <= ex.workspace_bytes &&
+    const bool use_slab = splits > 1 && ex.workspace != nullptr && (long)splits * nb * M * N * 4 <= ex.workspace_bytes &&
                           (((uintptr_t)ex.workspace & 15) == 0) && ex.m_rows == nullptr;
+    g.z_splits = splits;
+    I3D_CHECK_ARG(nb == 1 || splits == 1 || use_slab, "batched product with K-slices needs the scratch");
     if (use_slab) {
         g.slab = (float*)ex.workspace;
         g.atomic_out = 0;
@@ -1319,7 +1340,8 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     if (use_slab) {
         SlabReduce r;
         r.slab = g.slab; r.C = C; r.bias = bias; r.M = M; r.N = N; r.ldc = ldc; r.accumulate = accumulate ? 1 : 0;
-        r.n_groups = 1; r.c_group_stride = 0; r.seg_ptr[0] = 0; r.seg_ptr[1] = splits;
+        r.n_groups = nb; r.c_group_stride = ex.c_batch;
+        for (int b = 0; b <= nb; ++b) r.seg_ptr[b] = b * splits;
         r.c_split = ex.c_split; r.c_delta = ex.c_delta;
         r.post_aff = ex.post_aff; r.post_row = ex.post_row;
         launch_slab_reduce(r, s);
@@ -1495,6 +1517,17 @@ extern "C" int i3d_gemm_f32_blocks(int trans_a, int trans_b, int M, int N, int K
     if (b_split > 0) { ex.b_split = b_split; ex.b_delta = b_delta; ex.b_view_floats = b_view_floats; }
     if (c_split > 0) { ex.c_split = c_split; ex.c_delta = c_delta; }
     I3D_CHECK_ARG(!(trans_a && trans_b), "layout not supported");
+    return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, nullptr, accumulate, -1, 0, ex, stream);
+}
+
+// n_batch products of one shape in ONE launch (include/infomax3d_hip.h)
+extern "C" int i3d_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, long a_batch,
+                                    const float* B, int ldb, long b_batch, float* C, int ldc, long c_batch, int n_batch,
+                                    int accumulate, void* workspace, long workspace_bytes, void* stream) {
+    I3D_CHECK_ARG(n_batch >= 1 && !(trans_a && trans_b), "n_batch >= 1, layout not supported");
+    Extra ex;
+    ex.workspace = workspace; ex.workspace_bytes = workspace_bytes;
+    ex.n_batch = n_batch; ex.a_batch = a_batch; ex.b_batch = b_batch; ex.c_batch = c_batch;
     return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, nullptr, accumulate, -1, 0, ex, stream);
 }
 

@@ -63,8 +63,12 @@ bool args_ok(const I3dTowerLayerArgs* a) {
     return a != nullptr && a->num_nodes > 0 && a->num_edges > 0 && a->f_in > 0 && a->f_msg > 0 && a->f_out > 0 && a->f_edge >= 0 &&
            a->h != nullptr && a->Wp != nullptr && a->Wq != nullptr && a->Wm != nullptr && a->saved != nullptr && a->scratch != nullptr &&
            a->workspace != nullptr && a->n_aggregators >= 1 && a->n_aggregators <= 8 && a->n_scalers >= 1 && a->n_scalers <= 4 &&
-           (a->f_edge == 0 || a->e != nullptr) && a->ldp >= 2 * a->f_in + a->f_edge && a->ldq >= a->f_in + a->n_aggregators * a->n_scalers * a->f_msg;
+           (a->f_edge == 0 || a->e != nullptr) && a->ldp >= 2 * a->f_in + a->f_edge && a->ldq >= a->f_in + a->n_aggregators * a->n_scalers * a->f_msg &&
+           (a->n_towers <= 1 || (a->n_towers <= 32 && a->f_msg % (4 * a->n_towers) == 0 && a->f_out % (4 * a->n_towers) == 0));
 }
+
+// the posttrans products on the aggregation as `n_towers` diagonal blocks (I3dTowerLayerArgs::n_towers)
+inline bool tower_major(const I3dTowerLayerArgs* a) { return a->n_towers > 1; }
 
 }  // namespace
 
@@ -81,11 +85,21 @@ extern "C" int i3d_tower_layer_fwd(const I3dTowerLayerArgs* a, void* stream) {
     TRY(i3d_gemm_f32(0, 1, N, Mp, D, a->h, D, a->Wp + D, a->ldp, P + Mp, 2 * Mp, nullptr, 0, stream));
     if (Fe > 0) TRY(i3d_gemm_f32(0, 1, E, Mp, Fe, a->e, Fe, a->Wp + 2 * D, a->ldp, Q, Mp, nullptr, 0, stream));
     TRY(i3d_edge_combine_fwd(P, 2 * Mp, Fe > 0 ? Q : nullptr, nullptr, a->bp, a->src_s, a->dst_s, E, Mp, s.msg, stream));
-    TRY(i3d_pna_aggregate_fwd(s.msg, a->in_ptr, N, Mp, a->aggregators, a->n_aggregators, a->scalers, a->n_scalers, 1, a->avg_d_log,
-                              s.agg, stream));
+    const bool tm = tower_major(a);
+    const int T = tm ? a->n_towers : 1, Ft = Mp / T, Fo = Mq / T;
+    if (tm)
+        TRY(i3d_pna_aggregate_fwd_towers(s.msg, a->in_ptr, N, Mp, Ft, a->aggregators, a->n_aggregators, a->scalers, a->n_scalers, 1,
+                                         a->avg_d_log, s.agg, stream));
+    else
+        TRY(i3d_pna_aggregate_fwd(s.msg, a->in_ptr, N, Mp, a->aggregators, a->n_aggregators, a->scalers, a->n_scalers, 1, a->avg_d_log,
+                                  s.agg, stream));
     // posttrans on [h | agg] without the concatenation
     TRY(i3d_gemm_f32(0, 1, N, Mq, D, a->h, D, a->Wq, a->ldq, s.lin, Mq, a->bq, 0, stream));
-    TRY(i3d_gemm_f32(0, 1, N, Mq, B * Mp, s.agg, B * Mp, a->Wq + D, a->ldq, s.lin, Mq, nullptr, 1, stream));
+    if (tm)     // tower t: lin[:, t Fo ..] += agg[:, t B Ft ..] Wq[t Fo .., D + t B Ft ..]^T
+        TRY(i3d_gemm_f32_batched(0, 1, N, Fo, B * Ft, s.agg, B * Mp, (long)B * Ft, a->Wq + D, a->ldq, (long)Fo * a->ldq + (long)B * Ft,
+                                 s.lin, Mq, Fo, T, 1, nullptr, 0, stream));
+    else
+        TRY(i3d_gemm_f32(0, 1, N, Mq, B * Mp, s.agg, B * Mp, a->Wq + D, a->ldq, s.lin, Mq, nullptr, 1, stream));
     const float* yv = s.lin;
     if (a->gamma != nullptr) {
         if (a->training) {
@@ -147,16 +161,30 @@ extern "C" int i3d_tower_layer_bwd(const I3dTowerLayerArgs* a, void* stream) {
         gl = g_lin;
     }
     // posttrans Linear on [h | agg]
-    TRY(i3d_gemm_f32_ws(1, 0, Mq, B * Mp, N, gl, Mq, s.agg, B * Mp, a->grad_Wq + D, a->ldgq, nullptr, 0, ws, wsb, stream));
+    const bool tm = tower_major(a);
+    const int T = tm ? a->n_towers : 1, Ft = Mp / T, Fo = Mq / T;
+    if (tm)     // (the blocks off the diagonal of grad_Wq are not written: nothing reads them)
+        TRY(i3d_gemm_f32_batched(1, 0, Fo, B * Ft, N, gl, Mq, Fo, s.agg, B * Mp, (long)B * Ft, a->grad_Wq + D, a->ldgq,
+                                 (long)Fo * a->ldgq + (long)B * Ft, T, 0, ws, wsb, stream));
+    else
+        TRY(i3d_gemm_f32_ws(1, 0, Mq, B * Mp, N, gl, Mq, s.agg, B * Mp, a->grad_Wq + D, a->ldgq, nullptr, 0, ws, wsb, stream));
     TRY(i3d_gemm_f32_ws(1, 0, Mq, D, N, gl, Mq, a->h, D, a->grad_Wq, a->ldgq, nullptr, 0, ws, wsb, stream));
     TRY(i3d_colsum(gl, nullptr, N, Mq, a->grad_bq, a->workspace, stream));
-    TRY(i3d_gemm_f32(0, 0, N, B * Mp, Mq, gl, Mq, a->Wq + D, a->ldq, g_agg, B * Mp, nullptr, 0, stream));
+    if (tm)
+        TRY(i3d_gemm_f32_batched(0, 0, N, B * Ft, Fo, gl, Mq, Fo, a->Wq + D, a->ldq, (long)Fo * a->ldq + (long)B * Ft, g_agg, B * Mp,
+                                 (long)B * Ft, T, 0, nullptr, 0, stream));
+    else
+        TRY(i3d_gemm_f32(0, 0, N, B * Mp, Mq, gl, Mq, a->Wq + D, a->ldq, g_agg, B * Mp, nullptr, 0, stream));
     // dL/dh: the residual's share (grad_out itself), the posttrans block's, the edge block's below
     TRY(i3d_gemm_f32(0, 0, N, D, Mq, gl, Mq, a->Wq, a->ldq, a->grad_h, D, nullptr, 0, stream));
     if (a->residual) TRY(i3d_add_inplace(a->grad_h, a->grad_out, (long)N * D, stream));
     // aggregation
-    TRY(i3d_pna_aggregate_bwd(g_agg, s.msg, a->in_ptr, N, Mp, a->aggregators, a->n_aggregators, a->scalers, a->n_scalers, 1,
-                              a->avg_d_log, g_msg, stream));
+    if (tm)
+        TRY(i3d_pna_aggregate_bwd_towers(g_agg, s.msg, a->in_ptr, N, Mp, Ft, a->aggregators, a->n_aggregators, a->scalers,
+                                         a->n_scalers, 1, a->avg_d_log, g_msg, stream));
+    else
+        TRY(i3d_pna_aggregate_bwd(g_agg, s.msg, a->in_ptr, N, Mp, a->aggregators, a->n_aggregators, a->scalers, a->n_scalers, 1,
+                                  a->avg_d_log, g_msg, stream));
     // pretrans: msg[j] = P[src_j, :Mp] + P[dst_j, Mp:] + Q[j] + bp
     TRY(i3d_segment_sum(g_msg, Mp, a->out_ptr, a->out_epos, N, Mp, 0, gP, 2 * Mp, stream));
     TRY(i3d_segment_sum(g_msg, Mp, a->in_ptr, nullptr, N, Mp, 0, gP + Mp, 2 * Mp, stream));

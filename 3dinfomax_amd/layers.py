@@ -740,18 +740,18 @@ class AggregateFn(torch.autograd.Function):
     """K4: segmented mean/max/min/std x degree scalers (reference models/pna.py:206, 221-235)."""
 
     @staticmethod
-    def forward(ctx, e, index, aggregators, scalers, avg_d_log, force_scalers=False):
+    def forward(ctx, e, index, aggregators, scalers, avg_d_log, force_scalers=False, tower_feat=0):
         e = e.contiguous()
-        ctx.cfg = (index, aggregators, scalers, avg_d_log, force_scalers)
+        ctx.cfg = (index, aggregators, scalers, avg_d_log, force_scalers, tower_feat)
         ctx.save_for_backward(e)
-        return ops.pna_aggregate_fwd(e, index.in_ptr, index.num_nodes, aggregators, scalers, avg_d_log, force_scalers)
+        return ops.pna_aggregate_fwd(e, index.in_ptr, index.num_nodes, aggregators, scalers, avg_d_log, force_scalers, tower_feat)
 
     @staticmethod
     def backward(ctx, grad_out):
         (e,) = ctx.saved_tensors
-        index, aggregators, scalers, avg, force = ctx.cfg
+        index, aggregators, scalers, avg, force, tower_feat = ctx.cfg
         return ops.pna_aggregate_bwd(grad_out.contiguous(), e, index.in_ptr, index.num_nodes, aggregators, scalers,
-                                     avg, force), None, None, None, None, None
+                                     avg, force, tower_feat), None, None, None, None, None, None
 
 
 class ReadoutFn(torch.autograd.Function):

@@ -156,13 +156,19 @@ MULTIHOT_EMB_BWD = os.environ.get('I3D_MULTIHOT_EMB_BWD', '1') != '0'
 
 
 # ---- K4 / K6 ---------------------------------------------------------------------------------------------
-def pna_aggregate_fwd(e, in_ptr, num_nodes, aggregators, scalers, avg_d_log=1.0, force_scalers=False):
+def pna_aggregate_fwd(e, in_ptr, num_nodes, aggregators, scalers, avg_d_log=1.0, force_scalers=False, tower_feat=0):
+    """tower_feat > 0: the output row is [tower][block][feature of the tower] (include/infomax3d_hip.h: i3d_pna_aggregate_fwd_towers)"""
     _chk(e)
     _chk(in_ptr, torch.int32)
     feat = e.shape[1]
     n_sc = len(scalers) if (len(scalers) > 1 or force_scalers) else 1
     out = torch.empty(num_nodes, n_sc * len(aggregators) * feat, dtype=torch.float32, device=e.device)
     L = _lib.load()
+    if tower_feat:
+        check(L.i3d_pna_aggregate_fwd_towers(_p(e), _p(in_ptr), num_nodes, feat, tower_feat, int_array(aggregators), len(aggregators),
+                                             int_array(scalers), len(scalers), int(force_scalers), float(avg_d_log), _p(out), _stream()),
+              'i3d_pna_aggregate_fwd_towers')
+        return out
     timed = KERNEL_TIMERS is not None
     if timed:   # bench.py: HIP events on the launch stream around the roofline kernel
         t0, t1 = RawEvent(), RawEvent()
@@ -176,11 +182,16 @@ def pna_aggregate_fwd(e, in_ptr, num_nodes, aggregators, scalers, avg_d_log=1.0,
     return out
 
 
-def pna_aggregate_bwd(grad_out, e, in_ptr, num_nodes, aggregators, scalers, avg_d_log=1.0, force_scalers=False):
+def pna_aggregate_bwd(grad_out, e, in_ptr, num_nodes, aggregators, scalers, avg_d_log=1.0, force_scalers=False, tower_feat=0):
     _chk(grad_out)
     _chk(e)
     grad_e = torch.empty_like(e)
     L = _lib.load()
+    if tower_feat:
+        check(L.i3d_pna_aggregate_bwd_towers(_p(grad_out), _p(e), _p(in_ptr), num_nodes, e.shape[1], tower_feat, int_array(aggregators),
+                                             len(aggregators), int_array(scalers), len(scalers), int(force_scalers), float(avg_d_log),
+                                             _p(grad_e), _stream()), 'i3d_pna_aggregate_bwd_towers')
+        return grad_e
     check(L.i3d_pna_aggregate_bwd(_p(grad_out), _p(e), _p(in_ptr), num_nodes, e.shape[1], int_array(aggregators),
                                   len(aggregators), int_array(scalers), len(scalers), int(force_scalers), float(avg_d_log),
                                   _p(grad_e), _stream()), 'i3d_pna_aggregate_bwd')

@@ -26,6 +26,9 @@ TOWER_STACK = os.environ.get('I3D_TOWER_STACK', '1') != '0'
 # I3D_TOWER_PAD=0: the stacked layers at the model's own widths (hidden_dim 90 / edge_hidden_dim 70 of the yml: every kernel of the
 # layer in its unaligned form - 4.8 ms per step at batch 512 against the padded form's)
 PAD_WIDTHS = os.environ.get('I3D_TOWER_PAD', '1') != '0'
+# I3D_TOWER_BLOCKS=0: the posttrans products of a stacked layer as ONE dense product on the zero-padded stacked weight instead of
+# `towers` diagonal blocks
+TOWER_BLOCKS = os.environ.get('I3D_TOWER_BLOCKS', '1') != '0'
 
 
 class _RowScaleFn(torch.autograd.Function):
@@ -189,7 +192,7 @@ class PNAOriginal(nn.Module):
                         _layers._bump(c)
                 continue
             msg = tape.apply(EdgeFCFn, h, e_sorted if tw.edge_features else None, st.Wp, st.bp, None, None, idx, st.pre_spec, None)
-            agg = tape.apply(AggregateFn, msg, idx, tw.aggregators, tw.scalers, float(tw.avg_d), True)
+            agg = tape.apply(AggregateFn, msg, idx, tw.aggregators, tw.scalers, float(tw.avg_d), True, st.Fip if st.tower_major else 0)
             x = tape.apply(Concat2FCFn, h, agg, st.Wq, st.bq, st.gamma, st.beta, None, st.post_spec(layer.training))
             if layer.training:
                 for c in st.counters:
@@ -235,6 +238,10 @@ class _LayerStack:
         Dp, Fep, Fip, Fop, Mix = pad(D), pad(Fe), pad(Fi), pad(Fo), layer.out_dim
         Mixp = pad(Mix)
         self.D, self.Dp, self.Fe, self.Fep, self.Mix, self.Mixp = D, Dp, Fe, Fep, Mix, Mixp
+        # the aggregated columns tower-major ([tower][block][feature]): a tower's B blocks are one K range, the posttrans products on
+        # them run as T diagonal blocks (csrc/tower.hip, i3d_gemm_f32_batched) - needs the per-tower widths padded
+        self.T, self.Fip = T, Fip
+        self.tower_major = TOWER_BLOCKS and T > 1 and Fip % 4 == 0 and Fop % 4 == 0
         Mp, Kp, Mq, Kq = T * Fip, 2 * Dp + Fep, T * Fop, Dp + B * T * Fip
         ldp, ldq, ldm = pad4(Kp), pad4(Kq), Mq        # (csrc/tower.hip takes the mixing weights contiguous)
         sizes = [Mp * ldp, pad4(Mp), Mq * ldq, pad4(Mq), pad4(Mq), pad4(Mq), pad4(Mixp * ldm), pad4(Mixp)]
@@ -280,7 +287,8 @@ class _LayerStack:
             W2, b2 = post.linear.weight, post.linear.bias
             self.param_blocks.append((W2, 0, Fo, Fi, Kp_t(W2), 'Wq', t * Fop, c0))
             for k in range(B):
-                self.param_blocks.append((W2, Fi + k * Fi, Fo, Fi, Kp_t(W2), 'Wq', t * Fop, Dp + k * T * Fip + t * Fip))
+                col = Dp + t * B * Fip + k * Fip if self.tower_major else Dp + k * T * Fip + t * Fip
+                self.param_blocks.append((W2, Fi + k * Fi, Fo, Fi, Kp_t(W2), 'Wq', t * Fop, col))
             self.param_blocks.append((b2, 0, 1, Fo, Fo, 'bq', 0, t * Fop))
             self.params += [W, b, W2, b2]
             if self.has_bn:
@@ -471,6 +479,7 @@ class _TowerLayerFn(torch.autograd.Function):
             a.scalers[i] = v
         a.avg_d_log = float(tw.avg_d)
         a.residual, a.training = int(layer.residual), int(training)
+        a.n_towers = st.T if st.tower_major else 0
         a.h, a.e = h.data_ptr(), (e.data_ptr() if e is not None else None)
         a.snorm = snorm.data_ptr() if snorm is not None else None
         a.Wp, a.bp, a.Wq, a.bq = Wp.data_ptr(), bp.data_ptr(), Wq.data_ptr(), bq.data_ptr()

@@ -146,6 +146,25 @@ int i3d_gemm_f32_blocks(int trans_a, int trans_b, int M, int N, int K, const flo
                         int b_split, long b_delta, long b_view_floats, float* C, int ldc, int c_split, long c_delta,
                         int accumulate, void* workspace, long workspace_bytes, void* stream);
 
+/* K4 with a tower-major row layout (the tower variant's stacked layers, csrc/tower.hip): the feat message columns are feat /
+ * tower_feat towers; a node's output row is [tower][block (scaler, aggregator)][feature of the tower] instead of
+ * [block][feature] - the B blocks of one tower are one contiguous column range.  feat % 4 == tower_feat % 4 == 0; otherwise as
+ * i3d_pna_aggregate_fwd / _bwd (grad_out in the same layout). */
+int i3d_pna_aggregate_fwd_towers(const float* e, const int* in_ptr, int num_nodes, int feat, int tower_feat,
+                                 const int* aggregators, int n_aggregators, const int* scalers, int n_scalers,
+                                 int force_scalers, float avg_d_log, float* out, void* stream);
+int i3d_pna_aggregate_bwd_towers(const float* grad_out, const float* e, const int* in_ptr, int num_nodes, int feat,
+                                 int tower_feat, const int* aggregators, int n_aggregators, const int* scalers,
+                                 int n_scalers, int force_scalers, float avg_d_log, float* grad_e, void* stream);
+/* n_batch products of ONE shape in one launch: batch b multiplies A + b a_batch by B + b b_batch into C + b c_batch (strides in
+ * floats; layouts and `accumulate` as i3d_gemm_f32, no bias; K-slices of weight-gradient layouts go through `workspace` as in
+ * i3d_gemm_f32_ws and are required to: n_batch <= 32).  The diagonal blocks of a block-diagonal product: the posttrans Linear of
+ * the `towers` PNATowers of a layer (reference models/pna_original.py:209-211, 250: tower t reads only ITS aggregated columns),
+ * forward, data gradient and weight gradient, without the zero blocks of the stacked weight (csrc/tower.hip). */
+int i3d_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, long a_batch, const float* B,
+                         int ldb, long b_batch, float* C, int ldc, long c_batch, int n_batch, int accumulate, void* workspace,
+                         long workspace_bytes, void* stream);
+
 /* ---- degree-grouped posttrans of the PNA layer ------------------------------------------------------
  * replaces cat([h, agg]) -> posttrans Linear of reference models/pna.py:207-209 for the aggregated part:  the three
  * scaler blocks of agg are per-node multiples (functions of the in-degree D only) of the same aggregator block a,
@@ -387,6 +406,11 @@ typedef struct {
     float* grad_beta;
     float* grad_Wm;
     float* grad_bm;
+    /* > 1: the posttrans products as n_towers diagonal blocks (i3d_gemm_f32_batched) - tower t's rows of Wq hold its f_msg / n_towers
+     * x B aggregated columns at f_in + t B f_msg / n_towers .. (zeros elsewhere are never read) and the aggregation is written /
+     * its gradient read tower-major (i3d_pna_aggregate_fwd_towers); needs f_msg / n_towers and f_out / n_towers multiples of 4.
+     * 0 / 1: one dense product on [block][tower][feature] columns */
+    int n_towers;
 } I3dTowerLayerArgs;
 long i3d_tower_layer_saved_floats(const I3dTowerLayerArgs* a);
 long i3d_tower_layer_scratch_floats(const I3dTowerLayerArgs* a);

@@ -869,3 +869,68 @@ def test_edge_block_bn_backward_fused_with_its_segmented_sums(feat, act):
     ops.check(lib.i3d_colsum_strided(ctypes.c_void_p(DL.data_ptr() + 4 * feat), W, n, feat, p(bias), p(part), st), 'i3d_colsum_strided')
     ref_bias = gp_ref.double().sum(0).cpu()
     assert float((bias.cpu().double() - ref_bias).abs().max()) < 2e-6 * max(1.0, float(gp_ref.abs().double().sum(0).max()))
+
+
+# ---- the tower variant's block-diagonal posttrans products and tower-major aggregation (round 5) ---------------------------
+@pytest.mark.parametrize('rows,T,Fo,Kt', [(8500, 5, 20, 1104), (300, 5, 20, 240), (1000, 3, 8, 48), (64, 2, 4, 16)])
+def test_batched_gemm_is_the_block_diagonal_product(rows, T, Fo, Kt):
+    """i3d_gemm_f32_batched (csrc/gemm.hip): the T diagonal blocks of [rows, T Kt] x [T Fo, T Kt]^T in one launch - forward layout,
+    data-gradient layout and weight-gradient layout (K-slices through the scratch) - against fp64 products of the blocks."""
+    import ctypes
+    _lib = importlib.import_module('3dinfomax_amd._lib')
+    L = _lib.load()
+    st = ops._stream()
+    D = 12                                     # the blocks sit behind D columns of a wider weight, as in csrc/tower.hip
+    ldq = D + T * Kt
+    A = g(rnd(rows, T * Kt, seed=1))
+    W = g(rnd(T * Fo, ldq, seed=2))
+    G = g(rnd(rows, T * Fo, seed=3))
+    ws = ops._gemm_workspace(DEV)
+    Ad, Wd, Gd = A.double().cpu(), W.double().cpu(), G.double().cpu()
+    # forward: C[:, t Fo ..] += A[:, t Kt ..] W[t Fo .., D + t Kt ..]^T
+    C0 = g(rnd(rows, T * Fo, seed=4))
+    C = C0.clone()
+    _lib.check(L.i3d_gemm_f32_batched(0, 1, rows, Fo, Kt, A.data_ptr(), T * Kt, Kt, W.data_ptr() + 4 * D, ldq, Fo * ldq + Kt, C.data_ptr(),
+                                      T * Fo, Fo, T, 1, None, 0, st), 'i3d_gemm_f32_batched')
+    ref = C0.double().cpu().clone()
+    for t in range(T):
+        ref[:, t * Fo:(t + 1) * Fo] += Ad[:, t * Kt:(t + 1) * Kt] @ Wd[t * Fo:(t + 1) * Fo, D + t * Kt:D + (t + 1) * Kt].T
+    assert rel_err(C.cpu(), ref) < 2e-5
+    # data gradient: dA[:, t Kt ..] = G[:, t Fo ..] W[t Fo .., D + t Kt ..]
+    dA = torch.full_like(A, float('nan'))
+    _lib.check(L.i3d_gemm_f32_batched(0, 0, rows, Kt, Fo, G.data_ptr(), T * Fo, Fo, W.data_ptr() + 4 * D, ldq, Fo * ldq + Kt, dA.data_ptr(),
+                                      T * Kt, Kt, T, 0, None, 0, st), 'i3d_gemm_f32_batched')
+    ref = torch.cat([Gd[:, t * Fo:(t + 1) * Fo] @ Wd[t * Fo:(t + 1) * Fo, D + t * Kt:D + (t + 1) * Kt] for t in range(T)], dim=1)
+    assert rel_err(dA.cpu(), ref) < 2e-5
+    # weight gradient: dW[t Fo .., D + t Kt ..] = G[:, t Fo ..]^T A[:, t Kt ..]; nothing else of dW is written
+    dW = torch.full_like(W, 7.0)
+    _lib.check(L.i3d_gemm_f32_batched(1, 0, Fo, Kt, rows, G.data_ptr(), T * Fo, Fo, A.data_ptr(), T * Kt, Kt, dW.data_ptr() + 4 * D, ldq,
+                                      Fo * ldq + Kt, T, 0, ws.data_ptr(), ops.GEMM_WORKSPACE_BYTES, st), 'i3d_gemm_f32_batched')
+    ref = torch.full((T * Fo, ldq), 7.0, dtype=torch.float64)
+    for t in range(T):
+        ref[t * Fo:(t + 1) * Fo, D + t * Kt:D + (t + 1) * Kt] = Gd[:, t * Fo:(t + 1) * Fo].T @ Ad[:, t * Kt:(t + 1) * Kt]
+    assert rel_err(dW.cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize('T,Ft,std', [(5, 20, True), (5, 92, True), (3, 8, False)])
+def test_tower_major_aggregation_is_a_column_permutation(T, Ft, std):
+    """i3d_pna_aggregate_fwd_towers / _bwd_towers: the node rows as [tower][block][feature] - the same values as the
+    [block][tower][feature] rows of i3d_pna_aggregate_fwd, bit for bit, and the same message gradient from the permuted gradient."""
+    synth = importlib.import_module('3dinfomax_amd.synth')
+    amd = importlib.import_module('3dinfomax_amd')
+    mols = synth.make_dataset(24, seed=3)
+    idx = amd.batch([amd.bond_graph(m) for m in mols]).to(DEV).index()
+    E, N, F_ = idx.num_edges, idx.num_nodes, T * Ft
+    aggs = ops.agg_codes(['mean', 'max', 'min', 'std'] if std else ['sum', 'max', 'var'])
+    scal = ops.scaler_codes(['identity', 'amplification', 'attenuation'] if std else ['identity', 'attenuation'])
+    B = len(aggs) * len(scal)
+    e = g(rnd(E, F_, seed=5))
+    ref = ops.pna_aggregate_fwd(e, idx.in_ptr, N, aggs, scal, 1.3, True)
+    out = ops.pna_aggregate_fwd(e, idx.in_ptr, N, aggs, scal, 1.3, True, tower_feat=Ft)
+    perm = ref.view(N, B, T, Ft).permute(0, 2, 1, 3).reshape(N, B * F_)
+    assert torch.equal(out, perm)
+    go = g(rnd(N, B * F_, seed=6))
+    go_tm = go.view(N, B, T, Ft).permute(0, 2, 1, 3).reshape(N, B * F_).contiguous()
+    ge_ref = ops.pna_aggregate_bwd(go, e, idx.in_ptr, N, aggs, scal, 1.3, True)
+    ge = ops.pna_aggregate_bwd(go_tm, e, idx.in_ptr, N, aggs, scal, 1.3, True, tower_feat=Ft)
+    assert torch.equal(ge, ge_ref)
