@@ -116,7 +116,8 @@ class TowerLayerArgs(ctypes.Structure):
                 + [('gemm_workspace_bytes', c_long)]
                 + [(n, _P) for n in ('out', 'grad_out', 'grad_h', 'grad_e', 'grad_Wp', 'grad_bp', 'grad_Wq', 'grad_bq', 'grad_gamma',
                                      'grad_beta', 'grad_Wm', 'grad_bm')]
-                + [('n_towers', c_int)])
+                + [('n_towers', c_int), ('n_deg_groups', c_int), ('m_padded', c_int), ('group_start', c_int * 32),
+                   ('group_count', c_int * 32), ('coef', c_float * 128), ('deg_rows', _P), ('deg_tile_group', _P)])
 
 
 ALL_GATHER_F32 = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p)

@@ -27,7 +27,8 @@ static inline long al4(long n) { return (n + 3) & ~3L; }
 extern "C" long i3d_tower_layer_saved_floats(const I3dTowerLayerArgs* a) {
     if (a == nullptr) return 0;
     const long N = a->num_nodes, E = a->num_edges, Mp = a->f_msg, Mq = a->f_out, B = (long)a->n_aggregators * a->n_scalers;
-    return al4(E * Mp) + al4(N * B * Mp) + al4(N * Mq) + 2 * al4(Mq) + 2 * al4(N * Mq);
+    const long wd = a->n_deg_groups > 0 ? al4((long)a->n_deg_groups * Mq * a->n_aggregators * Mp) : 0;
+    return al4(E * Mp) + al4(N * B * Mp) + al4(N * Mq) + 2 * al4(Mq) + 2 * al4(N * Mq) + wd;
 }
 
 // floats of `scratch`: forward P | Q | y;  backward g_mixpre | g_y | g_lin | g_agg | g_msg | gP
@@ -35,14 +36,15 @@ extern "C" long i3d_tower_layer_scratch_floats(const I3dTowerLayerArgs* a) {
     if (a == nullptr) return 0;
     const long N = a->num_nodes, E = a->num_edges, Mp = a->f_msg, Mq = a->f_out, B = (long)a->n_aggregators * a->n_scalers;
     const long fwd = al4(N * 2 * Mp) + al4(E * Mp) + al4(N * Mq);
-    const long bwd = 3 * al4(N * Mq) + al4(N * B * Mp) + al4(E * Mp) + al4(N * 2 * Mp);
+    const long wd = a->n_deg_groups > 0 ? al4((long)a->n_deg_groups * Mq * a->n_aggregators * Mp) : 0;
+    const long bwd = 3 * al4(N * Mq) + al4(N * B * Mp) + al4(E * Mp) + al4(N * 2 * Mp) + wd;
     return fwd > bwd ? fwd : bwd;
 }
 
 namespace {
 
 struct Saved {
-    float *msg, *agg, *lin, *mean, *invstd, *xs, *mixpre;
+    float *msg, *agg, *lin, *mean, *invstd, *xs, *mixpre, *WD;
 };
 
 Saved saved_of(const I3dTowerLayerArgs* a) {
@@ -55,7 +57,8 @@ Saved saved_of(const I3dTowerLayerArgs* a) {
     s.mean = p; p += al4(Mq);
     s.invstd = p; p += al4(Mq);
     s.xs = p; p += al4(N * Mq);
-    s.mixpre = p;
+    s.mixpre = p; p += al4(N * Mq);
+    s.WD = p;
     return s;
 }
 
@@ -64,8 +67,14 @@ bool args_ok(const I3dTowerLayerArgs* a) {
            a->h != nullptr && a->Wp != nullptr && a->Wq != nullptr && a->Wm != nullptr && a->saved != nullptr && a->scratch != nullptr &&
            a->workspace != nullptr && a->n_aggregators >= 1 && a->n_aggregators <= 8 && a->n_scalers >= 1 && a->n_scalers <= 4 &&
            (a->f_edge == 0 || a->e != nullptr) && a->ldp >= 2 * a->f_in + a->f_edge && a->ldq >= a->f_in + a->n_aggregators * a->n_scalers * a->f_msg &&
-           (a->n_towers <= 1 || (a->n_towers <= 32 && a->f_msg % (4 * a->n_towers) == 0 && a->f_out % (4 * a->n_towers) == 0));
+           (a->n_towers <= 1 || (a->n_towers <= 32 && a->f_msg % (4 * a->n_towers) == 0 && a->f_out % (4 * a->n_towers) == 0)) &&
+           (a->n_deg_groups <= 0 || (a->n_towers <= 1 && a->n_deg_groups <= 32 && a->n_deg_groups * a->n_scalers <= 128 &&
+                                     a->deg_rows != nullptr && a->deg_tile_group != nullptr && a->m_padded % 64 == 0));
 }
+
+// the scalers folded into per-degree weights (I3dTowerLayerArgs::n_deg_groups)
+inline bool scalers_folded(const I3dTowerLayerArgs* a) { return a->n_deg_groups > 0; }
+const int kIdentityScaler[1] = {I3D_SCALE_IDENTITY};
 
 // the posttrans products on the aggregation as `n_towers` diagonal blocks (I3dTowerLayerArgs::n_towers)
 inline bool tower_major(const I3dTowerLayerArgs* a) { return a->n_towers > 1; }
@@ -87,7 +96,12 @@ extern "C" int i3d_tower_layer_fwd(const I3dTowerLayerArgs* a, void* stream) {
     TRY(i3d_edge_combine_fwd(P, 2 * Mp, Fe > 0 ? Q : nullptr, nullptr, a->bp, a->src_s, a->dst_s, E, Mp, s.msg, stream));
     const bool tm = tower_major(a);
     const int T = tm ? a->n_towers : 1, Ft = Mp / T, Fo = Mq / T;
-    if (tm)
+    const bool fold = scalers_folded(a);
+    const int AW = a->n_aggregators * Mp;      // width of the identity blocks
+    if (fold)
+        TRY(i3d_pna_aggregate_fwd(s.msg, a->in_ptr, N, Mp, a->aggregators, a->n_aggregators, kIdentityScaler, 1, 0, a->avg_d_log, s.agg,
+                                  stream));
+    else if (tm)
         TRY(i3d_pna_aggregate_fwd_towers(s.msg, a->in_ptr, N, Mp, Ft, a->aggregators, a->n_aggregators, a->scalers, a->n_scalers, 1,
                                          a->avg_d_log, s.agg, stream));
     else
@@ -95,7 +109,11 @@ extern "C" int i3d_tower_layer_fwd(const I3dTowerLayerArgs* a, void* stream) {
                                   s.agg, stream));
     // posttrans on [h | agg] without the concatenation
     TRY(i3d_gemm_f32(0, 1, N, Mq, D, a->h, D, a->Wq, a->ldq, s.lin, Mq, a->bq, 0, stream));
-    if (tm)     // tower t: lin[:, t Fo ..] += agg[:, t B Ft ..] Wq[t Fo .., D + t B Ft ..]^T
+    if (fold) {  // lin[r, :] += agg[r, :] W_D^T for the nodes r of in-degree D, W_D = sum_s c_s(D) W_s
+        TRY(i3d_pna_combine_weights_fwd(a->Wq, a->ldq, D, Mq, AW, a->n_deg_groups, a->n_scalers, a->coef, s.WD, stream));
+        TRY(i3d_gemm_f32_grouped(1, a->m_padded, Mq, AW, s.agg, AW, N, a->deg_rows, a->deg_tile_group, s.WD, AW, (long)Mq * AW, s.lin, Mq,
+                                 1, stream));
+    } else if (tm)     // tower t: lin[:, t Fo ..] += agg[:, t B Ft ..] Wq[t Fo .., D + t B Ft ..]^T
         TRY(i3d_gemm_f32_batched(0, 1, N, Fo, B * Ft, s.agg, B * Mp, (long)B * Ft, a->Wq + D, a->ldq, (long)Fo * a->ldq + (long)B * Ft,
                                  s.lin, Mq, Fo, T, 1, nullptr, 0, stream));
     else
@@ -163,14 +181,24 @@ extern "C" int i3d_tower_layer_bwd(const I3dTowerLayerArgs* a, void* stream) {
     // posttrans Linear on [h | agg]
     const bool tm = tower_major(a);
     const int T = tm ? a->n_towers : 1, Ft = Mp / T, Fo = Mq / T;
-    if (tm)     // (the blocks off the diagonal of grad_Wq are not written: nothing reads them)
+    const bool fold = scalers_folded(a);
+    const int AW = a->n_aggregators * Mp;
+    float* gWD = gP + al4((long)N * 2 * Mp);
+    if (fold) {  // dW_D = dY_D^T agg_D over the rows of each in-degree group (one launch), folded back into the scaler blocks
+        TRY(i3d_gemm_f32_rowsubset_multi(Mq, AW, a->n_deg_groups, a->group_start, a->group_count, gl, Mq, s.agg, AW, a->deg_rows, N, gWD,
+                                         (long)Mq * AW, AW, 0, -1, 0, ws, wsb, stream));
+        TRY(i3d_pna_combine_weights_bwd(gWD, a->ldgq, D, Mq, AW, a->n_deg_groups, a->n_scalers, a->coef, a->grad_Wq, stream));
+    } else if (tm)     // (the blocks off the diagonal of grad_Wq are not written: nothing reads them)
         TRY(i3d_gemm_f32_batched(1, 0, Fo, B * Ft, N, gl, Mq, Fo, s.agg, B * Mp, (long)B * Ft, a->grad_Wq + D, a->ldgq,
                                  (long)Fo * a->ldgq + (long)B * Ft, T, 0, ws, wsb, stream));
     else
         TRY(i3d_gemm_f32_ws(1, 0, Mq, B * Mp, N, gl, Mq, s.agg, B * Mp, a->grad_Wq + D, a->ldgq, nullptr, 0, ws, wsb, stream));
     TRY(i3d_gemm_f32_ws(1, 0, Mq, D, N, gl, Mq, a->h, D, a->grad_Wq, a->ldgq, nullptr, 0, ws, wsb, stream));
     TRY(i3d_colsum(gl, nullptr, N, Mq, a->grad_bq, a->workspace, stream));
-    if (tm)
+    if (fold)
+        TRY(i3d_gemm_f32_grouped(0, a->m_padded, AW, Mq, gl, Mq, N, a->deg_rows, a->deg_tile_group, s.WD, AW, (long)Mq * AW, g_agg, AW, 0,
+                                 stream));
+    else if (tm)
         TRY(i3d_gemm_f32_batched(0, 0, N, B * Ft, Fo, gl, Mq, Fo, a->Wq + D, a->ldq, (long)Fo * a->ldq + (long)B * Ft, g_agg, B * Mp,
                                  (long)B * Ft, T, 0, nullptr, 0, stream));
     else
@@ -179,7 +207,10 @@ extern "C" int i3d_tower_layer_bwd(const I3dTowerLayerArgs* a, void* stream) {
     TRY(i3d_gemm_f32(0, 0, N, D, Mq, gl, Mq, a->Wq, a->ldq, a->grad_h, D, nullptr, 0, stream));
     if (a->residual) TRY(i3d_add_inplace(a->grad_h, a->grad_out, (long)N * D, stream));
     // aggregation
-    if (tm)
+    if (fold)
+        TRY(i3d_pna_aggregate_bwd(g_agg, s.msg, a->in_ptr, N, Mp, a->aggregators, a->n_aggregators, kIdentityScaler, 1, 0, a->avg_d_log,
+                                  g_msg, stream));
+    else if (tm)
         TRY(i3d_pna_aggregate_bwd_towers(g_agg, s.msg, a->in_ptr, N, Mp, Ft, a->aggregators, a->n_aggregators, a->scalers,
                                          a->n_scalers, 1, a->avg_d_log, g_msg, stream));
     else

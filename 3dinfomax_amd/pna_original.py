@@ -19,7 +19,7 @@ from . import _lib, layers as _layers, ops, tape
 from .graph import as_batched_graph
 from .layers import MLP, AggregateFn, BNSpec, Concat2FCFn, EdgeFCFn, FCFn, FCSpec, ReadoutFn, dropout as _dropout
 from .mol_encoder import AtomEncoder, BondEncoder
-from .pna import _codes, _GatherRowsFn
+from .pna import _codes, _GatherRowsFn, _scaler_coef
 
 # I3D_TOWER_STACK=0: the towers of a layer one after the other (one autograd node per block and tower: the first version)
 TOWER_STACK = os.environ.get('I3D_TOWER_STACK', '1') != '0'
@@ -29,6 +29,10 @@ PAD_WIDTHS = os.environ.get('I3D_TOWER_PAD', '1') != '0'
 # I3D_TOWER_BLOCKS=0: the posttrans products of a stacked layer as ONE dense product on the zero-padded stacked weight instead of
 # `towers` diagonal blocks
 TOWER_BLOCKS = os.environ.get('I3D_TOWER_BLOCKS', '1') != '0'
+# I3D_TOWER_FOLD=1: the scalers of a stacked layer folded into per-degree posttrans weights as in the 2D network (the aggregation
+# writes its identity blocks only, K of the products on it is n_scalers times shorter) on ONE dense grouped product - instead of
+# the towers' diagonal blocks
+TOWER_FOLD = os.environ.get('I3D_TOWER_FOLD', '0') == '1'
 
 
 class _RowScaleFn(torch.autograd.Function):
@@ -241,7 +245,8 @@ class _LayerStack:
         # the aggregated columns tower-major ([tower][block][feature]): a tower's B blocks are one K range, the posttrans products on
         # them run as T diagonal blocks (csrc/tower.hip, i3d_gemm_f32_batched) - needs the per-tower widths padded
         self.T, self.Fip = T, Fip
-        self.tower_major = TOWER_BLOCKS and T > 1 and Fip % 4 == 0 and Fop % 4 == 0
+        self.fold = TOWER_FOLD
+        self.tower_major = TOWER_BLOCKS and not self.fold and T > 1 and Fip % 4 == 0 and Fop % 4 == 0
         Mp, Kp, Mq, Kq = T * Fip, 2 * Dp + Fep, T * Fop, Dp + B * T * Fip
         ldp, ldq, ldm = pad4(Kp), pad4(Kq), Mq        # (csrc/tower.hip takes the mixing weights contiguous)
         sizes = [Mp * ldp, pad4(Mp), Mq * ldq, pad4(Mq), pad4(Mq), pad4(Mq), pad4(Mixp * ldm), pad4(Mixp)]
@@ -480,6 +485,16 @@ class _TowerLayerFn(torch.autograd.Function):
         a.avg_d_log = float(tw.avg_d)
         a.residual, a.training = int(layer.residual), int(training)
         a.n_towers = st.T if st.tower_major else 0
+        if st.fold:
+            rows, tiles, groups = idx.degree_groups()
+            nS = len(tw.scalers)
+            if len(groups) <= 32 and len(groups) * nS <= 128:
+                a.n_deg_groups, a.m_padded = len(groups), rows.shape[0]
+                for gi, (deg, start, count) in enumerate(groups):
+                    a.group_start[gi], a.group_count[gi] = start, count
+                    for si, sc in enumerate(tw.scalers):
+                        a.coef[gi * nS + si] = _scaler_coef(sc, deg, float(tw.avg_d))
+                a.deg_rows, a.deg_tile_group = rows.data_ptr(), tiles.data_ptr()
         a.h, a.e = h.data_ptr(), (e.data_ptr() if e is not None else None)
         a.snorm = snorm.data_ptr() if snorm is not None else None
         a.Wp, a.bp, a.Wq, a.bq = Wp.data_ptr(), bp.data_ptr(), Wq.data_ptr(), bq.data_ptr()
@@ -498,6 +513,7 @@ class _TowerLayerFn(torch.autograd.Function):
         a.workspace = ops._workspace(max(a.f_msg, a.f_out), dev).data_ptr()
         _lib.check(L.i3d_tower_layer_fwd(ctypes.byref(a), ops._stream()), 'i3d_tower_layer_fwd')
         ctx.args, ctx.keep = a, (h, e, snorm, Wp, bp, Wq, bq, gamma, beta, Wm, bm, saved)
+        ctx.idx = idx                   # (its degree tables are read by the backward pass)
         ctx.has_e_grad = e is not None and ctx.needs_input_grad[1]
         return out
 

@@ -411,6 +411,17 @@ typedef struct {
      * its gradient read tower-major (i3d_pna_aggregate_fwd_towers); needs f_msg / n_towers and f_out / n_towers multiples of 4.
      * 0 / 1: one dense product on [block][tower][feature] columns */
     int n_towers;
+    /* > 0 (with n_towers <= 1): the scalers folded into per-degree weights as in the 2D network's posttrans block (above:
+     * "degree-grouped posttrans") - the aggregation writes its identity blocks only ([N, n_aggregators f_msg]), the product on it
+     * is grouped by in-degree with W_D = sum_s coef[g][s] W_s: K of the dominant products n_scalers times shorter, the aggregated
+     * tensor n_scalers times smaller.  group_start / group_count / coef / deg_rows / deg_tile_group / m_padded as in
+     * I3dGroupedFcArgs (graph.py: GraphIndex.degree_groups) */
+    int n_deg_groups, m_padded;
+    int group_start[32];
+    int group_count[32];
+    float coef[128];
+    const int* deg_rows;
+    const int* deg_tile_group;
 } I3dTowerLayerArgs;
 long i3d_tower_layer_saved_floats(const I3dTowerLayerArgs* a);
 long i3d_tower_layer_scratch_floats(const I3dTowerLayerArgs* a);
