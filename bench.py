@@ -563,6 +563,7 @@ def main():
     # secondary figure (SURVEY.md 8d "also report with H2D/collate included", row f1): every step first assembles a
     # fresh batch from the flat dataset on the host (vectorised numpy), copies it and builds the 3D graphs on device
     with_assembly = with_assembly_inline = None
+    with_prefetch = {}
     if (not use_dist or world == 1) and not qmugs:
         dataset = importlib.import_module('3dinfomax_amd.dataset')
         all_mols = [m for _, _, shard in batches for m in shard]
@@ -622,6 +623,26 @@ def main():
                 torch.cuda.synchronize()
                 rates.append((n_ld // 3) * B / (time.perf_counter() - ta))
             with_assembly = round(sorted(rates)[1], 1)
+            # the same with the device half of the assembly on a helper thread (dataset.DevicePrefetcher), two batches ahead
+            for interval in (None, 2e-4, 5e-5):
+                stream = dataset.BatchStream(flat, B, steps=n_ld + 12, seed=2)
+                loader = torch.utils.data.DataLoader(stream, batch_size=None, num_workers=args.loader_workers, pin_memory=True,
+                                                     prefetch_factor=4)
+                pf = dataset.DevicePrefetcher(loader, dev, depth=2, switch_interval=interval)
+                for _ in range(12):
+                    (a,), (b,) = next(pf)
+                    step_on(a, b)
+                rates = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    ta = time.perf_counter()
+                    for _ in range(n_ld // 3):
+                        (a,), (b,) = next(pf)
+                        step_on(a, b)
+                    torch.cuda.synchronize()
+                    rates.append((n_ld // 3) * B / (time.perf_counter() - ta))
+                pf.close()
+                with_prefetch[str(interval)] = round(sorted(rates)[1], 1)
             if os.environ.get('I3D_BENCH_DEBUG'):
                 print('loader windows, molecules/s:', ' '.join(f'{v:.0f}' for v in rates), file=sys.stderr)
             del it, loader
@@ -829,7 +850,11 @@ def main():
                                ms_per_step_median=round(step_ms[len(step_ms) // 2], 3),
                                ms_per_step_p10_p90=[round(step_ms[len(step_ms) // 10], 3), round(step_ms[(9 * len(step_ms)) // 10], 3)],
                                molecules_per_s_incl_batch_assembly_and_h2d=with_assembly,
-                               molecules_per_s_incl_batch_assembly_in_the_training_thread=with_assembly_inline),
+                               molecules_per_s_incl_batch_assembly_in_the_training_thread=with_assembly_inline,
+                               molecules_per_s_incl_batch_assembly_device_half_on_a_helper_thread=(
+                                   dict(default_switch_interval=with_prefetch.get('None'), switch_interval_200us=with_prefetch.get('0.0002'),
+                                        switch_interval_50us=with_prefetch.get('5e-05'))
+                                   if with_prefetch else None)),
                    roofline=roof)
         if collectives is not None:
             out['collectives'] = collectives
