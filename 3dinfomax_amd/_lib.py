@@ -260,6 +260,8 @@ _SIGNATURES = {
     'i3d_gemm_f32_blocks': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_long, c_long, _P, c_int,
                                     c_int, c_long, c_int, _P, c_long, _P]),
     'i3d_gemm_f32_ws': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_long, _P]),
+    'i3d_gemm_f32_grouped_batched': (c_int, [c_int, c_int, c_int, c_int, _P, c_int, c_long, c_long, _P, _P, _P, c_int, c_long, c_long, _P, c_int,
+                                             c_long, c_int, c_int, _P]),
     'i3d_gemm_f32_batched': (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, c_long, _P, c_int, c_long, _P, c_int, c_long, c_int,
                                      c_int, _P, c_long, _P]),
     'i3d_pna_combine_weights_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), _P, _P]),

@@ -612,6 +612,9 @@ extern "C" int i3d_pna_aggregate_fwd_towers(const float* e, const int* in_ptr, i
     if (is_std_cfg(cfg))
         hipLaunchKernelGGL((pna_aggregate_fwd_kernel<1, false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)e, in_ptr,
                            num_nodes, FV, cfg, (float4*)out, (const float4*)nullptr, tower_feat / 4);
+    else if (is_ident_cfg(cfg))
+        hipLaunchKernelGGL((pna_aggregate_fwd_kernel<2, false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)e, in_ptr,
+                           num_nodes, FV, cfg, (float4*)out, (const float4*)nullptr, tower_feat / 4);
     else
         hipLaunchKernelGGL((pna_aggregate_fwd_kernel<0, false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)e, in_ptr,
                            num_nodes, FV, cfg, (float4*)out, (const float4*)nullptr, tower_feat / 4);
@@ -631,6 +634,9 @@ extern "C" int i3d_pna_aggregate_bwd_towers(const float* grad_out, const float* 
     const long items = (long)num_nodes * (feat / 4);
     if (is_std_cfg(cfg))
         hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 1, false, true>), dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream,
+                           grad_out, e, in_ptr, num_nodes, feat, cfg, grad_e, (const float*)nullptr, tower_feat);
+    else if (is_ident_cfg(cfg))
+        hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 2, false, true>), dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream,
                            grad_out, e, in_ptr, num_nodes, feat, cfg, grad_e, (const float*)nullptr, tower_feat);
     else
         hipLaunchKernelGGL((pna_aggregate_bwd_kernel<4, 0, false, true>), dim3(cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream,

@@ -1218,9 +1218,9 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     if (ex.c_delta % 4 != 0 || (nb > 1 && ex.c_batch % 4 != 0)) g.c_vec = 0;
     const int layout = trans_a ? (trans_b ? 3 : 2) : (trans_b ? 0 : 1);
     if (nb > 1) {
-        I3D_CHECK_ARG(nb <= 32 && layout != 3 && ex.m_rows == nullptr && ex.tile_group == nullptr && ex.b_split == 0x7fffffff &&
-                          ex.c_split == 0x7fffffff && bias == nullptr && ex.post_aff == nullptr,
-                      "batched product: plain operands, at most 32 batches");
+        I3D_CHECK_ARG(nb <= 32 && layout != 3 && (trans_a == 0 || (ex.m_rows == nullptr && ex.tile_group == nullptr)) &&
+                          ex.b_split == 0x7fffffff && ex.c_split == 0x7fffffff && bias == nullptr && ex.post_aff == nullptr,
+                      "batched product: plain (or row-grouped forward / data-gradient) operands, at most 32 batches");
         g.n_batch = nb; g.a_batch = ex.a_batch; g.b_batch = ex.b_batch; g.c_batch = ex.c_batch;
     }
 
@@ -1529,6 +1529,18 @@ extern "C" int i3d_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int 
     ex.workspace = workspace; ex.workspace_bytes = workspace_bytes;
     ex.n_batch = n_batch; ex.a_batch = a_batch; ex.b_batch = b_batch; ex.c_batch = c_batch;
     return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, nullptr, accumulate, -1, 0, ex, stream);
+}
+
+// i3d_gemm_f32_grouped with n_batch diagonal blocks per group (include/infomax3d_hip.h)
+extern "C" int i3d_gemm_f32_grouped_batched(int trans_b, int m_padded, int N, int K, const float* A, int lda, long a_batch,
+                                            long a_rows_total, const int* m_rows, const int* tile_group, const float* B, int ldb,
+                                            long b_group_stride, long b_batch, float* C, int ldc, long c_batch, int n_batch,
+                                            int accumulate, void* stream) {
+    I3D_CHECK_ARG(m_rows != nullptr && tile_group != nullptr && m_padded % 64 == 0 && n_batch >= 1, "grouped GEMM needs 64-padded m_rows");
+    Extra ex;
+    ex.m_rows = m_rows; ex.tile_group = tile_group; ex.b_group_stride = b_group_stride; ex.a_rows_total = a_rows_total;
+    ex.n_batch = n_batch; ex.a_batch = a_batch; ex.b_batch = b_batch; ex.c_batch = c_batch;
+    return gemm_impl(0, trans_b, m_padded, N, K, A, lda, B, ldb, C, ldc, nullptr, accumulate, -1, 0, ex, stream);
 }
 
 // C[m_rows[m], :] (+)= A[m_rows[m], :] * op(B_g),  g = tile_group[m / 64];  m_rows is padded with -1 to 64 per group

@@ -68,7 +68,7 @@ bool args_ok(const I3dTowerLayerArgs* a) {
            a->workspace != nullptr && a->n_aggregators >= 1 && a->n_aggregators <= 8 && a->n_scalers >= 1 && a->n_scalers <= 4 &&
            (a->f_edge == 0 || a->e != nullptr) && a->ldp >= 2 * a->f_in + a->f_edge && a->ldq >= a->f_in + a->n_aggregators * a->n_scalers * a->f_msg &&
            (a->n_towers <= 1 || (a->n_towers <= 32 && a->f_msg % (4 * a->n_towers) == 0 && a->f_out % (4 * a->n_towers) == 0)) &&
-           (a->n_deg_groups <= 0 || (a->n_towers <= 1 && a->n_deg_groups <= 32 && a->n_deg_groups * a->n_scalers <= 128 &&
+           (a->n_deg_groups <= 0 || (a->n_deg_groups <= 32 && a->n_deg_groups * a->n_scalers <= 128 &&
                                      a->deg_rows != nullptr && a->deg_tile_group != nullptr && a->m_padded % 64 == 0));
 }
 
@@ -98,7 +98,11 @@ extern "C" int i3d_tower_layer_fwd(const I3dTowerLayerArgs* a, void* stream) {
     const int T = tm ? a->n_towers : 1, Ft = Mp / T, Fo = Mq / T;
     const bool fold = scalers_folded(a);
     const int AW = a->n_aggregators * Mp;      // width of the identity blocks
-    if (fold)
+    const int nA = a->n_aggregators;
+    if (fold && tm)      // identity blocks only, tower-major: [tower][aggregator][feature]
+        TRY(i3d_pna_aggregate_fwd_towers(s.msg, a->in_ptr, N, Mp, Ft, a->aggregators, nA, kIdentityScaler, 1, 0, a->avg_d_log, s.agg,
+                                         stream));
+    else if (fold)
         TRY(i3d_pna_aggregate_fwd(s.msg, a->in_ptr, N, Mp, a->aggregators, a->n_aggregators, kIdentityScaler, 1, 0, a->avg_d_log, s.agg,
                                   stream));
     else if (tm)
@@ -111,8 +115,12 @@ extern "C" int i3d_tower_layer_fwd(const I3dTowerLayerArgs* a, void* stream) {
     TRY(i3d_gemm_f32(0, 1, N, Mq, D, a->h, D, a->Wq, a->ldq, s.lin, Mq, a->bq, 0, stream));
     if (fold) {  // lin[r, :] += agg[r, :] W_D^T for the nodes r of in-degree D, W_D = sum_s c_s(D) W_s
         TRY(i3d_pna_combine_weights_fwd(a->Wq, a->ldq, D, Mq, AW, a->n_deg_groups, a->n_scalers, a->coef, s.WD, stream));
-        TRY(i3d_gemm_f32_grouped(1, a->m_padded, Mq, AW, s.agg, AW, N, a->deg_rows, a->deg_tile_group, s.WD, AW, (long)Mq * AW, s.lin, Mq,
-                                 1, stream));
+        if (tm)      // the diagonal blocks of W_D: tower t's rows of W_D on its own nA Ft aggregated columns
+            TRY(i3d_gemm_f32_grouped_batched(1, a->m_padded, Fo, nA * Ft, s.agg, AW, (long)nA * Ft, N, a->deg_rows, a->deg_tile_group, s.WD,
+                                             AW, (long)Mq * AW, (long)Fo * AW + (long)nA * Ft, s.lin, Mq, Fo, T, 1, stream));
+        else
+            TRY(i3d_gemm_f32_grouped(1, a->m_padded, Mq, AW, s.agg, AW, N, a->deg_rows, a->deg_tile_group, s.WD, AW, (long)Mq * AW, s.lin,
+                                     Mq, 1, stream));
     } else if (tm)     // tower t: lin[:, t Fo ..] += agg[:, t B Ft ..] Wq[t Fo .., D + t B Ft ..]^T
         TRY(i3d_gemm_f32_batched(0, 1, N, Fo, B * Ft, s.agg, B * Mp, (long)B * Ft, a->Wq + D, a->ldq, (long)Fo * a->ldq + (long)B * Ft,
                                  s.lin, Mq, Fo, T, 1, nullptr, 0, stream));
@@ -195,7 +203,11 @@ extern "C" int i3d_tower_layer_bwd(const I3dTowerLayerArgs* a, void* stream) {
         TRY(i3d_gemm_f32_ws(1, 0, Mq, B * Mp, N, gl, Mq, s.agg, B * Mp, a->grad_Wq + D, a->ldgq, nullptr, 0, ws, wsb, stream));
     TRY(i3d_gemm_f32_ws(1, 0, Mq, D, N, gl, Mq, a->h, D, a->grad_Wq, a->ldgq, nullptr, 0, ws, wsb, stream));
     TRY(i3d_colsum(gl, nullptr, N, Mq, a->grad_bq, a->workspace, stream));
-    if (fold)
+    if (fold && tm)
+        TRY(i3d_gemm_f32_grouped_batched(0, a->m_padded, a->n_aggregators * Ft, Fo, gl, Mq, Fo, N, a->deg_rows, a->deg_tile_group, s.WD, AW,
+                                         (long)Mq * AW, (long)Fo * AW + (long)a->n_aggregators * Ft, g_agg, AW, (long)a->n_aggregators * Ft,
+                                         T, 0, stream));
+    else if (fold)
         TRY(i3d_gemm_f32_grouped(0, a->m_padded, AW, Mq, gl, Mq, N, a->deg_rows, a->deg_tile_group, s.WD, AW, (long)Mq * AW, g_agg, AW, 0,
                                  stream));
     else if (tm)
@@ -207,7 +219,10 @@ extern "C" int i3d_tower_layer_bwd(const I3dTowerLayerArgs* a, void* stream) {
     TRY(i3d_gemm_f32(0, 0, N, D, Mq, gl, Mq, a->Wq, a->ldq, a->grad_h, D, nullptr, 0, stream));
     if (a->residual) TRY(i3d_add_inplace(a->grad_h, a->grad_out, (long)N * D, stream));
     // aggregation
-    if (fold)
+    if (fold && tm)
+        TRY(i3d_pna_aggregate_bwd_towers(g_agg, s.msg, a->in_ptr, N, Mp, Ft, a->aggregators, a->n_aggregators, kIdentityScaler, 1, 0,
+                                         a->avg_d_log, g_msg, stream));
+    else if (fold)
         TRY(i3d_pna_aggregate_bwd(g_agg, s.msg, a->in_ptr, N, Mp, a->aggregators, a->n_aggregators, kIdentityScaler, 1, 0, a->avg_d_log,
                                   g_msg, stream));
     else if (tm)

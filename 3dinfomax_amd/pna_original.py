@@ -17,7 +17,8 @@ import torch.nn as nn
 
 from . import _lib, layers as _layers, ops, tape
 from .graph import as_batched_graph
-from .layers import MLP, AggregateFn, BNSpec, Concat2FCFn, EdgeFCFn, FCFn, FCSpec, ReadoutFn, dropout as _dropout
+from .layers import (MLP, AggregateFn, BNSpec, Concat2FCFn, EdgeFCFn, FCFn, FCSpec, GroupedConcat2FCFn, ReadoutFn,
+                     dropout as _dropout)
 from .mol_encoder import AtomEncoder, BondEncoder
 from .pna import _codes, _GatherRowsFn, _scaler_coef
 
@@ -29,10 +30,11 @@ PAD_WIDTHS = os.environ.get('I3D_TOWER_PAD', '1') != '0'
 # I3D_TOWER_BLOCKS=0: the posttrans products of a stacked layer as ONE dense product on the zero-padded stacked weight instead of
 # `towers` diagonal blocks
 TOWER_BLOCKS = os.environ.get('I3D_TOWER_BLOCKS', '1') != '0'
-# I3D_TOWER_FOLD=1: the scalers of a stacked layer folded into per-degree posttrans weights as in the 2D network (the aggregation
-# writes its identity blocks only, K of the products on it is n_scalers times shorter) on ONE dense grouped product - instead of
-# the towers' diagonal blocks
-TOWER_FOLD = os.environ.get('I3D_TOWER_FOLD', '0') == '1'
+# I3D_TOWER_FOLD=0: the aggregation of a stacked layer with all its scaler blocks ([N, 12 F]) instead of the scalers folded into
+# per-degree posttrans weights as in the 2D network (the aggregation writes its identity blocks only, K of the products on it is
+# n_scalers times shorter, the aggregated tensor n_scalers times smaller; with I3D_TOWER_BLOCKS the per-degree weights' diagonal
+# blocks are multiplied, without it one dense grouped product)
+TOWER_FOLD = os.environ.get('I3D_TOWER_FOLD', '1') != '0'
 
 
 class _RowScaleFn(torch.autograd.Function):
@@ -196,8 +198,14 @@ class PNAOriginal(nn.Module):
                         _layers._bump(c)
                 continue
             msg = tape.apply(EdgeFCFn, h, e_sorted if tw.edge_features else None, st.Wp, st.bp, None, None, idx, st.pre_spec, None)
-            agg = tape.apply(AggregateFn, msg, idx, tw.aggregators, tw.scalers, float(tw.avg_d), True, st.Fip if st.tower_major else 0)
-            x = tape.apply(Concat2FCFn, h, agg, st.Wq, st.bq, st.gamma, st.beta, None, st.post_spec(layer.training))
+            if st.fold:       # identity blocks only, the scalers in per-degree weights (the columns of st.Wq are laid out for it)
+                agg = tape.apply(AggregateFn, msg, idx, tw.aggregators, [ops.SCALER['identity']], float(tw.avg_d), False,
+                                 st.Fip if st.tower_major else 0)
+                coef = [[_scaler_coef(sc, deg, float(tw.avg_d)) for sc in tw.scalers] for deg, _, _ in idx.degree_groups()[2]]
+                x = tape.apply(GroupedConcat2FCFn, h, agg, st.Wq, st.bq, st.gamma, st.beta, None, idx, coef, st.post_spec(layer.training))
+            else:
+                agg = tape.apply(AggregateFn, msg, idx, tw.aggregators, tw.scalers, float(tw.avg_d), True, st.Fip if st.tower_major else 0)
+                x = tape.apply(Concat2FCFn, h, agg, st.Wq, st.bq, st.gamma, st.beta, None, st.post_spec(layer.training))
             if layer.training:
                 for c in st.counters:
                     _layers._bump(c)
@@ -245,8 +253,9 @@ class _LayerStack:
         # the aggregated columns tower-major ([tower][block][feature]): a tower's B blocks are one K range, the posttrans products on
         # them run as T diagonal blocks (csrc/tower.hip, i3d_gemm_f32_batched) - needs the per-tower widths padded
         self.T, self.Fip = T, Fip
-        self.fold = TOWER_FOLD
-        self.tower_major = TOWER_BLOCKS and not self.fold and T > 1 and Fip % 4 == 0 and Fop % 4 == 0
+        # (csrc/grouped.hip builds the per-degree weights with 16-byte accesses)
+        self.fold = TOWER_FOLD and Dp % 4 == 0 and (T * Fip) % 4 == 0
+        self.tower_major = TOWER_BLOCKS and T > 1 and Fip % 4 == 0 and Fop % 4 == 0
         Mp, Kp, Mq, Kq = T * Fip, 2 * Dp + Fep, T * Fop, Dp + B * T * Fip
         ldp, ldq, ldm = pad4(Kp), pad4(Kq), Mq        # (csrc/tower.hip takes the mixing weights contiguous)
         sizes = [Mp * ldp, pad4(Mp), Mq * ldq, pad4(Mq), pad4(Mq), pad4(Mq), pad4(Mixp * ldm), pad4(Mixp)]
@@ -292,7 +301,13 @@ class _LayerStack:
             W2, b2 = post.linear.weight, post.linear.bias
             self.param_blocks.append((W2, 0, Fo, Fi, Kp_t(W2), 'Wq', t * Fop, c0))
             for k in range(B):
-                col = Dp + t * B * Fip + k * Fip if self.tower_major else Dp + k * T * Fip + t * Fip
+                nA = len(towers[0].aggregators)
+                if self.tower_major and self.fold:      # [scaler][tower][aggregator][feature]
+                    col = Dp + (k // nA) * (T * nA * Fip) + t * (nA * Fip) + (k % nA) * Fip
+                elif self.tower_major:                  # [tower][block][feature]
+                    col = Dp + t * B * Fip + k * Fip
+                else:                                   # [block][tower][feature]
+                    col = Dp + k * T * Fip + t * Fip
                 self.param_blocks.append((W2, Fi + k * Fi, Fo, Fi, Kp_t(W2), 'Wq', t * Fop, col))
             self.param_blocks.append((b2, 0, 1, Fo, Fo, 'bq', 0, t * Fop))
             self.params += [W, b, W2, b2]
@@ -488,7 +503,9 @@ class _TowerLayerFn(torch.autograd.Function):
         if st.fold:
             rows, tiles, groups = idx.degree_groups()
             nS = len(tw.scalers)
-            if len(groups) <= 32 and len(groups) * nS <= 128:
+            if not (len(groups) <= 32 and len(groups) * nS <= 128):
+                raise NotImplementedError('I3D_TOWER_FOLD: more than 32 distinct in-degrees in one batch')
+            if True:
                 a.n_deg_groups, a.m_padded = len(groups), rows.shape[0]
                 for gi, (deg, start, count) in enumerate(groups):
                     a.group_start[gi], a.group_count[gi] = start, count

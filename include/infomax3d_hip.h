@@ -165,6 +165,13 @@ int i3d_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int K, const fl
                          int ldb, long b_batch, float* C, int ldc, long c_batch, int n_batch, int accumulate, void* workspace,
                          long workspace_bytes, void* stream);
 
+/* i3d_gemm_f32_grouped (below) whose per-group weight is block-diagonal: batch b multiplies the columns A + b a_batch of the
+ * group's rows by B_g + b b_batch into the columns C + b c_batch - the towers' blocks of the per-degree posttrans weights of the
+ * tower variant (csrc/tower.hip with I3dTowerLayerArgs.n_towers > 1 and n_deg_groups > 0) */
+int i3d_gemm_f32_grouped_batched(int trans_b, int m_padded, int N, int K, const float* A, int lda, long a_batch, long a_rows_total,
+                                 const int* m_rows, const int* tile_group, const float* B, int ldb, long b_group_stride, long b_batch,
+                                 float* C, int ldc, long c_batch, int n_batch, int accumulate, void* stream);
+
 /* ---- degree-grouped posttrans of the PNA layer ------------------------------------------------------
  * replaces cat([h, agg]) -> posttrans Linear of reference models/pna.py:207-209 for the aggregated part:  the three
  * scaler blocks of agg are per-node multiples (functions of the in-degree D only) of the same aggregator block a,
@@ -411,11 +418,13 @@ typedef struct {
      * its gradient read tower-major (i3d_pna_aggregate_fwd_towers); needs f_msg / n_towers and f_out / n_towers multiples of 4.
      * 0 / 1: one dense product on [block][tower][feature] columns */
     int n_towers;
-    /* > 0 (with n_towers <= 1): the scalers folded into per-degree weights as in the 2D network's posttrans block (above:
+    /* > 0: the scalers folded into per-degree weights as in the 2D network's posttrans block (above:
      * "degree-grouped posttrans") - the aggregation writes its identity blocks only ([N, n_aggregators f_msg]), the product on it
      * is grouped by in-degree with W_D = sum_s coef[g][s] W_s: K of the dominant products n_scalers times shorter, the aggregated
      * tensor n_scalers times smaller.  group_start / group_count / coef / deg_rows / deg_tile_group / m_padded as in
-     * I3dGroupedFcArgs (graph.py: GraphIndex.degree_groups) */
+     * I3dGroupedFcArgs (graph.py: GraphIndex.degree_groups).  With n_towers > 1 as well: the columns behind f_in are
+     * [scaler][tower][aggregator][feature], the aggregation is written tower-major and the per-degree weights' diagonal blocks
+     * are multiplied (i3d_gemm_f32_grouped_batched); the weight gradient stays one dense grouped product */
     int n_deg_groups, m_padded;
     int group_start[32];
     int group_count[32];
