@@ -239,7 +239,9 @@ class DevicePrefetcher:
     the index views, the complete-graph build: `to_device`, ~0.5 ms of Python per batch - done by a helper thread `depth` batches ahead
     of the training loop instead of inside it.  The reference does this part in its training loop too (`move_to_device` +
     per-batch graph handling, trainer/trainer.py:111-115); here the loop is ~1.4 ms of host time per step against 2.0 ms on the
-    device, so another 0.5 ms per batch makes the HOST the bound (bench.py: 203 k against 255 k molecules/s).  The helper runs its
+    device, so on a slower host another 0.5 ms per batch makes the HOST the bound (bench.py: 179-200 k against 252 k molecules/s; with
+    a 200 us switch interval the helper brings that to 215-219 k).  On a box whose host keeps up anyway the two Python threads only
+    contend for the interpreter lock (246 -> 199 k measured): use it when the loop is host-bound.  The helper runs its
     Python while the training thread is inside the library's C calls (they release the interpreter lock: ~0.9 ms per step).
     Everything is enqueued on the stream that was current where the prefetcher was built, in the order the batches are handed
     out, so a batch's build kernels are always in front of its first use; `switch_interval` (seconds, optional) bounds how long
@@ -295,13 +297,16 @@ class DevicePrefetcher:
         return item
 
     def close(self):
+        """stops the helper (batches it still holds are dropped) and restores the switch interval"""
+        import queue
         import sys
         self._stop = True
-        try:
-            while self.thread.is_alive():
+        while self.thread.is_alive():
+            try:
                 self.q.get(timeout=0.05)
-        except Exception:
-            pass
+            except queue.Empty:
+                pass
+        self.thread.join()
         if self._old_interval is not None:
             sys.setswitchinterval(self._old_interval)
             self._old_interval = None

@@ -94,6 +94,9 @@ def parse():
     ap.add_argument('--no-prewarm', action='store_true', help='skip dist.warm_up before init_process_group (A/B)')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise RCCL and run the data-parallel code path even with one rank (self-test)')
+    ap.add_argument('--prefetch-thread', action='store_true',
+                    help='also measure the assembly-inclusive rate with dataset.DevicePrefetcher (the device half of the assembly on a '
+                         'helper thread); box-dependent: helps a host-bound loop, costs a device-bound one')
     ap.add_argument('--no-extra-workloads', action='store_true',
                     help='skip the short windows of the other BASELINE.json configs after the timed region (config.extra_workloads)')
     ap.add_argument('--dry-run', action='store_true',
@@ -624,7 +627,7 @@ def main():
                 rates.append((n_ld // 3) * B / (time.perf_counter() - ta))
             with_assembly = round(sorted(rates)[1], 1)
             # the same with the device half of the assembly on a helper thread (dataset.DevicePrefetcher), two batches ahead
-            for interval in (None, 2e-4, 5e-5):
+            for interval in ((None, 2e-4) if args.prefetch_thread else ()):
                 stream = dataset.BatchStream(flat, B, steps=n_ld + 12, seed=2)
                 loader = torch.utils.data.DataLoader(stream, batch_size=None, num_workers=args.loader_workers, pin_memory=True,
                                                      prefetch_factor=4)
@@ -642,6 +645,7 @@ def main():
                     torch.cuda.synchronize()
                     rates.append((n_ld // 3) * B / (time.perf_counter() - ta))
                 pf.close()
+                del pf, loader, stream
                 with_prefetch[str(interval)] = round(sorted(rates)[1], 1)
             if os.environ.get('I3D_BENCH_DEBUG'):
                 print('loader windows, molecules/s:', ' '.join(f'{v:.0f}' for v in rates), file=sys.stderr)
@@ -852,8 +856,7 @@ def main():
                                molecules_per_s_incl_batch_assembly_and_h2d=with_assembly,
                                molecules_per_s_incl_batch_assembly_in_the_training_thread=with_assembly_inline,
                                molecules_per_s_incl_batch_assembly_device_half_on_a_helper_thread=(
-                                   dict(default_switch_interval=with_prefetch.get('None'), switch_interval_200us=with_prefetch.get('0.0002'),
-                                        switch_interval_50us=with_prefetch.get('5e-05'))
+                                   dict(default_switch_interval=with_prefetch.get('None'), switch_interval_200us=with_prefetch.get('0.0002'))
                                    if with_prefetch else None)),
                    roofline=roof)
         if collectives is not None:
