@@ -125,7 +125,7 @@ def embedding_sum_bwd(idx, grad_out, dims, row_perm=None):
     feat = grad_out.shape[1]
     total = sum(dims)
     L = _lib.load()
-    if MULTIHOT_EMB_BWD and rows > 0 and total <= 1024 and n_cols <= 16 and feat % 4 == 0:
+    if MULTIHOT_EMB_BWD and rows > 0 and total <= 1024 and n_cols <= 16 and (feat % 4 == 0 or MULTIHOT_UNALIGNED):
         # all tables at once: multi-hot^T dY, split-K through the scratch (deterministic; the LDS-atomics kernel below
         # needs ~115 us for the 9 atom tables of a 512-molecule batch)
         v_pad = (total + 31) // 32 * 32
@@ -153,6 +153,8 @@ def embedding_sum_bwd(idx, grad_out, dims, row_perm=None):
 
 # I3D_MULTIHOT_EMB_BWD=0: embedding-table gradients by LDS-privatised atomics instead of the multi-hot GEMM
 MULTIHOT_EMB_BWD = os.environ.get('I3D_MULTIHOT_EMB_BWD', '1') != '0'
+# I3D_MULTIHOT_UNALIGNED=0: table widths that are not multiples of 4 (the tower variant's 90 / 70) through the LDS-atomics kernel
+MULTIHOT_UNALIGNED = os.environ.get('I3D_MULTIHOT_UNALIGNED', '1') != '0'
 
 
 # ---- K4 / K6 ---------------------------------------------------------------------------------------------
