@@ -567,10 +567,14 @@ class FCLayer(nn.Module):
     def __init__(self, in_dim, out_dim, activation='relu', dropout=0., batch_norm=False, batch_norm_momentum=0.1,
                  bias=True, init_fn=None, device='cpu'):
         super().__init__()
-        if not bias:
-            raise NotImplementedError('bias=False is not on the accelerated path')
         self.in_dim, self.out_dim, self.bias = in_dim, out_dim, bias
         self.linear = nn.Linear(in_dim, out_dim, bias=bias).to(device)
+        if not bias:
+            # reference models/base_layers.py:86: nn.Linear(..., bias=False) - no bias parameter, no state_dict key.  The kernels take
+            # a bias vector: a zero buffer outside the state_dict (it follows .to(); its gradient is computed and dropped).  The MLPs of
+            # the models never build such a layer (base_layers.py:114-147 does not pass `bias`), so the whole-model sequencers never
+            # meet one (pna_native / net3d_native check).
+            self.register_buffer('_zero_bias', torch.zeros(out_dim, device=device), persistent=False)
         self.dropout = nn.Dropout(p=dropout) if dropout else None      # (the reference's attribute; applied in _Tail, training mode only)
         self.batch_norm = nn.BatchNorm1d(out_dim, momentum=batch_norm_momentum).to(device) if batch_norm else None
         self.activation = act_name(activation)
@@ -603,7 +607,8 @@ class FCLayer(nn.Module):
         h = cache.get(post_act)
         if h is not None:
             lp, bp = h[5], h[6]      # the sub-modules' parameter dicts: a re-assigned Parameter object invalidates the entry
-            if lp['weight'] is h[0] and lp['bias'] is h[1] and (bp is None or (bp['weight'] is h[2] and bp['bias'] is h[3])):
+            bias_now = lp['bias'] if self.bias else self._buffers['_zero_bias']
+            if lp['weight'] is h[0] and bias_now is h[1] and (bp is None or (bp['weight'] is h[2] and bp['bias'] is h[3])):
                 dm = h[7]            # the nn.Dropout module (or None): `layer.dropout.p = ...` in place must take effect too
                 if dm is None or (float(dm.p) if self.training else 0.0) == h[4].dropout:
                     return h
@@ -615,8 +620,8 @@ class FCLayer(nn.Module):
             gamma, beta, bp = m.weight, m.bias, m._parameters
         lin = self.linear
         drop = float(self.dropout.p) if (self.dropout is not None and self.training) else 0.0
-        h = cache[post_act] = (lin.weight, lin.bias, gamma, beta, FCSpec(self.activation, bn, post_act, drop), lin._parameters, bp,
-                               self.dropout)
+        h = cache[post_act] = (lin.weight, lin.bias if self.bias else self._buffers['_zero_bias'], gamma, beta,
+                               FCSpec(self.activation, bn, post_act, drop), lin._parameters, bp, self.dropout)
         return h
 
     def _drop_hot(self):

@@ -56,7 +56,7 @@ def eligible(model, g):
     fcs = [edge_in] + [fc for m, _, u, _ in layers for fc in m + u] + nw + out[:-1]
     for fc in fcs:
         h = fc.hot()
-        if not (_composite_ok(h[4]) and h[0].is_cuda and h[0].is_contiguous() and h[1] is not None):
+        if not (_composite_ok(h[4]) and h[0].is_cuda and h[0].is_contiguous() and h[1] is not None and fc.bias):
             return False
     last = out[-1].hot()
     if last[4].bn is not None:                       # BatchNorm on the last output layer: an ordinary block

@@ -29,6 +29,8 @@ class _Desc:
 
 
 def _fc_ok(fc, need_bn):
+    if not fc.bias:                     # FCLayer(bias=False): the block Functions only
+        return False
     if fc.dropout is not None:          # dropout > 0: the per-kernel path (layers._Tail)
         return False
     if fc.batch_norm is None:
