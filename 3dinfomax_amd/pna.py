@@ -147,6 +147,17 @@ class PNAGNN(nn.Module):
         n_comb = 1
         for d in dims:
             n_comb *= d
+        pairwise = any(l.pairwise_distances for l in self.mp_layers)
+        if pairwise:
+            # reference models/pna.py:243-245: every layer's edge input gets the squared distance of the end points' coordinates
+            # (ndata['x']) as one more column - a per-edge value, so the bond-table form (60 joint values) does not apply: the
+            # materialised embeddings [E, F], one column wider, built once for all layers
+            ef_sorted = self.bond_encoder(bond_idx, perm=idx.perm)
+            q = tape.apply(_AppendSqDistFn, ef_sorted, g.ndata['x'], idx)
+            for mp_layer in self.mp_layers:
+                mp_layer(g, ef_sorted=q if mp_layer.pairwise_distances else ef_sorted, dist_appended=True)
+            g.edata['feat'] = ops.gather_rows(ef_sorted.detach(), idx.inv_perm)
+            return
         if EDGE_TABLE and n_comb <= 256 and idx.num_edges > 0 and bond_idx.dtype == torch.int64:
             # the bond embedding takes n_comb (60) distinct values: every layer's  e_feat W_q^T  is a gather from the
             # [n_comb, F] table of all combinations times W_q^T (layers.EdgeTable) instead of an [E, F] x [F, F] product
@@ -178,6 +189,37 @@ class PNAGNN(nn.Module):
                 stride *= d
             cache[key] = torch.stack(cols, 1).contiguous().to(device)
         return cache[key]
+
+
+class _AppendSqDistFn(torch.autograd.Function):
+    """[ef | d^2]: the edge features (destination-sorted, or None) with the squared end-point distance as last column
+    (csrc/pack.hip: i3d_copy_cols + i3d_edge_sqdist); coordinates are data: the gradient is the crop."""
+
+    @staticmethod
+    def forward(ctx, ef, x, index):
+        E = index.num_edges
+        x = x.contiguous().float()
+        assert x.dim() == 2 and x.shape[1] == 3, "pairwise_distances=True needs the atom coordinates in ndata['x'] [N, 3]"
+        F = ef.shape[1] if ef is not None else 0
+        ctx.F = F
+        out = torch.empty(E, F + 1, dtype=torch.float32, device=x.device)
+        L = ops._lib.load()
+        if ef is not None:
+            ef = ef.contiguous()
+            ops.check(L.i3d_copy_cols(ef.data_ptr(), E, F, out.data_ptr(), F + 1, ops._stream()), 'i3d_copy_cols')
+        ops.check(L.i3d_edge_sqdist(x.data_ptr(), index.src_s.data_ptr(), index.dst_s.data_ptr(), E, out.data_ptr(), F + 1, F,
+                                    ops._stream()), 'i3d_edge_sqdist')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.F == 0:
+            return None, None, None
+        g = g.contiguous()
+        out = torch.empty(g.shape[0], ctx.F, dtype=torch.float32, device=g.device)
+        ops.check(ops._lib.load().i3d_copy_cols(g.data_ptr(), g.shape[0], g.shape[1], out.data_ptr(), ctx.F, ops._stream()),
+                  'i3d_copy_cols')
+        return out, None, None
 
 
 class _LayerPlan:
@@ -274,8 +316,6 @@ class PNALayer(nn.Module):
                  mid_batch_norm: bool = False, last_batch_norm: bool = False, batch_norm_momentum=0.1,
                  avg_d: Dict[str, float] = {"log": 1.0}, posttrans_layers: int = 2, pretrans_layers: int = 1):
         super().__init__()
-        if pairwise_distances:
-            raise NotImplementedError('pairwise_distances=True is not on the accelerated path (no BASELINE config uses it)')
         self.aggregators = _codes(aggregators, ops.AGG, 'aggregator')
         self.scalers = _codes(scalers, ops.SCALER, 'scaler')
         self.edge_features = in_dim_edges > 0
@@ -285,7 +325,8 @@ class PNALayer(nn.Module):
         self.residual = residual
         if in_dim != out_dim:
             self.residual = False
-        self.pretrans = MLP(in_dim=2 * in_dim + in_dim_edges, hidden_size=in_dim, out_dim=in_dim,
+        # (pairwise_distances: one more input column, the squared distance of the edge's end points, reference :243-249)
+        self.pretrans = MLP(in_dim=2 * in_dim + in_dim_edges + (1 if pairwise_distances else 0), hidden_size=in_dim, out_dim=in_dim,
                             mid_batch_norm=mid_batch_norm, last_batch_norm=last_batch_norm, layers=pretrans_layers,
                             mid_activation=activation, dropout=dropout, last_activation=last_activation,
                             batch_norm_momentum=batch_norm_momentum)
@@ -294,12 +335,17 @@ class PNALayer(nn.Module):
                              last_activation=last_activation, dropout=dropout, mid_batch_norm=mid_batch_norm,
                              last_batch_norm=last_batch_norm, batch_norm_momentum=batch_norm_momentum)
 
-    def forward(self, g, ef_sorted=None, qmap=None):
+    def forward(self, g, ef_sorted=None, qmap=None, dist_appended=False):
         g = as_batched_graph(g)
         idx = g.index()
         h = g.ndata['feat']
         if ef_sorted is None and self.edge_features:
             ef_sorted = tape.apply(_GatherRowsFn, g.edata['feat'], idx.perm, idx.inv_perm)
+        has_q = self.edge_features
+        if self.pairwise_distances:
+            if not dist_appended:       # stand-alone use: PNAGNN appends the column once for all its layers
+                ef_sorted = tape.apply(_AppendSqDistFn, ef_sorted if self.edge_features else None, g.ndata['x'], idx)
+            has_q, qmap = True, None
         avg = float(self.avg_d["log"])
         grouped = GROUPED_POSTTRANS and len(self.scalers) > 1 and h.shape[1] % 4 == 0
         if FUSED_LAYER and h.is_cuda:
@@ -326,13 +372,12 @@ class PNALayer(nn.Module):
                     plan.coef = cache[key] = [[_scaler_coef(s, D, avg) for s in self.scalers]
                                               for D, _, _ in idx.degree_groups()[2]]
             params = [t for hot in hots for t in hot[:4]]
-            h_new = tape.apply(PNALayerFn, h, ef_sorted if self.edge_features else None, idx,
-                                     qmap if self.edge_features else None, plan, *params)
+            h_new = tape.apply(PNALayerFn, h, ef_sorted if has_q else None, idx,
+                                     qmap if has_q else None, plan, *params)
             g.ndata['feat'] = h_new
             return h_new
         # pretransformation (edge MLP on [h_src | h_dst | e_feat]) -> messages, destination-sorted
-        e = self.pretrans.forward_edge(h, ef_sorted if self.edge_features else None, idx,
-                                       qmap=qmap if self.edge_features else None)
+        e = self.pretrans.forward_edge(h, ef_sorted if has_q else None, idx, qmap=qmap if has_q else None)
         if grouped:
             # the scaler blocks are per-node multiples of the aggregator block that depend on the in-degree only:
             # aggregate once ([N, n_agg*F], identity block) and fold the scalers into per-degree posttrans weights

@@ -99,6 +99,8 @@ def _structure_ok(module):
     if n_comb > 256 or len(gnn.bond_encoder.dims) > 8 or len(gnn.atom_encoder.dims) > 16:
         return False
     for layer in gnn.mp_layers:
+        if layer.pairwise_distances:        # a per-edge input column: the block Functions (pna.PNAGNN.forward)
+            return False
         pre, post = list(layer.pretrans.fully_connected), list(layer.posttrans.fully_connected)
         if len(post) != 1 or not 1 <= len(pre) <= 4:
             return False

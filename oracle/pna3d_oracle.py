@@ -174,11 +174,13 @@ def pna_reduce(mailbox, D, aggregators, scalers, avg_d_log=1.0, route=None):
     return h
 
 
-def pna_layer(h, ef, src, dst, P, prefix, cfg, training, capture=None, route=None):
+def pna_layer(h, ef, src, dst, P, prefix, cfg, training, capture=None, route=None, x=None):
     """reference models/pna.py:199-252 (PNALayer.forward / pretrans_edges).  route (tests): {'max': [N, F], 'min': [N, F]}
     mailbox positions the max / min gradients of every node are routed to; capture receives this side's own choices."""
     n = h.shape[0]
     z = torch.cat([h[src], h[dst], ef], dim=-1)                          # :249
+    if cfg.get('pairwise_distances', False):                             # :243-245: squared distance of the end points' coordinates
+        z = torch.cat([z, torch.sum((x[src] - x[dst]) ** 2, dim=-1)[:, None]], dim=-1)
     e = mlp(z, P, f'{prefix}.pretrans', cfg['pretrans_layers'], cfg['activation'], cfg['last_activation'],
             cfg['mid_batch_norm'], cfg['last_batch_norm'], cfg['batch_norm_momentum'], training)   # :252
     n_out = len(cfg['aggregators']) * (len(cfg['scalers']) if len(cfg['scalers']) > 1 else 1) * h.shape[1]
@@ -215,7 +217,7 @@ def pna_forward(graph, P, cfg, training=True, capture=None, route=None):
         if capture is not None:
             cap = capture.setdefault(f'layer{l}', {})
         h = pna_layer(h, ef, graph['src'], graph['dst'], P, f'node_gnn.mp_layers.{l}', cfg, training, cap,
-                      route.get(f'layer{l}') if route is not None else None)
+                      route.get(f'layer{l}') if route is not None else None, x=graph.get('x'))
     rcap = capture.setdefault('readout', {}) if capture is not None else None
     r = torch.cat([segment_readout(h, graph['batch_num_nodes'], op, route.get('readout') if route is not None else None, rcap)
                    for op in cfg['readout_aggregators']], dim=-1)
@@ -431,7 +433,9 @@ def graphs_from_molecules(mols, coords_list=None):
         off += n
     t = lambda x, dt: torch.from_numpy(np.concatenate(x)).to(dt)
     g2 = dict(src=t(srcs, torch.long), dst=t(dsts, torch.long), atom_feat=t(af, torch.long),
-              bond_feat=t(bf, torch.long), batch_num_nodes=bnn, num_nodes=off)
+              bond_feat=t(bf, torch.long), batch_num_nodes=bnn, num_nodes=off,
+              x=torch.from_numpy(np.concatenate([(m.coords if coords_list is None else coords_list[i]).astype(np.float32)
+                                                 for i, m in enumerate(mols)])))      # ndata['x'] (pairwise_distances=True)
     g3 = dict(src=t(s3, torch.long), dst=t(d3, torch.long), d=t(dd, torch.float32), batch_num_nodes=bnn,
               num_nodes=off)
     return g2, g3

@@ -1265,3 +1265,34 @@ def test_pna_and_net3d_with_dropout(amd):
     with torch.no_grad():
         assert rel_err(pna(a1).cpu(), p0(a2).cpu()) < 1e-5
         assert rel_err(net(b1).cpu(), n0(b2).cpu()) < 1e-5
+
+
+def test_pna_with_pairwise_distances_vs_reference_fixture(amd):
+    """PNA(pairwise_distances=True), reference models/pna.py:105, 239-249: every layer's pretrans MLP also sees the squared distance of
+    the edge's end points (ndata['x']).  The reference's own state_dict loads strictly (in_dim 3 F + 1); outputs, node embeddings,
+    gradients and running statistics against the fixture tests/golden/gen_golden_pairwise.py made from the reference."""
+    from test_oracle_golden import PNA_PAIRWISE
+    z = load('pna_pairwise.npz')
+    mols = mols_from_npz(z)
+    pna = amd.PNA(avg_d=1.0, device='cuda:0', **PNA_PAIRWISE)
+    pna.load_state_dict(sd_from_npz(z, 'sd'), strict=True)
+    pna.cuda().train()
+    graphs = []
+    for m in mols:
+        g = amd.bond_graph(m)
+        g.ndata['x'] = torch.from_numpy(m.coords.astype(np.float32))
+        graphs.append(g)
+    g2 = amd.batch(graphs).to('cuda:0')
+    g_eval = g2.local_copy()             # (the forward overwrites ndata['feat'] / edata['feat'] with the embeddings, as the reference's)
+    out = pna(g2)
+    assert rel_err(g2.ndata['feat'].cpu(), z['node_emb']) < TOL
+    assert rel_err(out.cpu(), z['out']) < TOL
+    (out * torch.from_numpy(z['cot']).cuda()).sum().backward()
+    grads_close(param_grads(pna), sd_from_npz(z, 'grad'), 5e-4)
+    for k, v in sd_from_npz(z, 'sd_after').items():
+        if 'running' in k:
+            assert close(pna.state_dict()[k], v, TOL, 1e-6), k
+    # eval mode (running statistics) through the same path
+    pna.eval()
+    with torch.no_grad():
+        assert torch.isfinite(pna(g_eval)).all()

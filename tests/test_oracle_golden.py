@@ -158,3 +158,26 @@ def test_known_answer_initial_loss_is_log_b_minus_1():
     z2, _ = O.pna_forward(g2, O.init_pna_params(cfg2, 3), cfg2, True)
     z3, _ = O.net3d_forward(g3, O.init_net3d_params(cfg3, 4), cfg3, True)
     assert abs(O.ntxent(z2, z3, tau=0.1).item() - math.log(B - 1)) < 0.35
+
+
+PNA_PAIRWISE = dict(target_dim=8, hidden_dim=16, mid_batch_norm=True, last_batch_norm=True, readout_batchnorm=True,
+                    batch_norm_momentum=0.9, readout_hidden_dim=16, readout_layers=2, dropout=0.0, propagation_depth=2,
+                    aggregators=['mean', 'max', 'min', 'std'], scalers=['identity', 'amplification', 'attenuation'],
+                    readout_aggregators=['min', 'max', 'mean'], pretrans_layers=2, posttrans_layers=1, residual=True,
+                    pairwise_distances=True)
+
+
+def test_pna_with_pairwise_distances_matches_reference():
+    """PNA(pairwise_distances=True), reference models/pna.py:105, 239-249: the squared distance of an edge's end points (ndata['x'])
+    as one more input of every layer's pretrans MLP; fixture from the reference itself (tests/golden/gen_golden_pairwise.py)."""
+    z = load('pna_pairwise.npz')
+    g2, _ = _graphs(z)
+    cfg = O.pna_config(**PNA_PAIRWISE)
+    P = O.require_grad(sd_from_npz(z, 'sd'))
+    assert P['node_gnn.mp_layers.0.pretrans.fully_connected.0.linear.weight'].shape[1] == 3 * 16 + 1
+    out, emb = O.pna_forward(g2, P, cfg, True)
+    assert rel_err(emb, z['node_emb']) < TOL
+    assert rel_err(out, z['out']) < TOL
+    (out * torch.from_numpy(z['cot'])).sum().backward()
+    ref = sd_from_npz(z, 'grad')
+    grads_close({k: P[k].grad for k in ref}, ref, 1e-4)
