@@ -104,13 +104,37 @@ class NTXentFn(torch.autograd.Function):
         return dz1, dz2, None, None, None, None, None, None
 
 
-# Optional regularisers (weights 0 in every BASELINE config, so they are plain differentiable torch expressions here,
-# not kernels).  Semantics of reference commons/losses.py:946-964.
+class _GramFn(torch.autograd.Function):
+    """x x^T (rows=True: [n, n]) or x^T x ([d, d]) through the library's GEMM (csrc/gemm.hip) - the matrix products of the
+    regularisers below stay on the hand-written kernels; d(G)/dx = (dG + dG^T) x  resp.  x (dG + dG^T)."""
+
+    @staticmethod
+    def forward(ctx, x, rows):
+        x = x.contiguous()
+        ctx.rows = rows
+        ctx.save_for_backward(x)
+        return ops.gemm(x, x, trans_b=True) if rows else ops.gemm(x, x, trans_a=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        gs = (g + g.transpose(0, 1)).contiguous()
+        return (ops.gemm(gs, x) if ctx.rows else ops.gemm(x, gs)), None
+
+
+def _gram(x, rows):
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
+        return _GramFn.apply(x, rows)
+    return x @ x.T if rows else x.T @ x          # (CPU tensors: the host-logic tests)
+
+
+# Optional regularisers (weights 0 in every BASELINE config): differentiable torch expressions around the library's GEMM for
+# their matrix products.  Semantics of reference commons/losses.py:946-964.
 def _log_mean_gaussian_potential(x, t):
     """log of the mean of exp(-t |x_i - x_j|^2) over all unordered pairs i < j"""
     n = x.shape[0]
     sq = (x * x).sum(dim=1)
-    d2 = (sq[:, None] + sq[None, :] - 2.0 * (x @ x.T)).clamp_min(0.0)
+    d2 = (sq[:, None] + sq[None, :] - 2.0 * _gram(x, True)).clamp_min(0.0)
     iu = torch.triu_indices(n, n, offset=1, device=x.device)
     return torch.exp(-t * d2[iu[0], iu[1]]).mean().log()
 
@@ -124,7 +148,7 @@ def cov_loss(x):
     """sum of squared off-diagonal entries of the feature covariance, divided by the feature count (reference :954-959)"""
     n, dim = x.shape
     centred = x - x.mean(dim=0, keepdim=True)
-    cov = centred.T @ centred / (n - 1)
+    cov = _gram(centred, False) / (n - 1)
     off = cov - torch.diag_embed(torch.diagonal(cov))
     return (off * off).sum() / dim
 
