@@ -53,13 +53,14 @@ __global__ void __launch_bounds__(256) copy_cols_kernel(const float* __restrict_
 // out[j * ld + col] = |x[src_j] - x[dst_j]|^2 (three coordinates; squares, then sums in order, no contraction: torch's
 // sum((a - b) ** 2, dim=-1) bit for bit)
 __global__ void __launch_bounds__(256) edge_sqdist_kernel(const float* __restrict__ x, const int* __restrict__ src, const int* __restrict__ dst,
-                                                          int E, float* __restrict__ out, int ld, int col) {
+                                                          int E, float* __restrict__ out, int ld, int col, int take_sqrt) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= E) return;
     const float* a = x + 3L * src[j];
     const float* b = x + 3L * dst[j];
     const float d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
-    out[(long)j * ld + col] = __fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2));
+    const float sq = __fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2));
+    out[(long)j * ld + col] = take_sqrt ? __fsqrt_rn(sq) : sq;
 }
 
 }  // namespace
@@ -67,11 +68,13 @@ __global__ void __launch_bounds__(256) edge_sqdist_kernel(const float* __restric
 
 using namespace i3d;
 
-extern "C" int i3d_edge_sqdist(const float* x, const int* src, const int* dst, int num_edges, float* out, int ld, int col, void* stream) {
+extern "C" int i3d_edge_sqdist(const float* x, const int* src, const int* dst, int num_edges, float* out, int ld, int col, int take_sqrt,
+                               void* stream) {
     I3D_CHECK_ARG(num_edges >= 0 && ld > col && col >= 0 && (num_edges == 0 || (x != nullptr && src != nullptr && dst != nullptr && out != nullptr)),
                   "bad arguments");
     if (num_edges == 0) return I3D_OK;
-    hipLaunchKernelGGL(edge_sqdist_kernel, dim3(cdiv(num_edges, 256)), dim3(256), 0, (hipStream_t)stream, x, src, dst, num_edges, out, ld, col);
+    hipLaunchKernelGGL(edge_sqdist_kernel, dim3(cdiv(num_edges, 256)), dim3(256), 0, (hipStream_t)stream, x, src, dst, num_edges, out, ld, col,
+                       take_sqrt);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }

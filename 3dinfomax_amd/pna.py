@@ -193,10 +193,11 @@ class PNAGNN(nn.Module):
 
 class _AppendSqDistFn(torch.autograd.Function):
     """[ef | d^2]: the edge features (destination-sorted, or None) with the squared end-point distance as last column
-    (csrc/pack.hip: i3d_copy_cols + i3d_edge_sqdist); coordinates are data: the gradient is the crop."""
+    (csrc/pack.hip: i3d_copy_cols + i3d_edge_sqdist; take_sqrt: the distance itself, the tower variant's use_3d); coordinates are
+    data: the gradient is the crop."""
 
     @staticmethod
-    def forward(ctx, ef, x, index):
+    def forward(ctx, ef, x, index, take_sqrt=False):
         E = index.num_edges
         x = x.contiguous().float()
         assert x.dim() == 2 and x.shape[1] == 3, "pairwise_distances=True needs the atom coordinates in ndata['x'] [N, 3]"
@@ -208,18 +209,18 @@ class _AppendSqDistFn(torch.autograd.Function):
             ef = ef.contiguous()
             ops.check(L.i3d_copy_cols(ef.data_ptr(), E, F, out.data_ptr(), F + 1, ops._stream()), 'i3d_copy_cols')
         ops.check(L.i3d_edge_sqdist(x.data_ptr(), index.src_s.data_ptr(), index.dst_s.data_ptr(), E, out.data_ptr(), F + 1, F,
-                                    ops._stream()), 'i3d_edge_sqdist')
+                                    int(take_sqrt), ops._stream()), 'i3d_edge_sqdist')
         return out
 
     @staticmethod
     def backward(ctx, g):
         if ctx.F == 0:
-            return None, None, None
+            return None, None, None, None
         g = g.contiguous()
         out = torch.empty(g.shape[0], ctx.F, dtype=torch.float32, device=g.device)
         ops.check(ops._lib.load().i3d_copy_cols(g.data_ptr(), g.shape[0], g.shape[1], out.data_ptr(), ctx.F, ops._stream()),
                   'i3d_copy_cols')
-        return out, None, None
+        return out, None, None, None
 
 
 class _LayerPlan:

@@ -7,7 +7,7 @@ pretrans, the two-segment posttrans GEMMs, `h * snorm_n` as a row-scale kernel, 
 
 dropout / in_feat_dropout > 0 (configs/pna_original_simple.yml: 0.3) draw torch's own mask (layers.DropoutFn) and keep the
 towers on the per-tower path.  Not on the accelerated path (raise NotImplementedError; no yml of these models uses them):
-gru_enable, use_3d, moment aggregators.
+gru_enable, moment aggregators.
 """
 import ctypes
 import os
@@ -20,7 +20,7 @@ from .graph import as_batched_graph
 from .layers import (MLP, AggregateFn, BNSpec, Concat2FCFn, EdgeFCFn, FCFn, FCSpec, GroupedConcat2FCFn, ReadoutFn,
                      dropout as _dropout)
 from .mol_encoder import AtomEncoder, BondEncoder
-from .pna import _codes, _GatherRowsFn, _scaler_coef
+from .pna import _AppendSqDistFn, _codes, _GatherRowsFn, _scaler_coef
 
 # I3D_TOWER_STACK=0: the towers of a layer one after the other (one autograd node per block and tower: the first version)
 TOWER_STACK = os.environ.get('I3D_TOWER_STACK', '1') != '0'
@@ -119,8 +119,6 @@ class MLPReadout(nn.Module):
 def _check_unsupported(dropout=0.0, in_feat_dropout=0.0, gru_enable=False, use_3d=False):
     if gru_enable:
         raise NotImplementedError('gru_enable=True is not on the accelerated path')
-    if use_3d:
-        raise NotImplementedError('use_3d=True is not on the accelerated path')
 
 
 class PNAOriginal(nn.Module):
@@ -429,6 +427,8 @@ def _stackable(model):
     gnn = model.node_gnn
     if getattr(gnn, 'gru_enable', False):
         return False
+    if any(tw.use_3d for layer in gnn.layers for tw in layer.towers):
+        return False          # (a per-edge input column: the per-tower path)
     if any(tw.dropout.p > 0 for layer in gnn.layers for tw in layer.towers):
         return False          # (a mask per tower, drawn in the towers' order: the per-tower path keeps the reference's random stream)
     for layer in gnn.layers:
@@ -691,9 +691,10 @@ class PNATower(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.graph_norm = graph_norm
         self.edge_features = edge_features
+        self.use_3d = use_3d           # reference :215-216, 224-226: the end points' distance (ndata['x']) as one more pretrans input
         self.aggregators = _codes(aggregators, ops.AGG, 'aggregator')
         self.scalers = _codes(scalers, ops.SCALER, 'scaler')
-        self.pretrans = MLP(in_dim=2 * in_dim + (edge_hidden_dim if edge_features else 0), hidden_size=in_dim,
+        self.pretrans = MLP(in_dim=2 * in_dim + (edge_hidden_dim if edge_features else 0) + (1 if use_3d else 0), hidden_size=in_dim,
                             out_dim=in_dim, layers=pretrans_layers, mid_activation='relu', last_activation='none')
         self.posttrans = MLP(in_dim=(len(aggregators) * len(scalers) + 1) * in_dim, hidden_size=out_dim,
                              mid_batch_norm=mid_batch_norm, last_batch_norm=last_batch_norm, out_dim=out_dim,
@@ -702,7 +703,8 @@ class PNATower(nn.Module):
 
     def forward(self, g, h, e_sorted, snorm_n):
         idx = as_batched_graph(g).index()
-        msg = self.pretrans.forward_edge(h, e_sorted if self.edge_features else None, idx)        # :246
+        q = e_sorted if (self.edge_features or self.use_3d) else None      # (use_3d: PNALayer.forward appended the distance column)
+        msg = self.pretrans.forward_edge(h, q, idx)                                               # :246
         agg = AggregateFn.apply(msg, idx, self.aggregators, self.scalers, float(self.avg_d), True)   # :249
         h = self.posttrans.forward_concat2(h, agg)                                                # :250-253
         if self.graph_norm:
@@ -745,6 +747,8 @@ class PNALayer(nn.Module):
             e = _GatherRowsFn.apply(e, idx.perm, idx.inv_perm)
         snorm_n = snorm_n.to(h.device)
         it = self.input_tower
+        if self.towers[0].use_3d:       # [e | |x_src - x_dst|], built once for the layer's towers
+            e = _AppendSqDistFn.apply(e if self.edge_features else None, g.ndata['x'], g.index(), True)
         outs = [tower(g, h[:, t * it:(t + 1) * it].contiguous() if self.divide_input else h, e, snorm_n)
                 for t, tower in enumerate(self.towers)]
         h_cat = torch.cat(outs, dim=1)

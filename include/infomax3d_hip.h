@@ -363,8 +363,10 @@ int i3d_block_copy(const I3dCopyBlock* table /* device */, int n_blocks, int rev
 int i3d_copy_cols(const float* src, int rows, int cols_src, float* dst, int cols_dst, void* stream);
 /* out[j * ld + col] = sum_k (x[src[j], k] - x[dst[j], k])^2 over the three coordinates of x [N, 3] - the squared distance that
  * PNALayer.pretrans_edges appends to an edge's features with pairwise_distances=True (reference models/pna.py:243-245);
- * src / dst: the edge list in the order of the rows of `out` (the kernels' destination-sorted order) */
-int i3d_edge_sqdist(const float* x, const int* src, const int* dst, int num_edges, float* out, int ld, int col, void* stream);
+ * src / dst: the edge list in the order of the rows of `out` (the kernels' destination-sorted order).  take_sqrt: the distance
+ * itself, torch.norm(x_src - x_dst, dim=-1) - PNATower.pretrans_edges with use_3d=True (reference models/pna_original.py:224-226) */
+int i3d_edge_sqdist(const float* x, const int* src, const int* dst, int num_edges, float* out, int ld, int col, int take_sqrt,
+                    void* stream);
 
 /* ---- one PNALayer of the tower variant from ONE call per direction (csrc/tower.hip) --------------------------------------
  * Replaces PNALayer.forward of reference models/pna_original.py:296-319 (all `towers` PNATower.forward, :239-261, the

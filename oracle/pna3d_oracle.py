@@ -492,6 +492,8 @@ def pna_original_forward(graph, snorm_n, P, cfg, training=True):
             pre = f'node_gnn.layers.{l}.towers.{t}'
             ht = h[:, t * it:(t + 1) * it] if divide else h
             z = torch.cat([ht[src], ht[dst]] + ([e] if e is not None else []), dim=1)              # :221-225
+            if cfg.get('use_3d', False):                                                           # :224-226
+                z = torch.cat([z, torch.norm(graph['x'][src] - graph['x'][dst], dim=-1)[:, None]], dim=1)
             msg = mlp(z, P, f'{pre}.pretrans', cfg['pretrans_layers'], 'relu', 'none', False, False, mom, training)
             agg = degree_bucketed_reduce(msg, dst, n, lambda mb, D: pna_original_reduce(
                 mb, D, cfg['aggregators'], cfg['scalers'], cfg['avg_d']), n_blocks * it)            # :250

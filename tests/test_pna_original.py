@@ -253,3 +253,50 @@ def test_simple_variant_with_the_dropout_of_its_yml():
     model.eval(), plain.eval()
     with torch.no_grad():
         assert torch.equal(model(g2.local_copy()), plain(g2.local_copy()))
+
+
+def _mols_with_x(amd, mols):
+    import numpy as np
+    graphs = []
+    for m in mols:
+        g = amd.bond_graph(m)
+        g.ndata['x'] = torch.from_numpy(m.coords.astype(np.float32))
+        graphs.append(g)
+    return amd.batch(graphs)
+
+
+def test_oracle_with_use_3d_matches_reference_fixture():
+    """PNAOriginal(use_3d=True), reference models/pna_original.py:215-216, 224-226; fixture tests/golden/gen_golden_original3d.py"""
+    z = load('pna_original_3d.npz')
+    mols = mols_from_npz(z)
+    g2, _ = O.graphs_from_molecules(mols)
+    P = O.require_grad(sd_from_npz(z, 'sd'))
+    out, emb = O.pna_original_forward(g2, O.snorm_n(g2['batch_num_nodes']), P, dict(PNA_ORIG_KW, use_3d=True), True)
+    assert rel_err(emb, z['node_emb']) < 2e-5
+    assert rel_err(out, z['out']) < 2e-5
+    (out * torch.from_numpy(z['cot'])).sum().backward()
+    ref = _used(sd_from_npz(z, 'grad'))
+    try:
+        grads_close({k: P[k].grad for k in ref}, ref, 2e-4)
+    except AssertionError:      # (arg-max routing on another host's summation order: see test_oracle_matches_reference_fixture)
+        grads_close_l2({k: P[k].grad for k in ref}, ref, 2e-2)
+
+
+@pytest.mark.gpu
+def test_hip_towers_with_use_3d_match_reference_fixture():
+    """use_3d=True on the HIP path: the distance column appended once per layer (csrc/pack.hip: i3d_edge_sqdist), the towers one after
+    the other (a per-edge input: not stacked); the reference's state_dict loads strictly (pretrans in_dim + 1)."""
+    amd = importlib.import_module('3dinfomax_amd')
+    z = load('pna_original_3d.npz')
+    mols = mols_from_npz(z)
+    model = amd.PNAOriginal(**dict(PNA_ORIG_KW, use_3d=True))
+    model.load_state_dict(sd_from_npz(z, 'sd'), strict=True)
+    model.cuda().train()
+    g2 = _mols_with_x(amd, mols).to('cuda:0')
+    snorm = O.snorm_n([m.n_atoms for m in mols]).cuda()
+    out = model(g2, snorm)
+    assert rel_err(g2.ndata['feat'].cpu(), z['node_emb']) < 1e-4
+    assert rel_err(out.cpu(), z['out']) < 1e-4
+    (out * torch.from_numpy(z['cot']).cuda()).sum().backward()
+    ref = sd_from_npz(z, 'grad')
+    grads_close({k: p.grad for k, p in model.named_parameters() if k in ref}, ref, 5e-4)
