@@ -155,6 +155,8 @@ _SIGNATURES = {
     'i3d_rccl_destroy': (c_int, [_P]),
     'i3d_set_collectives_rccl': (c_int, [_P, c_int, _P, c_long]),
     'i3d_block_copy': (c_int, [_P, c_int, c_int, _P]),
+    'i3d_gru_gates_fwd': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P]),
+    'i3d_gru_gates_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     'i3d_copy_cols': (c_int, [_P, c_int, c_int, _P, c_int, _P]),
     'i3d_edge_sqdist': (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, _P]),
     'i3d_tower_layer_saved_floats': (c_long, [POINTER(TowerLayerArgs)]),

@@ -6,8 +6,7 @@ always-applied scalers (reference :231-236 - no single-scaler quirk here), the e
 pretrans, the two-segment posttrans GEMMs, `h * snorm_n` as a row-scale kernel, LeakyReLU mixing.
 
 dropout / in_feat_dropout > 0 (configs/pna_original_simple.yml: 0.3) draw torch's own mask (layers.DropoutFn) and keep the
-towers on the per-tower path.  Not on the accelerated path (raise NotImplementedError; no yml of these models uses them):
-gru_enable, moment aggregators.
+towers on the per-tower path, as do use_3d and gru_enable.  Refused by name: the moment aggregators.
 """
 import ctypes
 import os
@@ -116,9 +115,53 @@ class MLPReadout(nn.Module):
                           FCSpec(None, None))
 
 
+class _GRUCellFn(torch.autograd.Function):
+    """One GRU step h' = GRU(x, h0) (torch's nn.GRU arithmetic, gate order r | z | n): two products of the library's GEMM and the
+    gate kernels of csrc/gru.hip; backward: the gate kernel, then four products and two column sums."""
+
+    @staticmethod
+    def forward(ctx, x, h0, W_ih, W_hh, b_ih, b_hh):
+        x, h0 = x.contiguous(), h0.contiguous()
+        N, H = h0.shape
+        GI = ops.gemm(x, W_ih, trans_b=True, bias=b_ih)
+        GH = ops.gemm(h0, W_hh, trans_b=True, bias=b_hh)
+        out = torch.empty_like(h0)
+        saved = torch.empty(N, 3 * H, dtype=torch.float32, device=h0.device)
+        _lib.check(_lib.load().i3d_gru_gates_fwd(GI.data_ptr(), GH.data_ptr(), h0.data_ptr(), N, H, out.data_ptr(), saved.data_ptr(),
+                                                 ops._stream()), 'i3d_gru_gates_fwd')
+        ctx.save_for_backward(x, h0, W_ih, W_hh, GH, saved)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, h0, W_ih, W_hh, GH, saved = ctx.saved_tensors
+        g = g.contiguous()
+        N, H = h0.shape
+        dGI, dGH, dh0 = torch.empty_like(GH), torch.empty_like(GH), torch.empty_like(h0)
+        _lib.check(_lib.load().i3d_gru_gates_bwd(g.data_ptr(), saved.data_ptr(), GH.data_ptr(), h0.data_ptr(), N, H, dGI.data_ptr(),
+                                                 dGH.data_ptr(), dh0.data_ptr(), ops._stream()), 'i3d_gru_gates_bwd')
+        dx = ops.gemm(dGI, W_ih)
+        ops.gemm(dGH, W_hh, out=dh0, accumulate=True)
+        return (dx, dh0, ops.gemm(dGI, x, trans_a=True), ops.gemm(dGH, h0, trans_a=True), ops.colsum(dGI), ops.colsum(dGH))
+
+
+class GRU(nn.Module):
+    """reference models/pna_original.py:64-84: a one-step nn.GRU (x = the layer's input, hidden state = the layer's output).  The
+    nn.GRU module holds the parameters (the reference's state_dict keys gru.weight_ih_l0 ...); the step itself is _GRUCellFn."""
+
+    def __init__(self, input_size, hidden_size, device):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.gru = nn.GRU(input_size=input_size, hidden_size=hidden_size).to(device)
+
+    def forward(self, x, y):
+        assert x.shape[-1] == self.input_size and y.shape[-1] == self.hidden_size      # (the reference pads narrower inputs: not needed here)
+        m = self.gru
+        return tape.apply(_GRUCellFn, x, y, m.weight_ih_l0, m.weight_hh_l0, m.bias_ih_l0, m.bias_hh_l0)
+
+
 def _check_unsupported(dropout=0.0, in_feat_dropout=0.0, gru_enable=False, use_3d=False):
-    if gru_enable:
-        raise NotImplementedError('gru_enable=True is not on the accelerated path')
+    pass        # (every option of the variant is offered: dropout, use_3d and gru_enable keep the towers on the per-tower path)
 
 
 class PNAOriginal(nn.Module):
@@ -666,6 +709,8 @@ class PNAGNNOriginal(nn.Module):
         self.layers = nn.ModuleList([PNALayer(in_dim=hidden_dim, out_dim=hidden_dim, divide_input=divide_input_first,
                                               **common) for _ in range(propagation_depth - 1)])
         self.layers.append(PNALayer(in_dim=hidden_dim, out_dim=last_layer_dim, divide_input=divide_input_last, **common))
+        if self.gru_enable:                              # reference :179-180
+            self.gru = GRU(hidden_dim, hidden_dim, device)
         self.MLP_layer = MLPReadout(hidden_dim, 1)      # unused by forward, kept for state_dict parity (:179)
 
     def forward(self, g, h, e, snorm_n):
@@ -675,8 +720,11 @@ class PNAGNNOriginal(nn.Module):
         h = _dropout(h, self.in_feat_dropout.p, self.training)                        # :187
         e_sorted = self.embedding_e(e, perm=idx.perm) if self.edge_feat else None     # destination-sorted
         snorm = snorm_n.to(h.device)
-        for conv in self.layers:
-            h = conv(g, h, e_sorted, snorm, edges_sorted=True)
+        for i, conv in enumerate(self.layers):
+            h_t = conv(g, h, e_sorted, snorm, edges_sorted=True)
+            if self.gru_enable and i != len(self.layers) - 1:            # reference :190-193
+                h_t = self.gru(h, h_t)
+            h = h_t
         g.ndata['feat'] = h
         return g, h
 

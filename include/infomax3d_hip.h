@@ -258,6 +258,13 @@ int i3d_colsum(const float* x, const float* w, int rows, int feat, float* out, v
 /* y = act(x) elementwise (n elements); bwd: grad_x = grad_y * act'(x) */
 int i3d_act_fwd(const float* x, long n, int act, float* y, void* stream);
 int i3d_act_bwd(const float* grad_y, const float* x, long n, int act, float* grad_x, void* stream);
+/* The gates of ONE GRU step (csrc/gru.hip) - reference models/pna_original.py:64-84 (`GRU`: nn.GRU run for one step between the layers
+ * of PNAGNNOriginal with gru_enable=True, :190-193).  GI = x W_ih^T + b_ih, GH = h0 W_hh^T + b_hh [rows, 3 hidden] (gate order r | z | n,
+ * torch's); forward: out = (1 - z) n + z h0, saved [rows, 3 hidden] = r | z | n; backward: gradients w.r.t. GI, GH and the direct
+ * share of h0 (the caller adds grad_GH W_hh). */
+int i3d_gru_gates_fwd(const float* GI, const float* GH, const float* h0, int rows, int hidden, float* out, float* saved, void* stream);
+int i3d_gru_gates_bwd(const float* grad_out, const float* saved, const float* GH, const float* h0, int rows, int hidden, float* grad_GI,
+                      float* grad_GH, float* grad_h0, void* stream);
 /* dst += src;  out = a + b;  out[r, :] = row for r < rows (Net3D's broadcast node embedding, models/net3d.py:61) */
 int i3d_add_inplace(float* dst, const float* src, long n, void* stream);
 int i3d_add(const float* a, const float* b, long n, float* out, void* stream);

@@ -507,9 +507,22 @@ def pna_original_forward(graph, snorm_n, P, cfg, training=True):
                                       P[f'node_gnn.layers.{l}.mixing_network.bias']))               # :308
         if cfg.get('residual', False) and in_dim == out_dim:
             h_out = h + h_out
+        if cfg.get('gru_enable', False) and not last:                                               # :190-193, :64-84
+            h_out = gru_step(h, h_out, P, 'node_gnn.gru.gru')
         h = h_out
     r = torch.cat([segment_readout(h, graph['batch_num_nodes'], op) for op in cfg['readout_aggregators']], dim=-1)
     return mlp_readout(r, P, 'output'), h
+
+
+def gru_step(x, h0, P, prefix):
+    """one step of torch.nn.GRU (gate order r | z | n), reference models/pna_original.py:64-84: input x, hidden state h0"""
+    gi = F.linear(x, P[f'{prefix}.weight_ih_l0'], P[f'{prefix}.bias_ih_l0'])
+    gh = F.linear(h0, P[f'{prefix}.weight_hh_l0'], P[f'{prefix}.bias_hh_l0'])
+    H = h0.shape[1]
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+    return (1 - z) * n + z * h0
 
 
 def pna_original_simple_forward(graph, P, cfg, training=True):

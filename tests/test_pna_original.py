@@ -300,3 +300,40 @@ def test_hip_towers_with_use_3d_match_reference_fixture():
     (out * torch.from_numpy(z['cot']).cuda()).sum().backward()
     ref = sd_from_npz(z, 'grad')
     grads_close({k: p.grad for k, p in model.named_parameters() if k in ref}, ref, 5e-4)
+
+
+def test_oracle_with_gru_matches_reference_fixture():
+    """PNAOriginal(gru_enable=True), reference models/pna_original.py:64-84, 179-180, 190-193; fixture gen_golden_originalgru.py"""
+    z = load('pna_original_gru.npz')
+    mols = mols_from_npz(z)
+    g2, _ = O.graphs_from_molecules(mols)
+    P = O.require_grad(sd_from_npz(z, 'sd'))
+    out, emb = O.pna_original_forward(g2, O.snorm_n(g2['batch_num_nodes']), P, dict(PNA_ORIG_KW, gru_enable=True), True)
+    assert rel_err(emb, z['node_emb']) < 2e-5
+    assert rel_err(out, z['out']) < 2e-5
+    (out * torch.from_numpy(z['cot'])).sum().backward()
+    ref = _used(sd_from_npz(z, 'grad'))
+    try:
+        grads_close({k: P[k].grad for k in ref}, ref, 2e-4)
+    except AssertionError:      # (arg-max routing on another host's summation order: see test_oracle_matches_reference_fixture)
+        grads_close_l2({k: P[k].grad for k in ref}, ref, 2e-2)
+
+
+@pytest.mark.gpu
+def test_hip_towers_with_gru_match_reference_fixture():
+    """gru_enable=True on the HIP path: the GRU step between the layers as two products of the library's GEMM + the gate kernels of
+    csrc/gru.hip (pna_original._GRUCellFn); the reference's state_dict (node_gnn.gru.gru.*) loads strictly."""
+    amd = importlib.import_module('3dinfomax_amd')
+    z = load('pna_original_gru.npz')
+    mols = mols_from_npz(z)
+    model = amd.PNAOriginal(**dict(PNA_ORIG_KW, gru_enable=True))
+    model.load_state_dict(sd_from_npz(z, 'sd'), strict=True)
+    model.cuda().train()
+    g2 = amd.batch([amd.bond_graph(m) for m in mols]).to('cuda:0')
+    snorm = O.snorm_n([m.n_atoms for m in mols]).cuda()
+    out = model(g2, snorm)
+    assert rel_err(g2.ndata['feat'].cpu(), z['node_emb']) < 1e-4
+    assert rel_err(out.cpu(), z['out']) < 1e-4
+    (out * torch.from_numpy(z['cot']).cuda()).sum().backward()
+    ref = sd_from_npz(z, 'grad')
+    grads_close({k: p.grad for k, p in model.named_parameters() if k in ref}, ref, 5e-4)
