@@ -628,10 +628,10 @@ def main():
             with_assembly = round(sorted(rates)[1], 1)
             # the same with the device half of the assembly on a helper thread (dataset.DevicePrefetcher), two batches ahead
             for interval in ((None, 2e-4) if args.prefetch_thread else ()):
-                stream = dataset.BatchStream(flat, B, steps=n_ld + 12, seed=2)
-                loader = torch.utils.data.DataLoader(stream, batch_size=None, num_workers=args.loader_workers, pin_memory=True,
+                pf_stream = dataset.BatchStream(flat, B, steps=n_ld + 12, seed=2)
+                pf_loader = torch.utils.data.DataLoader(pf_stream, batch_size=None, num_workers=args.loader_workers, pin_memory=True,
                                                      prefetch_factor=4)
-                pf = dataset.DevicePrefetcher(loader, dev, depth=2, switch_interval=interval)
+                pf = dataset.DevicePrefetcher(pf_loader, dev, depth=2, switch_interval=interval)
                 for _ in range(12):
                     (a,), (b,) = next(pf)
                     step_on(a, b)
@@ -645,7 +645,7 @@ def main():
                     torch.cuda.synchronize()
                     rates.append((n_ld // 3) * B / (time.perf_counter() - ta))
                 pf.close()
-                del pf, loader, stream
+                del pf, pf_loader, pf_stream
                 with_prefetch[str(interval)] = round(sorted(rates)[1], 1)
             if os.environ.get('I3D_BENCH_DEBUG'):
                 print('loader windows, molecules/s:', ' '.join(f'{v:.0f}' for v in rates), file=sys.stderr)
