@@ -337,3 +337,47 @@ def test_hip_towers_with_gru_match_reference_fixture():
     (out * torch.from_numpy(z['cot']).cuda()).sum().backward()
     ref = sd_from_npz(z, 'grad')
     grads_close({k: p.grad for k, p in model.named_parameters() if k in ref}, ref, 5e-4)
+
+
+@pytest.mark.gpu
+def test_full_size_tower_batch_properties():
+    """The tower variant at the bench's full size (512 molecules, configs/pna_original.yml shape: hidden 90, 5 towers, depth 4) in its
+    default form (stacked towers, widths padded to 4 floats, scalers folded into per-degree weights, diagonal blocks), through
+    properties that need no oracle at that size: two copies of one molecule get bit-identical outputs; reordering the molecules
+    reorders the outputs (BatchNorm statistics and the per-degree groups only change their summation order: 1e-4) and leaves the
+    parameter gradients in place (relative L2 5e-3: arg-max near-ties of the max / min aggregators may move single rows)."""
+    import numpy as np
+    amd = importlib.import_module('3dinfomax_amd')
+    synth = importlib.import_module('3dinfomax_amd.synth')
+    mols = synth.make_dataset(511, seed=33)
+    mols = mols + [mols[11]]
+    perm = np.random.default_rng(6).permutation(512)
+    cot = torch.randn(512, 1, generator=torch.Generator().manual_seed(8)).cuda()
+
+    def step(order):
+        torch.manual_seed(7)
+        model = amd.PNAOriginal(**PNA_ORIG_YML)
+        with torch.no_grad():       # O(1) activations in front of the BatchNorms
+            for n, p in model.named_parameters():
+                if n.endswith('linear.weight'):
+                    p.mul_(p.shape[1] * 0.5)
+        model.cuda().train()
+        ms = [mols[i] for i in order]
+        g2 = amd.batch([amd.bond_graph(m) for m in ms]).to('cuda:0')
+        snorm = O.snorm_n([m.n_atoms for m in ms]).cuda()
+        out = model(g2, snorm)
+        (out * cot[torch.as_tensor(list(order)).cuda()]).sum().backward()
+        assert isinstance(model.__dict__.get('_i3d_stacks'), importlib.import_module('3dinfomax_amd.pna_original')._TowerStacks)
+        grads = torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
+        return out.detach(), grads
+
+    out, grads = step(list(range(512)))
+    assert out.shape == (512, 1) and torch.isfinite(out).all() and out.std().item() > 1e-3
+    assert torch.equal(out[11], out[511])
+    outp, gradsp = step(list(perm))
+    idx = torch.from_numpy(perm).cuda()
+    err = ((out[idx] - outp).abs().max() / out.abs().max()).item()
+    gerr = ((grads - gradsp).norm() / grads.norm()).item()
+    print(f'full-size tower properties: outputs {err:.2e}, gradients {gerr:.2e}')
+    assert err <= 1e-4
+    assert gerr <= 5e-3
