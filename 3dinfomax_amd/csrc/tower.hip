@@ -90,8 +90,9 @@ extern "C" int i3d_tower_layer_fwd(const I3dTowerLayerArgs* a, void* stream) {
     float* Q = P + al4((long)N * 2 * Mp);
     float* y = Q + al4((long)E * Mp);
     // pretrans of every tower: node-level products, then gather-combine (the [E, 2 D + Fe] concatenation never exists)
-    TRY(i3d_gemm_f32(0, 1, N, Mp, D, a->h, D, a->Wp, a->ldp, P, 2 * Mp, nullptr, 0, stream));
-    TRY(i3d_gemm_f32(0, 1, N, Mp, D, a->h, D, a->Wp + D, a->ldp, P + Mp, 2 * Mp, nullptr, 0, stream));
+    // P = h [W_src | W_dst]^T as ONE product: row n >= Mp of the operand is row n - Mp of Wp, D columns further (i3d_gemm_f32_blocks)
+    const long wp_delta = (long)D - (long)Mp * a->ldp, wp_view = (long)(Mp - 1) * a->ldp + 2L * D;
+    TRY(i3d_gemm_f32_blocks(0, 1, N, 2 * Mp, D, a->h, D, a->Wp, a->ldp, Mp, wp_delta, wp_view, P, 2 * Mp, 0, 0, 0, nullptr, 0, stream));
     if (Fe > 0) TRY(i3d_gemm_f32(0, 1, E, Mp, Fe, a->e, Fe, a->Wp + 2 * D, a->ldp, Q, Mp, nullptr, 0, stream));
     TRY(i3d_edge_combine_fwd(P, 2 * Mp, Fe > 0 ? Q : nullptr, nullptr, a->bp, a->src_s, a->dst_s, E, Mp, s.msg, stream));
     const bool tm = tower_major(a);
@@ -239,10 +240,12 @@ extern "C" int i3d_tower_layer_bwd(const I3dTowerLayerArgs* a, void* stream) {
         if (a->grad_e != nullptr)
             TRY(i3d_gemm_f32(0, 0, E, Fe, Mp, g_msg, Mp, a->Wp + 2 * D, a->ldp, a->grad_e, Fe, nullptr, a->grad_e_accumulate, stream));
     }
-    TRY(i3d_gemm_f32_ws(1, 0, Mp, D, N, gP, 2 * Mp, a->h, D, a->grad_Wp, a->ldgp, nullptr, 0, ws, wsb, stream));
-    TRY(i3d_gemm_f32_ws(1, 0, Mp, D, N, gP + Mp, 2 * Mp, a->h, D, a->grad_Wp + D, a->ldgp, nullptr, 0, ws, wsb, stream));
+    // d[W_src | W_dst] = gP^T h as ONE product whose rows >= Mp land D columns further in rows - Mp of grad_Wp
+    TRY(i3d_gemm_f32_blocks(1, 0, 2 * Mp, D, N, gP, 2 * Mp, a->h, D, 0, 0, 0, a->grad_Wp, a->ldgp, Mp, (long)D - (long)Mp * a->ldgp, 0, ws,
+                            wsb, stream));
     TRY(i3d_colsum(g_msg, nullptr, E, Mp, a->grad_bp, a->workspace, stream));
-    TRY(i3d_gemm_f32(0, 0, N, D, Mp, gP, 2 * Mp, a->Wp, a->ldp, a->grad_h, D, nullptr, 1, stream));
-    TRY(i3d_gemm_f32(0, 0, N, D, Mp, gP + Mp, 2 * Mp, a->Wp + D, a->ldp, a->grad_h, D, nullptr, 1, stream));
+    // dh += gP [W_src; W_dst] as ONE product (K = 2 Mp)
+    TRY(i3d_gemm_f32_blocks(0, 0, N, D, 2 * Mp, gP, 2 * Mp, a->Wp, a->ldp, Mp, (long)D - (long)Mp * a->ldp,
+                            (long)(Mp - 1) * a->ldp + 2L * D, a->grad_h, D, 0, 0, 1, nullptr, 0, stream));
     return I3D_OK;
 }
