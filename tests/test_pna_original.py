@@ -381,3 +381,35 @@ def test_full_size_tower_batch_properties():
     print(f'full-size tower properties: outputs {err:.2e}, gradients {gerr:.2e}')
     assert err <= 1e-4
     assert gerr <= 5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('towers,hidden,edge', [(1, 24, 12), (2, 36, 10), (3, 30, 7)])
+def test_stacked_towers_equal_the_per_tower_path_for_other_tower_counts(towers, hidden, edge, monkeypatch):
+    """one tower (no diagonal blocks), two / three towers with widths that are not multiples of 4 per tower (18, 10) and an odd edge width:
+    the default stacked form (padded widths, folded scalers, blocks) against the towers one after the other - outputs 1e-4, gradients 2e-3."""
+    amd = importlib.import_module('3dinfomax_amd')
+    po = importlib.import_module('3dinfomax_amd.pna_original')
+    synth = importlib.import_module('3dinfomax_amd.synth')
+    mols = synth.make_dataset(40, seed=91)
+    snorm = O.snorm_n([m.n_atoms for m in mols]).cuda()
+    kw = dict(PNA_ORIG_KW, towers=towers, hidden_dim=hidden, last_layer_dim=hidden, edge_hidden_dim=edge)
+    res = {}
+    for stacked in (True, False):
+        monkeypatch.setattr(po, 'TOWER_STACK', stacked)
+        torch.manual_seed(13)
+        model = amd.PNAOriginal(**kw)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n.endswith('linear.weight'):
+                    p.mul_(p.shape[1] * 0.5)
+        model.cuda().train()
+        g2 = amd.batch([amd.bond_graph(m) for m in mols]).to('cuda:0')
+        out = model(g2, snorm)
+        out.square().mean().backward()
+        torch.cuda.synchronize()
+        assert isinstance(model.__dict__.get('_i3d_stacks'), po._TowerStacks) == stacked
+        res[stacked] = (out.detach().cpu(), {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None})
+    assert rel_err(res[True][0], res[False][0]) < 1e-4
+    assert set(res[True][1]) == set(res[False][1])
+    grads_close(res[True][1], res[False][1], 2e-3)
