@@ -135,8 +135,9 @@ __device__ __forceinline__ void finalize_column(const Final& f, int c, double s1
             f.sums_out[c] = s1;
             f.sums_out[f.feat + c] = s2;
         }
-        if (f.out1 != nullptr) f.out1[c] = (float)s1;
-        if (f.out2 != nullptr) f.out2[c] = (float)s2;
+        // agent-scope stores: the one-launch backward's other workgroups read these inside the same launch
+        if (f.out1 != nullptr) st_agent(f.out1 + c, (float)s1);
+        if (f.out2 != nullptr) st_agent(f.out2 + c, (float)s2);
     }
 }
 
@@ -155,9 +156,9 @@ __device__ __forceinline__ void finalize_column_global(const Final& f, int c, do
         }
         if (c == 0 && f.batches_tracked != nullptr) *f.batches_tracked += 1;
     } else {                    // == sums_to_float_kernel
-        f.g1[c] = (float)T1;
-        f.g2[c] = (float)T2;
-        if (c == 0) f.ginv[0] = (float)(1.0 / N);
+        st_agent(f.g1 + c, (float)T1);
+        st_agent(f.g2 + c, (float)T2);
+        if (c == 0) st_agent(f.ginv, (float)(1.0 / N));
     }
 }
 
@@ -171,8 +172,8 @@ __device__ __forceinline__ void finalize_column_local(const Final& f, int c, dou
         a = s1 + n * shift;
         b = s2 + 2.0 * shift * s1 + n * shift * shift;
     } else {
-        if (f.out1 != nullptr) f.out1[c] = (float)s1;
-        if (f.out2 != nullptr) f.out2[c] = (float)s2;
+        if (f.out1 != nullptr) st_agent(f.out1 + c, (float)s1);
+        if (f.out2 != nullptr) st_agent(f.out2 + c, (float)s2);
     }
     for (int p = 0; p < f.peer.world; ++p) {
         peer_put_f64(f.peer, p, c, a);
@@ -181,9 +182,12 @@ __device__ __forceinline__ void finalize_column_local(const Final& f, int c, dou
     }
 }
 
-// called by ALL threads of every workgroup after the partial row of the workgroup has been stored with st_agent
-template <bool GA>
-__device__ __forceinline__ void arrive_and_finalize(const Final& f, const float* partial, int nblk) {
+// called by ALL threads of every workgroup after the partial row of the workgroup has been stored with st_agent.
+// ALL_WAIT (the one-launch BatchNorm backward, bn_bwd_fused_kernel): nobody leaves before the finalised vectors are published -
+// the last reducer bumps the generation word counters[2] (gen0 = its value when the workgroup started), every workgroup polls it.
+// Workgroups of 256 threads or more; threads >= 256 only keep the barriers company.
+template <bool GA, bool ALL_WAIT = false>
+__device__ __forceinline__ void arrive_and_finalize(const Final& f, const float* partial, int nblk, unsigned gen0 = 0u) {
     __shared__ unsigned s_ticket;
     __shared__ double s_red[2][FIN_LANES][FIN_COLS];
     __shared__ double s_peer[3][PEER_MAX_WORLD][FIN_COLS];
@@ -196,18 +200,21 @@ __device__ __forceinline__ void arrive_and_finalize(const Final& f, const float*
     const unsigned ticket = s_ticket;
     const unsigned ncb = (unsigned)((f.feat + FIN_COLS - 1) / FIN_COLS);
     const unsigned R = ncb < total ? ncb : total;
-    if (ticket < total - R) return;
+    const bool reducer = ticket >= total - R;
+    if (!ALL_WAIT && !reducer) return;
+    if (reducer) {
     if (threadIdx.x == 0) {        // bounded: a poisoned counter must not hang the device (results are then wrong, not stuck)
         int spins = 0;
         while (__hip_atomic_load(&f.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total && ++spins < (1 << 24))
             __builtin_amdgcn_s_sleep(2);
     }
     __syncthreads();
-    const int cx = threadIdx.x & (FIN_COLS - 1), ly = threadIdx.x / FIN_COLS;
+    const bool worker = threadIdx.x < FIN_COLS * FIN_LANES;
+    const int cx = threadIdx.x & (FIN_COLS - 1), ly = (threadIdx.x / FIN_COLS) & (FIN_LANES - 1);
     for (unsigned cb = ticket - (total - R); cb < ncb; cb += R) {
         const int c = (int)cb * FIN_COLS + cx;
         double a1 = 0.0, a2 = 0.0;
-        if (c < f.feat) {
+        if (worker && c < f.feat) {
             // all loads of the lane first (<= MAX_PARTIAL_BLOCKS / FIN_LANES = 8 partial rows, 16 uncached loads in
             // flight), then the sums: a load-add loop pays the ~1.5 us agent-scope latency once per iteration
             constexpr int NB = MAX_PARTIAL_BLOCKS / FIN_LANES;
@@ -223,10 +230,12 @@ __device__ __forceinline__ void arrive_and_finalize(const Final& f, const float*
                 if (ly + k * FIN_LANES < nblk) { a1 += (double)v1[k]; a2 += (double)v2[k]; }
             }
         }
-        s_red[0][ly][cx] = a1;
-        s_red[1][ly][cx] = a2;
+        if (worker) {
+            s_red[0][ly][cx] = a1;
+            s_red[1][ly][cx] = a2;
+        }
         __syncthreads();
-        if (ly == 0 && c < f.feat) {
+        if (worker && ly == 0 && c < f.feat) {
             double s1 = 0.0, s2 = 0.0;
 #pragma unroll
             for (int k = 0; k < FIN_LANES; ++k) { s1 += s_red[0][k][cx]; s2 += s_red[1][k][cx]; }
@@ -234,13 +243,13 @@ __device__ __forceinline__ void arrive_and_finalize(const Final& f, const float*
             else finalize_column<GA>(f, c, s1, s2);
         }
         if (f.peer_on) {        // (uniform) the column block's exchange: lane `ly` < world fetches rank ly's triple of its column
-            if (ly < f.peer.world && c < f.feat) {
+            if (worker && ly < f.peer.world && c < f.feat) {
                 double t[3];
                 peer_get3_f64(f.peer, ly, c, f.feat + c, 2 * f.feat + c, t);
                 s_peer[0][ly][cx] = t[0]; s_peer[1][ly][cx] = t[1]; s_peer[2][ly][cx] = t[2];
             }
             __syncthreads();
-            if (ly == 0 && c < f.feat) {
+            if (worker && ly == 0 && c < f.feat) {
                 double T1 = 0.0, T2 = 0.0, N = 0.0;
                 for (int q = 0; q < f.peer.world; ++q) {      // rank order: the same bits on every rank
                     T1 += s_peer[0][q][cx];
@@ -250,6 +259,7 @@ __device__ __forceinline__ void arrive_and_finalize(const Final& f, const float*
                 finalize_column_global(f, c, T1, T2, N);
             }
         }
+        if (ALL_WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the finalised values (agent-scope stores) have left
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -257,7 +267,20 @@ __device__ __forceinline__ void arrive_and_finalize(const Final& f, const float*
         if (d == R - 1) {          // every reducer is done reading: re-arm for the next launch
             __hip_atomic_store(&f.counters[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&f.counters[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ALL_WAIT) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(&f.counters[2], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
+    }
+    }
+    if (ALL_WAIT) {
+        if (threadIdx.x == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(&f.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0 && ++spins < (1 << 24))
+                __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
     }
 }
 
@@ -757,6 +780,114 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_colsum_kernel(BwdApplyArgs g
     if (fin.counters != nullptr) arrive_and_finalize<GA>(fin, partial, gridDim.x);
 }
 
+// ---- BatchNorm backward in ONE launch (round 6) ----------------------------------------------------------------------------
+// The reduction (sum dy, sum dy xhat over the rows) and the data gradient that needs those sums were two launches, each reading
+// dy and x: colreduce_partial_kernel<MODE_BN_BWD> 15.6 us + bn_bwd_apply_kernel 14.1 us + a launch boundary at batch 512, on the
+// dependent chain, three BatchNorms per layer (profiles/r05_step_kernel_trace_v4.txt; counters: profiles/r06_bn_pmc.txt).  Here a
+// workgroup of 1024 threads owns a row chunk and KEEPS it in registers (RPT rows of 4 columns per thread, all loads issued up front):
+// partial sums -> the in-launch finalisation above (ticket, the last arrivers reduce the chunk partials in fp64, fixed order) ->
+// everybody waits for the generation word -> the data gradient from the registers.  dy and x are read once, not twice, and one
+// launch boundary is gone.  Same expressions as the two-pass kernels; the row sums are taken in another (fixed) order.
+//
+// Residency: every workgroup must be resident for the wait to end.  The grid is <= 256 workgroups of <= 64 VGPRs (two fit on a
+// CU, RPT <= 4: amdgpu_waves_per_eu), so two such launches on two streams always fit the 256 CUs together - the 2D chain and the
+// 3D network's stream are the only concurrent callers of a process - and other kernels in flight end on their own.  Larger
+// tensors (rows > 256 * rl * 4) take the two-pass path.  Several PROCESSES on one GPU (the one-GPU data-parallel tests) have no
+// such guarantee: i3d_set_bn_bwd_one_launch(0).  Every spin is bounded.
+struct FusedBwdGeom {
+    int rpb;      // rows per workgroup
+    int tpr;      // threads per row = feat / 4
+    int rl;       // row lanes = 1024 / tpr
+};
+
+template <int RPT, bool GA>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+bn_bwd_fused_kernel(BwdApplyArgs g, int rows, FusedBwdGeom ge, float* partial, Final fin) {
+    I3D_CHAIN_PRIO();
+    __shared__ float sm[2 * 4096];          // [2][rl][feat], rl * feat <= 4096
+    __shared__ unsigned s_gen;
+    const int t = threadIdx.x;
+    if (t == 0) s_gen = __hip_atomic_load(&fin.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int cl = t % ge.tpr, rlane = t / ge.tpr;
+    const bool active = rlane < ge.rl;
+    const int F = g.feat, c0 = cl * 4;
+    if (g.zero_out != nullptr && blockIdx.x == 0 && rlane == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g.zero_out[c0 + i] = 0.f;
+    }
+    float mu[4], is[4], ga[4], be[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { mu[i] = 0.f; is[i] = 1.f; ga[i] = 1.f; be[i] = 0.f; }
+    const int r_begin = blockIdx.x * ge.rpb;
+    const int r_end = min(rows, r_begin + ge.rpb);
+    float dy[RPT][4], x[RPT][4];
+    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {      // all loads first (clamped row: unconditional)
+            const int r = min(r_begin + rlane + u * ge.rl, r_end - 1);
+            const long off = (long)r * F + c0;
+            const float4 a = *reinterpret_cast<const float4*>(g.grad_y + off);
+            const float4 b = load4_maybe_bf16(g.x, off, g.x_bf16);
+            dy[u][0] = a.x; dy[u][1] = a.y; dy[u][2] = a.z; dy[u][3] = a.w;
+            x[u][0] = b.x; x[u][1] = b.y; x[u][2] = b.z; x[u][3] = b.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { mu[i] = g.mean[c0 + i]; is[i] = g.invstd[c0 + i]; ga[i] = g.gamma[c0 + i]; be[i] = g.beta[c0 + i]; }
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {      // rows r, r + rl, r + 2 rl, ... in this order
+            if (r_begin + rlane + u * ge.rl >= r_end) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float xh = (x[u][i] - mu[i]) * is[i];
+                float d = dy[u][i];
+                if (g.post_act != I3D_ACT_NONE) d *= act_grad_c<GA>(xh * ga[i] + be[i], g.post_act);
+                dy[u][i] = d;
+                a1[i] += d;
+                a2[i] += d * xh;
+            }
+        }
+    }
+    // the workgroup's partial row: [rl][feat] per sum through the LDS, one thread per (sum, column) adds the row lanes in order
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sm[rlane * F + c0 + i] = a1[i];
+            sm[4096 + rlane * F + c0 + i] = a2[i];
+        }
+    }
+    __syncthreads();
+    if (t < 2 * F) {
+        const int which = t >= F ? 1 : 0, c = t - which * F;
+        float s = 0.f;
+        for (int k = 0; k < ge.rl; ++k) s += sm[which * 4096 + k * F + c];
+        st_agent(partial + (long)blockIdx.x * 2 * F + which * F + c, s);
+    }
+    arrive_and_finalize<GA, true>(fin, partial, gridDim.x, s_gen);
+    if (!active) return;
+    // the sums every workgroup waited for (agent-scope loads: written inside this launch by other CUs)
+    const float inv_n = g.inv_n_ptr ? ld_agent(g.inv_n_ptr) : g.inv_n;
+    float k1[4], k2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { k1[i] = ld_agent(g.sum_dy + c0 + i); k2[i] = ld_agent(g.sum_dy_xhat + c0 + i); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { k1[i] *= inv_n; k2[i] *= inv_n; }
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int r = r_begin + rlane + u * ge.rl;
+        if (r >= r_end) continue;
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xh = (x[u][i] - mu[i]) * is[i];
+            float gx = ga[i] * is[i] * (dy[u][i] - k1[i] - xh * k2[i]);
+            if (g.act != I3D_ACT_NONE) gx *= act_grad_c<GA>(x[u][i], g.act);     // relu'(pre) == relu'(x)
+            o[i] = gx;
+        }
+        *reinterpret_cast<float4*>(g.grad_pre + (long)r * g.ld_out + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // BatchNorm backward of the edge block fused with what follows it on the chain (round 4): the data gradient
 //     g_e = gamma invstd (dy_e - mean(dy) - xhat_e mean(dy xhat)) act'(x_e)
 // of every edge row (bn_bwd_apply_kernel's expression) is formed ON THE FLY by the two segmented sums that consume it -
@@ -926,6 +1057,36 @@ static Final pair_final_desc(void* workspace, int feat, float* out1, float* out2
     return f;
 }
 
+// the one-launch BatchNorm backward (bn_bwd_fused_kernel): process-wide switch, on by default (I3D_BN_BWD_ONE_LAUNCH=0 / the setter)
+static int g_one_launch = [] { const char* e = getenv("I3D_BN_BWD_ONE_LAUNCH"); return (e == nullptr || e[0] != '0') ? 1 : 0; }();
+
+// launches bn_bwd_fused_kernel when the call qualifies (-> true); f: the pair finalisation of the reduction (local or peer form)
+static bool bn_bwd_one_launch(const BwdApplyArgs& b, int rows, int feat, float* partial, const Final& f, hipStream_t s) {
+    if (!g_one_launch || f.counters == nullptr || feat % 4 != 0 || feat > 512 || b.pre != nullptr || b.grad_pre == nullptr) return false;
+    if (b.ld_out % 4 != 0 || ((((uintptr_t)b.grad_y) | ((uintptr_t)b.grad_pre)) & 15) != 0 || (((uintptr_t)b.x) & (b.x_bf16 ? 7 : 15)) != 0)
+        return false;
+    FusedBwdGeom ge;
+    ge.tpr = feat / 4;
+    ge.rl = 1024 / ge.tpr;
+    if ((long)rows > 256L * ge.rl * 4) return false;         // RPT <= 4: two workgroups per CU (the residency argument above)
+    int G = cdiv(rows, ge.rl);
+    if (G > 256) G = 256;
+    ge.rpb = cdiv(rows, G);
+    G = cdiv(rows, ge.rpb);
+    const int rpt = cdiv(ge.rpb, ge.rl);
+    const bool ga = !(relu_class(b.act) && relu_class(b.post_act));
+#define I3D_LAUNCH_FUSED(R)                                                                                              \
+    do {                                                                                                                   \
+        if (ga) hipLaunchKernelGGL((bn_bwd_fused_kernel<R, true>), dim3(G), dim3(1024), 0, s, b, rows, ge, partial, f);    \
+        else hipLaunchKernelGGL((bn_bwd_fused_kernel<R, false>), dim3(G), dim3(1024), 0, s, b, rows, ge, partial, f);     \
+    } while (0)
+    if (rpt <= 1) I3D_LAUNCH_FUSED(1);
+    else if (rpt == 2) I3D_LAUNCH_FUSED(2);
+    else I3D_LAUNCH_FUSED(4);
+#undef I3D_LAUNCH_FUSED
+    return true;
+}
+
 // stage 1 (+ stage 2 in the same launch, or as a second launch when I3D_FUSED_FINAL=0)
 template <int MODE>
 static void launch_reduction(const ReduceArgs& g, const Chunking& ch, const Final& f, hipStream_t s) {
@@ -1089,6 +1250,12 @@ extern "C" int i3d_bn_bwd(const float* grad_y, const float* x, const float* pre,
                                     grad_pre, grad_bias, sums_out, sums_in, total_rows, workspace, nullptr, stream);
 }
 
+extern "C" int i3d_set_bn_bwd_one_launch(int on) {
+    const int was = g_one_launch;
+    g_one_launch = on ? 1 : 0;
+    return was;
+}
+
 extern "C" long i3d_bn_bias_partial_floats(int feat) { return (long)MAX_PARTIAL_BLOCKS * 2 * feat; }
 
 // grad_bias = column sums of grad_pre from the row-chunk partials the data-gradient pass left in bias_partial
@@ -1142,6 +1309,18 @@ static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, in
             Final f = pair_final_desc(workspace, feat, grad_beta, grad_gamma, nullptr);
             f.rows = rows; f.peer_on = 1; f.g1 = tmp; f.g2 = tmp + feat; f.ginv = tmp + 2 * feat;
             if (int rc = peer_next(pc, &f.peer)) return rc;
+            if (g_sums_only == nullptr && g_edge_sums == nullptr && grad_pre != nullptr &&
+                (grad_bias == nullptr || (act == I3D_ACT_NONE && exact_zero_bias_grad()))) {
+                // one launch: reduction, exchange and data gradient (bn_bwd_fused_kernel)
+                BwdApplyArgs b = {};
+                b.grad_y = grad_y; b.x = x; b.pre = relu_class(act) ? nullptr : pre; b.mean = mean; b.invstd = invstd; b.gamma = gamma;
+                b.beta = beta; b.sum_dy = tmp; b.sum_dy_xhat = tmp + feat; b.inv_n_ptr = tmp + 2 * feat; b.grad_pre = grad_pre;
+                b.ld_out = ld_out; b.feat = feat; b.act = act; b.post_act = post_act; b.zero_out = grad_bias; b.x_bf16 = g_x_bf16;
+                if (bn_bwd_one_launch(b, rows, feat, partial, f, s)) {
+                    I3D_CHECK_LAUNCH();
+                    return I3D_OK;
+                }
+            }
             launch_reduction<MODE_BN_BWD>(g, ch, f, s);
             I3D_CHECK_LAUNCH();
             g_sums_ready = 1;
@@ -1177,6 +1356,18 @@ static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, in
     }
     Chunking ch = make_chunking(rows, feat);
     float* partial = partial_of(workspace);
+    if (sums_in == nullptr && sums_out == nullptr && g_sums_only == nullptr && g_edge_sums == nullptr && grad_pre != nullptr &&
+        (grad_bias == nullptr || (act == I3D_ACT_NONE && exact_zero_bias_grad()))) {
+        // one launch: reduction, finalisation and data gradient (bn_bwd_fused_kernel) - tensors of up to 256 * rl * 4 rows
+        BwdApplyArgs b = {};
+        b.grad_y = grad_y; b.x = x; b.pre = relu_class(act) ? nullptr : pre; b.mean = mean; b.invstd = invstd; b.gamma = gamma;
+        b.beta = beta; b.sum_dy = grad_beta; b.sum_dy_xhat = grad_gamma; b.inv_n = 1.f / (float)rows; b.grad_pre = grad_pre;
+        b.ld_out = ld_out; b.feat = feat; b.act = act; b.post_act = post_act; b.zero_out = grad_bias; b.x_bf16 = g_x_bf16;
+        if (bn_bwd_one_launch(b, rows, feat, partial, pair_final_desc(workspace, feat, grad_beta, grad_gamma, nullptr), s)) {
+            I3D_CHECK_LAUNCH();
+            return I3D_OK;
+        }
+    }
     if (sums_in == nullptr) {   // phase 1: column sums of dy and dy*xhat
         ReduceArgs g = {};
         g.a = grad_y; g.b = x; g.mean = mean; g.invstd = invstd; g.gamma = gamma; g.beta = beta;

@@ -14,7 +14,10 @@
  *  - return value: I3D_OK (0) or a negative I3D_ERR_*; i3d_last_error() returns a thread-local message.
  *  - edge-sized tensors are in DESTINATION-SORTED ("epos") order: the in-edges of node v are the
  *    contiguous rows [in_ptr[v], in_ptr[v+1]) (stable w.r.t. edge id = DGL's mailbox order).
- *  - thread safety: no global mutable state besides the thread-local error string.
+ *  - thread safety: the error string is thread-local.  PROCESS-WIDE state exists and is set through explicit setters only:
+ *    the fp32 product form (i3d_set_fp32_products), the one-launch BatchNorm backward (i3d_set_bn_bwd_one_launch), the
+ *    collective table of synchronised BatchNorm (i3d_set_collectives / the peer exchange) and the per-stream side-stream
+ *    table; call the setters before the first compute call of the other threads.
  */
 #ifndef INFOMAX3D_HIP_H
 #define INFOMAX3D_HIP_H
@@ -645,6 +648,12 @@ int i3d_pna_aggregate_bwd_ex(const float* grad_out, const void* e, int e_bf16, c
                              int feat, const int* aggregators, int n_aggregators, const int* scalers, int n_scalers,
                              int force_scalers, float avg_d_log, float* grad_e, void* stream);
 
+/* The BatchNorm backward (i3d_bn_bwd and its variants; reference models/base_layers.py:100-111 under autograd) as ONE launch for
+ * tensors of up to 256 * (4096 / feat) * 4 rows, feat % 4 == 0, feat <= 512, activations none / ReLU / LeakyReLU: a workgroup
+ * keeps its row chunk in registers across an in-launch reduction (every workgroup of the launch is resident: <= 256 workgroups,
+ * two per CU).  Process-wide, on by default (environment I3D_BN_BWD_ONE_LAUNCH=0); switch it OFF when several processes share
+ * one GPU (their launches compete for the CUs and the residency argument no longer holds).  Returns the previous setting. */
+int i3d_set_bn_bwd_one_launch(int on);
 /* i3d_bn_bwd with the finalisation of grad_bias deferred (bias_partial != NULL): see I3dBnTail.bias_partial */
 long i3d_bn_bias_partial_floats(int feat);
 int i3d_bn_bwd_deferred_bias(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act, int post_act,
