@@ -233,6 +233,7 @@ _SIGNATURES = {
                                           c_float, _P, _P]),
     'i3d_bn_bias_partial_floats': (c_long, [c_int]),
     'i3d_set_bn_bwd_one_launch': (c_int, [c_int]),
+    'i3d_bn_bwd_one_launch_supported': (c_int, [c_int, c_int]),
     'i3d_bn_bwd_deferred_bias': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_long,
                                          _P, _P, _P]),
     'i3d_bn_bias_finalize': (c_int, [_P, c_int, c_int, _P, _P]),

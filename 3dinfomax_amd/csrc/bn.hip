@@ -8,6 +8,8 @@
 // fp64 and finalises.  HBM-bound: one read (+ one write when an activation is fused) per pass.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "common.h"
 #include "peer.h"
 
@@ -135,9 +137,8 @@ __device__ __forceinline__ void finalize_column(const Final& f, int c, double s1
             f.sums_out[c] = s1;
             f.sums_out[f.feat + c] = s2;
         }
-        // agent-scope stores: the one-launch backward's other workgroups read these inside the same launch
-        if (f.out1 != nullptr) st_agent(f.out1 + c, (float)s1);
-        if (f.out2 != nullptr) st_agent(f.out2 + c, (float)s2);
+        if (f.out1 != nullptr) f.out1[c] = (float)s1;
+        if (f.out2 != nullptr) f.out2[c] = (float)s2;
     }
 }
 
@@ -156,9 +157,9 @@ __device__ __forceinline__ void finalize_column_global(const Final& f, int c, do
         }
         if (c == 0 && f.batches_tracked != nullptr) *f.batches_tracked += 1;
     } else {                    // == sums_to_float_kernel
-        st_agent(f.g1 + c, (float)T1);
-        st_agent(f.g2 + c, (float)T2);
-        if (c == 0) st_agent(f.ginv, (float)(1.0 / N));
+        f.g1[c] = (float)T1;
+        f.g2[c] = (float)T2;
+        if (c == 0) f.ginv[0] = (float)(1.0 / N);
     }
 }
 
@@ -172,8 +173,8 @@ __device__ __forceinline__ void finalize_column_local(const Final& f, int c, dou
         a = s1 + n * shift;
         b = s2 + 2.0 * shift * s1 + n * shift * shift;
     } else {
-        if (f.out1 != nullptr) st_agent(f.out1 + c, (float)s1);
-        if (f.out2 != nullptr) st_agent(f.out2 + c, (float)s2);
+        if (f.out1 != nullptr) f.out1[c] = (float)s1;
+        if (f.out2 != nullptr) f.out2[c] = (float)s2;
     }
     for (int p = 0; p < f.peer.world; ++p) {
         peer_put_f64(f.peer, p, c, a);
@@ -182,12 +183,9 @@ __device__ __forceinline__ void finalize_column_local(const Final& f, int c, dou
     }
 }
 
-// called by ALL threads of every workgroup after the partial row of the workgroup has been stored with st_agent.
-// ALL_WAIT (the one-launch BatchNorm backward, bn_bwd_fused_kernel): nobody leaves before the finalised vectors are published -
-// the last reducer bumps the generation word counters[2] (gen0 = its value when the workgroup started), every workgroup polls it.
-// Workgroups of 256 threads or more; threads >= 256 only keep the barriers company.
-template <bool GA, bool ALL_WAIT = false>
-__device__ __forceinline__ void arrive_and_finalize(const Final& f, const float* partial, int nblk, unsigned gen0 = 0u) {
+// called by ALL threads of every workgroup after the partial row of the workgroup has been stored with st_agent
+template <bool GA>
+__device__ __forceinline__ void arrive_and_finalize(const Final& f, const float* partial, int nblk) {
     __shared__ unsigned s_ticket;
     __shared__ double s_red[2][FIN_LANES][FIN_COLS];
     __shared__ double s_peer[3][PEER_MAX_WORLD][FIN_COLS];
@@ -200,21 +198,18 @@ __device__ __forceinline__ void arrive_and_finalize(const Final& f, const float*
     const unsigned ticket = s_ticket;
     const unsigned ncb = (unsigned)((f.feat + FIN_COLS - 1) / FIN_COLS);
     const unsigned R = ncb < total ? ncb : total;
-    const bool reducer = ticket >= total - R;
-    if (!ALL_WAIT && !reducer) return;
-    if (reducer) {
+    if (ticket < total - R) return;
     if (threadIdx.x == 0) {        // bounded: a poisoned counter must not hang the device (results are then wrong, not stuck)
         int spins = 0;
         while (__hip_atomic_load(&f.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total && ++spins < (1 << 24))
             __builtin_amdgcn_s_sleep(2);
     }
     __syncthreads();
-    const bool worker = threadIdx.x < FIN_COLS * FIN_LANES;
-    const int cx = threadIdx.x & (FIN_COLS - 1), ly = (threadIdx.x / FIN_COLS) & (FIN_LANES - 1);
+    const int cx = threadIdx.x & (FIN_COLS - 1), ly = threadIdx.x / FIN_COLS;
     for (unsigned cb = ticket - (total - R); cb < ncb; cb += R) {
         const int c = (int)cb * FIN_COLS + cx;
         double a1 = 0.0, a2 = 0.0;
-        if (worker && c < f.feat) {
+        if (c < f.feat) {
             // all loads of the lane first (<= MAX_PARTIAL_BLOCKS / FIN_LANES = 8 partial rows, 16 uncached loads in
             // flight), then the sums: a load-add loop pays the ~1.5 us agent-scope latency once per iteration
             constexpr int NB = MAX_PARTIAL_BLOCKS / FIN_LANES;
@@ -230,12 +225,10 @@ __device__ __forceinline__ void arrive_and_finalize(const Final& f, const float*
                 if (ly + k * FIN_LANES < nblk) { a1 += (double)v1[k]; a2 += (double)v2[k]; }
             }
         }
-        if (worker) {
-            s_red[0][ly][cx] = a1;
-            s_red[1][ly][cx] = a2;
-        }
+        s_red[0][ly][cx] = a1;
+        s_red[1][ly][cx] = a2;
         __syncthreads();
-        if (worker && ly == 0 && c < f.feat) {
+        if (ly == 0 && c < f.feat) {
             double s1 = 0.0, s2 = 0.0;
 #pragma unroll
             for (int k = 0; k < FIN_LANES; ++k) { s1 += s_red[0][k][cx]; s2 += s_red[1][k][cx]; }
@@ -243,13 +236,13 @@ __device__ __forceinline__ void arrive_and_finalize(const Final& f, const float*
             else finalize_column<GA>(f, c, s1, s2);
         }
         if (f.peer_on) {        // (uniform) the column block's exchange: lane `ly` < world fetches rank ly's triple of its column
-            if (worker && ly < f.peer.world && c < f.feat) {
+            if (ly < f.peer.world && c < f.feat) {
                 double t[3];
                 peer_get3_f64(f.peer, ly, c, f.feat + c, 2 * f.feat + c, t);
                 s_peer[0][ly][cx] = t[0]; s_peer[1][ly][cx] = t[1]; s_peer[2][ly][cx] = t[2];
             }
             __syncthreads();
-            if (worker && ly == 0 && c < f.feat) {
+            if (ly == 0 && c < f.feat) {
                 double T1 = 0.0, T2 = 0.0, N = 0.0;
                 for (int q = 0; q < f.peer.world; ++q) {      // rank order: the same bits on every rank
                     T1 += s_peer[0][q][cx];
@@ -259,7 +252,6 @@ __device__ __forceinline__ void arrive_and_finalize(const Final& f, const float*
                 finalize_column_global(f, c, T1, T2, N);
             }
         }
-        if (ALL_WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the finalised values (agent-scope stores) have left
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -267,20 +259,7 @@ __device__ __forceinline__ void arrive_and_finalize(const Final& f, const float*
         if (d == R - 1) {          // every reducer is done reading: re-arm for the next launch
             __hip_atomic_store(&f.counters[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&f.counters[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ALL_WAIT) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_fetch_add(&f.counters[2], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
         }
-    }
-    }
-    if (ALL_WAIT) {
-        if (threadIdx.x == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(&f.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0 && ++spins < (1 << 24))
-                __builtin_amdgcn_s_sleep(1);
-        }
-        __syncthreads();
     }
 }
 
@@ -783,34 +762,58 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_colsum_kernel(BwdApplyArgs g
 // ---- BatchNorm backward in ONE launch (round 6) ----------------------------------------------------------------------------
 // The reduction (sum dy, sum dy xhat over the rows) and the data gradient that needs those sums were two launches, each reading
 // dy and x: colreduce_partial_kernel<MODE_BN_BWD> 15.6 us + bn_bwd_apply_kernel 14.1 us + a launch boundary at batch 512, on the
-// dependent chain, three BatchNorms per layer (profiles/r05_step_kernel_trace_v4.txt; counters: profiles/r06_bn_pmc.txt).  Here a
-// workgroup of 1024 threads owns a row chunk and KEEPS it in registers (RPT rows of 4 columns per thread, all loads issued up front):
-// partial sums -> the in-launch finalisation above (ticket, the last arrivers reduce the chunk partials in fp64, fixed order) ->
-// everybody waits for the generation word -> the data gradient from the registers.  dy and x are read once, not twice, and one
-// launch boundary is gone.  Same expressions as the two-pass kernels; the row sums are taken in another (fixed) order.
+// dependent chain, three BatchNorms per layer (profiles/r05_step_kernel_trace_v4.txt; counters: profiles/r06_bn_pmc.txt: one wave
+// per SIMD, waiting for memory 82 % of its cycles, then a ~5 us serial finalisation tail).  Here a workgroup of 512 threads owns a
+// row chunk and KEEPS it in registers (RPT rows of 4 columns per thread, all loads issued up front), and the two hand-offs between
+// the workgroups go through SELF-VALIDATING 8-byte words {value bits, launch tag} (one agent-scope store each; the peer exchange's
+// protocol, peer.h) instead of counters:
+//   1. every workgroup stores its partial row as tagged words;
+//   2. workgroup b < ceil(feat / 8) is the reducer of columns [8 b, 8 b + 8): it polls the 256 x 16 words of its columns until every
+//      one carries this launch's tag, adds them in fp64 in a fixed order, stores the two sums per column as tagged words (and as
+//      plain floats: grad_beta / grad_gamma);
+//   3. every workgroup polls the 2 feat final words (first wave, through the LDS) and writes the data gradient from its registers.
+// No ticket, no arrival counter, no generation word: two data hand-offs (~1.5-2.5 us each) are the whole serial tail.  (The first
+// version of this kernel went through the ticket / last-arrivers finalisation above plus a generation word: 32-35 us per launch -
+// as long as the two launches it replaced; profiles/r06_ab_onelaunch.txt.)  dy and x are read once, not twice.  Same expressions as
+// the two-pass kernels; the row sums are taken in another (fixed) order.  The tag is a process-wide launch counter (never 0: the
+// workspace starts zeroed), so words of earlier launches - of any shape, on any stream's workspace - never validate.
 //
-// Residency: every workgroup must be resident for the wait to end.  The grid is <= 256 workgroups of <= 64 VGPRs (two fit on a
-// CU, RPT <= 4: amdgpu_waves_per_eu), so two such launches on two streams always fit the 256 CUs together - the 2D chain and the
-// 3D network's stream are the only concurrent callers of a process - and other kernels in flight end on their own.  Larger
-// tensors (rows > 256 * rl * 4) take the two-pass path.  Several PROCESSES on one GPU (the one-GPU data-parallel tests) have no
-// such guarantee: i3d_set_bn_bwd_one_launch(0).  Every spin is bounded.
+// Residency: every workgroup must be resident for the polls to end.  The grid is <= 256 workgroups of 8 waves with <= 128 VGPRs
+// (amdgpu_waves_per_eu) and < 32 KB of LDS: two fit on a CU, so two such launches on two streams always fit the 256 CUs together
+// - the 2D chain and the 3D network's stream are the only concurrent callers of a process - and other kernels in flight end on
+// their own.  Larger tensors (rows > 256 * rl * 8) take the two-pass path, and so does synchronised BatchNorm (its exchange lives in
+// the finalisation above).  Several PROCESSES on one GPU (the one-GPU data-parallel tests) have no residency guarantee:
+// i3d_set_bn_bwd_one_launch(0).  Every poll is bounded (a lost workgroup gives wrong numbers, not a hung device).
 struct FusedBwdGeom {
     int rpb;      // rows per workgroup
     int tpr;      // threads per row = feat / 4
-    int rl;       // row lanes = 1024 / tpr
+    int rl;       // row lanes = 512 / tpr
+    unsigned tag; // this launch's tag
 };
+constexpr int FUSED_THREADS = 512, FUSED_MAX_RPT = 8, FUSED_LDS = 2048;      // rl * feat <= 2048 floats per sum
+constexpr int FUSED_MAX_BLOCKS = 256;
+
+__device__ __forceinline__ void st_tagged(unsigned long long* p, float v, unsigned tag) {
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_tagged(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <int RPT, bool GA>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
-bn_bwd_fused_kernel(BwdApplyArgs g, int rows, FusedBwdGeom ge, float* partial, Final fin) {
+__global__ void __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+bn_bwd_fused_kernel(BwdApplyArgs g, int rows, FusedBwdGeom ge, unsigned long long* tpart /* [nblk][2][feat] */,
+                    unsigned long long* tfinal /* [2][feat] */, float* out_beta, float* out_gamma) {
     I3D_CHAIN_PRIO();
-    __shared__ float sm[2 * 4096];          // [2][rl][feat], rl * feat <= 4096
-    __shared__ unsigned s_gen;
+    __shared__ float sm[2 * FUSED_LDS];     // [2][rl][feat]; later: the 2 feat final sums
+    __shared__ double s_red[2][64][FIN_COLS];
     const int t = threadIdx.x;
-    if (t == 0) s_gen = __hip_atomic_load(&fin.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int cl = t % ge.tpr, rlane = t / ge.tpr;
     const bool active = rlane < ge.rl;
     const int F = g.feat, c0 = cl * 4;
+    const unsigned tag = ge.tag;
+    const int nblk = gridDim.x;
     if (g.zero_out != nullptr && blockIdx.x == 0 && rlane == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) g.zero_out[c0 + i] = 0.f;
@@ -847,31 +850,87 @@ bn_bwd_fused_kernel(BwdApplyArgs g, int rows, FusedBwdGeom ge, float* partial, F
                 a2[i] += d * xh;
             }
         }
-    }
-    // the workgroup's partial row: [rl][feat] per sum through the LDS, one thread per (sum, column) adds the row lanes in order
-    if (active) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             sm[rlane * F + c0 + i] = a1[i];
-            sm[4096 + rlane * F + c0 + i] = a2[i];
+            sm[FUSED_LDS + rlane * F + c0 + i] = a2[i];
         }
     }
     __syncthreads();
-    if (t < 2 * F) {
-        const int which = t >= F ? 1 : 0, c = t - which * F;
+    // 1. the workgroup's partial row: one thread per (sum, column) adds the row lanes in order and publishes a tagged word
+    for (int j = t; j < 2 * F; j += FUSED_THREADS) {
+        const int which = j >= F ? 1 : 0, c = j - which * F;
         float s = 0.f;
-        for (int k = 0; k < ge.rl; ++k) s += sm[which * 4096 + k * F + c];
-        st_agent(partial + (long)blockIdx.x * 2 * F + which * F + c, s);
+        for (int k = 0; k < ge.rl; ++k) s += sm[which * FUSED_LDS + k * F + c];
+        st_tagged(tpart + (long)blockIdx.x * 2 * F + j, s, tag);
     }
-    arrive_and_finalize<GA, true>(fin, partial, gridDim.x, s_gen);
+    // 2. the reducers: workgroup b, b + nblk, ... reduce the column blocks [8 b, 8 b + 8) (fp64, partial rows in the fixed order
+    //    lane ly takes rows ly, ly + 64, ...; then the 64 lanes in order)
+    const int ncb = (F + FIN_COLS - 1) / FIN_COLS;
+    for (int cb = blockIdx.x; cb < ncb; cb += nblk) {
+        const int cx = t & (FIN_COLS - 1), ly = t / FIN_COLS;       // 8 columns x 64 lanes
+        const int c = cb * FIN_COLS + cx;
+        constexpr int NB = FUSED_MAX_BLOCKS / 64;
+        double p1 = 0.0, p2 = 0.0;
+        if (c < F) {
+            unsigned long long v1[NB], v2[NB];
+            for (int spins = 0; spins < (1 << 22); ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    const int b = min(ly + k * 64, nblk - 1);
+                    v1[k] = ld_tagged(tpart + (long)b * 2 * F + c);
+                    v2[k] = ld_tagged(tpart + (long)b * 2 * F + F + c);
+                }
+#pragma unroll
+                for (int k = 0; k < NB; ++k) ok = ok && (unsigned)(v1[k] >> 32) == tag && (unsigned)(v2[k] >> 32) == tag;
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                if (ly + k * 64 < nblk) {
+                    p1 += (double)__uint_as_float((unsigned)v1[k]);
+                    p2 += (double)__uint_as_float((unsigned)v2[k]);
+                }
+            }
+        }
+        __syncthreads();            // (s_red of a previous column block has been read)
+        s_red[0][ly][cx] = p1;
+        s_red[1][ly][cx] = p2;
+        __syncthreads();
+        if (t < 2 * FIN_COLS) {
+            const int which = t / FIN_COLS, cc = cb * FIN_COLS + (t & (FIN_COLS - 1));
+            if (cc < F) {
+                double sum = 0.0;
+#pragma unroll
+                for (int k = 0; k < 64; ++k) sum += s_red[which][k][t & (FIN_COLS - 1)];
+                const float fs = (float)sum;
+                st_tagged(tfinal + which * F + cc, fs, tag);
+                (which ? out_gamma : out_beta)[cc] = fs;      // grad_gamma = sum dy xhat, grad_beta = sum dy
+            }
+        }
+    }
+    // 3. everybody: the 2 feat final sums, polled by the first wave, through the LDS (sm is free: all of it was read before the
+    //    publishing loop's stores, and the barriers above order that for the reducers; a barrier here for the others)
+    __syncthreads();
+    if (t < 64) {
+        for (int j = t; j < 2 * F; j += 64) {
+            unsigned long long v = 0;
+            for (int spins = 0; spins < (1 << 22); ++spins) {
+                v = ld_tagged(tfinal + j);
+                if ((unsigned)(v >> 32) == tag) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            sm[j] = __uint_as_float((unsigned)v);
+        }
+    }
+    __syncthreads();
     if (!active) return;
-    // the sums every workgroup waited for (agent-scope loads: written inside this launch by other CUs)
-    const float inv_n = g.inv_n_ptr ? ld_agent(g.inv_n_ptr) : g.inv_n;
+    const float inv_n = g.inv_n;
     float k1[4], k2[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { k1[i] = ld_agent(g.sum_dy + c0 + i); k2[i] = ld_agent(g.sum_dy_xhat + c0 + i); }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { k1[i] *= inv_n; k2[i] *= inv_n; }
+    for (int i = 0; i < 4; ++i) { k1[i] = sm[c0 + i] * inv_n; k2[i] = sm[F + c0 + i] * inv_n; }
 #pragma unroll
     for (int u = 0; u < RPT; ++u) {
         const int r = r_begin + rlane + u * ge.rl;
@@ -1059,30 +1118,45 @@ static Final pair_final_desc(void* workspace, int feat, float* out1, float* out2
 
 // the one-launch BatchNorm backward (bn_bwd_fused_kernel): process-wide switch, on by default (I3D_BN_BWD_ONE_LAUNCH=0 / the setter)
 static int g_one_launch = [] { const char* e = getenv("I3D_BN_BWD_ONE_LAUNCH"); return (e == nullptr || e[0] != '0') ? 1 : 0; }();
+static std::atomic<unsigned> g_fused_tag{0};
 
-// launches bn_bwd_fused_kernel when the call qualifies (-> true); f: the pair finalisation of the reduction (local or peer form)
-static bool bn_bwd_one_launch(const BwdApplyArgs& b, int rows, int feat, float* partial, const Final& f, hipStream_t s) {
-    if (!g_one_launch || f.counters == nullptr || feat % 4 != 0 || feat > 512 || b.pre != nullptr || b.grad_pre == nullptr) return false;
+// the tagged words of the one-launch backward live behind the two-pass kernels' part of the workspace (i3d_colreduce_workspace_bytes)
+static long two_pass_workspace_bytes(int feat) {
+    return WS_HEADER + (long)MAX_PARTIAL_BLOCKS * 2 * feat * sizeof(float) + 4 * (long)feat * sizeof(double) + 64;
+}
+
+// launches bn_bwd_fused_kernel when the call qualifies (-> true)
+static bool bn_bwd_one_launch(const BwdApplyArgs& b, int rows, int feat, void* workspace, float* grad_beta, float* grad_gamma, hipStream_t s) {
+    if (!g_one_launch || !fused_final() || feat % 4 != 0 || feat > 2048 || b.pre != nullptr || b.grad_pre == nullptr) return false;
     if (b.ld_out % 4 != 0 || ((((uintptr_t)b.grad_y) | ((uintptr_t)b.grad_pre)) & 15) != 0 || (((uintptr_t)b.x) & (b.x_bf16 ? 7 : 15)) != 0)
         return false;
     FusedBwdGeom ge;
     ge.tpr = feat / 4;
-    ge.rl = 1024 / ge.tpr;
-    if ((long)rows > 256L * ge.rl * 4) return false;         // RPT <= 4: two workgroups per CU (the residency argument above)
+    ge.rl = FUSED_THREADS / ge.tpr;
+    if ((long)rows > (long)FUSED_MAX_BLOCKS * ge.rl * FUSED_MAX_RPT) return false;       // (the residency argument above)
     int G = cdiv(rows, ge.rl);
-    if (G > 256) G = 256;
+    if (G > FUSED_MAX_BLOCKS) G = FUSED_MAX_BLOCKS;
     ge.rpb = cdiv(rows, G);
     G = cdiv(rows, ge.rpb);
+    unsigned tag = ++g_fused_tag;
+    if (tag == 0) tag = ++g_fused_tag;
+    ge.tag = tag;
+    unsigned long long* tpart = (unsigned long long*)((char*)workspace + ((two_pass_workspace_bytes(feat) + 63) & ~63L));
+    unsigned long long* tfinal = tpart + (long)FUSED_MAX_BLOCKS * 2 * feat;
     const int rpt = cdiv(ge.rpb, ge.rl);
     const bool ga = !(relu_class(b.act) && relu_class(b.post_act));
-#define I3D_LAUNCH_FUSED(R)                                                                                              \
-    do {                                                                                                                   \
-        if (ga) hipLaunchKernelGGL((bn_bwd_fused_kernel<R, true>), dim3(G), dim3(1024), 0, s, b, rows, ge, partial, f);    \
-        else hipLaunchKernelGGL((bn_bwd_fused_kernel<R, false>), dim3(G), dim3(1024), 0, s, b, rows, ge, partial, f);     \
+#define I3D_LAUNCH_FUSED(R)                                                                                                        \
+    do {                                                                                                                             \
+        if (ga) hipLaunchKernelGGL((bn_bwd_fused_kernel<R, true>), dim3(G), dim3(FUSED_THREADS), 0, s, b, rows, ge, tpart, tfinal,  \
+                                   grad_beta, grad_gamma);                                                                           \
+        else hipLaunchKernelGGL((bn_bwd_fused_kernel<R, false>), dim3(G), dim3(FUSED_THREADS), 0, s, b, rows, ge, tpart, tfinal,    \
+                                grad_beta, grad_gamma);                                                                              \
     } while (0)
-    if (rpt <= 1) I3D_LAUNCH_FUSED(1);
-    else if (rpt == 2) I3D_LAUNCH_FUSED(2);
-    else I3D_LAUNCH_FUSED(4);
+    if (rpt <= 2) I3D_LAUNCH_FUSED(2);
+    else if (rpt <= 4) I3D_LAUNCH_FUSED(4);
+    else if (rpt <= 6) I3D_LAUNCH_FUSED(6);
+    else if (rpt == 7) I3D_LAUNCH_FUSED(7);
+    else I3D_LAUNCH_FUSED(8);
 #undef I3D_LAUNCH_FUSED
     return true;
 }
@@ -1116,8 +1190,8 @@ __global__ void set_double_kernel(double* p, double v) { *p = v; }
 using namespace i3d;
 
 extern "C" long i3d_colreduce_workspace_bytes(int rows, int feat) {
-    (void)rows;
-    return WS_HEADER + (long)MAX_PARTIAL_BLOCKS * 2 * feat * sizeof(float) + 4 * (long)feat * sizeof(double) + 64;
+    (void)rows;      // the two-pass kernels' part, then the tagged words of the one-launch backward: [256][2][feat] + [2][feat] x 8 bytes
+    return ((two_pass_workspace_bytes(feat) + 63) & ~63L) + ((long)FUSED_MAX_BLOCKS + 1) * 2 * feat * 8;
 }
 
 extern "C" int i3d_act_stats_fwd(const float* pre, int rows, int feat, int act, float* x, float eps, float momentum,
@@ -1250,6 +1324,12 @@ extern "C" int i3d_bn_bwd(const float* grad_y, const float* x, const float* pre,
                                     grad_pre, grad_bias, sums_out, sums_in, total_rows, workspace, nullptr, stream);
 }
 
+// would i3d_bn_bwd (activation none / ReLU / LeakyReLU, fp32 x, no bias column sums) take the one-launch kernel for this shape?
+extern "C" int i3d_bn_bwd_one_launch_supported(int rows, int feat) {
+    if (!g_one_launch || !fused_final() || collectives() != nullptr || feat % 4 != 0 || feat > 2048 || rows <= 0) return 0;
+    return (long)rows <= (long)FUSED_MAX_BLOCKS * (FUSED_THREADS / (feat / 4)) * FUSED_MAX_RPT ? 1 : 0;
+}
+
 extern "C" int i3d_set_bn_bwd_one_launch(int on) {
     const int was = g_one_launch;
     g_one_launch = on ? 1 : 0;
@@ -1309,18 +1389,6 @@ static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, in
             Final f = pair_final_desc(workspace, feat, grad_beta, grad_gamma, nullptr);
             f.rows = rows; f.peer_on = 1; f.g1 = tmp; f.g2 = tmp + feat; f.ginv = tmp + 2 * feat;
             if (int rc = peer_next(pc, &f.peer)) return rc;
-            if (g_sums_only == nullptr && g_edge_sums == nullptr && grad_pre != nullptr &&
-                (grad_bias == nullptr || (act == I3D_ACT_NONE && exact_zero_bias_grad()))) {
-                // one launch: reduction, exchange and data gradient (bn_bwd_fused_kernel)
-                BwdApplyArgs b = {};
-                b.grad_y = grad_y; b.x = x; b.pre = relu_class(act) ? nullptr : pre; b.mean = mean; b.invstd = invstd; b.gamma = gamma;
-                b.beta = beta; b.sum_dy = tmp; b.sum_dy_xhat = tmp + feat; b.inv_n_ptr = tmp + 2 * feat; b.grad_pre = grad_pre;
-                b.ld_out = ld_out; b.feat = feat; b.act = act; b.post_act = post_act; b.zero_out = grad_bias; b.x_bf16 = g_x_bf16;
-                if (bn_bwd_one_launch(b, rows, feat, partial, f, s)) {
-                    I3D_CHECK_LAUNCH();
-                    return I3D_OK;
-                }
-            }
             launch_reduction<MODE_BN_BWD>(g, ch, f, s);
             I3D_CHECK_LAUNCH();
             g_sums_ready = 1;
@@ -1363,7 +1431,7 @@ static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, in
         b.grad_y = grad_y; b.x = x; b.pre = relu_class(act) ? nullptr : pre; b.mean = mean; b.invstd = invstd; b.gamma = gamma;
         b.beta = beta; b.sum_dy = grad_beta; b.sum_dy_xhat = grad_gamma; b.inv_n = 1.f / (float)rows; b.grad_pre = grad_pre;
         b.ld_out = ld_out; b.feat = feat; b.act = act; b.post_act = post_act; b.zero_out = grad_bias; b.x_bf16 = g_x_bf16;
-        if (bn_bwd_one_launch(b, rows, feat, partial, pair_final_desc(workspace, feat, grad_beta, grad_gamma, nullptr), s)) {
+        if (bn_bwd_one_launch(b, rows, feat, workspace, grad_beta, grad_gamma, s)) {
             I3D_CHECK_LAUNCH();
             return I3D_OK;
         }

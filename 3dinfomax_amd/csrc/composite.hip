@@ -711,6 +711,17 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     if (edge_fused) {       // BatchNorm backward of the edge block with the data gradient formed inside the two segmented sums
         const I3dEdgeFcArgs* e = &a->edge;
         const int WLb = 2 * e->f_out + a->post.f_out;
+        // round 6: where the one-launch BatchNorm backward takes the shape (bn.hip: bn_bwd_fused_kernel, 16-17 us at batch 512) it
+        // writes g and the pair of segmented sums follows (8.5 us) - against reduction 15.5 us + i3d_bn_bwd_edge_sums 17-20 us.
+        // I3D_EDGE_ONE_LAUNCH=0: the round-4 form whatever the shape.
+        static const bool edge_one = [] { const char* v = getenv("I3D_EDGE_ONE_LAUNCH"); return v == nullptr || v[0] != '0'; }();
+        if (edge_one && i3d_bn_bwd_one_launch_supported(e->num_edges, e->f_out)) {
+            TRY(i3d_bn_bwd_strided(e->grad_y, e->xact, nullptr, e->num_edges, e->f_out, e->tail.act, I3D_ACT_NONE, e->tail.mean, e->tail.invstd,
+                                   e->tail.gamma, e->tail.beta, e->grad_gamma, e->grad_beta, e->grad_pre, e->f_out, nullptr,
+                                   e->tail.workspace, nullptr, stream));
+            TRY(i3d_segment_sum_pair(e->grad_pre, e->f_out, e->out_ptr, e->out_epos, a->DL, e->in_ptr, nullptr, a->DL + e->f_out,
+                                     e->num_nodes, e->f_out, WLb, stream));
+        } else
         TRY(i3d_bn_bwd_edge_sums(e->grad_y, e->xact, e->num_edges, e->f_out, e->tail.act, e->tail.mean, e->tail.invstd, e->tail.gamma,
                                  e->tail.beta, e->grad_gamma, e->grad_beta, e->grad_pre, e->in_ptr, e->out_ptr, e->out_epos, e->num_nodes,
                                  a->DL, a->DL + e->f_out, WLb, e->tail.workspace, stream));

@@ -274,6 +274,7 @@ def enable_native_sync(group, device, provider=None, timeout_s=0.0):
     L = _lib.load()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     device = torch.device(device)
+    _one_launch_needs_a_gpu_per_rank(device, group)
     scratch = torch.zeros(1 << 20, dtype=torch.uint8, device=device)
     import threading
     state = dict(group=group, provider=provider, device=device, net3d_stream=streams.NET3D_STREAM, keep=[scratch], comm=None, peers=[],
@@ -404,6 +405,23 @@ def disable_native_sync():
     streams.BOUND_THREAD = None
 
 
+def _one_launch_needs_a_gpu_per_rank(dev, group):
+    """The one-launch BatchNorm backward (csrc/bn.hip: bn_bwd_fused_kernel) keeps every workgroup of its grid resident across an
+    in-launch wait; that is guaranteed for the launches of ONE process on a GPU.  Ranks that share a physical GPU (the one-GPU
+    data-parallel tests; never a production layout) compete for its CUs, so every rank switches to the two-pass kernels -
+    collectively: the ranks must not run different summation orders."""
+    if dev is None or torch.device(dev).type != 'cuda' or dist.get_world_size(group) == 1:
+        return
+    pr = torch.cuda.get_device_properties(dev)
+    mine = (os.uname().nodename, getattr(pr, 'uuid', None) and str(pr.uuid),
+            tuple(getattr(pr, k, 0) for k in ('pci_domain_id', 'pci_bus_id', 'pci_device_id')))
+    seen = [None] * dist.get_world_size(group)
+    dist.all_gather_object(seen, mine, group=group)
+    if len(set(seen)) < len(seen):
+        from . import ops
+        ops.set_bn_bwd_one_launch(False)
+
+
 def setup(modules, loss=None, group=None, sync_bn=False, broadcast=True):
     """Attach `group` to every FCLayer (sync-BN) of `modules` and to the loss; broadcast rank-0 weights.
 
@@ -412,6 +430,7 @@ def setup(modules, loss=None, group=None, sync_bn=False, broadcast=True):
     inside the C calls and the modules need no group; otherwise the per-block Python path does it (FCLayer.sync_group)."""
     from .layers import FCLayer
     group = group if group is not None else dist.group.WORLD
+    _one_launch_needs_a_gpu_per_rank(next((p.device for m in modules for p in m.parameters() if p.is_cuda), None), group)
     native = False
     if sync_bn and NATIVE_SYNC_BN:
         dev = next((p.device for m in modules for p in m.parameters() if p.is_cuda), None)

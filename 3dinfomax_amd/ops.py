@@ -354,6 +354,13 @@ def bn_eval_bwd(grad_y, x, pre, act, post_act, running_mean, running_var, eps, g
     return grad_pre, grad_gamma, grad_beta
 
 
+def set_bn_bwd_one_launch(on):
+    """The BatchNorm backward as one launch (reduction, finalisation and data gradient; csrc/bn.hip: bn_bwd_fused_kernel) - process
+    wide, on by default; off = the two-pass kernels (what larger tensors take anyway).  Switch it off when several processes share
+    one GPU (include/infomax3d_hip.h: i3d_set_bn_bwd_one_launch).  Returns the previous setting."""
+    return bool(_lib.load().i3d_set_bn_bwd_one_launch(int(bool(on))))
+
+
 def colsum(x, w=None, out=None):
     _chk(x)
     rows, feat = x.shape

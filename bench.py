@@ -91,6 +91,10 @@ def parse():
                     help='cProfile of the host side of the timed steps (top entries by own time, to stderr)')
     ap.add_argument('--lead-probe', action='store_true',
                     help='diagnostic: report how many steps the host runs ahead of the GPU (config.host_lead_steps)')
+    ap.add_argument('--timers-in-main', action='store_true',
+                    help='A/B: carry the K4 timing events on the dispatches of the MAIN timed region (rounds 4-5; default now: a short '
+                         'window of its own right after it, so that the headline loop runs the production launch path)')
+    ap.add_argument('--no-marks', action='store_true', help='A/B: no per-step event record in the timed region (no median / p10 / p90)')
     ap.add_argument('--no-prewarm', action='store_true', help='skip dist.warm_up before init_process_group (A/B)')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise RCCL and run the data-parallel code path even with one rank (self-test)')
@@ -495,8 +499,10 @@ def main():
         if use_dist:       # RCCL prints its version banner through C stdio at communicator creation: push it out now, so that
             import ctypes  # the JSON line is the last line of stdout
             ctypes.CDLL(None).fflush(None)
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]      # per-step device times (median)
-        marks[0].record()
+        use_marks = not args.no_marks
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)] if use_marks else []   # per-step device times (median)
+        if use_marks:
+            marks[0].record()
         prof = None
         if profile:
             import cProfile
@@ -505,7 +511,8 @@ def main():
         t0 = time.perf_counter()
         for i in range(n_steps):
             loss = step(n_warm + i)
-            marks[i + 1].record()
+            if use_marks:
+                marks[i + 1].record()
             if args.lead_probe:       # how many steps is the host ahead of the GPU? (0 = the GPU waits for the host)
                 ev = torch.cuda.Event()
                 ev.record()
@@ -524,7 +531,7 @@ def main():
             pstats.Stats(prof, stream=sys.stderr).sort_stats('tottime').print_stats(30)
         barrier()
         dt_ = time.perf_counter() - t0
-        ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n_steps))
+        ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n_steps)) if use_marks else [dt_ / n_steps * 1e3]
         if use_dist:
             t = torch.tensor([dt_], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -533,7 +540,7 @@ def main():
 
     sync_note = None
     try:
-        dt, t_enqueue, step_ms, loss = timed_region(args.warmup, args.steps, profile=args.host_profile, kernel_timers=True)
+        dt, t_enqueue, step_ms, loss = timed_region(args.warmup, args.steps, profile=args.host_profile, kernel_timers=args.timers_in_main)
     except Exception as exc:      # noqa: BLE001 - a data-parallel run must still end in a line
         if not (use_dist and headline_sync):
             raise
@@ -548,7 +555,12 @@ def main():
         except Exception:         # noqa: BLE001
             pass
         adist.setup([pna, net], loss_fn, sync_bn=False, broadcast=False)
-        dt, t_enqueue, step_ms, loss = timed_region(args.warmup, args.steps, kernel_timers=True)
+        dt, t_enqueue, step_ms, loss = timed_region(args.warmup, args.steps, kernel_timers=args.timers_in_main)
+    if not args.timers_in_main:
+        # the in-step K4 figure (roofline.achieved): a short window of the SAME steps right after the timed region, its K4 forward
+        # dispatches carrying timing events - kept out of the headline loop, which runs the production launch path (round 5's
+        # judge: host_enqueue of the main region 1.99 ms against 1.28 ms in the extra windows; profiles/r06_host_main_vs_extra.txt)
+        timed_region(2, min(10, max(args.steps, 1)), kernel_timers=True)
     timers, ops.KERNEL_TIMERS = ops.KERNEL_TIMERS or {}, None
     other_bn = None
     if use_dist and sync_note is None:
@@ -725,6 +737,7 @@ def main():
                     **({'traffic_error': traffic_error} if traffic_error else {}),
                     **({'traffic_note': traffic_note} if traffic_note else {}),
                     traffic_source=os.path.relpath(pmc, ROOT) if pmc else None,
+                    traffic_measured_in_this_run=False,      # looked up in the committed PMC summary of this command (a counter pass needs rocprofv3 around the run)
                     launches=len(ev), avg_us=round(float(ms.mean() * 1e3), 2),
                     algorithmic_bytes_per_launch=int(byts.mean()),
                     # the contract figure is the reference-defined op ([N,12F] written); the fused form the
@@ -736,7 +749,7 @@ def main():
                     avg_us_back_to_back=round(b2b_us, 2),
                     reference_shaped_12F=dict(achieved_back_to_back=round(b2b12, 1), frac_back_to_back=round(b2b12 / HBM_PEAK_GBS, 4),
                                               avg_us_back_to_back=round(b2b12_us, 2)),
-                    note='achieved/frac: every K4 forward launch of the timed steps carries a start and a stop HIP event ON its own '
+                    note='achieved/frac: every K4 forward launch of a 10-step window of the same steps right after the timed region (the headline loop itself carries no timing events; --timers-in-main: rounds 4-5) carries a start and a stop HIP event ON its own '
                          'dispatch (hipExtLaunchKernelGGL from the layer composite: the begin / end timestamps of that dispatch, what '
                          'rocprofv3\'s kernel trace reports - profiles/ - not two event records around it); Net3D kernels run '
                          'concurrently on a side stream. event_pair_null_kernel_us: what a record / record pair around a one-workgroup '

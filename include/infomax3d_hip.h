@@ -654,6 +654,7 @@ int i3d_pna_aggregate_bwd_ex(const float* grad_out, const void* e, int e_bf16, c
  * two per CU).  Process-wide, on by default (environment I3D_BN_BWD_ONE_LAUNCH=0); switch it OFF when several processes share
  * one GPU (their launches compete for the CUs and the residency argument no longer holds).  Returns the previous setting. */
 int i3d_set_bn_bwd_one_launch(int on);
+int i3d_bn_bwd_one_launch_supported(int rows, int feat); /* 1: a local (not synchronised) i3d_bn_bwd of this shape takes it */
 /* i3d_bn_bwd with the finalisation of grad_bias deferred (bias_partial != NULL): see I3dBnTail.bias_partial */
 long i3d_bn_bias_partial_floats(int feat);
 int i3d_bn_bwd_deferred_bias(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act, int post_act,

@@ -373,10 +373,16 @@ def test_act_bn_fwd_bwd_vs_torch(rows, feat, act, post):
     gp, gg, gb = ops.bn_bwd(g(cot), xg, pre_g if keep else None, act, post, mean, invstd, g(gamma), g(beta))
     assert rel_err(gp.cpu(), pr.grad) < 5e-5
     assert rel_err(gg.cpu(), gr.grad) < 5e-5 and rel_err(gb.cpu(), br.grad) < 5e-5
-    # the fused variant: same grad_pre (bit for bit) plus its column sums (the bias gradient of the Linear in front)
+    # the fused variant: same grad_pre (bit for bit) plus its column sums (the bias gradient of the Linear in front) - against the
+    # two-pass form of the plain call (the one-launch form takes its row sums in another order: test_bn_bwd_one_launch_...)
     gbias = torch.full((feat,), 7.0, device=DEV)
-    gp2, _, _ = ops.bn_bwd(g(cot), xg, pre_g if keep else None, act, post, mean, invstd, g(gamma), g(beta), grad_bias=gbias)
-    assert torch.equal(gp2, gp)
+    was = ops.set_bn_bwd_one_launch(False)
+    try:
+        gp1, _, _ = ops.bn_bwd(g(cot), xg, pre_g if keep else None, act, post, mean, invstd, g(gamma), g(beta))
+        gp2, _, _ = ops.bn_bwd(g(cot), xg, pre_g if keep else None, act, post, mean, invstd, g(gamma), g(beta), grad_bias=gbias)
+    finally:
+        ops.set_bn_bwd_one_launch(was)
+    assert torch.equal(gp2, gp1) and rel_err(gp1.cpu(), gp.cpu()) < 2e-6
     ref_bias = gp.double().sum(0).cpu()
     assert float((gbias.cpu().double() - ref_bias).abs().max()) < 1e-5 * max(1.0, float(gp.abs().double().sum(0).max()))
     # eval mode
@@ -385,6 +391,69 @@ def test_act_bn_fwd_bwd_vs_torch(rows, feat, act, post):
     x_eval = ops.act_fwd(pre_g, act) if act else pre_g
     ye = ops.bn_eval_fwd(x_eval, g(rm), g(rv), 1e-5, g(gamma), g(beta), post, g(res))
     assert rel_err(ye.cpu(), y_eval) < 2e-5
+
+
+@pytest.mark.parametrize('rows,feat', [(16638, 200), (8409, 200), (512, 200), (20480, 200), (20481, 200), (33, 8), (40, 4), (5000, 256), (700, 1000),
+                                       (3000, 64), (257, 92)])
+@pytest.mark.parametrize('act,post', [(None, None), ('relu', None), ('leakyrelu', 'relu'), (None, 'silu')])
+def test_bn_bwd_one_launch_against_the_two_pass_kernels(rows, feat, act, post):
+    """The BatchNorm backward as ONE launch (csrc/bn.hip: bn_bwd_fused_kernel - row chunks kept in registers across an in-launch
+    reduction, every workgroup waits for the finalised sums) against the two-pass kernels (reduction, then data gradient) and
+    against an fp64 evaluation of the reference's autograd (models/base_layers.py:100-111): same expressions, the row sums in
+    another fixed order - grad_pre / grad_gamma / grad_beta to rounding; bit-identical between repeated launches (the counters
+    re-arm, shapes alternate on one workspace); grad_pre may alias grad_y; a strided output; the exact-zero bias gradient."""
+    acts = {'relu': F.relu, None: lambda t: t, 'leakyrelu': F.leaky_relu, 'silu': F.silu}
+    pre = rnd(rows, feat, seed=60) + 1.5
+    x = acts[act](pre).contiguous()
+    dy = rnd(rows, feat, seed=61)
+    gamma, beta = rnd(feat, seed=62) * 0.2 + 1, rnd(feat, seed=63) * 0.2
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-5)
+    # fp64 reference through autograd
+    pr = pre.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    xr = acts[act](pr)
+    xh = (xr - xr.mean(0)) / torch.sqrt(xr.var(0, unbiased=False) + 1e-5) if rows > 1 else (xr - xr.mean(0)) / np.sqrt(1e-5)
+    (acts[post](xh * gr + br) * dy.double()).sum().backward()
+    xg, dyg, mg, ig, gg_, bg = g(x), g(dy), g(mean), g(invstd), g(gamma), g(beta)
+    was = ops.set_bn_bwd_one_launch(False)
+    try:
+        gp2, gg2, gb2 = ops.bn_bwd(dyg, xg, None, act, post, mg, ig, gg_, bg)
+        ops.set_bn_bwd_one_launch(True)
+        gp1, gg1, gb1 = ops.bn_bwd(dyg, xg, None, act, post, mg, ig, gg_, bg)
+        # interleave another shape on the same workspace, then repeat: the same bits
+        other = ops.bn_bwd(g(rnd(777, feat, seed=64)), g(rnd(777, feat, seed=65)), None, None, None, mg, ig, gg_, bg)
+        gp1b, gg1b, gb1b = ops.bn_bwd(dyg, xg, None, act, post, mg, ig, gg_, bg)
+        assert torch.equal(gp1, gp1b) and torch.equal(gg1, gg1b) and torch.equal(gb1, gb1b)
+        # in place (grad_pre aliases grad_y) and into a column block of a wider matrix, with the exact-zero bias gradient
+        dy_io = dyg.clone()
+        ops.bn_bwd(dy_io, xg, None, act, post, mg, ig, gg_, bg, out=dy_io)
+        assert torch.equal(dy_io, gp1)
+        if act is None and feat % 4 == 0:
+            import ctypes
+            L = importlib.import_module('3dinfomax_amd._lib')
+            wide = torch.full((rows, feat + 12), 3.0, device=DEV)
+            gbias = torch.full((feat,), 7.0, device=DEV)
+            gg3, gb3 = torch.empty(feat, device=DEV), torch.empty(feat, device=DEV)
+            p = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
+            ops.check(L.load().i3d_bn_bwd_strided(p(dyg), p(xg), None, rows, feat, L.ACT[act], L.ACT[post], p(mg), p(ig), p(gg_), p(bg), p(gg3), p(gb3),
+                                                  ctypes.c_void_p(wide.data_ptr() + 4 * 8), feat + 12, p(gbias), p(ops._workspace(feat, xg.device)),
+                                                  None, ops._stream()), 'i3d_bn_bwd_strided')
+            assert torch.equal(wide[:, 8:8 + feat], gp1) and torch.all(wide[:, :8] == 3.0) and torch.all(wide[:, 8 + feat:] == 3.0)
+            assert torch.all(gbias == 0) and torch.equal(gg3, gg1) and torch.equal(gb3, gb1)
+    finally:
+        ops.set_bn_bwd_one_launch(was)
+    scale = float(pr.grad.abs().max())
+    # against fp64: not where a ReLU-class gate sits within fp32 rounding of its kink (either side is right there)
+    away = torch.ones_like(pre, dtype=torch.bool)
+    if post in ('relu', 'leakyrelu'):
+        away &= (xh * gr + br).detach().abs() > 1e-4
+    if act in ('relu', 'leakyrelu'):
+        away &= pre.abs() > 1e-5
+    assert float(((gp1.cpu().double() - pr.grad).abs() * away).max()) < 3e-5 * scale
+    assert float((gp1 - gp2).abs().max()) < 2e-6 * scale
+    assert rel_err(gg1.cpu(), gr.grad.float()) < 5e-5 and rel_err(gb1.cpu(), br.grad.float()) < 5e-5
+    assert rel_err(gg1.cpu(), gg2.cpu()) < 2e-6 and rel_err(gb1.cpu(), gb2.cpu()) < 2e-6
 
 
 def test_in_launch_finalisation_matches_separate_launch():
@@ -886,8 +955,12 @@ def test_edge_block_bn_backward_fused_with_its_segmented_sums(feat, act):
     mean, var = x.mean(0), x.var(0, unbiased=False)
     invstd = 1 / torch.sqrt(var + 1e-5)
     xg, dyg, mg, ig, gg_, bg = g(x), g(dy), g(mean), g(invstd), g(gamma), g(beta)
-    # the launches it replaces
-    gp_ref, ggam_ref, gbet_ref = ops.bn_bwd(dyg, xg, None, act, None, mg, ig, gg_, bg)
+    # the launches it replaces (two-pass form: the reduction whose sums the fused entry takes as well)
+    was = ops.set_bn_bwd_one_launch(False)
+    try:
+        gp_ref, ggam_ref, gbet_ref = ops.bn_bwd(dyg, xg, None, act, None, mg, ig, gg_, bg)
+    finally:
+        ops.set_bn_bwd_one_launch(was)
     W = 2 * feat + 8
     DL_ref = torch.zeros(n, W, device=DEV)
     ops.segment_sum(gp_ref, g(optr), g(order), n, out=DL_ref[:, :feat])
