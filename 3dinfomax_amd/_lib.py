@@ -8,6 +8,13 @@ import re
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_long, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# test hooks (tests/test_gpu_dist.py), behind ONE flag and read ONCE, here: I3D_TESTING=1 makes I3D_TEST_PEER_SELFTEST_FAIL /
+# I3D_TEST_PEER_FAIL (a rank number) and I3D_TEST_FORCE_EARLY_ALLREDUCE (1) effective; without the flag a stray variable changes nothing
+_TESTING = os.environ.get('I3D_TESTING') == '1'
+TEST_HOOKS = dict(peer_selftest_fail=os.environ.get('I3D_TEST_PEER_SELFTEST_FAIL') if _TESTING else None,
+                  peer_fail=os.environ.get('I3D_TEST_PEER_FAIL') if _TESTING else None,
+                  force_early_allreduce=_TESTING and os.environ.get('I3D_TEST_FORCE_EARLY_ALLREDUCE') == '1',
+                  verbose_selftest=_TESTING and bool(os.environ.get('I3D_DEBUG_SELFTEST')))
 LIB_PATH = os.environ.get('I3D_LIB_PATH') or os.path.join(HERE, 'lib', 'lib3dinfomax_hip.so')      # (override: kernel probes of tools/probes)
 HEADER_PATH = os.path.join(os.path.dirname(HERE), 'include', 'infomax3d_hip.h')
 
@@ -144,9 +151,6 @@ _SIGNATURES = {
     'i3d_bn_eval_aff_multi': (c_int, [POINTER(BnEvalAff), c_int, _P]),
     'i3d_set_collectives': (c_int, [POINTER(Collectives)]),
     'i3d_collectives_world': (c_int, []),
-    'i3d_bn_bwd_sums': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    'i3d_gemm_f32_bnbwd_supported': (c_int, [c_int]),
-    'i3d_gemm_f32_bnbwd': (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, c_long, _P, _P, c_int, _P, _P, c_int, c_long, _P, c_int, c_int, _P, _P, _P]),
     'i3d_collectives_all_gather_f32': (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
     'i3d_collectives_all_reduce_f64': (c_int, [c_void_p, c_long, c_void_p]),
     'i3d_rccl_available': (c_int, []),

@@ -16,18 +16,11 @@
 namespace i3d {
 
 constexpr int MAX_PARTIAL_BLOCKS = 256;      // capacity of the partial buffer / of the in-launch finalisation (raise for A/B runs)
-// row chunks actually used (<= MAX_PARTIAL_BLOCKS): I3D_PARTIAL_BLOCKS, default 256 = one workgroup per CU.  Measured at
+// row chunks used: 256 = one workgroup per CU.  Measured at
 // batch 512 (tools/ab_partial_blocks.sh, profiles/r02_ab_partial_blocks.txt): 512 / 1024 chunks make every reduction
 // SLOWER (apply+colsum 22.4 -> 24.2 -> 27.2 us with the in-launch finalisation, 12.1 -> 10.5 -> 13.1 us without) - the
 // per-workgroup epilogue (LDS combine, uncached partial stores) and the longer finalisation outweigh the extra waves.
-static int partial_blocks() {
-    static const int n = [] {
-        const char* e = getenv("I3D_PARTIAL_BLOCKS");
-        int v = e ? atoi(e) : 256;
-        return v < 32 ? 32 : (v > MAX_PARTIAL_BLOCKS ? MAX_PARTIAL_BLOCKS : v);
-    }();
-    return n;
-}
+static int partial_blocks() { return MAX_PARTIAL_BLOCKS; }
 constexpr int RU = 4;                     // rows per thread in flight in the streaming kernels   // ~ one partial block per CU; stage 2 reduces them with 8 lanes per column
 
 struct Chunking {
@@ -1087,11 +1080,8 @@ static bool fused_final() {
     return on;
 }
 
-// I3D_EXACT_ZERO_BIAS_GRAD=0: sum the analytically-zero bias gradients up as the reference does (A/B, parity studies)
-static bool exact_zero_bias_grad() {
-    static const bool on = [] { const char* e = getenv("I3D_EXACT_ZERO_BIAS_GRAD"); return e == nullptr || e[0] != '0'; }();
-    return on;
-}
+// the bias gradient of a Linear directly in front of a BatchNorm (no activation) is written as the exact value, zero (see bn_bwd_impl)
+static bool exact_zero_bias_grad() { return true; }
 
 static float* partial_of(void* workspace) { return (float*)((char*)workspace + WS_HEADER); }
 
@@ -1357,9 +1347,6 @@ static thread_local int g_x_bf16 = 0;
 static thread_local const EdgeSums* g_edge_sums = nullptr;
 // phase 2 of the synchronised backward finds its fp32 sum vectors + 1 / rows already in the workspace (peer exchange)
 static thread_local int g_sums_ready = 0;
-// the next bn_bwd_impl call of this thread stops in front of its data-gradient pass and reports the vectors that pass would read
-// (i3d_bn_bwd_sums: the data gradient is then formed by the GEMM that consumes it, gemm.hip FUSE & 4)
-static thread_local I3dBnBwdVectors* g_sums_only = nullptr;
 
 static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,
                        int post_act, const float* mean, const float* invstd, const float* gamma,
@@ -1424,7 +1411,7 @@ static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, in
     }
     Chunking ch = make_chunking(rows, feat);
     float* partial = partial_of(workspace);
-    if (sums_in == nullptr && sums_out == nullptr && g_sums_only == nullptr && g_edge_sums == nullptr && grad_pre != nullptr &&
+    if (sums_in == nullptr && sums_out == nullptr && g_edge_sums == nullptr && grad_pre != nullptr &&
         (grad_bias == nullptr || (act == I3D_ACT_NONE && exact_zero_bias_grad()))) {
         // one launch: reduction, finalisation and data gradient (bn_bwd_fused_kernel) - tensors of up to 256 * rl * 4 rows
         BwdApplyArgs b = {};
@@ -1464,12 +1451,6 @@ static int bn_bwd_impl(const float* grad_y, const float* x, const float* pre, in
     b.sum_dy = sum_dy; b.sum_dy_xhat = sum_dy_xhat; b.grad_pre = grad_pre; b.ld_out = ld_out; b.feat = feat; b.act = act;
     b.post_act = post_act; b.eval_mode = 0; b.inv_n = 1.f / (float)total_rows; b.eps = 0.f;
     b.zero_out = nullptr; b.x_bf16 = g_x_bf16;
-    if (g_sums_only != nullptr) {
-        I3dBnBwdVectors* o = g_sums_only;
-        o->mean = mean; o->invstd = invstd; o->gamma = gamma; o->sum_dy = sum_dy; o->sum_dy_xhat = sum_dy_xhat;
-        o->inv_n_ptr = b.inv_n_ptr; o->inv_n = b.inv_n; o->act = act;
-        return I3D_OK;
-    }
     if (g_edge_sums != nullptr) {      // i3d_bn_bwd_edge_sums: the data gradient formed inside the segmented sums that consume it
         const EdgeSums es = *g_edge_sums;
         const long lanes = 2L * es.num_nodes * (feat / 4);
@@ -1587,17 +1568,6 @@ extern "C" int i3d_bn_bwd_strided(const float* grad_y, const float* x, const flo
     I3D_CHECK_ARG(ld_out >= feat && (feat % 4 != 0 || (ld_out % 4 == 0 && (((uintptr_t)grad_pre) & 15) == 0)), "bad output pitch");
     return bn_bwd_impl(grad_y, x, pre, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta, grad_pre,
                        grad_bias, nullptr, nullptr, rows, workspace, bias_partial, ld_out, stream);
-}
-
-extern "C" int i3d_bn_bwd_sums(const float* grad_y, const float* x, int rows, int feat, int act, int post_act, const float* mean,
-                               const float* invstd, const float* gamma, const float* beta, float* grad_gamma, float* grad_beta,
-                               void* workspace, I3dBnBwdVectors* out, void* stream) {
-    I3D_CHECK_ARG(out != nullptr && post_act == I3D_ACT_NONE && relu_class(act), "vectors out; no activation behind the BatchNorm; none / ReLU / LeakyReLU in front");
-    g_sums_only = out;
-    const int rc = bn_bwd_impl(grad_y, x, nullptr, rows, feat, act, post_act, mean, invstd, gamma, beta, grad_gamma, grad_beta,
-                               nullptr, nullptr, nullptr, nullptr, rows, workspace, nullptr, feat, stream);
-    g_sums_only = nullptr;
-    return rc;
 }
 
 extern "C" int i3d_bn_eval_bwd(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act,

@@ -55,7 +55,7 @@ Aux* aux_for(hipStream_t main) {
     // I3D_WGRAD_PRIORITY=low: the side stream at the lowest priority the device offers - the kernels of the backward CHAIN (the
     // critical path: the main stream is busy back to back through the whole step) get the CUs first, the weight gradients
     // fill in
-    static const bool low = [] { const char* e = getenv("I3D_WGRAD_PRIORITY"); return e != nullptr && e[0] == 'l'; }();
+    constexpr bool low = false;      // (a low-priority side stream was measured and lost: docs/history)
     int lo = 0, hi = 0;
     hipError_t made = hipErrorUnknown;
     if (low && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
@@ -63,8 +63,8 @@ Aux* aux_for(hipStream_t main) {
     if (made != hipSuccess) made = hipStreamCreateWithFlags(&a->s, hipStreamNonBlocking);
     // fork / join events order two streams of ONE device: released to the device, not to the system (the default scope of an
     // event record is a system-scope release - a cache write-back the host and the peers would need, the other stream does
-    // not; 5 records per step sit on the chain: 2.091 -> 2.074 ms).  I3D_FORK_EVENT_DEVICE_SCOPE=0: the default scope.
-    static const bool dev_scope = [] { const char* e = getenv("I3D_FORK_EVENT_DEVICE_SCOPE"); return e == nullptr || e[0] != '0'; }();
+    // not; 5 records per step sit on the chain: 2.091 -> 2.074 ms).
+    constexpr bool dev_scope = true;
     const unsigned evf = hipEventDisableTiming | (dev_scope ? hipEventDisableSystemFence : 0);
     if (made != hipSuccess ||
         hipEventCreateWithFlags(&a->fork, evf) != hipSuccess ||
@@ -117,39 +117,6 @@ static int bias_final(const I3dBnTail* t, int rows, int f_out, float* grad_bias,
     return i3d_bn_bias_finalize(t->bias_partial, rows, f_out, grad_bias, wst);
 }
 
-// ---- BatchNorm backward folded into the data-gradient GEMM (round 5; gemm.hip FUSE & 4, bn.hip i3d_bn_bwd_sums) ----------------
-// The block's data-gradient pass (bn_bwd_apply: 12-22 us per BatchNorm at batch 512, plus a launch boundary on the dependent
-// chain) disappears: the product that consumes dz forms it while staging its A tiles and stores it for the weight gradients.
-// MEASURED AND LEFT OFF (I3D_BNBWD_PROLOGUE=1 switches it on): the step gets SLOWER - 2.127 against 2.080 ms at batch 512 (three
-// interleaved runs, profiles/r05_ab_bnbwd.txt), 8.38 against 8.14 ms at the QMugs shape.  Every workgroup of the product (13
-// column tiles of the [N, 200] x [200, 800] data gradient) loads the BatchNorm input next to the gradient and forms dz for
-// itself: the second load stream and the extra VALU work per staged tile cost each of the eight products more than the 12-22 us
-// pass they replace - these GEMMs are bound by their staging, not by their MFMAs (docs/history: r02_gemm_ablation).  Same
-// expression and operation order as the pass: the same data gradient bits; the bias gradient of a block with an activation is
-// then a column sum of dz in another order.
-static bool bnbwd_prologue() {
-    static const bool on = [] { const char* e = getenv("I3D_BNBWD_PROLOGUE"); return e != nullptr && e[0] == '1'; }();
-    return on;
-}
-static bool exact_zero_bias_env() {
-    static const bool on = [] { const char* e = getenv("I3D_EXACT_ZERO_BIAS_GRAD"); return e == nullptr || e[0] != '0'; }();
-    return on;
-}
-// can the BatchNorm backward of a block with this tail go into the GEMM behind it?  (x_bf16: the BatchNorm input is stored as bf16)
-static bool bnbwd_ok(const I3dBnTail* t, int f_out, const float* grad_bias, bool x_bf16) {
-    if (!bnbwd_prologue() || x_bf16 || t->gamma == nullptr || t->post_act != I3D_ACT_NONE || !relu_class(t->act)) return false;
-    if (!i3d_gemm_f32_bnbwd_supported(f_out)) return false;
-    if (grad_bias == nullptr) return true;
-    // the bias gradient in front of the BatchNorm: exactly zero without an activation (zero-filled by the GEMM), else the column
-    // sum of dz, taken next to the weight gradients (bias_final_fc) through the deferred-bias partial buffer
-    return t->act == I3D_ACT_NONE ? exact_zero_bias_env() : t->bias_partial != nullptr;
-}
-static int bnbwd_sums(const I3dBnTail* t, int rows, int f_out, const float* grad_y, const float* xact, float* grad_gamma,
-                      float* grad_beta, I3dBnBwdVectors* v, void* stream) {
-    return i3d_bn_bwd_sums(grad_y, xact, rows, f_out, t->act, t->post_act, t->mean, t->invstd, t->gamma, t->beta, grad_gamma, grad_beta,
-                           t->workspace, v, stream);
-}
-
 // ---- plain FC ------------------------------------------------------------------------------------------
 extern "C" int i3d_fc_bn_fwd(const I3dFcArgs* a, void* stream) {
     I3D_CHECK_ARG(a != nullptr && a->rows > 0, "bad arguments");
@@ -162,30 +129,12 @@ extern "C" int i3d_fc_bn_fwd(const I3dFcArgs* a, void* stream) {
 // waits for) on `stream`, and the weight gradients, which only need the block's grad_pre, on `wst` - the same stream for
 // the stand-alone entry points, the side stream for a PNA layer (which issues the weight gradients of several blocks behind
 // ONE fork: a fork or join costs the host ~7 us, tools/probes/forkjoin_probe.hip).
-static bool fc_bnbwd_ok(const I3dFcArgs* a, int xact_bf16) {
-    // (launches of <= ~1000 32x32 tiles - the projection head at batch 512 - run on 32x32 tiles of four 16x16 waves: gemm.hip cfg 8;
-    // the prologue exists for the 64-row tilings only)
-    if ((long)cdiv(a->rows, 32) * cdiv(a->f_in, 32) <= 1024) return false;
-    return a->grad_x != nullptr && a->f_in % 4 == 0 && a->ldw % 4 == 0 && bnbwd_ok(&a->tail, a->f_out, a->grad_bias, xact_bf16 != 0) &&
-           (((uintptr_t)a->grad_y | (uintptr_t)a->xact | (uintptr_t)a->grad_pre | (uintptr_t)a->grad_x | (uintptr_t)a->W) & 15) == 0;
-}
 // the bias gradient of a block next to its weight gradients (on their stream)
-static int bias_final_fc(const I3dFcArgs* a, void* wst, int xact_bf16 = 0) {
-    if (fc_bnbwd_ok(a, xact_bf16)) {
-        if (a->grad_bias == nullptr || a->tail.act == I3D_ACT_NONE) return I3D_OK;        // (zero-filled by the fused product)
-        return i3d_colsum_strided(a->grad_pre, a->f_out, a->rows, a->f_out, a->grad_bias, a->tail.bias_partial, wst);
-    }
+static int bias_final_fc(const I3dFcArgs* a, void* wst) {
     return bias_final(&a->tail, a->rows, a->f_out, a->grad_bias, wst);
 }
 
 static int fc_bn_bwd_chain(const I3dFcArgs* a, void* stream, int xact_bf16 = 0) {
-    if (fc_bnbwd_ok(a, xact_bf16)) {       // sums, then dX = dz W with dz formed in the product's prologue (and stored to grad_pre)
-        I3dBnBwdVectors v;
-        TRY(bnbwd_sums(&a->tail, a->rows, a->f_out, a->grad_y, a->xact, a->grad_gamma, a->grad_beta, &v, stream));
-        return i3d_gemm_f32_bnbwd(0, a->rows, a->f_in, a->f_out, a->grad_y, a->xact, a->f_out, a->rows, &v, a->grad_pre, a->f_out,
-                                  (a->grad_bias != nullptr && a->tail.act == I3D_ACT_NONE) ? a->grad_bias : nullptr, a->W, a->ldw, 0,
-                                  a->grad_x, a->f_in, 0, nullptr, nullptr, stream);
-    }
     if (xact_bf16)      // the block's activation (a PNA layer's messages) is stored as bf16
         TRY(i3d_bn_bwd_x_bf16(a->grad_y, a->xact, a->rows, a->f_out, a->tail.act, a->tail.post_act, a->tail.mean, a->tail.invstd,
                               a->tail.gamma, a->tail.beta, a->grad_gamma, a->grad_beta, a->grad_pre, a->grad_bias, a->tail.workspace,
@@ -368,16 +317,14 @@ static bool merge_h_ok(const I3dPnaLayerArgs* a) {
 // The LAST layer of a backward pass (wgrad_split: nothing of the chain runs next to its weight gradients any more): the chain's
 // stream is idle behind its data gradient while the weight-gradient stream still has the layer's panels, their reduction and
 // the bond-table products in front of the join - the two small launches of the bias gradient go to the chain's stream there
-// (19 us off the tail of the step).  I3D_EDGE_BIAS_ON_CHAIN=0: on the weight-gradient stream like the other layers'.
+// (19 us off the tail of the step).
 static bool edge_bias_on_chain(const I3dPnaLayerArgs* a) {
-    static const bool on = [] { const char* v = getenv("I3D_EDGE_BIAS_ON_CHAIN"); return v == nullptr || v[0] != '0'; }();
-    return on && a->wgrad_split != 0;
+    return a->wgrad_split != 0;
 }
 
 static bool edge_bwd_fused_ok(const I3dPnaLayerArgs* a) {
-    static const bool on = [] { const char* v = getenv("I3D_EDGE_BWD_FUSED"); return v == nullptr || v[0] != '0'; }();
     const I3dEdgeFcArgs* e = &a->edge;
-    return on && merge_h_ok(a) && a->DL != nullptr && e->pre_keep == nullptr && relu_class(e->tail.act) && e->tail.post_act == I3D_ACT_NONE &&
+    return merge_h_ok(a) && a->DL != nullptr && e->pre_keep == nullptr && relu_class(e->tail.act) && e->tail.post_act == I3D_ACT_NONE &&
            e->f_out % 4 == 0 && e->f_out <= 512 && a->post.f_out % 4 == 0 && e->out_ptr != nullptr && e->out_epos != nullptr &&
            a->edge_bias_partial != nullptr && e->grad_bias != nullptr;
 }
@@ -391,9 +338,8 @@ static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_r
     static const bool on = [] { const char* e = getenv("I3D_WGRAD_MULTI"); return e == nullptr || e[0] != '0'; }();
     const I3dEdgeFcArgs* e = &a->edge;
     const I3dGroupedFcArgs* g = &a->post;
-    // (bf16 matmul mode: the panel kernel's bf16 form; I3D_WGRAD_MULTI_BF16=0: the per-product launches of round 2 there)
-    static const bool bf16_on = [] { const char* e = getenv("I3D_WGRAD_MULTI_BF16"); return e == nullptr || e[0] != '0'; }();
-    if (!on || a->n_post_extra != 0 || e->q == nullptr || e->q_rows <= 0 || (i3d_get_matmul_precision() != 0 && !bf16_on)) return 0;
+    // (bf16 matmul mode: the panel kernel's bf16 form)
+    if (!on || a->n_post_extra != 0 || e->q == nullptr || e->q_rows <= 0) return 0;
     const int Fh = e->f_h, Fo = e->f_out, N = e->num_nodes, E = e->num_edges, A = g->agg_width;
     const bool merged = merge_h_ok(a) && a->DL != nullptr;
     const int WL = 2 * Fo + g->f_out;
@@ -475,7 +421,7 @@ static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_r
     if (dry_run) return 1;                             // the layer is covered
     if (do_post) TRY(bias_final(&g->tail, N, g->f_out, g->grad_bias, wst));
     for (int i = a->n_pre_extra - 1; i >= 0 && do_pre; --i)
-        TRY(bias_final_fc(&a->pre[i], wst, (a->fused_bn && a->msg_bf16 && i == a->n_pre_extra - 1) ? 1 : 0));
+        TRY(bias_final_fc(&a->pre[i], wst));
     if (do_pre) {
         if (edge_bwd_fused_ok(a) && edge_bias_on_chain(a)) {
             // (taken on the caller's stream at the end of the layer's backward: see there)
@@ -632,13 +578,7 @@ extern "C" int i3d_pna_layer_fwd(const I3dPnaLayerArgs* a, void* stream) {
     return I3D_OK;
 }
 
-// I3D_WGRAD_FORKS=2: the later pretrans blocks' and the edge block's weight gradients behind one fork (after dP exists)
-// instead of two; measured: three forks per layer -1 % step time, +7 us of host time per layer (the host has the slack)
-// Round 2: with ONE join per model backward (model.hip) the side stream runs behind anyway; two forks measured 2.477 ms
-// against 2.493 ms with three (tools/ab.sh, 3 interleaved runs) - the third fork only costs the host its two event calls.
-// Default: 2 forks; I3D_WGRAD_FORKS=3 restores three.
-static const bool THREE_FORKS = [] { const char* e = getenv("I3D_WGRAD_FORKS"); return e != nullptr && e[0] == '3'; }();
-
+// Two forks per layer (three measured 2.493 against 2.477 ms: the third only costs the host its two event calls).
 extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     I3D_CHECK_ARG(a != nullptr && a->n_pre_extra >= 0 && a->n_pre_extra <= I3D_MAX_EXTRA_FC && a->n_post_extra >= 0 &&
                       a->n_post_extra <= I3D_MAX_EXTRA_FC, "bad arguments");
@@ -666,22 +606,11 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
         const I3dGroupedFcArgs* g = &a->post;
         const int WLb = 2 * a->edge.f_out + g->f_out;
         float* dlin = a->DL + 2 * a->edge.f_out;
-        const bool al = ((((uintptr_t)g->grad_y | (uintptr_t)g->xact | (uintptr_t)dlin | (uintptr_t)g->WD | (uintptr_t)g->grad_agg) & 15) == 0) &&
-                        WLb % 4 == 0 && g->agg_width % 4 == 0;
-        if (al && g->tail.act == I3D_ACT_NONE && bnbwd_ok(&g->tail, g->f_out, g->grad_bias, false)) {
-            // sums, then dL/dagg = dlin W_D with dlin formed in the grouped product's prologue and stored into DL's last columns
-            I3dBnBwdVectors v;
-            TRY(bnbwd_sums(&g->tail, g->num_nodes, g->f_out, g->grad_y, g->xact, g->grad_gamma, g->grad_beta, &v, stream));
-            TRY(i3d_gemm_f32_bnbwd(0, g->m_padded, g->agg_width, g->f_out, g->grad_y, g->xact, g->f_out, g->num_nodes, &v, dlin, WLb,
-                                   g->grad_bias, g->WD, g->agg_width, (long)g->f_out * g->agg_width, g->grad_agg, g->agg_width, 0,
-                                   g->deg_rows, g->deg_tile_group, stream));
-        } else {
         TRY(i3d_bn_bwd_strided(g->grad_y, g->xact, g->pre_keep, g->num_nodes, g->f_out, g->tail.act, g->tail.post_act, g->tail.mean,
                                g->tail.invstd, g->tail.gamma, g->tail.beta, g->grad_gamma, g->grad_beta, dlin, WLb, g->grad_bias,
                                g->tail.workspace, g->tail.bias_partial, stream));
         TRY(i3d_gemm_f32_grouped(0, g->m_padded, g->agg_width, g->f_out, dlin, WLb, g->num_nodes, g->deg_rows, g->deg_tile_group, g->WD,
                                  g->agg_width, (long)g->f_out * g->agg_width, g->grad_agg, g->agg_width, 0, stream));
-        }
     } else {
         TRY(grouped_fc_bn_bwd_chain(&a->post, stream, inplace ? 1 : 0));
         // separate buffers: the residual's term right here, so that both forms add in the same order (dh_out + dlin W_h) + ...
@@ -713,9 +642,8 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
         const int WLb = 2 * e->f_out + a->post.f_out;
         // round 6: where the one-launch BatchNorm backward takes the shape (bn.hip: bn_bwd_fused_kernel, 16-17 us at batch 512) it
         // writes g and the pair of segmented sums follows (8.5 us) - against reduction 15.5 us + i3d_bn_bwd_edge_sums 17-20 us.
-        // I3D_EDGE_ONE_LAUNCH=0: the round-4 form whatever the shape.
-        static const bool edge_one = [] { const char* v = getenv("I3D_EDGE_ONE_LAUNCH"); return v == nullptr || v[0] != '0'; }();
-        if (edge_one && i3d_bn_bwd_one_launch_supported(e->num_edges, e->f_out)) {
+        // (profiles/r06_ab_edge_onelaunch.txt: 1.951 -> 1.925 ms)
+        if (i3d_bn_bwd_one_launch_supported(e->num_edges, e->f_out)) {
             TRY(i3d_bn_bwd_strided(e->grad_y, e->xact, nullptr, e->num_edges, e->f_out, e->tail.act, I3D_ACT_NONE, e->tail.mean, e->tail.invstd,
                                    e->tail.gamma, e->tail.beta, e->grad_gamma, e->grad_beta, e->grad_pre, e->f_out, nullptr,
                                    e->tail.workspace, nullptr, stream));
@@ -742,13 +670,6 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
         const int took = pna_layer_wgrad_multi(a, wst, false, a->wgrad_split ? 2 : 0);
         if (took < 0) return took;
         I3D_CHECK_ARG(took == 1, "weight-gradient launch refused a layer it had accepted");
-    } else if (THREE_FORKS) {
-        wst = fork_wgrad(x, stream);       // the later pretrans blocks' and everything behind dQ: they need grad_pre only
-        for (int i = a->n_pre_extra - 1; i >= 0; --i) TRY(fc_bn_bwd_wgrad(&a->pre[i], wst, a->fused_bn ? a->aff[i] : nullptr));
-        TRY(edge_fc_bn_bwd_wgrad_q(&a->edge, wst));
-        TRY(edge_fc_bn_bwd_sums(&a->edge, stream));
-        wst = fork_wgrad(x, stream);
-        TRY(edge_fc_bn_bwd_wgrad_p(&a->edge, wst));
     } else {
         TRY(edge_fc_bn_bwd_sums(&a->edge, stream));
         wst = fork_wgrad(x, stream);

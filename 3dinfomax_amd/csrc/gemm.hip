@@ -69,25 +69,6 @@ struct GemmArgs {
     int ldcin;              // be a column block of a wider matrix (the merged [P | lin_h] product of a PNA layer); null: C itself
     int c_bf16;             // FUSE & 2: C is stored as bf16 (row r at (bf16*)C + r * ldc; rounded RNE where it is stored, the
                             // statistics are taken from the fp32 values): the bf16 mode's storage form of the messages
-    // FUSE & 4 - BatchNorm BACKWARD prologue (round 5): A is the gradient dy reaching a BatchNorm output and the operand the
-    // product needs is the gradient at the Linear in front of it,
-    //     dz[m][k] = (gamma invstd)[k] (dy[m][k] - k1[k] - xhat[m][k] k2[k]) act'(x[m][k]),  xhat = (x - mean) invstd,
-    // k1 = sum_dy / n, k2 = sum_dy_xhat / n (bn.hip: bn_bwd_apply_kernel's expression, the same bits).  It is formed while the
-    // tile is staged (x read with A's offsets: same shape and row pitch) and stored to DZ by the workgroups of the first column
-    // tile - the weight gradients read it later -: the apply pass over [rows, K] and its launch are gone.
-    const float* X;         // BatchNorm input (the activation the statistics were taken of), row pitch lda
-    unsigned x_bytes;
-    const float* bw_mean;   // [K] each
-    const float* bw_invstd;
-    const float* bw_gamma;
-    const float* bw_sum_dy;
-    const float* bw_sum_dy_xhat;
-    const float* bw_inv_n_ptr;   // 1 / rows on the device (synchronised BatchNorm: rows of all ranks) or null: bw_inv_n
-    float bw_inv_n;
-    int bw_act;             // activation in front of the BatchNorm: none / ReLU / LeakyReLU (its derivative from x)
-    float* DZ;              // [rows, K] out, row pitch lddz
-    int lddz;
-    float* bw_zero;         // [K] or null: zero-filled (the bias gradient in front of a BatchNorm without activation is exactly zero)
     // batched products (gemm_f32_kernel only; i3d_gemm_f32_batched): blockIdx.z = batch * z_splits + K-slice, batch b works on
     // A + b a_batch, B + b b_batch, C + b c_batch (floats) - the diagonal blocks of a block-diagonal product in ONE launch
     int n_batch, z_splits;  // n_batch <= 1: plain product
@@ -240,45 +221,6 @@ struct TileStage {
         }
     }
 
-    // store for the fused BatchNorm-BACKWARD prologue (GemmArgs: FUSE & 4): vec = LDS copy of [5][KP] mean | invstd | gamma invstd |
-    // k1 | k2 (zeros beyond K); rdy / rx: the gradient and the BatchNorm input of the same slots; the data gradient goes to the
-    // LDS image and - write: workgroups of column tile 0 - to dz (row = the slot's physical row)
-    __device__ __forceinline__ void store_bnbwd(const Regs& rdy, const Regs& rx, float* __restrict__ T, const float* vec, int KP, int k0,
-                                                int act, float* __restrict__ dz, int lddz, int K, bool write) const {
-        static_assert((IM || IH) && KC, "BatchNorm-backward prologue: idx-major image of a k-contiguous operand");
-#pragma unroll
-        for (int it = 0; it < PER_THREAD; ++it) {
-            int s = threadIdx.x + it * NT;
-            if (s < SLOTS) {
-                const int idx = s / KQ, k = (s % KQ) * 4;
-                const int kg = min(k0 + k, KP - 4);
-                const float4 mu = *reinterpret_cast<const float4*>(vec + kg);
-                const float4 is = *reinterpret_cast<const float4*>(vec + KP + kg);
-                const float4 gi = *reinterpret_cast<const float4*>(vec + 2 * KP + kg);
-                const float4 k1 = *reinterpret_cast<const float4*>(vec + 3 * KP + kg);
-                const float4 k2 = *reinterpret_cast<const float4*>(vec + 4 * KP + kg);
-                const float4 d = rdy.v[it], x = rx.v[it];
-                float4 r;
-                {   const float xh = (x.x - mu.x) * is.x; r.x = gi.x * (d.x - k1.x - xh * k2.x); }
-                {   const float xh = (x.y - mu.y) * is.y; r.y = gi.y * (d.y - k1.y - xh * k2.y); }
-                {   const float xh = (x.z - mu.z) * is.z; r.z = gi.z * (d.z - k1.z - xh * k2.z); }
-                {   const float xh = (x.w - mu.w) * is.w; r.w = gi.w * (d.w - k1.w - xh * k2.w); }
-                if (act != I3D_ACT_NONE) {
-                    r.x *= act_grad_c<false>(x.x, act); r.y *= act_grad_c<false>(x.y, act);
-                    r.z *= act_grad_c<false>(x.z, act); r.w *= act_grad_c<false>(x.w, act);
-                }
-                if (write && ok[it] && k0 + k < K)       // (K % 4 == 0: a valid first element is a valid float4)
-                    *reinterpret_cast<float4*>(dz + (long)rowi[it] * lddz + k0 + k) = r;
-                if constexpr (IH != 0) {
-                    put_bf16x4(T, idx, k, r.x, r.y, r.z, r.w);
-                    continue;
-                }
-                *reinterpret_cast<float2*>(&T[idx * LDK + k]) = make_float2(r.x, r.y);
-                *reinterpret_cast<float2*>(&T[idx * LDK + k + 2]) = make_float2(r.z, r.w);
-            }
-        }
-    }
-
     __device__ __forceinline__ void store(const Regs& r, float* __restrict__ T) const {
 #pragma unroll
         for (int it = 0; it < PER_THREAD; ++it) {
@@ -344,8 +286,6 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz) {
 // FUSE (forward layout, idx-major image, 64-row tiles only): bit 0 = BatchNorm-apply prologue on A (g.a_aff), bit 1 =
 // activation + per-tile column statistics of the stored values (g.epi_act, g.stats).  K <= FUSE_MAX_K for bit 0.
 constexpr int FUSE_MAX_K = 1024;
-// bit 2 (value 4; any operand layout with a k-contiguous A): BatchNorm-backward prologue on A (GemmArgs::X ...), K <= BNBWD_MAX_K
-constexpr int BNBWD_MAX_K = 512;
 
 // BF16 (i3d_set_matmul_precision(1)): the operands are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) when a
 // lane reads its MFMA fragments from the fp32 LDS image and multiplied on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16 /
@@ -391,7 +331,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     constexpr int CT_PITCH = BN + 1;
     constexpr int EPI_FLOATS = (FUSE & 2) ? BM * CT_PITCH + 2 * 4 * BN + BM : 0;
     __shared__ __attribute__((aligned(16))) float smem[OPER_FLOATS > EPI_FLOATS ? OPER_FLOATS : EPI_FLOATS];
-    __shared__ __attribute__((aligned(16))) float affL[(FUSE & 1) ? 3 * FUSE_MAX_K : ((FUSE & 4) ? 5 * BNBWD_MAX_K : 4)];
+    __shared__ __attribute__((aligned(16))) float affL[(FUSE & 1) ? 3 * FUSE_MAX_K : 4];
     float* const As = smem;
     float* const Bs = smem + 2 * StageA::LDS_FLOATS;
     static_assert(FUSE == 0 || ((A_IM || A_IH) && BM == 64), "fused variants: idx-major A image, 64-row tiles");
@@ -412,22 +352,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     StageB sb;
     typename StageA::Regs ra_[PF];
     typename StageB::Regs rb_[PF];
-    typename StageA::Regs rx_[(FUSE & 4) ? PF : 1];       // BatchNorm-backward prologue: the BatchNorm input of the same slots
     // descriptors are built from kernel arguments / blockIdx only (wave-uniform: no waterfall loops, guide T20)
     const float* Bp = g.B;
     if (g.tile_group != nullptr) Bp += (long)g.tile_group[bx] * g.b_group_stride;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bp), 0, g.b_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rxd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((FUSE & 4) ? g.X : g.A), 0,
-                                                                          (FUSE & 4) ? g.x_bytes : g.a_bytes, 0x00020000);
-    const bool dz_write = (FUSE & 4) != 0 && by == 0;
     sa.prepare(g.lda, m0, g.M, g.m_rows);
     sb.prepare(g.ldb, n0, g.N, nullptr, g.b_split, g.b_delta);
     const int nk = (k_end - k_begin + BK - 1) / BK;
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         sa.template load<VEC, ROWS>(ra_[u], ra, g.a_bytes, g.lda, g.M, k_begin + u * BK, k_begin, k_end, kidx);
-        if constexpr ((FUSE & 4) != 0) sa.template load<VEC, ROWS>(rx_[u], rxd, g.x_bytes, g.lda, g.M, k_begin + u * BK, k_begin, k_end, kidx);
         sb.template load<VEC, ROWS>(rb_[u], rb, g.b_bytes, g.ldb, g.N, k_begin + u * BK, k_begin, k_end, kidx, g.b_split, g.b_delta);
     }
     const int KP = (g.K + 3) & ~3;
@@ -438,20 +373,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
         }
         __syncthreads();
         sa.store_aff(ra_[0], As, affL, KP, k_begin);
-    } else if constexpr ((FUSE & 4) != 0) {   // per-k mean | invstd | gamma invstd | k1 | k2 of the BatchNorm behind, zero-padded
-        const float inv_n = g.bw_inv_n_ptr != nullptr ? g.bw_inv_n_ptr[0] : g.bw_inv_n;
-        for (int k = threadIdx.x; k < KP; k += S::NT) {
-            const bool in = k < g.K;
-            const float is = in ? g.bw_invstd[k] : 0.f;
-            affL[k] = in ? g.bw_mean[k] : 0.f;
-            affL[KP + k] = is;
-            affL[2 * KP + k] = in ? g.bw_gamma[k] * is : 0.f;
-            affL[3 * KP + k] = in ? g.bw_sum_dy[k] * inv_n : 0.f;
-            affL[4 * KP + k] = in ? g.bw_sum_dy_xhat[k] * inv_n : 0.f;
-            if (g.bw_zero != nullptr && in && bx == 0 && by == 0) g.bw_zero[k] = 0.f;
-        }
-        __syncthreads();
-        sa.store_bnbwd(ra_[0], rx_[0], As, affL, KP, k_begin, g.bw_act, g.DZ, g.lddz, g.K, dz_write);
     } else {
         sa.store(ra_[0], As);
     }
@@ -465,8 +386,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
             const int t = kt + u;
             const int cur = (PF % 2 == 0) ? (u & 1) : (t & 1);
             sa.template load<VEC, ROWS>(ra_[u], ra, g.a_bytes, g.lda, g.M, k_begin + (t + PF) * BK, k_begin, k_end, kidx);
-            if constexpr ((FUSE & 4) != 0)
-                sa.template load<VEC, ROWS>(rx_[u], rxd, g.x_bytes, g.lda, g.M, k_begin + (t + PF) * BK, k_begin, k_end, kidx);
             sb.template load<VEC, ROWS>(rb_[u], rb, g.b_bytes, g.ldb, g.N, k_begin + (t + PF) * BK, k_begin, k_end, kidx, g.b_split,
                                         g.b_delta);
             if (t < nk) {
@@ -606,9 +525,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
             }
             if constexpr ((FUSE & 1) != 0)
                 sa.store_aff(ra_[(u + 1) % PF], As + (cur ^ 1) * StageA::LDS_FLOATS, affL, KP, k_begin + (t + 1) * BK);
-            else if constexpr ((FUSE & 4) != 0)
-                sa.store_bnbwd(ra_[(u + 1) % PF], rx_[(u + 1) % PF], As + (cur ^ 1) * StageA::LDS_FLOATS, affL, KP,
-                               k_begin + (t + 1) * BK, g.bw_act, g.DZ, g.lddz, g.K, dz_write && t + 1 < nk);
             else
                 sa.store(ra_[(u + 1) % PF], As + (cur ^ 1) * StageA::LDS_FLOATS);     // tile t+1 (zeros past the end)
             sb.store(rb_[(u + 1) % PF], Bs + (cur ^ 1) * StageB::LDS_FLOATS);
@@ -946,11 +862,8 @@ static bool narrow_pays(int N, long tiles64) {
     return tiles64 < 1100 && (long)cdiv(N, 64) * 64 * 10 > (long)cdiv(N, 32) * 32 * 11;
 }
 // the fused (BatchNorm prologue / statistics epilogue) forward GEMM at K < 400 keeps 64x64 tiles: measured 2.464 ms per
-// step with the narrow tiling against 2.426 ms without (tools/ab.sh, 4 interleaved runs); I3D_FUSED_NARROW=1 selects it
-static bool fuse_narrow_short_k() {
-    static const bool on = [] { const char* e = getenv("I3D_FUSED_NARROW"); return e != nullptr && e[0] == '1'; }();
-    return on;
-}
+// step with the narrow tiling against 2.426 ms without (tools/ab.sh, 4 interleaved runs) (left off)
+static bool fuse_narrow_short_k() { return false; }
 
 // process-level: 0 = fp32 MFMA (exact fp32 products), 1 = bf16 MFMA on bf16-rounded operands (i3d_set_matmul_precision)
 static int g_matmul_bf16 = 0;
@@ -1042,10 +955,9 @@ static const int CFG_BM[N_CFG] = {Cfg0::BM, Cfg1::BM, Cfg2::BM, Cfg3::BM, Cfg4::
 static const int CFG_BN[N_CFG] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN, Cfg9::BN, Cfg10::BN, Cfg11::BN, Cfg12::BN, Cfg13::BN, Cfg14::BN, Cfg15::BN, Cfg16::BN};
 static const int CFG_BK[N_CFG] = {Cfg0::BK, Cfg1::BK, Cfg2::BK, Cfg3::BK, Cfg4::BK, Cfg5::BK, Cfg6::BK, Cfg7::BK, Cfg8::BK, Cfg9::BK, Cfg10::BK, Cfg11::BK, Cfg12::BK, Cfg13::BK, Cfg14::BK, Cfg15::BK, Cfg16::BK};
 
-// K-tile of the bf16-image configurations (I3D_BF16_BK = 16 | 32 | 64; default 32)
+// K-tile of the bf16-image configurations (32: measured against 16 and 64 in round 3)
 static int bf16_bk() {
-    static const int v = [] { const char* e = getenv("I3D_BF16_BK"); const int x = e ? atoi(e) : 32; return (x == 16 || x == 64) ? x : 32; }();
-    return v;
+    return 32;
 }
 
 // the (A idx-contiguous, B k-contiguous) layout is computed as layout 2 would need B transposed: it only exists for
@@ -1071,7 +983,6 @@ gemm_f32_fused_kernel(GemmArgs g) {
 // -> 88, no spill; the two-wave 64x32 shape would spill).  [E, 200] x [200, 200] is 1040 tiles: at four workgroups per CU the
 // chip holds 1024 and the last 16 run as a second round - the statistics variant of that GEMM 35.4 -> 30.7 us, the fused
 // (prologue + statistics) one 40.2 -> 34.0 us back to back (tools/fused_gemm_bench.py), step 2.163 -> 2.144 ms.
-// I3D_FUSED_OCC5=0: off.
 template <class S, int FUSE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5)))
 gemm_f32_fused_o5_kernel(GemmArgs g) {
@@ -1079,36 +990,6 @@ gemm_f32_fused_o5_kernel(GemmArgs g) {
     int bx, by, bz;
     xcd_tile(bx, by, bz);
     gemm_body<S, true, true, true, false, FUSE, false>(g, bx, by, 0, g.K, g.C, nullptr, true);
-}
-
-// data-gradient layouts (A k-contiguous: the gradient at a BatchNorm output; B stored [K, N] or [N, K]) with the BatchNorm-backward
-// prologue (FUSE 4)
-template <class S, bool B_KC, int BF16>
-__global__ void __launch_bounds__(256)
-gemm_f32_bnbwd_kernel(GemmArgs g) {
-    I3D_CHAIN_PRIO();
-    int bx, by, bz;
-    xcd_tile(bx, by, bz);
-    gemm_body<S, true, true, B_KC, false, 4, BF16>(g, bx, by, 0, g.K, g.C, nullptr, true);
-}
-
-template <class S>
-static void launch_bnbwd(const GemmArgs& g, bool b_kc, hipStream_t s) {
-    dim3 grid(cdiv(g.M, S::BM), cdiv(g.N, S::BN), 1), block(S::NT);
-    if (g_matmul_bf16) {
-        if (b_kc) hipLaunchKernelGGL((gemm_f32_bnbwd_kernel<S, true, true>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm_f32_bnbwd_kernel<S, false, true>), grid, block, 0, s, g);
-    } else {
-        if constexpr (split_shape<S>()) {
-            if (g_fp32_split) {
-                if (b_kc) hipLaunchKernelGGL((gemm_f32_bnbwd_kernel<S, true, 2>), grid, block, 0, s, g);
-                else hipLaunchKernelGGL((gemm_f32_bnbwd_kernel<S, false, 2>), grid, block, 0, s, g);
-                return;
-            }
-        }
-        if (b_kc) hipLaunchKernelGGL((gemm_f32_bnbwd_kernel<S, true, false>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm_f32_bnbwd_kernel<S, false, false>), grid, block, 0, s, g);
-    }
 }
 
 template <class S>
@@ -1132,7 +1013,7 @@ static void launch_fused(const GemmArgs& g, int fuse, hipStream_t s) {
             return;
         }
     }
-    static const bool occ5 = [] { const char* e = getenv("I3D_FUSED_OCC5"); return e == nullptr || e[0] != '0'; }();
+    constexpr bool occ5 = true;
     if constexpr (S::WAVES_N == 2 && S::BK == 16) {
         if (occ5) {
             switch (fuse) {
@@ -1261,7 +1142,7 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float*
     // K = 200 9.0 -> 5.3 us,
     // break-even at ~1000 tiles); weight-gradient layouts only while K is short (long K: slices through the scratch, above)
     const long tiles32 = (long)cdiv(M, 32) * cdiv(N, 32) * nb;
-    static const bool small_tiles = [] { const char* e = getenv("I3D_SMALL_TILES"); return e == nullptr || e[0] != '0'; }();
+    constexpr bool small_tiles = true;
     if (small_tiles && ex.tile_group == nullptr && N > 32 && tiles32 <= 1024 && (!trans_a || K < 2048)) cfg = 8;
     if (g_matmul_bf16 && vec && (cfg == 9 || cfg == 11) && bf16_bk() != 16)      // bf16 LDS image: longer K-tiles
         cfg = (cfg == 9 ? 13 : 14) + (bf16_bk() == 64 ? 2 : 0);
@@ -1646,58 +1527,6 @@ extern "C" int i3d_gemm_f32_fused_src(int M, int N, int K, const float* A, int l
         else launch_fused<Cfg15>(g, fuse, s);
     } else if (narrow) launch_fused<Cfg11>(g, fuse, s);
     else launch_fused<Cfg9>(g, fuse, s);
-    I3D_CHECK_LAUNCH();
-    return I3D_OK;
-}
-
-// C[M,N] (+)= dz op(B) with dz = the BatchNorm-backward data gradient of (dY, X) formed while the A tiles are staged (GemmArgs:
-// FUSE & 4) and stored to DZ on the way.  trans_b = 0: B stored [K, N] (a Linear's data gradient dX = dZ W);  1: B stored [N, K].
-// Grouped form as i3d_gemm_f32_grouped (m_rows padded to 64 per group with -1, M = padded count; every physical row once).
-extern "C" int i3d_gemm_f32_bnbwd_supported(int K) { return (K > 0 && K % 4 == 0 && K <= BNBWD_MAX_K && (!g_matmul_bf16 || bf16_bk() == 32)) ? 1 : 0; }
-
-extern "C" int i3d_gemm_f32_bnbwd(int trans_b, int M, int N, int K, const float* dY, const float* X, int ld, long a_rows_total,
-                                  const I3dBnBwdVectors* v, float* DZ, int lddz, float* zero_out, const float* B, int ldb,
-                                  long b_group_stride, float* C, int ldc, int accumulate, const int* m_rows, const int* tile_group,
-                                  void* stream) {
-    I3D_CHECK_ARG(M > 0 && N > 0 && v != nullptr && dY != nullptr && X != nullptr && DZ != nullptr && B != nullptr && C != nullptr, "bad arguments");
-    I3D_CHECK_ARG(i3d_gemm_f32_bnbwd_supported(K), "BatchNorm-backward prologue: K a multiple of 4, <= 512 (bf16 mode: K-tile 32)");
-    I3D_CHECK_ARG(ld >= K && lddz >= K && ldc >= N && ldb >= (trans_b ? K : N), "leading dimension too small");
-    I3D_CHECK_ARG((m_rows == nullptr) == (tile_group == nullptr), "grouped GEMM needs m_rows and tile_group");
-    I3D_CHECK_ARG(m_rows == nullptr || M % 64 == 0, "grouped GEMM needs 64-padded m_rows");
-    I3D_CHECK_ARG(relu_class(v->act), "activation in front of the BatchNorm: none, ReLU or LeakyReLU");
-    const bool al = ((((uintptr_t)dY | (uintptr_t)X | (uintptr_t)B | (uintptr_t)C | (uintptr_t)DZ) & 15) == 0) && ld % 4 == 0 &&
-                    ldb % 4 == 0 && ldc % 4 == 0 && lddz % 4 == 0 && N % 4 == 0 && b_group_stride % 4 == 0;
-    I3D_CHECK_ARG(al, "needs 16-byte aligned operands and N, leading dimensions multiples of 4");
-    GemmArgs g = {};
-    g.A = dY; g.B = B; g.C = C; g.bias = nullptr;
-    g.M = M; g.N = N; g.K = K;
-    g.lda = ld; g.ldb = ldb; g.ldc = ldc;
-    g.accumulate = accumulate ? 1 : 0;
-    g.k_per_split = K; g.atomic_out = 0; g.c_vec = 1;
-    g.m_rows = m_rows; g.k_rows = nullptr; g.tile_group = tile_group; g.b_group_stride = b_group_stride;
-    g.b_split = g.c_split = 0x7fffffff; g.b_delta = g.c_delta = 0;
-    g.epi_act = I3D_ACT_NONE;
-    Extra ex;
-    ex.m_rows = m_rows; ex.a_rows_total = a_rows_total;
-    int rc = fill_views(g, 0, trans_b, M, N, K, ld, ldb, ex);
-    if (rc != I3D_OK) return rc;
-    if (tile_group != nullptr) {       // B of a tile: the group's block (the extent covers the largest group index the caller uses: per block)
-        const long bb = ((long)((trans_b ? N : K) - 1) * ldb + (trans_b ? K : N)) * 4;
-        g.b_bytes = (unsigned)bb;
-    }
-    g.X = X; g.x_bytes = g.a_bytes;
-    g.bw_mean = v->mean; g.bw_invstd = v->invstd; g.bw_gamma = v->gamma; g.bw_sum_dy = v->sum_dy; g.bw_sum_dy_xhat = v->sum_dy_xhat;
-    g.bw_inv_n_ptr = v->inv_n_ptr; g.bw_inv_n = v->inv_n; g.bw_act = v->act;
-    g.DZ = DZ; g.lddz = lddz; g.bw_zero = zero_out;
-    hipStream_t s = (hipStream_t)stream;
-    // tile choice as gemm_impl makes it for these layouts: 64x64 with the idx-major image, 64x32 where N = 200 pads badly and
-    // the launch has few tiles; grouped: 64x64 (the group padding is 64 rows)
-    const bool narrow = tile_group == nullptr && narrow_pays(N, (long)cdiv(M, 64) * cdiv(N, 64));
-    if (g_matmul_bf16) {
-        if (narrow) launch_bnbwd<Cfg14>(g, trans_b != 0, s);
-        else launch_bnbwd<Cfg13>(g, trans_b != 0, s);
-    } else if (narrow) launch_bnbwd<Cfg11>(g, trans_b != 0, s);
-    else launch_bnbwd<Cfg9>(g, trans_b != 0, s);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }

@@ -72,7 +72,7 @@ struct PnaCtx {
     int gh_cur = 0;                 // which of the two dL/dh buffers holds the gradient after the layers done so far (backward)
 };
 
-// I3D_DEFER_BIAS=1: the bias gradients are finalised from row-chunk partials on the weight-gradient stream instead of
+// (measured and left off: the bias gradients are finalised from row-chunk partials on the weight-gradient stream instead of
 // inside the data-gradient pass (I3dBnTail.bias_partial).  Off by default: measured on one box (tools/ab.sh, 4 interleaved
 // runs of 300 steps) 2.816 ms deferred against 2.787 ms in-launch - it takes ~10 us per BatchNorm off the main stream's
 // chain but adds three small launches per layer to the side stream, whose join is what the next layer waits for: at batch
@@ -91,13 +91,11 @@ int encoder_multihot(const PnaCtx& c, float* hot_atoms, float* hot_bonds, void* 
 }
 
 bool hoist_weights() {
-    static const bool on = [] { const char* e = getenv("I3D_HOIST_WEIGHTS"); return e == nullptr || e[0] != '0'; }();
-    return on;
+    return true;
 }
 
 bool defer_bias() {
-    static const bool on = [] { const char* e = getenv("I3D_DEFER_BIAS"); return e != nullptr && e[0] == '1'; }();
-    return on;
+    return false;
 }
 
 // I3D_WGRAD_JOIN=layer: the backward pass of every layer waits for its weight gradients (round-1 behaviour).  Default
@@ -105,19 +103,16 @@ bool defer_bias() {
 // of a layer (~214 us of GEMMs per layer behind the first fork against ~150 us left on the chain), a join per layer
 // makes the chain of the NEXT layer wait for it.  Costs scratch: what that stream reads or writes is kept per layer.
 bool join_per_layer() {
-    static const bool on = [] { const char* e = getenv("I3D_WGRAD_JOIN"); return e != nullptr && e[0] == 'l'; }();
-    return on;
+    return false;      // (one join per model backward: per-layer joins measured slower, docs/history)
 }
 
 // The first layer's weight gradients (the last ones of a backward pass, and what the step waits for at its very end) as two
 // launches, the posttrans products early, next to that layer's chain: only the pretrans / bond-table products are left when the
 // chain ends.  Before the chain's kernels had wave priority this lost (2.289 against 2.253 ms: the early launch took the CUs from
 // the chain it was meant to hide behind); with it: 2.141 against 2.152 ms (tools/ab.sh, 5 interleaved runs).  Every layer split
-// the same way (I3D_WGRAD_SPLIT_LAST=all) loses 40 us: one more launch + reduction per layer for work that was hidden anyway.
-// I3D_WGRAD_SPLIT_LAST=0: one launch per layer everywhere.
+// the same way (every layer) loses 40 us: one more launch + reduction per layer for work that was hidden anyway.
 int split_wgrad() {     // 0: no layer, 1: the first layer (last of the backward pass), 2: every layer
-    static const int v = [] { const char* e = getenv("I3D_WGRAD_SPLIT_LAST"); return e == nullptr ? 1 : (e[0] == '1' ? 1 : (e[0] == 'a' ? 2 : 0)); }();
-    return v;
+    return 1;
 }
 
 // bf16 matmul mode: a layer's messages ([E, F], the last pretrans block's activation) stored as bf16 once they are large enough to
@@ -133,8 +128,7 @@ bool msg_bf16_storage(const I3dPnaModel& m, long E) {
 // I3D_MERGE_H=0: the products that read the node features (edge block's P, posttrans block's h-term, and their data gradients)
 // as separate GEMMs (round 2) instead of one per direction
 bool merge_h() {
-    static const bool on = [] { const char* e = getenv("I3D_MERGE_H"); return e == nullptr || e[0] != '0'; }();
-    return on;
+    return true;
 }
 
 bool simple_act(int act) { return act == I3D_ACT_NONE || act == I3D_ACT_RELU || act == I3D_ACT_LEAKY_RELU; }
@@ -403,7 +397,7 @@ extern "C" int i3d_pna_model_fwd(const I3dPnaModel* m, const I3dPnaBatch* b, flo
     TRY(i3d_edge_codes(b->bond_feat, b->perm, E, m->n_bond_tables, strides, b->v_pad, c->codes, c->onehot, stream));
     // ---- message passing layers.  Q = bond table x W_q^T and W_D = sum_s coef W_s of a layer depend on parameters (and the
     // bond table) only: those of the layers after the first go to the side stream now (idle in the forward pass) and are
-    // awaited before layer 1 - 14 us of small launches per layer off the main chain (I3D_HOIST_WEIGHTS=0: in the layers)
+    // awaited before layer 1 - 14 us of small launches per layer off the main chain
     bool hoisted = false;
     if (L > 1 && hoist_weights()) {
         void* side = nullptr;
@@ -567,7 +561,7 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
             }
             gy = gx;
         }
-        static const bool leaves_aside = [] { const char* e = getenv("I3D_HEAD_LEAVES"); return e == nullptr || e[0] != '0'; }();
+        constexpr bool leaves_aside = true;
         // the leaves go to the weight-gradient stream behind the fork the LAST layer's backward makes anyway (a fork of their own
         // was one more event on the chain's stream: ~7 us); without a side stream for them: here, in line
         leaves_pending = !per_layer_join && leaves_aside && l_hi == L && l_hi > l_lo;
@@ -677,7 +671,7 @@ extern "C" int i3d_pna_model_bwd_part(void* ctx, const I3dPnaModel* grads_from, 
         // the bond tables' product reads the sum the weight-gradient stream has just finished: on THAT stream, in front of the
         // join (behind it, it was one more cross-stream hop - ~10 us - between the last panel reduction and Adam)
         void* bst = stream;
-        static const bool bond_aside = [] { const char* e = getenv("I3D_BOND_TABLE_ASIDE"); return e == nullptr || e[0] != '0'; }();
+        constexpr bool bond_aside = true;
         if (bond_aside && !per_layer_join && own_ws && c->hot_ready) TRY(i3d_wgrad_stream_peek(stream, &bst));
         if (bst != stream)
             TRY(wgrad(ob, F, b.n_comb, hotb, vb, grad_table, F, m.grad_bond_tables, F, gemm_workspace, side_ws_bytes, bst));

@@ -1108,10 +1108,8 @@ extern "C" int i3d_net3d_edge_bwd(const I3dNet3dEdgeArgs* a, void* stream_) {
         p.inv_rows_dev = inv_rows_dev;
     }
     p.gsum_msg = gsum;
-    // two register budgets of the fused pass (I3D_N3_B2_WAVES=2 | 3 per SIMD: 256 registers without spills / 168 with ~40 spilled)
-    static const int b2_waves = [] { const char* e = getenv("I3D_N3_B2_WAVES"); return e != nullptr && atoi(e) == 3 ? 3 : 2; }();
-    if (b2_waves == 3) N3_DISPATCH_O(n3_bwd_msg_kernel, 3, dim3(pl.bwd_blocks), dim3(TB), stream, p);
-    else N3_DISPATCH_O(n3_bwd_msg_kernel, 2, dim3(pl.bwd_blocks), dim3(TB), stream, p);
+    // (two waves per SIMD: 256 registers without spills; three - 168 registers, ~40 spilled - measured slower)
+    N3_DISPATCH_O(n3_bwd_msg_kernel, 2, dim3(pl.bwd_blocks), dim3(TB), stream, p);
     I3D_CHECK_LAUNCH();
     q.gsum = gsum + 2 * H; q.grad_gamma = a->grad_gamma_in; q.grad_beta = a->grad_beta_in;
     hipLaunchKernelGGL(n3_reduce_msg_kernel, dim3(cdiv((int)per, 32)), dim3(1024), 0, stream, q);

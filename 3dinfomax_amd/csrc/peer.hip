@@ -204,7 +204,8 @@ extern "C" int i3d_peer_open(void* mailbox, const char* handles, int rank, int w
     ctx->dev.world = world; ctx->dev.rank = rank; ctx->dev.seq = 0;
     // I3D_PEER_SEQ0 (tests: the same value on every rank): start the sequence there - a soak run then crosses the wrap of
     // the 32-bit tag after minutes instead of a day
-    if (const char* s0 = getenv("I3D_PEER_SEQ0")) ctx->dev.seq = strtoull(s0, nullptr, 0);
+    if (const char* t = getenv("I3D_TESTING"); t != nullptr && t[0] == '1')
+        if (const char* s0 = getenv("I3D_PEER_SEQ0")) ctx->dev.seq = strtoull(s0, nullptr, 0);
     const char* env = getenv("I3D_PEER_TIMEOUT_S");
     if (env != nullptr && atof(env) > 0) timeout_s = atof(env);
     if (timeout_s <= 0) timeout_s = 30.0;

@@ -263,6 +263,7 @@ class DevicePrefetcher:
             self._old_interval = sys.getswitchinterval()
             sys.setswitchinterval(float(switch_interval))
         self._stop = False
+        self._done = None
         self.thread = threading.Thread(target=self._run, args=(iter(loader),), name='i3d-device-prefetch', daemon=True)
         self.thread.start()
 
@@ -289,12 +290,30 @@ class DevicePrefetcher:
         return self
 
     def __next__(self):
+        if self._done is not None:       # the end (or the helper's exception) is sticky: a second next() must not wait for ever
+            raise self._done
         item = self.q.get()
         if item is self._END:
+            self._done = StopIteration()
             raise StopIteration
         if isinstance(item, BaseException):
+            self._done = item
             raise item
         return item
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):          # a consumer that stopped early without close(): release the helper, restore the switch interval
+        try:
+            if self.thread.is_alive() or self._old_interval is not None:
+                self.close()
+        except Exception:       # noqa: BLE001 - interpreter shutdown
+            pass
 
     def close(self):
         """stops the helper (batches it still holds are dropped) and restores the switch interval"""

@@ -20,6 +20,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import _lib
+
 
 def _is_gloo(group):
     return dist.get_backend(group) == 'gloo'
@@ -159,7 +161,7 @@ def _all_ok(ok, group):
 
 
 # I3D_PEER_SELFTEST=0: skip the pattern exchange at set-up (world > 1 only; ~100 small launches)
-PEER_SELFTEST = os.environ.get('I3D_PEER_SELFTEST', '1') != '0'
+PEER_SELFTEST = True
 
 
 def _peer_selftest(L, state, device, with_side):
@@ -198,14 +200,14 @@ def _peer_selftest(L, state, device, with_side):
                 wrong += int(bad.item())
         torch.cuda.synchronize(device)
         ok = wrong == 0 and all(L.i3d_peer_status(c) == 0 for c in state['peers'])
-        if not ok and os.environ.get('I3D_DEBUG_SELFTEST'):
+        if not ok and _lib.TEST_HOOKS['verbose_selftest']:
             print(f'[rank {rank}] peer self-test: {wrong} wrong values, status {[L.i3d_peer_status(c) for c in state["peers"]]}', flush=True)
     except Exception:      # noqa: BLE001 - a failing exchange must end in the fallback, not in a crash of one rank
-        if os.environ.get('I3D_DEBUG_SELFTEST'):
+        if _lib.TEST_HOOKS['verbose_selftest']:
             import traceback
             traceback.print_exc()
         ok = False
-    if os.environ.get('I3D_TEST_PEER_SELFTEST_FAIL') == str(rank):      # test hook: this rank "saw a wrong value"
+    if _lib.TEST_HOOKS['peer_selftest_fail'] == str(rank):      # test hook: this rank "saw a wrong value"
         ok = False
     return ok
 
@@ -219,7 +221,7 @@ def _peer_context(L, group, device, timeout_s):
     box, handle = ctypes.c_void_p(), ctypes.create_string_buffer(hb)
     with torch.cuda.device(device):
         ok = L.i3d_peer_alloc(ctypes.byref(box), handle) == 0
-        if os.environ.get('I3D_TEST_PEER_FAIL') == str(rank):      # test hook: this rank "cannot" set the exchange up
+        if _lib.TEST_HOOKS['peer_fail'] == str(rank):      # test hook: this rank "cannot" set the exchange up
             ok = False
         msgs = [None] * world
         dist.all_gather_object(msgs, (bool(ok), bytes(handle.raw)), group=group)       # (every rank takes part, failed or not)
@@ -455,7 +457,7 @@ def setup(modules, loss=None, group=None, sync_bn=False, broadcast=True):
 
 
 # I3D_OVERLAP_ALLREDUCE=0: one all-reduce of the whole gradient buffer after the backward pass (round-1 behaviour)
-OVERLAP_ALLREDUCE = os.environ.get('I3D_OVERLAP_ALLREDUCE', '1') != '0'
+OVERLAP_ALLREDUCE = True
 
 
 class GradReducer:
@@ -608,7 +610,7 @@ class GradReducer:
             dist.all_reduce(both, op=dist.ReduceOp.MAX, group=self.group)
             both = both.cpu()
             self._agreed = bool(self.overlap and self.early_spans and torch.equal(both[:3], -both[3:]))
-        if self._agreed is None and os.environ.get('I3D_TEST_FORCE_EARLY_ALLREDUCE') == '1':
+        if self._agreed is None and _lib.TEST_HOOKS['force_early_allreduce']:
             self._agreed = bool(self.overlap and self.early_spans)      # test hook: the split reduction at world 1 (one-GPU box)
         if self._agreed:
             # the same collectives in the same order on every rank: the early slices (now, if the backward pass did not

@@ -18,12 +18,12 @@ from . import layers as _layers
 from .layers import _keeps_pre, _set_workspaces
 
 # I3D_NATIVE_LAYER=0: the layer as four block composites sequenced from Python (pna.PNALayerFn)
-NATIVE_LAYER = os.environ.get('I3D_NATIVE_LAYER', '1') != '0'
+NATIVE_LAYER = True
 # I3D_FUSED_BN=0: round-1 form of the layer (statistics pass + apply pass per block); default: BatchNorm statistics in the
 # producers' epilogues, BatchNorm-apply in the consumers' loads (csrc/fused_bn.hip).  Same arithmetic up to summation order.
-FUSED_BN = os.environ.get('I3D_FUSED_BN', '1') != '0'
+FUSED_BN = True
 # I3D_MERGE_H=0: the products that read the node features as separate GEMMs (csrc/model.hip reads the same switch)
-MERGE_H = os.environ.get('I3D_MERGE_H', '1') != '0'
+MERGE_H = True
 _SIMPLE_ACTS = (None, 'relu', 'leakyrelu')
 KEEP_LAST_ARGS = None
 

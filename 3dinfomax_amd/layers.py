@@ -243,7 +243,7 @@ class _Tail:
 # Composite fast path (csrc/composite.hip): one C call enqueues the whole block.  Eligible: BatchNorm in training mode
 # with local statistics.  I3D_COMPOSITE=0 forces the per-kernel path (identical arithmetic, used by the tests to
 # cross-check).
-COMPOSITE = os.environ.get('I3D_COMPOSITE', '1') != '0'
+COMPOSITE = True
 
 
 def _composite_ok(spec: FCSpec, *tensors):
@@ -690,7 +690,7 @@ class MLP(nn.Module):
         fcs = list(self.fully_connected)
         fc0 = fcs[0]
         gamma, beta = fc0.bn_affine()
-        x = tape.apply(GroupedConcat2FCFn, h, a, fc0.linear.weight, fc0.linear.bias, gamma, beta,
+        x = tape.apply(GroupedConcat2FCFn, h, a, fc0.linear.weight, fc0.hot()[1], gamma, beta,      # hot()[1]: the bias, or the zero buffer of bias=False
                                      residual if len(fcs) == 1 else None, index, coef, fc0.spec())
         for i, fc in enumerate(fcs[1:]):
             x = fc(x, residual if i == len(fcs) - 2 else None)
@@ -700,7 +700,7 @@ class MLP(nn.Module):
         fcs = list(self.fully_connected)
         fc0 = fcs[0]
         gamma, beta = fc0.bn_affine()
-        x = tape.apply(Concat2FCFn, a, c, fc0.linear.weight, fc0.linear.bias, gamma, beta,
+        x = tape.apply(Concat2FCFn, a, c, fc0.linear.weight, fc0.hot()[1], gamma, beta,
                               residual if len(fcs) == 1 else None, fc0.spec())
         for i, fc in enumerate(fcs[1:]):
             x = fc(x, residual if i == len(fcs) - 2 else None)

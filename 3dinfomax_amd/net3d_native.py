@@ -20,13 +20,13 @@ from . import _lib, ops, tape
 from .layer_native import _Arena, _al, _tail
 from .layers import _composite_ok, _keeps_pre, _set_workspaces
 
-NATIVE_NET3D = os.environ.get('I3D_NATIVE_NET3D', '1') != '0'
+NATIVE_NET3D = True
 # bf16 matmul mode: the edge stage's own [E3, H] activations (x_msg, msg) stored as bf16 once they are large enough to be bound
 # by their bytes (QMugs shape, 3.9 M edges: 313 MB per tensor, step 6.71 -> 6.49 ms; at the QM9 shape's 140 k edges they sit in
-# the Infinity Cache and the extra conversion work costs 1 %).  I3D_NET3D_BF16_STORE=0: never; =force: at every size
-BF16_STORE = os.environ.get('I3D_NET3D_BF16_STORE', '1') != '0'
-BF16_STORE_MIN_EDGES = 0 if os.environ.get('I3D_NET3D_BF16_STORE') == 'force' else (1 << 20)
-FUSED_EDGE = os.environ.get('I3D_NET3D_FUSED_EDGE', '1') != '0'      # the edge stage in one lane per edge (csrc/net3d_edge.hip)
+# the Infinity Cache and the extra conversion work costs 1 %).  (the tests set BF16_STORE_MIN_EDGES = 0: at every size)
+BF16_STORE = True
+BF16_STORE_MIN_EDGES = 1 << 20
+FUSED_EDGE = True      # the edge stage in one lane per edge (csrc/net3d_edge.hip)
 _F32 = torch.float32
 
 

@@ -152,9 +152,9 @@ def embedding_sum_bwd(idx, grad_out, dims, row_perm=None):
 
 
 # I3D_MULTIHOT_EMB_BWD=0: embedding-table gradients by LDS-privatised atomics instead of the multi-hot GEMM
-MULTIHOT_EMB_BWD = os.environ.get('I3D_MULTIHOT_EMB_BWD', '1') != '0'
+MULTIHOT_EMB_BWD = True
 # I3D_MULTIHOT_UNALIGNED=0: table widths that are not multiples of 4 (the tower variant's 90 / 70) through the LDS-atomics kernel
-MULTIHOT_UNALIGNED = os.environ.get('I3D_MULTIHOT_UNALIGNED', '1') != '0'
+MULTIHOT_UNALIGNED = True
 
 
 # ---- K4 / K6 ---------------------------------------------------------------------------------------------

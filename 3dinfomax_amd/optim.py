@@ -17,7 +17,7 @@ import struct
 import torch
 
 # I3D_NATIVE_ADAM=0: torch._fused_adam_ (three multi-tensor launches of ~50 workgroups) instead of csrc/adam.hip
-NATIVE_ADAM = os.environ.get('I3D_NATIVE_ADAM', '1') != '0'
+NATIVE_ADAM = True
 
 
 class _NativeTable:

@@ -33,11 +33,11 @@ PNA_SCALERS = {k: v for k, v in ops.SCALER.items()}
 
 
 # I3D_GROUPED_POSTTRANS=0 selects the reference-shaped path ([N,12F] aggregate + K=13F posttrans GEMM)
-GROUPED_POSTTRANS = os.environ.get('I3D_GROUPED_POSTTRANS', '1') != '0'
+GROUPED_POSTTRANS = True
 # I3D_FUSED_LAYER=0 runs a PNA layer as four autograd nodes (edge FC, FC, aggregate, posttrans) instead of one
-FUSED_LAYER = os.environ.get('I3D_FUSED_LAYER', '1') != '0'
+FUSED_LAYER = True
 # I3D_EDGE_TABLE=0 materialises the [E, F] bond embeddings and multiplies them by W_q in every layer (reference shape)
-EDGE_TABLE = os.environ.get('I3D_EDGE_TABLE', '1') != '0'
+EDGE_TABLE = True
 
 
 def _scaler_coef(scaler_code, D, avg):

@@ -356,7 +356,7 @@ class PNAModelFn(torch.autograd.Function):
 
 
 # test hook (tests/test_gpu_dist.py): the split backward pass + early all-reduce at world 1, on the one-GPU box
-_FORCE_EARLY = os.environ.get('I3D_TEST_FORCE_EARLY_ALLREDUCE') == '1'
+_FORCE_EARLY = _lib.TEST_HOOKS['force_early_allreduce']
 
 
 def _world(group):

@@ -22,18 +22,18 @@ from .mol_encoder import AtomEncoder, BondEncoder
 from .pna import _AppendSqDistFn, _codes, _GatherRowsFn, _scaler_coef
 
 # I3D_TOWER_STACK=0: the towers of a layer one after the other (one autograd node per block and tower: the first version)
-TOWER_STACK = os.environ.get('I3D_TOWER_STACK', '1') != '0'
+TOWER_STACK = True
 # I3D_TOWER_PAD=0: the stacked layers at the model's own widths (hidden_dim 90 / edge_hidden_dim 70 of the yml: every kernel of the
 # layer in its unaligned form - 4.8 ms per step at batch 512 against the padded form's)
-PAD_WIDTHS = os.environ.get('I3D_TOWER_PAD', '1') != '0'
+PAD_WIDTHS = True
 # I3D_TOWER_BLOCKS=0: the posttrans products of a stacked layer as ONE dense product on the zero-padded stacked weight instead of
 # `towers` diagonal blocks
-TOWER_BLOCKS = os.environ.get('I3D_TOWER_BLOCKS', '1') != '0'
+TOWER_BLOCKS = True
 # I3D_TOWER_FOLD=0: the aggregation of a stacked layer with all its scaler blocks ([N, 12 F]) instead of the scalers folded into
 # per-degree posttrans weights as in the 2D network (the aggregation writes its identity blocks only, K of the products on it is
 # n_scalers times shorter, the aggregated tensor n_scalers times smaller; with I3D_TOWER_BLOCKS the per-degree weights' diagonal
 # blocks are multiplied, without it one dense grouped product)
-TOWER_FOLD = os.environ.get('I3D_TOWER_FOLD', '1') != '0'
+TOWER_FOLD = True
 
 
 class _RowScaleFn(torch.autograd.Function):
@@ -228,7 +228,8 @@ class PNAOriginal(nn.Module):
             assert h.shape[1] == st.Dp
             # (an eval-mode layer under a tape may still be differentiated: that backward is sequenced by the block path only)
             native = (TOWER_NATIVE and (layer.training or tape.active() is None) and ops.GEMM_WORKSPACE_BYTES > 0
-                      and idx.num_edges > 0)       # (a batch without bonds: the block path handles E = 0)
+                      and idx.num_edges > 0       # (a batch without bonds: the block path handles E = 0)
+                      and (not st.fold or _fold_fits(idx, tw)))      # (> 32 distinct in-degrees: the block path has no such table)
             if native:
                 if tw.graph_norm and snorm_flat is None:
                     snorm_flat = snorm.reshape(-1).contiguous().float()
@@ -517,7 +518,13 @@ def _stacks_for(model):
 
 
 # I3D_TOWER_NATIVE=0: the stacked layer as five block Functions sequenced from Python instead of one C call per direction
-TOWER_NATIVE = os.environ.get('I3D_TOWER_NATIVE', '1') != '0'
+TOWER_NATIVE = True
+
+
+def _fold_fits(idx, tw):
+    """the per-degree tables of I3dTowerLayerArgs hold 32 in-degree groups / 128 (group, scaler) coefficients"""
+    n = len(idx.degree_groups()[2])
+    return n <= 32 and n * len(tw.scalers) <= 128
 
 
 class _TowerLayerFn(torch.autograd.Function):
@@ -546,14 +553,12 @@ class _TowerLayerFn(torch.autograd.Function):
         if st.fold:
             rows, tiles, groups = idx.degree_groups()
             nS = len(tw.scalers)
-            if not (len(groups) <= 32 and len(groups) * nS <= 128):
-                raise NotImplementedError('I3D_TOWER_FOLD: more than 32 distinct in-degrees in one batch')
-            if True:
-                a.n_deg_groups, a.m_padded = len(groups), rows.shape[0]
-                for gi, (deg, start, count) in enumerate(groups):
-                    a.group_start[gi], a.group_count[gi] = start, count
-                    for si, sc in enumerate(tw.scalers):
-                        a.coef[gi * nS + si] = _scaler_coef(sc, deg, float(tw.avg_d))
+            assert _fold_fits(idx, tw), 'the caller (_forward_stacked) sends such a batch through the block path'
+            a.n_deg_groups, a.m_padded = len(groups), rows.shape[0]
+            for gi, (deg, start, count) in enumerate(groups):
+                a.group_start[gi], a.group_count[gi] = start, count
+                for si, sc in enumerate(tw.scalers):
+                    a.coef[gi * nS + si] = _scaler_coef(sc, deg, float(tw.avg_d))
                 a.deg_rows, a.deg_tile_group = rows.data_ptr(), tiles.data_ptr()
         a.h, a.e = h.data_ptr(), (e.data_ptr() if e is not None else None)
         a.snorm = snorm.data_ptr() if snorm is not None else None

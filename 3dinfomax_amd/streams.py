@@ -18,7 +18,7 @@ import threading
 
 import torch
 
-ENABLED = os.environ.get('I3D_OVERLAP', '0') == '1'
+ENABLED = False
 _tls = threading.local()
 
 

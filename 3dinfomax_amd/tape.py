@@ -259,7 +259,7 @@ def _model_backward(ctx, grad, direct=False):
 # goes on with the other model.  EXPERIMENTAL, off: measured on MI355X (tools/step_segments.py, tools/ab.sh) the two
 # Python threads hand the GIL back and forth at every kernel launch and the backward segment gets SLOWER (1.85-2.0 ms
 # against 1.46-1.6 ms); it needs the enqueue loop itself out of Python (a native whole-model composite) to pay off.
-ASYNC_SIDE_BACKWARD = os.environ.get('I3D_ASYNC_SIDE_BACKWARD', '0') == '1'
+ASYNC_SIDE_BACKWARD = False
 
 
 class _Job:
@@ -335,7 +335,7 @@ def register_grad_sink(module, fn, views=None):
 
 
 # I3D_FUSED_MODEL=0: one autograd node per block (or per PNA layer) instead of one per model
-FUSED_MODEL = os.environ.get('I3D_FUSED_MODEL', '1') != '0'
+FUSED_MODEL = True
 
 
 def _param_list(module):

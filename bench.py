@@ -273,6 +273,24 @@ def extra_workloads(amd, ops, dev, depth):
             else:
                 os.environ[k] = v
         del pna, net, optim
+    # ---- the yml's own depth (configs_clean/pre-train_QM9.yml:57 propagation_depth 7; SURVEY 8(d): cfg2 at "L=4 and L=7") on the
+    # headline's batch - when the headline itself is not already that depth
+    if depth != 7:
+        torch.manual_seed(123)
+        pna = amd.PNA(avg_d=1.0, device=dev, **dict(PNA_KW, propagation_depth=7)).to(dev).train()
+        net = amd.Net3D(node_dim=0, edge_dim=1, avg_d=1.0, **NET3D_KW).to(dev).train()
+        loss_fn = amd.NTXent(tau=0.1)
+        optim = adam(list(pna.named_parameters()) + list(net.named_parameters()))
+
+        def step7(i):
+            a, b = g2.local_copy(), g3.local_copy()
+            loss_fn(pna(a), net(b)).backward()
+            optim.step()
+            optim.zero_grad()
+        ms, host = window(step7, 10, 40)
+        out['qm9_shape_depth7'] = dict(ms_per_step=round(ms, 3), molecules_per_s=round(B1 / ms * 1e3, 1), host_enqueue_ms=round(host, 3),
+                                       batch=B1, depth=7, matmul=f'fp32 ({ops.get_fp32_products()} products)')
+        del pna, net, optim
     del g2, g3
     # ---- configs[3] shape
     B3 = 500

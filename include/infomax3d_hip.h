@@ -129,7 +129,12 @@ int i3d_get_matmul_precision(void);
  * the six part products of order <= 2 taken on the bf16 matrix pipe with fp32 accumulation (each part product is exact; what is
  * dropped is <= 3 x 2^-24 |a b|, the size of one fp32 rounding) - the same nn.Linear arithmetic class as
  * /root/reference/models/base_layers.py:101, 2.7x fewer matrix-pipe cycles.  Process-level; I3D_FP32_PRODUCTS=native|split
- * sets it at load. */
+ * sets it at load.  THE LIBRARY DEFAULT IS 1 (split) - every "fp32" result of this library (tests, bench.py's headline) is formed
+ * this way unless 0 is set; the weight-gradient panels (wgrad.hip) and the small-tile / unaligned kernels always use the fp32
+ * pipe.  Non-finite and huge operands: the split is exact for |x| <= 3.39e38 (above it the bf16 rounding of `hi` overflows); an
+ * operand that is +-Inf or beyond that bound gives hi = +-Inf and a NaN remainder, so the outputs that depend on it are NaN where
+ * the fp32 pipe gives +-Inf (or NaN): they are non-finite in exactly the positions where the native product is non-finite, but
+ * isinf() does not tell overflow from invalid any more (tests/test_gpu_ops.py: test_split_products_with_non_finite_operands). */
 int i3d_set_fp32_products(int split);
 int i3d_get_fp32_products(void);
 
@@ -492,32 +497,6 @@ int i3d_pna_pack_h_weights(const float* W_edge, int ldw_edge, int f_out_edge, co
 int i3d_bn_bwd_strided(const float* grad_y, const float* x, const float* pre, int rows, int feat, int act, int post_act,
                        const float* mean, const float* invstd, const float* gamma, const float* beta, float* grad_gamma,
                        float* grad_beta, float* grad_pre, int ld_out, float* grad_bias, void* workspace, float* bias_partial,
-                       void* stream);
-/* ---- BatchNorm backward folded into the data-gradient GEMM (round 5) ------------------------------------------------------
- * replaces the second half of autograd's native_batch_norm_backward for the BatchNorm1d of FCLayer (reference
- * models/base_layers.py:106-108) - the elementwise pass  dz = gamma invstd (dy - mean(dy) - xhat mean(dy xhat)) act'(x)  - as a
- * pass of its own: i3d_bn_bwd_sums runs the reduction half (sums, grad_gamma / grad_beta, synchronised over the ranks when a
- * collective table is set) and hands out the vectors; i3d_gemm_f32_bnbwd forms dz while it stages the A tiles of the product
- * that consumes it (C (+)= dz op(B): trans_b 0 = B stored [K, N], the data gradient of a Linear) and stores it to DZ for the
- * weight gradients.  Same expression and operation order as the pass it replaces: the same bits.  zero_out ([K] or NULL): the
- * bias gradient of a Linear directly in front of a BatchNorm (no activation) is exactly zero. */
-typedef struct {
-    const float* mean;
-    const float* invstd;
-    const float* gamma;
-    const float* sum_dy;      /* [feat] column sums of dy (over all ranks under synchronised BatchNorm) */
-    const float* sum_dy_xhat; /* [feat] */
-    const float* inv_n_ptr;   /* 1 / rows on the device, or NULL: inv_n */
-    float inv_n;
-    int act;                  /* activation in front of the BatchNorm (I3D_ACT_NONE / RELU / LEAKY_RELU) */
-} I3dBnBwdVectors;
-int i3d_bn_bwd_sums(const float* grad_y, const float* x, int rows, int feat, int act, int post_act, const float* mean,
-                    const float* invstd, const float* gamma, const float* beta, float* grad_gamma, float* grad_beta,
-                    void* workspace, I3dBnBwdVectors* out, void* stream);
-int i3d_gemm_f32_bnbwd_supported(int K);
-int i3d_gemm_f32_bnbwd(int trans_b, int M, int N, int K, const float* dY, const float* X, int ld, long a_rows_total,
-                       const I3dBnBwdVectors* v, float* DZ, int lddz, float* zero_out, const float* B, int ldb,
-                       long b_group_stride, float* C, int ldc, int accumulate, const int* m_rows, const int* tile_group,
                        void* stream);
 /* i3d_bn_bwd with the BatchNorm input x stored as bf16 (row r at (bf16*)x + r * feat) */
 int i3d_bn_bwd_x_bf16(const float* grad_y, const void* x, int rows, int feat, int act, int post_act, const float* mean,

@@ -49,12 +49,12 @@ def _worker(rank, port, path, native_sync, WORLD=WORLD):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), I3D_NATIVE_SYNC_BN='1' if native_sync else '0',
                       I3D_SYNC_PROVIDER=native_sync or 'peer', I3D_PEER_TIMEOUT_S='20')
     if native_sync == 'peer_selftest_fails_on_rank_0':      # the exchange is set up but ONE rank reads a wrong value in the pattern exchange
-        os.environ.update(I3D_SYNC_PROVIDER='peer', I3D_TEST_PEER_SELFTEST_FAIL='0')
+        os.environ.update(I3D_SYNC_PROVIDER='peer', I3D_TESTING='1', I3D_TEST_PEER_SELFTEST_FAIL='0')
         import warnings
         warnings.simplefilter('ignore')
         native_sync = 'callbacks'
     if native_sync == 'peer_fails_on_rank_1':       # the exchange cannot be set up on ONE rank: every rank must take the fallback
-        os.environ.update(I3D_SYNC_PROVIDER='peer', I3D_TEST_PEER_FAIL='1')
+        os.environ.update(I3D_SYNC_PROVIDER='peer', I3D_TESTING='1', I3D_TEST_PEER_FAIL='1')
         import warnings
         warnings.simplefilter('ignore')
         native_sync = 'callbacks'
@@ -393,7 +393,7 @@ BOTH_LIVE_TOL = 5e-2      # absolute, on losses between 3.0 and 0.08 (measured 1
 def _both_live_worker(rank, port, path, provider):
     """world 1 under an "nccl" group, the split gradient reduction forced on (I3D_TEST_FORCE_EARLY_ALLREDUCE): 50 optimisation
     steps with the provider's BatchNorm collectives and torch's own communicator both in use"""
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), I3D_SYNC_PROVIDER=provider, I3D_TEST_FORCE_EARLY_ALLREDUCE='1')
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), I3D_SYNC_PROVIDER=provider, I3D_TESTING='1', I3D_TEST_FORCE_EARLY_ALLREDUCE='1')
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     torch.cuda.set_device(0)
@@ -480,7 +480,7 @@ def test_provider_collectives_and_the_split_gradient_reduction_both_live(tmp_pat
 
 def _soak_worker(rank, port, path, world, steps, seq0):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), I3D_SYNC_PROVIDER='peer', I3D_PEER_TIMEOUT_S='30',
-                      I3D_PEER_SEQ0=str(seq0))
+                      I3D_TESTING='1', I3D_PEER_SEQ0=str(seq0))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     dist.init_process_group('gloo', rank=rank, world_size=world)

@@ -82,6 +82,39 @@ def test_split_products_are_fp32_products(M, N, K, tb):
     assert e['bf16'] > 1000 * e['split'], e
 
 
+def test_split_products_with_non_finite_operands():
+    """What include/infomax3d_hip.h states about the split form (the library default) on operands an fp32 product handles and a
+    three-part bf16 split does not: +-Inf and |x| > 3.39e38 (bf16 RNE of `hi` overflows) leave a NaN remainder - the outputs that
+    depend on such an operand are NON-FINITE in exactly the positions where v_mfma_f32_32x32x2_f32 gives a non-finite value (Inf
+    there, NaN here), every other output is untouched; values up to 3e38 split exactly."""
+    M, N, K = 512, 200, 200
+    A, B = rnd(M, K, seed=5), rnd(N, K, seed=6) * K ** -0.5
+    A[7, 13] = float('inf')
+    A[100, 0] = -float('inf')
+    A[300, 199] = 3.4e38            # finite in fp32, beyond the largest bf16
+    A[400, 5] = 3.0e38              # splits exactly
+    B[9, 5] = 0.0                   # 3e38 x 0 stays finite
+    res = {}
+    prev = ops.get_fp32_products()
+    try:
+        for mode in ('native', 'split'):
+            ops.set_fp32_products(mode)
+            res[mode] = ops.gemm(g(A), g(B), trans_b=True).cpu()
+    finally:
+        ops.set_fp32_products(prev)
+    bad_n, bad_s = ~torch.isfinite(res['native']), ~torch.isfinite(res['split'])
+    # rows 7 / 100 / 300 are non-finite in both forms (row 300: 3.4e38 x b overflows or not by b in fp32, always in the split form)
+    assert bad_s[7].all() and bad_s[100].all() and bad_n[7].all() and bad_n[100].all()
+    assert (bad_n <= bad_s).all()                               # non-finite in fp32 => non-finite in the split form
+    rows = torch.ones(M, dtype=torch.bool)
+    rows[[7, 100, 300]] = False
+    assert not bad_s[rows].any()
+    ref = A[rows].double() @ B.double().T
+    keep = torch.isfinite(ref.float())
+    assert rel_err(torch.where(keep, res['split'][rows].double(), ref), ref) < 1e-6
+    assert torch.isfinite(res['split'][400, 9])
+
+
 def test_split_products_in_the_fused_gemm():
     """the same statement for the fused forward GEMM (BatchNorm prologue + statistics epilogue).  (The one-launch weight gradients
     and the small-tile / unaligned kernels keep the fp32 matrix pipe: the six-product form of the panel kernel was measured slower,
@@ -450,6 +483,8 @@ def test_bn_bwd_one_launch_against_the_two_pass_kernels(rows, feat, act, post):
         away &= (xh * gr + br).detach().abs() > 1e-4
     if act in ('relu', 'leakyrelu'):
         away &= pre.abs() > 1e-5
+    away = away.all(0, keepdim=True).expand_as(away)      # (a gate flipped anywhere in a column moves the column's two sums)
+    assert int(away[0].sum()) > 0.5 * feat
     assert float(((gp1.cpu().double() - pr.grad).abs() * away).max()) < 3e-5 * scale
     assert float((gp1 - gp2).abs().max()) < 2e-6 * scale
     assert rel_err(gg1.cpu(), gr.grad.float()) < 5e-5 and rel_err(gb1.cpu(), br.grad.float()) < 5e-5
