@@ -38,7 +38,7 @@ class FcArgs(ctypes.Structure):
     _fields_ = [('tail', BnTail), ('rows', c_int), ('f_in', c_int), ('f_out', c_int), ('ldw', c_int), ('x', _P),
                 ('W', _P), ('bias', _P), ('residual', _P), ('xact', _P), ('pre_keep', _P), ('y', _P), ('grad_y', _P),
                 ('grad_pre', _P), ('grad_gamma', _P), ('grad_beta', _P), ('grad_W', _P), ('grad_bias', _P),
-                ('grad_x', _P)]
+                ('grad_x', _P), ('W_dgrad_panel', _P)]
 
 
 class EdgeFcArgs(ctypes.Structure):
@@ -68,7 +68,7 @@ class PnaLayerArgs(ctypes.Structure):
                 ('postx', FcArgs * 3), ('residual', c_int), ('grad_out', _P), ('agg_event_start', _P), ('agg_event_stop', _P),
                 ('fused_bn', c_int), ('defer_join', c_int), ('stats_ws', _P), ('aff', _P * 4), ('weights_ready', c_int),
                 ('merge_h', c_int), ('Wcat', _P), ('bcat', _P), ('PL', _P), ('DL', _P), ('wgrad_split', c_int), ('eval_mode', c_int), ('msg_bf16', c_int),
-                ('edge_bias_partial', _P)]
+                ('edge_bias_partial', _P), ('Wcat_panel', _P)]
 
 
 class Net3dEdgeArgs(ctypes.Structure):
@@ -237,6 +237,9 @@ _SIGNATURES = {
                                           c_float, _P, _P]),
     'i3d_bn_bias_partial_floats': (c_long, [c_int]),
     'i3d_set_bn_bwd_one_launch': (c_int, [c_int]),
+    'i3d_panel_packed_bytes': (c_long, [c_int, c_int]),
+    'i3d_panel_pack': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    'i3d_panel_gemm': (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P]),
     'i3d_bn_bwd_one_launch_supported': (c_int, [c_int, c_int]),
     'i3d_bn_bwd_deferred_bias': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_long,
                                          _P, _P, _P]),

@@ -95,6 +95,14 @@ int join_wgrad(Aux* x, void* main) {
 
 }  // namespace
 
+// the row-panel product (panel.hip) takes a packed weight: fp32 mode with split products, K % 8 == 0, N % 4 == 0 - and pays where the
+// reduction is short (K <= 256: 34 -> 21 us at [E,200]x[200,200], 31 -> 22 us at [N,200]x[600,200]^T; level at K = 600 / 800:
+// profiles/r06_panel_bench.txt)
+static bool panel_ok(const void* packed, int K, int N) {
+    static const bool on = [] { const char* e = getenv("I3D_PANEL_GEMM"); return e == nullptr || e[0] != '0'; }();      // (A/B)
+    return on && packed != nullptr && i3d_get_matmul_precision() == 0 && i3d_get_fp32_products() == 1 && K % 8 == 0 && K <= 256 && N % 4 == 0;
+}
+
 static int tail_fwd(const I3dBnTail* t, int rows, int f_out, float* pre, float* xact, const float* residual, float* y,
                     void* stream) {
     // pre holds the Linear output.  xact == pre: activation in place (ReLU/none); else pre is kept for act'
@@ -142,9 +150,13 @@ static int fc_bn_bwd_chain(const I3dFcArgs* a, void* stream, int xact_bf16 = 0) 
     else
         TRY(tail_bwd(&a->tail, a->rows, a->f_out, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre,
                      a->grad_bias, stream));
-    if (a->grad_x != nullptr)
-        TRY(i3d_gemm_f32(0, 0, a->rows, a->f_in, a->f_out, a->grad_pre, a->f_out, a->W, a->ldw, a->grad_x, a->f_in, nullptr,
-                         0, stream));
+    if (a->grad_x != nullptr) {
+        if (panel_ok(a->W_dgrad_panel, a->f_out, a->f_in) && (((uintptr_t)a->grad_pre | (uintptr_t)a->grad_x) & 15) == 0)
+            TRY(i3d_panel_gemm(a->rows, a->f_in, a->f_out, a->grad_pre, a->f_out, a->W_dgrad_panel, a->grad_x, a->f_in, nullptr, 0, stream));
+        else
+            TRY(i3d_gemm_f32(0, 0, a->rows, a->f_in, a->f_out, a->grad_pre, a->f_out, a->W, a->ldw, a->grad_x, a->f_in, nullptr,
+                             0, stream));
+    }
     return I3D_OK;
 }
 
@@ -311,6 +323,19 @@ static bool merge_h_ok(const I3dPnaLayerArgs* a) {
            a->post.f_h == a->edge.f_h && a->post.pre_keep == nullptr;
 }
 
+// Wcat / bcat of a merged layer, and the packed images the row-panel products read (Wcat for the forward h-product, the later pretrans
+// blocks' weights for their data gradients): parameters only - once per forward pass, off the chain when the sequencer hoists it
+static int pack_layer_weights(const I3dPnaLayerArgs* a, void* stream) {
+    const I3dEdgeFcArgs* e = &a->edge;
+    const I3dGroupedFcArgs* p = &a->post;
+    TRY(i3d_pna_pack_h_weights(e->W, e->ldw, e->f_out, p->W, p->ldw, p->f_out, p->bias, e->f_h, a->Wcat, a->bcat, stream));
+    if (a->Wcat_panel != nullptr) TRY(i3d_panel_pack(a->Wcat, e->f_h, 2 * e->f_out + p->f_out, e->f_h, 1, a->Wcat_panel, stream));
+    for (int i = 0; i < a->n_pre_extra; ++i)
+        if (a->pre[i].W_dgrad_panel != nullptr)
+            TRY(i3d_panel_pack(a->pre[i].W, a->pre[i].ldw, a->pre[i].f_in, a->pre[i].f_out, 0, a->pre[i].W_dgrad_panel, stream));
+    return I3D_OK;
+}
+
 // the edge block's BatchNorm backward fused with the segmented sums behind it (bn.hip: i3d_bn_bwd_edge_sums): merged h-products
 // (dP lands in the first two column blocks of DL), an activation whose derivative follows from the stored activation, 16-byte rows.
 // I3D_EDGE_BWD_FUSED=0: BatchNorm backward + i3d_segment_sum_pair (the same bits).
@@ -470,9 +495,11 @@ static int pna_layer_fwd_fused(const I3dPnaLayerArgs* a, void* stream) {
     const float* P = e->P;
     int ldp = 2 * Fo;
     if (merged) {
-        if (!a->weights_ready)
-            TRY(i3d_pna_pack_h_weights(e->W, e->ldw, Fo, pg->W, pg->ldw, pg->f_out, pg->bias, Fh, a->Wcat, a->bcat, stream));
-        TRY(i3d_gemm_f32(0, 1, N, WL, Fh, e->h, Fh, a->Wcat, Fh, a->PL, WL, a->bcat, 0, stream));
+        if (!a->weights_ready) TRY(pack_layer_weights(a, stream));
+        if (panel_ok(a->Wcat_panel, Fh, WL))      // row-panel form: h read and split once per 208-column block (panel.hip)
+            TRY(i3d_panel_gemm(N, WL, Fh, e->h, Fh, a->Wcat_panel, a->PL, WL, a->bcat, 0, stream));
+        else
+            TRY(i3d_gemm_f32(0, 1, N, WL, Fh, e->h, Fh, a->Wcat, Fh, a->PL, WL, a->bcat, 0, stream));
         P = a->PL;
         ldp = WL;
     } else {
@@ -534,8 +561,7 @@ extern "C" int i3d_pna_layer_weights_fwd(const I3dPnaLayerArgs* a, void* stream)
     if (e->q != nullptr)
         TRY(i3d_gemm_f32(0, 1, e->q_rows > 0 ? e->q_rows : e->num_edges, e->f_out, e->f_q, e->q, e->f_q, e->W + 2 * e->f_h, e->ldw,
                          e->Q, e->f_out, nullptr, 0, stream));
-    if (merge_h_ok(a))
-        TRY(i3d_pna_pack_h_weights(e->W, e->ldw, e->f_out, p->W, p->ldw, p->f_out, p->bias, e->f_h, a->Wcat, a->bcat, stream));
+    if (merge_h_ok(a)) TRY(pack_layer_weights(a, stream));
     return i3d_pna_combine_weights_fwd(p->W, p->ldw, p->f_h, p->f_out, p->agg_width, p->n_groups, p->n_scalers, p->coef, p->WD,
                                        stream);
 }

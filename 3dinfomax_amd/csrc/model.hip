@@ -263,6 +263,7 @@ long plan_forward(PnaCtx& c, float* saved, float* node_emb, float* out) {
             a.Wcat = ar.take((long)(2 * Fo0 + F) * F);
             a.bcat = ar.take(2 * Fo0 + F);
             a.PL = ar.take((long)N * (2 * Fo0 + F));
+            a.Wcat_panel = ar.take(i3d_panel_packed_bytes(2 * Fo0 + F, F) / 4);      // (csrc/panel.hip; packed where Wcat is)
         }
         e.xact = ar.take((long)E * Fo0);
         a.aff[0] = ar.take(3L * Fo0);
@@ -276,6 +277,7 @@ long plan_forward(PnaCtx& c, float* saved, float* node_emb, float* out) {
             fc.rows = E; fc.f_in = f_in; fc.f_out = p.f_out; fc.ldw = p.f_in;
             fc.x = x; fc.W = p.W; fc.bias = p.bias;
             fc.xact = ar.take((long)E * p.f_out);
+            if (merge_h()) fc.W_dgrad_panel = ar.take(i3d_panel_packed_bytes(f_in, p.f_out) / 4);
             a.aff[i] = ar.take(3L * p.f_out);
             x = fc.xact;
             f_in = p.f_out;

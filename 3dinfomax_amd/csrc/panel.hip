@@ -1,0 +1,258 @@
+// Row-panel GEMM for the chain's products (round 6): C[M, N] (+)= A[M, K] op(W) (+ bias) with N a few hundred - the nn.Linear products of
+// a PNA layer (reference models/base_layers.py:101 forward; autograd's data gradient dX = dY W) at hidden 200.
+//
+// The tiled kernels of gemm.hip cut such a product into 64 x 64 tiles: every 64-row slab of A is loaded - and, in the split form,
+// split into its three bf16 images - by every column tile's workgroup (4 x at N = 200, 13 x at N = 800), the weight tile likewise by
+// every row tile's workgroup, and N = 200 pads to 256 columns (profiles/r05_split_products.txt: MFMA busy 0.22 of the CU's cycles).
+// Here
+//   * the WEIGHT is split ONCE per optimisation step by a pack kernel into its three bf16 images hi | mid | lo (x = hi + mid + lo
+//     exactly: gemm.hip split_pair), laid out in global memory exactly as the LDS image the MFMA fragments are read from:
+//     [column block of 208][K-step of 32][13 column tiles][3 images][64 lanes][8 bf16] - a K-step's slice of a column block is 39
+//     pieces of 1 KiB that go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no staging registers, no ds_write), and a lane's B
+//     fragment is ONE conflict-free ds_read_b128 at lane * 16;
+//   * a workgroup (4 waves) owns 64 rows x one 208-column block (13 tiles of 16: 200 = 12.5 tiles, 4 % padding instead of 22 %); a
+//     wave owns 32 rows x 7 (or 6) column tiles; its A fragments never touch the LDS: a lane loads the 8 consecutive k of its row
+//     straight from global memory (32 B per lane, 128 B contiguous per row and K-step), splits them ONCE and uses them for all its
+//     column tiles;
+//   * v_mfma_f32_16x16x32_bf16, the six part products of order <= 2 (hh, hm, mh, hl, lh, mm; each exact in the fp32 accumulator;
+//     dropped: <= 3 x 2^-24 |a b| - the same arithmetic as gemm.hip's split form), issued product-major so that consecutive MFMAs
+//     never share an accumulator; mfma(B fragment, A fragment): a lane owns 4 consecutive columns of one row -> 16-byte stores.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace i3d {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int PN = 208, PT = 13, PBK = 32, PBM = 64;
+constexpr int PIECE = 1024;                       // one (column tile, image) of a K-step: 64 lanes x 16 bytes
+constexpr int STEP_BYTES = PT * 3 * PIECE;        // 39 KiB per K-step and column block
+
+// (a, b) -> packed bf16 pairs hi | mid | lo with a = hi.a + mid.a + lo.a exactly (gemm.hip: split_pair)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    auto pack = [](f32x2_t v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t)); };
+    auto widen = [](unsigned u) { f32x2_t r; r.x = __uint_as_float(u << 16); r.y = __uint_as_float(u & 0xffff0000u); return r; };
+    f32x2_t v;
+    v.x = a; v.y = b;
+    hi = pack(v);
+    const f32x2_t r1 = v - widen(hi);
+    mid = pack(r1);
+    const f32x2_t r2 = r1 - widen(mid);
+    lo = pack(r2);
+}
+__device__ __forceinline__ void split8(const float4 lo4, const float4 hi4, bf16x8& h, bf16x8& m, bf16x8& l) {
+    uint4 uh, um, ul;
+    split_pair(lo4.x, lo4.y, uh.x, um.x, ul.x);
+    split_pair(lo4.z, lo4.w, uh.y, um.y, ul.y);
+    split_pair(hi4.x, hi4.y, uh.z, um.z, ul.z);
+    split_pair(hi4.z, hi4.w, uh.w, um.w, ul.w);
+    h = __builtin_bit_cast(bf16x8, uh);
+    m = __builtin_bit_cast(bf16x8, um);
+    l = __builtin_bit_cast(bf16x8, ul);
+}
+
+// ---- pack: W -> [col block][K-step][13][3][64][8] bf16 -------------------------------------------------------------------------
+// trans = 1: B[n][k] = W[n * ldw + k] (a Linear's forward: W stored [out, in]);  0: B[n][k] = W[k * ldw + n] (its data gradient)
+struct PackArgs {
+    const float* W;
+    int ldw, N, K, trans;
+    unsigned short* out;
+};
+
+__global__ void __launch_bounds__(256) panel_pack_kernel(PackArgs a) {
+    const int KT = (a.K + PBK - 1) / PBK;
+    const int cb = blockIdx.y, t = blockIdx.x;
+    unsigned short* dst = a.out + ((long)(cb * KT + t) * STEP_BYTES) / 2;
+    for (int q = threadIdx.x; q < PT * 64; q += 256) {       // one (column tile, lane) per trip: 8 k of one column
+        const int j = q / 64, lane = q % 64;
+        const int n = cb * PN + j * 16 + (lane & 15), k0 = t * PBK + (lane >> 4) * 8;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e;
+            v[e] = (n < a.N && k < a.K) ? (a.trans ? a.W[(long)n * a.ldw + k] : a.W[(long)k * a.ldw + n]) : 0.f;
+        }
+        uint4 uh, um, ul;
+        split_pair(v[0], v[1], uh.x, um.x, ul.x);
+        split_pair(v[2], v[3], uh.y, um.y, ul.y);
+        split_pair(v[4], v[5], uh.z, um.z, ul.z);
+        split_pair(v[6], v[7], uh.w, um.w, ul.w);
+        uint4* p = reinterpret_cast<uint4*>(dst + ((long)(j * 3) * PIECE) / 2) + lane;
+        p[0] = uh;
+        p[PIECE / 16] = um;
+        p[2 * PIECE / 16] = ul;
+    }
+}
+
+// ---- the product -------------------------------------------------------------------------------------------------------------------
+struct PanelArgs {
+    const float* A;
+    int lda, M, K, N;
+    const unsigned char* Bp;     // packed weight (panel_pack_kernel)
+    float* C;
+    int ldc;
+    const float* bias;           // [N] or null
+    int accumulate;              // C += product
+    int debug;                   // probe builds: 1 skip the MFMAs, 2 skip the B stage, 4 skip the A loads, 8 skip the stores
+};
+
+__global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
+    I3D_CHAIN_PRIO();
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][STEP_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rt = wave >> 1, ch = wave & 1;
+    const int j0 = ch * 7, nj = ch ? PT - 7 : 7;
+    const int cb = blockIdx.y;
+    const int m0 = blockIdx.x * PBM + rt * 32;
+    const int KT = (g.K + PBK - 1) / PBK;
+    const unsigned char* bsrc = g.Bp + (long)cb * KT * STEP_BYTES;
+
+    // Loads are issued through inline asm: hipcc does not count asm memory operations, so NO compiler-made s_waitcnt vmcnt(0) lands
+    // between the prefetch of step t + 1 and the MFMAs of step t (with the builtins every ds_read of the B image was preceded by one:
+    // 33 in the kernel, the prefetch was drained before the products began - 20 us instead of 12 at [E,200]x[200,200]).  The waits
+    // are ours: one vmcnt(0) at the top of a step, when only that step's operands are outstanding.
+    const unsigned bs_base = (unsigned)(unsigned long long)(lds_ptr_t)&Bs[0][0];
+    auto stage_b = [&](int t, int buf) {      // 39 pieces of 1 KiB over 4 waves: global -> LDS by LDS-DMA
+        const unsigned char* src = bsrc + (long)t * STEP_BYTES + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int p = wave + 4 * i;
+            if (p < PT * 3) {
+                unsigned keep;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(bs_base + (unsigned)(buf * STEP_BYTES + p * PIECE));
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(src + p * PIECE), "s"(dst)
+                             : "memory");
+            }
+        }
+    };
+    const int arow = lane & 15, akc = (lane >> 4) * 8;
+    // A: ordinary loads (the compiler keeps their values safe: asm-load results may be copied before they land); issued right after
+    // the step's barrier and first used BEHIND the step's MFMAs, where the compiler's vmcnt(0) is the wait the next step needs anyway
+    auto load_a = [&](int t, float4 (&r)[2][2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = m0 + i * 16 + arow, k = t * PBK + akc;
+            if (row < g.M && k < g.K) {            // K % 8 == 0: a lane's 8 k are valid or not as a whole
+                const float4* p = reinterpret_cast<const float4*>(g.A + (long)row * g.lda + k);
+                r[i][0] = p[0];
+                r[i][1] = p[1];
+            } else {
+                r[i][0] = r[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+
+    floatx4 acc[2][7];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 ah[2], am[2], al[2];
+    {
+        float4 a0[2][2];
+        stage_b(0, 0);
+        load_a(0, a0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) split8(a0[i][0], a0[i][1], ah[i], am[i], al[i]);
+    }
+    for (int t = 0; t < KT; ++t) {
+        const int buf = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of B(t) have landed
+        __syncthreads();          // every wave's pieces of B(t) are in Bs[buf]; every wave has left step t - 1 (Bs[buf ^ 1] is free)
+        float4 an[2][2];
+        if (t + 1 < KT) {
+            if (!(g.debug & 2)) stage_b(t + 1, buf ^ 1);
+            if (!(g.debug & 4)) load_a(t + 1, an);
+            else an[0][0] = an[0][1] = an[1][0] = an[1][1] = make_float4(1.f, 2.f, 3.f, 4.f);
+        }
+        const unsigned char* bl = &Bs[buf][0] + lane * 16;
+#pragma unroll
+        for (int jj = 0; jj < 7; ++jj) {
+            if (jj < nj && !(g.debug & 1)) {
+                const int j = j0 + jj;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bl + (j * 3 + 0) * PIECE);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bl + (j * 3 + 1) * PIECE);
+                const bf16x8 bo = *reinterpret_cast<const bf16x8*>(bl + (j * 3 + 2) * PIECE);
+                // small products first; consecutive MFMAs alternate between the two row tiles' accumulators
+                acc[0][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bo, ah[0], acc[0][jj], 0, 0, 0);
+                acc[1][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bo, ah[1], acc[1][jj], 0, 0, 0);
+                acc[0][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[0], acc[0][jj], 0, 0, 0);
+                acc[1][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[1], acc[1][jj], 0, 0, 0);
+                acc[0][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am[0], acc[0][jj], 0, 0, 0);
+                acc[1][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am[1], acc[1][jj], 0, 0, 0);
+                acc[0][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah[0], acc[0][jj], 0, 0, 0);
+                acc[1][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah[1], acc[1][jj], 0, 0, 0);
+                acc[0][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am[0], acc[0][jj], 0, 0, 0);
+                acc[1][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am[1], acc[1][jj], 0, 0, 0);
+                acc[0][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[0], acc[0][jj], 0, 0, 0);
+                acc[1][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[1], acc[1][jj], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);       // the split of step t + 1 (and its wait for the A values) stays behind the MFMAs
+        if (t + 1 < KT) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) split8(an[i][0], an[i][1], ah[i], am[i], al[i]);
+        }
+    }
+    // epilogue: lane owns row (lane & 15) of a row tile, columns (lane >> 4) * 4 .. + 3 of a column tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = m0 + i * 16 + (lane & 15);
+        if (row >= g.M || (g.debug & 8)) continue;
+#pragma unroll
+        for (int jj = 0; jj < 7; ++jj) {
+            if (jj >= nj) continue;
+            const int col = cb * PN + (j0 + jj) * 16 + (lane >> 4) * 4;
+            if (col >= g.N) continue;             // N % 4 == 0
+            floatx4 v = acc[i][jj];
+            if (g.bias != nullptr) {
+                const float4 b = *reinterpret_cast<const float4*>(g.bias + col);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            float4* c = reinterpret_cast<float4*>(g.C + (long)row * g.ldc + col);
+            if (g.accumulate) {
+                const float4 o = *c;
+                v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+            }
+            *c = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+}  // namespace
+}  // namespace i3d
+
+using namespace i3d;
+
+extern "C" long i3d_panel_packed_bytes(int N, int K) {
+    return (long)cdiv(N, PN) * cdiv(K, PBK) * STEP_BYTES;
+}
+
+extern "C" int i3d_panel_pack(const float* W, int ldw, int N, int K, int trans, void* packed, void* stream) {
+    I3D_CHECK_ARG(W != nullptr && packed != nullptr && N > 0 && K > 0 && ldw >= (trans ? K : N), "bad arguments");
+    PackArgs a{W, ldw, N, K, trans, (unsigned short*)packed};
+    hipLaunchKernelGGL(panel_pack_kernel, dim3(cdiv(K, PBK), cdiv(N, PN)), dim3(256), 0, (hipStream_t)stream, a);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}
+
+extern "C" int i3d_panel_gemm(int M, int N, int K, const float* A, int lda, const void* packed, float* C, int ldc, const float* bias,
+                              int accumulate, void* stream) {
+    I3D_CHECK_ARG(M > 0 && N > 0 && K > 0 && A != nullptr && packed != nullptr && C != nullptr, "bad arguments");
+    I3D_CHECK_ARG(K % 8 == 0 && N % 4 == 0 && lda % 4 == 0 && ldc % 4 == 0 && lda >= K && ldc >= N, "K % 8, N % 4, 16-byte rows");
+    I3D_CHECK_ARG(((((uintptr_t)A) | ((uintptr_t)C) | ((uintptr_t)packed) | ((uintptr_t)bias)) & 15) == 0, "16-byte aligned operands");
+    static const int dbg = [] { const char* e = getenv("I3D_PANEL_DEBUG"); return e ? atoi(e) : 0; }();
+    PanelArgs g{A, lda, M, K, N, (const unsigned char*)packed, C, ldc, bias, accumulate ? 1 : 0, dbg};
+    hipLaunchKernelGGL(panel_gemm_kernel, dim3(cdiv(M, PBM), cdiv(N, PN)), dim3(256), 0, (hipStream_t)stream, g);
+    I3D_CHECK_LAUNCH();
+    return I3D_OK;
+}

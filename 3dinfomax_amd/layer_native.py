@@ -130,6 +130,12 @@ def forward(ctx, h, q, index, qmap, plan, params):
     WL = 2 * Fo0 + Fp0
     if merged:
         total += _al(WL * Fh) + _al(WL) + _al(N * WL)
+        # the packed weights of the row-panel products (csrc/panel.hip): Wcat forward, the later pretrans blocks' data gradients
+        total += _al(L.i3d_panel_packed_bytes(WL, Fh) // 4)
+        f_prev = Fo0
+        for i in range(1, n_pre):
+            total += _al(L.i3d_panel_packed_bytes(f_prev, pre_p[i][0].shape[0]) // 4)
+            f_prev = pre_p[i][0].shape[0]
     for i, spec in enumerate(plan.post_specs):
         Fo = post_p[i][0].shape[0]
         total += _al(N * Fo) * (2 + (1 if _keeps_pre(spec) else 0)) + 2 * _al(Fo)
@@ -159,6 +165,7 @@ def forward(ctx, h, q, index, qmap, plan, params):
     if merged:          # the products that read h as one GEMM per direction (include/infomax3d_hip.h: I3dPnaLayerArgs.merge_h)
         a.merge_h = 1
         a.Wcat, a.bcat, a.PL = ar.take(WL * Fh), ar.take(WL), ar.take(N * WL)
+        a.Wcat_panel = ar.take(L.i3d_panel_packed_bytes(WL, Fh) // 4)
     e.xact = ar.take(E * Fo0)
     if _keeps_pre(spec):
         e.pre_keep = ar.take(E * Fo0)
@@ -179,6 +186,8 @@ def forward(ctx, h, q, index, qmap, plan, params):
         c.rows, c.f_in, c.f_out, c.ldw = E, f_in, Fo, W.stride(0)
         c.x, c.W, c.bias = x_ptr, W.data_ptr(), b.data_ptr()
         c.xact = ar.take(E * Fo)
+        if merged:
+            c.W_dgrad_panel = ar.take(L.i3d_panel_packed_bytes(f_in, Fo) // 4)
         if _keeps_pre(spec):
             c.pre_keep = ar.take(E * Fo)
         if fused:

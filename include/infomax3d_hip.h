@@ -138,6 +138,17 @@ int i3d_get_matmul_precision(void);
 int i3d_set_fp32_products(int split);
 int i3d_get_fp32_products(void);
 
+/* Row-panel form of the chain's Linear products (csrc/panel.hip; reference models/base_layers.py:101 and its data gradient): the
+ * weight is split ONCE per optimisation step into the three bf16 images of the split form (i3d_set_fp32_products) and laid out as the
+ * LDS image of the product kernel - i3d_panel_pack: trans 1 = B[n][k] = W[n * ldw + k] (forward, W stored [out, in]), 0 = B[n][k] =
+ * W[k * ldw + n] (data gradient); `packed`: i3d_panel_packed_bytes(N, K) bytes, 16-byte aligned - and i3d_panel_gemm forms
+ * C[M, N] (+)= A[M, K] B^T (+ bias) with every 64-row slab of A read and split once per 208-column block.  K % 8 == 0, N % 4 == 0,
+ * 16-byte aligned rows.  Same arithmetic as the split form of i3d_gemm_f32 (six bf16 part products, fp32 accumulation). */
+long i3d_panel_packed_bytes(int N, int K);
+int i3d_panel_pack(const float* W, int ldw, int N, int K, int trans, void* packed, void* stream);
+int i3d_panel_gemm(int M, int N, int K, const float* A, int lda, const void* packed, float* C, int ldc, const float* bias,
+                   int accumulate, void* stream);
+
 /* i3d_gemm_f32 with scratch: when the reduction dimension is split over workgroups (weight gradients), the slices are
  * written to workspace[slices][M][N] and summed in a fixed order by a second kernel (deterministic, no zero-fill, no
  * atomics).  workspace NULL or too small: fp32 atomics as i3d_gemm_f32. */
@@ -697,6 +708,9 @@ typedef struct { /* y = tail(x W^T + b) */
     float* grad_W;
     float* grad_bias;
     float* grad_x;
+    void* W_dgrad_panel; /* optional: the block's weight packed for the row-panel data gradient (i3d_panel_pack(W, ldw, f_in, f_out,
+                          * trans 0): i3d_panel_packed_bytes(f_in, f_out) bytes) - filled by i3d_pna_layer_weights_fwd / the layer's
+                          * forward pass, read by its backward pass (dX = dZ W through i3d_panel_gemm).  NULL: the tiled product */
 } I3dFcArgs;
 
 typedef struct { /* y = tail(P[src,:F] + P[dst,F:] + q W_q^T + b),  P = h [W_s|W_d]^T  (reference models/pna.py:237-252) */
@@ -818,6 +832,8 @@ typedef struct { /* one PNA layer, reference models/pna.py:199-216: pretrans edg
                         * activation of the none / ReLU / LeakyReLU class, 16-byte rows) the edge block's BatchNorm backward runs
                         * as i3d_bn_bwd_edge_sums - the data gradient formed inside the two segmented sums behind it - and its
                         * bias gradient is taken from dP[dst] on the weight-gradient stream through this buffer */
+    void* Wcat_panel;  /* optional (merge_h): Wcat packed for the row-panel forward product PL = h Wcat^T + bcat (i3d_panel_pack, trans 1:
+                        * i3d_panel_packed_bytes(2 f_out(edge) + f_out(post), f_h) bytes), packed where Wcat is.  NULL: the tiled product */
 } I3dPnaLayerArgs;
 
 /* eval-mode affine vector of one BatchNorm: aff [3 feat] = running_mean | gamma / sqrt(running_var + eps) | beta */
