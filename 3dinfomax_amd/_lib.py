@@ -38,7 +38,7 @@ class FcArgs(ctypes.Structure):
     _fields_ = [('tail', BnTail), ('rows', c_int), ('f_in', c_int), ('f_out', c_int), ('ldw', c_int), ('x', _P),
                 ('W', _P), ('bias', _P), ('residual', _P), ('xact', _P), ('pre_keep', _P), ('y', _P), ('grad_y', _P),
                 ('grad_pre', _P), ('grad_gamma', _P), ('grad_beta', _P), ('grad_W', _P), ('grad_bias', _P),
-                ('grad_x', _P), ('W_dgrad_panel', _P)]
+                ('grad_x', _P), ('W_dgrad_panel', _P), ('W_fwd_panel', _P)]
 
 
 class EdgeFcArgs(ctypes.Structure):
@@ -240,6 +240,8 @@ _SIGNATURES = {
     'i3d_panel_packed_bytes': (c_long, [c_int, c_int]),
     'i3d_panel_pack': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     'i3d_panel_gemm': (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P]),
+    'i3d_panel_stats_tiles': (c_int, [c_int]),
+    'i3d_panel_gemm_fused': (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, _P, c_int, _P, _P]),
     'i3d_bn_bwd_one_launch_supported': (c_int, [c_int, c_int]),
     'i3d_bn_bwd_deferred_bias': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_long,
                                          _P, _P, _P]),

@@ -333,6 +333,9 @@ static int pack_layer_weights(const I3dPnaLayerArgs* a, void* stream) {
     for (int i = 0; i < a->n_pre_extra; ++i)
         if (a->pre[i].W_dgrad_panel != nullptr)
             TRY(i3d_panel_pack(a->pre[i].W, a->pre[i].ldw, a->pre[i].f_in, a->pre[i].f_out, 0, a->pre[i].W_dgrad_panel, stream));
+    for (int i = 0; i < a->n_pre_extra; ++i)
+        if (a->pre[i].W_fwd_panel != nullptr)
+            TRY(i3d_panel_pack(a->pre[i].W, a->pre[i].ldw, a->pre[i].f_out, a->pre[i].f_in, 1, a->pre[i].W_fwd_panel, stream));
     return I3D_OK;
 }
 
@@ -521,13 +524,19 @@ static int pna_layer_fwd_fused(const I3dPnaLayerArgs* a, void* stream) {
         I3D_CHECK_ARG(c->pre_keep == nullptr && simple_act(c->tail.act) && c->tail.post_act == I3D_ACT_NONE &&
                           a->aff[i + 1] != nullptr && c->rows == E && c->f_in == f_in, "fused BatchNorm: unsupported block shape");
         // lin = BN_prev(x) W^T + b with the BatchNorm applied while x is staged; activation + statistics in the epilogue
+        int stat_tiles = cdiv(E, 64);
         if (a->msg_bf16 && i == a->n_pre_extra - 1)      // the messages: stored as bf16 (K4 and this block's BatchNorm backward read them)
             TRY(i3d_gemm_f32_fused_bf16out(E, c->f_out, f_in, x, f_in, E, c->W, c->ldw, c->xact, c->f_out, c->bias, aff, c->tail.act,
                                            a->stats_ws, stream));
-        else
+        else if (merged && panel_ok(c->W_fwd_panel, f_in, c->f_out) && (((uintptr_t)x | (uintptr_t)c->xact | (uintptr_t)aff) & 15) == 0) {
+            // row-panel form (panel.hip): the BatchNorm prologue, bias, activation and the statistics of 32-row tiles in one launch
+            TRY(i3d_panel_gemm_fused(E, c->f_out, f_in, x, f_in, c->W_fwd_panel, c->xact, c->f_out, c->bias, aff, c->tail.act, a->stats_ws,
+                                     stream));
+            stat_tiles = i3d_panel_stats_tiles(E);
+        } else
             TRY(i3d_gemm_f32_fused(E, c->f_out, f_in, x, f_in, E, c->W, c->ldw, c->xact, c->f_out, c->bias, 0, aff, c->tail.act,
                                    a->stats_ws, nullptr, nullptr, 0, stream));
-        TRY(finalize_stats(&c->tail, a->stats_ws, cdiv(E, 64), c->f_out, a->aff[i + 1], stream, a->eval_mode));
+        TRY(finalize_stats(&c->tail, a->stats_ws, stat_tiles, c->f_out, a->aff[i + 1], stream, a->eval_mode));
         x = c->xact;
         aff = a->aff[i + 1];
         f_in = c->f_out;
@@ -585,7 +594,7 @@ extern "C" long i3d_pna_layer_stats_floats(int num_nodes, int num_edges, int m_p
     (void)num_nodes;
     const int rpt = i3d_edge_stats_rows_per_tile(f);
     long tiles = cdiv(num_edges, rpt > 0 ? rpt : 1);
-    tiles = std::max<long>(tiles, cdiv(num_edges, 64));
+    tiles = std::max<long>(tiles, 2L * cdiv(num_edges, 64));       // (the row-panel product's 32-row tiles)
     tiles = std::max<long>(tiles, m_padded / 64 + 1);
     return tiles * 3 * f;
 }

@@ -277,7 +277,10 @@ long plan_forward(PnaCtx& c, float* saved, float* node_emb, float* out) {
             fc.rows = E; fc.f_in = f_in; fc.f_out = p.f_out; fc.ldw = p.f_in;
             fc.x = x; fc.W = p.W; fc.bias = p.bias;
             fc.xact = ar.take((long)E * p.f_out);
-            if (merge_h()) fc.W_dgrad_panel = ar.take(i3d_panel_packed_bytes(f_in, p.f_out) / 4);
+            if (merge_h()) {
+                fc.W_dgrad_panel = ar.take(i3d_panel_packed_bytes(f_in, p.f_out) / 4);
+                fc.W_fwd_panel = ar.take(i3d_panel_packed_bytes(p.f_out, f_in) / 4);
+            }
             a.aff[i] = ar.take(3L * p.f_out);
             x = fc.xact;
             f_in = p.f_out;

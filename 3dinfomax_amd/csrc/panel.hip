@@ -99,9 +99,14 @@ struct PanelArgs {
     int ldc;
     const float* bias;           // [N] or null
     int accumulate;              // C += product
-    int debug;                   // probe builds: 1 skip the MFMAs, 2 skip the B stage, 4 skip the A loads, 8 skip the stores
+    // fused BatchNorm (the forward of a block behind a BatchNorm whose output is never materialised: fused_bn.hip)
+    const float* aff;            // AFF: [3 K] mean | scale | shift - A is read as (A[m][k] - mean[k]) * scale[k] + shift[k]
+    int act;                     // STATS: activation of the stored value (none / ReLU / LeakyReLU)
+    float* stats;                // STATS: [2 ceil(M / 64)][3][N] per 32-row tile and column {sum, M2 about the tile mean, row count} of
+                                 // the stored values (bn_finalize_partials_kernel merges the tiles)
 };
 
+template <bool AFF, bool STATS>
 __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
     I3D_CHAIN_PRIO();
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2][STEP_BYTES];
@@ -113,10 +118,9 @@ __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
     const int KT = (g.K + PBK - 1) / PBK;
     const unsigned char* bsrc = g.Bp + (long)cb * KT * STEP_BYTES;
 
-    // Loads are issued through inline asm: hipcc does not count asm memory operations, so NO compiler-made s_waitcnt vmcnt(0) lands
-    // between the prefetch of step t + 1 and the MFMAs of step t (with the builtins every ds_read of the B image was preceded by one:
-    // 33 in the kernel, the prefetch was drained before the products began - 20 us instead of 12 at [E,200]x[200,200]).  The waits
-    // are ours: one vmcnt(0) at the top of a step, when only that step's operands are outstanding.
+    // The B pieces are issued through inline asm: hipcc does not count asm memory operations, so NO compiler-made s_waitcnt vmcnt(0)
+    // lands between the prefetch of step t + 1 and the MFMAs of step t (with the builtin every ds_read of the B image was preceded by
+    // one: the prefetch was drained before the products began).  The wait is ours: one vmcnt(0) at the top of a step.
     const unsigned bs_base = (unsigned)(unsigned long long)(lds_ptr_t)&Bs[0][0];
     auto stage_b = [&](int t, int buf) {      // 39 pieces of 1 KiB over 4 waves: global -> LDS by LDS-DMA
         const unsigned char* src = bsrc + (long)t * STEP_BYTES + lane * 16;
@@ -136,17 +140,47 @@ __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
     const int arow = lane & 15, akc = (lane >> 4) * 8;
     // A: ordinary loads (the compiler keeps their values safe: asm-load results may be copied before they land); issued right after
     // the step's barrier and first used BEHIND the step's MFMAs, where the compiler's vmcnt(0) is the wait the next step needs anyway
-    auto load_a = [&](int t, float4 (&r)[2][2]) {
+    struct AStep {
+        float4 v[2][2];
+        float4 f[3][2];      // AFF: mean | scale | shift of the lane's 8 k
+    };
+    auto load_a = [&](int t, AStep& r) {
+        const int k = t * PBK + akc;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int row = m0 + i * 16 + arow, k = t * PBK + akc;
+            const int row = m0 + i * 16 + arow;
             if (row < g.M && k < g.K) {            // K % 8 == 0: a lane's 8 k are valid or not as a whole
                 const float4* p = reinterpret_cast<const float4*>(g.A + (long)row * g.lda + k);
-                r[i][0] = p[0];
-                r[i][1] = p[1];
+                r.v[i][0] = p[0];
+                r.v[i][1] = p[1];
             } else {
-                r[i][0] = r[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                r.v[i][0] = r.v[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        }
+        if (AFF) {
+            const int kc = min(k, g.K - 8);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float4* p = reinterpret_cast<const float4*>(g.aff + (long)q * g.K + kc);
+                r.f[q][0] = p[0];
+                r.f[q][1] = p[1];
+            }
+        }
+    };
+    auto split_a = [&](int t, const AStep& r, bf16x8 (&h)[2], bf16x8 (&m)[2], bf16x8 (&l)[2]) {
+        const bool kok = t * PBK + akc < g.K;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float4 x0 = r.v[i][0], x1 = r.v[i][1];
+            if (AFF) {       // gemm.hip store_aff's expression: the same bits; lanes outside the matrix stay exact zeros
+                const bool ok = kok && m0 + i * 16 + arow < g.M;
+                auto af = [&](float x, float mu, float sc, float sh) { return ok ? (x - mu) * sc + sh : 0.f; };
+                x0 = make_float4(af(x0.x, r.f[0][0].x, r.f[1][0].x, r.f[2][0].x), af(x0.y, r.f[0][0].y, r.f[1][0].y, r.f[2][0].y),
+                                 af(x0.z, r.f[0][0].z, r.f[1][0].z, r.f[2][0].z), af(x0.w, r.f[0][0].w, r.f[1][0].w, r.f[2][0].w));
+                x1 = make_float4(af(x1.x, r.f[0][1].x, r.f[1][1].x, r.f[2][1].x), af(x1.y, r.f[0][1].y, r.f[1][1].y, r.f[2][1].y),
+                                 af(x1.z, r.f[0][1].z, r.f[1][1].z, r.f[2][1].z), af(x1.w, r.f[0][1].w, r.f[1][1].w, r.f[2][1].w));
+            }
+            split8(x0, x1, h[i], m[i], l[i]);
         }
     };
 
@@ -158,26 +192,24 @@ __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
 
     bf16x8 ah[2], am[2], al[2];
     {
-        float4 a0[2][2];
+        AStep a0;
         stage_b(0, 0);
         load_a(0, a0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) split8(a0[i][0], a0[i][1], ah[i], am[i], al[i]);
+        split_a(0, a0, ah, am, al);
     }
     for (int t = 0; t < KT; ++t) {
         const int buf = t & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of B(t) have landed
         __syncthreads();          // every wave's pieces of B(t) are in Bs[buf]; every wave has left step t - 1 (Bs[buf ^ 1] is free)
-        float4 an[2][2];
+        AStep an;
         if (t + 1 < KT) {
-            if (!(g.debug & 2)) stage_b(t + 1, buf ^ 1);
-            if (!(g.debug & 4)) load_a(t + 1, an);
-            else an[0][0] = an[0][1] = an[1][0] = an[1][1] = make_float4(1.f, 2.f, 3.f, 4.f);
+            stage_b(t + 1, buf ^ 1);
+            load_a(t + 1, an);
         }
         const unsigned char* bl = &Bs[buf][0] + lane * 16;
 #pragma unroll
         for (int jj = 0; jj < 7; ++jj) {
-            if (jj < nj && !(g.debug & 1)) {
+            if (jj < nj) {
                 const int j = j0 + jj;
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bl + (j * 3 + 0) * PIECE);
                 const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bl + (j * 3 + 1) * PIECE);
@@ -198,32 +230,65 @@ __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);       // the split of step t + 1 (and its wait for the A values) stays behind the MFMAs
-        if (t + 1 < KT) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) split8(an[i][0], an[i][1], ah[i], am[i], al[i]);
-        }
+        if (t + 1 < KT) split_a(t + 1, an, ah, am, al);
     }
     // epilogue: lane owns row (lane & 15) of a row tile, columns (lane >> 4) * 4 .. + 3 of a column tile
+    const int row_lo = m0 + (lane & 15);
+    const bool rok[2] = {row_lo < g.M, row_lo + 16 < g.M};
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = m0 + i * 16 + (lane & 15);
-        if (row >= g.M || (g.debug & 8)) continue;
+    for (int jj = 0; jj < 7; ++jj) {
+        if (jj >= nj) continue;
+        const int col = cb * PN + (j0 + jj) * 16 + (lane >> 4) * 4;
+        const bool cok = col < g.N;               // N % 4 == 0
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cok && g.bias != nullptr) b4 = *reinterpret_cast<const float4*>(g.bias + col);
+        floatx4 v[2];
 #pragma unroll
-        for (int jj = 0; jj < 7; ++jj) {
-            if (jj >= nj) continue;
-            const int col = cb * PN + (j0 + jj) * 16 + (lane >> 4) * 4;
-            if (col >= g.N) continue;             // N % 4 == 0
-            floatx4 v = acc[i][jj];
-            if (g.bias != nullptr) {
-                const float4 b = *reinterpret_cast<const float4*>(g.bias + col);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        for (int i = 0; i < 2; ++i) {
+            v[i] = acc[i][jj];
+            v[i][0] += b4.x; v[i][1] += b4.y; v[i][2] += b4.z; v[i][3] += b4.w;
+            if (rok[i] && cok) {
+                float4* c = reinterpret_cast<float4*>(g.C + (long)(row_lo + 16 * i) * g.ldc + col);
+                if (g.accumulate) {
+                    const float4 o = *c;
+                    v[i][0] += o.x; v[i][1] += o.y; v[i][2] += o.z; v[i][3] += o.w;
+                }
+                if (STATS) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[i][q] = apply_act_c<false>(v[i][q], g.act);
+                }
+                *c = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
             }
-            float4* c = reinterpret_cast<float4*>(g.C + (long)row * g.ldc + col);
-            if (g.accumulate) {
-                const float4 o = *c;
-                v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+        }
+        if (STATS) {
+            // column statistics of this wave's 32-row tile: lane sums over its two rows, then over the 16 lanes that share the columns
+            // (xor 1, 2, 4, 8: a fixed tree), the tile mean, M2 about it the same way
+            float s[4], cnt = (rok[0] ? 1.f : 0.f) + (rok[1] ? 1.f : 0.f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[q] = (rok[0] ? v[0][q] : 0.f) + (rok[1] ? v[1][q] : 0.f);
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s[q] += __shfl_xor(s[q], m, 64);
+                cnt += __shfl_xor(cnt, m, 64);
             }
-            *c = make_float4(v[0], v[1], v[2], v[3]);
+            float m2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float mean_t = cnt > 0.f ? s[q] / cnt : 0.f;
+                const float d0 = v[0][q] - mean_t, d1 = v[1][q] - mean_t;
+                m2[q] = (rok[0] ? d0 * d0 : 0.f) + (rok[1] ? d1 * d1 : 0.f);
+            }
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) m2[q] += __shfl_xor(m2[q], m, 64);
+            if ((lane & 15) == 0 && cok) {
+                float* o = g.stats + (long)(blockIdx.x * 2 + rt) * 3 * g.N + col;
+                *reinterpret_cast<float4*>(o) = make_float4(s[0], s[1], s[2], s[3]);
+                *reinterpret_cast<float4*>(o + g.N) = make_float4(m2[0], m2[1], m2[2], m2[3]);
+                *reinterpret_cast<float4*>(o + 2 * g.N) = make_float4(cnt, cnt, cnt, cnt);
+            }
         }
     }
 }
@@ -245,14 +310,33 @@ extern "C" int i3d_panel_pack(const float* W, int ldw, int N, int K, int trans, 
     return I3D_OK;
 }
 
-extern "C" int i3d_panel_gemm(int M, int N, int K, const float* A, int lda, const void* packed, float* C, int ldc, const float* bias,
-                              int accumulate, void* stream) {
+static int panel_launch(int M, int N, int K, const float* A, int lda, const void* packed, float* C, int ldc, const float* bias,
+                        int accumulate, const float* aff, int act, float* stats, void* stream) {
     I3D_CHECK_ARG(M > 0 && N > 0 && K > 0 && A != nullptr && packed != nullptr && C != nullptr, "bad arguments");
     I3D_CHECK_ARG(K % 8 == 0 && N % 4 == 0 && lda % 4 == 0 && ldc % 4 == 0 && lda >= K && ldc >= N, "K % 8, N % 4, 16-byte rows");
-    I3D_CHECK_ARG(((((uintptr_t)A) | ((uintptr_t)C) | ((uintptr_t)packed) | ((uintptr_t)bias)) & 15) == 0, "16-byte aligned operands");
-    static const int dbg = [] { const char* e = getenv("I3D_PANEL_DEBUG"); return e ? atoi(e) : 0; }();
-    PanelArgs g{A, lda, M, K, N, (const unsigned char*)packed, C, ldc, bias, accumulate ? 1 : 0, dbg};
-    hipLaunchKernelGGL(panel_gemm_kernel, dim3(cdiv(M, PBM), cdiv(N, PN)), dim3(256), 0, (hipStream_t)stream, g);
+    I3D_CHECK_ARG(((((uintptr_t)A) | ((uintptr_t)C) | ((uintptr_t)packed) | ((uintptr_t)bias) | ((uintptr_t)aff) | ((uintptr_t)stats)) & 15) == 0,
+                  "16-byte aligned operands");
+    I3D_CHECK_ARG(stats == nullptr || relu_class(act), "epilogue activation: none, ReLU or LeakyReLU");
+    PanelArgs g{A, lda, M, K, N, (const unsigned char*)packed, C, ldc, bias, accumulate ? 1 : 0, aff, act, stats};
+    const dim3 grid(cdiv(M, PBM), cdiv(N, PN)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (aff != nullptr && stats != nullptr) hipLaunchKernelGGL((panel_gemm_kernel<true, true>), grid, block, 0, s, g);
+    else if (aff != nullptr) hipLaunchKernelGGL((panel_gemm_kernel<true, false>), grid, block, 0, s, g);
+    else if (stats != nullptr) hipLaunchKernelGGL((panel_gemm_kernel<false, true>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((panel_gemm_kernel<false, false>), grid, block, 0, s, g);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
+}
+
+extern "C" int i3d_panel_gemm(int M, int N, int K, const float* A, int lda, const void* packed, float* C, int ldc, const float* bias,
+                              int accumulate, void* stream) {
+    return panel_launch(M, N, K, A, lda, packed, C, ldc, bias, accumulate, nullptr, I3D_ACT_NONE, nullptr, stream);
+}
+
+extern "C" int i3d_panel_stats_tiles(int M) { return 2 * cdiv(M, PBM); }
+
+extern "C" int i3d_panel_gemm_fused(int M, int N, int K, const float* A, int lda, const void* packed, float* C, int ldc, const float* bias,
+                                    const float* a_aff, int epi_act, float* stats, void* stream) {
+    I3D_CHECK_ARG(stats == nullptr || ((long)N * 4) % 16 == 0, "N % 4");
+    return panel_launch(M, N, K, A, lda, packed, C, ldc, bias, 0, a_aff, epi_act, stats, stream);
 }

@@ -135,6 +135,7 @@ def forward(ctx, h, q, index, qmap, plan, params):
         f_prev = Fo0
         for i in range(1, n_pre):
             total += _al(L.i3d_panel_packed_bytes(f_prev, pre_p[i][0].shape[0]) // 4)
+            total += _al(L.i3d_panel_packed_bytes(pre_p[i][0].shape[0], f_prev) // 4)
             f_prev = pre_p[i][0].shape[0]
     for i, spec in enumerate(plan.post_specs):
         Fo = post_p[i][0].shape[0]
@@ -188,6 +189,7 @@ def forward(ctx, h, q, index, qmap, plan, params):
         c.xact = ar.take(E * Fo)
         if merged:
             c.W_dgrad_panel = ar.take(L.i3d_panel_packed_bytes(f_in, Fo) // 4)
+            c.W_fwd_panel = ar.take(L.i3d_panel_packed_bytes(Fo, f_in) // 4)
         if _keeps_pre(spec):
             c.pre_keep = ar.take(E * Fo)
         if fused:

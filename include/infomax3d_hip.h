@@ -148,6 +148,12 @@ long i3d_panel_packed_bytes(int N, int K);
 int i3d_panel_pack(const float* W, int ldw, int N, int K, int trans, void* packed, void* stream);
 int i3d_panel_gemm(int M, int N, int K, const float* A, int lda, const void* packed, float* C, int ldc, const float* bias,
                    int accumulate, void* stream);
+/* the fused forward of a block behind a never-materialised BatchNorm (i3d_gemm_f32_fused in row-panel form): A read as
+ * (A - mean) * scale + shift (a_aff [3 K], may be NULL), the stored value = act(product + bias), and - stats != NULL - per 32-row
+ * tile and column {sum, M2 about the tile mean, row count} of the stored values: stats [i3d_panel_stats_tiles(M)][3][N] */
+int i3d_panel_stats_tiles(int M);
+int i3d_panel_gemm_fused(int M, int N, int K, const float* A, int lda, const void* packed, float* C, int ldc, const float* bias,
+                         const float* a_aff, int epi_act, float* stats, void* stream);
 
 /* i3d_gemm_f32 with scratch: when the reduction dimension is split over workgroups (weight gradients), the slices are
  * written to workspace[slices][M][N] and summed in a fixed order by a second kernel (deterministic, no zero-fill, no
@@ -711,6 +717,8 @@ typedef struct { /* y = tail(x W^T + b) */
     void* W_dgrad_panel; /* optional: the block's weight packed for the row-panel data gradient (i3d_panel_pack(W, ldw, f_in, f_out,
                           * trans 0): i3d_panel_packed_bytes(f_in, f_out) bytes) - filled by i3d_pna_layer_weights_fwd / the layer's
                           * forward pass, read by its backward pass (dX = dZ W through i3d_panel_gemm).  NULL: the tiled product */
+    void* W_fwd_panel;   /* optional: the same weight packed for the row-panel FORWARD product of the fused-BatchNorm layer path
+                          * (i3d_panel_pack(W, ldw, f_out, f_in, trans 1): i3d_panel_packed_bytes(f_out, f_in) bytes) */
 } I3dFcArgs;
 
 typedef struct { /* y = tail(P[src,:F] + P[dst,F:] + q W_q^T + b),  P = h [W_s|W_d]^T  (reference models/pna.py:237-252) */

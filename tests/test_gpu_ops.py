@@ -82,6 +82,88 @@ def test_split_products_are_fp32_products(M, N, K, tb):
     assert e['bf16'] > 1000 * e['split'], e
 
 
+def _panel_pack(W, N, K, trans):
+    import ctypes
+    _lib = importlib.import_module('3dinfomax_amd._lib')
+    L = _lib.load()
+    packed = torch.empty(L.i3d_panel_packed_bytes(N, K), dtype=torch.uint8, device=DEV)
+    _lib.check(L.i3d_panel_pack(ctypes.c_void_p(W.data_ptr()), W.stride(0), N, K, trans, ctypes.c_void_p(packed.data_ptr()), ops._stream()),
+               'i3d_panel_pack')
+    return packed
+
+
+@pytest.mark.parametrize('M,N,K,trans', [(16638, 200, 200, 1), (16638, 200, 200, 0), (8409, 600, 200, 1), (8409, 200, 600, 0), (8409, 800, 200, 0),
+                                         (1, 200, 200, 1), (63, 4, 8, 1), (65, 212, 40, 0), (300, 416, 72, 1), (129, 92, 256, 0)])
+def test_row_panel_gemm_against_fp64_and_the_tiled_kernels(M, N, K, trans):
+    """csrc/panel.hip: C (+)= A op(W) (+ bias) from the weight packed once into its three bf16 images, A read and split once per
+    208-column block - the split-product arithmetic of the tiled kernels (nn.Linear forward and data gradient, reference
+    models/base_layers.py:101): against the fp64 product not further away than the tiled split form; ragged row / column / K tails,
+    the accumulate form, a wider output row pitch."""
+    import ctypes
+    _lib = importlib.import_module('3dinfomax_amd._lib')
+    L = _lib.load()
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None      # noqa: E731
+    A = g(rnd(M, K, seed=1))
+    W = g((rnd(N, K, seed=2) if trans else rnd(K, N, seed=2)) * K ** -0.5)
+    bias = g(rnd(N, seed=3))
+    ref = A.double() @ (W.double().T if trans else W.double()) + bias.double()
+    packed = _panel_pack(W, N, K, trans)
+    ldc = N + 8
+    C = torch.full((M, ldc), 7.0, device=DEV)
+    _lib.check(L.i3d_panel_gemm(M, N, K, p(A), K, p(packed), p(C), ldc, p(bias), 0, ops._stream()), 'i3d_panel_gemm')
+    assert torch.all(C[:, N:] == 7.0)
+    prev = ops.get_fp32_products()
+    try:
+        ops.set_fp32_products('split')
+        tiled = ops.gemm(A, W, trans_b=bool(trans), bias=bias)
+    finally:
+        ops.set_fp32_products(prev)
+    scale = float(ref.abs().max())
+    e_panel, e_tiled = float((C[:, :N].double() - ref).abs().max()) / scale, float((tiled.double() - ref).abs().max()) / scale
+    assert e_panel < 2e-6 and e_panel <= 1.5 * e_tiled + 1e-7, (e_panel, e_tiled)
+    C2 = C.clone()
+    _lib.check(L.i3d_panel_gemm(M, N, K, p(A), K, p(packed), p(C2), ldc, None, 1, ops._stream()), 'i3d_panel_gemm')
+    assert float((C2[:, :N].double() - (2 * ref - bias.double())).abs().max()) / scale < 4e-6 and torch.all(C2[:, N:] == 7.0)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('M,N,K,act', [(16638, 200, 200, None), (5000, 200, 200, 'relu'), (777, 64, 40, 'leakyrelu'), (31, 200, 200, None)])
+def test_row_panel_gemm_fused_with_batchnorm_prologue_and_statistics(M, N, K, act):
+    """i3d_panel_gemm_fused against i3d_gemm_f32_fused (csrc/gemm.hip FUSE 3): the BatchNorm-apply prologue on A, bias, activation,
+    and per-tile column statistics of the stored values - 32-row tiles here, 64-row tiles there; the finalised mean / invstd (and
+    aff) of the two agree to rounding, the outputs to the split form's rounding."""
+    import ctypes
+    _lib = importlib.import_module('3dinfomax_amd._lib')
+    L = _lib.load()
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None      # noqa: E731
+    A, W, bias, aff = g(rnd(M, K, seed=1) + 0.7), g(rnd(N, K, seed=2) * K ** -0.5), g(rnd(N, seed=3)), g(rnd(3, K, seed=4))
+    gamma, beta = g(rnd(N, seed=5) * 0.2 + 1), g(rnd(N, seed=6) * 0.2)
+    a = aff.double()
+    acts = {None: lambda t: t, 'relu': F.relu, 'leakyrelu': F.leaky_relu}
+    ref = acts[act](((A.double() - a[0]) * a[1] + a[2]) @ W.double().T + bias.double())
+    prev = ops.get_fp32_products()
+    try:
+        ops.set_fp32_products('split')
+        out_t, part_t, tiles_t = ops.gemm_fused(A, W, bias, aff, act)
+    finally:
+        ops.set_fp32_products(prev)
+    packed = _panel_pack(W, N, K, 1)
+    tiles = L.i3d_panel_stats_tiles(M)
+    out_p = torch.empty(M, N, device=DEV)
+    part_p = torch.full((tiles, 3, N), float('nan'), device=DEV)
+    _lib.check(L.i3d_panel_gemm_fused(M, N, K, p(A), K, p(packed), p(out_p), N, p(bias), p(aff), _lib.ACT[act], p(part_p), ops._stream()),
+               'i3d_panel_gemm_fused')
+    scale = float(ref.abs().max())
+    assert float((out_p.double() - ref).abs().max()) / scale < 2e-6
+    assert float((out_p - out_t).abs().max()) / scale < 2e-6
+    assert not torch.isnan(part_p).any() and float(part_p[:, 2, 0].sum()) == M
+    m_t, i_t, aff_t = ops.bn_finalize_partials(part_t, tiles_t, N, 1e-5, 0.1, gamma, beta)
+    m_p, i_p, aff_p = ops.bn_finalize_partials(part_p, tiles, N, 1e-5, 0.1, gamma, beta)
+    ref_mean, ref_var = ref.mean(0), ref.var(0, unbiased=False)
+    assert rel_err(m_p.cpu(), ref_mean.float().cpu()) < 1e-5 and rel_err(i_p.cpu(), (1 / torch.sqrt(ref_var + 1e-5)).float().cpu()) < 2e-5
+    assert rel_err(m_p.cpu(), m_t.cpu()) < 2e-6 and rel_err(i_p.cpu(), i_t.cpu()) < 5e-6 and rel_err(aff_p.cpu(), aff_t.cpu()) < 5e-6
+
+
 def test_split_products_with_non_finite_operands():
     """What include/infomax3d_hip.h states about the split form (the library default) on operands an fp32 product handles and a
     three-part bf16 split does not: +-Inf and |x| > 3.39e38 (bf16 RNE of `hi` overflows) leave a NaN remainder - the outputs that
