@@ -68,7 +68,7 @@ class PnaLayerArgs(ctypes.Structure):
                 ('postx', FcArgs * 3), ('residual', c_int), ('grad_out', _P), ('agg_event_start', _P), ('agg_event_stop', _P),
                 ('fused_bn', c_int), ('defer_join', c_int), ('stats_ws', _P), ('aff', _P * 4), ('weights_ready', c_int),
                 ('merge_h', c_int), ('Wcat', _P), ('bcat', _P), ('PL', _P), ('DL', _P), ('wgrad_split', c_int), ('eval_mode', c_int), ('msg_bf16', c_int),
-                ('edge_bias_partial', _P), ('Wcat_panel', _P)]
+                ('edge_bias_partial', _P), ('Wcat_panel', _P), ('Wcat_dgrad_panel', _P)]
 
 
 class Net3dEdgeArgs(ctypes.Structure):

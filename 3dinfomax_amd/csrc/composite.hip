@@ -98,9 +98,9 @@ int join_wgrad(Aux* x, void* main) {
 // the row-panel product (panel.hip) takes a packed weight: fp32 mode with split products, K % 8 == 0, N % 4 == 0 - and pays where the
 // reduction is short (K <= 256: 34 -> 21 us at [E,200]x[200,200], 31 -> 22 us at [N,200]x[600,200]^T; level at K = 600 / 800:
 // profiles/r06_panel_bench.txt)
-static bool panel_ok(const void* packed, int K, int N) {
+static bool panel_ok(const void* packed, int K, int N, int k_max = 256) {
     static const bool on = [] { const char* e = getenv("I3D_PANEL_GEMM"); return e == nullptr || e[0] != '0'; }();      // (A/B)
-    return on && packed != nullptr && i3d_get_matmul_precision() == 0 && i3d_get_fp32_products() == 1 && K % 8 == 0 && K <= 256 && N % 4 == 0;
+    return on && packed != nullptr && i3d_get_matmul_precision() == 0 && i3d_get_fp32_products() == 1 && K % 8 == 0 && K <= k_max && N % 4 == 0;
 }
 
 static int tail_fwd(const I3dBnTail* t, int rows, int f_out, float* pre, float* xact, const float* residual, float* y,
@@ -330,6 +330,8 @@ static int pack_layer_weights(const I3dPnaLayerArgs* a, void* stream) {
     const I3dGroupedFcArgs* p = &a->post;
     TRY(i3d_pna_pack_h_weights(e->W, e->ldw, e->f_out, p->W, p->ldw, p->f_out, p->bias, e->f_h, a->Wcat, a->bcat, stream));
     if (a->Wcat_panel != nullptr) TRY(i3d_panel_pack(a->Wcat, e->f_h, 2 * e->f_out + p->f_out, e->f_h, 1, a->Wcat_panel, stream));
+    if (a->Wcat_dgrad_panel != nullptr)
+        TRY(i3d_panel_pack(a->Wcat, e->f_h, e->f_h, 2 * e->f_out + p->f_out, 0, a->Wcat_dgrad_panel, stream));
     for (int i = 0; i < a->n_pre_extra; ++i)
         if (a->pre[i].W_dgrad_panel != nullptr)
             TRY(i3d_panel_pack(a->pre[i].W, a->pre[i].ldw, a->pre[i].f_in, a->pre[i].f_out, 0, a->pre[i].W_dgrad_panel, stream));
@@ -713,8 +715,12 @@ extern "C" int i3d_pna_layer_bwd(const I3dPnaLayerArgs* a, void* stream) {
     }
     if (merged) {
         const int WLb = 2 * a->edge.f_out + a->post.f_out;
-        TRY(i3d_gemm_f32(0, 0, a->edge.num_nodes, a->edge.f_h, WLb, a->DL, WLb, a->Wcat, a->edge.f_h, a->post.grad_h, a->edge.f_h,
-                         nullptr, inplace ? 1 : 0, stream));
+        if (panel_ok(a->Wcat_dgrad_panel, WLb, a->edge.f_h, 1024) && (((uintptr_t)a->DL | (uintptr_t)a->post.grad_h) & 15) == 0)
+            TRY(i3d_panel_gemm(a->edge.num_nodes, a->edge.f_h, WLb, a->DL, WLb, a->Wcat_dgrad_panel, a->post.grad_h, a->edge.f_h, nullptr,
+                               inplace ? 1 : 0, stream));      // (32-row slabs at batch 512: 37 -> 27 us)
+        else
+            TRY(i3d_gemm_f32(0, 0, a->edge.num_nodes, a->edge.f_h, WLb, a->DL, WLb, a->Wcat, a->edge.f_h, a->post.grad_h, a->edge.f_h,
+                             nullptr, inplace ? 1 : 0, stream));
         if (a->residual && !inplace) TRY(i3d_add_inplace(a->post.grad_h, a->grad_out, n, stream));
     } else {
         TRY(edge_fc_bn_bwd_dgrad(&a->edge, stream, a->post.grad_h));       // post.grad_h += edge block's dh

@@ -264,6 +264,7 @@ long plan_forward(PnaCtx& c, float* saved, float* node_emb, float* out) {
             a.bcat = ar.take(2 * Fo0 + F);
             a.PL = ar.take((long)N * (2 * Fo0 + F));
             a.Wcat_panel = ar.take(i3d_panel_packed_bytes(2 * Fo0 + F, F) / 4);      // (csrc/panel.hip; packed where Wcat is)
+            a.Wcat_dgrad_panel = ar.take(i3d_panel_packed_bytes(F, 2 * Fo0 + F) / 4);
         }
         e.xact = ar.take((long)E * Fo0);
         a.aff[0] = ar.take(3L * Fo0);

@@ -106,7 +106,8 @@ struct PanelArgs {
                                  // the stored values (bn_finalize_partials_kernel merges the tiles)
 };
 
-template <bool AFF, bool STATS>
+// RT: 16-row tiles per wave (2: 64 rows per workgroup; 1: 32 rows - twice the workgroups where 64-row slabs leave CUs idle)
+template <bool AFF, bool STATS, int RT>
 __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
     I3D_CHAIN_PRIO();
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2][STEP_BYTES];
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
     const int rt = wave >> 1, ch = wave & 1;
     const int j0 = ch * 7, nj = ch ? PT - 7 : 7;
     const int cb = blockIdx.y;
-    const int m0 = blockIdx.x * PBM + rt * 32;
+    const int m0 = blockIdx.x * (32 * RT) + rt * (16 * RT);
     const int KT = (g.K + PBK - 1) / PBK;
     const unsigned char* bsrc = g.Bp + (long)cb * KT * STEP_BYTES;
 
@@ -141,13 +142,13 @@ __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
     // A: ordinary loads (the compiler keeps their values safe: asm-load results may be copied before they land); issued right after
     // the step's barrier and first used BEHIND the step's MFMAs, where the compiler's vmcnt(0) is the wait the next step needs anyway
     struct AStep {
-        float4 v[2][2];
+        float4 v[RT][2];
         float4 f[3][2];      // AFF: mean | scale | shift of the lane's 8 k
     };
     auto load_a = [&](int t, AStep& r) {
         const int k = t * PBK + akc;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RT; ++i) {
             const int row = m0 + i * 16 + arow;
             if (row < g.M && k < g.K) {            // K % 8 == 0: a lane's 8 k are valid or not as a whole
                 const float4* p = reinterpret_cast<const float4*>(g.A + (long)row * g.lda + k);
@@ -167,10 +168,10 @@ __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
             }
         }
     };
-    auto split_a = [&](int t, const AStep& r, bf16x8 (&h)[2], bf16x8 (&m)[2], bf16x8 (&l)[2]) {
+    auto split_a = [&](int t, const AStep& r, bf16x8 (&h)[RT], bf16x8 (&m)[RT], bf16x8 (&l)[RT]) {
         const bool kok = t * PBK + akc < g.K;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RT; ++i) {
             float4 x0 = r.v[i][0], x1 = r.v[i][1];
             if (AFF) {       // gemm.hip store_aff's expression: the same bits; lanes outside the matrix stay exact zeros
                 const bool ok = kok && m0 + i * 16 + arow < g.M;
@@ -184,13 +185,13 @@ __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
         }
     };
 
-    floatx4 acc[2][7];
+    floatx4 acc[RT][7];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < 7; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    bf16x8 ah[2], am[2], al[2];
+    bf16x8 ah[RT], am[RT], al[RT];
     {
         AStep a0;
         stage_b(0, 0);
@@ -214,19 +215,19 @@ __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bl + (j * 3 + 0) * PIECE);
                 const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bl + (j * 3 + 1) * PIECE);
                 const bf16x8 bo = *reinterpret_cast<const bf16x8*>(bl + (j * 3 + 2) * PIECE);
-                // small products first; consecutive MFMAs alternate between the two row tiles' accumulators
-                acc[0][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bo, ah[0], acc[0][jj], 0, 0, 0);
-                acc[1][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bo, ah[1], acc[1][jj], 0, 0, 0);
-                acc[0][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[0], acc[0][jj], 0, 0, 0);
-                acc[1][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[1], acc[1][jj], 0, 0, 0);
-                acc[0][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am[0], acc[0][jj], 0, 0, 0);
-                acc[1][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am[1], acc[1][jj], 0, 0, 0);
-                acc[0][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah[0], acc[0][jj], 0, 0, 0);
-                acc[1][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah[1], acc[1][jj], 0, 0, 0);
-                acc[0][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am[0], acc[0][jj], 0, 0, 0);
-                acc[1][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am[1], acc[1][jj], 0, 0, 0);
-                acc[0][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[0], acc[0][jj], 0, 0, 0);
-                acc[1][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[1], acc[1][jj], 0, 0, 0);
+                // small products first; consecutive MFMAs alternate between the row tiles' accumulators
+#pragma unroll
+                for (int i = 0; i < RT; ++i) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bo, ah[i], acc[i][jj], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < RT; ++i) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[i], acc[i][jj], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < RT; ++i) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am[i], acc[i][jj], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < RT; ++i) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah[i], acc[i][jj], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < RT; ++i) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am[i], acc[i][jj], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < RT; ++i) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[i], acc[i][jj], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);       // the split of step t + 1 (and its wait for the A values) stays behind the MFMAs
@@ -234,7 +235,9 @@ __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
     }
     // epilogue: lane owns row (lane & 15) of a row tile, columns (lane >> 4) * 4 .. + 3 of a column tile
     const int row_lo = m0 + (lane & 15);
-    const bool rok[2] = {row_lo < g.M, row_lo + 16 < g.M};
+    bool rok[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) rok[i] = row_lo + 16 * i < g.M;
 #pragma unroll
     for (int jj = 0; jj < 7; ++jj) {
         if (jj >= nj) continue;
@@ -242,9 +245,9 @@ __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
         const bool cok = col < g.N;               // N % 4 == 0
         float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (cok && g.bias != nullptr) b4 = *reinterpret_cast<const float4*>(g.bias + col);
-        floatx4 v[2];
+        floatx4 v[RT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RT; ++i) {
             v[i] = acc[i][jj];
             v[i][0] += b4.x; v[i][1] += b4.y; v[i][2] += b4.z; v[i][3] += b4.w;
             if (rok[i] && cok) {
@@ -261,11 +264,15 @@ __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
             }
         }
         if (STATS) {
-            // column statistics of this wave's 32-row tile: lane sums over its two rows, then over the 16 lanes that share the columns
+            // column statistics of this wave's 16 RT-row tile: lane sums over its rows, then over the 16 lanes that share the columns
             // (xor 1, 2, 4, 8: a fixed tree), the tile mean, M2 about it the same way
-            float s[4], cnt = (rok[0] ? 1.f : 0.f) + (rok[1] ? 1.f : 0.f);
+            float s[4] = {0.f, 0.f, 0.f, 0.f}, cnt = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) s[q] = (rok[0] ? v[0][q] : 0.f) + (rok[1] ? v[1][q] : 0.f);
+            for (int i = 0; i < RT; ++i) {
+                cnt += rok[i] ? 1.f : 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s[q] += rok[i] ? v[i][q] : 0.f;
+            }
 #pragma unroll
             for (int m = 1; m < 16; m <<= 1) {
 #pragma unroll
@@ -276,15 +283,19 @@ __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float mean_t = cnt > 0.f ? s[q] / cnt : 0.f;
-                const float d0 = v[0][q] - mean_t, d1 = v[1][q] - mean_t;
-                m2[q] = (rok[0] ? d0 * d0 : 0.f) + (rok[1] ? d1 * d1 : 0.f);
+                m2[q] = 0.f;
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+                    const float d = v[i][q] - mean_t;
+                    m2[q] += rok[i] ? d * d : 0.f;
+                }
             }
 #pragma unroll
             for (int m = 1; m < 16; m <<= 1)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) m2[q] += __shfl_xor(m2[q], m, 64);
             if ((lane & 15) == 0 && cok) {
-                float* o = g.stats + (long)(blockIdx.x * 2 + rt) * 3 * g.N + col;
+                float* o = g.stats + (long)(blockIdx.x * 2 + rt) * 3 * g.N + col;      // (STATS: RT == 2)
                 *reinterpret_cast<float4*>(o) = make_float4(s[0], s[1], s[2], s[3]);
                 *reinterpret_cast<float4*>(o + g.N) = make_float4(m2[0], m2[1], m2[2], m2[3]);
                 *reinterpret_cast<float4*>(o + 2 * g.N) = make_float4(cnt, cnt, cnt, cnt);
@@ -318,12 +329,21 @@ static int panel_launch(int M, int N, int K, const float* A, int lda, const void
                   "16-byte aligned operands");
     I3D_CHECK_ARG(stats == nullptr || relu_class(act), "epilogue activation: none, ReLU or LeakyReLU");
     PanelArgs g{A, lda, M, K, N, (const unsigned char*)packed, C, ldc, bias, accumulate ? 1 : 0, aff, act, stats};
-    const dim3 grid(cdiv(M, PBM), cdiv(N, PN)), block(256);
+    // 64-row slabs where they fill the chip, 32-row slabs (same kernel, one row tile per wave) where they would leave CUs idle;
+    // the statistics form keeps 64-row workgroups (its tile count is part of the interface: i3d_panel_stats_tiles)
+    static const int force_rt = [] { const char* e = getenv("I3D_PANEL_RT"); return e ? atoi(e) : 0; }();
+    const bool rt1 = stats == nullptr && (force_rt ? force_rt == 1 : (long)cdiv(M, PBM) * cdiv(N, PN) < 256);
+    const dim3 grid(cdiv(M, rt1 ? 32 : PBM), cdiv(N, PN)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (aff != nullptr && stats != nullptr) hipLaunchKernelGGL((panel_gemm_kernel<true, true>), grid, block, 0, s, g);
-    else if (aff != nullptr) hipLaunchKernelGGL((panel_gemm_kernel<true, false>), grid, block, 0, s, g);
-    else if (stats != nullptr) hipLaunchKernelGGL((panel_gemm_kernel<false, true>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((panel_gemm_kernel<false, false>), grid, block, 0, s, g);
+    if (aff != nullptr && stats != nullptr) hipLaunchKernelGGL((panel_gemm_kernel<true, true, 2>), grid, block, 0, s, g);
+    else if (stats != nullptr) hipLaunchKernelGGL((panel_gemm_kernel<false, true, 2>), grid, block, 0, s, g);
+    else if (aff != nullptr) {
+        if (rt1) hipLaunchKernelGGL((panel_gemm_kernel<true, false, 1>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((panel_gemm_kernel<true, false, 2>), grid, block, 0, s, g);
+    } else {
+        if (rt1) hipLaunchKernelGGL((panel_gemm_kernel<false, false, 1>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((panel_gemm_kernel<false, false, 2>), grid, block, 0, s, g);
+    }
     I3D_CHECK_LAUNCH();
     return I3D_OK;
 }

@@ -131,7 +131,7 @@ def forward(ctx, h, q, index, qmap, plan, params):
     if merged:
         total += _al(WL * Fh) + _al(WL) + _al(N * WL)
         # the packed weights of the row-panel products (csrc/panel.hip): Wcat forward, the later pretrans blocks' data gradients
-        total += _al(L.i3d_panel_packed_bytes(WL, Fh) // 4)
+        total += _al(L.i3d_panel_packed_bytes(WL, Fh) // 4) + _al(L.i3d_panel_packed_bytes(Fh, WL) // 4)
         f_prev = Fo0
         for i in range(1, n_pre):
             total += _al(L.i3d_panel_packed_bytes(f_prev, pre_p[i][0].shape[0]) // 4)
@@ -167,6 +167,7 @@ def forward(ctx, h, q, index, qmap, plan, params):
         a.merge_h = 1
         a.Wcat, a.bcat, a.PL = ar.take(WL * Fh), ar.take(WL), ar.take(N * WL)
         a.Wcat_panel = ar.take(L.i3d_panel_packed_bytes(WL, Fh) // 4)
+        a.Wcat_dgrad_panel = ar.take(L.i3d_panel_packed_bytes(Fh, WL) // 4)
     e.xact = ar.take(E * Fo0)
     if _keeps_pre(spec):
         e.pre_keep = ar.take(E * Fo0)

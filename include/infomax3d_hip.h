@@ -842,6 +842,8 @@ typedef struct { /* one PNA layer, reference models/pna.py:199-216: pretrans edg
                         * bias gradient is taken from dP[dst] on the weight-gradient stream through this buffer */
     void* Wcat_panel;  /* optional (merge_h): Wcat packed for the row-panel forward product PL = h Wcat^T + bcat (i3d_panel_pack, trans 1:
                         * i3d_panel_packed_bytes(2 f_out(edge) + f_out(post), f_h) bytes), packed where Wcat is.  NULL: the tiled product */
+    void* Wcat_dgrad_panel; /* optional (merge_h): Wcat packed for the backward product dL/dh (+)= DL Wcat (trans 0:
+                        * i3d_panel_packed_bytes(f_h, 2 f_out(edge) + f_out(post)) bytes) */
 } I3dPnaLayerArgs;
 
 /* eval-mode affine vector of one BatchNorm: aff [3 feat] = running_mean | gamma / sqrt(running_var + eps) | beta */
