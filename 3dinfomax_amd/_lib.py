@@ -239,6 +239,7 @@ _SIGNATURES = {
     'i3d_set_bn_bwd_one_launch': (c_int, [c_int]),
     'i3d_panel_packed_bytes': (c_long, [c_int, c_int]),
     'i3d_panel_pack': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    'i3d_panel_pack_multi': (c_int, [_P, c_int, _P]),
     'i3d_panel_gemm': (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P]),
     'i3d_panel_stats_tiles': (c_int, [c_int]),
     'i3d_panel_gemm_fused': (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, _P, c_int, _P, _P]),

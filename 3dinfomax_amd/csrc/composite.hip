@@ -329,15 +329,17 @@ static int pack_layer_weights(const I3dPnaLayerArgs* a, void* stream) {
     const I3dEdgeFcArgs* e = &a->edge;
     const I3dGroupedFcArgs* p = &a->post;
     TRY(i3d_pna_pack_h_weights(e->W, e->ldw, e->f_out, p->W, p->ldw, p->f_out, p->bias, e->f_h, a->Wcat, a->bcat, stream));
-    if (a->Wcat_panel != nullptr) TRY(i3d_panel_pack(a->Wcat, e->f_h, 2 * e->f_out + p->f_out, e->f_h, 1, a->Wcat_panel, stream));
-    if (a->Wcat_dgrad_panel != nullptr)
-        TRY(i3d_panel_pack(a->Wcat, e->f_h, e->f_h, 2 * e->f_out + p->f_out, 0, a->Wcat_dgrad_panel, stream));
-    for (int i = 0; i < a->n_pre_extra; ++i)
-        if (a->pre[i].W_dgrad_panel != nullptr)
-            TRY(i3d_panel_pack(a->pre[i].W, a->pre[i].ldw, a->pre[i].f_in, a->pre[i].f_out, 0, a->pre[i].W_dgrad_panel, stream));
-    for (int i = 0; i < a->n_pre_extra; ++i)
-        if (a->pre[i].W_fwd_panel != nullptr)
-            TRY(i3d_panel_pack(a->pre[i].W, a->pre[i].ldw, a->pre[i].f_out, a->pre[i].f_in, 1, a->pre[i].W_fwd_panel, stream));
+    I3dPanelPack w[8];          // ONE pack launch for the layer (16 launches of ~6 us per step as separate ones)
+    int n = 0;
+    const int WL = 2 * e->f_out + p->f_out;
+    if (a->Wcat_panel != nullptr) w[n++] = I3dPanelPack{a->Wcat, e->f_h, WL, e->f_h, 1, a->Wcat_panel};
+    if (a->Wcat_dgrad_panel != nullptr) w[n++] = I3dPanelPack{a->Wcat, e->f_h, e->f_h, WL, 0, a->Wcat_dgrad_panel};
+    for (int i = 0; i < a->n_pre_extra && n + 2 <= 8; ++i) {
+        const I3dFcArgs* c = &a->pre[i];
+        if (c->W_dgrad_panel != nullptr) w[n++] = I3dPanelPack{c->W, c->ldw, c->f_in, c->f_out, 0, c->W_dgrad_panel};
+        if (c->W_fwd_panel != nullptr) w[n++] = I3dPanelPack{c->W, c->ldw, c->f_out, c->f_in, 1, c->W_fwd_panel};
+    }
+    if (n > 0) TRY(i3d_panel_pack_multi(w, n, stream));
     return I3D_OK;
 }
 

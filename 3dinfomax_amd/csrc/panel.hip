@@ -19,6 +19,9 @@
 //     never share an accumulator; mfma(B fragment, A fragment): a lane owns 4 consecutive columns of one row -> 16-byte stores.
 #include <stdlib.h>
 
+#include <algorithm>
+#include <type_traits>
+
 #include "common.h"
 
 namespace i3d {
@@ -65,9 +68,17 @@ struct PackArgs {
     unsigned short* out;
 };
 
-__global__ void __launch_bounds__(256) panel_pack_kernel(PackArgs a) {
+constexpr int PACK_MAX = 8;
+struct PackMulti {
+    PackArgs a[PACK_MAX];
+};
+
+// blockIdx.z: which weight (one launch packs every weight of a layer); blocks beyond a weight's own (K-steps, column blocks) leave
+__global__ void __launch_bounds__(256) panel_pack_kernel(PackMulti m) {
+    const PackArgs a = m.a[blockIdx.z];
     const int KT = (a.K + PBK - 1) / PBK;
     const int cb = blockIdx.y, t = blockIdx.x;
+    if (t >= KT || cb * PN >= a.N) return;
     unsigned short* dst = a.out + ((long)(cb * KT + t) * STEP_BYTES) / 2;
     for (int q = threadIdx.x; q < PT * 64; q += 256) {       // one (column tile, lane) per trip: 8 k of one column
         const int j = q / 64, lane = q % 64;
@@ -88,6 +99,18 @@ __global__ void __launch_bounds__(256) panel_pack_kernel(PackArgs a) {
         p[PIECE / 16] = um;
         p[2 * PIECE / 16] = ul;
     }
+}
+
+// sum over the 16 lanes of a DPP row (all lanes get it)
+__device__ __forceinline__ float row16_sum(float x) {
+    auto dpp = [](float v, auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    x += dpp(x, std::integral_constant<int, 0xB1>{});       // quad_perm [1, 0, 3, 2]
+    x += dpp(x, std::integral_constant<int, 0x4E>{});       // quad_perm [2, 3, 0, 1]
+    x += dpp(x, std::integral_constant<int, 0x141>{});      // row_half_mirror
+    x += dpp(x, std::integral_constant<int, 0x140>{});      // row_mirror
+    return x;
 }
 
 // ---- the product -------------------------------------------------------------------------------------------------------------------
@@ -266,19 +289,18 @@ __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
         if (STATS) {
             // column statistics of this wave's 16 RT-row tile: lane sums over its rows, then over the 16 lanes that share the columns
             // (xor 1, 2, 4, 8: a fixed tree), the tile mean, M2 about it the same way
-            float s[4] = {0.f, 0.f, 0.f, 0.f}, cnt = 0.f;
+            // (the 16 lanes are one DPP row: quad_perm xor 1, xor 2, row_half_mirror, row_mirror - VALU adds, no LDS crossbar;
+            // both lanes of a pair add the same two numbers: the same bits in every lane)
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
-                cnt += rok[i] ? 1.f : 0.f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) s[q] += rok[i] ? v[i][q] : 0.f;
             }
 #pragma unroll
-            for (int m = 1; m < 16; m <<= 1) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) s[q] += __shfl_xor(s[q], m, 64);
-                cnt += __shfl_xor(cnt, m, 64);
-            }
+            for (int q = 0; q < 4; ++q) s[q] = row16_sum(s[q]);
+            const int rows_here = min(max(g.M - m0, 0), 16 * RT);
+            const float cnt = (float)rows_here;
             float m2[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -289,11 +311,8 @@ __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
                     const float d = v[i][q] - mean_t;
                     m2[q] += rok[i] ? d * d : 0.f;
                 }
+                m2[q] = row16_sum(m2[q]);
             }
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) m2[q] += __shfl_xor(m2[q], m, 64);
             if ((lane & 15) == 0 && cok) {
                 float* o = g.stats + (long)(blockIdx.x * 2 + rt) * 3 * g.N + col;      // (STATS: RT == 2)
                 *reinterpret_cast<float4*>(o) = make_float4(s[0], s[1], s[2], s[3]);
@@ -313,12 +332,25 @@ extern "C" long i3d_panel_packed_bytes(int N, int K) {
     return (long)cdiv(N, PN) * cdiv(K, PBK) * STEP_BYTES;
 }
 
-extern "C" int i3d_panel_pack(const float* W, int ldw, int N, int K, int trans, void* packed, void* stream) {
-    I3D_CHECK_ARG(W != nullptr && packed != nullptr && N > 0 && K > 0 && ldw >= (trans ? K : N), "bad arguments");
-    PackArgs a{W, ldw, N, K, trans, (unsigned short*)packed};
-    hipLaunchKernelGGL(panel_pack_kernel, dim3(cdiv(K, PBK), cdiv(N, PN)), dim3(256), 0, (hipStream_t)stream, a);
+extern "C" int i3d_panel_pack_multi(const I3dPanelPack* w, int n, void* stream) {
+    I3D_CHECK_ARG(w != nullptr && n >= 1 && n <= PACK_MAX, "1..8 weights per launch");
+    PackMulti m = {};
+    int kt = 1, nb = 1;
+    for (int i = 0; i < n; ++i) {
+        I3D_CHECK_ARG(w[i].W != nullptr && w[i].packed != nullptr && w[i].N > 0 && w[i].K > 0 && w[i].ldw >= (w[i].trans ? w[i].K : w[i].N) &&
+                          (((uintptr_t)w[i].packed) & 15) == 0, "bad arguments");
+        m.a[i] = PackArgs{w[i].W, w[i].ldw, w[i].N, w[i].K, w[i].trans, (unsigned short*)w[i].packed};
+        kt = std::max(kt, cdiv(w[i].K, PBK));
+        nb = std::max(nb, cdiv(w[i].N, PN));
+    }
+    hipLaunchKernelGGL(panel_pack_kernel, dim3(kt, nb, n), dim3(256), 0, (hipStream_t)stream, m);
     I3D_CHECK_LAUNCH();
     return I3D_OK;
+}
+
+extern "C" int i3d_panel_pack(const float* W, int ldw, int N, int K, int trans, void* packed, void* stream) {
+    const I3dPanelPack w{W, ldw, N, K, trans, packed};
+    return i3d_panel_pack_multi(&w, 1, stream);
 }
 
 static int panel_launch(int M, int N, int K, const float* A, int lda, const void* packed, float* C, int ldc, const float* bias,

@@ -666,6 +666,42 @@ def gemm_fused(A, W, bias=None, a_aff=None, act=None, want_stats=True, out=None,
     return out, partial, tiles
 
 
+def panel_pack(W, trans):
+    """The weight of a Linear packed for the row-panel products (csrc/panel.hip): its three bf16 images in the LDS layout of the product
+    kernel.  trans=True: B[n][k] = W[n, k] (forward, W stored [out, in]); False: B[n][k] = W[k, n] (data gradient).  -> uint8 tensor"""
+    _chk(W)
+    N, K = (W.shape[0], W.shape[1]) if trans else (W.shape[1], W.shape[0])
+    L = _lib.load()
+    packed = torch.empty(L.i3d_panel_packed_bytes(N, K), dtype=torch.uint8, device=W.device)
+    check(L.i3d_panel_pack(_p(W), W.stride(0), N, K, int(bool(trans)), _p(packed), _stream()), 'i3d_panel_pack')
+    return packed, N, K
+
+
+def panel_gemm(A, packed, N, bias=None, out=None, accumulate=False):
+    """out (+)= A B^T (+ bias) with B packed by panel_pack: every 64-row (or 32-row) slab of A read and split once per 208 columns"""
+    _chk(A)
+    M, K = A.shape
+    if out is None:
+        assert not accumulate
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    check(_lib.load().i3d_panel_gemm(M, N, K, _p(A), A.stride(0), _p(packed), _p(out), out.stride(0), _p(bias), int(accumulate), _stream()),
+          'i3d_panel_gemm')
+    return out
+
+
+def panel_gemm_fused(A, packed, N, bias=None, a_aff=None, act=None, want_stats=True):
+    """gemm_fused in row-panel form -> (out, partial [tiles, 3, N] of 32-row tiles or None, tiles)"""
+    _chk(A)
+    M, K = A.shape
+    L = _lib.load()
+    out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    tiles = L.i3d_panel_stats_tiles(M)
+    partial = torch.empty(tiles, 3, N, dtype=torch.float32, device=A.device) if want_stats else None
+    check(L.i3d_panel_gemm_fused(M, N, K, _p(A), A.stride(0), _p(packed), _p(out), N, _p(bias), _p(a_aff), ACT[act], _p(partial), _stream()),
+          'i3d_panel_gemm_fused')
+    return out, partial, tiles
+
+
 def gemm_wgrad_bn(dY, x, grad_bias, aff):
     """dW = dY^T ((x - mean) * scale + shift) from the raw x (aff [3, f_in]); grad_bias = column sums of dY"""
     _chk(dY), _chk(x)

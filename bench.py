@@ -831,6 +831,15 @@ def main():
             gradient_bytes=int(red.flat.numel() * 4), overlapped_with_backward=bool(red.overlap and world > 1),
             note='the gradient all-reduce of the head and the upper half of the PNA layers is started in the middle of the '
                  'backward pass (dist.GradReducer.launch_async), the rest after it')
+        # sanity line for the first real multi-GPU run: a ring all-reduce of G bytes moves 2 (n - 1) / n G bytes per GPU over its
+        # xGMI links (7 links x ~153 GB/s per GPU, task statement); an all-reduce that takes >= 10 x that is not running over xGMI
+        # (PCIe / host-staged fallback) - flagged, not fatal
+        gbytes = float(red.flat.numel() * 4)
+        xgmi_us = 2.0 * (world - 1) / max(world, 1) * gbytes / (7 * 153e9) * 1e6 if world > 1 else 0.0
+        collectives['allreduce_xgmi_floor_us'] = round(xgmi_us, 1)
+        collectives['allreduce_vs_xgmi_floor'] = round(collectives['allreduce_all_gradients_us'] / xgmi_us, 1) if xgmi_us > 0 else None
+        collectives['suspect_not_xgmi'] = bool(xgmi_us > 0 and collectives['allreduce_all_gradients_us'] > 10.0 * xgmi_us and
+                                               args.backend != 'gloo')
     families = step_line = None
     if rank == 0 and roof is not None and not args.no_families:
         fb = importlib.import_module('tools.family_bench')

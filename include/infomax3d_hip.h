@@ -146,6 +146,12 @@ int i3d_get_fp32_products(void);
  * 16-byte aligned rows.  Same arithmetic as the split form of i3d_gemm_f32 (six bf16 part products, fp32 accumulation). */
 long i3d_panel_packed_bytes(int N, int K);
 int i3d_panel_pack(const float* W, int ldw, int N, int K, int trans, void* packed, void* stream);
+typedef struct {
+    const float* W;
+    int ldw, N, K, trans;
+    void* packed;
+} I3dPanelPack;
+int i3d_panel_pack_multi(const I3dPanelPack* weights, int n, void* stream); /* up to 8 weights (a layer's) in ONE launch */
 int i3d_panel_gemm(int M, int N, int K, const float* A, int lda, const void* packed, float* C, int ldc, const float* bias,
                    int accumulate, void* stream);
 /* the fused forward of a block behind a never-materialised BatchNorm (i3d_gemm_f32_fused in row-panel form): A read as

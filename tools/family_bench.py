@@ -35,6 +35,14 @@ def _time(fn, reps=20):
     return a.elapsed_time(b) / reps * 1e3          # us
 
 
+def _two_pass_bn(ops, dy, x, mean, invstd, gamma, beta, gb):
+    was = ops.set_bn_bwd_one_launch(False)
+    try:
+        return _time(lambda: ops.bn_bwd(dy, x, None, None, None, mean, invstd, gamma, beta, grad_bias=gb))
+    finally:
+        ops.set_bn_bwd_one_launch(was)
+
+
 def layer_flops(N, E, m_pad, F, n_comb=60):
     """MFMA flops of one PNA layer (hidden F, pretrans 2 blocks, grouped posttrans): forward, data gradients, weight gradients"""
     fwd = 2.0 * N * 2 * F * F + 2.0 * n_comb * F * F + 2.0 * E * F * F + 2.0 * N * F * F + 2.0 * m_pad * 4 * F * F
@@ -64,19 +72,36 @@ def measure(amd, ops, g2, dev, F=200, big_batch=8192):
     Wcat = torch.cat([Wsd, W3[:, :F]], 0).contiguous()                          # [3F, F]
     bias3 = torch.cat([torch.zeros(2 * F, device=dev), bias])
     dPL = rnd(N, 3 * F) * 0.1
+    # round 6: the products whose reduction is short (and the merged dL/dh product) run in row-panel form (csrc/panel.hip) on weights
+    # packed once per step - what the step launches; the tiled forms stay listed next to them
+    pk_cat, _, _ = ops.panel_pack(Wcat, True)
+    pk_w2, _, _ = ops.panel_pack(W2, True)
+    pk_w2d, _, _ = ops.panel_pack(W2, False)
+    pk_catd, _, _ = ops.panel_pack(Wcat, False)
+    tiled = {
+        'tiled fwd PL [N,F]x[3F,F]^T': (lambda: ops.gemm(h, Wcat, trans_b=True, bias=bias3), 2.0 * N * 3 * F * F),
+        'tiled fwd FC2 [E,F]x[F,F]^T + BN prologue + statistics': (lambda: ops.gemm_fused(x1, W2, bias, aff, None), 2.0 * E * F * F),
+        'tiled dgrad FC2 [E,F]x[F,F]': (lambda: ops.gemm(dY_e, W2), 2.0 * E * F * F),
+        'tiled dgrad DL [N,3F]x[3F,F]': (lambda: ops.gemm(dPL, Wcat), 2.0 * N * 3 * F * F),
+    }
     gemms = {
         # the three products that read the node features are ONE GEMM per direction since round 3 (I3dPnaLayerArgs.merge_h):
         # PL = h [W_s ; W_d ; W_h]^T forward, dL/dh = [dP | dlin] [W_s ; W_d ; W_h] backward
-        'fwd PL [N,F]x[3F,F]^T (P | post h)': (lambda: ops.gemm(h, Wcat, trans_b=True, bias=bias3), 2.0 * N * 3 * F * F),
-        'fwd FC2 [E,F]x[F,F]^T + BN prologue + statistics': (lambda: ops.gemm_fused(x1, W2, bias, aff, None), 2.0 * E * F * F),
+        'fwd PL [N,F]x[3F,F]^T (P | post h), row-panel': (lambda: ops.panel_gemm(h, pk_cat, 3 * F, bias=bias3), 2.0 * N * 3 * F * F),
+        'fwd FC2 [E,F]x[F,F]^T + BN prologue + statistics, row-panel': (lambda: ops.panel_gemm_fused(x1, pk_w2, F, bias, aff, None), 2.0 * E * F * F),
         'fwd post agg grouped [N,4F]->F + statistics': (
             lambda: ops.gemm_fused(agg, WD, None, None, None, out=lin3, accumulate=True, m_rows=rows_d, tile_group=tiles_d),
             2.0 * m_pad * 4 * F * F),
-        'dgrad FC2 [E,F]x[F,F]': (lambda: ops.gemm(dY_e, W2), 2.0 * E * F * F),
-        'dgrad DL [N,3F]x[3F,F] (dP | dlin)': (lambda: ops.gemm(dPL, Wcat), 2.0 * N * 3 * F * F),
+        'dgrad FC2 [E,F]x[F,F], row-panel': (lambda: ops.panel_gemm(dY_e, pk_w2d, F), 2.0 * E * F * F),
+        'dgrad DL [N,3F]x[3F,F] (dP | dlin), row-panel': (lambda: ops.panel_gemm(dPL, pk_catd, F), 2.0 * N * 3 * F * F),
         'dgrad post agg grouped [N,F]->4F': (lambda: ops.gemm_grouped(dY_n, rows_d, tiles_d, WD, agg, trans_b=False, accumulate=False),
                                               2.0 * m_pad * 4 * F * F),
     }
+    if not (ops.get_matmul_precision() == 'fp32' and ops.get_fp32_products() == 'split'):
+        # bf16 matmul mode / native fp32 products: the step launches the tiled forms (csrc/composite.hip: panel_ok)
+        gemms = {k: v for k, v in gemms.items() if 'row-panel' not in k}
+        gemms.update({k.replace('tiled ', ''): v for k, v in tiled.items()})
+        tiled = {}
     # all weight gradients of the layer: ONE launch + one reduction (csrc/wgrad.hip) in fp32; the per-product launches of
     # round 2 in the bf16 matmul mode (the panel kernel has no bf16 form yet)
     onehot = torch.zeros(E, 64, device=dev)
@@ -108,8 +133,13 @@ def measure(amd, ops, g2, dev, F=200, big_batch=8192):
         rows.append(dict(kernel=name, us=round(us, 2), tflops=round(fl / us / 1e6, 1), frac=round(fl / us / 1e6 / peak_tf, 3)))
         tot_us += us
         tot_fl += fl
+    tiled_rows = []
+    if ops.get_matmul_precision() == 'fp32':
+        for name, (fn, fl) in tiled.items():
+            us = _time(fn)
+            tiled_rows.append(dict(kernel=name, us=round(us, 2), tflops=round(fl / us / 1e6, 1), frac=round(fl / us / 1e6 / peak_tf, 3)))
     out['gemm'] = dict(bound='mfma', peak=peak_tf, unit='TFLOP/s', achieved=round(tot_fl / tot_us / 1e6, 1),
-                       frac=round(tot_fl / tot_us / 1e6 / peak_tf, 3), kernels=rows,
+                       frac=round(tot_fl / tot_us / 1e6 / peak_tf, 3), kernels=rows, tiled_forms_of_the_row_panel_products=tiled_rows,
                        note='flop-weighted over the GEMM launches of one PNA layer (forward, data gradient, all weight gradients), '
                             'each launched 20 times back to back between one event pair')
 
@@ -124,8 +154,12 @@ def measure(amd, ops, g2, dev, F=200, big_batch=8192):
         'edge gather-combine + ReLU + statistics [E,F]': (lambda: ops.edge_combine_act_stats(P, Q, bias, idx.src_s, idx.dst_s, 'relu', code),
                                                           4.0 * E * F * 3),
         'statistics finalisation': (lambda: ops.bn_finalize_partials(partial, tiles, F, 1e-5, 0.1, gamma, beta), 4.0 * tiles * 3 * F),
-        'backward reduction + data gradient [E,F] (ReLU block)': (
-            lambda: ops.bn_bwd(dY_e, xact, None, 'relu', None, mean, invstd, gamma, beta, grad_bias=gb), 4.0 * E * F * 5),
+        # the chain's form since round 6: ONE launch (csrc/bn.hip: bn_bwd_fused_kernel; dy and x read once, the data gradient written:
+        # 3 tensors) - the pretrans FC2 / posttrans blocks (no activation in front of the BatchNorm: exact-zero bias gradient)
+        'backward, one launch: reduction + data gradient [E,F]': (
+            lambda: ops.bn_bwd(dY_e, xact, None, None, None, mean, invstd, gamma, beta, grad_bias=gb), 4.0 * E * F * 3),
+        'backward, one launch: reduction + data gradient [N,F]': (
+            lambda: ops.bn_bwd(dY_n, lin3, None, None, None, mean, invstd, gamma, beta, grad_bias=gb), 4.0 * N * F * 3),
         'apply + residual [N,F]': (lambda: ops.bn_apply_fwd(lin3, mean, invstd, gamma, beta, None, h), 4.0 * N * F * 3),
     }
     rows, tot_us, tot_b = [], 0.0, 0.0
@@ -136,7 +170,9 @@ def measure(amd, ops, g2, dev, F=200, big_batch=8192):
         tot_b += byts
     out['batchnorm'] = dict(bound='hbm', peak=HBM_PEAK_GBS, unit='GB/s', achieved=round(tot_b / tot_us / 1e3, 1),
                             frac=round(tot_b / tot_us / 1e3 / HBM_PEAK_GBS, 3), kernels=rows,
-                            note='algorithmic bytes (one read per input tensor, one write per output tensor) / event time; at batch 512 the '
+                            two_pass_backward_us=round(_two_pass_bn(ops, dY_e, xact, mean, invstd, gamma, beta, gb), 2),
+                            note='algorithmic bytes (one read per input tensor, one write per output tensor) / event time; two_pass_backward_us: '
+                                 'the [E,F] backward as rounds 1-5 ran it (reduction launch + data-gradient launch, 5 tensor passes); at batch 512 the '
                                  'tensors (13.5 MB each) sit in the 256 MiB Infinity Cache, the kernels are bound by launch + finalisation latency')
 
     # ---- K4 (HBM): forward with the BatchNorm applied on load, backward; batch 512 and a batch beyond the Infinity Cache
