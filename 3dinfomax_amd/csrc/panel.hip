@@ -300,11 +300,11 @@ __global__ void __launch_bounds__(256, 2) panel_gemm_kernel(PanelArgs g) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) s[q] = row16_sum(s[q]);
             const int rows_here = min(max(g.M - m0, 0), 16 * RT);
-            const float cnt = (float)rows_here;
+            const float cnt = (float)rows_here, inv_cnt = rows_here > 0 ? 1.f / cnt : 0.f;
             float m2[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float mean_t = cnt > 0.f ? s[q] / cnt : 0.f;
+                const float mean_t = s[q] * inv_cnt;
                 m2[q] = 0.f;
 #pragma unroll
                 for (int i = 0; i < RT; ++i) {
@@ -364,7 +364,10 @@ static int panel_launch(int M, int N, int K, const float* A, int lda, const void
     // 64-row slabs where they fill the chip, 32-row slabs (same kernel, one row tile per wave) where they would leave CUs idle;
     // the statistics form keeps 64-row workgroups (its tile count is part of the interface: i3d_panel_stats_tiles)
     static const int force_rt = [] { const char* e = getenv("I3D_PANEL_RT"); return e ? atoi(e) : 0; }();
-    const bool rt1 = stats == nullptr && (force_rt ? force_rt == 1 : (long)cdiv(M, PBM) * cdiv(N, PN) < 256);
+    // (32-row slabs: 37 -> 27 us stand-alone at [N,600]x[600,200], but every workgroup streams the whole packed weight - next to the
+    // weight-gradient panels the 64-row form is level or ahead in the step: 1.839 vs 1.831 ms - so only where < 128 slabs exist.
+    // Also measured and dropped: the output tile staged through the LDS for whole-row stores - 20.7 vs 20.2 us, step 1.834 vs 1.840.)
+    const bool rt1 = stats == nullptr && (force_rt ? force_rt == 1 : (long)cdiv(M, PBM) * cdiv(N, PN) < 128);
     const dim3 grid(cdiv(M, rt1 ? 32 : PBM), cdiv(N, PN)), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (aff != nullptr && stats != nullptr) hipLaunchKernelGGL((panel_gemm_kernel<true, true, 2>), grid, block, 0, s, g);
