@@ -138,7 +138,16 @@ extern "C" int i3d_fc_bn_fwd(const I3dFcArgs* a, void* stream) {
 // the stand-alone entry points, the side stream for a PNA layer (which issues the weight gradients of several blocks behind
 // ONE fork: a fork or join costs the host ~7 us, tools/probes/forkjoin_probe.hip).
 // the bias gradient of a block next to its weight gradients (on their stream)
-static int bias_final_fc(const I3dFcArgs* a, void* wst) {
+// A block with an activation in front of its BatchNorm: the bias gradient is the column sum of grad_pre.  Where the one-launch
+// BatchNorm backward takes the shape (bn.hip), the chain runs it WITHOUT those sums (reduction + data gradient + their column sums
+// were two launches: 10 + 11.5 us at the head's 512 rows) and the sums are taken next to the weight gradients, from grad_pre.
+static bool bias_aside(const I3dFcArgs* a, int xact_bf16 = 0) {
+    return !xact_bf16 && a->grad_bias != nullptr && a->tail.bias_partial != nullptr && a->tail.act != I3D_ACT_NONE && relu_class(a->tail.act) &&
+           relu_class(a->tail.post_act) && a->pre_keep == nullptr && i3d_bn_bwd_one_launch_supported(a->rows, a->f_out) != 0;
+}
+
+static int bias_final_fc(const I3dFcArgs* a, void* wst, int xact_bf16 = 0) {
+    if (bias_aside(a, xact_bf16)) return i3d_colsum_strided(a->grad_pre, a->f_out, a->rows, a->f_out, a->grad_bias, a->tail.bias_partial, wst);
     return bias_final(&a->tail, a->rows, a->f_out, a->grad_bias, wst);
 }
 
@@ -149,7 +158,7 @@ static int fc_bn_bwd_chain(const I3dFcArgs* a, void* stream, int xact_bf16 = 0) 
                               a->tail.bias_partial, stream));
     else
         TRY(tail_bwd(&a->tail, a->rows, a->f_out, a->grad_y, a->xact, a->pre_keep, a->grad_gamma, a->grad_beta, a->grad_pre,
-                     a->grad_bias, stream));
+                     bias_aside(a, xact_bf16) ? nullptr : a->grad_bias, stream));
     if (a->grad_x != nullptr) {
         if (panel_ok(a->W_dgrad_panel, a->f_out, a->f_in) && (((uintptr_t)a->grad_pre | (uintptr_t)a->grad_x) & 15) == 0)
             TRY(i3d_panel_gemm(a->rows, a->f_in, a->f_out, a->grad_pre, a->f_out, a->W_dgrad_panel, a->grad_x, a->f_in, nullptr, 0, stream));
@@ -453,7 +462,7 @@ static int pna_layer_wgrad_multi(const I3dPnaLayerArgs* a, void* wst, bool dry_r
     if (dry_run) return 1;                             // the layer is covered
     if (do_post) TRY(bias_final(&g->tail, N, g->f_out, g->grad_bias, wst));
     for (int i = a->n_pre_extra - 1; i >= 0 && do_pre; --i)
-        TRY(bias_final_fc(&a->pre[i], wst));
+        TRY(bias_final_fc(&a->pre[i], wst, (a->fused_bn && a->msg_bf16 && i == a->n_pre_extra - 1) ? 1 : 0));
     if (do_pre) {
         if (edge_bwd_fused_ok(a) && edge_bias_on_chain(a)) {
             // (taken on the caller's stream at the end of the layer's backward: see there)
