@@ -366,7 +366,8 @@ static int panel_launch(int M, int N, int K, const float* A, int lda, const void
     static const int force_rt = [] { const char* e = getenv("I3D_PANEL_RT"); return e ? atoi(e) : 0; }();
     // (32-row slabs: 37 -> 27 us stand-alone at [N,600]x[600,200], but every workgroup streams the whole packed weight - next to the
     // weight-gradient panels the 64-row form is level or ahead in the step: 1.839 vs 1.831 ms - so only where < 128 slabs exist.
-    // Also measured and dropped: the output tile staged through the LDS for whole-row stores - 20.7 vs 20.2 us, step 1.834 vs 1.840.)
+    // Also measured and dropped: the output tile staged through the LDS for whole-row stores - 20.7 vs 20.2 us, step 1.834 vs 1.840;
+    // the LDS-DMA pieces of step t + 1 issued between the column tiles' MFMA groups instead of in front of them - 22.1 vs 20.7 us.)
     const bool rt1 = stats == nullptr && (force_rt ? force_rt == 1 : (long)cdiv(M, PBM) * cdiv(N, PN) < 128);
     const dim3 grid(cdiv(M, rt1 ? 32 : PBM), cdiv(N, PN)), block(256);
     hipStream_t s = (hipStream_t)stream;
